@@ -1,0 +1,48 @@
+"""Golden-vector case recipes: inputs are regenerated from seeds (nerf_loc_amd.synth), only the
+reference's OUTPUTS are stored in tests/golden/<case>.npz (made by tools/gen_golden.py, which imports
+the reference in the build container).  Edge cases follow SURVEY.md §8(c)."""
+from __future__ import annotations
+
+import numpy as np
+
+from nerf_loc_amd.synth import SceneConfig, make_frame, make_rays, make_u, make_weights
+
+TINY = SceneConfig("tiny", R=16, S=16, W=32, V=3, H=32, Wimg=40, seed=11)
+
+CASES = {
+    # name: (config, store_intermediates)
+    "c1": (SceneConfig("c1", R=256, S=32, W=64, V=5, H=64, Wimg=80, seed=1), False),
+    "tiny_full": (TINY, True),
+    "white": (TINY.replace(name="white", white_bkgd=True, seed=12), True),
+    "fewpts": (TINY.replace(name="fewpts", seed=13), True),      # M=5 < K=8 support points
+    "offview": (TINY.replace(name="offview", V=4, seed=14), True),  # views behind / outside, zero visibility
+    "ties": (TINY.replace(name="ties", seed=15), True),          # duplicated support points -> exact KNN ties
+    "hier": (TINY.replace(name="hier", S=16, N_importance=16, seed=16), True),
+    "w128s64": (SceneConfig("w128s64", R=32, S=64, W=128, V=10, H=64, Wimg=80, seed=17), False),
+    "w256s128": (SceneConfig("w256s128", R=24, S=128, W=256, V=10, H=64, Wimg=80, seed=18), False),
+}
+
+
+def build_case(name: str):
+    """-> dict(cfg, frame, rays, weights, u) of numpy arrays for golden case `name`."""
+    cfg, _ = CASES[name]
+    frame = make_frame(cfg)
+    if name == "fewpts":
+        frame["support_fine"] = {k: np.ascontiguousarray(v[:5]) for k, v in frame["support_fine"].items()}
+    if name == "ties":
+        sp = frame["support_fine"]
+        m = sp["xyz"].shape[0]
+        src = np.arange(0, m, 3)
+        dst = (src + 1) % m
+        sp["xyz"][dst] = sp["xyz"][src]          # exact duplicates with different features
+    if name == "offview":
+        poses = frame["topk_poses"]
+        flip = np.diag([-1.0, 1.0, -1.0]).astype(np.float32)
+        poses[1, :3, :3] = poses[1, :3, :3] @ flip      # view 1 looks backwards: samples behind camera
+        poses[2, :3, 3] += np.array([30.0, 0, 0], np.float32)   # view 2 far to the side: out of image
+        poses[3, :3, 3] += np.array([0, 0, 2.0], np.float32)    # view 3 inside the volume: mixed signs
+    rays = make_rays(cfg, frame)
+    if name == "offview":
+        # half of the rays start far outside every frustum -> <=8 valid samples -> mask False
+        rays["rays_o"][::2] += np.array([0, 50.0, 0], np.float32)
+    return {"cfg": cfg, "frame": frame, "rays": rays, "weights": make_weights(cfg), "u": make_u(cfg)}

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (build container only).
+
+Imports /root/reference's `ConditionalNeRF` unmodified through four sys.modules shims:
+  1. torchvision.transforms        -- imported, unused (conditional_nerf/model.py:15)
+  2. inplace_abn.ABN               -- imported, unused (conditional_nerf/depth_fusion.py:5)
+  3. third_party.IBRNet.ibrnet.*   -- empty submodule; aliased to the in-tree nerf_loc/models/ibrnet/ibrnet.py
+  4. pytorch3d.ops                 -- absent; served by the reference's own in-tree wrapper
+                                      nerf_loc/models/ops/knn/knn_utils.py, whose native backend
+                                      `knn_points_idx` is the reference's knn_cpu.cpp compiled in place
+                                      (oracle/_ref/libref_knn.so, see oracle/Makefile).
+Inputs are the seeded recipes of tests/golden_cases.py; weights enter through load_state_dict; the
+per-frame caches (`support_neural_points`, `multiview_aggregator.vis_featmaps`) are injected
+(both are `is None`-guarded, model.py:473, multiview_aggregator.py:178).  For the hierarchical
+case torch.rand inside sample_pdf (utils.py:96) is replaced by the recipe's `u`.
+Only outputs are written.  Nothing here travels to the GPU box except the .npz files.
+"""
+import ctypes
+import importlib
+import os
+import sys
+import types
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from tests.golden_cases import CASES, build_case  # noqa: E402
+
+
+def install_shims():
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+    ia = types.ModuleType("inplace_abn")
+    ia.ABN = object
+    sys.modules["inplace_abn"] = ia
+    ibr = importlib.import_module("nerf_loc.models.ibrnet.ibrnet")
+    for n in ("third_party", "third_party.IBRNet", "third_party.IBRNet.ibrnet"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["third_party.IBRNet.ibrnet.projection"] = ibr
+    sys.modules["third_party.IBRNet.ibrnet.mlp_network"] = ibr
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_knn.so"))
+    lib.ref_knn_cpu.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_void_p]
+
+    def knn_points_idx(p1, p2, l1, l2, K, version):
+        assert p1.shape[0] == 1 and p1.shape[2] == 3
+        q = np.ascontiguousarray(p1[0].numpy(), np.float32)
+        p = np.ascontiguousarray(p2[0].numpy(), np.float32)
+        n, m = q.shape[0], p.shape[0]
+        idx = np.zeros((1, n, K), np.int64)
+        d2 = np.zeros((1, n, K), np.float32)
+        lib.ref_knn_cpu(q.ctypes.data, n, p.ctypes.data, m, K, d2.ctypes.data, idx.ctypes.data)
+        return torch.from_numpy(idx), torch.from_numpy(d2)
+
+    native = types.ModuleType("nerf_loc.models.ops.knn.knn")
+    native.knn_points_idx = knn_points_idx
+    sys.modules["nerf_loc.models.ops.knn.knn"] = native
+    ku = importlib.import_module("nerf_loc.models.ops.knn.knn_utils")
+    p3, p3o = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.ops")
+    p3o.knn_points, p3o.knn_gather = ku.knn_points, ku.knn_gather
+    p3.ops = p3o
+    sys.modules["pytorch3d"], sys.modules["pytorch3d.ops"] = p3, p3o
+    return importlib.import_module("nerf_loc.models.conditional_nerf.model"), ku
+
+
+def ref_args(cfg):
+    return NS(multires=10, multires_views=4, i_embed=0, backbone2d_fpn_dim=cfg.C, model_3d_hidden_dim=cfg.W,
+              render=NS(N_samples=cfg.S, N_importance=cfg.N_importance, N_rand=1024, chunk=2048, lindisp=False,
+                        white_bkgd=False, use_render_uncertainty=True, render_feature=True),
+              use_scene_coord_memorization=False, matcher_hidden_dim=192, use_depth_supervision=False,
+              matching=NS(fine_num_3d_keypoints=1024))
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def run_case(model_mod, ku, name):
+    case = build_case(name)
+    cfg, frame, rays, weights, u = case["cfg"], case["frame"], case["rays"], case["weights"], case["u"]
+    net = model_mod.ConditionalNeRF(ref_args(cfg)).eval()
+    sd = net.state_dict()
+    ours = {k: t(v) for k, v in weights.items()}
+    path_keys = {k for k in sd if "depth_fusion" not in k}
+    assert path_keys == set(ours), (sorted(path_keys ^ set(ours)))
+    for k in ours:
+        assert tuple(sd[k].shape) == tuple(ours[k].shape), (k, sd[k].shape, ours[k].shape)
+    net.load_state_dict(ours, strict=False)
+
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "depth_range", "K", "pose")}
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "white_bkgd": bool(frame["white_bkgd"])})
+    net.support_neural_points = {"fine": {k: t(v) for k, v in frame["support_fine"].items()}}
+    net.multiview_aggregator.vis_featmaps = t(frame["vis_featmaps"])
+    ray_d = {"rays_o": t(rays["rays_o"]), "rays_d": t(rays["rays_d"]), "depth_range": t(rays["depth_range"]),
+             "pixel_coordinates": t(rays["pixel_coordinates"]), "K": t(rays["K"]), "pose": t(rays["pose"]), "H": cfg.H, "W": cfg.Wimg}
+
+    inter = {}
+    # capture intermediates by wrapping (not editing) reference callables
+    orig_query = net.query
+
+    def query_spy(*a, **k):
+        out = orig_query(*a, **k)
+        inter["feature_agg"] = out["feature_agg"].detach().clone()
+        inter["multiview_visibility"] = out["multiview_visibility"].detach().squeeze(-1).clone()
+        return out
+    net.query = query_spy
+    orig_mv = net.multiview_aggregator.forward
+
+    def mv_spy(*a, **k):
+        out = orig_mv(*a, **k)
+        inter["multiview_feature_agg"] = out[0].detach().clone()
+        return out
+    net.multiview_aggregator.forward = mv_spy
+    orig_knn = model_mod.knn_points
+
+    def knn_spy(*a, **k):
+        out = orig_knn(*a, **k)
+        if k.get("K", 1) == 8:
+            inter["knn_d2"] = out.dists[0].detach().clone()
+            inter["knn_idx"] = out.idx[0].detach().clone()
+        return out
+    model_mod.knn_points = knn_spy
+    orig_sigma = net.sigma_mlp.forward
+
+    def sigma_spy(x):
+        out = orig_sigma(x)
+        inter["sigma"] = out.detach().clone()
+        return out
+    net.sigma_mlp.forward = sigma_spy
+    orig_unet = net.ray_unet.forward
+
+    def unet_spy(x):
+        out = orig_unet(x)
+        inter["geo"] = out.detach().permute(0, 2, 1).reshape(-1, out.shape[1]).clone()
+        return out
+    net.ray_unet.forward = unet_spy
+
+    orig_rand = torch.rand
+    if cfg.N_importance > 0:
+        def rand_fixed(*shape, **kw):
+            assert tuple(shape) == tuple(u.shape), (shape, u.shape)
+            return t(u).clone()
+        torch.rand = rand_fixed
+    try:
+        with torch.no_grad():
+            out = net.render_rays(data, ray_d)
+    finally:
+        torch.rand = orig_rand
+        model_mod.knn_points = orig_knn
+
+    save = {k: v.numpy() for k, v in out.items()}
+    R, S = cfg.R, cfg.S_total
+    save["sigma"] = inter["sigma"].view(R, S).numpy()
+    save["knn_d2"] = inter["knn_d2"].numpy()
+    save["knn_idx"] = inter["knn_idx"].numpy().astype(np.int32)
+    if CASES[name][1]:
+        save["feature_agg"] = inter["feature_agg"].numpy()
+        save["multiview_feature_agg"] = inter["multiview_feature_agg"].numpy()
+        save["multiview_visibility"] = inter["multiview_visibility"].numpy()
+        save["geo"] = inter["geo"].numpy()
+    else:  # subsample the (N, W) intermediates to keep fixtures small
+        sel = np.arange(0, R * S, 37)
+        save["rows"] = sel.astype(np.int32)
+        save["feature_agg"] = inter["feature_agg"].numpy()[sel]
+        save["multiview_feature_agg"] = inter["multiview_feature_agg"].numpy()[sel]
+        save["geo"] = inter["geo"].numpy()[sel]
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **save)
+    msk = save["mask"]
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) rays={R} S={S} mask_true={int(msk.sum())}/{R} "
+          f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
+
+
+def main():
+    model_mod, ku = install_shims()
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        run_case(model_mod, ku, n)
+
+
+if __name__ == "__main__":
+    main()
