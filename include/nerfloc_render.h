@@ -1,0 +1,173 @@
+/* nerfloc_render.h — C-ABI of libnerfloc_render.so (MI355X / gfx950 HIP renderer for NeRF-Loc's
+ * conditional-NeRF hot path).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference/nerf_loc/models/):
+ *   nl_knn               pytorch3d.ops.knn_points == ops/knn/knn_utils.py:97-174 -> ops/knn/src/knn_api.cpp:10-14
+ *                        (`knn_points_idx`), CUDA path ops/knn/src/knn.cu:131-241, CPU path knn_cpu.cpp:13-64;
+ *                        call sites conditional_nerf/model.py:289,318,376-383
+ *   nl_mv_aggregate      MultiviewFeatureAggregator.forward, conditional_nerf/multiview_aggregator.py:156-222
+ *                        (Projector.compute ibrnet/ibrnet.py:194-231, project_points_dict depth_fusion.py:128-147,
+ *                         MixtureLogisticsDistDecoder visibility_decoder.py:99-148)
+ *   nl_point_mlp         ConditionalNeRF.query neighbour branch, conditional_nerf/model.py:372-427
+ *                        (base_mlp :63-71, MultiHeadAttention ibrnet/ibrnet.py:69-119, aggregation :415-427)
+ *   nl_ray_unet          RayUnet.forward, conditional_nerf/ray_unet.py:55-69
+ *   nl_heads_composite   sigma/rgb-blend/feat heads + alpha compositing + valid mask, conditional_nerf/model.py:525-598
+ *   nl_coarse_weights    MultiviewFeatureAggregator.predict_weights_from_neuray, multiview_aggregator.py:95-154
+ *   nl_sample_pdf        sample_pdf + sort/merge, conditional_nerf/utils.py:73-112 and model.py:492-495
+ *   nl_render_rays       ConditionalNeRF.render_rays, conditional_nerf/model.py:472-600 (eval mode), rows a2-a18 fused
+ *   nl_pack_weights      (no reference counterpart: state_dict fp32 tensors -> kernel layouts; names = SURVEY App. C)
+ *   nl_frame_*           per-frame caches the reference keeps on the module: `support_neural_points['fine']`
+ *                        (model.py:79,180-197) and `multiview_aggregator.vis_featmaps` (multiview_aggregator.py:29,178)
+ *
+ * Conventions
+ *   - every function returns 0 (NL_OK) or a negative nl_status; nl_strerror() names it; nothing throws.
+ *   - all tensor pointers are DEVICE pointers to contiguous fp32 unless marked HOST; the library never
+ *     allocates device memory: the caller passes workspaces sized by the *_bytes() queries.
+ *   - `stream` is a hipStream_t (as void*); kernels are enqueued asynchronously on it, no host sync.
+ *   - indices are int32 on the device side (N, M < 2^31); sizes are int64_t in the signatures.
+ */
+#ifndef NERFLOC_RENDER_H
+#define NERFLOC_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NL_ABI_VERSION 1
+#define NL_MAX_VIEWS 16
+#define NL_KNN_MAX_K 8
+
+typedef enum nl_status {
+  NL_OK = 0,
+  NL_ERR_BAD_ARG = -1,       /* null pointer / negative size / inconsistent shapes */
+  NL_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for (see nl_config) */
+  NL_ERR_WORKSPACE = -3,     /* workspace too small; call the matching *_bytes() */
+  NL_ERR_HIP = -4,           /* a HIP runtime call failed (hipGetLastError is left set) */
+  NL_ERR_NO_DEVICE = -5
+} nl_status;
+
+typedef enum nl_precision {
+  NL_PREC_F32 = 0,     /* f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products/accumulation   */
+  NL_PREC_BF16X3 = 1,  /* 3-term split-bf16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate: parity mode  */
+  NL_PREC_BF16 = 2     /* single bf16 MFMA, fp32 accumulate: throughput mode (does not meet 1e-4)       */
+} nl_precision;
+
+typedef struct nl_config {
+  int32_t W;          /* model_3d_hidden_dim: multiple of 32, 32..256                      */
+  int32_t C;          /* backbone2d_fpn_dim (feature channels of the support maps), 192    */
+  int32_t S;          /* samples per ray seen by ray_unet (N_samples + N_importance), S%8==0, S<=256 */
+  int32_t precision;  /* nl_precision for the GEMM-shaped stages                           */
+} nl_config;
+
+/* Per-frame inputs (reference `data` dict, nerf_pose_estimator.py:255-290, plus the two module caches). */
+typedef struct nl_frame_desc {
+  int32_t V, H, Wimg, h, w;      /* support views, full-res image size, feature-map size (H/4, Wimg/4) */
+  float near_, far_;             /* data['depth_range'][0]                                             */
+  const float* images;           /* (V,3,H,Wimg)   data['topk_images']                                 */
+  const float* featmaps;         /* (V,h,w,C)      data['feat_fine_src'] (channels-last, as the reference stores it) */
+  const float* vis_featmaps;     /* (V,32,h,w)     multiview_aggregator.vis_featmaps                   */
+  const float* proj_ibr;         /* HOST (V,3,4)   rows 0..2 of  K4 @ inv(c2w)   (ibrnet.py:183)       */
+  const float* proj_neuray;      /* HOST (V,3,4)   K @ inv(c2w)[:3]             (depth_fusion.py:90)   */
+  const float* cam_centers;      /* HOST (V,3)     c2w[:3,3]                    (ibrnet.py:159)        */
+  int64_t M;                     /* support neural points (fine level)                                 */
+  const float* sp_xyz;           /* (M,3)   support_neural_points['fine']['xyz']                       */
+  const float* sp_feature;       /* (M,C+3) ...['feature']  = [rgb, feat]                              */
+  const float* sp_confidence;    /* (M,1)   ...['confidence']                                          */
+  const float* sp_direction;     /* (M,4)   ...['direction'] = [unit view dir, depth]                  */
+} nl_frame_desc;
+
+typedef struct nl_frame nl_frame;   /* opaque: device tables + KNN grid living in caller-provided memory */
+
+/* Outputs of render_rays (model.py:577-598).  Any pointer may be NULL to skip that output. */
+typedef struct nl_render_out {
+  float* rgb;                /* (R,3)  */
+  float* depth;              /* (R)    */
+  float* weights;            /* (R,S)  */
+  uint8_t* mask;             /* (R)    0/1 */
+  float* depth_uncertainty;  /* (R)    */
+  float* feat;               /* (R,C)  */
+  /* optional intermediates for testing / staged callers */
+  float* sigma;              /* (R*S)   */
+  float* feature_agg;        /* (R*S,W) */
+  float* mv_feature_agg;     /* (R*S,W) */
+  float* geo;                /* (R*S,W) ray_unet output */
+  int32_t* knn_idx;          /* (R*S,8) */
+  float* knn_d2;             /* (R*S,8) */
+} nl_render_out;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int nl_abi_version(void);
+const char* nl_strerror(int status);
+/* Names of the state_dict tensors nl_pack_weights consumes, in the order it expects them. */
+int nl_num_weights(void);
+const char* nl_weight_name(int i);
+
+/* ---- weights ---------------------------------------------------------------------------------- */
+size_t nl_packed_weights_bytes(const nl_config* cfg);
+/* tensors[i] = DEVICE pointer of state_dict[nl_weight_name(i)] (fp32, contiguous, torch layout). */
+int nl_pack_weights(const nl_config* cfg, const float* const* tensors, int n_tensors,
+                    void* packed, size_t packed_bytes, void* stream);
+
+/* ---- per-frame state --------------------------------------------------------------------------- */
+size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* desc);
+int nl_frame_create(const nl_config* cfg, const nl_frame_desc* desc, void* frame_mem, size_t frame_bytes,
+                    void* stream, nl_frame** out);
+int nl_frame_destroy(nl_frame* frame);
+
+/* ---- stages (each is also reachable through nl_render_rays) -------------------------------------- */
+/* a8: exact K nearest support points (squared L2 in the reference's fp32 order, ascending, ties by index). */
+int nl_knn(const nl_frame* frame, const float* xyz, int64_t N, int K, int32_t* idx, float* d2, void* stream);
+
+/* a2-a3: z_vals (R,S) [given, or generated from near/far when z_vals_in==NULL] -> xyz (R*S,3), z_out (R,S). */
+int nl_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_,
+                     const float* z_vals_in, float* z_out, float* xyz, void* stream);
+
+size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N);
+/* a4-a7: -> mv_feat (N,W), rgb_feat (N*V,196) [cols 0..194 valid], vis_ang (N*V,8) = [vis, ang(4), pad],
+ *        valid_s (N) = #views(in-bounds & in front) > 1. query_center = data['pose'][:3,3] (HOST, 3 floats). */
+int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,
+                    const float* xyz, int64_t N, float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s,
+                    void* ws, size_t ws_bytes, void* stream);
+
+size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N);
+/* a8-a12: xyz (N,3), dir (N,3) viewing direction per sample (NULL: nearest neighbour's, model.py:391-392),
+ *         mv_feat (N,W) -> feature_agg (N,W); optional knn outputs. */
+int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, const float* dir,
+                 int64_t dir_stride, const float* mv_feat, int64_t N, int K, float* feature_agg, int32_t* knn_idx, float* knn_d2,
+                 void* ws, size_t ws_bytes, void* stream);
+
+size_t nl_ray_unet_workspace_bytes(const nl_config* cfg, int64_t R);
+/* a13: x (R*S,W) sample-major -> geo (R*S,W). */
+int nl_ray_unet(const nl_config* cfg, const void* packed, const float* x, int64_t R, float* geo,
+                void* ws, size_t ws_bytes, void* stream);
+
+size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R);
+/* a14-a18 */
+int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const float* z_vals, const float* feature_agg,
+                       const float* geo, const float* rgb_feat, const float* vis_ang, const int32_t* valid_s,
+                       int64_t R, int white_bkgd, const nl_render_out* out, void* ws, size_t ws_bytes, void* stream);
+
+/* a20 (hierarchical): coarse NeuRay weights (R,Sc) for z_coarse (R,Sc) along un-normalised K^-1[u,v,1] rays.
+ * query_cam HOST 12+9 floats: inv(pose)[:3] (3x4) then inv(K) (3x3). */
+int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_w2c_kinv,
+                      const float* pixel_coordinates, const float* z_coarse, int64_t R, int Sc, float* weights,
+                      float* depth_coarse, void* stream);
+/* inverse-CDF sampling with caller-provided uniforms u (R,Ni), merged with z_base (R,Sb) and sorted -> z_out (R,Sb+Ni). */
+int nl_sample_pdf(const float* z_coarse, const float* weights_coarse, int Sc, const float* u, int Ni,
+                  const float* z_base, int Sb, int64_t R, float* z_out, void* stream);
+
+/* ---- the fused path ----------------------------------------------------------------------------- */
+size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R);   /* recommended size */
+size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V);          /* one-ray-chunk minimum */
+/* rays_o, rays_d (R,3); z_vals (R,S) or NULL to generate linspace(near,far,S) (model.py:451-458,483-484). */
+int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,
+                   const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd,
+                   const nl_render_out* out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFLOC_RENDER_H */

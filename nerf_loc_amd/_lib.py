@@ -1,0 +1,113 @@
+"""ctypes binding of libnerfloc_render.so (C-ABI in include/nerfloc_render.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnerfloc_render.so")
+
+NL_OK = 0
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+MAX_VIEWS = 16
+
+
+class NlConfig(C.Structure):
+    _fields_ = [("W", C.c_int32), ("C", C.c_int32), ("S", C.c_int32), ("precision", C.c_int32)]
+
+
+class NlFrameDesc(C.Structure):
+    _fields_ = [
+        ("V", C.c_int32), ("H", C.c_int32), ("Wimg", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("near_", C.c_float), ("far_", C.c_float),
+        ("images", C.c_void_p), ("featmaps", C.c_void_p), ("vis_featmaps", C.c_void_p),
+        ("proj_ibr", C.c_void_p), ("proj_neuray", C.c_void_p), ("cam_centers", C.c_void_p),
+        ("M", C.c_int64),
+        ("sp_xyz", C.c_void_p), ("sp_feature", C.c_void_p), ("sp_confidence", C.c_void_p), ("sp_direction", C.c_void_p),
+    ]
+
+
+class NlRenderOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "rgb", "depth", "weights", "mask", "depth_uncertainty", "feat",
+        "sigma", "feature_agg", "mv_feature_agg", "geo", "knn_idx", "knn_d2")]
+
+
+# every symbol include/nerfloc_render.h declares: (name, restype, argtypes)
+_P, _I, _L, _Z, _F = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_CFG, _DESC, _OUT = C.POINTER(NlConfig), C.POINTER(NlFrameDesc), C.POINTER(NlRenderOut)
+SYMBOLS = [
+    ("nl_abi_version", _I, []),
+    ("nl_strerror", C.c_char_p, [_I]),
+    ("nl_num_weights", _I, []),
+    ("nl_weight_name", C.c_char_p, [_I]),
+    ("nl_packed_weights_bytes", _Z, [_CFG]),
+    ("nl_pack_weights", _I, [_CFG, C.POINTER(_P), _I, _P, _Z, _P]),
+    ("nl_frame_bytes", _Z, [_CFG, _DESC]),
+    ("nl_frame_create", _I, [_CFG, _DESC, _P, _Z, _P, C.POINTER(_P)]),
+    ("nl_frame_destroy", _I, [_P]),
+    ("nl_knn", _I, [_P, _P, _L, _I, _P, _P, _P]),
+    ("nl_sample_points", _I, [_P, _P, _L, _I, _F, _F, _P, _P, _P, _P]),
+    ("nl_mv_aggregate_workspace_bytes", _Z, [_CFG, _I, _L]),
+    ("nl_mv_aggregate", _I, [_CFG, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _Z, _P]),
+    ("nl_point_mlp_workspace_bytes", _Z, [_CFG, _L]),
+    ("nl_point_mlp", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
+    ("nl_ray_unet_workspace_bytes", _Z, [_CFG, _L]),
+    ("nl_ray_unet", _I, [_CFG, _P, _P, _L, _P, _P, _Z, _P]),
+    ("nl_heads_composite_workspace_bytes", _Z, [_CFG, _I, _L]),
+    ("nl_heads_composite", _I, [_CFG, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P]),
+    ("nl_coarse_weights", _I, [_CFG, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    ("nl_sample_pdf", _I, [_P, _P, _I, _P, _I, _P, _I, _L, _P, _P]),
+    ("nl_render_rays_workspace_bytes", _Z, [_CFG, _I, _L]),
+    ("nl_render_rays_min_workspace_bytes", _Z, [_CFG, _I]),
+    ("nl_render_rays", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P]),
+]
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libnerfloc_render.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the renderer)")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nl_abi_version() != 1:
+        raise RuntimeError("libnerfloc_render.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != NL_OK:
+        msg = load().nl_strerror(status).decode()
+        raise RuntimeError(f"libnerfloc_render {what}: {msg} ({status})")
+
+
+def weight_names():
+    lib = load()
+    return [lib.nl_weight_name(i).decode() for i in range(lib.nl_num_weights())]

@@ -1,0 +1,683 @@
+// C-ABI of libnerfloc_render.so: weight packing, per-frame state, stage entry points and the chunked
+// render_rays orchestrator (include/nerfloc_render.h documents which reference code each replaces).
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "common.h"
+
+// ---- launchers implemented in the other translation units -------------------------------------------
+struct NlKnnGrid {
+  NlGridParams* params; int* starts; int* counts; int* cursor; int* cell_of; float4* sorted; int M;
+};
+size_t nl_knn_grid_bytes(int64_t M);
+int nl_knn_grid_build(NlKnnGrid* g, void* mem, const float* xyz, int64_t M, hipStream_t st);
+int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* idx, float* d2, hipStream_t st);
+int nl_launch_chw_to_hwc(const float* src, float* dst, int V, int Cc, int HW, hipStream_t st);
+int nl_launch_mv_vis(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, float* vis_out, float* dd_out, hipStream_t st);
+int nl_launch_mv_stats(const NlViews& vw, const float* images, const float* feat, int C, const float* xyz, int64_t N, const float* vis_in,
+                       const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang, int* valid_s, hipStream_t st);
+int nl_launch_point_encode(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx, const float* d2,
+                           const float* sp_xyz, const float* sp_feat, int F, const float* sp_conf, const float* sp_dir, const float* rd_w,
+                           float inv_span, float* X, int ldx, float* wscale, hipStream_t st);
+int nl_launch_attn(const float* Q, const float* KV, int64_t N, int K, float* O, hipStream_t st);
+int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const float* gamma, const float* beta, float eps, const float* wscale, float* out, hipStream_t st);
+int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
+int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
+int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
+int nl_launch_blend(const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
+int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
+                        int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st);
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ weight table
+const char* kWeightNames[] = {
+    "ray_diff_fc.0.weight", "ray_diff_fc.0.bias", "ray_diff_fc.2.weight", "ray_diff_fc.2.bias",
+#define NL_DEC(d)                                                                                                         \
+  "multiview_aggregator.dist_decoder." d "_decoder.0.weight", "multiview_aggregator.dist_decoder." d "_decoder.0.bias",   \
+  "multiview_aggregator.dist_decoder." d "_decoder.2.weight", "multiview_aggregator.dist_decoder." d "_decoder.2.bias",   \
+  "multiview_aggregator.dist_decoder." d "_decoder.4.weight", "multiview_aggregator.dist_decoder." d "_decoder.4.bias"
+    NL_DEC("mean"), NL_DEC("var"), NL_DEC("aw"), NL_DEC("vis"),
+#undef NL_DEC
+    "multiview_aggregator.out_fc.0.weight", "multiview_aggregator.out_fc.0.bias",
+    "multiview_aggregator.out_fc.2.weight", "multiview_aggregator.out_fc.2.bias",
+    "base_mlp.0.weight", "base_mlp.0.bias", "base_mlp.2.weight", "base_mlp.2.bias", "base_mlp.4.weight", "base_mlp.4.bias",
+    "base_mlp_attn.w_qs.weight", "base_mlp_attn.w_ks.weight", "base_mlp_attn.w_vs.weight", "base_mlp_attn.fc.weight",
+    "base_mlp_attn.layer_norm.weight", "base_mlp_attn.layer_norm.bias",
+#define NL_UN(n) "ray_unet." n ".0.weight", "ray_unet." n ".0.bias", "ray_unet." n ".1.weight", "ray_unet." n ".1.bias"
+    NL_UN("conv1"), NL_UN("conv2"), NL_UN("conv3"), NL_UN("trans_conv3"), NL_UN("trans_conv2"), NL_UN("trans_conv1"), NL_UN("conv_out"),
+#undef NL_UN
+    "sigma_mlp.0.weight", "sigma_mlp.0.bias",
+    "feat_mlp.0.weight", "feat_mlp.0.bias", "feat_mlp.2.weight", "feat_mlp.2.bias",
+    "rgb_blending_mlp.0.weight", "rgb_blending_mlp.0.bias", "rgb_blending_mlp.2.weight", "rgb_blending_mlp.2.bias",
+    "rgb_blending_mlp.4.weight", "rgb_blending_mlp.4.bias",
+};
+constexpr int kNumWeights = sizeof(kWeightNames) / sizeof(kWeightNames[0]);
+enum {
+  T_RD0W = 0, T_RD0B, T_RD2W, T_RD2B, T_DEC = 4,  // 24 decoder tensors
+  T_OUT0W = 28, T_OUT0B, T_OUT2W, T_OUT2B, T_B0W, T_B0B, T_B2W, T_B2B, T_B4W, T_B4B,
+  T_WQ, T_WK, T_WV, T_FC, T_LNW, T_LNB, T_UNET = 44,  // 7 x {conv w, conv b, ln w, ln b}
+  T_SIGW = 72, T_SIGB, T_F0W, T_F0B, T_F2W, T_F2B, T_BL0W, T_BL0B, T_BL2W, T_BL2B, T_BL4W, T_BL4B
+};
+static_assert(kNumWeights == 84, "weight table");
+
+// ------------------------------------------------------------------------------------------ GEMM layer table
+enum {
+  G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLEND0, G_COUNT
+};
+enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
+
+struct GemmDim { int K, N, Kpad, Npad; bool bias; };
+
+struct Layout {
+  GemmDim g[G_COUNT];
+  size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bias[G_COUNT];
+  size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
+  size_t un_g[U_COUNT], un_b[U_COUNT];
+  int un_c[U_COUNT], un_l[U_COUNT];
+  size_t total;
+};
+
+bool cfg_ok(const nl_config* c) {
+  return c && c->W >= 32 && c->W <= 256 && c->W % 32 == 0 && c->C > 0 && c->C <= 192 && c->S >= 8 && c->S <= 256 && c->S % 8 == 0 &&
+         c->precision >= 0 && c->precision <= 2;
+}
+
+Layout make_layout(const nl_config* c) {
+  Layout L;
+  memset(&L, 0, sizeof(L));
+  const int W = c->W, C = c->C, F = C + 3, S = c->S;
+  auto set = [&](int i, int K, int N, bool bias) { L.g[i] = {K, N, (int)nl_align_up(K, 32), (int)nl_align_up(N, 32), bias}; };
+  set(G_OUTFC0, 2 * F + 3, 64, true);
+  set(G_OUTFC2, 64, W, true);
+  set(G_BASE0, F + 90, W, true);
+  set(G_BASE2, W, W, true);
+  set(G_BASE4, W, W, true);
+  set(G_KV, W, 256, false);
+  set(G_Q, W, 128, false);
+  set(G_FC, 128, W, false);
+  set(G_CONV1, 3 * W, 64, true);
+  set(G_CONV2, 3 * 64, 128, true);
+  set(G_CONV3, 3 * 128, 128, true);
+  set(G_T3E, 128, 128, true);
+  set(G_T3O, 256, 128, true);
+  set(G_T2E, 256, 64, true);
+  set(G_T2O, 512, 64, true);
+  set(G_T1E, 128, 32, true);
+  set(G_T1O, 256, 32, true);
+  set(G_CONVOUT, 3 * (W + 32), W, true);
+  set(G_FEAT0, W, W, true);
+  set(G_FEAT2, W, C, true);
+  set(G_BLEND0, W + F + 5, 32, true);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
+  for (int i = 0; i < G_COUNT; ++i) {
+    const size_t n = (size_t)L.g[i].Kpad * L.g[i].Npad;
+    L.b32[i] = take(n * 4);
+    L.bhi[i] = take(n * 2);
+    L.blo[i] = take(n * 2);
+    L.bias[i] = take((size_t)L.g[i].Npad * 4);
+  }
+  L.rd_w = take(4 * (64 + 16 + 27 * 16 + 27));
+  L.dec_w = take(4 * 4 * 2178);
+  L.sig_w = take(4 * W); L.sig_b = take(4);
+  L.bl2_w = take(4 * 512); L.bl2_b = take(4 * 16); L.bl4_w = take(4 * 16); L.bl4_b = take(4);
+  L.ln_g = take(4 * W); L.ln_b = take(4 * W);
+  const int uc[U_COUNT] = {64, 128, 128, 128, 64, 32, W};
+  const int ul[U_COUNT] = {S, S / 2, S / 4, S / 4, S / 2, S, S};
+  for (int u = 0; u < U_COUNT; ++u) {
+    L.un_c[u] = uc[u]; L.un_l[u] = ul[u];
+    L.un_g[u] = take(4 * (size_t)uc[u] * ul[u]);
+    L.un_b[u] = take(4 * (size_t)uc[u] * ul[u]);
+  }
+  L.total = off;
+  return L;
+}
+
+// ------------------------------------------------------------------------------------------ pack kernels
+__device__ __forceinline__ unsigned short pk_f2bf(float x) {
+  unsigned int u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// dst[k0+k][n] (f32 [Kpad][Npad]) and bf16 hi/lo [n][Kpad] <- src[off + n*ld_n + k*ld_k], k < kc, n < N
+__global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld_n, int ld_k, int kc, int N, int k0,
+                                  float* __restrict__ b32, unsigned short* __restrict__ bhi, unsigned short* __restrict__ blo,
+                                  int Kpad, int Npad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kc * N) return;
+  int k = i / N, n = i - k * N;
+  float v = src[off + (size_t)n * ld_n + (size_t)k * ld_k];
+  b32[(size_t)(k0 + k) * Npad + n] = v;
+  unsigned short h = pk_f2bf(v);
+  float hf = __uint_as_float(((unsigned int)h) << 16);
+  bhi[(size_t)n * Kpad + k0 + k] = h;
+  blo[(size_t)n * Kpad + k0 + k] = pk_f2bf(v - hf);
+}
+
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+struct Packer {
+  const float* const* t;
+  char* base;
+  const Layout* L;
+  hipStream_t st;
+  int rc = NL_OK;
+  void block(int g, int k0, const float* src, int off, int ld_n, int ld_k, int kc) {
+    const GemmDim& d = L->g[g];
+    int n = kc * d.N;
+    hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, off, ld_n, ld_k, kc, d.N, k0,
+                       (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad);
+  }
+  void copy(const float* src, size_t dst_off, int n) {
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), n);
+  }
+  void linear(int g, const float* w, const float* b) {  // torch (out, in)
+    block(g, 0, w, 0, L->g[g].K, 1, L->g[g].K);
+    if (b) copy(b, L->bias[g], L->g[g].N);
+  }
+  // conv taps over concatenated sources: weight (co, ci, 3); K index = tap-major then source channels
+  void conv3(int g, const float* w, const float* b, int ci) {
+    for (int j = 0; j < 3; ++j) block(g, j * ci, w, j, ci * 3, 3, ci);
+    copy(b, L->bias[g], L->g[g].N);
+  }
+  // transposed conv weight (ci, co, 3): even phase uses tap 1; odd phase taps 2 (ioff 0) then 0 (ioff +1)
+  void convT(int ge, int go, const float* w, const float* b, int ci, int co) {
+    block(ge, 0, w, 1, 3, co * 3, ci);
+    block(go, 0, w, 2, 3, co * 3, ci);
+    block(go, ci, w, 0, 3, co * 3, ci);
+    copy(b, L->bias[ge], co);
+    copy(b, L->bias[go], co);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ frame
+}  // namespace
+
+struct nl_frame {
+  NlViews views;
+  int C;
+  const float* images; const float* feat; float* visf_hwc;
+  const float* sp_xyz; const float* sp_feat; const float* sp_conf; const float* sp_dir;
+  int64_t M;
+  NlKnnGrid grid;
+};
+
+namespace {
+
+struct Bump {
+  char* base; size_t off;
+  template <class T> T* take(size_t count) {
+    size_t o = off;
+    off += nl_align_up(count * sizeof(T), 256);
+    return base ? (T*)(base + o) : nullptr;
+  }
+};
+
+// ---- per-stage buffers ---------------------------------------------------------------------------
+struct MvBufs { float *vis, *dd, *g393, *t64; };
+struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; };
+struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
+struct HdBufs { float *sigma, *fth, *ft, *bl1, *rgb_s; };
+
+constexpr int LDG = 396, LDX = 288;
+
+void carve_mv(Bump& b, const nl_config* c, int V, int64_t N, MvBufs& m) {
+  m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N);
+  m.g393 = b.take<float>((size_t)N * LDG); m.t64 = b.take<float>((size_t)N * 64);
+}
+void carve_pt(Bump& b, const nl_config* c, int64_t N, int K, PtBufs& p) {
+  const int W = c->W;
+  p.idx = b.take<int>((size_t)N * K); p.d2 = b.take<float>((size_t)N * K);
+  p.X = b.take<float>((size_t)N * K * LDX);
+  p.H1 = b.take<float>((size_t)N * K * W); p.H2 = b.take<float>((size_t)N * K * W);
+  p.KV = b.take<float>((size_t)N * K * 256);
+  p.Q = b.take<float>((size_t)N * 128); p.O = b.take<float>((size_t)N * 128);
+  p.FCo = b.take<float>((size_t)N * W); p.wscale = b.take<float>((size_t)N);
+}
+void carve_un(Bump& b, const nl_config* c, int64_t R, UnBufs& u) {
+  const size_t N = (size_t)R * c->S;
+  u.r1 = b.take<float>(N * 64); u.c1 = b.take<float>(N / 2 * 64);
+  u.r2 = b.take<float>(N / 2 * 128); u.c2 = b.take<float>(N / 4 * 128);
+  u.r3 = b.take<float>(N / 4 * 128); u.c3 = b.take<float>(N / 8 * 128);
+  u.x0r = b.take<float>(N / 4 * 128); u.x0 = b.take<float>(N / 4 * 128);
+  u.x1r = b.take<float>(N / 2 * 64); u.x1 = b.take<float>(N / 2 * 64);
+  u.x2r = b.take<float>(N * 32); u.x2 = b.take<float>(N * 32);
+  u.outr = b.take<float>(N * c->W);
+}
+void carve_hd(Bump& b, const nl_config* c, int V, int64_t R, HdBufs& h) {
+  const size_t N = (size_t)R * c->S;
+  h.sigma = b.take<float>(N); h.fth = b.take<float>(N * c->W); h.ft = b.take<float>(N * c->C);
+  h.bl1 = b.take<float>(N * V * 32); h.rgb_s = b.take<float>(N * 3);
+}
+
+struct RenderBufs {
+  float *xyz, *z, *G, *rgb_feat, *vis_ang, *FA, *geo; int* valid_s;
+  MvBufs mv; PtBufs pt; UnBufs un; HdBufs hd;
+};
+void carve_render(Bump& b, const nl_config* c, int V, int64_t R, RenderBufs& rb) {
+  const size_t N = (size_t)R * c->S;
+  rb.xyz = b.take<float>(N * 3); rb.z = b.take<float>(N);
+  rb.G = b.take<float>(N * c->W);
+  rb.rgb_feat = b.take<float>(N * V * NL_FPAD); rb.vis_ang = b.take<float>(N * V * 8);
+  rb.valid_s = b.take<int>(N);
+  rb.FA = b.take<float>(N * c->W); rb.geo = b.take<float>(N * c->W);
+  carve_mv(b, c, V, N, rb.mv); carve_pt(b, c, N, 8, rb.pt); carve_un(b, c, R, rb.un); carve_hd(b, c, V, R, rb.hd);
+}
+
+// ---- GEMM helper ----------------------------------------------------------------------------------
+struct Ctx {
+  const nl_config* c; Layout L; const char* pk; hipStream_t st;
+  template <class T> const T* p(size_t off) const { return (const T*)(pk + off); }
+};
+
+struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; };
+
+int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
+             int So = 0, int Li = 0, int Lo = 0, int ostride = 1, int ooff = 0) {
+  NlGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  int ksum = 0;
+  for (int i = 0; i < nseg; ++i) {
+    a.seg[i].ptr = segs[i].ptr; a.seg[i].ld = segs[i].ld; a.seg[i].k = segs[i].k; a.seg[i].ioff = segs[i].ioff;
+    a.seg[i].rdiv = segs[i].rdiv > 0 ? segs[i].rdiv : 1;
+    ksum += segs[i].k;
+  }
+  const GemmDim& d = x.L.g[g];
+  if (ksum != d.K) return NL_ERR_BAD_ARG;
+  a.nseg = nseg; a.M = (int)M; a.K = d.K; a.N = d.N; a.Kpad = d.Kpad; a.Npad = d.Npad;
+  if (x.c->precision == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
+  else { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; }
+  a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
+  a.C = C; a.ldc = ldc; a.act = act;
+  a.So = So; a.Li = Li; a.Lo = Lo; a.ostride = ostride; a.ooff = ooff;
+  return nl_gemm_launch(a, x.c->precision, x.st);
+}
+
+#define NL_TRY(e) do { int _rc = (e); if (_rc != NL_OK) return _rc; } while (0)
+
+NlViews with_query(const nl_frame* f, const float* qc) {
+  NlViews v = f->views;
+  v.qcam[0] = qc ? qc[0] : 0.f; v.qcam[1] = qc ? qc[1] : 0.f; v.qcam[2] = qc ? qc[2] : 0.f;
+  return v;
+}
+
+int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
+          float* vis_ang, int* valid_s, const MvBufs& m) {
+  const NlViews vw = with_query(f, qc);
+  NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
+  NL_TRY(nl_launch_mv_stats(vw, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, x.st));
+  SegSpec s0{m.g393, LDG, 2 * (f->C + 3) + 3, 0, 1};
+  NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
+  SegSpec s1{m.t64, 64, 64, 0, 1};
+  NL_TRY(run_gemm(x, G_OUTFC2, &s1, 1, N, G, x.c->W, NL_ACT_ELU));
+  return NL_OK;
+}
+
+int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
+             float* FA, const PtBufs& p) {
+  const int W = x.c->W, F = f->C + 3;
+  NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
+  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, f->M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir,
+                                x.p<float>(x.L.rd_w), 1.f / (f->views.far_ - f->views.near_), p.X, LDX, p.wscale, x.st));
+  const int64_t MK = N * K;
+  SegSpec sx{p.X, LDX, F + 90, 0, 1};
+  NL_TRY(run_gemm(x, G_BASE0, &sx, 1, MK, p.H1, W, NL_ACT_LRELU));
+  SegSpec s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1};
+  NL_TRY(run_gemm(x, G_BASE2, &s1, 1, MK, p.H2, W, NL_ACT_LRELU));
+  NL_TRY(run_gemm(x, G_BASE4, &s2, 1, MK, p.H1, W, NL_ACT_LRELU));
+  NL_TRY(run_gemm(x, G_KV, &s1, 1, MK, p.KV, 256, NL_ACT_NONE));
+  SegSpec sg{G, W, W, 0, 1};
+  NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
+  NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
+  SegSpec so{p.O, 128, 128, 0, 1};
+  NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE));
+  NL_TRY(nl_launch_ln_agg(p.FCo, G, N, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, p.wscale, FA, x.st));
+  return NL_OK;
+}
+
+int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u) {
+  const int W = x.c->W, S = x.c->S;
+  auto g = [&](int i) { return x.p<float>(x.L.un_g[i]); };
+  auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
+  const float eps = 1e-5f;
+  {  // conv1: W -> 64 over S
+    SegSpec s[3] = {{in, W, W, -1, 1}, {in, W, W, 0, 1}, {in, W, W, 1, 1}};
+    NL_TRY(run_gemm(x, G_CONV1, s, 3, R * S, u.r1, 64, NL_ACT_NONE, S, S, S));
+    NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
+  }
+  {  // conv2: 64 -> 128 over S/2
+    SegSpec s[3] = {{u.c1, 64, 64, -1, 1}, {u.c1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}};
+    NL_TRY(run_gemm(x, G_CONV2, s, 3, R * (S / 2), u.r2, 128, NL_ACT_NONE, S / 2, S / 2, S / 2));
+    NL_TRY(nl_launch_ln_slab_elu(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, nullptr, u.c2, x.st));
+  }
+  {  // conv3: 128 -> 128 over S/4
+    SegSpec s[3] = {{u.c2, 128, 128, -1, 1}, {u.c2, 128, 128, 0, 1}, {u.c2, 128, 128, 1, 1}};
+    NL_TRY(run_gemm(x, G_CONV3, s, 3, R * (S / 4), u.r3, 128, NL_ACT_NONE, S / 4, S / 4, S / 4));
+    NL_TRY(nl_launch_ln_slab_elu(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, nullptr, u.c3, x.st));
+  }
+  {  // trans_conv3: S/8 -> S/4
+    const int Li = S / 8, Lo = S / 4;
+    SegSpec e[1] = {{u.c3, 128, 128, 0, 1}};
+    NL_TRY(run_gemm(x, G_T3E, e, 1, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 0));
+    SegSpec o[2] = {{u.c3, 128, 128, 0, 1}, {u.c3, 128, 128, 1, 1}};
+    NL_TRY(run_gemm(x, G_T3O, o, 2, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    NL_TRY(nl_launch_ln_slab_elu(u.x0r, R, Lo, 128, g(U_T3), b(U_T3), eps, u.x0, nullptr, x.st));
+  }
+  {  // trans_conv2 on cat[c2, x0]: S/4 -> S/2
+    const int Li = S / 4, Lo = S / 2;
+    SegSpec e[2] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}};
+    NL_TRY(run_gemm(x, G_T2E, e, 2, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 0));
+    SegSpec o[4] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}, {u.c2, 128, 128, 1, 1}, {u.x0, 128, 128, 1, 1}};
+    NL_TRY(run_gemm(x, G_T2O, o, 4, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    NL_TRY(nl_launch_ln_slab_elu(u.x1r, R, Lo, 64, g(U_T2), b(U_T2), eps, u.x1, nullptr, x.st));
+  }
+  {  // trans_conv1 on cat[c1, x1]: S/2 -> S
+    const int Li = S / 2, Lo = S;
+    SegSpec e[2] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}};
+    NL_TRY(run_gemm(x, G_T1E, e, 2, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 0));
+    SegSpec o[4] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}, {u.x1, 64, 64, 1, 1}};
+    NL_TRY(run_gemm(x, G_T1O, o, 4, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
+  }
+  {  // conv_out on cat[in, x2]
+    SegSpec s[6] = {{in, W, W, -1, 1}, {u.x2, 32, 32, -1, 1}, {in, W, W, 0, 1}, {u.x2, 32, 32, 0, 1}, {in, W, W, 1, 1}, {u.x2, 32, 32, 1, 1}};
+    NL_TRY(run_gemm(x, G_CONVOUT, s, 6, R * S, u.outr, W, NL_ACT_NONE, S, S, S));
+    NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
+  }
+  return NL_OK;
+}
+
+int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* rgb_feat, const float* vis_ang,
+             const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h) {
+  const int W = x.c->W, S = x.c->S, C = x.c->C, F = C + 3;
+  const int64_t N = R * S;
+  NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
+  const bool want_feat = out->feat != nullptr;
+  if (want_feat) {
+    SegSpec s0{FA, W, W, 0, 1};
+    NL_TRY(run_gemm(x, G_FEAT0, &s0, 1, N, h.fth, W, NL_ACT_LRELU));
+    SegSpec s1{h.fth, W, W, 0, 1};
+    NL_TRY(run_gemm(x, G_FEAT2, &s1, 1, N, h.ft, C, NL_ACT_NONE));
+  }
+  SegSpec sb[3] = {{FA, W, W, 0, V}, {rgb_feat, NL_FPAD, F, 0, 1}, {vis_ang, 8, 5, 0, 1}};
+  NL_TRY(run_gemm(x, G_BLEND0, sb, 3, N * V, h.bl1, 32, NL_ACT_LRELU));
+  NL_TRY(nl_launch_blend(h.bl1, rgb_feat, vis_ang, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
+                         x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
+  NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.ft : nullptr, valid_s, R, S, C, white, out, ray0, x.st));
+  if (out->sigma) NL_CHECK_HIP(hipMemcpyAsync(out->sigma + ray0 * S, h.sigma, sizeof(float) * N, hipMemcpyDeviceToDevice, x.st));
+  return NL_OK;
+}
+
+Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
+  Ctx x;
+  x.c = c; x.L = make_layout(c); x.pk = (const char*)packed; x.st = (hipStream_t)stream;
+  return x;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int nl_abi_version(void) { return NL_ABI_VERSION; }
+
+const char* nl_strerror(int s) {
+  switch (s) {
+    case NL_OK: return "ok";
+    case NL_ERR_BAD_ARG: return "bad argument";
+    case NL_ERR_UNSUPPORTED: return "unsupported shape or option";
+    case NL_ERR_WORKSPACE: return "workspace too small";
+    case NL_ERR_HIP: return "HIP runtime error";
+    case NL_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+
+int nl_num_weights(void) { return kNumWeights; }
+const char* nl_weight_name(int i) { return (i >= 0 && i < kNumWeights) ? kWeightNames[i] : nullptr; }
+
+size_t nl_packed_weights_bytes(const nl_config* cfg) { return cfg_ok(cfg) ? make_layout(cfg).total : 0; }
+
+int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* packed, size_t bytes, void* stream) {
+  if (!cfg_ok(cfg) || !t || n != kNumWeights || !packed) return NL_ERR_BAD_ARG;
+  for (int i = 0; i < n; ++i) if (!t[i]) return NL_ERR_BAD_ARG;
+  const Layout L = make_layout(cfg);
+  if (bytes < L.total) return NL_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  NL_CHECK_HIP(hipMemsetAsync(packed, 0, L.total, st));
+  Packer P{t, (char*)packed, &L, st};
+  const int W = cfg->W, C = cfg->C, F = C + 3;
+  P.linear(G_OUTFC0, t[T_OUT0W], t[T_OUT0B]);
+  P.linear(G_OUTFC2, t[T_OUT2W], t[T_OUT2B]);
+  P.linear(G_BASE0, t[T_B0W], t[T_B0B]);
+  P.linear(G_BASE2, t[T_B2W], t[T_B2B]);
+  P.linear(G_BASE4, t[T_B4W], t[T_B4B]);
+  // KV: columns 0..127 = w_ks rows, 128..255 = w_vs rows
+  {
+    const GemmDim& d = L.g[G_KV];
+    for (int half = 0; half < 2; ++half) {
+      const float* w = t[half ? T_WV : T_WK];
+      int nel = W * 128;
+      // reuse pack_block with N=128 into a column window: emulate by offsetting destination pointers
+      hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(nel, 256)), dim3(256), 0, st, w, 0, W, 1, W, 128, 0,
+                         (float*)((char*)packed + L.b32[G_KV]) + half * 128,
+                         (unsigned short*)((char*)packed + L.bhi[G_KV]) + (size_t)half * 128 * d.Kpad,
+                         (unsigned short*)((char*)packed + L.blo[G_KV]) + (size_t)half * 128 * d.Kpad, d.Kpad, d.Npad);
+    }
+  }
+  P.linear(G_Q, t[T_WQ], nullptr);
+  P.linear(G_FC, t[T_FC], nullptr);
+  const float* const* un = t + T_UNET;
+  P.conv3(G_CONV1, un[0], un[1], W);
+  P.conv3(G_CONV2, un[4], un[5], 64);
+  P.conv3(G_CONV3, un[8], un[9], 128);
+  P.convT(G_T3E, G_T3O, un[12], un[13], 128, 128);
+  P.convT(G_T2E, G_T2O, un[16], un[17], 256, 64);
+  P.convT(G_T1E, G_T1O, un[20], un[21], 128, 32);
+  P.conv3(G_CONVOUT, un[24], un[25], W + 32);
+  for (int u = 0; u < U_COUNT; ++u) {
+    P.copy(un[4 * u + 2], L.un_g[u], L.un_c[u] * L.un_l[u]);
+    P.copy(un[4 * u + 3], L.un_b[u], L.un_c[u] * L.un_l[u]);
+  }
+  P.linear(G_FEAT0, t[T_F0W], t[T_F0B]);
+  P.linear(G_FEAT2, t[T_F2W], t[T_F2B]);
+  P.linear(G_BLEND0, t[T_BL0W], t[T_BL0B]);
+  // small VALU-side weights
+  P.copy(t[T_RD0W], L.rd_w, 64); P.copy(t[T_RD0B], L.rd_w + 4 * 64, 16);
+  P.copy(t[T_RD2W], L.rd_w + 4 * 80, 27 * 16); P.copy(t[T_RD2B], L.rd_w + 4 * (80 + 432), 27);
+  for (int d = 0; d < 4; ++d) {
+    const float* const* q = t + T_DEC + 6 * d;
+    const size_t o = L.dec_w + 4 * (size_t)d * 2178;
+    const int nout = d < 2 ? 2 : 1;
+    P.copy(q[0], o, 1024); P.copy(q[1], o + 4 * 1024, 32);
+    P.copy(q[2], o + 4 * 1056, 1024); P.copy(q[3], o + 4 * 2080, 32);
+    P.copy(q[4], o + 4 * 2112, 32 * nout); P.copy(q[5], o + 4 * 2176, nout);
+  }
+  P.copy(t[T_SIGW], L.sig_w, W); P.copy(t[T_SIGB], L.sig_b, 1);
+  P.copy(t[T_BL2W], L.bl2_w, 512); P.copy(t[T_BL2B], L.bl2_b, 16);
+  P.copy(t[T_BL4W], L.bl4_w, 16); P.copy(t[T_BL4B], L.bl4_b, 1);
+  P.copy(t[T_LNW], L.ln_g, W); P.copy(t[T_LNB], L.ln_b, W);
+  (void)F;
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+// ---- frame ---------------------------------------------------------------------------------------------
+static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
+  return cfg_ok(c) && d && d->V >= 1 && d->V <= NL_MAX_VIEWS && d->H > 1 && d->Wimg > 1 && d->h > 1 && d->w > 1 && d->M >= 0 &&
+         d->images && d->featmaps && d->vis_featmaps && d->proj_ibr && d->proj_neuray && d->cam_centers &&
+         (d->M == 0 || (d->sp_xyz && d->sp_feature && d->sp_confidence && d->sp_direction));
+}
+
+size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
+  if (!desc_ok(cfg, d)) return 0;
+  return nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
+}
+
+int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
+  if (!desc_ok(cfg, d) || !mem || !out) return NL_ERR_BAD_ARG;
+  if (bytes < nl_frame_bytes(cfg, d)) return NL_ERR_WORKSPACE;
+  nl_frame* f = new (std::nothrow) nl_frame;
+  if (!f) return NL_ERR_BAD_ARG;
+  memset(&f->views, 0, sizeof(NlViews));
+  f->views.V = d->V; f->views.H = d->H; f->views.Wimg = d->Wimg; f->views.h = d->h; f->views.w = d->w;
+  f->views.near_ = d->near_; f->views.far_ = d->far_;
+  for (int v = 0; v < d->V; ++v) {
+    memcpy(f->views.P1[v], d->proj_ibr + 12 * v, 48);
+    memcpy(f->views.P2[v], d->proj_neuray + 12 * v, 48);
+    memcpy(f->views.cam[v], d->cam_centers + 3 * v, 12);
+  }
+  f->C = cfg->C;
+  f->images = d->images; f->feat = d->featmaps;
+  f->sp_xyz = d->sp_xyz; f->sp_feat = d->sp_feature; f->sp_conf = d->sp_confidence; f->sp_dir = d->sp_direction;
+  f->M = d->M;
+  hipStream_t st = (hipStream_t)stream;
+  f->visf_hwc = (float*)mem;
+  int rc = nl_launch_chw_to_hwc(d->vis_featmaps, f->visf_hwc, d->V, 32, d->h * d->w, st);
+  if (rc == NL_OK) rc = nl_knn_grid_build(&f->grid, (char*)mem + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256), d->sp_xyz, d->M, st);
+  if (rc != NL_OK) { delete f; return rc; }
+  *out = f;
+  return NL_OK;
+}
+
+int nl_frame_destroy(nl_frame* f) {
+  delete f;
+  return NL_OK;
+}
+
+// ---- stages ----------------------------------------------------------------------------------------------
+int nl_knn(const nl_frame* f, const float* xyz, int64_t N, int K, int32_t* idx, float* d2, void* stream) {
+  if (!f || !xyz || !idx || !d2 || N < 0 || K < 1 || K > NL_KNN_MAX_K) return NL_ERR_BAD_ARG;
+  return nl_knn_search(&f->grid, xyz, N, K, idx, d2, (hipStream_t)stream);
+}
+
+int nl_sample_points(const float* o, const float* d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out,
+                     float* xyz, void* stream) {
+  if (!o || !d || !xyz || R < 0 || S < 1) return NL_ERR_BAD_ARG;
+  return nl_launch_sample_points(o, d, R, S, near_, far_, z_in, z_out, xyz, (hipStream_t)stream);
+}
+
+size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  if (!cfg_ok(cfg)) return 0;
+  Bump b{nullptr, 0}; MvBufs m; carve_mv(b, cfg, V, N, m); return b.off;
+}
+
+int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, int64_t N,
+                    float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s, void* ws, size_t ws_bytes, void* stream) {
+  if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !rgb_feat || !vis_ang || !valid_s || !ws || N < 0) return NL_ERR_BAD_ARG;
+  if (ws_bytes < nl_mv_aggregate_workspace_bytes(cfg, f->views.V, N)) return NL_ERR_WORKSPACE;
+  Bump b{(char*)ws, 0}; MvBufs m; carve_mv(b, cfg, f->views.V, N, m);
+  Ctx x = make_ctx(cfg, packed, stream);
+  return do_mv(x, f, qc, xyz, N, mv_feat, rgb_feat, vis_ang, valid_s, m);
+}
+
+size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N) {
+  if (!cfg_ok(cfg)) return 0;
+  Bump b{nullptr, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p); return b.off;
+}
+
+int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
+                 const float* mv_feat, int64_t N, int K, float* feature_agg, int32_t* knn_idx, float* knn_d2, void* ws, size_t ws_bytes,
+                 void* stream) {
+  if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !feature_agg || !ws || N < 0 || K < 1 || K > 8) return NL_ERR_BAD_ARG;
+  if (ws_bytes < nl_point_mlp_workspace_bytes(cfg, N)) return NL_ERR_WORKSPACE;
+  Bump b{(char*)ws, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p);
+  Ctx x = make_ctx(cfg, packed, stream);
+  NL_TRY(do_point(x, f, xyz, dir, (int)dir_stride, 1, mv_feat, N, K, feature_agg, p));
+  if (knn_idx) NL_CHECK_HIP(hipMemcpyAsync(knn_idx, p.idx, sizeof(int) * N * K, hipMemcpyDeviceToDevice, x.st));
+  if (knn_d2) NL_CHECK_HIP(hipMemcpyAsync(knn_d2, p.d2, sizeof(float) * N * K, hipMemcpyDeviceToDevice, x.st));
+  return NL_OK;
+}
+
+size_t nl_ray_unet_workspace_bytes(const nl_config* cfg, int64_t R) {
+  if (!cfg_ok(cfg)) return 0;
+  Bump b{nullptr, 0}; UnBufs u; carve_un(b, cfg, R, u); return b.off;
+}
+
+int nl_ray_unet(const nl_config* cfg, const void* packed, const float* xin, int64_t R, float* geo, void* ws, size_t ws_bytes, void* stream) {
+  if (!cfg_ok(cfg) || !packed || !xin || !geo || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (ws_bytes < nl_ray_unet_workspace_bytes(cfg, R)) return NL_ERR_WORKSPACE;
+  Bump b{(char*)ws, 0}; UnBufs u; carve_un(b, cfg, R, u);
+  Ctx x = make_ctx(cfg, packed, stream);
+  return do_unet(x, xin, R, geo, u);
+}
+
+size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
+  if (!cfg_ok(cfg)) return 0;
+  Bump b{nullptr, 0}; HdBufs h; carve_hd(b, cfg, V, R, h); return b.off;
+}
+
+int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const float* z, const float* FA, const float* geo,
+                       const float* rgb_feat, const float* vis_ang, const int32_t* valid_s, int64_t R, int white,
+                       const nl_render_out* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!cfg_ok(cfg) || !packed || !z || !FA || !geo || !rgb_feat || !vis_ang || !out || !ws || R < 0 || V < 1 || V > NL_MAX_VIEWS) return NL_ERR_BAD_ARG;
+  if (ws_bytes < nl_heads_composite_workspace_bytes(cfg, V, R)) return NL_ERR_WORKSPACE;
+  Bump b{(char*)ws, 0}; HdBufs h; carve_hd(b, cfg, V, R, h);
+  Ctx x = make_ctx(cfg, packed, stream);
+  return do_heads(x, V, z, FA, geo, rgb_feat, vis_ang, valid_s, R, white, out, 0, h);
+}
+
+// ---- fused path ---------------------------------------------------------------------------------------------
+static size_t render_bytes(const nl_config* cfg, int V, int64_t rc) {
+  Bump b{nullptr, 0}; RenderBufs rb; carve_render(b, cfg, V, rc, rb); return b.off;
+}
+
+size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V) { return cfg_ok(cfg) ? render_bytes(cfg, V, 1) : 0; }
+
+size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
+  if (!cfg_ok(cfg)) return 0;
+  int64_t rc = R < 1 ? 1 : R;
+  const int64_t cap = (1 << 17) / cfg->S > 0 ? (1 << 17) / cfg->S : 1;  // ~131k samples per chunk
+  if (rc > cap) rc = cap;
+  return render_bytes(cfg, V, rc);
+}
+
+int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
+                   const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
+                   size_t ws_bytes, void* stream) {
+  if (!cfg_ok(cfg) || !packed || !f || !qc || !rays_o || !rays_d || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
+  const int V = f->views.V, S = cfg->S, W = cfg->W;
+  // largest ray chunk whose buffers fit the workspace
+  const size_t b1 = render_bytes(cfg, V, 1);
+  if (ws_bytes < b1) return NL_ERR_WORKSPACE;
+  int64_t lo = 1, hi = R > 1 ? R : 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi + 1) / 2;
+    if (render_bytes(cfg, V, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
+  }
+  const int64_t RC = lo;
+  Bump b{(char*)ws, 0}; RenderBufs rb; carve_render(b, cfg, V, RC, rb);
+  Ctx x = make_ctx(cfg, packed, stream);
+  for (int64_t r0 = 0; r0 < R; r0 += RC) {
+    const int64_t rc = (R - r0 < RC) ? R - r0 : RC;
+    const int64_t N = rc * S;
+    NL_TRY(nl_launch_sample_points(rays_o + 3 * r0, rays_d + 3 * r0, rc, S, f->views.near_, f->views.far_,
+                                   z_vals ? z_vals + r0 * S : nullptr, rb.z, rb.xyz, x.st));
+    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, rb.rgb_feat, rb.vis_ang, rb.valid_s, rb.mv));
+    // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
+    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt));
+    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.rgb_feat, rb.vis_ang, rb.valid_s, rc, white, out, r0, rb.hd));
+    if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
+    if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
+    if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
+    if (out->knn_idx) NL_CHECK_HIP(hipMemcpyAsync(out->knn_idx + r0 * S * 8, rb.pt.idx, sizeof(int) * N * 8, hipMemcpyDeviceToDevice, x.st));
+    if (out->knn_d2) NL_CHECK_HIP(hipMemcpyAsync(out->knn_d2 + r0 * S * 8, rb.pt.d2, sizeof(float) * N * 8, hipMemcpyDeviceToDevice, x.st));
+  }
+  return NL_OK;
+}
+
+int nl_coarse_weights(const nl_config*, const void*, const nl_frame*, const float*, const float*, const float*, int64_t, int, float*, float*, void*) {
+  return NL_ERR_UNSUPPORTED;
+}
+int nl_sample_pdf(const float*, const float*, int, const float*, int, const float*, int, int64_t, float*, void*) {
+  return NL_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

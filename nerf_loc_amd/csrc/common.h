@@ -1,0 +1,93 @@
+// Shared host/device definitions for libnerfloc_render.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nerfloc_render.h"
+
+#define NL_WAVE 64
+#define NL_F (195)        // C+3 for C=192; kernels take F at run time, this is the padded-row default
+#define NL_FPAD (196)
+
+#define NL_CHECK_HIP(expr)                      \
+  do {                                          \
+    hipError_t _e = (expr);                     \
+    if (_e != hipSuccess) return NL_ERR_HIP;    \
+  } while (0)
+
+#define NL_LAUNCH_CHECK()                                   \
+  do {                                                      \
+    if (hipPeekAtLastError() != hipSuccess) return NL_ERR_HIP; \
+  } while (0)
+
+static inline size_t nl_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t nl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ activations (match torch fp32 CPU ops)
+enum { NL_ACT_NONE = 0, NL_ACT_LRELU = 1, NL_ACT_ELU = 2 };
+
+__device__ __forceinline__ float nl_lrelu(float x) { return x > 0.f ? x : x * 0.01f; }
+__device__ __forceinline__ float nl_elu(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float nl_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float nl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float nl_act(float x, int act) {
+  return act == NL_ACT_LRELU ? nl_lrelu(x) : (act == NL_ACT_ELU ? nl_elu(x) : x);
+}
+
+// ------------------------------------------------------------------ wave helpers (wave64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ camera block passed by value (kernarg -> SGPRs)
+struct NlViews {
+  float P1[NL_MAX_VIEWS][12];   // Projector rows 0..2 (ibrnet.py:183)
+  float P2[NL_MAX_VIEWS][12];   // NeuRay K@Rt (depth_fusion.py:90)
+  float cam[NL_MAX_VIEWS][3];   // support camera centres
+  float qcam[3];                // query camera centre
+  int V, H, Wimg, h, w;
+  float near_, far_;
+};
+
+// ------------------------------------------------------------------ KNN grid (device-resident parameters)
+struct NlGridParams {
+  float origin[3];
+  float inv_cell;
+  float cell;
+  int dims[3];
+  float bmax[3];
+  int ncells;
+};
+
+// ------------------------------------------------------------------ generic segment GEMM (gemm.hip)
+#define NL_GEMM_MAX_SEG 6
+struct NlGemmSeg {
+  const float* ptr;  // source rows
+  int ld;            // row stride (floats)
+  int k;             // columns taken from this source
+  int ioff;          // conv tap offset along the ray (row-mapped modes)
+  int rdiv;          // plain mode: source row = m / rdiv (row broadcast), >=1
+};
+struct NlGemmArgs {
+  NlGemmSeg seg[NL_GEMM_MAX_SEG];
+  int nseg;
+  int M, K, N;          // output rows (compute index space), total K, output columns
+  int Kpad, Npad;       // padded sizes of B
+  const void* B;        // packed weights: f32 [Kpad][Npad]  or bf16 hi/lo [Npad][Kpad] (see pack.hip)
+  const void* Blo;      // bf16x3 only
+  const float* bias;    // [N] or null
+  float* C;
+  int ldc;
+  int act;
+  // row mapping: So==0 plain (out row = m); else r=m/So, t=m%So, in row = r*Li + t + ioff (valid 0<=t+ioff<Li),
+  // out row = r*Lo + t*ostride + ooff
+  int So, Li, Lo, ostride, ooff;
+};
+
+int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);

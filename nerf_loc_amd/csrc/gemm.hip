@@ -1,0 +1,293 @@
+// Generic "segment GEMM" for the GEMM-shaped stages that are not (yet) inside a fused kernel:
+//   C[out_row(m), n] = act( sum_seg sum_k A_seg[in_row_seg(m), k] * B[koff_seg + k, n] + bias[n] )
+// A is assembled on the fly from up to 6 sources (channel concat, conv taps along the ray, row
+// broadcast), so Linear, Conv1d(k=3), ConvTranspose1d(k=3,s=2) and the concat-MLPs of the
+// reference all run through one MFMA kernel without materialising im2col / concat tensors.
+//
+// Tiling (wave64, gfx950): 256 threads = 4 waves; block tile 128 (M) x BN (N) x 32 (K); wave w owns
+// rows [32w,32w+32) x all BN columns as BN/32 accumulators of 32x32 (16 VGPR each).
+//   NL_PREC_F32    : v_mfma_f32_32x32x2_f32, operands staged in LDS as f32 (A transposed [k][m] so
+//                    both operand reads are conflict-free ds_read_b32)
+//   NL_PREC_BF16X3 : v_mfma_f32_32x32x16_bf16 x3 (hi*hi + hi*lo + lo*hi), A split to bf16 hi/lo when
+//   NL_PREC_BF16   : staged ([m][k] rows padded to 80 B -> conflict-free ds_read_b128), weights pre-split
+// Global loads of tile t+1 are issued before the MFMAs of tile t (register prefetch).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+
+__device__ __forceinline__ unsigned short f2bf(float x) {  // round-to-nearest-even
+  unsigned int u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+struct RowMap {
+  int base;   // r*Li  (or m for plain)
+  int t;      // position along the ray (row-mapped) ; unused for plain
+  int mdiv;   // m / rdiv for broadcast segments
+  bool ok;
+};
+
+__device__ __forceinline__ RowMap map_row(const NlGemmArgs& a, int m, int rdiv) {
+  RowMap r;
+  r.ok = m < a.M;
+  if (a.So > 0) {
+    int q = m / a.So;
+    r.t = m - q * a.So;
+    r.base = q * a.Li;
+    r.mdiv = 0;
+  } else {
+    r.t = 0;
+    r.base = m;
+    r.mdiv = rdiv > 1 ? m / rdiv : m;
+  }
+  return r;
+}
+
+__device__ __forceinline__ float load_a(const NlGemmArgs& a, const RowMap& rm, int s, int kin) {
+  // s = segment, kin = column inside the segment (already validated: s >= 0)
+  const NlGemmSeg& sg = a.seg[s];
+  int row;
+  if (a.So > 0) {
+    int i = rm.t + sg.ioff;
+    if (i < 0 || i >= a.Li) return 0.f;
+    row = rm.base + i;
+  } else {
+    row = sg.rdiv > 1 ? rm.mdiv : rm.base;
+  }
+  return sg.ptr[(size_t)row * sg.ld + kin];
+}
+
+__device__ __forceinline__ int out_row(const NlGemmArgs& a, int m) {
+  if (a.So > 0) {
+    int q = m / a.So;
+    int t = m - q * a.So;
+    return q * a.Lo + t * a.ostride + a.ooff;
+  }
+  return m;
+}
+
+// ------------------------------------------------------------------------------------------ F32
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const NlGemmArgs a) {
+  __shared__ float As[BK][BM + 1];
+  __shared__ float Bs[BK][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kk_a = tid & 31, row_a = tid >> 5;  // this thread stages A[row_a + 8*i][kk_a]
+  int rdiv = 1;
+  for (int s = 0; s < a.nseg; ++s) rdiv = a.seg[s].rdiv > rdiv ? a.seg[s].rdiv : rdiv;
+
+  RowMap rm[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rm[i] = map_row(a, m0 + row_a + 8 * i, rdiv);
+
+  constexpr int NB4 = BN / 32;  // float4 B loads per thread per tile
+  const float* Bg = (const float*)a.B;
+  float areg[16];
+  float4 breg[NB4];
+
+  auto prefetch = [&](int k0) {
+    int kg = k0 + kk_a;
+    int s = -1, kin = 0, acc = 0;
+    for (int j = 0; j < a.nseg; ++j) {
+      if (s < 0 && kg < acc + a.seg[j].k) { s = j; kin = kg - acc; }
+      acc += a.seg[j].k;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a(a, rm[i], s, kin) : 0.f;
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) {
+      int idx = tid + 256 * j;
+      int kk = idx / (BN / 4), c4 = idx % (BN / 4);
+      int col = n0 + c4 * 4;
+      breg[j] = (col < a.Npad) ? *(const float4*)(Bg + (size_t)(k0 + kk) * a.Npad + col) : make_float4(0, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[BN / 32];
+#pragma unroll
+  for (int c = 0; c < BN / 32; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  prefetch(0);
+  for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) As[kk_a][row_a + 8 * i] = areg[i];
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) {
+      int idx = tid + 256 * j;
+      int kk = idx / (BN / 4), c4 = idx % (BN / 4);
+      *(float4*)&Bs[kk][c4 * 4] = breg[j];
+    }
+    __syncthreads();
+    if (k0 + BK < a.Kpad) prefetch(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      int kk = 2 * ks + (lane >> 5);
+      float av = As[kk][32 * wave + (lane & 31)];
+#pragma unroll
+      for (int c = 0; c < BN / 32; ++c) {
+        float bv = Bs[kk][32 * c + (lane & 31)];
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m >= a.M) continue;
+    size_t orow = (size_t)out_row(a, m) * a.ldc;
+#pragma unroll
+    for (int c = 0; c < BN / 32; ++c) {
+      int col = n0 + 32 * c + (lane & 31);
+      if (col < a.N) {
+        float v = acc[c][r] + (a.bias ? a.bias[col] : 0.f);
+        a.C[orow + col] = nl_act(v, a.act);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ BF16 / BF16X3
+// LDS rows are 32 bf16 (64 B) padded to 80 B: a 16-lane ds_read_b128 group then touches 16 distinct
+// 16-B slots of the 256-B bank row.
+constexpr int LDS_ROW = 40;  // in bf16 elements (80 B)
+
+template <int BN, bool X3>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const NlGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short Ah[BM * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Al[X3 ? BM * LDS_ROW : 8];
+  __shared__ __attribute__((aligned(16))) unsigned short Bh[BN * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) unsigned short Bl[X3 ? BN * LDS_ROW : 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kk_a = tid & 31, row_a = tid >> 5;
+  int rdiv = 1;
+  for (int s = 0; s < a.nseg; ++s) rdiv = a.seg[s].rdiv > rdiv ? a.seg[s].rdiv : rdiv;
+  RowMap rm[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rm[i] = map_row(a, m0 + row_a + 8 * i, rdiv);
+
+  // B: packed [Npad][Kpad] bf16 (k contiguous). Tile = BN rows x 32 k = BN*64 B -> BN*4 16-B chunks / 256 thr
+  constexpr int NBC = BN / 64;  // 16-B chunks per thread (BN=64 -> 1, 128 -> 2, 256 -> 4); BN=32 handled below
+  const unsigned short* Bgh = (const unsigned short*)a.B;
+  const unsigned short* Bgl = (const unsigned short*)a.Blo;
+  float areg[16];
+  uint4 bh[NBC > 0 ? NBC : 1], bl[NBC > 0 ? NBC : 1];
+
+  auto prefetch = [&](int k0) {
+    int kg = k0 + kk_a;
+    int s = -1, kin = 0, accn = 0;
+    for (int j = 0; j < a.nseg; ++j) {
+      if (s < 0 && kg < accn + a.seg[j].k) { s = j; kin = kg - accn; }
+      accn += a.seg[j].k;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a(a, rm[i], s, kin) : 0.f;
+    constexpr int NCH = (NBC > 0 ? NBC : 1);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int idx = tid + 256 * j;        // chunk id: n = idx>>2, part = idx&3 (8 bf16 each)
+      int n = idx >> 2, part = idx & 3;
+      bool ok = (n < BN) && (n0 + n < a.Npad);
+      size_t off = (size_t)(n0 + n) * a.Kpad + k0 + part * 8;
+      bh[j] = ok ? *(const uint4*)(Bgh + off) : make_uint4(0, 0, 0, 0);
+      if (X3) bl[j] = ok ? *(const uint4*)(Bgl + off) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[BN / 32];
+#pragma unroll
+  for (int c = 0; c < BN / 32; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  prefetch(0);
+  for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = areg[i];
+      unsigned short h = f2bf(v);
+      Ah[(row_a + 8 * i) * LDS_ROW + kk_a] = h;
+      if (X3) Al[(row_a + 8 * i) * LDS_ROW + kk_a] = f2bf(v - bf2f(h));
+    }
+    constexpr int NCH = (NBC > 0 ? NBC : 1);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      int idx = tid + 256 * j;
+      int n = idx >> 2, part = idx & 3;
+      if (n < BN) {
+        *(uint4*)&Bh[n * LDS_ROW + part * 8] = bh[j];
+        if (X3) *(uint4*)&Bl[n * LDS_ROW + part * 8] = bl[j];
+      }
+    }
+    __syncthreads();
+    if (k0 + BK < a.Kpad) prefetch(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two 16-deep MFMA k-steps per 32-wide tile
+      int ko = ks * 16 + 8 * (lane >> 5);
+      bf16x8 ah = *(const bf16x8*)&Ah[(32 * wave + (lane & 31)) * LDS_ROW + ko];
+      bf16x8 al;
+      if (X3) al = *(const bf16x8*)&Al[(32 * wave + (lane & 31)) * LDS_ROW + ko];
+#pragma unroll
+      for (int c = 0; c < BN / 32; ++c) {
+        bf16x8 bhv = *(const bf16x8*)&Bh[(32 * c + (lane & 31)) * LDS_ROW + ko];
+        if (X3) {
+          bf16x8 blv = *(const bf16x8*)&Bl[(32 * c + (lane & 31)) * LDS_ROW + ko];
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc[c], 0, 0, 0);
+        }
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m >= a.M) continue;
+    size_t orow = (size_t)out_row(a, m) * a.ldc;
+#pragma unroll
+    for (int c = 0; c < BN / 32; ++c) {
+      int col = n0 + 32 * c + (lane & 31);
+      if (col < a.N) {
+        float v = acc[c][r] + (a.bias ? a.bias[col] : 0.f);
+        a.C[orow + col] = nl_act(v, a.act);
+      }
+    }
+  }
+}
+
+template <int BN>
+int launch_bn(const NlGemmArgs& a, int precision, hipStream_t st) {
+  dim3 grid((unsigned)nl_cdiv(a.M, BM), (unsigned)nl_cdiv(a.N, BN));
+  if (precision == NL_PREC_F32) {
+    hipLaunchKernelGGL(gemm_f32_kernel<BN>, grid, dim3(256), 0, st, a);
+  } else if (precision == NL_PREC_BF16X3) {
+    hipLaunchKernelGGL((gemm_bf16_kernel<BN, true>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_kernel<BN, false>), grid, dim3(256), 0, st, a);
+  }
+  return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+
+}  // namespace
+
+int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
+  if (a.M <= 0) return NL_OK;
+  if (a.N <= 64) return launch_bn<64>(a, precision, st);
+  if (a.N <= 128) return launch_bn<128>(a, precision, st);
+  return launch_bn<256>(a, precision, st);
+}

@@ -1,0 +1,212 @@
+// Ray sampling (rows a2-a3) and the post-U-Net heads + compositing (rows a14-a18).
+#include "common.h"
+
+namespace {
+
+// z = near*(1-t) + far*t with torch.linspace's symmetric formula (model.py:451-458); xyz = o + d*z (model.py:498)
+__global__ void sample_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int R, int S,
+                                     float near_, float far_, const float* __restrict__ z_in, float* __restrict__ z_out,
+                                     float* __restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * S) return;
+  const int r = i / S, s = i - r * S;
+  float z;
+  if (z_in) z = z_in[i];
+  else {
+    const float step = S > 1 ? (1.f - 0.f) / (float)(S - 1) : 0.f;
+    const float t = (s < S / 2) ? __fmul_rn(step, (float)s) : __fsub_rn(1.f, __fmul_rn(step, (float)(S - 1 - s)));
+    z = __fadd_rn(__fmul_rn(near_, __fsub_rn(1.f, t)), __fmul_rn(far_, t));
+  }
+  if (z_out) z_out[i] = z;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) xyz[3 * (size_t)i + d] = __fadd_rn(rays_o[3 * r + d], __fmul_rn(rays_d[3 * r + d], z));
+}
+
+// sigma = softplus(w . geo + b)  (model.py:525, sigma_mlp :83) — one wave per sample
+__global__ __launch_bounds__(256) void sigma_kernel(const float* __restrict__ geo, int N, int W, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float* __restrict__ sigma) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = lane; c < W; c += 64) s = fmaf(geo[(size_t)n * W + c], w[c], s);
+  s = wave_sum(s);
+  if (lane == 0) sigma[n] = nl_softplus(s + b[0]);
+}
+
+// colour blending tail (model.py:535-538): h1 (N*V,32) [already LeakyReLU'd by the GEMM] -> 16 -> 1,
+// masked_fill(vis == 0, -1e9), softmax over views, rgb = sum_v w_v * rgb_in.   One lane per sample.
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ h1, const float* __restrict__ rgb_feat,
+                                                    const float* __restrict__ vis_ang, int N, int V,
+                                                    const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
+                                                    const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
+                                                    float* __restrict__ rgb_s) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float lg[NL_MAX_VIEWS];
+  float mx = -3.4e38f;
+  for (int v = 0; v < V; ++v) {
+    const float* h = h1 + ((size_t)n * V + v) * 32;
+    float x[32];
+#pragma unroll
+    for (int i4 = 0; i4 < 8; ++i4) {
+      float4 t = *(const float4*)(h + 4 * i4);
+      x[4 * i4] = t.x; x[4 * i4 + 1] = t.y; x[4 * i4 + 2] = t.z; x[4 * i4 + 3] = t.w;
+    }
+    float o = b4[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float a = b2[j];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) a = fmaf(w2[j * 32 + i], x[i], a);
+      o = fmaf(w4[j], nl_lrelu(a), o);
+    }
+    const float vis = vis_ang[((size_t)n * V + v) * 8];
+    o = (vis == 0.f) ? -1e9f : o;
+    lg[v] = o;
+    mx = fmaxf(mx, o);
+  }
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) { lg[v] = expf(lg[v] - mx); den += lg[v]; }
+  float r = 0.f, g = 0.f, b = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float wv = lg[v] / den;
+    const float* c = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
+    r += c[0] * wv; g += c[1] * wv; b += c[2] * wv;
+  }
+  rgb_s[3 * (size_t)n] = r; rgb_s[3 * (size_t)n + 1] = g; rgb_s[3 * (size_t)n + 2] = b;
+}
+
+// Front-to-back compositing (model.py:541-560,597) + valid-ray mask (:572-575).  One wave per ray.
+// Each lane owns CH = ceil(S/64) consecutive samples; transmittance = exclusive product scan
+// (lane-local serial product, then a wave-level multiplicative scan of the lane totals).
+template <int CH>
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ z_vals, const float* __restrict__ sigma,
+                                                        const float* __restrict__ rgb_s, const float* __restrict__ ft /*(R*S,C)*/,
+                                                        const int* __restrict__ valid_s, int R, int S, int C, int white_bkgd,
+                                                        float* __restrict__ o_rgb, float* __restrict__ o_depth,
+                                                        float* __restrict__ o_w, unsigned char* __restrict__ o_mask,
+                                                        float* __restrict__ o_unc, float* __restrict__ o_feat) {
+  __shared__ float wsh[4][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wv;
+  if (r >= R) return;
+  const float* z = z_vals + (size_t)r * S;
+  float zs[CH], al[CH];
+  float prod = 1.f;
+  int nvalid = 0;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) {
+      zs[j] = z[s];
+      const float delta = (s + 1 < S) ? z[s + 1] - zs[j] : 1e2f;
+      al[j] = 1.f - expf(-delta * sigma[(size_t)r * S + s]);
+      prod *= (1.f - al[j]);
+      nvalid += valid_s ? valid_s[(size_t)r * S + s] : 0;
+    } else { zs[j] = 0.f; al[j] = 0.f; }
+  }
+  // inclusive multiplicative scan of lane products, shifted to exclusive
+  float inc = prod;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc *= t;
+  }
+  float T = __shfl_up(inc, 1, 64);
+  if (lane == 0) T = 1.f;
+  float w[CH];
+  float wsum = 0.f, dsum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) {
+      w[j] = al[j] * T;
+      T *= (1.f - al[j]);
+      wsum += w[j];
+      dsum += w[j] * zs[j];
+      const float* c = rgb_s + 3 * ((size_t)r * S + s);
+      cr += w[j] * c[0]; cg += w[j] * c[1]; cb += w[j] * c[2];
+      if (o_w) o_w[(size_t)r * S + s] = w[j];
+      wsh[wv][s] = w[j];
+    } else w[j] = 0.f;
+  }
+  wsum = wave_sum(wsum); dsum = wave_sum(dsum);
+  cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb);
+  int nv = nvalid;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o, 64);
+  float us = 0.f;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) { float d = zs[j] - dsum; us += w[j] * (d * d); }
+  }
+  us = wave_sum(us);
+  if (lane == 0) {
+    if (white_bkgd) { cr += 1.f - wsum; cg += 1.f - wsum; cb += 1.f - wsum; }
+    if (o_rgb) { o_rgb[3 * (size_t)r] = cr; o_rgb[3 * (size_t)r + 1] = cg; o_rgb[3 * (size_t)r + 2] = cb; }
+    if (o_depth) o_depth[r] = dsum;
+    if (o_unc) o_unc[r] = us;
+    if (o_mask) o_mask[r] = nv > 8 ? 1 : 0;
+  }
+  if (o_feat && ft) {
+    __builtin_amdgcn_wave_barrier();
+    // lanes across channels, serial over samples; weights broadcast from LDS (written by this wave only)
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      float acc = 0.f;
+      if (c < C)
+        for (int s = 0; s < S; ++s) acc = fmaf(wsh[wv][s], ft[((size_t)r * S + s) * C + c], acc);
+      if (c < C) o_feat[(size_t)r * C + c] = acc;
+    }
+  }
+}
+
+}  // namespace
+
+int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_,
+                            const float* z_in, float* z_out, float* xyz, hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  hipLaunchKernelGGL(sample_points_kernel, dim3((unsigned)nl_cdiv(R * S, 256)), dim3(256), 0, st, rays_o, rays_d, (int)R, S,
+                     near_, far_, z_in, z_out, xyz);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(sigma_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, geo, (int)N, W, w, b, sigma);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_blend(const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2,
+                    const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, h1, rgb_feat, vis_ang, (int)N, V, w2, b2, w4, b4, rgb_s);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s,
+                        int64_t R, int S, int C, int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  if (S > 256) return NL_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)nl_cdiv(R, 4));
+  float* o_rgb = out->rgb ? out->rgb + 3 * ray0 : nullptr;
+  float* o_depth = out->depth ? out->depth + ray0 : nullptr;
+  float* o_w = out->weights ? out->weights + ray0 * S : nullptr;
+  unsigned char* o_mask = out->mask ? out->mask + ray0 : nullptr;
+  float* o_unc = out->depth_uncertainty ? out->depth_uncertainty + ray0 : nullptr;
+  float* o_feat = out->feat ? out->feat + ray0 * C : nullptr;
+#define NL_COMP(CH) hipLaunchKernelGGL(composite_kernel<CH>, grid, dim3(256), 0, st, z_vals, sigma, rgb_s, ft, valid_s, (int)R, S, C, \
+                                       white_bkgd, o_rgb, o_depth, o_w, o_mask, o_unc, o_feat)
+  if (S <= 64) NL_COMP(1);
+  else if (S <= 128) NL_COMP(2);
+  else if (S <= 192) NL_COMP(3);
+  else NL_COMP(4);
+#undef NL_COMP
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}

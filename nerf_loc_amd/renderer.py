@@ -1,0 +1,228 @@
+"""Thin host wrapper over the C-ABI: torch tensors -> raw device pointers, stream handling, workspaces.
+
+PyTorch is plumbing here (device memory + the current HIP stream); every computation on the ray path
+happens inside libnerfloc_render.so.  Mirrors the pieces of state the reference keeps on the module:
+packed weights <- state_dict, frame <- (`data`, `support_neural_points['fine']`, `vis_featmaps`).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t, device) -> torch.Tensor:
+    t = torch.as_tensor(t)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipRenderer:
+    """One renderer per (device, W, C, S, precision).  Not thread-safe (like the reference module)."""
+
+    def __init__(self, W: int, C: int, S: int, precision: str = "bf16x3", device: str = "cuda:0", workspace_bytes: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipRenderer needs a HIP device; there is no CPU fallback (the oracle is test-only)")
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.cfg = L.NlConfig(W, C, S, L.PRECISIONS[precision])
+        self.W, self.C, self.S = W, C, S
+        self.precision = precision
+        nbytes = self.lib.nl_packed_weights_bytes(ct.byref(self.cfg))
+        if nbytes == 0:
+            raise ValueError(f"unsupported renderer config W={W} C={C} S={S}")
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._weights_loaded = False
+        self._frame = ct.c_void_p(None)
+        self._frame_keep = None
+        self._ws = None
+        self._ws_request = workspace_bytes
+        self.V = 0
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        names = L.weight_names()
+        keep = []
+        arr = (ct.c_void_p * len(names))()
+        for i, n in enumerate(names):
+            if n not in state_dict:
+                raise KeyError(f"state_dict is missing {n}")
+            t = _dev_f32(state_dict[n].detach() if isinstance(state_dict[n], torch.Tensor) else state_dict[n], self.device)
+            keep.append(t)
+            arr[i] = t.data_ptr()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.nl_pack_weights(ct.byref(self.cfg), arr, len(names), self.packed.data_ptr(), self.packed.numel(), st), "nl_pack_weights")
+        torch.cuda.current_stream(self.device).synchronize()  # sources may be freed after this
+        self._weights_loaded = True
+
+    def set_precision(self, precision: str) -> None:
+        """All three weight layouts are packed at once, so switching is free."""
+        self.precision = precision
+        self.cfg.precision = L.PRECISIONS[precision]
+
+    # ------------------------------------------------------------------ frame
+    def set_frame(self, images, featmaps_hwc, vis_featmaps, Ks, poses, near: float, far: float, support: Dict[str, torch.Tensor]) -> None:
+        """images (V,3,H,W); featmaps_hwc (V,h,w,C) = data['feat_fine_src']; vis_featmaps (V,32,h,w);
+        Ks (V,3,3); poses (V,4,4) c2w; support = support_neural_points['fine'] (xyz, feature, confidence, direction)."""
+        self.clear_frame()
+        dev = self.device
+        images = _dev_f32(images, dev)
+        feat = _dev_f32(featmaps_hwc, dev)
+        visf = _dev_f32(vis_featmaps, dev)
+        V, _, H, Wimg = images.shape
+        h, w = feat.shape[1], feat.shape[2]
+        if V > L.MAX_VIEWS:
+            raise ValueError(f"at most {L.MAX_VIEWS} support views")
+        # the tiny per-view matrices are formed on the host exactly like the reference forms them
+        Kc = torch.as_tensor(Ks).detach().float().cpu()
+        Pc = torch.as_tensor(poses).detach().float().cpu()
+        K4 = torch.eye(4).expand(V, 4, 4).clone()
+        K4[:, :3, :3] = Kc
+        proj_ibr = K4.bmm(torch.inverse(Pc))[:, :3].contiguous()       # ibrnet.py:183
+        proj_neuray = (Kc @ Pc.inverse()[:, :3]).contiguous()          # depth_fusion.py:90, multiview_aggregator.py:184
+        cams = Pc[:, :3, 3].contiguous()
+        sp = {k: _dev_f32(support[k], dev) for k in ("xyz", "feature", "confidence", "direction")}
+        M = sp["xyz"].shape[0]
+        d = L.NlFrameDesc()
+        d.V, d.H, d.Wimg, d.h, d.w = V, H, Wimg, h, w
+        d.near_, d.far_ = float(near), float(far)
+        d.images, d.featmaps, d.vis_featmaps = images.data_ptr(), feat.data_ptr(), visf.data_ptr()
+        d.proj_ibr, d.proj_neuray, d.cam_centers = proj_ibr.data_ptr(), proj_neuray.data_ptr(), cams.data_ptr()
+        d.M = M
+        if M > 0:
+            d.sp_xyz, d.sp_feature = sp["xyz"].data_ptr(), sp["feature"].data_ptr()
+            d.sp_confidence, d.sp_direction = sp["confidence"].data_ptr(), sp["direction"].data_ptr()
+        nbytes = self.lib.nl_frame_bytes(ct.byref(self.cfg), ct.byref(d))
+        if nbytes == 0:
+            raise ValueError("nl_frame_bytes rejected the frame description")
+        mem = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        fr = ct.c_void_p(None)
+        L.check(self.lib.nl_frame_create(ct.byref(self.cfg), ct.byref(d), mem.data_ptr(), nbytes, st, ct.byref(fr)), "nl_frame_create")
+        self._frame = fr
+        self._frame_keep = (images, feat, visf, sp, mem, proj_ibr, proj_neuray, cams)
+        self.V, self.near, self.far, self.M = V, float(near), float(far), M
+
+    def clear_frame(self) -> None:
+        if self._frame:
+            self.lib.nl_frame_destroy(self._frame)
+        self._frame = ct.c_void_p(None)
+        self._frame_keep = None
+
+    def __del__(self):
+        try:
+            self.clear_frame()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _ready(self):
+        if not self._weights_loaded:
+            raise RuntimeError("load_weights() first")
+        if not self._frame:
+            raise RuntimeError("set_frame() first")
+
+    # ------------------------------------------------------------------ fused path
+    def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
+                    intermediates: bool = False, want_feat: bool = True) -> Dict[str, torch.Tensor]:
+        self._ready()
+        dev = self.device
+        o, d = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev)
+        R, S, W = o.shape[0], self.S, self.W
+        z = None if z_vals is None else _dev_f32(z_vals, dev)
+        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        out = {
+            "rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
+            "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev),
+        }
+        if want_feat:
+            out["feat"] = torch.empty(R, self.C, device=dev)
+        if intermediates:
+            N = R * S
+            out.update({"sigma": torch.empty(N, device=dev), "feature_agg": torch.empty(N, W, device=dev),
+                        "mv_feature_agg": torch.empty(N, W, device=dev), "geo": torch.empty(N, W, device=dev),
+                        "knn_idx": torch.empty(N, 8, dtype=torch.int32, device=dev), "knn_d2": torch.empty(N, 8, device=dev)})
+        ro = L.NlRenderOut()
+        for k, t in out.items():
+            setattr(ro, k, t.data_ptr())
+        need = self._ws_request or self.lib.nl_render_rays_workspace_bytes(ct.byref(self.cfg), self.V, R)
+        ws = self._workspace(need)
+        L.check(self.lib.nl_render_rays(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(),
+                                        _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream()), "nl_render_rays")
+        out["mask"] = out["mask"].bool()
+        if intermediates:
+            out["sigma"] = out["sigma"].view(R, S)
+        return out
+
+    # ------------------------------------------------------------------ stages (used by tests and staged callers)
+    def knn(self, xyz, K: int = 8):
+        self._ready()
+        x = _dev_f32(xyz, self.device)
+        N = x.shape[0]
+        idx = torch.empty(N, K, dtype=torch.int32, device=self.device)
+        d2 = torch.empty(N, K, device=self.device)
+        L.check(self.lib.nl_knn(self._frame, x.data_ptr(), N, K, idx.data_ptr(), d2.data_ptr(), self._stream()), "nl_knn")
+        return d2, idx
+
+    def sample_points(self, rays_o, rays_d, z_vals=None):
+        o, d = _dev_f32(rays_o, self.device), _dev_f32(rays_d, self.device)
+        R = o.shape[0]
+        z = None if z_vals is None else _dev_f32(z_vals, self.device)
+        zo = torch.empty(R, self.S, device=self.device)
+        xyz = torch.empty(R * self.S, 3, device=self.device)
+        L.check(self.lib.nl_sample_points(o.data_ptr(), d.data_ptr(), R, self.S, self.near, self.far, _ptr(z), zo.data_ptr(), xyz.data_ptr(), self._stream()), "nl_sample_points")
+        return zo, xyz
+
+    def mv_aggregate(self, xyz, query_center):
+        self._ready()
+        x = _dev_f32(xyz, self.device)
+        N, V = x.shape[0], self.V
+        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        mv = torch.empty(N, self.W, device=self.device)
+        rgb_feat = torch.empty(N * V, 196, device=self.device)
+        vis_ang = torch.empty(N * V, 8, device=self.device)
+        valid = torch.empty(N, dtype=torch.int32, device=self.device)
+        ws = self._workspace(self.lib.nl_mv_aggregate_workspace_bytes(ct.byref(self.cfg), V, N))
+        L.check(self.lib.nl_mv_aggregate(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), N, mv.data_ptr(),
+                                         rgb_feat.data_ptr(), vis_ang.data_ptr(), valid.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate")
+        return mv, rgb_feat.view(N, V, 196), vis_ang.view(N, V, 8), valid
+
+    def point_mlp(self, xyz, direction, mv_feat, K: int = 8):
+        self._ready()
+        x = _dev_f32(xyz, self.device)
+        N = x.shape[0]
+        dr = None if direction is None else _dev_f32(direction, self.device)
+        g = _dev_f32(mv_feat, self.device)
+        fa = torch.empty(N, self.W, device=self.device)
+        idx = torch.empty(N, K, dtype=torch.int32, device=self.device)
+        d2 = torch.empty(N, K, device=self.device)
+        ws = self._workspace(self.lib.nl_point_mlp_workspace_bytes(ct.byref(self.cfg), N))
+        L.check(self.lib.nl_point_mlp(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
+                                      g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
+        return fa, d2, idx
+
+    def ray_unet(self, x):
+        """x (R*S, W) sample-major -> geo (R*S, W)."""
+        if not self._weights_loaded:
+            raise RuntimeError("load_weights() first")
+        xin = _dev_f32(x, self.device)
+        R = xin.shape[0] // self.S
+        geo = torch.empty_like(xin)
+        ws = self._workspace(self.lib.nl_ray_unet_workspace_bytes(ct.byref(self.cfg), R))
+        L.check(self.lib.nl_ray_unet(ct.byref(self.cfg), self.packed.data_ptr(), xin.data_ptr(), R, geo.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_ray_unet")
+        return geo
