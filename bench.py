@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — rendered rays/s of the HIP conditional-NeRF renderer on synthetic BASELINE.json configs.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2] [--precision bf16x3]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one `render_rays` pass (rows a2-a18 of SURVEY.md §8) over one batch of R rays whose inputs are
+already resident in HBM; per-frame setup (weight packing, KNN grid, map repack) is outside the timed region,
+like the reference's cached `support_neural_points` / `vis_featmaps`.  With N>1 every rank renders its own
+R-ray shard of the same frame (weak scaling) and the per-ray outputs are joined by ONE RCCL all-gather inside
+the timed step.  Rank 0 prints one JSON line.
+
+`roofline`: bound = MFMA; achieved = ALGORITHMIC flops of one step (SURVEY.md §8(d) formula: GEMM/conv MACs x2,
+q-projection counted once) / mean step duration from HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16
+(MI355X_MICROARCH.md).  `cpu_baseline`: the CPU oracle (oracle/, a port of the reference's PyTorch path, "kind":"port")
+timed on rank 0's host cores over a bounded ray sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nerf_loc_amd.synth import CONFIGS, make_frame, make_rays, make_weights  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def algorithmic_mac_per_sample(W: int, V: int, C: int = 192, K: int = 8) -> float:
+    """forward GEMM/conv multiply-adds per sample (reference formulation, q-proj once)."""
+    F = C + 3
+    point = K * (496 + (F + 90) * W + 2 * W * W + 2 * 128 * W + 128 * W + W * W + W) + 128 * W
+    attn = 16384  # 8 query rows x 8 keys x 128 dims x {qk, av} as the reference evaluates it
+    mv = (2 * F + 3) * 64 + 64 * W + V * 8384
+    unet = 192 * W + 12288 + 12288 + 6144 + 12288 + 6144 + 3 * (W + 32) * W
+    heads = W + W * W + C * W + V * ((W + F + 5) * 32 + 528)
+    return float(point + attn + mv + unet + heads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"])
+    ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default="bf16", help="comma list of extra precisions timed after the headline (''=none)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nerf_loc_amd.renderer import HipRenderer
+    from nerf_loc_amd.sharding import gather_ray_outputs
+
+    cfg = CONFIGS[args.config]
+    R = args.rays or cfg.R
+    S = cfg.S_total
+    frame = make_frame(cfg)
+    rays = make_rays(cfg, frame, R=R, seed_offset=1000 + rank)  # every rank its own shard of pixels
+    weights = make_weights(cfg)
+
+    rnd = HipRenderer(cfg.W, cfg.C, S, args.precision, device=f"cuda:{local_rank}")
+    rnd.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
+    rnd.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"],
+                  cfg.near, cfg.far, frame["support_fine"])
+    o = torch.from_numpy(rays["rays_o"]).to(dev)
+    d = torch.from_numpy(rays["rays_d"]).to(dev)
+    t_lin = torch.linspace(0, 1, S)
+    z = torch.tensor(cfg.near, dtype=torch.float32) * (1 - t_lin) + torch.tensor(cfg.far, dtype=torch.float32) * t_lin  # model.py:451-458
+    z = z.expand(R, S).contiguous().to(dev)
+    qc = frame["pose"][:3, 3]
+
+    def step():
+        out = rnd.render_rays(o, d, qc, z_vals=z, white_bkgd=cfg.white_bkgd)
+        if world > 1:
+            out = gather_ray_outputs(out, dist)
+        return out
+
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+        return wall, dev_ms
+
+    wall, dev_ms = timed(args.steps, args.warmup)
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * R * args.steps / wall
+    flops_step = 2.0 * algorithmic_mac_per_sample(cfg.W, cfg.V, cfg.C) * R * S
+    ach = flops_step / (dev_ms * 1e-3 / args.steps) / 1e12
+    result = {
+        "metric": "rendered rays/sec (4096 rays x 128 samples, 256-wide MLP)", "value": value, "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
+                                                            "bf16": "bf16", "fp32": "f32"}[args.precision],
+        "data": "synthetic",
+        "config": {"workload": f"{cfg.name}: {R} rays x {S} samples, W={cfg.W}, V={cfg.V} views {cfg.H}x{cfg.Wimg}, M={frame['support_fine']['xyz'].shape[0]} neural points",
+                   "rays_per_gpu": R, "precision": args.precision, "parallelism": f"ray-shard x{world} + all-gather"},
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                     "traffic": None, "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
+                     "flops_per_step": flops_step, "device_ms_per_step": dev_ms / args.steps},
+    }
+
+    if args.also and world == 1:
+        extra = {}
+        for p in [x for x in args.also.split(",") if x and x != args.precision]:
+            rnd.set_precision(p)
+            w2, d2 = timed(max(3, args.steps // 2), 2)
+            n2 = max(3, args.steps // 2)
+            extra[p] = {"rays_per_s": R * n2 / w2, "ms_per_step": w2 * 1e3 / n2, "roofline_frac": flops_step / (d2 * 1e-3 / n2) / 1e12 / PEAK_BF16_TFLOPS}
+        rnd.set_precision(args.precision)
+        result["other_precisions"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, frame, rays, weights, budget_s: float = 20.0):
+    """Time the CPU oracle (port of the reference's PyTorch path) on a bounded ray sample of the same workload."""
+    from oracle import render_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = {k: torch.from_numpy(v) for k, v in weights.items()}
+    fr = orc.to_torch(frame)
+
+    def run(n):
+        sub = {k: (torch.from_numpy(v[:n]) if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[0] >= n and k in ("rays_o", "rays_d", "pixel_coordinates")
+                   else (torch.from_numpy(v) if isinstance(v, np.ndarray) else v)) for k, v in rays.items()}
+        timers = {}
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc.render_rays(p, fr, sub, cfg.S, cfg.N_importance, knn_threads=cores, timers=timers)
+        return time.perf_counter() - t0, timers
+
+    n = 8
+    t, _ = run(n)                       # includes first-touch warm-up
+    t, _ = run(n)
+    n2 = int(max(8, min(len(rays["rays_o"]), n * budget_s / max(t, 1e-3))))
+    n2 = min(n2, 256)                   # bound RAM (a 256-ray chunk of c2 peaks around 15 GB)
+    t2, timers = run(n2)
+    return {"value": n2 / t2, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n2} rays x {cfg.S_total} samples of the same workload, one chunk, {t2:.1f} s",
+            "stage_seconds": {k: round(v, 3) for k, v in timers.items()}}
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,10 @@ import ctypes as C
 import os
 import subprocess
 
+import torch  # noqa: F401  -- MUST precede CDLL: torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 (same
+# SONAMEs as /opt/rocm's); loading ours first would put two HIP runtimes in the process and every torch pointer
+# would be foreign to our kernels.  Importing torch first makes the dynamic loader resolve our DT_NEEDED to its copy.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnerfloc_render.so")
 

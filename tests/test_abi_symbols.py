@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library is built in-tree, loads, and exports every
+symbol include/nerfloc_render.h declares; the product path refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from nerf_loc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "nerfloc_render.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nl_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(n for n, _, _ in _lib.SYMBOLS) == declared, "ctypes table and header disagree"
+
+
+def test_weight_table_matches_state_dict_contract():
+    from nerf_loc_amd.synth import CONFIGS, weight_shapes
+    names = _lib.weight_names()
+    shapes = weight_shapes(CONFIGS["c1"])
+    assert len(names) == 84 and len(set(names)) == 84
+    for n in names:
+        assert n in shapes, n
+
+
+def test_error_codes_and_bad_args_do_not_crash():
+    lib = _lib.load()
+    assert lib.nl_strerror(0) == b"ok"
+    assert lib.nl_strerror(-3) == b"workspace too small"
+    bad = _lib.NlConfig(100, 192, 30, 0)   # W not multiple of 32, S not multiple of 8
+    import ctypes as ct
+    assert lib.nl_packed_weights_bytes(ct.byref(bad)) == 0
+    ok = _lib.NlConfig(256, 192, 128, 1)
+    assert lib.nl_packed_weights_bytes(ct.byref(ok)) > 1_000_000
+    assert lib.nl_render_rays_min_workspace_bytes(ct.byref(ok), 10) > 0
+    assert lib.nl_render_rays(ct.byref(ok), None, None, None, None, None, None, 4, 0, None, None, 0, None) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a GPU-less host")
+def test_product_path_fails_loudly_without_gpu():
+    from nerf_loc_amd.renderer import HipRenderer
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipRenderer(64, 192, 32)

@@ -1,0 +1,199 @@
+"""GPU parity tests (run with `pytest -m gpu` on the MI355X box): everything goes through the C-ABI.
+
+Tolerances (max |a-b| / max |b|, SURVEY.md App. B metric): fp32 MFMA mode 5e-5; bf16x3 split mode 1e-4
+(BASELINE.json's bar); integer/index work (KNN distances, indices, ray mask) bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_cases import CASES, build_case
+from tests.util import load_golden, oracle_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 5e-5, "bf16x3": 1e-4}
+PLAIN = [n for n in CASES if CASES[n][0].N_importance == 0]
+
+
+def _renderer(case, precision, **kw):
+    from nerf_loc_amd.renderer import HipRenderer
+    cfg, fr = case["cfg"], case["frame"]
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision, **kw)
+    r.load_weights({k: torch.from_numpy(v) for k, v in case["weights"].items()})
+    r.set_frame(fr["topk_images"], fr["feat_fine_src"], fr["vis_featmaps"], fr["topk_Ks"], fr["topk_poses"], cfg.near, cfg.far, fr["support_fine"])
+    return r
+
+
+def _z(cfg, R):
+    from oracle.render_oracle import sample_depths
+    return sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(R, cfg.S).contiguous()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", PLAIN)
+def test_render_rays_matches_reference_golden(name, precision):
+    cfg, full = CASES[name]
+    case = build_case(name)
+    g = load_golden(name)
+    r = _renderer(case, precision)
+    out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], case["frame"]["pose"][:3, 3], z_vals=_z(cfg, cfg.R),
+                        white_bkgd=cfg.white_bkgd, intermediates=True)
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.array_equal(o["knn_d2"], g["knn_d2"]), "squared distances are bit-exact"
+    assert np.array_equal(o["mask"], g["mask"])
+    if name != "ties":
+        assert np.array_equal(o["knn_idx"], g["knn_idx"])
+    tol = TOL[precision]
+    for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat", "sigma"):
+        assert rel_err(o[k], g[k]) < tol, (k, rel_err(o[k], g[k]))
+    rows = g["rows"] if "rows" in g else slice(None)
+    for k, gk in (("mv_feature_agg", "multiview_feature_agg"), ("feature_agg", "feature_agg"), ("geo", "geo")):
+        assert rel_err(o[k][rows], g[gk]) < tol, (k, rel_err(o[k][rows], g[gk]))
+
+
+def test_bf16_throughput_mode_error_is_reported_not_hidden():
+    """Plain bf16 does NOT meet 1e-4 (SURVEY §7 'hard parts'); keep its error bounded and known."""
+    case = build_case("c1")
+    g = load_golden("c1")
+    cfg = case["cfg"]
+    r = _renderer(case, "bf16")
+    out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], case["frame"]["pose"][:3, 3], z_vals=_z(cfg, cfg.R))
+    errs = {k: rel_err(out[k].cpu().numpy(), g[k]) for k in ("rgb", "depth", "weights", "feat")}
+    assert all(e < 3e-2 for e in errs.values()), errs
+    assert max(errs.values()) > 1e-4, "if this ever passes 1e-4 the headline mode should switch to bf16"
+
+
+@pytest.mark.parametrize("n,m,K,kind", [(5000, 3000, 8, "cloud"), (4096, 20000, 8, "sheets"), (2000, 5, 8, "few"), (3000, 700, 1, "cloud"),
+                                         (2000, 900, 8, "lattice"), (1500, 1, 8, "one"), (1000, 2000, 8, "far")])
+def test_knn_exact_vs_oracle(n, m, K, kind):
+    from nerf_loc_amd.renderer import HipRenderer
+    from oracle import render_oracle as orc
+    rng = np.random.default_rng(n + m + K)
+    p = rng.standard_normal((m, 3)).astype(np.float32)
+    q = (rng.standard_normal((n, 3)) * 1.5).astype(np.float32)
+    if kind == "sheets":
+        p[:, 2] = (0.05 * np.sin(3 * p[:, 0]) + np.round(p[:, 2])).astype(np.float32)
+    if kind == "lattice":
+        p = (np.round(p * 3) / 3).astype(np.float32)
+        q = (np.round(q * 3) / 3).astype(np.float32)
+    if kind == "far":
+        q[::2] += np.array([40.0, -25.0, 10.0], np.float32)
+    case = build_case("tiny_full")
+    case["frame"]["support_fine"] = {"xyz": p, "feature": np.zeros((m, 195), np.float32), "confidence": np.ones((m, 1), np.float32),
+                                     "direction": np.zeros((m, 4), np.float32)}
+    r = _renderer(case, "fp32")
+    d2, idx = r.knn(q, K)
+    d2o, idxo = orc.knn_points(torch.from_numpy(q), torch.from_numpy(p), K)
+    assert np.array_equal(d2.cpu().numpy(), d2o.numpy())
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), idxo.numpy()), "ties resolve by index exactly like knn_cpu.cpp's heap"
+
+
+@pytest.mark.parametrize("name", ["tiny_full", "offview", "w256s128"])
+def test_stage_entry_points_match_oracle(name):
+    from oracle import render_oracle as orc
+    cfg, _ = CASES[name]
+    case = build_case(name)
+    params, frame, rays = oracle_inputs(case)
+    r = _renderer(case, "fp32")
+    z = _z(cfg, cfg.R)
+    zo, xyz = r.sample_points(rays["rays_o"], rays["rays_d"], z)
+    xyz_ref = (rays["rays_o"][:, None] + rays["rays_d"][:, None] * z[..., None]).view(-1, 3)
+    assert np.array_equal(xyz.cpu().numpy(), xyz_ref.numpy()), "a3 is bit-exact (no fma contraction)"
+    with torch.no_grad():
+        mv_o, rgbf_o, vis_o, mask1_o = orc.mv_aggregate(params, frame, xyz_ref)
+    mv, rgbf, vis_ang, valid = r.mv_aggregate(xyz, case["frame"]["pose"][:3, 3])
+    assert rel_err(mv.cpu().numpy(), mv_o.numpy()) < 5e-5
+    assert rel_err(rgbf[:, :, :195].cpu().numpy(), rgbf_o.numpy()) < 1e-5
+    assert rel_err(vis_ang[:, :, 0].cpu().numpy(), vis_o.squeeze(-1).numpy()) < 2e-5
+    assert np.array_equal(valid.cpu().numpy() > 0, (mask1_o.squeeze(-1).sum(1) > 1).numpy())
+    ang_o = orc.compute_angle(xyz_ref, frame["pose"], frame["topk_poses"]).permute(1, 0, 2)
+    # unit(difference of two nearly parallel unit vectors) is ill-conditioned: fp32 rounding (~1e-7 on each unit
+    # vector) is amplified by 1/|diff|, |diff| = sqrt(2 - 2 dot).  Bound the error accordingly.
+    ang_h, ang_r = vis_ang[:, :, 1:5].cpu().numpy(), ang_o.numpy()
+    nd = np.sqrt(np.maximum(2.0 - 2.0 * ang_r[..., 3:4].astype(np.float64), 1e-10))
+    assert (np.abs(ang_h[..., :3] - ang_r[..., :3]) <= 1e-6 / nd + 2e-6).all()
+    assert np.abs(ang_h[..., 3] - ang_r[..., 3]).max() < 1e-6
+    d = torch.cat([rays["rays_d"][:, None].repeat(1, cfg.S, 1).view(-1, 3), z.reshape(-1, 1)], -1)
+    with torch.no_grad():
+        qd = orc.query(params, frame, xyz_ref, d)
+    fa, d2, idx = r.point_mlp(xyz, d[:, :3].contiguous(), mv_o)
+    assert np.array_equal(d2.cpu().numpy(), qd["knn_d2"].numpy())
+    assert rel_err(fa.cpu().numpy(), qd["feature_agg"].numpy()) < 5e-5
+    W = cfg.W
+    with torch.no_grad():
+        geo_o = orc.ray_unet(params, qd["feature_agg"].view(cfg.R, cfg.S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(-1, W)
+    geo = r.ray_unet(qd["feature_agg"])
+    assert rel_err(geo.cpu().numpy(), geo_o.numpy()) < 5e-5
+
+
+def test_descriptor_query_direction_falls_back_to_nearest_neighbour():
+    """query() with direction=None (model.py:391-392), as query_coarse/query_fine call it."""
+    from oracle import render_oracle as orc
+    case = build_case("tiny_full")
+    params, frame, rays = oracle_inputs(case)
+    r = _renderer(case, "fp32")
+    xyz = frame["support_fine"]["xyz"][::7][:200].clone() + 0.01
+    with torch.no_grad():
+        qd = orc.query(params, frame, xyz, None)
+    fa, _, _ = r.point_mlp(xyz, None, qd["multiview_feature_agg"])
+    assert rel_err(fa.cpu().numpy(), qd["feature_agg"].numpy()) < 5e-5
+
+
+# ------------------------------------------------------------------ full-size (BASELINE config 2) properties
+@pytest.fixture(scope="module")
+def c2():
+    from nerf_loc_amd.synth import CONFIGS, make_frame, make_rays, make_weights
+    cfg = CONFIGS["c2"]
+    frame = make_frame(cfg)
+    return {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+
+
+def test_full_size_properties_c2(c2):
+    cfg = c2["cfg"]
+    r = _renderer(c2, "bf16x3")
+    o, d = c2["rays"]["rays_o"], c2["rays"]["rays_d"]
+    qc = c2["frame"]["pose"][:3, 3]
+    z = _z(cfg, cfg.R)
+    a = r.render_rays(o, d, qc, z_vals=z)
+    torch.cuda.synchronize()
+    for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+        assert torch.isfinite(a[k]).all(), k
+    # last delta = 1e2 makes every ray opaque: weights sum to 1 (model.py:544-553)
+    assert float((a["weights"].sum(1) - 1).abs().max()) < 1e-4
+    assert float(a["depth"].min()) >= cfg.near - 1e-4 and float(a["depth"].max()) <= cfg.far + 1e-4
+    # determinism
+    b = r.render_rays(o, d, qc, z_vals=z)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # chunk invariance: a much smaller workspace (more, smaller ray chunks) gives bit-identical results
+    from nerf_loc_amd import _lib
+    import ctypes as ct
+    small = _lib.load().nl_render_rays_workspace_bytes(ct.byref(r.cfg), r.V, 96)
+    r2 = _renderer(c2, "bf16x3", workspace_bytes=small)
+    c = r2.render_rays(o, d, qc, z_vals=z)
+    for k in a:
+        assert torch.equal(a[k], c[k]), k
+    # ray-permutation equivariance
+    perm = torch.randperm(cfg.R, generator=torch.Generator().manual_seed(0))
+    e = r.render_rays(o[perm.numpy()], d[perm.numpy()], qc, z_vals=z)
+    for k in a:
+        assert torch.equal(a[k][perm.to(a[k].device)], e[k]), k
+
+
+def test_full_size_sampled_rays_match_oracle_c2(c2):
+    """64 of the 4096 rays of the headline workload against the CPU oracle (bf16x3, 1e-4)."""
+    from oracle import render_oracle as orc
+    cfg = c2["cfg"]
+    sel = np.arange(0, cfg.R, cfg.R // 64)[:64]
+    r = _renderer(c2, "bf16x3")
+    z = _z(cfg, len(sel))
+    out = r.render_rays(c2["rays"]["rays_o"][sel], c2["rays"]["rays_d"][sel], c2["frame"]["pose"][:3, 3], z_vals=z)
+    params = {k: torch.from_numpy(v) for k, v in c2["weights"].items()}
+    sub = {k: (torch.from_numpy(v[sel]) if k in ("rays_o", "rays_d", "pixel_coordinates") else (torch.from_numpy(v) if isinstance(v, np.ndarray) else v))
+           for k, v in c2["rays"].items()}
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(c2["frame"]), sub, cfg.S, knn_threads=16)
+    assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+    for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 1e-4, (k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))

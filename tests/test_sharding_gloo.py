@@ -1,0 +1,66 @@
+"""N>1 path on CPU: contiguous ray-range sharding + the single all-gather, world_size 2 over gloo."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_loc_amd.sharding import gather_ray_outputs, pack_outputs, shard_range, unpack_outputs
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 4096, 4097):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_roundtrip():
+    R = 5
+    out = {"rgb": torch.rand(R, 3), "depth": torch.rand(R), "weights": torch.rand(R, 16), "mask": torch.rand(R) > 0.5,
+           "depth_uncertainty": torch.rand(R), "feat": torch.rand(R, 192)}
+    buf, layout = pack_outputs(out)
+    assert buf.shape == (R, 3 + 1 + 1 + 1 + 192 + 16)
+    back = unpack_outputs(buf, layout)
+    for k in out:
+        assert torch.equal(back[k], out[k]), k
+
+
+def _worker(rank, world, port, uneven, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R = 11 if uneven else 12
+    g = torch.Generator().manual_seed(0)
+    full = {"rgb": torch.rand(R, 3, generator=g), "depth": torch.rand(R, generator=g), "weights": torch.rand(R, 8, generator=g),
+            "mask": torch.rand(R, generator=g) > 0.5, "depth_uncertainty": torch.rand(R, generator=g), "feat": torch.rand(R, 4, generator=g)}
+    lo, hi = shard_range(R, rank, world)
+    mine = {k: v[lo:hi].clone() for k, v in full.items()}
+    counts = [shard_range(R, r, world)[1] - shard_range(R, r, world)[0] for r in range(world)]
+    got = gather_ray_outputs(mine, dist, counts if uneven else None)
+    ok = all(torch.equal(got[k], full[k]) for k in full)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _run(uneven, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, uneven, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_two_rank_gather_even():
+    _run(False, 29611)
+
+
+def test_two_rank_gather_uneven():
+    _run(True, 29612)
