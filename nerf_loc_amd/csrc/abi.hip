@@ -28,6 +28,21 @@ int nl_launch_blend(const float* h1, const float* rgb_feat, const float* vis_ang
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
                         int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st);
 
+struct NlPointFusedArgs {
+  const float* xyz; const float* dir; int dir_stride, dir_div;
+  const int* idx; const float* Q; float* O;
+  const uint4* fhi; const uint4* flo;
+  const float* sp_xyz; const float* sp_dir;
+  const uint4* wstream; const float* bias; const float* rd_w;
+  int N, M; float inv_span;
+};
+size_t nl_point_stream_bytes(int W);
+int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
+int nl_split_feature_table(const float* src, int64_t M, int F, void* hi, void* lo, hipStream_t st);
+int nl_launch_wscale(const int* idx, const float* d2, const float* conf, int64_t N, int K, int64_t M, float* wscale, hipStream_t st);
+bool nl_point_fused_supported(int W, int precision);
+int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
+
 namespace {
 
 // ------------------------------------------------------------------------------------------ weight table
@@ -74,6 +89,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bias[G_COUNT];
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
+  size_t pt_stream, pt_bias;  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];
   int un_c[U_COUNT], un_l[U_COUNT];
   size_t total;
@@ -131,6 +147,8 @@ Layout make_layout(const nl_config* c) {
     L.un_g[u] = take(4 * (size_t)uc[u] * ul[u]);
     L.un_b[u] = take(4 * (size_t)uc[u] * ul[u]);
   }
+  L.pt_bias = take(4 * 3 * (size_t)W);
+  L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
   L.total = off;
   return L;
 }
@@ -206,6 +224,7 @@ struct nl_frame {
   const float* sp_xyz; const float* sp_feat; const float* sp_conf; const float* sp_dir;
   int64_t M;
   NlKnnGrid grid;
+  uint4* fhi; uint4* flo;   // bf16 hi / lo split of sp_feat, [M][208]
 };
 
 namespace {
@@ -234,9 +253,12 @@ void carve_mv(Bump& b, const nl_config* c, int V, int64_t N, MvBufs& m) {
 void carve_pt(Bump& b, const nl_config* c, int64_t N, int K, PtBufs& p) {
   const int W = c->W;
   p.idx = b.take<int>((size_t)N * K); p.d2 = b.take<float>((size_t)N * K);
-  p.X = b.take<float>((size_t)N * K * LDX);
-  p.H1 = b.take<float>((size_t)N * K * W); p.H2 = b.take<float>((size_t)N * K * W);
-  p.KV = b.take<float>((size_t)N * K * 256);
+  if (nl_point_fused_supported(W, c->precision)) { p.X = p.H1 = p.H2 = p.KV = nullptr; }
+  else {
+    p.X = b.take<float>((size_t)N * K * LDX);
+    p.H1 = b.take<float>((size_t)N * K * W); p.H2 = b.take<float>((size_t)N * K * W);
+    p.KV = b.take<float>((size_t)N * K * 256);
+  }
   p.Q = b.take<float>((size_t)N * 128); p.O = b.take<float>((size_t)N * 128);
   p.FCo = b.take<float>((size_t)N * W); p.wscale = b.take<float>((size_t)N);
 }
@@ -323,18 +345,29 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
              float* FA, const PtBufs& p) {
   const int W = x.c->W, F = f->C + 3;
   NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
-  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, f->M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir,
-                                x.p<float>(x.L.rd_w), 1.f / (f->views.far_ - f->views.near_), p.X, LDX, p.wscale, x.st));
-  const int64_t MK = N * K;
-  SegSpec sx{p.X, LDX, F + 90, 0, 1};
-  NL_TRY(run_gemm(x, G_BASE0, &sx, 1, MK, p.H1, W, NL_ACT_LRELU));
-  SegSpec s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1};
-  NL_TRY(run_gemm(x, G_BASE2, &s1, 1, MK, p.H2, W, NL_ACT_LRELU));
-  NL_TRY(run_gemm(x, G_BASE4, &s2, 1, MK, p.H1, W, NL_ACT_LRELU));
-  NL_TRY(run_gemm(x, G_KV, &s1, 1, MK, p.KV, 256, NL_ACT_NONE));
   SegSpec sg{G, W, W, 0, 1};
   NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
-  NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
+  if (K == 8 && nl_point_fused_supported(W, x.c->precision)) {
+    NL_TRY(nl_launch_wscale(p.idx, p.d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
+    NlPointFusedArgs a;
+    a.xyz = xyz; a.dir = dir; a.dir_stride = dir_stride; a.dir_div = dir_div > 0 ? dir_div : 1;
+    a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.fhi = f->fhi; a.flo = f->flo; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
+    a.wstream = x.p<uint4>(x.L.pt_stream); a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
+    a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
+    NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));
+  } else {
+    if (!p.X) return NL_ERR_UNSUPPORTED;
+    NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, f->M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir,
+                                  x.p<float>(x.L.rd_w), 1.f / (f->views.far_ - f->views.near_), p.X, LDX, p.wscale, x.st));
+    const int64_t MK = N * K;
+    SegSpec sx{p.X, LDX, F + 90, 0, 1};
+    NL_TRY(run_gemm(x, G_BASE0, &sx, 1, MK, p.H1, W, NL_ACT_LRELU));
+    SegSpec s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1};
+    NL_TRY(run_gemm(x, G_BASE2, &s1, 1, MK, p.H2, W, NL_ACT_LRELU));
+    NL_TRY(run_gemm(x, G_BASE4, &s2, 1, MK, p.H1, W, NL_ACT_LRELU));
+    NL_TRY(run_gemm(x, G_KV, &s1, 1, MK, p.KV, 256, NL_ACT_NONE));
+    NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
+  }
   SegSpec so{p.O, 128, 128, 0, 1};
   NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE));
   NL_TRY(nl_launch_ln_agg(p.FCo, G, N, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, p.wscale, FA, x.st));
@@ -503,7 +536,11 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.copy(t[T_BL2W], L.bl2_w, 512); P.copy(t[T_BL2B], L.bl2_b, 16);
   P.copy(t[T_BL4W], L.bl4_w, 16); P.copy(t[T_BL4B], L.bl4_b, 1);
   P.copy(t[T_LNW], L.ln_g, W); P.copy(t[T_LNB], L.ln_b, W);
-  (void)F;
+  P.copy(t[T_B0B], L.pt_bias, W); P.copy(t[T_B2B], L.pt_bias + 4 * (size_t)W, W); P.copy(t[T_B4B], L.pt_bias + 8 * (size_t)W, W);
+  if (W == 64 || W == 128 || W == 256) {
+    int rc = nl_pack_point_stream(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], (char*)packed + L.pt_stream, W, F, st);
+    if (rc != NL_OK) return rc;
+  }
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
@@ -517,7 +554,7 @@ static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
 
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
   if (!desc_ok(cfg, d)) return 0;
-  return nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
+  return nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256);
 }
 
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
@@ -541,6 +578,12 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
   f->visf_hwc = (float*)mem;
   int rc = nl_launch_chw_to_hwc(d->vis_featmaps, f->visf_hwc, d->V, 32, d->h * d->w, st);
   if (rc == NL_OK) rc = nl_knn_grid_build(&f->grid, (char*)mem + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256), d->sp_xyz, d->M, st);
+  {
+    char* p = (char*)mem + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
+    f->fhi = (uint4*)p;
+    f->flo = (uint4*)(p + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
+    if (rc == NL_OK) rc = nl_split_feature_table(d->sp_feature, d->M, cfg->C + 3, f->fhi, f->flo, st);
+  }
   if (rc != NL_OK) { delete f; return rc; }
   *out = f;
   return NL_OK;

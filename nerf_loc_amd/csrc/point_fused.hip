@@ -1,0 +1,436 @@
+// Fused neural-point branch — the MFMA roofline kernel.
+//
+//   per (sample, neighbour) row:  [feature(195) | posenc(63) | ray_diff_fc(27)]            model.py:394-409
+//       -> base_mlp 285->W->W->W (LeakyReLU)                                                model.py:63-71
+//       -> k/v projections W->128+128                                                       ibrnet.py:98-99
+//   per sample: 4-head attention of the (precomputed) query over its 8 neighbours -> O (N,128)  ibrnet.py:28-45,104
+//
+// MI355X design
+//   * Transposed MFMA: D^T = W * X^T, i.e. the WEIGHTS are the A operand and the activations the B operand of
+//     v_mfma_f32_32x32x16_bf16.  A wave owns 32 rows (= 4 samples x 8 neighbours) for the whole chain; the C/D
+//     fragment of layer L (lane = row, registers = 16 of every 32 features) is converted in registers to bf16
+//     and IS the B fragment of layer L+1 — the K order of every packed weight matrix is permuted offline to the
+//     accumulator's register order, so activations never touch LDS or HBM between the four layers.
+//   * Weights stream from L2 into LDS with LDS-DMA (global_load_lds_dwordx4), double-buffered in 2-k-step chunks
+//     whose LDS image is already in A-fragment order (one conflict-free ds_read_b128 per fragment), shared by
+//     the 4 waves of the workgroup.
+//   * bf16x3 mode (parity): activations and weights are split hi+lo; D += Alo*Bhi + Ahi*Blo + Ahi*Bhi (fp32 acc).
+//   * Layer-1 operands are assembled in registers: pre-split bf16 feature rows are gathered with 16-B loads that
+//     are already B fragments; positional encoding / ray_diff_fc are computed per lane in fp32 and split.
+//   * One wave per SIMD (the kernel lives in the 512-register file): 128 accumulators + up to 152 operand regs.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct NlPointFusedArgs {
+  const float* xyz; const float* dir; int dir_stride, dir_div;
+  const int* idx;          // (N,8) neighbour indices
+  const float* Q;          // (N,128) query projection (w_qs . mv_feat)
+  float* O;                // (N,128) attention output
+  const uint4* fhi; const uint4* flo;  // [M][26] uint4 = [M][208] bf16 feature table, hi / lo parts
+  const float* sp_xyz; const float* sp_dir;
+  const uint4* wstream;    // packed weight stream (pack_point_stream_kernel)
+  const float* bias;       // [3][W] base_mlp biases
+  const float* rd_w;       // ray_diff_fc: W0[16][4], b0[16], W2[27][16], b2[27]
+  int N, M;
+  float inv_span;
+};
+
+namespace {
+
+constexpr int L1_KSTEPS = 19;   // 13 feature + 4 posenc + 2 ray_diff_fc k-steps (K = 304 incl. zero padding)
+constexpr int L1_CHUNKS = 10;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <bool X3>
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    __bf16 h = (__bf16)v[t];
+    hi[t] = h;
+    if (X3) lo[t] = (__bf16)(v[t] - (float)h);
+  }
+}
+
+template <int NRT, bool X3>
+__global__ __launch_bounds__(256, 1) void point_fused_kernel(const NlPointFusedArgs a) {
+  __shared__ uint4 lds[2][2048];   // 2 x 32 KB: [part hi/lo][k-step 0/1][row tile][lane] A fragments
+  constexpr int W = 32 * NRT;
+  constexpr int PARTS = X3 ? 2 : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31, kk = j & 7;
+  const int n = blockIdx.x * 16 + wave * 4 + (j >> 3);
+  const bool live = n < a.N;
+  const int nn = live ? n : a.N - 1;
+  const char* wptr = (const char*)a.wstream;
+
+  // LDS-DMA one chunk (2 k-steps) of `ort` row tiles: global image == LDS image, hi parts first.
+  auto stage = [&](int buf, int ort) {
+    const int nkb = PARTS * 2 * ort;
+    for (int i = wave; i < nkb; i += 4) glds16(wptr + (size_t)i * 1024 + lane * 16, &lds[buf][i * 64]);
+    wptr += (size_t)4 * ort * 1024;
+  };
+  stage(0, NRT);
+
+  // ---------------------------------------------------------------- layer-1 operand fragments
+  bf16x8 fh[L1_KSTEPS + 1], fl[L1_KSTEPS + 1];
+  const int id = a.idx[(size_t)nn * 8 + kk];
+  const bool have = live && kk < a.M;   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
+  {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 13; ++q) {
+      uint4 vh = have ? a.fhi[(size_t)id * 26 + 2 * q + hh] : z4;
+      fh[q] = __builtin_bit_cast(bf16x8, vh);
+      if (X3) {
+        uint4 vl = have ? a.flo[(size_t)id * 26 + 2 * q + hh] : z4;
+        fl[q] = __builtin_bit_cast(bf16x8, vl);
+      }
+    }
+  }
+  {
+    const float qx = a.xyz[3 * (size_t)nn], qy = a.xyz[3 * (size_t)nn + 1], qz = a.xyz[3 * (size_t)nn + 2];
+    const float px = have ? a.sp_xyz[3 * (size_t)id] : 0.f, py = have ? a.sp_xyz[3 * (size_t)id + 1] : 0.f, pz = have ? a.sp_xyz[3 * (size_t)id + 2] : 0.f;
+    const float o0 = (qx - px) * a.inv_span, o1 = (qy - py) * a.inv_span, o2 = (qz - pz) * a.inv_span;
+    // positional encoding, 4 k-steps: slot pair (2*t2, 2*t2+1) of half hh in k-step 13+qs holds pair
+    // pi = 8*qs + 4*hh + t2:  pi<30 -> (sin, cos)(off[pi%3] * 2^(pi/3)); 30 -> (x, y); 31 -> (z, 0)
+#pragma unroll
+    for (int qs = 0; qs < 4; ++qs) {
+      float v[8];
+#pragma unroll
+      for (int t2 = 0; t2 < 4; ++t2) {
+        const int pi = 8 * qs + 4 * hh + t2;
+        const int f = pi / 3, ax = pi - 3 * f;
+        const float o = ax == 0 ? o0 : (ax == 1 ? o1 : o2);
+        float s, c;
+        sincosf(o * (float)(1 << (f < 10 ? f : 0)), &s, &c);
+        if (pi == 30) { s = o0; c = o1; }
+        if (pi == 31) { s = o2; c = 0.f; }
+        v[2 * t2] = s;
+        v[2 * t2 + 1] = c;
+      }
+      split8<X3>(v, fh[13 + qs], fl[13 + qs]);
+    }
+    // ray direction difference (model.py:396-399) -> ray_diff_fc (model.py:36-39), 2 k-steps
+    const size_t dr = (size_t)(nn / a.dir_div) * a.dir_stride;
+    float dx, dy, dz;
+    if (a.dir) { dx = a.dir[dr]; dy = a.dir[dr + 1]; dz = a.dir[dr + 2]; }
+    else {
+      const int i0 = a.idx[(size_t)nn * 8];
+      const bool ok = live && a.M > 0;
+      dx = ok ? a.sp_dir[4 * (size_t)i0] : 0.f; dy = ok ? a.sp_dir[4 * (size_t)i0 + 1] : 0.f; dz = ok ? a.sp_dir[4 * (size_t)i0 + 2] : 0.f;
+    }
+    const float ndx = have ? a.sp_dir[4 * (size_t)id] : 0.f, ndy = have ? a.sp_dir[4 * (size_t)id + 1] : 0.f, ndz = have ? a.sp_dir[4 * (size_t)id + 2] : 0.f;
+    float r0 = dx - ndx, r1 = dy - ndy, r2 = dz - ndz;
+    const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2) + 1e-8f;
+    r0 /= nr; r1 /= nr; r2 /= nr;
+    const float r3 = dx * ndx + dy * ndy + dz * ndz;
+    float hid[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = a.rd_w[64 + i];
+      s = fmaf(a.rd_w[i * 4 + 0], r0, s); s = fmaf(a.rd_w[i * 4 + 1], r1, s);
+      s = fmaf(a.rd_w[i * 4 + 2], r2, s); s = fmaf(a.rd_w[i * 4 + 3], r3, s);
+      hid[i] = nl_lrelu(s);
+    }
+    // all 27 outputs with wave-uniform (scalar-loaded) weights, then each half picks its 16 k-slots
+    const float* w2 = a.rd_w + 80;
+    float ro[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+      if (o < 27) {
+        float s = w2[27 * 16 + o];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s = fmaf(w2[o * 16 + i], hid[i], s);
+        ro[o] = nl_lrelu(s);
+      } else ro[o] = 0.f;
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = hh ? ro[16 * qs + 8 + t] : ro[16 * qs + t];
+      split8<X3>(v, fh[17 + qs], fl[17 + qs]);
+    }
+  }
+
+  f32x16 acc[8];
+  auto init_acc = [&](const float* bias, int ort) {
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+      if (rt < ort) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 b = bias ? *(const float4*)(bias + 32 * rt + 8 * g + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[rt][4 * g] = b.x; acc[rt][4 * g + 1] = b.y; acc[rt][4 * g + 2] = b.z; acc[rt][4 * g + 3] = b.w;
+        }
+      }
+  };
+
+  // one chunk: up to 2 k-steps x ort row tiles x (3 | 1) MFMAs
+  auto compute = [&](int buf, int ort, int nks, const bf16x8& bh0, const bf16x8& bl0, const bf16x8& bh1, const bf16x8& bl1) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < nks) {
+        const bf16x8 bh = ks ? bh1 : bh0;
+        const bf16x8 bl = ks ? bl1 : bl0;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+          if (rt < ort) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, lds[buf][((0 * 2 + ks) * ort + rt) * 64 + lane]);
+            if (X3) {
+              const bf16x8 al = __builtin_bit_cast(bf16x8, lds[buf][((1 * 2 + ks) * ort + rt) * 64 + lane]);
+              acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rt], 0, 0, 0);
+              acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rt], 0, 0, 0);
+            }
+            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // LeakyReLU + bf16 split of the finished layer: C/D registers -> next layer's B fragments
+  auto epilogue = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { float x = acc[rt][8 * s + t]; v[t] = fmaxf(x, 0.01f * x); }
+        split8<X3>(v, fh[2 * rt + s], fl[2 * rt + s]);
+      }
+  };
+
+  // ---------------------------------------------------------------- layer 1 (K = 304)
+  init_acc(a.bias, NRT);
+  __syncthreads();
+  int buf = 0;
+#pragma unroll
+  for (int c = 0; c < L1_CHUNKS; ++c) {
+    stage(buf ^ 1, NRT);   // next chunk (chunk L1_CHUNKS == first chunk of layer 2, same geometry)
+    compute(buf, NRT, (2 * c + 1 < L1_KSTEPS) ? 2 : 1, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
+    __syncthreads();
+    buf ^= 1;
+  }
+  epilogue();
+  // ---------------------------------------------------------------- layers 2, 3 (K = W)
+#pragma unroll
+  for (int layer = 1; layer < 3; ++layer) {
+    init_acc(a.bias + layer * W, NRT);
+#pragma unroll
+    for (int c = 0; c < NRT; ++c) {
+      stage(buf ^ 1, (layer == 2 && c == NRT - 1) ? 8 : NRT);
+      compute(buf, NRT, 2, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
+      __syncthreads();
+      buf ^= 1;
+    }
+    epilogue();
+  }
+  // ---------------------------------------------------------------- k / v projections (256 outputs, no bias)
+  init_acc(nullptr, 8);
+#pragma unroll
+  for (int c = 0; c < NRT; ++c) {
+    if (c + 1 < NRT) stage(buf ^ 1, 8);
+    compute(buf, 8, 2, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
+    if (c + 1 < NRT) __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---------------------------------------------------------------- attention over the 8 neighbours of each sample
+  // acc[h] = k-projection of head h, acc[4+h] = v-projection; register r <-> dim i = (r&3) + 8*(r>>2) + 4*hh
+  const float inv_temp = 1.0f / 5.656854249492381f;
+  const float* qrow = a.Q + (size_t)nn * 128;
+  float att[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    float p = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 q4 = *(const float4*)(qrow + 32 * h + 8 * g + 4 * hh);
+      p = fmaf(q4.x * inv_temp, acc[h][4 * g], p);
+      p = fmaf(q4.y * inv_temp, acc[h][4 * g + 1], p);
+      p = fmaf(q4.z * inv_temp, acc[h][4 * g + 2], p);
+      p = fmaf(q4.w * inv_temp, acc[h][4 * g + 3], p);
+    }
+    p += __shfl_xor(p, 32, 64);
+    float mx = p;
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    const float e = expf(p - mx);
+    float sm = e;
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    att[h] = e / sm;
+  }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float o[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v = att[h] * acc[4 + h][4 * g + t];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        o[t] = v;
+      }
+      if (live && kk == 0) *(float4*)(a.O + (size_t)n * 128 + 32 * h + 8 * g + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- packing
+__device__ __forceinline__ unsigned short pf_f2bf(float x) {
+  unsigned int u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// Weight stream: L1 (10 chunks) | L2 (NRT) | L3 (NRT) | KV (NRT); chunk = [hi ks0][hi ks1][lo ks0][lo ks1], each
+// ORT x 64 lanes x 8 bf16 in A-fragment order (lane: out row = 32*rt + (lane&31), k slots 8*(lane>>5) + t).
+__global__ void pack_point_stream_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                         const float* __restrict__ wk, const float* __restrict__ wv, unsigned short* __restrict__ out,
+                                         int NRT, int F) {
+  const int W = 32 * NRT;
+  const long long per_l1 = (long long)L1_CHUNKS * 2 * NRT * 512, per_lw = (long long)NRT * 2 * NRT * 512, per_kv = (long long)NRT * 2 * 8 * 512;
+  const long long total = per_l1 + 2 * per_lw + per_kv;   // number of (k-step, rt, lane, t) elements
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int layer; long long r = e;
+  if (r < per_l1) layer = 0; else if ((r -= per_l1) < per_lw) layer = 1; else if ((r -= per_lw) < per_lw) layer = 2; else { r -= per_lw; layer = 3; }
+  const int ort = layer == 3 ? 8 : NRT;
+  const int t = (int)(r & 7), lane = (int)((r >> 3) & 63);
+  long long r2 = r >> 9;
+  const int rt = (int)(r2 % ort); r2 /= ort;
+  const int ks = (int)(r2 & 1), chunk = (int)(r2 >> 1);
+  const int q = 2 * chunk + ks, hh = lane >> 5, orow = 32 * rt + (lane & 31);
+  float v = 0.f;
+  if (layer == 0) {
+    int col = -1;
+    if (q < 13) { int c = 16 * q + 8 * hh + t; col = c < F ? c : -1; }
+    else if (q < 17) {
+      const int pi = 8 * (q - 13) + 4 * hh + (t >> 1), comp = t & 1;
+      if (pi < 30) { const int f = pi / 3, ax = pi - 3 * f; col = F + 3 + 6 * f + (comp ? 3 : 0) + ax; }
+      else if (pi == 30) col = F + comp;
+      else col = comp == 0 ? F + 2 : -1;
+    } else if (q < 19) { const int o = 16 * (q - 17) + 8 * hh + t; col = o < 27 ? F + 63 + o : -1; }
+    if (col >= 0) v = w1[(size_t)orow * (F + 90) + col];
+  } else {
+    const int fin = 32 * (q >> 1) + 16 * (q & 1) + (t & 3) + 8 * (t >> 2) + 4 * hh;
+    if (layer == 1) v = w2[(size_t)orow * W + fin];
+    else if (layer == 2) v = w3[(size_t)orow * W + fin];
+    else v = orow < 128 ? wk[(size_t)orow * W + fin] : wv[(size_t)(orow - 128) * W + fin];
+  }
+  // destination
+  long long chunk_base;   // in bf16 elements
+  const long long c_l = (long long)4 * NRT * 512, c_kv = (long long)4 * 8 * 512;
+  if (layer == 0) chunk_base = chunk * c_l;
+  else if (layer == 1) chunk_base = L1_CHUNKS * c_l + chunk * c_l;
+  else if (layer == 2) chunk_base = (L1_CHUNKS + NRT) * c_l + chunk * c_l;
+  else chunk_base = (L1_CHUNKS + 2 * NRT) * c_l + chunk * c_kv;
+  const long long in_chunk = ((long long)(ks * ort + rt) * 64 + lane) * 8 + t;
+  const unsigned short h = pf_f2bf(v);
+  const float hf = __uint_as_float(((unsigned int)h) << 16);
+  out[chunk_base + in_chunk] = h;
+  out[chunk_base + (long long)2 * ort * 512 + in_chunk] = pf_f2bf(v - hf);
+}
+
+// support feature table (M, F) fp32 -> bf16 hi / lo [M][208] (zero padded)
+__global__ void split_feature_table_kernel(const float* __restrict__ src, int M, int F, unsigned short* __restrict__ hi,
+                                           unsigned short* __restrict__ lo) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)M * 208) return;
+  const int c = (int)(e % 208);
+  const long long m = e / 208;
+  const float v = c < F ? src[m * F + c] : 0.f;
+  const unsigned short h = pf_f2bf(v);
+  hi[e] = h;
+  lo[e] = pf_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+}
+
+// sum_k of the normalised aggregation weights (model.py:419-427 with correlation == 1/K), one lane per sample
+__global__ void wscale_kernel(const int* __restrict__ idx, const float* __restrict__ d2, const float* __restrict__ conf, int N, int K,
+                              int M, float* __restrict__ wscale) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float w[NL_KNN_MAX_K];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NL_KNN_MAX_K; ++k) {
+    w[k] = 0.f;
+    if (k < K) {
+      const float dist = sqrtf(d2[(size_t)n * K + k]);
+      const float c = k < M ? conf[idx[(size_t)n * K + k]] : 0.f;
+      float x = 1.f / fmaxf(dist, 1e-8f);
+      x = x * (1.f / (float)K);
+      x = x * c;
+      w[k] = x;
+      sum += x;
+    }
+  }
+  const float den = fmaxf(sum, 1e-8f);
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < NL_KNN_MAX_K; ++k) tot += w[k] / den;
+  wscale[n] = tot;
+}
+
+}  // namespace
+
+size_t nl_point_stream_bytes(int W) {
+  const int NRT = W / 32;
+  return ((size_t)(L1_CHUNKS + 2 * NRT) * 4 * NRT + (size_t)NRT * 32) * 1024;
+}
+
+int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F,
+                         hipStream_t st) {
+  const int NRT = W / 32;
+  const long long total = (long long)L1_CHUNKS * 2 * NRT * 512 + 2LL * NRT * 2 * NRT * 512 + (long long)NRT * 2 * 8 * 512;
+  hipLaunchKernelGGL(pack_point_stream_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv,
+                     (unsigned short*)out, NRT, F);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_split_feature_table(const float* src, int64_t M, int F, void* hi, void* lo, hipStream_t st) {
+  if (M <= 0) return NL_OK;
+  if (F > 208) return NL_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(split_feature_table_kernel, dim3((unsigned)nl_cdiv(M * 208, 256)), dim3(256), 0, st, src, (int)M, F,
+                     (unsigned short*)hi, (unsigned short*)lo);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_wscale(const int* idx, const float* d2, const float* conf, int64_t N, int K, int64_t M, float* wscale, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(wscale_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, idx, d2, conf, (int)N, K,
+                     (int)(M > 0x7fffffff ? 0x7fffffff : M), wscale);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+bool nl_point_fused_supported(int W, int precision) {
+  return precision != NL_PREC_F32 && (W == 64 || W == 128 || W == 256);
+}
+
+int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipStream_t st) {
+  if (a.N <= 0) return NL_OK;
+  dim3 grid((unsigned)nl_cdiv(a.N, 16));
+  const bool x3 = precision == NL_PREC_BF16X3;
+#define NL_PF(NRT)                                                                                           \
+  do {                                                                                                       \
+    if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a);                  \
+    else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a);                    \
+  } while (0)
+  if (W == 256) NL_PF(8);
+  else if (W == 128) NL_PF(4);
+  else if (W == 64) NL_PF(2);
+  else return NL_ERR_UNSUPPORTED;
+#undef NL_PF
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
