@@ -24,7 +24,7 @@ int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const fl
 int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
-int nl_launch_blend(const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
+int nl_launch_blend(const float* hA, const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
                         int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st);
 
@@ -79,7 +79,7 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLEND0, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDB, G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -125,7 +125,10 @@ Layout make_layout(const nl_config* c) {
   set(G_CONVOUT, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
   set(G_FEAT2, W, C, true);
-  set(G_BLEND0, W + F + 5, 32, true);
+  // colour-blend layer 1 split by linearity: per-sample part (feature_agg) + per-(sample,view) part ([rgb_feat | vis,angle]);
+  // the latter's two sources are padded to multiples of 4 in K-space: 196 + 8
+  set(G_BLENDA, W, 32, false);
+  set(G_BLENDB, (int)nl_align_up(F, 4) + 8, 32, true);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
   for (int i = 0; i < G_COUNT; ++i) {
@@ -242,7 +245,7 @@ struct Bump {
 struct MvBufs { float *vis, *dd, *g393, *t64; };
 struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; };
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
-struct HdBufs { float *sigma, *fth, *ft, *bl1, *rgb_s; };
+struct HdBufs { float *sigma, *fth, *ft, *blA, *bl1, *rgb_s; };
 
 constexpr int LDG = 396, LDX = 288;
 
@@ -275,7 +278,7 @@ void carve_un(Bump& b, const nl_config* c, int64_t R, UnBufs& u) {
 void carve_hd(Bump& b, const nl_config* c, int V, int64_t R, HdBufs& h) {
   const size_t N = (size_t)R * c->S;
   h.sigma = b.take<float>(N); h.fth = b.take<float>(N * c->W); h.ft = b.take<float>(N * c->C);
-  h.bl1 = b.take<float>(N * V * 32); h.rgb_s = b.take<float>(N * 3);
+  h.blA = b.take<float>(N * 32); h.bl1 = b.take<float>(N * V * 32); h.rgb_s = b.take<float>(N * 3);
 }
 
 struct RenderBufs {
@@ -308,10 +311,11 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   for (int i = 0; i < nseg; ++i) {
     a.seg[i].ptr = segs[i].ptr; a.seg[i].ld = segs[i].ld; a.seg[i].k = segs[i].k; a.seg[i].ioff = segs[i].ioff;
     a.seg[i].rdiv = segs[i].rdiv > 0 ? segs[i].rdiv : 1;
-    ksum += segs[i].k;
+    a.seg[i].vec = ((((size_t)segs[i].ptr) & 15) == 0 && (segs[i].ld & 3) == 0) ? 1 : 0;
+    ksum += (segs[i].k + 3) & ~3;   // every segment occupies round_up(k, 4) slots of K-space
   }
   const GemmDim& d = x.L.g[g];
-  if (ksum != d.K) return NL_ERR_BAD_ARG;
+  if (ksum != ((d.K + 3) & ~3)) return NL_ERR_BAD_ARG;
   a.nseg = nseg; a.M = (int)M; a.K = d.K; a.N = d.N; a.Kpad = d.Kpad; a.Npad = d.Npad;
   if (x.c->precision == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
   else { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; }
@@ -438,9 +442,11 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
     SegSpec s1{h.fth, W, W, 0, 1};
     NL_TRY(run_gemm(x, G_FEAT2, &s1, 1, N, h.ft, C, NL_ACT_NONE));
   }
-  SegSpec sb[3] = {{FA, W, W, 0, V}, {rgb_feat, NL_FPAD, F, 0, 1}, {vis_ang, 8, 5, 0, 1}};
-  NL_TRY(run_gemm(x, G_BLEND0, sb, 3, N * V, h.bl1, 32, NL_ACT_LRELU));
-  NL_TRY(nl_launch_blend(h.bl1, rgb_feat, vis_ang, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
+  SegSpec sa{FA, W, W, 0, 1};
+  NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
+  SegSpec sb[2] = {{rgb_feat, NL_FPAD, F, 0, 1}, {vis_ang, 8, 5, 0, 1}};
+  NL_TRY(run_gemm(x, G_BLENDB, sb, 2, N * V, h.bl1, 32, NL_ACT_NONE));
+  NL_TRY(nl_launch_blend(h.blA, h.bl1, rgb_feat, vis_ang, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
                          x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.ft : nullptr, valid_s, R, S, C, white, out, ray0, x.st));
   if (out->sigma) NL_CHECK_HIP(hipMemcpyAsync(out->sigma + ray0 * S, h.sigma, sizeof(float) * N, hipMemcpyDeviceToDevice, x.st));
@@ -520,7 +526,10 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   }
   P.linear(G_FEAT0, t[T_F0W], t[T_F0B]);
   P.linear(G_FEAT2, t[T_F2W], t[T_F2B]);
-  P.linear(G_BLEND0, t[T_BL0W], t[T_BL0B]);
+  P.block(G_BLENDA, 0, t[T_BL0W], 0, W + F + 5, 1, W);
+  P.block(G_BLENDB, 0, t[T_BL0W], W, W + F + 5, 1, F);
+  P.block(G_BLENDB, (int)nl_align_up(F, 4), t[T_BL0W], W + F, W + F + 5, 1, 5);
+  P.copy(t[T_BL0B], L.bias[G_BLENDB], 32);
   // small VALU-side weights
   P.copy(t[T_RD0W], L.rd_w, 64); P.copy(t[T_RD0B], L.rd_w + 4 * 64, 16);
   P.copy(t[T_RD2W], L.rd_w + 4 * 80, 27 * 16); P.copy(t[T_RD2B], L.rd_w + 4 * (80 + 432), 27);

@@ -73,11 +73,12 @@ struct NlGemmSeg {
   int k;             // columns taken from this source
   int ioff;          // conv tap offset along the ray (row-mapped modes)
   int rdiv;          // plain mode: source row = m / rdiv (row broadcast), >=1
+  int vec;           // 1: rows are 16-B aligned (ptr, ld) so 4 consecutive k may be fetched with one float4 load
 };
 struct NlGemmArgs {
   NlGemmSeg seg[NL_GEMM_MAX_SEG];
   int nseg;
-  int M, K, N;          // output rows (compute index space), total K, output columns
+  int M, K, N;          // output rows (compute index space), total PADDED K (each segment rounded up to 4), output columns
   int Kpad, Npad;       // padded sizes of B
   const void* B;        // packed weights: f32 [Kpad][Npad]  or bf16 hi/lo [Npad][Kpad] (see pack.hip)
   const void* Blo;      // bf16x3 only

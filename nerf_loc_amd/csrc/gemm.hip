@@ -51,18 +51,36 @@ __device__ __forceinline__ RowMap map_row(const NlGemmArgs& a, int m, int rdiv) 
   return r;
 }
 
-__device__ __forceinline__ float load_a(const NlGemmArgs& a, const RowMap& rm, int s, int kin) {
-  // s = segment, kin = column inside the segment (already validated: s >= 0)
+// 4 consecutive k of one segment for one output row (zero beyond the segment / outside the ray)
+__device__ __forceinline__ float4 load_a4(const NlGemmArgs& a, const RowMap& rm, int s, int kin) {
   const NlGemmSeg& sg = a.seg[s];
   int row;
   if (a.So > 0) {
     int i = rm.t + sg.ioff;
-    if (i < 0 || i >= a.Li) return 0.f;
+    if (i < 0 || i >= a.Li) return make_float4(0.f, 0.f, 0.f, 0.f);
     row = rm.base + i;
   } else {
     row = sg.rdiv > 1 ? rm.mdiv : rm.base;
   }
-  return sg.ptr[(size_t)row * sg.ld + kin];
+  const float* p = sg.ptr + (size_t)row * sg.ld + kin;
+  if (sg.vec && kin + 3 < sg.k) return *(const float4*)p;
+  float4 v;
+  v.x = kin + 0 < sg.k ? p[0] : 0.f;
+  v.y = kin + 1 < sg.k ? p[1] : 0.f;
+  v.z = kin + 2 < sg.k ? p[2] : 0.f;
+  v.w = kin + 3 < sg.k ? p[3] : 0.f;
+  return v;
+}
+
+// segment of padded-K position kg (every segment occupies round_up(k,4) slots) -> (segment, offset) or -1
+__device__ __forceinline__ int find_seg(const NlGemmArgs& a, int kg, int& kin) {
+  int s = -1, acc = 0;
+  for (int j = 0; j < a.nseg; ++j) {
+    const int kp = (a.seg[j].k + 3) & ~3;
+    if (s < 0 && kg < acc + kp) { s = j; kin = kg - acc; }
+    acc += kp;
+  }
+  return s;
 }
 
 __device__ __forceinline__ int out_row(const NlGemmArgs& a, int m) {
@@ -81,28 +99,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const NlGemmArgs a) {
   __shared__ float Bs[BK][BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kk_a = tid & 31, row_a = tid >> 5;  // this thread stages A[row_a + 8*i][kk_a]
+  const int k4_a = (tid & 7) * 4, row_a = tid >> 3;  // this thread stages A[row_a + 32*i][k4_a .. k4_a+3]
   int rdiv = 1;
   for (int s = 0; s < a.nseg; ++s) rdiv = a.seg[s].rdiv > rdiv ? a.seg[s].rdiv : rdiv;
 
-  RowMap rm[16];
+  RowMap rm[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) rm[i] = map_row(a, m0 + row_a + 8 * i, rdiv);
+  for (int i = 0; i < 4; ++i) rm[i] = map_row(a, m0 + row_a + 32 * i, rdiv);
 
   constexpr int NB4 = BN / 32;  // float4 B loads per thread per tile
   const float* Bg = (const float*)a.B;
-  float areg[16];
+  float4 areg[4];
   float4 breg[NB4];
 
   auto prefetch = [&](int k0) {
-    int kg = k0 + kk_a;
-    int s = -1, kin = 0, acc = 0;
-    for (int j = 0; j < a.nseg; ++j) {
-      if (s < 0 && kg < acc + a.seg[j].k) { s = j; kin = kg - acc; }
-      acc += a.seg[j].k;
-    }
+    int kin = 0;
+    const int s = find_seg(a, k0 + k4_a, kin);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a(a, rm[i], s, kin) : 0.f;
+    for (int i = 0; i < 4; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a4(a, rm[i], s, kin) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < NB4; ++j) {
       int idx = tid + 256 * j;
@@ -121,7 +135,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const NlGemmArgs a) {
   prefetch(0);
   for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) As[kk_a][row_a + 8 * i] = areg[i];
+    for (int i = 0; i < 4; ++i) {
+      As[k4_a + 0][row_a + 32 * i] = areg[i].x; As[k4_a + 1][row_a + 32 * i] = areg[i].y;
+      As[k4_a + 2][row_a + 32 * i] = areg[i].z; As[k4_a + 3][row_a + 32 * i] = areg[i].w;
+    }
 #pragma unroll
     for (int j = 0; j < NB4; ++j) {
       int idx = tid + 256 * j;
@@ -173,29 +190,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const NlGemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short Bl[X3 ? BN * LDS_ROW : 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kk_a = tid & 31, row_a = tid >> 5;
+  const int k4_a = (tid & 7) * 4, row_a = tid >> 3;
   int rdiv = 1;
   for (int s = 0; s < a.nseg; ++s) rdiv = a.seg[s].rdiv > rdiv ? a.seg[s].rdiv : rdiv;
-  RowMap rm[16];
+  RowMap rm[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) rm[i] = map_row(a, m0 + row_a + 8 * i, rdiv);
+  for (int i = 0; i < 4; ++i) rm[i] = map_row(a, m0 + row_a + 32 * i, rdiv);
 
   // B: packed [Npad][Kpad] bf16 (k contiguous). Tile = BN rows x 32 k = BN*64 B -> BN*4 16-B chunks / 256 thr
   constexpr int NBC = BN / 64;  // 16-B chunks per thread (BN=64 -> 1, 128 -> 2, 256 -> 4); BN=32 handled below
   const unsigned short* Bgh = (const unsigned short*)a.B;
   const unsigned short* Bgl = (const unsigned short*)a.Blo;
-  float areg[16];
+  float4 areg[4];
   uint4 bh[NBC > 0 ? NBC : 1], bl[NBC > 0 ? NBC : 1];
 
   auto prefetch = [&](int k0) {
-    int kg = k0 + kk_a;
-    int s = -1, kin = 0, accn = 0;
-    for (int j = 0; j < a.nseg; ++j) {
-      if (s < 0 && kg < accn + a.seg[j].k) { s = j; kin = kg - accn; }
-      accn += a.seg[j].k;
-    }
+    int kin = 0;
+    const int s = find_seg(a, k0 + k4_a, kin);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a(a, rm[i], s, kin) : 0.f;
+    for (int i = 0; i < 4; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a4(a, rm[i], s, kin) : make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int NCH = (NBC > 0 ? NBC : 1);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -217,11 +230,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const NlGemmArgs a) {
   prefetch(0);
   for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = areg[i];
-      unsigned short h = f2bf(v);
-      Ah[(row_a + 8 * i) * LDS_ROW + kk_a] = h;
-      if (X3) Al[(row_a + 8 * i) * LDS_ROW + kk_a] = f2bf(v - bf2f(h));
+    for (int i = 0; i < 4; ++i) {
+      const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+      unsigned short h[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = f2bf(v[j]); l[j] = X3 ? f2bf(v[j] - bf2f(h[j])) : 0; }
+      uint2 ph = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      *(uint2*)&Ah[(row_a + 32 * i) * LDS_ROW + k4_a] = ph;
+      if (X3) {
+        uint2 pl = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+        *(uint2*)&Al[(row_a + 32 * i) * LDS_ROW + k4_a] = pl;
+      }
     }
     constexpr int NCH = (NBC > 0 ? NBC : 1);
 #pragma unroll

@@ -34,9 +34,9 @@ __global__ __launch_bounds__(256) void sigma_kernel(const float* __restrict__ ge
   if (lane == 0) sigma[n] = nl_softplus(s + b[0]);
 }
 
-// colour blending tail (model.py:535-538): h1 (N*V,32) [already LeakyReLU'd by the GEMM] -> 16 -> 1,
+// colour blending tail (model.py:535-538): layer 1 = LeakyReLU(hA[n] + h1[n,v]) (split by linearity) -> 16 -> 1,
 // masked_fill(vis == 0, -1e9), softmax over views, rgb = sum_v w_v * rgb_in.   One lane per sample.
-__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ h1, const float* __restrict__ rgb_feat,
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA, const float* __restrict__ h1, const float* __restrict__ rgb_feat,
                                                     const float* __restrict__ vis_ang, int N, int V,
                                                     const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
                                                     const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
@@ -45,13 +45,20 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ h1
   if (n >= N) return;
   float lg[NL_MAX_VIEWS];
   float mx = -3.4e38f;
+  float xa[32];   // per-sample part of layer 1 (feature_agg columns of rgb_blending_mlp.0)
+#pragma unroll
+  for (int i4 = 0; i4 < 8; ++i4) {
+    float4 t = *(const float4*)(hA + (size_t)n * 32 + 4 * i4);
+    xa[4 * i4] = t.x; xa[4 * i4 + 1] = t.y; xa[4 * i4 + 2] = t.z; xa[4 * i4 + 3] = t.w;
+  }
   for (int v = 0; v < V; ++v) {
     const float* h = h1 + ((size_t)n * V + v) * 32;
     float x[32];
 #pragma unroll
     for (int i4 = 0; i4 < 8; ++i4) {
       float4 t = *(const float4*)(h + 4 * i4);
-      x[4 * i4] = t.x; x[4 * i4 + 1] = t.y; x[4 * i4 + 2] = t.z; x[4 * i4 + 3] = t.w;
+      x[4 * i4] = nl_lrelu(xa[4 * i4] + t.x); x[4 * i4 + 1] = nl_lrelu(xa[4 * i4 + 1] + t.y);
+      x[4 * i4 + 2] = nl_lrelu(xa[4 * i4 + 2] + t.z); x[4 * i4 + 3] = nl_lrelu(xa[4 * i4 + 3] + t.w);
     }
     float o = b4[0];
 #pragma unroll
@@ -181,10 +188,10 @@ int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const fl
   return NL_OK;
 }
 
-int nl_launch_blend(const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2,
+int nl_launch_blend(const float* hA, const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2,
                     const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st) {
   if (N <= 0) return NL_OK;
-  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, h1, rgb_feat, vis_ang, (int)N, V, w2, b2, w4, b4, rgb_s);
+  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgb_feat, vis_ang, (int)N, V, w2, b2, w4, b4, rgb_s);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
