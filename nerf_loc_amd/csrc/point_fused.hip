@@ -18,6 +18,7 @@
 //   * Layer-1 operands are assembled in registers: pre-split bf16 feature rows are gathered with 16-B loads that
 //     are already B fragments; positional encoding / ray_diff_fc are computed per lane in fp32 and split.
 //   * One wave per SIMD (the kernel lives in the 512-register file): 128 accumulators + up to 152 operand regs.
+#include <utility>
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,11 +58,63 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
+// branch-free sin/cos in fp64 (|x| up to ~1e5): Cody-Waite reduction to [-pi/4, pi/4] + Taylor (error < 1e-11)
+__device__ __forceinline__ void sincos_d(double x, double& s, double& c) {
+  const double kd = rint(x * 0.63661977236758134308);
+  const int k = (int)kd;
+  double r = fma(-kd, 1.5707963267948966, x);
+  r = fma(-kd, 6.123233995736766e-17, r);
+  const double r2 = r * r;
+  const double ps = r + r * r2 * (-1.0 / 6 + r2 * (1.0 / 120 + r2 * (-1.0 / 5040 + r2 * (1.0 / 362880 + r2 * (-1.0 / 39916800)))));
+  const double pc = 1.0 + r2 * (-0.5 + r2 * (1.0 / 24 + r2 * (-1.0 / 720 + r2 * (1.0 / 40320 + r2 * (-1.0 / 3628800 + r2 * (1.0 / 479001600))))));
+  const bool sw = k & 1;
+  const double ss = sw ? pc : ps, cc = sw ? ps : pc;
+  s = (k & 2) ? -ss : ss;
+  c = ((k + 1) & 2) ? -cc : cc;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: every index is a constant expression
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+constexpr int NBUF = 4;   // LDS ring: chunk g lives in buffer g % 4, three chunks of LDS-DMA in flight
+
+// Pointers are direct __restrict__ kernel arguments (not struct members) so that wave-uniform weight reads
+// become scalar loads instead of occupying VGPRs.
+struct PfScalars { int dir_stride, dir_div, N, M; float inv_span; };
+struct PfView {   // what the body calls `a.` : plain locals, nothing escapes
+  const float* xyz; const float* dir; int dir_stride, dir_div; const int* idx; const float* Q; float* O;
+  const uint4* fhi; const uint4* flo; const float* sp_xyz; const float* sp_dir; const uint4* wstream;
+  const float* bias; const float* rd_w; int N, M; float inv_span;
+};
+
 template <int NRT, bool X3>
-__global__ __launch_bounds__(256, 1) void point_fused_kernel(const NlPointFusedArgs a) {
-  __shared__ uint4 lds[2][2048];   // 2 x 32 KB: [part hi/lo][k-step 0/1][row tile][lane] A fragments
+__global__ __launch_bounds__(256, 1) void point_fused_kernel(
+    const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
+    float* __restrict__ p_O, const uint4* __restrict__ p_fhi, const uint4* __restrict__ p_flo, const float* __restrict__ p_sp_xyz,
+    const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const float* __restrict__ p_bias,
+    const float* __restrict__ p_rd_w, const PfScalars sc) {
+  const float* __restrict__ rd_w = p_rd_w;
+  const PfView a = {p_xyz, p_dir, sc.dir_stride, sc.dir_div, p_idx, p_Q, p_O, p_fhi, p_flo, p_sp_xyz, p_sp_dir, p_wstream,
+                    p_bias, p_rd_w, sc.N, sc.M, sc.inv_span};
+  // ONE __shared__ object (a second one makes hipcc drain vmcnt(0) before every ds_read of an LDS-DMA pipeline):
+  // 4 x 32 KB ring of A fragments [part hi/lo][k-step 0/1][row tile][lane], then 3 KB of biases
+  __shared__ uint4 lds_all[NBUF * 2048 + 192];
+  uint4 (*lds)[2048] = reinterpret_cast<uint4 (*)[2048]>(lds_all);
+  float* sbias = reinterpret_cast<float*>(lds_all + NBUF * 2048);
   constexpr int W = 32 * NRT;
   constexpr int PARTS = X3 ? 2 : 1;
+  constexpr int NC = L1_CHUNKS + 3 * NRT;   // chunks of the whole chain: L1 | L2 | L3 | KV
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31, kk = j & 7;
   const int n = blockIdx.x * 16 + wave * 4 + (j >> 3);
@@ -69,98 +122,127 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(const NlPointFusedA
   const int nn = live ? n : a.N - 1;
   const char* wptr = (const char*)a.wstream;
 
-  // LDS-DMA one chunk (2 k-steps) of `ort` row tiles: global image == LDS image, hi parts first.
-  auto stage = [&](int buf, int ort) {
+  auto ort_of = [](int g) constexpr { return g < L1_CHUNKS + 2 * NRT ? NRT : 8; };
+  auto glds_of = [=](int g) constexpr { return g < NC ? PARTS * 2 * (g < L1_CHUNKS + 2 * NRT ? NRT : 8) / 4 : 0; };   // LDS-DMA instructions per wave
+  // LDS-DMA chunk g (2 k-steps): global image == LDS image, hi parts first.
+  auto stage = [&](int g) __attribute__((always_inline)) {
+    const int ort = ort_of(g);
     const int nkb = PARTS * 2 * ort;
-    for (int i = wave; i < nkb; i += 4) glds16(wptr + (size_t)i * 1024 + lane * 16, &lds[buf][i * 64]);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      if (jj < nkb / 4) { const int i = wave + 4 * jj; glds16(wptr + (size_t)i * 1024 + lane * 16, &lds[g % NBUF][i * 64]); }
+    }
     wptr += (size_t)4 * ort * 1024;
   };
-  stage(0, NRT);
 
   // ---------------------------------------------------------------- layer-1 operand fragments
+  // k-step order: 0-3 positional encoding, 4-5 ray_diff_fc, 6-18 gathered features
   bf16x8 fh[L1_KSTEPS + 1], fl[L1_KSTEPS + 1];
-  const int id = a.idx[(size_t)nn * 8 + kk];
-  const bool have = live && kk < a.M;   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
+  const bool have = live && kk < a.M && a.M > 0;
+  const int id = a.idx[(size_t)nn * 8 + kk];   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
   {
-    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const size_t rowb = (size_t)(have ? id : 0) * 26 + hh;   // always a valid row; zeroed below when !have
+    const unsigned keep = have ? 0xffffffffu : 0u;
 #pragma unroll
     for (int q = 0; q < 13; ++q) {
-      uint4 vh = have ? a.fhi[(size_t)id * 26 + 2 * q + hh] : z4;
-      fh[q] = __builtin_bit_cast(bf16x8, vh);
+      uint4 vh = a.fhi[rowb + 2 * q];
+      vh.x &= keep; vh.y &= keep; vh.z &= keep; vh.w &= keep;
+      fh[6 + q] = __builtin_bit_cast(bf16x8, vh);
       if (X3) {
-        uint4 vl = have ? a.flo[(size_t)id * 26 + 2 * q + hh] : z4;
-        fl[q] = __builtin_bit_cast(bf16x8, vl);
+        uint4 vl = a.flo[rowb + 2 * q];
+        vl.x &= keep; vl.y &= keep; vl.z &= keep; vl.w &= keep;
+        fl[6 + q] = __builtin_bit_cast(bf16x8, vl);
       }
     }
   }
+  for (int i = tid; i < 3 * W; i += 256) sbias[i] = a.bias[i];
+  __builtin_amdgcn_sched_barrier(0);
+  stage(0); stage(1); stage(2);
   {
     const float qx = a.xyz[3 * (size_t)nn], qy = a.xyz[3 * (size_t)nn + 1], qz = a.xyz[3 * (size_t)nn + 2];
     const float px = have ? a.sp_xyz[3 * (size_t)id] : 0.f, py = have ? a.sp_xyz[3 * (size_t)id + 1] : 0.f, pz = have ? a.sp_xyz[3 * (size_t)id + 2] : 0.f;
-    const float o0 = (qx - px) * a.inv_span, o1 = (qy - py) * a.inv_span, o2 = (qz - pz) * a.inv_span;
-    // positional encoding, 4 k-steps: slot pair (2*t2, 2*t2+1) of half hh in k-step 13+qs holds pair
-    // pi = 8*qs + 4*hh + t2:  pi<30 -> (sin, cos)(off[pi%3] * 2^(pi/3)); 30 -> (x, y); 31 -> (z, 0)
-#pragma unroll
-    for (int qs = 0; qs < 4; ++qs) {
-      float v[8];
-#pragma unroll
-      for (int t2 = 0; t2 < 4; ++t2) {
-        const int pi = 8 * qs + 4 * hh + t2;
-        const int f = pi / 3, ax = pi - 3 * f;
-        const float o = ax == 0 ? o0 : (ax == 1 ? o1 : o2);
-        float s, c;
-        sincosf(o * (float)(1 << (f < 10 ? f : 0)), &s, &c);
-        if (pi == 30) { s = o0; c = o1; }
-        if (pi == 31) { s = o2; c = 0.f; }
-        v[2 * t2] = s;
-        v[2 * t2 + 1] = c;
+    const float off[3] = {(qx - px) * a.inv_span, (qy - py) * a.inv_span, (qz - pz) * a.inv_span};
+    // ---- ray direction difference (model.py:396-399) -> ray_diff_fc (model.py:36-39): k-steps 4, 5
+    {
+      const size_t dr = (size_t)(nn / a.dir_div) * a.dir_stride;
+      float dx, dy, dz;
+      if (a.dir) { dx = a.dir[dr]; dy = a.dir[dr + 1]; dz = a.dir[dr + 2]; }
+      else {
+        const int i0 = a.idx[(size_t)nn * 8];
+        const bool ok = live && a.M > 0;
+        dx = ok ? a.sp_dir[4 * (size_t)i0] : 0.f; dy = ok ? a.sp_dir[4 * (size_t)i0 + 1] : 0.f; dz = ok ? a.sp_dir[4 * (size_t)i0 + 2] : 0.f;
       }
-      split8<X3>(v, fh[13 + qs], fl[13 + qs]);
+      const float ndx = have ? a.sp_dir[4 * (size_t)id] : 0.f, ndy = have ? a.sp_dir[4 * (size_t)id + 1] : 0.f, ndz = have ? a.sp_dir[4 * (size_t)id + 2] : 0.f;
+      float r0 = dx - ndx, r1 = dy - ndy, r2 = dz - ndz;
+      const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2) + 1e-8f;
+      r0 /= nr; r1 /= nr; r2 /= nr;
+      const float r3 = dx * ndx + dy * ndy + dz * ndz;
+      float hid[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float s = rd_w[64 + i];
+        s = fmaf(rd_w[i * 4 + 0], r0, s); s = fmaf(rd_w[i * 4 + 1], r1, s);
+        s = fmaf(rd_w[i * 4 + 2], r2, s); s = fmaf(rd_w[i * 4 + 3], r3, s);
+        hid[i] = nl_lrelu(s);
+      }
+      // outputs with wave-uniform (scalar-loaded) weights; each half keeps its 8 of every 16 slots
+      const float* __restrict__ w2 = rd_w + 80;
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          float r[2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int o = 16 * qs + 8 * h2 + t;
+            if (o < 27) {
+              float s = w2[27 * 16 + o];
+#pragma unroll
+              for (int i = 0; i < 16; ++i) s = fmaf(w2[o * 16 + i], hid[i], s);
+              r[h2] = nl_lrelu(s);
+            } else r[h2] = 0.f;
+          }
+          v[t] = hh ? r[1] : r[0];
+        }
+        split8<X3>(v, fh[4 + qs], fl[4 + qs]);
+      }
     }
-    // ray direction difference (model.py:396-399) -> ray_diff_fc (model.py:36-39), 2 k-steps
-    const size_t dr = (size_t)(nn / a.dir_div) * a.dir_stride;
-    float dx, dy, dz;
-    if (a.dir) { dx = a.dir[dr]; dy = a.dir[dr + 1]; dz = a.dir[dr + 2]; }
-    else {
-      const int i0 = a.idx[(size_t)nn * 8];
-      const bool ok = live && a.M > 0;
-      dx = ok ? a.sp_dir[4 * (size_t)i0] : 0.f; dy = ok ? a.sp_dir[4 * (size_t)i0 + 1] : 0.f; dz = ok ? a.sp_dir[4 * (size_t)i0 + 2] : 0.f;
-    }
-    const float ndx = have ? a.sp_dir[4 * (size_t)id] : 0.f, ndy = have ? a.sp_dir[4 * (size_t)id + 1] : 0.f, ndz = have ? a.sp_dir[4 * (size_t)id + 2] : 0.f;
-    float r0 = dx - ndx, r1 = dy - ndy, r2 = dz - ndz;
-    const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2) + 1e-8f;
-    r0 /= nr; r1 /= nr; r2 /= nr;
-    const float r3 = dx * ndx + dy * ndy + dz * ndz;
-    float hid[16];
+    // ---- positional encoding (utils.py:5-35): sin/cos(off * 2^f), f = 0..9: k-steps 0..3.
+    // Octaves come from the double-angle recurrence in fp64 started from one accurate evaluation per axis (abs
+    // error < 1e-12, i.e. correctly rounded in fp32).  Pair order is axis-major, pi = 10*axis + f, so the
+    // recurrence streams straight into fragments: slot pair (2*t2, 2*t2+1) of half hh in k-step qs holds pair
+    // pi = 8*qs + 4*hh + t2;  pi = 30 -> (x, y);  pi = 31 -> (z, 0).
+    {
+      double s = 0.0, c = 1.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float s = a.rd_w[64 + i];
-      s = fmaf(a.rd_w[i * 4 + 0], r0, s); s = fmaf(a.rd_w[i * 4 + 1], r1, s);
-      s = fmaf(a.rd_w[i * 4 + 2], r2, s); s = fmaf(a.rd_w[i * 4 + 3], r3, s);
-      hid[i] = nl_lrelu(s);
-    }
-    // all 27 outputs with wave-uniform (scalar-loaded) weights, then each half picks its 16 k-slots
-    const float* w2 = a.rd_w + 80;
-    float ro[32];
+      for (int qs = 0; qs < 4; ++qs) {
+        float v0[8], v1[8];   // candidates for hh = 0 / 1
 #pragma unroll
-    for (int o = 0; o < 32; ++o) {
-      if (o < 27) {
-        float s = w2[27 * 16 + o];
+        for (int u = 0; u < 8; ++u) {
+          const int pi = 8 * qs + u;
+          float ps, pc;
+          if (pi < 30) {
+            const int ax = pi / 10, f = pi - 10 * ax;
+            if (f == 0) sincos_d((double)off[ax], s, c);
+            ps = (float)s; pc = (float)c;
+            const double s2 = 2.0 * s * c;
+            c = fma(-2.0 * s, s, 1.0);
+            s = s2;
+          } else if (pi == 30) { ps = off[0]; pc = off[1]; }
+          else { ps = off[2]; pc = 0.f; }
+          if (u < 4) { v0[2 * u] = ps; v0[2 * u + 1] = pc; } else { v1[2 * (u - 4)] = ps; v1[2 * (u - 4) + 1] = pc; }
+        }
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s = fmaf(w2[o * 16 + i], hid[i], s);
-        ro[o] = nl_lrelu(s);
-      } else ro[o] = 0.f;
-    }
-#pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      float v[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = hh ? ro[16 * qs + 8 + t] : ro[16 * qs + t];
-      split8<X3>(v, fh[17 + qs], fl[17 + qs]);
+        for (int t = 0; t < 8; ++t) v[t] = hh ? v1[t] : v0[t];
+        split8<X3>(v, fh[qs], fl[qs]);
+      }
     }
   }
 
   f32x16 acc[8];
-  auto init_acc = [&](const float* bias, int ort) {
+  auto init_acc = [&](const float* bias, int ort) __attribute__((always_inline)) {   // bias lives in LDS
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt)
       if (rt < ort) {
@@ -172,31 +254,37 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(const NlPointFusedA
       }
   };
 
-  // one chunk: up to 2 k-steps x ort row tiles x (3 | 1) MFMAs
-  auto compute = [&](int buf, int ort, int nks, const bf16x8& bh0, const bf16x8& bl0, const bf16x8& bh1, const bf16x8& bl1) {
+  // one chunk: up to 2 k-steps x ort row tiles x (3 | 1) MFMAs.  A fragments are read from LDS two row tiles
+  // ahead of their MFMAs and the scheduler is fenced per row tile, so at most 3 fragment pairs are live.
+  auto compute = [&](int buf, int ort, int nks, const bf16x8 bh0, const bf16x8 bl0, const bf16x8 bh1, const bf16x8 bl1) __attribute__((always_inline)) {
+    const int nt = nks * ort;   // (k-step, row tile) pairs in issue order: t = ks * ort + rt
+    auto ldA = [&](int t, bf16x8& ah, bf16x8& al) __attribute__((always_inline)) {
+      const int ks = t / ort, rt = t - ks * ort;
+      ah = __builtin_bit_cast(bf16x8, lds[buf][((0 * 2 + ks) * ort + rt) * 64 + lane]);
+      if (X3) al = __builtin_bit_cast(bf16x8, lds[buf][((1 * 2 + ks) * ort + rt) * 64 + lane]);
+    };
+    bf16x8 ah[3], al[3];
+    ldA(0, ah[0], al[0]);
+    if (nt > 1) ldA(1, ah[1], al[1]);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks < nks) {
+    for (int t = 0; t < 16; ++t) {
+      if (t < nt) {
+        if (t + 2 < nt) ldA(t + 2, ah[(t + 2) % 3], al[(t + 2) % 3]);
+        const int ks = t / ort, rt = t - ks * ort;
         const bf16x8 bh = ks ? bh1 : bh0;
         const bf16x8 bl = ks ? bl1 : bl0;
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
-          if (rt < ort) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, lds[buf][((0 * 2 + ks) * ort + rt) * 64 + lane]);
-            if (X3) {
-              const bf16x8 al = __builtin_bit_cast(bf16x8, lds[buf][((1 * 2 + ks) * ort + rt) * 64 + lane]);
-              acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rt], 0, 0, 0);
-              acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rt], 0, 0, 0);
-            }
-            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rt], 0, 0, 0);
-          }
+        if (X3) {
+          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t % 3], bh, acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t % 3], bl, acc[rt], 0, 0, 0);
         }
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t % 3], bh, acc[rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
 
   // LeakyReLU + bf16 split of the finished layer: C/D registers -> next layer's B fragments
-  auto epilogue = [&]() {
+  auto epilogue = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -208,40 +296,24 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(const NlPointFusedA
       }
   };
 
-  // ---------------------------------------------------------------- layer 1 (K = 304)
-  init_acc(a.bias, NRT);
-  __syncthreads();
-  int buf = 0;
-#pragma unroll
-  for (int c = 0; c < L1_CHUNKS; ++c) {
-    stage(buf ^ 1, NRT);   // next chunk (chunk L1_CHUNKS == first chunk of layer 2, same geometry)
-    compute(buf, NRT, (2 * c + 1 < L1_KSTEPS) ? 2 : 1, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
-    __syncthreads();
-    buf ^= 1;
-  }
-  epilogue();
-  // ---------------------------------------------------------------- layers 2, 3 (K = W)
-#pragma unroll
-  for (int layer = 1; layer < 3; ++layer) {
-    init_acc(a.bias + layer * W, NRT);
-#pragma unroll
-    for (int c = 0; c < NRT; ++c) {
-      stage(buf ^ 1, (layer == 2 && c == NRT - 1) ? 8 : NRT);
-      compute(buf, NRT, 2, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
-      __syncthreads();
-      buf ^= 1;
+  // ---------------------------------------------------------------- the whole chain as one chunk pipeline
+  static_for<NC>([&](auto G) __attribute__((always_inline)) {
+    constexpr int g = decltype(G)::value;
+    // chunk g must have landed: only the LDS-DMA of chunks g+1, g+2 (issued later) may still be in flight
+    wait_vmcnt<glds_of(g + 1) + glds_of(g + 2)>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (g + 3 < NC) stage(g + 3);   // its buffer held chunk g-1, which every wave finished before the barrier
+    if constexpr (g == 0) init_acc(sbias, NRT);
+    constexpr int layer = g < L1_CHUNKS ? 0 : (g - L1_CHUNKS) / NRT + 1;
+    constexpr int c = g < L1_CHUNKS ? g : (g - L1_CHUNKS) % NRT;
+    constexpr int nks = (layer == 0 && 2 * c + 1 >= L1_KSTEPS) ? 1 : 2;
+    compute(g % NBUF, ort_of(g), nks, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
+    constexpr bool last = layer == 0 ? (c == L1_CHUNKS - 1) : (c == NRT - 1);
+    if constexpr (last && layer < 3) {
+      epilogue();
+      if constexpr (layer < 2) init_acc(sbias + (layer + 1) * W, NRT); else init_acc(nullptr, 8);
     }
-    epilogue();
-  }
-  // ---------------------------------------------------------------- k / v projections (256 outputs, no bias)
-  init_acc(nullptr, 8);
-#pragma unroll
-  for (int c = 0; c < NRT; ++c) {
-    if (c + 1 < NRT) stage(buf ^ 1, 8);
-    compute(buf, 8, 2, fh[2 * c], fl[2 * c], fh[2 * c + 1], fl[2 * c + 1]);
-    if (c + 1 < NRT) __syncthreads();
-    buf ^= 1;
-  }
+  });
 
   // ---------------------------------------------------------------- attention over the 8 neighbours of each sample
   // acc[h] = k-projection of head h, acc[4+h] = v-projection; register r <-> dim i = (r&3) + 8*(r>>2) + 4*hh
@@ -309,15 +381,15 @@ __global__ void pack_point_stream_kernel(const float* __restrict__ w1, const flo
   const int ks = (int)(r2 & 1), chunk = (int)(r2 >> 1);
   const int q = 2 * chunk + ks, hh = lane >> 5, orow = 32 * rt + (lane & 31);
   float v = 0.f;
-  if (layer == 0) {
+  if (layer == 0) {   // k-steps 0-3 positional encoding, 4-5 ray_diff_fc, 6-18 features (zero beyond)
     int col = -1;
-    if (q < 13) { int c = 16 * q + 8 * hh + t; col = c < F ? c : -1; }
-    else if (q < 17) {
-      const int pi = 8 * (q - 13) + 4 * hh + (t >> 1), comp = t & 1;
-      if (pi < 30) { const int f = pi / 3, ax = pi - 3 * f; col = F + 3 + 6 * f + (comp ? 3 : 0) + ax; }
+    if (q < 4) {
+      const int pi = 8 * q + 4 * hh + (t >> 1), comp = t & 1;
+      if (pi < 30) { const int ax = pi / 10, f = pi - 10 * ax; col = F + 3 + 6 * f + (comp ? 3 : 0) + ax; }
       else if (pi == 30) col = F + comp;
       else col = comp == 0 ? F + 2 : -1;
-    } else if (q < 19) { const int o = 16 * (q - 17) + 8 * hh + t; col = o < 27 ? F + 63 + o : -1; }
+    } else if (q < 6) { const int o = 16 * (q - 4) + 8 * hh + t; col = o < 27 ? F + 63 + o : -1; }
+    else if (q < 19) { int c = 16 * (q - 6) + 8 * hh + t; col = c < F ? c : -1; }
     if (col >= 0) v = w1[(size_t)orow * (F + 90) + col];
   } else {
     const int fin = 32 * (q >> 1) + 16 * (q & 1) + (t & 3) + 8 * (t >> 2) + 4 * hh;
@@ -423,8 +495,11 @@ int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipSt
   const bool x3 = precision == NL_PREC_BF16X3;
 #define NL_PF(NRT)                                                                                           \
   do {                                                                                                       \
-    if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a);                  \
-    else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a);                    \
+    const PfScalars sc{a.dir_stride, a.dir_div, a.N, a.M, a.inv_span};                                       \
+    if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.fhi, a.flo, \
+                               a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                           \
+    else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.fhi, a.flo, \
+                            a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                              \
   } while (0)
   if (W == 256) NL_PF(8);
   else if (W == 128) NL_PF(4);
