@@ -150,11 +150,12 @@ int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const fl
                        const float* geo, const float* rgb_feat, const float* vis_ang, const int32_t* valid_s,
                        int64_t R, int white_bkgd, const nl_render_out* out, void* ws, size_t ws_bytes, void* stream);
 
-/* a20 (hierarchical): coarse NeuRay weights (R,Sc) for z_coarse (R,Sc) along un-normalised K^-1[u,v,1] rays.
- * query_cam HOST 12+9 floats: inv(pose)[:3] (3x4) then inv(K) (3x3). */
+/* a20 (hierarchical): coarse NeuRay weights (R,Sc) for z_coarse (R,Sc) along un-normalised K^-1[u,v,1] rays, Sc <= 64.
+ * query_w2c_kinv HOST 12+9 floats: inv(pose)[:3] (3x4 row-major) then inv(K) (3x3). */
+size_t nl_coarse_weights_workspace_bytes(int V, int64_t R, int Sc);
 int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_w2c_kinv,
                       const float* pixel_coordinates, const float* z_coarse, int64_t R, int Sc, float* weights,
-                      float* depth_coarse, void* stream);
+                      float* depth_coarse, void* ws, size_t ws_bytes, void* stream);
 /* inverse-CDF sampling with caller-provided uniforms u (R,Ni), merged with z_base (R,Sb) and sorted -> z_out (R,Sb+Ni). */
 int nl_sample_pdf(const float* z_coarse, const float* weights_coarse, int Sc, const float* u, int Ni,
                   const float* z_base, int Sb, int64_t R, float* z_out, void* stream);

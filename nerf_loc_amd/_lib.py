@@ -66,7 +66,8 @@ SYMBOLS = [
     ("nl_ray_unet", _I, [_CFG, _P, _P, _L, _P, _P, _Z, _P]),
     ("nl_heads_composite_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_heads_composite", _I, [_CFG, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P]),
-    ("nl_coarse_weights", _I, [_CFG, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    ("nl_coarse_weights_workspace_bytes", _Z, [_I, _L, _I]),
+    ("nl_coarse_weights", _I, [_CFG, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _Z, _P]),
     ("nl_sample_pdf", _I, [_P, _P, _I, _P, _I, _P, _I, _L, _P, _P]),
     ("nl_render_rays_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_render_rays_min_workspace_bytes", _Z, [_CFG, _I]),

@@ -25,6 +25,11 @@ int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
 int nl_launch_blend(const float* hA, const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
+int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const float* pix,
+                             const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask, float* weights,
+                             float* depth_coarse, hipStream_t st);
+int nl_launch_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R,
+                         float* z_out, hipStream_t st);
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
                         int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st);
 
@@ -725,11 +730,25 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
   return NL_OK;
 }
 
-int nl_coarse_weights(const nl_config*, const void*, const nl_frame*, const float*, const float*, const float*, int64_t, int, float*, float*, void*) {
-  return NL_ERR_UNSUPPORTED;
+size_t nl_coarse_weights_workspace_bytes(int V, int64_t R, int Sc) {
+  return 3 * nl_align_up((size_t)(V > 0 ? V : 1) * (R > 0 ? R : 1) * (Sc > 0 ? Sc : 1) * 4, 256);
 }
-int nl_sample_pdf(const float*, const float*, int, const float*, int, const float*, int, int64_t, float*, void*) {
-  return NL_ERR_UNSUPPORTED;
+
+int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* f, const float* w2c_kinv, const float* pix,
+                      const float* zc, int64_t R, int Sc, float* weights, float* depth_coarse, void* ws, size_t ws_bytes, void* stream) {
+  if (!cfg_ok(cfg) || !packed || !f || !w2c_kinv || !pix || !zc || !weights || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (ws_bytes < nl_coarse_weights_workspace_bytes(f->views.V, R, Sc)) return NL_ERR_WORKSPACE;
+  const size_t part = nl_align_up((size_t)f->views.V * R * Sc * 4, 256);
+  float* wa = (float*)ws; float* wv = (float*)((char*)ws + part); float* wm = (float*)((char*)ws + 2 * part);
+  const Layout L = make_layout(cfg);
+  return nl_launch_coarse_weights(f->views, w2c_kinv, f->visf_hwc, (const float*)((const char*)packed + L.dec_w), pix, zc, R, Sc, wa, wv, wm,
+                                  weights, depth_coarse, (hipStream_t)stream);
+}
+
+int nl_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R, float* z_out,
+                  void* stream) {
+  if (!zc || !wc || !u || !zb || !z_out || R < 0) return NL_ERR_BAD_ARG;
+  return nl_launch_sample_pdf(zc, wc, Sc, u, Ni, zb, Sb, R, z_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

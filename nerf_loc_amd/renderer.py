@@ -216,6 +216,30 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
+    def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64):
+        """a20: coarse NeuRay weights along the pixel rays -> inverse-CDF samples (uniforms `u` (R,Ni)) merged with
+        z_base (R,Sb) and sorted.  Returns (z_vals (R,Sb+Ni), depth_coarse (R,), weights_coarse (R,n_coarse))."""
+        self._ready()
+        dev = self.device
+        pix = _dev_f32(pixel_coordinates, dev)
+        zb = _dev_f32(z_base, dev)
+        uu = _dev_f32(u, dev)
+        R, Sb, Ni = pix.shape[0], zb.shape[1], uu.shape[1]
+        Kc = torch.as_tensor(K).detach().float().cpu()
+        Pc = torch.as_tensor(pose).detach().float().cpu()
+        cam = torch.cat([Pc[None].inverse()[0, :3].reshape(-1), torch.inverse(Kc).reshape(-1)]).contiguous()  # depth_fusion.py:19-26
+        t_lin = torch.linspace(0, 1, n_coarse)
+        zc = (torch.tensor(self.near) * (1 - t_lin) + torch.tensor(self.far) * t_lin).expand(R, n_coarse).contiguous().to(dev)  # model.py:489
+        wc = torch.empty(R, n_coarse, device=dev)
+        dc = torch.empty(R, device=dev)
+        zo = torch.empty(R, Sb + Ni, device=dev)
+        ws = self._workspace(self.lib.nl_coarse_weights_workspace_bytes(self.V, R, n_coarse))
+        L.check(self.lib.nl_coarse_weights(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, cam.data_ptr(), pix.data_ptr(), zc.data_ptr(),
+                                           R, n_coarse, wc.data_ptr(), dc.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_coarse_weights")
+        L.check(self.lib.nl_sample_pdf(zc.data_ptr(), wc.data_ptr(), n_coarse, uu.data_ptr(), Ni, zb.data_ptr(), Sb, R, zo.data_ptr(), self._stream()),
+                "nl_sample_pdf")
+        return zo, dc, wc
+
     def ray_unet(self, x):
         """x (R*S, W) sample-major -> geo (R*S, W)."""
         if not self._weights_loaded:

@@ -139,6 +139,29 @@ def test_descriptor_query_direction_falls_back_to_nearest_neighbour():
     assert rel_err(fa.cpu().numpy(), qd["feature_agg"].numpy()) < 5e-5
 
 
+def test_hierarchical_branch_matches_reference_golden():
+    """a20: coarse NeuRay weights -> sample_pdf (recipe uniforms) -> merge/sort -> render, vs the reference golden."""
+    from oracle import render_oracle as orc
+    cfg, _ = CASES["hier"]
+    case = build_case("hier")
+    g = load_golden("hier")
+    params, frame, rays = oracle_inputs(case)
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        zb = orc.sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, cfg.S).contiguous()
+        z, depth_coarse, wc = r.hierarchical_depths(case["rays"]["pixel_coordinates"], case["frame"]["K"], case["frame"]["pose"], zb, case["u"])
+        with torch.no_grad():
+            zc = orc.sample_depths(64, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, 64).contiguous()
+            wc_o = orc.predict_weights_from_neuray(params, frame, rays, zc)
+        assert rel_err(wc.cpu().numpy(), wc_o.numpy()) < 2e-5
+        assert rel_err(depth_coarse.cpu().numpy(), g["depth_coarse"]) < 2e-5
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], case["frame"]["pose"][:3, 3], z_vals=z, intermediates=True)
+        tol = TOL[precision] * 3   # z itself carries the coarse pass' rounding; still far inside 1e-3
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat", "sigma"):
+            assert rel_err(out[k].cpu().numpy(), g[k]) < tol, (precision, k, rel_err(out[k].cpu().numpy(), g[k]))
+        assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
+
+
 # ------------------------------------------------------------------ full-size (BASELINE config 2) properties
 @pytest.fixture(scope="module")
 def c2():
