@@ -64,11 +64,12 @@ typedef struct nl_config {
 
 /* Per-frame inputs (reference `data` dict, nerf_pose_estimator.py:255-290, plus the two module caches). */
 typedef struct nl_frame_desc {
-  int32_t V, H, Wimg, h, w;      /* support views, full-res image size, feature-map size (H/4, Wimg/4) */
+  int32_t V, H, Wimg, h, w;      /* support views, full-res image size, feature-map size (H/4 fine, H/8 coarse) */
+  int32_t vis_h, vis_w;          /* size of vis_featmaps (always H/4, Wimg/4: depth_fusion.py:239-282)     */
   float near_, far_;             /* data['depth_range'][0]                                             */
   const float* images;           /* (V,3,H,Wimg)   data['topk_images']                                 */
   const float* featmaps;         /* (V,h,w,C)      data['feat_fine_src'] (channels-last, as the reference stores it) */
-  const float* vis_featmaps;     /* (V,32,h,w)     multiview_aggregator.vis_featmaps                   */
+  const float* vis_featmaps;     /* (V,32,vis_h,vis_w) multiview_aggregator.vis_featmaps                */
   const float* proj_ibr;         /* HOST (V,3,4)   rows 0..2 of  K4 @ inv(c2w)   (ibrnet.py:183)       */
   const float* proj_neuray;      /* HOST (V,3,4)   K @ inv(c2w)[:3]             (depth_fusion.py:90)   */
   const float* cam_centers;      /* HOST (V,3)     c2w[:3,3]                    (ibrnet.py:159)        */

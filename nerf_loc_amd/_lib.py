@@ -29,6 +29,7 @@ class NlConfig(C.Structure):
 class NlFrameDesc(C.Structure):
     _fields_ = [
         ("V", C.c_int32), ("H", C.c_int32), ("Wimg", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("vis_h", C.c_int32), ("vis_w", C.c_int32),
         ("near_", C.c_float), ("far_", C.c_float),
         ("images", C.c_void_p), ("featmaps", C.c_void_p), ("vis_featmaps", C.c_void_p),
         ("proj_ibr", C.c_void_p), ("proj_neuray", C.c_void_p), ("cam_centers", C.c_void_p),

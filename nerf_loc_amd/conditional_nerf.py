@@ -1,0 +1,394 @@
+"""Drop-in replacement for `nerf_loc.models.conditional_nerf.model.ConditionalNeRF` (reference model.py:29-713).
+
+Same constructor (`ConditionalNeRF(args)` with the yacs field names of SURVEY.md §5), same public methods and return
+dicts, same mutable caches (`support_neural_points`, `multiview_aggregator.vis_featmaps`) and the same state_dict
+names/shapes, so `pl/model.py:33-41`-style checkpoint loading and
+`nerf_pose_estimator.py:150,316,365,379,445,465` call sites work unchanged.
+
+What runs where
+  * everything per ray / per sample (rows a2-a20 of SURVEY.md §8) runs in libnerfloc_render.so (HIP, gfx950) through
+    `HipRenderer`; there is NO PyTorch fallback for it — without the library or a GPU these methods raise.
+  * per-frame setup (row a21: back-projection, `DepthFusionNet`, `confidence_mlp`, `keypoint_head`) and the tiny
+    descriptor projections stay on PyTorch-ROCm, like the 2-D backbone (north_star).
+  * training-time pieces that need autograd through the renderer (`compute_render_loss`, `beta`) are "next rows"
+     and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .depth_fusion import DepthFusionNet
+from .renderer import HipRenderer
+
+
+# ----------------------------------------------------------------------------- parameter containers (names = reference)
+def _mlp(dims, act, last_act=None):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(act())
+    if last_act is not None:
+        layers.append(last_act())
+    return nn.Sequential(*layers)
+
+
+class _AddBias(nn.Module):
+    def __init__(self, v):
+        super().__init__()
+        self.v = v
+
+    def forward(self, x):
+        return x + self.v
+
+
+class MixtureLogisticsDistDecoder(nn.Module):
+    """Parameter container for visibility_decoder.py:53-97 (the arithmetic runs in mvagg.hip / hier.hip)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mean_decoder = _mlp([32, 32, 32, 2], nn.ELU, nn.Softplus)
+        self.var_decoder = nn.Sequential(*list(_mlp([32, 32, 32, 2], nn.ELU, nn.Softplus)), _AddBias(0.05))
+        self.aw_decoder = _mlp([32, 32, 32, 1], nn.ELU, nn.Sigmoid)
+        self.vis_decoder = _mlp([32, 32, 32, 1], nn.ELU, nn.Sigmoid)
+
+
+class MultiviewFeatureAggregator(nn.Module):
+    """multiview_aggregator.py:21-38: owns `depth_fusion` (PyTorch, per frame), `dist_decoder`, `out_fc` and the
+    `vis_featmaps` cache the caller resets every frame (nerf_pose_estimator.py:289-290)."""
+
+    def __init__(self, args, in_channels, out_channels, hidden_dim=64):
+        super().__init__()
+        self.args = args
+        self.depth_fusion = DepthFusionNet(in_channels=in_channels)
+        self.vis_featmaps = None
+        self.dist_decoder = MixtureLogisticsDistDecoder()
+        self.out_fc = nn.Sequential(nn.Linear((in_channels + 3) * 2 + 2 + 1, hidden_dim), nn.ELU(inplace=True),
+                                    nn.Linear(hidden_dim, out_channels), nn.ELU(inplace=True))
+
+    def compute_ref_depth_loss(self, *a, **k):
+        raise NotImplementedError("training loss through the HIP renderer is a next-row item (SURVEY.md §8f-2)")
+
+
+class _MHAParams(nn.Module):
+    """ibrnet/ibrnet.py:72-87 parameter names."""
+
+    def __init__(self, n_head, d_model, d_k, d_v):
+        super().__init__()
+        self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_ks = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_vs = nn.Linear(d_model, n_head * d_v, bias=False)
+        self.fc = nn.Linear(n_head * d_v, d_model, bias=False)
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+
+
+class _RayUnetParams(nn.Module):
+    """ray_unet.py:5-53 parameter names/shapes (Conv / ConvTranspose weights + LayerNorm([C,S]) affine)."""
+
+    def __init__(self, W, S):
+        super().__init__()
+
+        def blk(conv, c, s):
+            return nn.Sequential(conv, nn.LayerNorm([c, s]), nn.ELU(inplace=True))
+        self.conv1 = blk(nn.Conv1d(W, 64, 3, 1, padding=1), 64, S)
+        self.conv2 = blk(nn.Conv1d(64, 128, 3, 1, padding=1), 128, S // 2)
+        self.conv3 = blk(nn.Conv1d(128, 128, 3, 1, padding=1), 128, S // 4)
+        self.trans_conv3 = blk(nn.ConvTranspose1d(128, 128, 3, 2, padding=1, output_padding=1), 128, S // 4)
+        self.trans_conv2 = blk(nn.ConvTranspose1d(256, 64, 3, 2, padding=1, output_padding=1), 64, S // 2)
+        self.trans_conv1 = blk(nn.ConvTranspose1d(128, 32, 3, 2, padding=1, output_padding=1), 32, S)
+        self.conv_out = blk(nn.Conv1d(W + 32, W, 3, 1, padding=1), W, S)
+
+
+def get_rays(H, W, K, c2w):
+    """conditional_nerf/utils.py:56-70 (host-side torch, 'a1')."""
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+    i, j = i.t().to(K.device), j.t().to(K.device)
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], (j - K[1][2]) / K[1][1], torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    return c2w[:3, -1].expand(rays_d.shape), rays_d
+
+
+class ConditionalNeRF(nn.Module):
+    def __init__(self, args, activation_func=None, precision: str = "bf16x3", device: Optional[str] = None):
+        super().__init__()
+        self.args = copy.deepcopy(args)
+        C, W = args.backbone2d_fpn_dim, args.model_3d_hidden_dim
+        self.C, self.W = C, W
+        self.S = args.render.N_samples + args.render.N_importance
+        act = lambda: nn.LeakyReLU(inplace=True)  # noqa: E731
+        xyz_dim, view_dim = 3 + 3 * 2 * args.multires, 3 + 3 * 2 * args.multires_views
+        if args.i_embed != 0 or args.multires != 10 or args.multires_views != 4:
+            raise ValueError("the HIP renderer is built for multires=10, multires_views=4, i_embed=0 (all shipped configs)")
+        F_ = 3 + C
+        self.ray_diff_fc = nn.Sequential(nn.Linear(4, 16), act(), nn.Linear(16, view_dim), act())
+        self.multiview_aggregator = MultiviewFeatureAggregator(args, in_channels=C, out_channels=W)
+        self.confidence_mlp = nn.Sequential(nn.Linear(W, 64), act(), nn.Linear(64, 1), nn.Sigmoid())
+        self.keypoint_head = nn.Sequential(nn.Linear(C, 1), nn.Sigmoid())
+        self.base_mlp = nn.Sequential(nn.Linear(F_ + xyz_dim + view_dim, W), act(), nn.Linear(W, W), act(), nn.Linear(W, W), act())
+        self.base_mlp_attn = _MHAParams(4, W, 32, 32)
+        self.base_mlp_agg_weight = nn.Sequential(nn.Linear(W, W), act(), nn.Linear(W, 1))
+        self.support_neural_points = None
+        self.ray_unet = _RayUnetParams(W, self.S)
+        self.sigma_mlp = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+        if args.render.render_feature:
+            self.feat_mlp = nn.Sequential(nn.Linear(W, W), act(), nn.Linear(W, C))
+        self.rgb_blending_mlp = nn.Sequential(nn.Linear(W + F_ + 1 + 4, 32), act(), nn.Linear(32, 16), act(), nn.Linear(16, 1))
+        if args.render.use_render_uncertainty:
+            self.beta_mlp = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+            self.beta_min = 0.1
+        if args.use_scene_coord_memorization:
+            def cd():
+                return nn.Sequential(nn.Linear(xyz_dim, W), nn.ReLU(inplace=True), nn.Linear(W, W), nn.ReLU(inplace=True),
+                                     nn.Linear(W, args.matcher_hidden_dim))
+            self.coord_desc_mlp_coarse, self.coord_desc_mlp_fine = cd(), cd()
+        self.proj_layer_3d_coarse = nn.Linear(W + F_, args.matcher_hidden_dim)
+        self.proj_layer_3d_fine = nn.Linear(W + F_, args.matcher_hidden_dim)
+        # ---- HIP side
+        self._precision = precision
+        self._device = device
+        self._renderers: Dict[str, HipRenderer] = {}
+        self._frame_token: Dict[str, object] = {}
+        self._weights_version = -1
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def _renderer(self, level: str) -> HipRenderer:
+        dev = self._device or str(next(self.parameters()).device)
+        if not dev.startswith("cuda"):
+            raise RuntimeError("ConditionalNeRF's ray path runs only on a HIP device (no CPU fallback); move the module to cuda")
+        r = self._renderers.get(level)
+        if r is None:
+            if "feat_mlp.0.weight" not in self.state_dict():
+                raise NotImplementedError("render.render_feature=False is not supported by the HIP path")
+            r = HipRenderer(self.W, self.C, self.S, self._precision, device=dev)
+            self._renderers[level] = r
+            self._weights_version = -1
+        ver = sum(p._version for p in self.parameters())
+        if ver != self._weights_version or not r._weights_loaded:
+            sd = self.state_dict()
+            for rr in self._renderers.values():
+                rr.load_weights(sd)
+            self._weights_version = ver
+        return r
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._weights_version = -1
+        return out
+
+    def _ensure_frame(self, data, level: str) -> HipRenderer:
+        """(Re)build the HIP per-frame tables when the caller reset the caches (nerf_pose_estimator.py:289-290)."""
+        if self.support_neural_points is None:
+            self.build_support_neural_points(data)
+        r = self._renderer(level)
+        sp = self.support_neural_points[level]
+        token = (id(sp["xyz"]), id(self.multiview_aggregator.vis_featmaps), data["topk_images"].data_ptr())
+        if self._frame_token.get(level) != token:
+            feat = data["feat_fine_src"] if level == "fine" else data["feat_coarse_src"]
+            near, far = [float(x) for x in data["depth_range"][0]]
+            r.set_frame(data["topk_images"], feat, self._vis_featmaps(data), data["topk_Ks"], data["topk_poses"], near, far, sp)
+            self._frame_token[level] = token
+        return r
+
+    def _vis_featmaps(self, data):
+        agg = self.multiview_aggregator
+        if agg.vis_featmaps is None:
+            with torch.no_grad():
+                agg.vis_featmaps = agg.depth_fusion(data["topk_images"], data["feat_fine_src"].permute(0, 3, 1, 2), data["topk_depths"],
+                                                    data["topk_Ks"], data["topk_poses"], data["depth_range"][0])
+        return agg.vis_featmaps
+
+    # ------------------------------------------------------------------ per-frame setup (a21, PyTorch)
+    def backproject_support_frame(self, imgs, feats, depths, Ks, c2ws, stride=1):
+        """model.py:203-265."""
+        refs, worlds, descs, dirs = [], [], [], []
+        w2c_ref = c2ws[0].inverse()
+        for img, feat, depth, K, c2w in zip(imgs, feats, depths, Ks, c2ws):
+            H, W = int(img.shape[-2] / stride), int(img.shape[-1] / stride)
+            K = K.clone()
+            K[:2] /= stride
+            depth = F.interpolate(depth[None, None], size=(H, W)).squeeze()
+            img = F.interpolate(img[None], size=(H, W)).squeeze().permute(1, 2, 0)
+            v, u = torch.nonzero(depth > 0, as_tuple=True)
+            z = depth[v, u]
+            uv1 = torch.stack([u, v, torch.ones_like(u)], 0).float()
+            cam = torch.matmul(K.inverse(), uv1) * z
+            cam_h = torch.cat([cam, torch.ones_like(cam[:1])])
+            world = torch.matmul(c2w[:3, :3], cam) + c2w[:3, 3:]
+            ref = torch.matmul(torch.matmul(w2c_ref, c2w), cam_h)[:3]
+            _, rd = get_rays(H, W, K, c2w)
+            refs.append(ref.T)
+            worlds.append(world.T)
+            descs.append(torch.cat([img[v, u], feat[v, u]], 1))
+            dirs.append(torch.cat([rd[v, u], z.view(-1, 1)], 1))
+        return torch.cat(descs), torch.cat(worlds), torch.cat(refs), torch.cat(dirs)
+
+    def estimate_neural_points_confidence(self, points, data, level_feat):
+        """model.py:137-142: confidence_mlp(multiview aggregate at the support points) — aggregate on HIP, MLP on torch."""
+        r = self._renderers["fine"]
+        mv, _, _, _ = r.mv_aggregate(points, data["pose"][:3, 3] if "pose" in data else torch.zeros(3))
+        return self.confidence_mlp(mv)
+
+    @torch.no_grad()
+    def build_support_neural_points(self, data):
+        """model.py:144-201."""
+        d = data
+        desc_c, pts_c, ndc_c, dir_c = self.backproject_support_frame(d["topk_images"], d["feat_coarse_src"], d["topk_depths"], d["topk_Ks"],
+                                                                     d["topk_poses"], stride=d["stride_coarse"])
+        desc_f, pts_f, ndc_f, dir_f = self.backproject_support_frame(d["topk_images"], d["feat_fine_src"], d["topk_depths"], d["topk_Ks"],
+                                                                     d["topk_poses"], stride=d["stride_fine"])
+        # the fine-level confidence needs the aggregator -> a frame with provisional confidence is set first
+        fine = {"xyz": pts_f, "xyz_ndc": ndc_f, "feature": desc_f, "confidence": torch.ones_like(pts_f[:, :1]), "direction": dir_f}
+        r = self._renderer("fine")
+        near, far = [float(x) for x in d["depth_range"][0]]
+        r.set_frame(d["topk_images"], d["feat_fine_src"], self._vis_featmaps(d), d["topk_Ks"], d["topk_poses"], near, far, fine)
+        fine["confidence"] = self.estimate_neural_points_confidence(pts_f, d, None)
+        self.support_neural_points = {
+            "coarse": {"xyz": pts_c, "xyz_ndc": ndc_c, "feature": desc_c, "confidence": torch.ones_like(pts_c[:, :1]), "direction": dir_c,
+                       "keypoint_score": self.keypoint_head(desc_c[:, 3:])},
+            "fine": fine,
+        }
+        self._frame_token.pop("fine", None)   # rebuild tables with the real confidence on next use
+        if len(pts_c) == 0:
+            print(f"Error: zero support_neural_points {d.get('scene')} : {d.get('filename')}")
+
+    # ------------------------------------------------------------------ descriptor queries (model.py:267-342)
+    def sample_points_3d(self):
+        sp = self.support_neural_points["coarse"]
+        n = len(sp["xyz"])
+        k = self.args.matching.fine_num_3d_keypoints
+        idx = torch.multinomial(sp["keypoint_score"].squeeze(1), k, replacement=n < k)
+        return sp["xyz"][idx], sp["xyz_ndc"][idx], idx
+
+    def query(self, data, xyz, support_featmaps=None, support_neural_points=None, direction=None, K=8, embed_a=None, target_proj_mat=None):
+        """model.py:344-436.  `support_featmaps` / `support_neural_points` select the level exactly like the reference's
+        call sites do (fine: model.py:325-331,509-517; coarse: :296-302)."""
+        if self.support_neural_points is None:
+            self.build_support_neural_points(data)
+        level = "coarse" if (support_neural_points is not None and support_neural_points is self.support_neural_points.get("coarse")) else "fine"
+        r = self._ensure_frame(data, level)
+        mv, rgb_feat, vis_ang, _ = r.mv_aggregate(xyz, data["pose"][:3, 3] if "pose" in data else torch.zeros(3))
+        dirs = None if direction is None else direction[:, :3].contiguous()
+        fa, d2, idx = r.point_mlp(xyz, dirs, mv, K=K)
+        sp = self.support_neural_points[level]
+        dist = d2.sqrt()
+        conf = sp["confidence"].squeeze(-1)[idx.long()] if len(sp["xyz"]) >= K else torch.zeros_like(dist)
+        w = (1.0 / torch.clamp(dist, min=1e-8)) * (1.0 / K) * conf
+        w = w / torch.clamp(w.sum(1, keepdim=True), min=1e-8)
+        scale = w.sum(1, keepdim=True)
+        feature = (fa / torch.clamp(scale, min=1e-20)).unsqueeze(1).expand(-1, K, -1)   # identical for all K rows (see point.hip)
+        return {"feature_agg": fa, "feature": feature, "weights": w, "multiview_feature": rgb_feat[:, :, :self.C + 3],
+                "multiview_visibility": vis_ang[:, :, :1]}
+
+    def _nearest_feature(self, level, points, data):
+        r = self._ensure_frame(data, level)
+        _, idx = r.knn(points, 1)
+        return self.support_neural_points[level]["feature"][idx[:, 0].long()]
+
+    def query_coarse(self, data, points=None, embed_a=None):
+        if self.support_neural_points is None:
+            self.build_support_neural_points(data)
+        if points is None:
+            pts3d, pts3d_ndc, sidx = self.sample_points_3d()
+            feat2d = self.support_neural_points["coarse"]["feature"][sidx]
+        else:
+            pts3d = points
+            w2c = data["topk_poses"][0].inverse()
+            pts3d_ndc = (torch.matmul(w2c[:3, :3], points.T) + w2c[:3, 3:]).T
+            feat2d = self._nearest_feature("coarse", points, data)
+        q = self.query(data, pts3d, support_neural_points=self.support_neural_points["coarse"], K=8, embed_a=embed_a)
+        desc = self.proj_layer_3d_coarse(torch.cat([q["feature_agg"], feat2d], 1))
+        if self.args.use_scene_coord_memorization:
+            desc = desc + self.coord_desc_mlp_coarse(self._embed_xyz(pts3d))
+        return desc, pts3d, pts3d_ndc
+
+    def query_fine(self, data, points, embed_a=None):
+        if self.support_neural_points is None:
+            self.build_support_neural_points(data)
+        feat2d = self._nearest_feature("fine", points, data)
+        q = self.query(data, points, support_neural_points=self.support_neural_points["fine"], K=1, embed_a=embed_a)
+        desc = self.proj_layer_3d_fine(torch.cat([q["feature_agg"], feat2d], 1))
+        if self.args.use_scene_coord_memorization:
+            desc = desc + self.coord_desc_mlp_fine(self._embed_xyz(points))
+        return desc, None, None
+
+    @staticmethod
+    def _embed_xyz(x, n=10):
+        out = [x]
+        for f in 2.0 ** torch.linspace(0.0, n - 1, n):
+            out += [torch.sin(x * f), torch.cos(x * f)]
+        return torch.cat(out, -1)
+
+    # ------------------------------------------------------------------ rendering
+    def sample_depths(self, N_samples, near, far):
+        """model.py:451-458 (tiny, host-side torch like the reference)."""
+        t = torch.linspace(0, 1, N_samples, device=near.device)
+        if not self.args.render.lindisp:
+            return near * (1 - t) + far * t
+        return 1 / (1 / near * (1 - t) + 1 / far * t)
+
+    @torch.no_grad()
+    def render_rays(self, data, rays, u: Optional[torch.Tensor] = None):
+        """model.py:472-600, eval mode.  `u` optionally fixes sample_pdf's uniform draws (reference: torch.rand)."""
+        if self.training:
+            raise NotImplementedError("autograd through the HIP renderer (beta / render loss) is a next-row item (SURVEY.md §8f-2)")
+        r = self._ensure_frame(data, "fine")
+        near, far = rays["depth_range"]
+        o, d = rays["rays_o"], rays["rays_d"]
+        R = o.shape[0]
+        N = self.args.render.N_samples
+        z = self.sample_depths(N, near, far).expand(R, N).contiguous()
+        depth_coarse = None
+        if self.args.render.N_importance > 0:
+            if u is None:
+                u = torch.rand(R, self.args.render.N_importance, device=o.device)
+            z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u)
+        out = r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                            want_feat=bool(self.args.render.render_feature))
+        if depth_coarse is not None:
+            out["depth_coarse"] = depth_coarse
+        return out
+
+    @torch.no_grad()
+    def render_image(self, data):
+        """model.py:602-639."""
+        H, W, K, pose = data["H"], data["W"], data["K"], data["pose"]
+        o, d = get_rays(H, W, K, pose)
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        uu, vv = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+        pix = torch.stack([uu.t().reshape(-1), vv.t().reshape(-1)], 1).to(K.device)
+        chunk = self.args.render.chunk
+        parts: Dict[str, list] = {}
+        for i in range(0, o.shape[0], chunk):
+            ret = self.render_rays(data, {"pixel_coordinates": pix[i:i + chunk], "K": K, "pose": pose, "H": H, "W": W,
+                                          "rays_o": o[i:i + chunk], "rays_d": d[i:i + chunk], "depth_range": data["depth_range"][0]})
+            for k, v in ret.items():
+                parts.setdefault(k, []).append(v)
+        out = {k: torch.cat(v, 0).view(H, W, -1) for k, v in parts.items()}
+        if "target_mask" in data:
+            out["rgb"] = out["rgb"] * data["target_mask"][:, :, None].float()
+        return out
+
+    def compute_render_loss(self, data):
+        raise NotImplementedError("compute_render_loss needs the renderer's backward pass (SURVEY.md §8f-2, next row)")
+
+    def points_2d_to_rays(self, pts2d, H, W, K, pose):
+        """model.py:687-700."""
+        x, y = pts2d[:, 0].long(), pts2d[:, 1].long()
+        o, d = get_rays(H, W, K, pose)
+        return {"pose": pose, "K": K, "H": H, "W": W, "pixel_coordinates": pts2d, "rays_o": o[y, x], "rays_d": d[y, x]}
+
+    def sample_rays(self, n_rays, H, W, K, pose, mask=None):
+        """model.py:702-713."""
+        u, v = torch.meshgrid(torch.arange(W), torch.arange(H), indexing="ij")
+        pts = torch.stack([u.reshape(-1).float(), v.reshape(-1).float()], 1)
+        if mask is not None:
+            pts = pts[mask[pts[:, 1].long(), pts[:, 0].long()].bool().cpu()]
+        idx = np.random.choice(len(pts), n_rays, replace=False)
+        return self.points_2d_to_rays(pts[idx].to(K.device), H, W, K, pose)

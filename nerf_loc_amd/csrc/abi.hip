@@ -258,10 +258,10 @@ void carve_mv(Bump& b, const nl_config* c, int V, int64_t N, MvBufs& m) {
   m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N);
   m.g393 = b.take<float>((size_t)N * LDG); m.t64 = b.take<float>((size_t)N * 64);
 }
-void carve_pt(Bump& b, const nl_config* c, int64_t N, int K, PtBufs& p) {
+void carve_pt(Bump& b, const nl_config* c, int64_t N, int K, PtBufs& p, bool force_generic = false) {
   const int W = c->W;
   p.idx = b.take<int>((size_t)N * K); p.d2 = b.take<float>((size_t)N * K);
-  if (nl_point_fused_supported(W, c->precision)) { p.X = p.H1 = p.H2 = p.KV = nullptr; }
+  if (!force_generic && nl_point_fused_supported(W, c->precision)) { p.X = p.H1 = p.H2 = p.KV = nullptr; }
   else {
     p.X = b.take<float>((size_t)N * K * LDX);
     p.H1 = b.take<float>((size_t)N * K * W); p.H2 = b.take<float>((size_t)N * K * W);
@@ -561,14 +561,14 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
 
 // ---- frame ---------------------------------------------------------------------------------------------
 static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
-  return cfg_ok(c) && d && d->V >= 1 && d->V <= NL_MAX_VIEWS && d->H > 1 && d->Wimg > 1 && d->h > 1 && d->w > 1 && d->M >= 0 &&
+  return cfg_ok(c) && d && d->V >= 1 && d->V <= NL_MAX_VIEWS && d->H > 1 && d->Wimg > 1 && d->h > 1 && d->w > 1 && d->vis_h > 1 && d->vis_w > 1 && d->M >= 0 &&
          d->images && d->featmaps && d->vis_featmaps && d->proj_ibr && d->proj_neuray && d->cam_centers &&
          (d->M == 0 || (d->sp_xyz && d->sp_feature && d->sp_confidence && d->sp_direction));
 }
 
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
   if (!desc_ok(cfg, d)) return 0;
-  return nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256);
+  return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256);
 }
 
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
@@ -578,6 +578,7 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
   if (!f) return NL_ERR_BAD_ARG;
   memset(&f->views, 0, sizeof(NlViews));
   f->views.V = d->V; f->views.H = d->H; f->views.Wimg = d->Wimg; f->views.h = d->h; f->views.w = d->w;
+  f->views.vh = d->vis_h; f->views.vw = d->vis_w;
   f->views.near_ = d->near_; f->views.far_ = d->far_;
   for (int v = 0; v < d->V; ++v) {
     memcpy(f->views.P1[v], d->proj_ibr + 12 * v, 48);
@@ -590,10 +591,10 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
   f->M = d->M;
   hipStream_t st = (hipStream_t)stream;
   f->visf_hwc = (float*)mem;
-  int rc = nl_launch_chw_to_hwc(d->vis_featmaps, f->visf_hwc, d->V, 32, d->h * d->w, st);
-  if (rc == NL_OK) rc = nl_knn_grid_build(&f->grid, (char*)mem + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256), d->sp_xyz, d->M, st);
+  int rc = nl_launch_chw_to_hwc(d->vis_featmaps, f->visf_hwc, d->V, 32, d->vis_h * d->vis_w, st);
+  if (rc == NL_OK) rc = nl_knn_grid_build(&f->grid, (char*)mem + nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256), d->sp_xyz, d->M, st);
   {
-    char* p = (char*)mem + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
+    char* p = (char*)mem + nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
     f->fhi = (uint4*)p;
     f->flo = (uint4*)(p + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
     if (rc == NL_OK) rc = nl_split_feature_table(d->sp_feature, d->M, cfg->C + 3, f->fhi, f->flo, st);
@@ -636,7 +637,7 @@ int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* f,
 
 size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N) {
   if (!cfg_ok(cfg)) return 0;
-  Bump b{nullptr, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p); return b.off;
+  Bump b{nullptr, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p, true); return b.off;
 }
 
 int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
@@ -644,7 +645,7 @@ int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, co
                  void* stream) {
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !feature_agg || !ws || N < 0 || K < 1 || K > 8) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_point_mlp_workspace_bytes(cfg, N)) return NL_ERR_WORKSPACE;
-  Bump b{(char*)ws, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p);
+  Bump b{(char*)ws, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p, true);
   Ctx x = make_ctx(cfg, packed, stream);
   NL_TRY(do_point(x, f, xyz, dir, (int)dir_stride, 1, mv_feat, N, K, feature_agg, p));
   if (knn_idx) NL_CHECK_HIP(hipMemcpyAsync(knn_idx, p.idx, sizeof(int) * N * K, hipMemcpyDeviceToDevice, x.st));

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void mv_vis_kernel(const NlViews vw, const flo
   float px, py, depth;
   const bool valid = project_neuray(vw.P2[v], X, Y, Z, vw.Wimg, vw.H, px, py, depth);
   float x[32];
-  sample_visf(visf + (size_t)v * vw.h * vw.w * 32, vw.h, vw.w, vw.Wimg, vw.H, px, py, valid, x);
+  sample_visf(visf + (size_t)v * vw.vh * vw.vw * 32, vw.vh, vw.vw, vw.Wimg, vw.H, px, py, valid, x);
   float m0, m1, v0, v1, aw, vs;
   decode_all(dw, x, m0, m1, v0, v1, vs, aw);
 

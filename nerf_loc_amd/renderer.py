@@ -91,6 +91,7 @@ class HipRenderer:
         M = sp["xyz"].shape[0]
         d = L.NlFrameDesc()
         d.V, d.H, d.Wimg, d.h, d.w = V, H, Wimg, h, w
+        d.vis_h, d.vis_w = visf.shape[2], visf.shape[3]
         d.near_, d.far_ = float(near), float(far)
         d.images, d.featmaps, d.vis_featmaps = images.data_ptr(), feat.data_ptr(), visf.data_ptr()
         d.proj_ibr, d.proj_neuray, d.cam_centers = proj_ibr.data_ptr(), proj_neuray.data_ptr(), cams.data_ptr()

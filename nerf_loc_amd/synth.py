@@ -263,3 +263,31 @@ def make_weights(cfg: SceneConfig, seed: int | None = None) -> Dict[str, np.ndar
             a = rng.standard_normal(shp) * np.sqrt(2.0 / fan_in)
         out[name] = a.astype(F32)
     return out
+
+
+def make_depth_fusion_weights(seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded weights for the per-frame CNN (`multiview_aggregator.depth_fusion.*`, 72 tensors).  Names/shapes are taken
+    from nerf_loc_amd.depth_fusion.DepthFusionNet, whose state_dict equals the reference's (asserted by gen_golden)."""
+    from .depth_fusion import DepthFusionNet
+    rng = np.random.default_rng(seed + 104729)
+    out = {}
+    sd = DepthFusionNet().state_dict()
+    for name in sorted(sd):
+        shp = tuple(sd[name].shape)
+        if len(shp) == 4:
+            a = rng.standard_normal(shp) * np.sqrt(2.0 / (shp[1] * shp[2] * shp[3]))
+        elif name.endswith("weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shp)
+        else:
+            a = 0.1 * rng.standard_normal(shp)
+        out["multiview_aggregator.depth_fusion." + name] = a.astype(F32)
+    return out
+
+
+def add_setup_inputs(cfg: SceneConfig, frame: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Extra `data` keys the per-frame setup reads (model.py:144-165): coarse feature map + strides."""
+    rng = np.random.default_rng(cfg.seed + 31337)
+    frame = dict(frame)
+    frame["feat_coarse_src"] = rng.standard_normal((cfg.V, cfg.H // 8, cfg.Wimg // 8, cfg.C), dtype=F32)
+    frame["stride_fine"], frame["stride_coarse"] = 4, 8
+    return frame

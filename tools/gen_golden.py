@@ -181,11 +181,53 @@ def run_case(model_mod, ku, name):
           f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
 
 
+def run_setup_case(model_mod):
+    """Per-frame setup (a21) + end-to-end render through the reference, with seeded DepthFusionNet weights."""
+    import json
+    from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_weights
+    cfg = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
+    frame = add_setup_inputs(cfg, make_frame(cfg))
+    rays = make_rays(cfg, frame)
+    weights = dict(make_weights(cfg))
+    weights.update(make_depth_fusion_weights(cfg.seed))
+    net = model_mod.ConditionalNeRF(ref_args(cfg)).eval()
+    sd = net.state_dict()
+    assert set(sd) == set(weights), sorted(set(sd) ^ set(weights))[:10]
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(weights[k].shape), (k, sd[k].shape, weights[k].shape)
+    net.load_state_dict({k: t(v) for k, v in weights.items()}, strict=True)
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8, "scene": "s", "filename": "f"})
+    ray_d = {"rays_o": t(rays["rays_o"]), "rays_d": t(rays["rays_d"]), "depth_range": t(rays["depth_range"]),
+             "pixel_coordinates": t(rays["pixel_coordinates"]), "K": t(rays["K"]), "pose": t(rays["pose"]), "H": cfg.H, "W": cfg.Wimg}
+    with torch.no_grad():
+        out = net.render_rays(data, ray_d)
+        pts = net.support_neural_points["fine"]["xyz"][::5][:64].contiguous() + 0.003
+        desc_f, _, _ = net.query_fine(data, pts)
+        desc_c, _, _ = net.query_coarse(data, pts)
+    sp = net.support_neural_points
+    save = {k: v.numpy() for k, v in out.items()}
+    save.update({"vis_featmaps": net.multiview_aggregator.vis_featmaps.numpy(), "fine_xyz": sp["fine"]["xyz"].numpy(),
+                 "fine_confidence": sp["fine"]["confidence"].numpy(), "fine_direction": sp["fine"]["direction"].numpy(),
+                 "fine_feature_head": sp["fine"]["feature"][:, :8].numpy(), "coarse_xyz": sp["coarse"]["xyz"].numpy(),
+                 "coarse_keypoint_score": sp["coarse"]["keypoint_score"].numpy(), "query_pts": pts.numpy(),
+                 "desc_fine": desc_f.numpy(), "desc_coarse": desc_c.numpy()})
+    path = os.path.join(ROOT, "tests", "golden", "setup.npz")
+    np.savez_compressed(path, **save)
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract.json"), "w") as fh:
+        json.dump({k: list(v.shape) for k, v in sd.items()}, fh, indent=0, sort_keys=True)
+    print(f"setup: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB), M_fine={len(sp['fine']['xyz'])}, conf range=({float(sp['fine']['confidence'].min()):.3f},{float(sp['fine']['confidence'].max()):.3f})")
+
+
 def main():
     model_mod, ku = install_shims()
+    if len(sys.argv) > 1 and sys.argv[1] == "setup":
+        return run_setup_case(model_mod)
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
+    if not sys.argv[1:]:
+        run_setup_case(model_mod)
 
 
 if __name__ == "__main__":
