@@ -127,11 +127,13 @@ int nl_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S,
                      const float* z_vals_in, float* z_out, float* xyz, void* stream);
 
 size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N);
-/* a4-a7: -> mv_feat (N,W), rgb_feat (N*V,196) [cols 0..194 valid], vis_ang (N*V,8) = [vis, ang(4), pad],
- *        valid_s (N) = #views(in-bounds & in front) > 1. query_center = data['pose'][:3,3] (HOST, 3 floats). */
+/* a4-a7 (+ a15's per-view part): -> mv_feat (N,W), valid_s (N) = #views(in-bounds & in front) > 1, and optionally
+ *   rgb_feat (N*V,196) [cols 0..194 = raw multi-view projection], vis_ang (N*V,8) = [vis, angle(4), pad]   (staged callers), and/or
+ *   blend1 (N*V,32) = per-(sample,view) part of rgb_blending_mlp layer 1 (pre-activation, bias included), rgbv (N*V,4) = [r,g,b,vis]
+ *   (what nl_heads_composite consumes).  query_center = data['pose'][:3,3] (HOST, 3 floats). */
 int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,
                     const float* xyz, int64_t N, float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s,
-                    void* ws, size_t ws_bytes, void* stream);
+                    float* blend1, float* rgbv, void* ws, size_t ws_bytes, void* stream);
 
 size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N);
 /* a8-a12: xyz (N,3), dir (N,3) viewing direction per sample (NULL: nearest neighbour's, model.py:391-392),
@@ -148,7 +150,7 @@ int nl_ray_unet(const nl_config* cfg, const void* packed, const float* x, int64_
 size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R);
 /* a14-a18 */
 int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const float* z_vals, const float* feature_agg,
-                       const float* geo, const float* rgb_feat, const float* vis_ang, const int32_t* valid_s,
+                       const float* geo, const float* blend1, const float* rgbv, const int32_t* valid_s,
                        int64_t R, int white_bkgd, const nl_render_out* out, void* ws, size_t ws_bytes, void* stream);
 
 /* a20 (hierarchical): coarse NeuRay weights (R,Sc) for z_coarse (R,Sc) along un-normalised K^-1[u,v,1] rays, Sc <= 64.

@@ -60,7 +60,7 @@ SYMBOLS = [
     ("nl_knn", _I, [_P, _P, _L, _I, _P, _P, _P]),
     ("nl_sample_points", _I, [_P, _P, _L, _I, _F, _F, _P, _P, _P, _P]),
     ("nl_mv_aggregate_workspace_bytes", _Z, [_CFG, _I, _L]),
-    ("nl_mv_aggregate", _I, [_CFG, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _Z, _P]),
+    ("nl_mv_aggregate", _I, [_CFG, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_point_mlp_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
     ("nl_ray_unet_workspace_bytes", _Z, [_CFG, _L]),

@@ -15,7 +15,8 @@ int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* i
 int nl_launch_chw_to_hwc(const float* src, float* dst, int V, int Cc, int HW, hipStream_t st);
 int nl_launch_mv_vis(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, float* vis_out, float* dd_out, hipStream_t st);
 int nl_launch_mv_stats(const NlViews& vw, const float* images, const float* feat, int C, const float* xyz, int64_t N, const float* vis_in,
-                       const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang, int* valid_s, hipStream_t st);
+                       const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang, int* valid_s, const float* pfeat, const float* blw,
+                       float* bl1, float* rgbv, hipStream_t st);
 int nl_launch_point_encode(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx, const float* d2,
                            const float* sp_xyz, const float* sp_feat, int F, const float* sp_conf, const float* sp_dir, const float* rd_w,
                            float inv_span, float* X, int ldx, float* wscale, hipStream_t st);
@@ -24,7 +25,7 @@ int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const fl
 int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
-int nl_launch_blend(const float* hA, const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
+int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
 int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const float* pix,
                              const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask, float* weights,
                              float* depth_coarse, hipStream_t st);
@@ -84,7 +85,7 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDB, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -94,7 +95,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bias[G_COUNT];
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_bias;  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_bias, blw;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];
   int un_c[U_COUNT], un_l[U_COUNT];
   size_t total;
@@ -130,10 +131,11 @@ Layout make_layout(const nl_config* c) {
   set(G_CONVOUT, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
   set(G_FEAT2, W, C, true);
-  // colour-blend layer 1 split by linearity: per-sample part (feature_agg) + per-(sample,view) part ([rgb_feat | vis,angle]);
-  // the latter's two sources are padded to multiples of 4 in K-space: 196 + 8
+  // colour-blend layer 1 split by linearity (model.py:532-535): per-sample part (feature_agg columns), and a per-frame
+  // projection of the support feature maps through the feature columns (G_BLENDP, applied once per frame; the
+  // per-(sample, view) value is then a bilinear tap of the projected map inside mv_stats)
   set(G_BLENDA, W, 32, false);
-  set(G_BLENDB, (int)nl_align_up(F, 4) + 8, 32, true);
+  set(G_BLENDP, C, 32, false);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
   for (int i = 0; i < G_COUNT; ++i) {
@@ -155,6 +157,7 @@ Layout make_layout(const nl_config* c) {
     L.un_g[u] = take(4 * (size_t)uc[u] * ul[u]);
     L.un_b[u] = take(4 * (size_t)uc[u] * ul[u]);
   }
+  L.blw = take(4 * (256 + 32));
   L.pt_bias = take(4 * 3 * (size_t)W);
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
   L.total = off;
@@ -181,6 +184,16 @@ __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld
   float hf = __uint_as_float(((unsigned int)h) << 16);
   bhi[(size_t)n * Kpad + k0 + k] = h;
   blo[(size_t)n * Kpad + k0 + k] = pk_f2bf(v - hf);
+}
+
+// [32][8] = rgb(3) | vis(1) | angle(4) columns of rgb_blending_mlp.0.weight (32, W+F+5), then its bias[32]
+__global__ void pack_blw_kernel(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dst, int W, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 256) {
+    const int j = i >> 3, c = i & 7;
+    const int col = c < 3 ? W + c : W + F + (c - 3);
+    dst[i] = w[(size_t)j * (W + F + 5) + col];
+  } else if (i < 288) dst[i] = b[i - 256];
 }
 
 __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
@@ -233,6 +246,8 @@ struct nl_frame {
   int64_t M;
   NlKnnGrid grid;
   uint4* fhi; uint4* flo;   // bf16 hi / lo split of sp_feat, [M][208]
+  float* pfeat;             // (V,h,w,32) feature maps projected through the blend layer's feature columns
+  const void* pfeat_for;    // packed weights pfeat was computed with (lazily, first render of the frame)
 };
 
 namespace {
@@ -250,7 +265,7 @@ struct Bump {
 struct MvBufs { float *vis, *dd, *g393, *t64; };
 struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; };
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
-struct HdBufs { float *sigma, *fth, *ft, *blA, *bl1, *rgb_s; };
+struct HdBufs { float *sigma, *fth, *ft, *blA, *rgb_s; };
 
 constexpr int LDG = 396, LDX = 288;
 
@@ -283,18 +298,18 @@ void carve_un(Bump& b, const nl_config* c, int64_t R, UnBufs& u) {
 void carve_hd(Bump& b, const nl_config* c, int V, int64_t R, HdBufs& h) {
   const size_t N = (size_t)R * c->S;
   h.sigma = b.take<float>(N); h.fth = b.take<float>(N * c->W); h.ft = b.take<float>(N * c->C);
-  h.blA = b.take<float>(N * 32); h.bl1 = b.take<float>(N * V * 32); h.rgb_s = b.take<float>(N * 3);
+  h.blA = b.take<float>(N * 32); h.rgb_s = b.take<float>(N * 3);
 }
 
 struct RenderBufs {
-  float *xyz, *z, *G, *rgb_feat, *vis_ang, *FA, *geo; int* valid_s;
+  float *xyz, *z, *G, *bl1, *rgbv, *FA, *geo; int* valid_s;
   MvBufs mv; PtBufs pt; UnBufs un; HdBufs hd;
 };
 void carve_render(Bump& b, const nl_config* c, int V, int64_t R, RenderBufs& rb) {
   const size_t N = (size_t)R * c->S;
   rb.xyz = b.take<float>(N * 3); rb.z = b.take<float>(N);
   rb.G = b.take<float>(N * c->W);
-  rb.rgb_feat = b.take<float>(N * V * NL_FPAD); rb.vis_ang = b.take<float>(N * V * 8);
+  rb.bl1 = b.take<float>(N * V * 32); rb.rgbv = b.take<float>(N * V * 4);
   rb.valid_s = b.take<int>(N);
   rb.FA = b.take<float>(N * c->W); rb.geo = b.take<float>(N * c->W);
   carve_mv(b, c, V, N, rb.mv); carve_pt(b, c, N, 8, rb.pt); carve_un(b, c, R, rb.un); carve_hd(b, c, V, R, rb.hd);
@@ -338,11 +353,27 @@ NlViews with_query(const nl_frame* f, const float* qc) {
   return v;
 }
 
+// per-frame projection of the support feature maps through the blend layer (exact fp32 MFMA), done once per (frame, weights)
+int ensure_pfeat(const Ctx& x, const nl_frame* fc) {
+  nl_frame* f = const_cast<nl_frame*>(fc);
+  if (f->pfeat_for == (const void*)x.pk) return NL_OK;
+  nl_config c32 = *x.c;
+  c32.precision = NL_PREC_F32;
+  Ctx x32 = x;
+  x32.c = &c32;
+  SegSpec s{f->feat, f->C, f->C, 0, 1};
+  NL_TRY(run_gemm(x32, G_BLENDP, &s, 1, (int64_t)f->views.V * f->views.h * f->views.w, f->pfeat, 32, NL_ACT_NONE));
+  f->pfeat_for = (const void*)x.pk;
+  return NL_OK;
+}
+
 int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
-          float* vis_ang, int* valid_s, const MvBufs& m) {
+          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m) {
   const NlViews vw = with_query(f, qc);
+  if (bl1) NL_TRY(ensure_pfeat(x, f));
   NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
-  NL_TRY(nl_launch_mv_stats(vw, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, x.st));
+  NL_TRY(nl_launch_mv_stats(vw, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, f->pfeat,
+                            x.p<float>(x.L.blw), bl1, rgbv, x.st));
   SegSpec s0{m.g393, LDG, 2 * (f->C + 3) + 3, 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
   SegSpec s1{m.t64, 64, 64, 0, 1};
@@ -435,9 +466,9 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   return NL_OK;
 }
 
-int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* rgb_feat, const float* vis_ang,
+int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
              const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h) {
-  const int W = x.c->W, S = x.c->S, C = x.c->C, F = C + 3;
+  const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
   NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
   const bool want_feat = out->feat != nullptr;
@@ -449,9 +480,7 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
   }
   SegSpec sa{FA, W, W, 0, 1};
   NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
-  SegSpec sb[2] = {{rgb_feat, NL_FPAD, F, 0, 1}, {vis_ang, 8, 5, 0, 1}};
-  NL_TRY(run_gemm(x, G_BLENDB, sb, 2, N * V, h.bl1, 32, NL_ACT_NONE));
-  NL_TRY(nl_launch_blend(h.blA, h.bl1, rgb_feat, vis_ang, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
+  NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
                          x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.ft : nullptr, valid_s, R, S, C, white, out, ray0, x.st));
   if (out->sigma) NL_CHECK_HIP(hipMemcpyAsync(out->sigma + ray0 * S, h.sigma, sizeof(float) * N, hipMemcpyDeviceToDevice, x.st));
@@ -532,9 +561,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.linear(G_FEAT0, t[T_F0W], t[T_F0B]);
   P.linear(G_FEAT2, t[T_F2W], t[T_F2B]);
   P.block(G_BLENDA, 0, t[T_BL0W], 0, W + F + 5, 1, W);
-  P.block(G_BLENDB, 0, t[T_BL0W], W, W + F + 5, 1, F);
-  P.block(G_BLENDB, (int)nl_align_up(F, 4), t[T_BL0W], W + F, W + F + 5, 1, 5);
-  P.copy(t[T_BL0B], L.bias[G_BLENDB], 32);
+  P.block(G_BLENDP, 0, t[T_BL0W], W + 3, W + F + 5, 1, C);
+  hipLaunchKernelGGL(pack_blw_kernel, dim3(2), dim3(256), 0, st, t[T_BL0W], t[T_BL0B], (float*)((char*)packed + L.blw), W, F);
   // small VALU-side weights
   P.copy(t[T_RD0W], L.rd_w, 64); P.copy(t[T_RD0B], L.rd_w + 4 * 64, 16);
   P.copy(t[T_RD2W], L.rd_w + 4 * 80, 27 * 16); P.copy(t[T_RD2B], L.rd_w + 4 * (80 + 432), 27);
@@ -568,7 +596,8 @@ static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
 
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
   if (!desc_ok(cfg, d)) return 0;
-  return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256);
+  return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256) +
+         nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256);
 }
 
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
@@ -598,6 +627,8 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
     f->fhi = (uint4*)p;
     f->flo = (uint4*)(p + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
     if (rc == NL_OK) rc = nl_split_feature_table(d->sp_feature, d->M, cfg->C + 3, f->fhi, f->flo, st);
+    f->pfeat = (float*)((char*)f->flo + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
+    f->pfeat_for = nullptr;
   }
   if (rc != NL_OK) { delete f; return rc; }
   *out = f;
@@ -627,12 +658,13 @@ size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
 }
 
 int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, int64_t N,
-                    float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s, void* ws, size_t ws_bytes, void* stream) {
-  if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !rgb_feat || !vis_ang || !valid_s || !ws || N < 0) return NL_ERR_BAD_ARG;
+                    float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s, float* blend1, float* rgbv, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !valid_s || !ws || N < 0 || (blend1 && !rgbv)) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_mv_aggregate_workspace_bytes(cfg, f->views.V, N)) return NL_ERR_WORKSPACE;
   Bump b{(char*)ws, 0}; MvBufs m; carve_mv(b, cfg, f->views.V, N, m);
   Ctx x = make_ctx(cfg, packed, stream);
-  return do_mv(x, f, qc, xyz, N, mv_feat, rgb_feat, vis_ang, valid_s, m);
+  return do_mv(x, f, qc, xyz, N, mv_feat, rgb_feat, vis_ang, valid_s, blend1, rgbv, m);
 }
 
 size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N) {
@@ -672,13 +704,13 @@ size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R
 }
 
 int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const float* z, const float* FA, const float* geo,
-                       const float* rgb_feat, const float* vis_ang, const int32_t* valid_s, int64_t R, int white,
+                       const float* blend1, const float* rgbv, const int32_t* valid_s, int64_t R, int white,
                        const nl_render_out* out, void* ws, size_t ws_bytes, void* stream) {
-  if (!cfg_ok(cfg) || !packed || !z || !FA || !geo || !rgb_feat || !vis_ang || !out || !ws || R < 0 || V < 1 || V > NL_MAX_VIEWS) return NL_ERR_BAD_ARG;
+  if (!cfg_ok(cfg) || !packed || !z || !FA || !geo || !blend1 || !rgbv || !out || !ws || R < 0 || V < 1 || V > NL_MAX_VIEWS) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_heads_composite_workspace_bytes(cfg, V, R)) return NL_ERR_WORKSPACE;
   Bump b{(char*)ws, 0}; HdBufs h; carve_hd(b, cfg, V, R, h);
   Ctx x = make_ctx(cfg, packed, stream);
-  return do_heads(x, V, z, FA, geo, rgb_feat, vis_ang, valid_s, R, white, out, 0, h);
+  return do_heads(x, V, z, FA, geo, blend1, rgbv, valid_s, R, white, out, 0, h);
 }
 
 // ---- fused path ---------------------------------------------------------------------------------------------
@@ -717,11 +749,11 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
     const int64_t N = rc * S;
     NL_TRY(nl_launch_sample_points(rays_o + 3 * r0, rays_d + 3 * r0, rc, S, f->views.near_, f->views.far_,
                                    z_vals ? z_vals + r0 * S : nullptr, rb.z, rb.xyz, x.st));
-    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, rb.rgb_feat, rb.vis_ang, rb.valid_s, rb.mv));
+    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt));
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.rgb_feat, rb.vis_ang, rb.valid_s, rc, white, out, r0, rb.hd));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -307,6 +307,8 @@ int launch_bn(const NlGemmArgs& a, int precision, hipStream_t st) {
 int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   if (a.M <= 0) return NL_OK;
   if (a.N <= 64) return launch_bn<64>(a, precision, st);
-  if (a.N <= 128) return launch_bn<128>(a, precision, st);
+  // 128-wide column blocks also for N = 256: 2 waves/SIMD instead of 1 hides the tile-load latency better than the
+  // saved A re-read (A comes from L2 the second time)
+  if (a.N <= 128 || precision != NL_PREC_F32) return launch_bn<128>(a, precision, st);
   return launch_bn<256>(a, precision, st);
 }

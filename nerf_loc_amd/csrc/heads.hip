@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void sigma_kernel(const float* __restrict__ ge
 
 // colour blending tail (model.py:535-538): layer 1 = LeakyReLU(hA[n] + h1[n,v]) (split by linearity) -> 16 -> 1,
 // masked_fill(vis == 0, -1e9), softmax over views, rgb = sum_v w_v * rgb_in.   One lane per sample.
-__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA, const float* __restrict__ h1, const float* __restrict__ rgb_feat,
-                                                    const float* __restrict__ vis_ang, int N, int V,
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA, const float* __restrict__ h1, const float* __restrict__ rgbv /*(N*V,4) = [r,g,b,vis]*/,
+                                                    int N, int V,
                                                     const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
                                                     const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
                                                     float* __restrict__ rgb_s) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA
       for (int i = 0; i < 32; ++i) a = fmaf(w2[j * 32 + i], x[i], a);
       o = fmaf(w4[j], nl_lrelu(a), o);
     }
-    const float vis = vis_ang[((size_t)n * V + v) * 8];
+    const float vis = rgbv[((size_t)n * V + v) * 4 + 3];
     o = (vis == 0.f) ? -1e9f : o;
     lg[v] = o;
     mx = fmaxf(mx, o);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA
   float r = 0.f, g = 0.f, b = 0.f;
   for (int v = 0; v < V; ++v) {
     const float wv = lg[v] / den;
-    const float* c = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
+    const float* c = rgbv + ((size_t)n * V + v) * 4;
     r += c[0] * wv; g += c[1] * wv; b += c[2] * wv;
   }
   rgb_s[3 * (size_t)n] = r; rgb_s[3 * (size_t)n + 1] = g; rgb_s[3 * (size_t)n + 2] = b;
@@ -188,10 +188,10 @@ int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const fl
   return NL_OK;
 }
 
-int nl_launch_blend(const float* hA, const float* h1, const float* rgb_feat, const float* vis_ang, int64_t N, int V, const float* w2,
+int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2,
                     const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st) {
   if (N <= 0) return NL_OK;
-  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgb_feat, vis_ang, (int)N, V, w2, b2, w4, b4, rgb_s);
+  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgbv, (int)N, V, w2, b2, w4, b4, rgb_s);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
                                                        const float* __restrict__ xyz, int N,
                                                        const float* __restrict__ vis_in, const float* __restrict__ dd_in,
-                                                       float* __restrict__ g393, int ldg, float* __restrict__ rgb_feat /*(N*V,196)*/,
-                                                       float* __restrict__ vis_ang /*(N*V,8)*/, int* __restrict__ valid_s) {
+                                                       float* __restrict__ g393, int ldg, float* __restrict__ rgb_feat /*(N*V,196) or null*/,
+                                                       float* __restrict__ vis_ang /*(N*V,8) or null*/, int* __restrict__ valid_s,
+                                                       const float* __restrict__ pfeat /*(V,h,w,32) blend-projected feature map*/,
+                                                       const float* __restrict__ blw /*[32][8] = W[rgb3|vis1|ang4], then bias[32]*/,
+                                                       float* __restrict__ bl1 /*(N*V,32) or null*/, float* __restrict__ rgbv /*(N*V,4) or null*/) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -79,6 +82,10 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
 #pragma unroll
   for (int v = 0; v < VT; ++v) { visraw[v] = wgt[v]; wgt[v] = wgt[v] / (vsum + 1e-8f); }
 
+  float bwr[8], bbias = 0.f;   // this lane's row (j = lane < 32) of the small blend-layer weights
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bwr[i] = (bl1 && lane < 32) ? blw[lane * 8 + i] : 0.f;
+  if (bl1 && lane < 32) bbias = blw[256 + lane];
   float xv[VT][4];
   int cnt1 = 0;
   // query-camera unit ray (ibrnet.py:157-158)
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
       const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
       const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
       // feature map taps (align_corners=True, zeros)
+      float pv = 0.f;   // tap of the blend-projected map, channel = lane (< 32)
       {
         const Taps t = make_taps<true, false>(xn, yn, vw.w, vw.h);
         const float* base = feat + (size_t)v * vw.h * vw.w * C;
@@ -118,6 +126,12 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
             xv[v][j] = va * t.nw + vb * t.ne + vc * t.sw + vd * t.se;
           }
         }
+        if (bl1 && lane < 32) {
+          const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32 + lane;
+          const size_t p_nw = ((size_t)t.y0 * vw.w + t.x0) * 32, p_sw = p_nw + (size_t)vw.w * 32;
+          float va = a ? pb[p_nw] : 0.f, vb = b ? pb[p_nw + 32] : 0.f, vc = c ? pb[p_sw] : 0.f, vd = d ? pb[p_sw + 32] : 0.f;
+          pv = va * t.nw + vb * t.ne + vc * t.sw + vd * t.se;
+        }
       }
       // image taps: lanes 0..2 own the rgb planes
       if (lane < 3) {
@@ -128,25 +142,40 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
         float vc = (t.ms && t.mw) ? base[o_nw + vw.Wimg] : 0.f, vd = (t.ms && t.me) ? base[o_nw + vw.Wimg + 1] : 0.f;
         xv[v][3] = va * t.nw + vb * t.ne + vc * t.sw + vd * t.se;
       }
-      // materialise rgb_feat row and [vis, view-angle] row for the colour-blend head
-      float* row = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int ch = lane + 64 * j;
-        if (ch < C) row[3 + ch] = xv[v][j];
+      // view-angle features (ibrnet.py:144-167), wave-uniform
+      float tt[3] = {vw.cam[v][0] - X, vw.cam[v][1] - Y, vw.cam[v][2] - Z};
+      const float nt = sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f;
+      tt[0] /= nt; tt[1] /= nt; tt[2] /= nt;
+      const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+      const float nd = fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
+      const float ang[4] = {df[0] / nd, df[1] / nd, df[2] / nd, tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2]};
+      if (bl1) {
+        // colour-blend layer 1, per-(sample, view) part, by linearity of the bilinear tap (model.py:532-535):
+        //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap) = pv ; plus rgb / visibility / angle columns + bias
+        const float r = __shfl(xv[v][3], 0, 64), g = __shfl(xv[v][3], 1, 64), bb = __shfl(xv[v][3], 2, 64);
+        if (lane < 32) {
+          float o = pv + bbias;
+          o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
+          o = fmaf(bwr[3], visraw[v], o);
+          o = fmaf(bwr[4], ang[0], o); o = fmaf(bwr[5], ang[1], o); o = fmaf(bwr[6], ang[2], o); o = fmaf(bwr[7], ang[3], o);
+          bl1[((size_t)n * V + v) * 32 + lane] = o;
+        }
+        if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][3] : visraw[v];
       }
-      if (lane < 3) row[lane] = xv[v][3];
-      if (lane == 3) row[F] = 0.f;
-      if (lane == 0) {
-        float tt[3] = {vw.cam[v][0] - X, vw.cam[v][1] - Y, vw.cam[v][2] - Z};
-        float nt = sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f;
-        tt[0] /= nt; tt[1] /= nt; tt[2] /= nt;
-        float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
-        float nd = fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
-        float dot = tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2];
-        float* va = vis_ang + ((size_t)n * V + v) * 8;
-        *(float4*)va = make_float4(visraw[v], df[0] / nd, df[1] / nd, df[2] / nd);
-        *(float4*)(va + 4) = make_float4(dot, 0.f, 0.f, 0.f);
+      if (rgb_feat) {   // stage API only: materialise the raw multi-view projection and [vis, angle]
+        float* row = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int ch = lane + 64 * j;
+          if (ch < C) row[3 + ch] = xv[v][j];
+        }
+        if (lane < 3) row[lane] = xv[v][3];
+        if (lane == 3) row[F] = 0.f;
+        if (lane == 0 && vis_ang) {
+          float* va = vis_ang + ((size_t)n * V + v) * 8;
+          *(float4*)va = make_float4(visraw[v], ang[0], ang[1], ang[2]);
+          *(float4*)(va + 4) = make_float4(ang[3], 0.f, 0.f, 0.f);
+        }
       }
     }
   }
@@ -200,14 +229,18 @@ int nl_launch_mv_vis(const NlViews& vw, const float* visf_hwc, const float* dec_
 
 int nl_launch_mv_stats(const NlViews& vw, const float* images, const float* feat, int C, const float* xyz, int64_t N,
                        const float* vis_in, const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang,
-                       int* valid_s, hipStream_t st) {
+                       int* valid_s, const float* pfeat, const float* blw, float* bl1, float* rgbv, hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(N, 4));
-  if (vw.V <= 8)
-    hipLaunchKernelGGL(mv_stats_kernel<8>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s);
+  if (vw.V <= 4)
+    hipLaunchKernelGGL(mv_stats_kernel<4>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+  else if (vw.V <= 8)
+    hipLaunchKernelGGL(mv_stats_kernel<8>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+  else if (vw.V <= 10)
+    hipLaunchKernelGGL(mv_stats_kernel<10>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   else
-    hipLaunchKernelGGL(mv_stats_kernel<16>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s);
+    hipLaunchKernelGGL(mv_stats_kernel<16>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -200,7 +200,7 @@ class HipRenderer:
         valid = torch.empty(N, dtype=torch.int32, device=self.device)
         ws = self._workspace(self.lib.nl_mv_aggregate_workspace_bytes(ct.byref(self.cfg), V, N))
         L.check(self.lib.nl_mv_aggregate(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), N, mv.data_ptr(),
-                                         rgb_feat.data_ptr(), vis_ang.data_ptr(), valid.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate")
+                                         rgb_feat.data_ptr(), vis_ang.data_ptr(), valid.data_ptr(), None, None, ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate")
         return mv, rgb_feat.view(N, V, 196), vis_ang.view(N, V, 8), valid
 
     def point_mlp(self, xyz, direction, mv_feat, K: int = 8):
