@@ -32,7 +32,7 @@ int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, cons
 int nl_launch_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R,
                          float* z_out, hipStream_t st);
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
-                        int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st);
+                        int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst, hipStream_t st);
 
 struct NlPointFusedArgs {
   const float* xyz; const float* dir; int dir_stride, dir_div;
@@ -130,7 +130,9 @@ Layout make_layout(const nl_config* c) {
   set(G_T1O, 256, 32, true);
   set(G_CONVOUT, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
-  set(G_FEAT2, W, C, true);
+  // feat_mlp's last Linear is applied AFTER compositing (it is linear): K = [composited hidden (W) | sum of weights (1)],
+  // the bias row multiplies the weight sum (model.py:594-597)
+  set(G_FEAT2, W + 32, C, false);
   // colour-blend layer 1 split by linearity (model.py:532-535): per-sample part (feature_agg columns), and a per-frame
   // projection of the support feature maps through the feature columns (G_BLENDP, applied once per frame; the
   // per-(sample, view) value is then a bilinear tap of the projected map inside mv_stats)
@@ -265,7 +267,7 @@ struct Bump {
 struct MvBufs { float *vis, *dd, *g393, *t64; };
 struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; };
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
-struct HdBufs { float *sigma, *fth, *ft, *blA, *rgb_s; };
+struct HdBufs { float *sigma, *fth, *hc, *wsum, *blA, *rgb_s; };
 
 constexpr int LDG = 396, LDX = 288;
 
@@ -297,7 +299,7 @@ void carve_un(Bump& b, const nl_config* c, int64_t R, UnBufs& u) {
 }
 void carve_hd(Bump& b, const nl_config* c, int V, int64_t R, HdBufs& h) {
   const size_t N = (size_t)R * c->S;
-  h.sigma = b.take<float>(N); h.fth = b.take<float>(N * c->W); h.ft = b.take<float>(N * c->C);
+  h.sigma = b.take<float>(N); h.fth = b.take<float>(N * c->W); h.hc = b.take<float>((size_t)R * c->W); h.wsum = b.take<float>((size_t)R);
   h.blA = b.take<float>(N * 32); h.rgb_s = b.take<float>(N * 3);
 }
 
@@ -332,10 +334,10 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.seg[i].ptr = segs[i].ptr; a.seg[i].ld = segs[i].ld; a.seg[i].k = segs[i].k; a.seg[i].ioff = segs[i].ioff;
     a.seg[i].rdiv = segs[i].rdiv > 0 ? segs[i].rdiv : 1;
     a.seg[i].vec = ((((size_t)segs[i].ptr) & 15) == 0 && (segs[i].ld & 3) == 0) ? 1 : 0;
-    ksum += (segs[i].k + 3) & ~3;   // every segment occupies round_up(k, 4) slots of K-space
+    ksum += (segs[i].k + 31) & ~31;   // every segment occupies round_up(k, 32) slots of K-space (one k-tile = one segment)
   }
   const GemmDim& d = x.L.g[g];
-  if (ksum != ((d.K + 3) & ~3)) return NL_ERR_BAD_ARG;
+  if (ksum != ((d.K + 31) & ~31)) return NL_ERR_BAD_ARG;
   a.nseg = nseg; a.M = (int)M; a.K = d.K; a.N = d.N; a.Kpad = d.Kpad; a.Npad = d.Npad;
   if (x.c->precision == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
   else { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; }
@@ -475,14 +477,17 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
   if (want_feat) {
     SegSpec s0{FA, W, W, 0, 1};
     NL_TRY(run_gemm(x, G_FEAT0, &s0, 1, N, h.fth, W, NL_ACT_LRELU));
-    SegSpec s1{h.fth, W, W, 0, 1};
-    NL_TRY(run_gemm(x, G_FEAT2, &s1, 1, N, h.ft, C, NL_ACT_NONE));
   }
   SegSpec sa{FA, W, W, 0, 1};
   NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
   NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
                          x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
-  NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.ft : nullptr, valid_s, R, S, C, white, out, ray0, x.st));
+  NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
+                             want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st));
+  if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
+    SegSpec s1[2] = {{h.hc, W, W, 0, 1}, {h.wsum, 1, 1, 0, 1}};
+    NL_TRY(run_gemm(x, G_FEAT2, s1, 2, R, out->feat + ray0 * C, C, NL_ACT_NONE));
+  }
   if (out->sigma) NL_CHECK_HIP(hipMemcpyAsync(out->sigma + ray0 * S, h.sigma, sizeof(float) * N, hipMemcpyDeviceToDevice, x.st));
   return NL_OK;
 }
@@ -559,7 +564,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     P.copy(un[4 * u + 3], L.un_b[u], L.un_c[u] * L.un_l[u]);
   }
   P.linear(G_FEAT0, t[T_F0W], t[T_F0B]);
-  P.linear(G_FEAT2, t[T_F2W], t[T_F2B]);
+  P.block(G_FEAT2, 0, t[T_F2W], 0, W, 1, W);
+  P.block(G_FEAT2, W, t[T_F2B], 0, 1, 0, 1);   // bias as the K-row that meets the weight-sum column
   P.block(G_BLENDA, 0, t[T_BL0W], 0, W + F + 5, 1, W);
   P.block(G_BLENDP, 0, t[T_BL0W], W + 3, W + F + 5, 1, C);
   hipLaunchKernelGGL(pack_blw_kernel, dim3(2), dim3(256), 0, st, t[T_BL0W], t[T_BL0B], (float*)((char*)packed + L.blw), W, F);

@@ -72,15 +72,17 @@ __device__ __forceinline__ float4 load_a4(const NlGemmArgs& a, const RowMap& rm,
   return v;
 }
 
-// segment of padded-K position kg (every segment occupies round_up(k,4) slots) -> (segment, offset) or -1
-__device__ __forceinline__ int find_seg(const NlGemmArgs& a, int kg, int& kin) {
+// Every segment occupies round_up(k, 32) slots of K-space, so a 32-wide k-tile lies inside exactly ONE segment: the
+// lookup depends on k0 only, is wave-uniform, and `a.seg[s]` becomes scalar loads (a per-lane index into the kernarg
+// struct costs dependent vector loads / waterfall loops on every element).
+__device__ __forceinline__ int find_seg(const NlGemmArgs& a, int k0, int& kbase) {
   int s = -1, acc = 0;
   for (int j = 0; j < a.nseg; ++j) {
-    const int kp = (a.seg[j].k + 3) & ~3;
-    if (s < 0 && kg < acc + kp) { s = j; kin = kg - acc; }
+    const int kp = (a.seg[j].k + 31) & ~31;
+    if (s < 0 && k0 < acc + kp) { s = j; kbase = k0 - acc; }
     acc += kp;
   }
-  return s;
+  return __builtin_amdgcn_readfirstlane(s);
 }
 
 __device__ __forceinline__ int out_row(const NlGemmArgs& a, int m) {
@@ -113,8 +115,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const NlGemmArgs a) {
   float4 breg[NB4];
 
   auto prefetch = [&](int k0) {
-    int kin = 0;
-    const int s = find_seg(a, k0 + k4_a, kin);
+    int kbase = 0;
+    const int s = find_seg(a, k0, kbase);
+    const int kin = __builtin_amdgcn_readfirstlane(kbase) + k4_a;
 #pragma unroll
     for (int i = 0; i < 4; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a4(a, rm[i], s, kin) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -178,8 +181,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const NlGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ BF16 / BF16X3
-// LDS rows are 32 bf16 (64 B) padded to 80 B: a 16-lane ds_read_b128 group then touches 16 distinct
-// 16-B slots of the 256-B bank row.
+// 128 x BN x 32 tiles.  LDS rows are 32 bf16 (64 B) padded to 80 B: a 16-lane ds_read_b128 group then touches 16
+// distinct 16-B slots of the 256-B bank row (conflict-free).  fp32 -> bf16 hi/lo split uses v_cvt_pk_bf16_f32.
 constexpr int LDS_ROW = 40;  // in bf16 elements (80 B)
 
 template <int BN, bool X3>
@@ -190,32 +193,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const NlGemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short Bl[X3 ? BN * LDS_ROW : 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int k4_a = (tid & 7) * 4, row_a = tid >> 3;
+  const int k4_a = (tid & 7) * 4, row_a = tid >> 3;   // this thread stages A[row_a + 32*i][k4_a .. k4_a+3], i < 4
   int rdiv = 1;
   for (int s = 0; s < a.nseg; ++s) rdiv = a.seg[s].rdiv > rdiv ? a.seg[s].rdiv : rdiv;
   RowMap rm[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) rm[i] = map_row(a, m0 + row_a + 32 * i, rdiv);
 
-  // B: packed [Npad][Kpad] bf16 (k contiguous). Tile = BN rows x 32 k = BN*64 B -> BN*4 16-B chunks / 256 thr
-  constexpr int NBC = BN / 64;  // 16-B chunks per thread (BN=64 -> 1, 128 -> 2, 256 -> 4); BN=32 handled below
+  // B: packed [Npad][Kpad] bf16 (k contiguous). Tile = BN rows x 32 k = BN*64 B -> BN*4 16-B chunks / 256 threads
+  constexpr int NBC = BN / 64;  // 16-B chunks per thread per part
   const unsigned short* Bgh = (const unsigned short*)a.B;
   const unsigned short* Bgl = (const unsigned short*)a.Blo;
   float4 areg[4];
-  uint4 bh[NBC > 0 ? NBC : 1], bl[NBC > 0 ? NBC : 1];
+  uint4 bh[NBC], bl[NBC];
 
   auto prefetch = [&](int k0) {
-    int kin = 0;
-    const int s = find_seg(a, k0 + k4_a, kin);
+    int kbase = 0;
+    const int s = find_seg(a, k0, kbase);
+    const int kin = __builtin_amdgcn_readfirstlane(kbase) + k4_a;
 #pragma unroll
     for (int i = 0; i < 4; ++i) areg[i] = (s >= 0 && rm[i].ok) ? load_a4(a, rm[i], s, kin) : make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int NCH = (NBC > 0 ? NBC : 1);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      int idx = tid + 256 * j;        // chunk id: n = idx>>2, part = idx&3 (8 bf16 each)
-      int n = idx >> 2, part = idx & 3;
-      bool ok = (n < BN) && (n0 + n < a.Npad);
-      size_t off = (size_t)(n0 + n) * a.Kpad + k0 + part * 8;
+    for (int j = 0; j < NBC; ++j) {
+      const int idx = tid + 256 * j;        // chunk id: n = idx>>2, part = idx&3 (8 bf16 each)
+      const int n = idx >> 2, part = idx & 3;
+      const bool ok = (n0 + n < a.Npad);
+      const size_t off = (size_t)(n0 + n) * a.Kpad + k0 + part * 8;
       bh[j] = ok ? *(const uint4*)(Bgh + off) : make_uint4(0, 0, 0, 0);
       if (X3) bl[j] = ok ? *(const uint4*)(Bgl + off) : make_uint4(0, 0, 0, 0);
     }
@@ -232,39 +235,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const NlGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
-      unsigned short h[4], l[4];
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 h, l;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { h[j] = f2bf(v[j]); l[j] = X3 ? f2bf(v[j] - bf2f(h[j])) : 0; }
-      uint2 ph = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-      *(uint2*)&Ah[(row_a + 32 * i) * LDS_ROW + k4_a] = ph;
-      if (X3) {
-        uint2 pl = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
-        *(uint2*)&Al[(row_a + 32 * i) * LDS_ROW + k4_a] = pl;
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)v[j];
+        if (X3) l[j] = (__bf16)(v[j] - (float)h[j]);
       }
+      *(uint2*)&Ah[(row_a + 32 * i) * LDS_ROW + k4_a] = __builtin_bit_cast(uint2, h);
+      if (X3) *(uint2*)&Al[(row_a + 32 * i) * LDS_ROW + k4_a] = __builtin_bit_cast(uint2, l);
     }
-    constexpr int NCH = (NBC > 0 ? NBC : 1);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      int idx = tid + 256 * j;
-      int n = idx >> 2, part = idx & 3;
-      if (n < BN) {
-        *(uint4*)&Bh[n * LDS_ROW + part * 8] = bh[j];
-        if (X3) *(uint4*)&Bl[n * LDS_ROW + part * 8] = bl[j];
-      }
+    for (int j = 0; j < NBC; ++j) {
+      const int idx = tid + 256 * j;
+      const int n = idx >> 2, part = idx & 3;
+      *(uint4*)&Bh[n * LDS_ROW + part * 8] = bh[j];
+      if (X3) *(uint4*)&Bl[n * LDS_ROW + part * 8] = bl[j];
     }
     __syncthreads();
     if (k0 + BK < a.Kpad) prefetch(k0 + BK);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {  // two 16-deep MFMA k-steps per 32-wide tile
-      int ko = ks * 16 + 8 * (lane >> 5);
-      bf16x8 ah = *(const bf16x8*)&Ah[(32 * wave + (lane & 31)) * LDS_ROW + ko];
+    for (int ks = 0; ks < BK / 16; ++ks) {  // two 16-deep MFMA k-steps per 32-wide tile
+      const int ko = ks * 16 + 8 * (lane >> 5);
+      const bf16x8 ah = *(const bf16x8*)&Ah[(32 * wave + (lane & 31)) * LDS_ROW + ko];
       bf16x8 al;
       if (X3) al = *(const bf16x8*)&Al[(32 * wave + (lane & 31)) * LDS_ROW + ko];
 #pragma unroll
       for (int c = 0; c < BN / 32; ++c) {
-        bf16x8 bhv = *(const bf16x8*)&Bh[(32 * c + (lane & 31)) * LDS_ROW + ko];
+        const bf16x8 bhv = *(const bf16x8*)&Bh[(32 * c + (lane & 31)) * LDS_ROW + ko];
         if (X3) {
-          bf16x8 blv = *(const bf16x8*)&Bl[(32 * c + (lane & 31)) * LDS_ROW + ko];
+          const bf16x8 blv = *(const bf16x8*)&Bl[(32 * c + (lane & 31)) * LDS_ROW + ko];
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc[c], 0, 0, 0);
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc[c], 0, 0, 0);
         }

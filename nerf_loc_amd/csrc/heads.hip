@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
                                                         const int* __restrict__ valid_s, int R, int S, int C, int white_bkgd,
                                                         float* __restrict__ o_rgb, float* __restrict__ o_depth,
                                                         float* __restrict__ o_w, unsigned char* __restrict__ o_mask,
-                                                        float* __restrict__ o_unc, float* __restrict__ o_feat) {
+                                                        float* __restrict__ o_unc, float* __restrict__ o_feat, float* __restrict__ o_wsum) {
   __shared__ float wsh[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wv;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
     if (o_depth) o_depth[r] = dsum;
     if (o_unc) o_unc[r] = us;
     if (o_mask) o_mask[r] = nv > 8 ? 1 : 0;
+    if (o_wsum) o_wsum[r] = wsum;
   }
   if (o_feat && ft) {
     __builtin_amdgcn_wave_barrier();
@@ -196,8 +197,10 @@ int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t
   return NL_OK;
 }
 
+// `ft` (R*S, C) is composited into feat_dst (R, C) (any channel count; the caller passes feat_mlp's hidden layer, see abi.hip)
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s,
-                        int64_t R, int S, int C, int white_bkgd, const nl_render_out* out, int64_t ray0, hipStream_t st) {
+                        int64_t R, int S, int C, int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst,
+                        hipStream_t st) {
   if (R <= 0) return NL_OK;
   if (S > 256) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(R, 4));
@@ -206,9 +209,8 @@ int nl_launch_composite(const float* z_vals, const float* sigma, const float* rg
   float* o_w = out->weights ? out->weights + ray0 * S : nullptr;
   unsigned char* o_mask = out->mask ? out->mask + ray0 : nullptr;
   float* o_unc = out->depth_uncertainty ? out->depth_uncertainty + ray0 : nullptr;
-  float* o_feat = out->feat ? out->feat + ray0 * C : nullptr;
 #define NL_COMP(CH) hipLaunchKernelGGL(composite_kernel<CH>, grid, dim3(256), 0, st, z_vals, sigma, rgb_s, ft, valid_s, (int)R, S, C, \
-                                       white_bkgd, o_rgb, o_depth, o_w, o_mask, o_unc, o_feat)
+                                       white_bkgd, o_rgb, o_depth, o_w, o_mask, o_unc, feat_dst, wsum_dst)
   if (S <= 64) NL_COMP(1);
   else if (S <= 128) NL_COMP(2);
   else if (S <= 192) NL_COMP(3);
