@@ -14,6 +14,10 @@ int nl_knn_grid_build(NlKnnGrid* g, void* mem, const float* xyz, int64_t M, hipS
 int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* idx, float* d2, hipStream_t st);
 int nl_launch_chw_to_hwc(const float* src, float* dst, int V, int Cc, int HW, hipStream_t st);
 int nl_launch_mv_vis(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, float* vis_out, float* dd_out, hipStream_t st);
+size_t nl_mv_decoder_pack_bytes();
+int nl_pack_mv_decoder(const float* dec_valu_layout, void* out, hipStream_t st);
+int nl_launch_mv_vis_mfma(const NlViews& vw, const float* visf_hwc, const void* dpack, const float* xyz, int64_t N, float* vis_out,
+                          float* dd_out, bool x3, hipStream_t st);
 int nl_launch_mv_stats(const NlViews& vw, const float* images, const float* feat, int C, const float* xyz, int64_t N, const float* vis_in,
                        const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang, int* valid_s, const float* pfeat, const float* blw,
                        float* bl1, float* rgbv, hipStream_t st);
@@ -95,7 +99,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bias[G_COUNT];
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_bias, blw;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_bias, blw, dec_mfma;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];
   int un_c[U_COUNT], un_l[U_COUNT];
   size_t total;
@@ -160,6 +164,7 @@ Layout make_layout(const nl_config* c) {
     L.un_b[u] = take(4 * (size_t)uc[u] * ul[u]);
   }
   L.blw = take(4 * (256 + 32));
+  L.dec_mfma = take(nl_mv_decoder_pack_bytes());
   L.pt_bias = take(4 * 3 * (size_t)W);
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
   L.total = off;
@@ -373,7 +378,8 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
           float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m) {
   const NlViews vw = with_query(f, qc);
   if (bl1) NL_TRY(ensure_pfeat(x, f));
-  NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
+  if (x.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
+  else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x.p<char>(x.L.dec_mfma), xyz, N, m.vis, m.dd, x.c->precision == NL_PREC_BF16X3, x.st));
   NL_TRY(nl_launch_mv_stats(vw, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, f->pfeat,
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
   SegSpec s0{m.g393, LDG, 2 * (f->C + 3) + 3, 0, 1};
@@ -580,6 +586,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     P.copy(q[2], o + 4 * 1056, 1024); P.copy(q[3], o + 4 * 2080, 32);
     P.copy(q[4], o + 4 * 2112, 32 * nout); P.copy(q[5], o + 4 * 2176, nout);
   }
+  if (nl_pack_mv_decoder((const float*)((char*)packed + L.dec_w), (char*)packed + L.dec_mfma, st) != NL_OK) return NL_ERR_HIP;
   P.copy(t[T_SIGW], L.sig_w, W); P.copy(t[T_SIGB], L.sig_b, 1);
   P.copy(t[T_BL2W], L.bl2_w, 512); P.copy(t[T_BL2B], L.bl2_b, 16);
   P.copy(t[T_BL4W], L.bl4_w, 16); P.copy(t[T_BL4B], L.bl4_b, 1);

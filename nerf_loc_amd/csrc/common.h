@@ -27,6 +27,9 @@ enum { NL_ACT_NONE = 0, NL_ACT_LRELU = 1, NL_ACT_ELU = 2 };
 
 __device__ __forceinline__ float nl_lrelu(float x) { return x > 0.f ? x : x * 0.01f; }
 __device__ __forceinline__ float nl_elu(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU with the negative branch on the hardware exp2 unit (abs error <= ~2e-7 on a quantity in (-1, 0]); used by the MFMA
+// decoder kernel where 192 ELUs per row would otherwise dominate
+__device__ __forceinline__ float nl_elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 __device__ __forceinline__ float nl_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float nl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float nl_act(float x, int act) {

@@ -177,7 +177,7 @@ __device__ __forceinline__ float node_mindist2(const QueryCtx& c, unsigned m, in
 }
 
 // Scan up to 32 point ranges (lane r < 32 holds (rs, len)) into the replicated best-K list.
-template <int K>
+template <int K, bool DEDUPE>
 __device__ __forceinline__ void scan_ranges(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, u64 (&best)[K]) {
   int pin = len;
 #pragma unroll
@@ -207,6 +207,12 @@ __device__ __forceinline__ void scan_ranges(const QueryCtx& c, const float4* __r
       d = __fadd_rn(d, __fmul_rn(ddy, ddy));
       d = __fadd_rn(d, __fmul_rn(ddz, ddz));
       key = ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+      if (DEDUPE) {   // phase 2 revisits the points phase 1 already selected: keys are unique per point
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < K; ++i) dup |= (key == best[i]);
+        if (dup) key = ~0ull;
+      }
     }
     while (true) {   // wave-level selection
       const bool cont = key < best[K - 1];
@@ -260,11 +266,9 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   }
   {
     const int rs0 = starts[m << (3 * L)], len0 = starts[(m + 1) << (3 * L)] - rs0;
-    scan_ranges<K>(c, sorted, lane == 0 ? rs0 : 0, lane == 0 ? len0 : 0, lane, best);
+    scan_ranges<K, false>(c, sorted, lane == 0 ? rs0 : 0, lane == 0 ? len0 : 0, lane, best);
   }
   float U = best[K - 1] != ~0ull ? __uint_as_float((unsigned)(best[K - 1] >> 32)) : 3.4e38f;
-#pragma unroll
-  for (int i = 0; i < K; ++i) best[i] = ~0ull;   // phase 2 revisits those points; restart to avoid duplicates
 
   // ---------------------------------------------------------------- phase 2: pruned breadth-first descent
   unsigned* front = s_front[wv][0];
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
     for (int b = 0; b < nleaf; b += 32) {
       const int i = b + lane;
       const bool ok = lane < 32 && i < nleaf;
-      scan_ranges<K>(c, sorted, ok ? leaf_s[i] : 0, ok ? leaf_l[i] : 0, lane, best);
+      scan_ranges<K, true>(c, sorted, ok ? leaf_s[i] : 0, ok ? leaf_l[i] : 0, lane, best);
     }
     nleaf = 0;
     if (best[K - 1] != ~0ull) U = fminf(U, __uint_as_float((unsigned)(best[K - 1] >> 32)));
