@@ -18,7 +18,7 @@ size_t nl_mv_decoder_pack_bytes();
 int nl_pack_mv_decoder(const float* dec_valu_layout, void* out, hipStream_t st);
 int nl_launch_mv_vis_mfma(const NlViews& vw, const float* visf_hwc, const void* dpack, const float* xyz, int64_t N, float* vis_out,
                           float* dd_out, bool x3, hipStream_t st);
-int nl_launch_mv_stats(const NlViews& vw, const float* images, const float* feat, int C, const float* xyz, int64_t N, const float* vis_in,
+int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* xyz, int64_t N, const float* vis_in,
                        const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang, int* valid_s, const float* pfeat, const float* blw,
                        float* bl1, float* rgbv, hipStream_t st);
 int nl_launch_point_encode(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx, const float* d2,
@@ -255,6 +255,8 @@ struct nl_frame {
   uint4* fhi; uint4* flo;   // bf16 hi / lo split of sp_feat, [M][208]
   float* pfeat;             // (V,h,w,32) feature maps projected through the blend layer's feature columns
   const void* pfeat_for;    // packed weights pfeat was computed with (lazily, first render of the frame)
+  float* views_dev;         // device copy of the per-view matrices: [16][12] proj_ibr rows, then [16][3] camera centres
+  float views_host[16 * 15];
 };
 
 namespace {
@@ -380,7 +382,7 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
   if (bl1) NL_TRY(ensure_pfeat(x, f));
   if (x.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
   else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x.p<char>(x.L.dec_mfma), xyz, N, m.vis, m.dd, x.c->precision == NL_PREC_BF16X3, x.st));
-  NL_TRY(nl_launch_mv_stats(vw, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, f->pfeat,
+  NL_TRY(nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, f->pfeat,
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
   SegSpec s0{m.g393, LDG, 2 * (f->C + 3) + 3, 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
@@ -610,7 +612,7 @@ static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
   if (!desc_ok(cfg, d)) return 0;
   return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256) +
-         nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256);
+         nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + 1024;
 }
 
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
@@ -642,6 +644,13 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
     if (rc == NL_OK) rc = nl_split_feature_table(d->sp_feature, d->M, cfg->C + 3, f->fhi, f->flo, st);
     f->pfeat = (float*)((char*)f->flo + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
     f->pfeat_for = nullptr;
+    f->views_dev = (float*)((char*)f->pfeat + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256));
+    memset(f->views_host, 0, sizeof(f->views_host));
+    for (int v = 0; v < d->V; ++v) {
+      memcpy(f->views_host + 12 * v, d->proj_ibr + 12 * v, 48);
+      memcpy(f->views_host + 192 + 3 * v, d->cam_centers + 3 * v, 12);
+    }
+    if (rc == NL_OK && hipMemcpyAsync(f->views_dev, f->views_host, sizeof(f->views_host), hipMemcpyHostToDevice, st) != hipSuccess) rc = NL_ERR_HIP;
   }
   if (rc != NL_OK) { delete f; return rc; }
   *out = f;

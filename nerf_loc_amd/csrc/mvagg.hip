@@ -252,8 +252,16 @@ __global__ void pack_mv_decoder_kernel(const float* __restrict__ dec /* packed V
   } else if (i < 8192 + 520) { const int e = i - 8192 - 512; of[512 + e] = dec[(e >> 1) * DEC_STRIDE + 2176 + (e & 1)]; }   // b4
 }
 
+__device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// One wave per sample.  Phase A: lane v (< V) does view v's scalar work once — IBRNet projection, tap offsets / weights for
+// the feature map and the image (validity folded into zero weights + clamped offsets, so phase-B loads are unconditional),
+// view-angle features, visibility weight.  Phase B: unrolled loop over views; the per-view scalars come from
+// v_readlane with a constant lane (-> SGPRs), lanes span channels (64 lanes x 3 floats = one 768-B texel row per tap).
 template <int VT>
-__global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const float* __restrict__ images /*(V,3,H,W)*/,
+__global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
+                                                       const float* __restrict__ images /*(V,3,H,W)*/,
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
                                                        const float* __restrict__ xyz, int N,
                                                        const float* __restrict__ vis_in, const float* __restrict__ dd_in,
@@ -269,97 +277,100 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
   const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
   const int F = C + 3;
 
-  float wgt[VT], dd[VT];
-  float vsum = 0.f;
+  // ---------------------------------------------------------------- phase A (lane = view)
+  const int vl = lane < V ? lane : 0;
+  const bool vact = lane < V;
+  float a_fw[4], a_iw[4];   // tap weights (nw, ne, sw, se), zero where the tap is outside
+  int a_fo[4], a_io[4];     // clamped tap offsets: feature map in texels, image in pixels
+  float a_ang[4], a_vis, a_dd, a_wgt;
+  int cnt1;
+  {
+    const float4 p0 = *(const float4*)(viewsdev + 12 * vl), p1 = *(const float4*)(viewsdev + 12 * vl + 4), p2 = *(const float4*)(viewsdev + 12 * vl + 8);
+    const float cx = fmaf(p0.z, Z, fmaf(p0.y, Y, p0.x * X)) + p0.w;
+    const float cy = fmaf(p1.z, Z, fmaf(p1.y, Y, p1.x * X)) + p1.w;
+    const float cz = fmaf(p2.z, Z, fmaf(p2.y, Y, p2.x * X)) + p2.w;
+    const float zc = fmaxf(cz, 1e-8f);
+    float px = cx / zc, py = cy / zc;
+    px = fminf(fmaxf(px, -1e6f), 1e6f);
+    py = fminf(fmaxf(py, -1e6f), 1e6f);
+    const bool m1 = vact && (px <= (float)vw.Wimg - 1.f) && (px >= 0.f) && (py <= (float)vw.H - 1.f) && (py >= 0.f) && (cz > 0.f);
+    cnt1 = __popcll(__ballot(m1));
+    const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
+    const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
+    {
+      const Taps t = make_taps<true, false>(xn, yn, vw.w, vw.h);
+      const int x0 = t.mw ? t.x0 : 0, x1 = t.me ? t.x0 + 1 : 0, y0 = t.mn ? t.y0 : 0, y1 = t.ms ? t.y0 + 1 : 0;
+      a_fo[0] = y0 * vw.w + x0; a_fo[1] = y0 * vw.w + x1; a_fo[2] = y1 * vw.w + x0; a_fo[3] = y1 * vw.w + x1;
+      a_fw[0] = (t.mn && t.mw) ? t.nw : 0.f; a_fw[1] = (t.mn && t.me) ? t.ne : 0.f;
+      a_fw[2] = (t.ms && t.mw) ? t.sw : 0.f; a_fw[3] = (t.ms && t.me) ? t.se : 0.f;
+    }
+    {
+      const Taps t = make_taps<true, false>(xn, yn, vw.Wimg, vw.H);
+      const int x0 = t.mw ? t.x0 : 0, x1 = t.me ? t.x0 + 1 : 0, y0 = t.mn ? t.y0 : 0, y1 = t.ms ? t.y0 + 1 : 0;
+      a_io[0] = y0 * vw.Wimg + x0; a_io[1] = y0 * vw.Wimg + x1; a_io[2] = y1 * vw.Wimg + x0; a_io[3] = y1 * vw.Wimg + x1;
+      a_iw[0] = (t.mn && t.mw) ? t.nw : 0.f; a_iw[1] = (t.mn && t.me) ? t.ne : 0.f;
+      a_iw[2] = (t.ms && t.mw) ? t.sw : 0.f; a_iw[3] = (t.ms && t.me) ? t.se : 0.f;
+    }
+    // view-angle features (ibrnet.py:144-167)
+    float tq[3] = {vw.qcam[0] - X, vw.qcam[1] - Y, vw.qcam[2] - Z};
+    const float nq = sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f;
+    tq[0] /= nq; tq[1] /= nq; tq[2] /= nq;
+    float tt[3] = {viewsdev[192 + 3 * vl] - X, viewsdev[192 + 3 * vl + 1] - Y, viewsdev[192 + 3 * vl + 2] - Z};
+    const float nt = sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f;
+    tt[0] /= nt; tt[1] /= nt; tt[2] /= nt;
+    const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+    const float nd = fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
+    a_ang[0] = df[0] / nd; a_ang[1] = df[1] / nd; a_ang[2] = df[2] / nd;
+    a_ang[3] = tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2];
+    a_vis = vact ? vis_in[(size_t)vl * N + n] : 0.f;
+    a_dd = vact ? dd_in[(size_t)vl * N + n] : 0.f;
+    // weight = vis / (sum_v vis + 1e-8): sequential sum over views like the reference's reduction
+    float vsum = 0.f;
 #pragma unroll
-  for (int v = 0; v < VT; ++v) {
-    wgt[v] = v < V ? vis_in[(size_t)v * N + n] : 0.f;
-    dd[v] = v < V ? dd_in[(size_t)v * N + n] : 0.f;
-    vsum += wgt[v];
+    for (int v = 0; v < VT; ++v) vsum += v < V ? rl(a_vis, v) : 0.f;
+    a_wgt = a_vis / (vsum + 1e-8f);
   }
-  float visraw[VT];
-#pragma unroll
-  for (int v = 0; v < VT; ++v) { visraw[v] = wgt[v]; wgt[v] = wgt[v] / (vsum + 1e-8f); }
 
+  // ---------------------------------------------------------------- phase B (lanes = channels)
   float bwr[8], bbias = 0.f;   // this lane's row (j = lane < 32) of the small blend-layer weights
 #pragma unroll
   for (int i = 0; i < 8; ++i) bwr[i] = (bl1 && lane < 32) ? blw[lane * 8 + i] : 0.f;
   if (bl1 && lane < 32) bbias = blw[256 + lane];
   float xv[VT][4];
-  int cnt1 = 0;
-  // query-camera unit ray (ibrnet.py:157-158)
-  float tq[3] = {vw.qcam[0] - X, vw.qcam[1] - Y, vw.qcam[2] - Z};
-  {
-    float nq = sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f;
-    tq[0] /= nq; tq[1] /= nq; tq[2] /= nq;
-  }
+  const int lch = lane < 3 ? lane : 0;
 #pragma unroll
   for (int v = 0; v < VT; ++v) {
     xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = 0.f;
     if (v < V) {
-      const float* P = vw.P1[v];
-      const float cx = fmaf(P[2], Z, fmaf(P[1], Y, P[0] * X)) + P[3];
-      const float cy = fmaf(P[6], Z, fmaf(P[5], Y, P[4] * X)) + P[7];
-      const float cz = fmaf(P[10], Z, fmaf(P[9], Y, P[8] * X)) + P[11];
-      const float zc = fmaxf(cz, 1e-8f);
-      float px = cx / zc, py = cy / zc;
-      px = fminf(fmaxf(px, -1e6f), 1e6f);
-      py = fminf(fmaxf(py, -1e6f), 1e6f);
-      const bool m1 = (px <= (float)vw.Wimg - 1.f) && (px >= 0.f) && (py <= (float)vw.H - 1.f) && (py >= 0.f) && (cz > 0.f);
-      cnt1 += m1 ? 1 : 0;
-      const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
-      const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
-      // feature map taps (align_corners=True, zeros)
-      float pv = 0.f;   // tap of the blend-projected map, channel = lane (< 32)
-      {
-        const Taps t = make_taps<true, false>(xn, yn, vw.w, vw.h);
-        const float* base = feat + (size_t)v * vw.h * vw.w * C;
-        const size_t o_nw = ((size_t)t.y0 * vw.w + t.x0) * C, o_ne = o_nw + C, o_sw = o_nw + (size_t)vw.w * C, o_se = o_sw + C;
-        const bool a = t.mn && t.mw, b = t.mn && t.me, c = t.ms && t.mw, d = t.ms && t.me;
+      const float w0 = rl(a_fw[0], v), w1 = rl(a_fw[1], v), w2 = rl(a_fw[2], v), w3 = rl(a_fw[3], v);
+      const int o0 = rli(a_fo[0], v), o1 = rli(a_fo[1], v), o2 = rli(a_fo[2], v), o3 = rli(a_fo[3], v);
+      const float* fb = feat + (size_t)v * vw.h * vw.w * C;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int ch = lane + 64 * j;
-          if (ch < C) {
-            float va = a ? base[o_nw + ch] : 0.f, vb = b ? base[o_ne + ch] : 0.f;
-            float vc = c ? base[o_sw + ch] : 0.f, vd = d ? base[o_se + ch] : 0.f;
-            xv[v][j] = va * t.nw + vb * t.ne + vc * t.sw + vd * t.se;
-          }
-        }
-        if (bl1 && lane < 32) {
-          const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32 + lane;
-          const size_t p_nw = ((size_t)t.y0 * vw.w + t.x0) * 32, p_sw = p_nw + (size_t)vw.w * 32;
-          float va = a ? pb[p_nw] : 0.f, vb = b ? pb[p_nw + 32] : 0.f, vc = c ? pb[p_sw] : 0.f, vd = d ? pb[p_sw + 32] : 0.f;
-          pv = va * t.nw + vb * t.ne + vc * t.sw + vd * t.se;
-        }
+      for (int j = 0; j < 3; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < C) xv[v][j] = fb[(size_t)o0 * C + ch] * w0 + fb[(size_t)o1 * C + ch] * w1 + fb[(size_t)o2 * C + ch] * w2 + fb[(size_t)o3 * C + ch] * w3;
       }
-      // image taps: lanes 0..2 own the rgb planes
-      if (lane < 3) {
-        const Taps t = make_taps<true, false>(xn, yn, vw.Wimg, vw.H);
-        const float* base = images + ((size_t)v * 3 + lane) * vw.H * vw.Wimg;
-        const size_t o_nw = (size_t)t.y0 * vw.Wimg + t.x0;
-        float va = (t.mn && t.mw) ? base[o_nw] : 0.f, vb = (t.mn && t.me) ? base[o_nw + 1] : 0.f;
-        float vc = (t.ms && t.mw) ? base[o_nw + vw.Wimg] : 0.f, vd = (t.ms && t.me) ? base[o_nw + vw.Wimg + 1] : 0.f;
-        xv[v][3] = va * t.nw + vb * t.ne + vc * t.sw + vd * t.se;
+      {
+        const float i0 = rl(a_iw[0], v), i1 = rl(a_iw[1], v), i2 = rl(a_iw[2], v), i3 = rl(a_iw[3], v);
+        const int q0 = rli(a_io[0], v), q1 = rli(a_io[1], v), q2 = rli(a_io[2], v), q3 = rli(a_io[3], v);
+        const float* ib = images + ((size_t)v * 3 + lch) * vw.H * vw.Wimg;
+        const float val = ib[q0] * i0 + ib[q1] * i1 + ib[q2] * i2 + ib[q3] * i3;
+        xv[v][3] = lane < 3 ? val : 0.f;
       }
-      // view-angle features (ibrnet.py:144-167), wave-uniform
-      float tt[3] = {vw.cam[v][0] - X, vw.cam[v][1] - Y, vw.cam[v][2] - Z};
-      const float nt = sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f;
-      tt[0] /= nt; tt[1] /= nt; tt[2] /= nt;
-      const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
-      const float nd = fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
-      const float ang[4] = {df[0] / nd, df[1] / nd, df[2] / nd, tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2]};
+      const float s_vis = rl(a_vis, v);
       if (bl1) {
         // colour-blend layer 1, per-(sample, view) part, by linearity of the bilinear tap (model.py:532-535):
-        //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap) = pv ; plus rgb / visibility / angle columns + bias
-        const float r = __shfl(xv[v][3], 0, 64), g = __shfl(xv[v][3], 1, 64), bb = __shfl(xv[v][3], 2, 64);
-        if (lane < 32) {
-          float o = pv + bbias;
-          o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
-          o = fmaf(bwr[3], visraw[v], o);
-          o = fmaf(bwr[4], ang[0], o); o = fmaf(bwr[5], ang[1], o); o = fmaf(bwr[6], ang[2], o); o = fmaf(bwr[7], ang[3], o);
-          bl1[((size_t)n * V + v) * 32 + lane] = o;
-        }
-        if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][3] : visraw[v];
+        //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap); plus rgb / visibility / angle columns + bias
+        const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32 + (lane & 31);
+        const float pv = pb[(size_t)o0 * 32] * w0 + pb[(size_t)o1 * 32] * w1 + pb[(size_t)o2 * 32] * w2 + pb[(size_t)o3 * 32] * w3;
+        const float r = rl(xv[v][3], 0), g = rl(xv[v][3], 1), bb = rl(xv[v][3], 2);
+        float o = pv + bbias;
+        o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
+        o = fmaf(bwr[3], s_vis, o);
+        o = fmaf(bwr[4], rl(a_ang[0], v), o); o = fmaf(bwr[5], rl(a_ang[1], v), o);
+        o = fmaf(bwr[6], rl(a_ang[2], v), o); o = fmaf(bwr[7], rl(a_ang[3], v), o);
+        if (lane < 32) bl1[((size_t)n * V + v) * 32 + lane] = o;
+        if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][3] : s_vis;
       }
       if (rgb_feat) {   // stage API only: materialise the raw multi-view projection and [vis, angle]
         float* row = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
@@ -372,22 +383,25 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
         if (lane == 3) row[F] = 0.f;
         if (lane == 0 && vis_ang) {
           float* va = vis_ang + ((size_t)n * V + v) * 8;
-          *(float4*)va = make_float4(visraw[v], ang[0], ang[1], ang[2]);
-          *(float4*)(va + 4) = make_float4(ang[3], 0.f, 0.f, 0.f);
+          *(float4*)va = make_float4(s_vis, rl(a_ang[0], v), rl(a_ang[1], v), rl(a_ang[2], v));
+          *(float4*)(va + 4) = make_float4(rl(a_ang[3], v), 0.f, 0.f, 0.f);
         }
       }
     }
   }
   // visibility-weighted mean / variance over views (ibrnet.py:8-12)
+  float wg[VT];
+#pragma unroll
+  for (int v = 0; v < VT; ++v) wg[v] = v < V ? rl(a_wgt, v) : 0.f;
   float* g = g393 + (size_t)n * ldg;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float mean = 0.f;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) mean += xv[v][j] * wgt[v];
+    for (int v = 0; v < VT; ++v) mean += xv[v][j] * wg[v];
     float var = 0.f;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) { float d = xv[v][j] - mean; var += wgt[v] * (d * d); }
+    for (int v = 0; v < VT; ++v) { float d = xv[v][j] - mean; var += wg[v] * (d * d); }
     int pos = -1;
     if (j < 3) { int ch = lane + 64 * j; if (ch < C) pos = 3 + ch; }
     else if (lane < 3) pos = lane;
@@ -396,10 +410,10 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
   if (lane == 0) {
     float mean = 0.f, wsum = 0.f;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) { mean += dd[v] * wgt[v]; wsum += wgt[v]; }
+    for (int v = 0; v < VT; ++v) { if (v < V) { mean += rl(a_dd, v) * wg[v]; wsum += wg[v]; } }
     float var = 0.f;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) { float d = dd[v] - mean; var += wgt[v] * (d * d); }
+    for (int v = 0; v < VT; ++v) { if (v < V) { float d = rl(a_dd, v) - mean; var += wg[v] * (d * d); } }
     g[2 * F] = mean;
     g[2 * F + 1] = var;
     g[2 * F + 2] = wsum / (float)V;
@@ -445,20 +459,20 @@ int nl_launch_mv_vis_mfma(const NlViews& vw, const float* visf_hwc, const void* 
   return NL_OK;
 }
 
-int nl_launch_mv_stats(const NlViews& vw, const float* images, const float* feat, int C, const float* xyz, int64_t N,
+int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* xyz, int64_t N,
                        const float* vis_in, const float* dd_in, float* g393, int ldg, float* rgb_feat, float* vis_ang,
                        int* valid_s, const float* pfeat, const float* blw, float* bl1, float* rgbv, hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(N, 4));
   if (vw.V <= 4)
-    hipLaunchKernelGGL(mv_stats_kernel<4>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    hipLaunchKernelGGL(mv_stats_kernel<4>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   else if (vw.V <= 8)
-    hipLaunchKernelGGL(mv_stats_kernel<8>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    hipLaunchKernelGGL(mv_stats_kernel<8>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   else if (vw.V <= 10)
-    hipLaunchKernelGGL(mv_stats_kernel<10>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    hipLaunchKernelGGL(mv_stats_kernel<10>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   else
-    hipLaunchKernelGGL(mv_stats_kernel<16>, grid, dim3(256), 0, st, vw, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    hipLaunchKernelGGL(mv_stats_kernel<16>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
