@@ -41,14 +41,14 @@ int nl_launch_composite(const float* z_vals, const float* sigma, const float* rg
 struct NlPointFusedArgs {
   const float* xyz; const float* dir; int dir_stride, dir_div;
   const int* idx; const float* Q; float* O;
-  const uint4* fhi; const uint4* flo;
+  const float* ptt;
   const float* sp_xyz; const float* sp_dir;
   const uint4* wstream; const float* bias; const float* rd_w;
   int N, M; float inv_span;
 };
 size_t nl_point_stream_bytes(int W);
 int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
-int nl_split_feature_table(const float* src, int64_t M, int F, void* hi, void* lo, hipStream_t st);
+int nl_pack_ptt(const float* w1, const float* b1, int W, int F, int Kpad, int Npad, float* B32, float* bias, hipStream_t st);
 int nl_launch_wscale(const int* idx, const float* d2, const float* conf, int64_t N, int K, int64_t M, float* wscale, hipStream_t st);
 bool nl_point_fused_supported(int W, int precision);
 int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
@@ -89,7 +89,7 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -142,6 +142,8 @@ Layout make_layout(const nl_config* c) {
   // per-(sample, view) value is then a bilinear tap of the projected map inside mv_stats)
   set(G_BLENDA, W, 32, false);
   set(G_BLENDP, C, 32, false);
+  // per-frame neural-point table T = sp_feature . base_mlp.0.weight[:, :F]^T + bias, columns in accumulator order (point_fused.hip)
+  set(G_PTT, F, W, true);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
   for (int i = 0; i < G_COUNT; ++i) {
@@ -252,7 +254,8 @@ struct nl_frame {
   const float* sp_xyz; const float* sp_feat; const float* sp_conf; const float* sp_dir;
   int64_t M;
   NlKnnGrid grid;
-  uint4* fhi; uint4* flo;   // bf16 hi / lo split of sp_feat, [M][208]
+  float* ptt;               // [(M+1)][W] table T (see G_PTT), built lazily per (frame, weights); row M = bias
+  const void* ptt_for;
   float* pfeat;             // (V,h,w,32) feature maps projected through the blend layer's feature columns
   const void* pfeat_for;    // packed weights pfeat was computed with (lazily, first render of the frame)
   float* views_dev;         // device copy of the per-view matrices: [16][12] proj_ibr rows, then [16][3] camera centres
@@ -376,6 +379,24 @@ int ensure_pfeat(const Ctx& x, const nl_frame* fc) {
   return NL_OK;
 }
 
+// per-frame table T for the fused point kernel (exact fp32 MFMA), once per (frame, weights)
+int ensure_ptt(const Ctx& x, const nl_frame* fc) {
+  nl_frame* f = const_cast<nl_frame*>(fc);
+  if (f->ptt_for == (const void*)x.pk) return NL_OK;
+  const int W = x.c->W, F = f->C + 3;
+  nl_config c32 = *x.c;
+  c32.precision = NL_PREC_F32;
+  Ctx x32 = x;
+  x32.c = &c32;
+  if (f->M > 0) {
+    SegSpec s{f->sp_feat, F, F, 0, 1};
+    NL_TRY(run_gemm(x32, G_PTT, &s, 1, f->M, f->ptt, W, NL_ACT_NONE));
+  }
+  NL_CHECK_HIP(hipMemcpyAsync(f->ptt + (size_t)f->M * W, x.pk + x.L.bias[G_PTT], sizeof(float) * W, hipMemcpyDeviceToDevice, x.st));
+  f->ptt_for = (const void*)x.pk;
+  return NL_OK;
+}
+
 int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
           float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m) {
   const NlViews vw = with_query(f, qc);
@@ -398,10 +419,11 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   SegSpec sg{G, W, W, 0, 1};
   NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
   if (K == 8 && nl_point_fused_supported(W, x.c->precision)) {
+    NL_TRY(ensure_ptt(x, f));
     NL_TRY(nl_launch_wscale(p.idx, p.d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
     NlPointFusedArgs a;
     a.xyz = xyz; a.dir = dir; a.dir_stride = dir_stride; a.dir_div = dir_div > 0 ? dir_div : 1;
-    a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.fhi = f->fhi; a.flo = f->flo; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
+    a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
     a.wstream = x.p<uint4>(x.L.pt_stream); a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
     a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
     NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));
@@ -576,6 +598,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.block(G_FEAT2, W, t[T_F2B], 0, 1, 0, 1);   // bias as the K-row that meets the weight-sum column
   P.block(G_BLENDA, 0, t[T_BL0W], 0, W + F + 5, 1, W);
   P.block(G_BLENDP, 0, t[T_BL0W], W + 3, W + F + 5, 1, C);
+  if (nl_pack_ptt(t[T_B0W], t[T_B0B], W, F, L.g[G_PTT].Kpad, L.g[G_PTT].Npad, (float*)((char*)packed + L.b32[G_PTT]),
+                  (float*)((char*)packed + L.bias[G_PTT]), st) != NL_OK) return NL_ERR_HIP;
   hipLaunchKernelGGL(pack_blw_kernel, dim3(2), dim3(256), 0, st, t[T_BL0W], t[T_BL0B], (float*)((char*)packed + L.blw), W, F);
   // small VALU-side weights
   P.copy(t[T_RD0W], L.rd_w, 64); P.copy(t[T_RD0B], L.rd_w + 4 * 64, 16);
@@ -611,7 +635,7 @@ static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
 
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
   if (!desc_ok(cfg, d)) return 0;
-  return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + 2 * nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256) +
+  return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + nl_align_up((size_t)(d->M + 1) * cfg->W * 4, 256) +
          nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + 1024;
 }
 
@@ -639,10 +663,9 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
   if (rc == NL_OK) rc = nl_knn_grid_build(&f->grid, (char*)mem + nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256), d->sp_xyz, d->M, st);
   {
     char* p = (char*)mem + nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
-    f->fhi = (uint4*)p;
-    f->flo = (uint4*)(p + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
-    if (rc == NL_OK) rc = nl_split_feature_table(d->sp_feature, d->M, cfg->C + 3, f->fhi, f->flo, st);
-    f->pfeat = (float*)((char*)f->flo + nl_align_up((size_t)(d->M > 0 ? d->M : 1) * 208 * 2, 256));
+    f->ptt = (float*)p;
+    f->ptt_for = nullptr;
+    f->pfeat = (float*)(p + nl_align_up((size_t)(d->M + 1) * cfg->W * 4, 256));
     f->pfeat_for = nullptr;
     f->views_dev = (float*)((char*)f->pfeat + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256));
     memset(f->views_host, 0, sizeof(f->views_host));

@@ -29,7 +29,7 @@ struct NlPointFusedArgs {
   const int* idx;          // (N,8) neighbour indices
   const float* Q;          // (N,128) query projection (w_qs . mv_feat)
   float* O;                // (N,128) attention output
-  const uint4* fhi; const uint4* flo;  // [M][26] uint4 = [M][208] bf16 feature table, hi / lo parts
+  const float* ptt;        // [(M+1)][W] per-frame table T = sp_feature . W1[:, :F]^T + b1 in accumulator order; row M = b1 only
   const float* sp_xyz; const float* sp_dir;
   const uint4* wstream;    // packed weight stream (pack_point_stream_kernel)
   const float* bias;       // [3][W] base_mlp biases
@@ -40,8 +40,8 @@ struct NlPointFusedArgs {
 
 namespace {
 
-constexpr int L1_KSTEPS = 19;   // 13 feature + 4 posenc + 2 ray_diff_fc k-steps (K = 304 incl. zero padding)
-constexpr int L1_CHUNKS = 10;
+constexpr int L1_KSTEPS = 6;    // 4 posenc + 2 ray_diff_fc k-steps (K = 96); the 195 feature columns come from the per-frame table T
+constexpr int L1_CHUNKS = 3;
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -94,18 +94,18 @@ constexpr int NBUF = 4;   // LDS ring: chunk g lives in buffer g % 4, three chun
 struct PfScalars { int dir_stride, dir_div, N, M; float inv_span; };
 struct PfView {   // what the body calls `a.` : plain locals, nothing escapes
   const float* xyz; const float* dir; int dir_stride, dir_div; const int* idx; const float* Q; float* O;
-  const uint4* fhi; const uint4* flo; const float* sp_xyz; const float* sp_dir; const uint4* wstream;
+  const float* ptt; const float* sp_xyz; const float* sp_dir; const uint4* wstream;
   const float* bias; const float* rd_w; int N, M; float inv_span;
 };
 
 template <int NRT, bool X3>
 __global__ __launch_bounds__(256, 1) void point_fused_kernel(
     const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
-    float* __restrict__ p_O, const uint4* __restrict__ p_fhi, const uint4* __restrict__ p_flo, const float* __restrict__ p_sp_xyz,
+    float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
     const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const float* __restrict__ p_bias,
     const float* __restrict__ p_rd_w, const PfScalars sc) {
   const float* __restrict__ rd_w = p_rd_w;
-  const PfView a = {p_xyz, p_dir, sc.dir_stride, sc.dir_div, p_idx, p_Q, p_O, p_fhi, p_flo, p_sp_xyz, p_sp_dir, p_wstream,
+  const PfView a = {p_xyz, p_dir, sc.dir_stride, sc.dir_div, p_idx, p_Q, p_O, p_ptt, p_sp_xyz, p_sp_dir, p_wstream,
                     p_bias, p_rd_w, sc.N, sc.M, sc.inv_span};
   // ONE __shared__ object (a second one makes hipcc drain vmcnt(0) before every ds_read of an LDS-DMA pipeline):
   // 4 x 32 KB ring of A fragments [part hi/lo][k-step 0/1][row tile][lane], then 3 KB of biases
@@ -135,25 +135,22 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
     wptr += (size_t)4 * ort * 1024;
   };
 
-  // ---------------------------------------------------------------- layer-1 operand fragments
-  // k-step order: 0-3 positional encoding, 4-5 ray_diff_fc, 6-18 gathered features
-  bf16x8 fh[L1_KSTEPS + 1], fl[L1_KSTEPS + 1];
-  const bool have = live && kk < a.M && a.M > 0;
-  const int id = a.idx[(size_t)nn * 8 + kk];   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
+  // ---------------------------------------------------------------- layer-1 operands
+  // feature columns: gathered row of the per-frame table T (already W1_feat . feature + b1, accumulator order) -> acc init;
+  // k-steps 0-3 positional encoding, 4-5 ray_diff_fc are assembled below
+  bf16x8 fh[2 * NRT > L1_KSTEPS ? 2 * NRT : L1_KSTEPS], fl[2 * NRT > L1_KSTEPS ? 2 * NRT : L1_KSTEPS];
+  const bool have = live && kk < a.M && a.M > 0;   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
+  const int id = a.idx[(size_t)nn * 8 + kk];
+  f32x16 acc[8];
   {
-    const size_t rowb = (size_t)(have ? id : 0) * 26 + hh;   // always a valid row; zeroed below when !have
-    const unsigned keep = have ? 0xffffffffu : 0u;
+    const float* trow = a.ptt + (size_t)(have ? id : a.M) * W + 16 * hh;   // row M holds the bias alone
 #pragma unroll
-    for (int q = 0; q < 13; ++q) {
-      uint4 vh = a.fhi[rowb + 2 * q];
-      vh.x &= keep; vh.y &= keep; vh.z &= keep; vh.w &= keep;
-      fh[6 + q] = __builtin_bit_cast(bf16x8, vh);
-      if (X3) {
-        uint4 vl = a.flo[rowb + 2 * q];
-        vl.x &= keep; vl.y &= keep; vl.z &= keep; vl.w &= keep;
-        fl[6 + q] = __builtin_bit_cast(bf16x8, vl);
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *(const float4*)(trow + 32 * rt + 4 * g);
+        acc[rt][4 * g] = t4.x; acc[rt][4 * g + 1] = t4.y; acc[rt][4 * g + 2] = t4.z; acc[rt][4 * g + 3] = t4.w;
       }
-    }
   }
   for (int i = tid; i < 3 * W; i += 256) sbias[i] = a.bias[i];
   __builtin_amdgcn_sched_barrier(0);
@@ -241,7 +238,6 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
     }
   }
 
-  f32x16 acc[8];
   auto init_acc = [&](const float* bias, int ort) __attribute__((always_inline)) {   // bias lives in LDS
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt)
@@ -303,7 +299,6 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
     wait_vmcnt<glds_of(g + 1) + glds_of(g + 2)>();
     __builtin_amdgcn_s_barrier();
     if constexpr (g + 3 < NC) stage(g + 3);   // its buffer held chunk g-1, which every wave finished before the barrier
-    if constexpr (g == 0) init_acc(sbias, NRT);
     constexpr int layer = g < L1_CHUNKS ? 0 : (g - L1_CHUNKS) / NRT + 1;
     constexpr int c = g < L1_CHUNKS ? g : (g - L1_CHUNKS) % NRT;
     constexpr int nks = (layer == 0 && 2 * c + 1 >= L1_KSTEPS) ? 1 : 2;
@@ -381,7 +376,7 @@ __global__ void pack_point_stream_kernel(const float* __restrict__ w1, const flo
   const int ks = (int)(r2 & 1), chunk = (int)(r2 >> 1);
   const int q = 2 * chunk + ks, hh = lane >> 5, orow = 32 * rt + (lane & 31);
   float v = 0.f;
-  if (layer == 0) {   // k-steps 0-3 positional encoding, 4-5 ray_diff_fc, 6-18 features (zero beyond)
+  if (layer == 0) {   // k-steps 0-3 positional encoding, 4-5 ray_diff_fc (feature columns live in the per-frame table T)
     int col = -1;
     if (q < 4) {
       const int pi = 8 * q + 4 * hh + (t >> 1), comp = t & 1;
@@ -389,7 +384,6 @@ __global__ void pack_point_stream_kernel(const float* __restrict__ w1, const flo
       else if (pi == 30) col = F + comp;
       else col = comp == 0 ? F + 2 : -1;
     } else if (q < 6) { const int o = 16 * (q - 4) + 8 * hh + t; col = o < 27 ? F + 63 + o : -1; }
-    else if (q < 19) { int c = 16 * (q - 6) + 8 * hh + t; col = c < F ? c : -1; }
     if (col >= 0) v = w1[(size_t)orow * (F + 90) + col];
   } else {
     const int fin = 32 * (q >> 1) + 16 * (q & 1) + (t & 3) + 8 * (t >> 2) + 4 * hh;
@@ -411,17 +405,17 @@ __global__ void pack_point_stream_kernel(const float* __restrict__ w1, const flo
   out[chunk_base + (long long)2 * ort * 512 + in_chunk] = pf_f2bf(v - hf);
 }
 
-// support feature table (M, F) fp32 -> bf16 hi / lo [M][208] (zero padded)
-__global__ void split_feature_table_kernel(const float* __restrict__ src, int M, int F, unsigned short* __restrict__ hi,
-                                           unsigned short* __restrict__ lo) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long long)M * 208) return;
-  const int c = (int)(e % 208);
-  const long long m = e / 208;
-  const float v = c < F ? src[m * F + c] : 0.f;
-  const unsigned short h = pf_f2bf(v);
-  hi[e] = h;
-  lo[e] = pf_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+// B operand + bias of the per-frame table GEMM  T[m][c'] = sum_k feat[m][k] * W1[f(c')][k] + b1[f(c')], where column c' =
+// 32*rt + 16*hh + r is the accumulator-order slot of output feature f(c') = 32*rt + (r&3) + 8*(r>>2) + 4*hh
+__global__ void pack_ptt_kernel(const float* __restrict__ w1 /*(W, F+90)*/, const float* __restrict__ b1, int W, int F, int Kpad, int Npad,
+                                float* __restrict__ B32 /*[Kpad][Npad]*/, float* __restrict__ bias /*[Npad]*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * W) return;
+  const int k = i / W, c = i - k * W;
+  const int rt = c >> 5, hh = (c >> 4) & 1, r = c & 15;
+  const int f = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+  B32[(size_t)k * Npad + c] = w1[(size_t)f * (F + 90) + k];
+  if (k == 0) bias[c] = b1[f];
 }
 
 // sum_k of the normalised aggregation weights (model.py:419-427 with correlation == 1/K), one lane per sample
@@ -468,11 +462,8 @@ int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, cons
   return NL_OK;
 }
 
-int nl_split_feature_table(const float* src, int64_t M, int F, void* hi, void* lo, hipStream_t st) {
-  if (M <= 0) return NL_OK;
-  if (F > 208) return NL_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(split_feature_table_kernel, dim3((unsigned)nl_cdiv(M * 208, 256)), dim3(256), 0, st, src, (int)M, F,
-                     (unsigned short*)hi, (unsigned short*)lo);
+int nl_pack_ptt(const float* w1, const float* b1, int W, int F, int Kpad, int Npad, float* B32, float* bias, hipStream_t st) {
+  hipLaunchKernelGGL(pack_ptt_kernel, dim3((unsigned)nl_cdiv((int64_t)F * W, 256)), dim3(256), 0, st, w1, b1, W, F, Kpad, Npad, B32, bias);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
@@ -496,9 +487,9 @@ int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipSt
 #define NL_PF(NRT)                                                                                           \
   do {                                                                                                       \
     const PfScalars sc{a.dir_stride, a.dir_div, a.N, a.M, a.inv_span};                                       \
-    if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.fhi, a.flo, \
+    if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
                                a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                           \
-    else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.fhi, a.flo, \
+    else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
                             a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                              \
   } while (0)
   if (W == 256) NL_PF(8);
