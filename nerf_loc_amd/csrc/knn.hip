@@ -226,7 +226,7 @@ __device__ __forceinline__ void scan_ranges(const QueryCtx& c, const float4* __r
 
 constexpr int FRONT_CAP = 256;   // frontier entries per wave (nodes kept as leaves beyond that)
 constexpr int LEAF_CAP = 128;
-constexpr int LEAF_COUNT_MAX = 24;  // nodes with <= this many points are scanned instead of expanded
+constexpr int LEAF_COUNT_MAX = 16;  // nodes with <= this many points are scanned instead of expanded
 
 template <int K>
 __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__ q, int N, const NlGridParams* __restrict__ gpp,

@@ -17,19 +17,29 @@ __global__ __launch_bounds__(256) void ln_slab_elu_kernel(const float* __restric
   const int n = L * Cc;
   const float* x = in + (size_t)r * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float s = 0.f;
-  for (int i = tid; i < n; i += 256) s += x[i];
+  // one pass over the slab: shifted sums (shift = first element) give mean and variance without the cancellation of
+  // E[x^2] - mean^2 and without a second read
+  const float x0 = x[0];
+  float s = 0.f, q = 0.f;
+  if ((n & 3) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int i = tid; i < n / 4; i += 256) {
+      const float4 v = x4[i];
+      const float a = v.x - x0, b = v.y - x0, c = v.z - x0, d = v.w - x0;
+      s += (a + b) + (c + d);
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) { const float d = x[i] - x0; s += d; q += d * d; }
+  }
   s = wave_sum(s);
-  if (lane == 0) red[wave] = s;
+  q = wave_sum(q);
+  if (lane == 0) { red[wave] = s; red[4 + wave] = q; }
   __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
-  __syncthreads();
-  float v = 0.f;
-  for (int i = tid; i < n; i += 256) { float d = x[i] - mean; v += d * d; }
-  v = wave_sum(v);
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+  const float ms = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+  const float mean = x0 + ms;
+  const float var = fmaxf((red[4] + red[5] + red[6] + red[7]) / (float)n - ms * ms, 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
   if (pooled) {
     // thread handles (position pair, channel)
     const int half = (L / 2) * Cc;
