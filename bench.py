@@ -134,7 +134,7 @@ def main():
         "config": {"workload": f"{cfg.name}: {R} rays x {S} samples, W={cfg.W}, V={cfg.V} views {cfg.H}x{cfg.Wimg}, M={frame['support_fine']['xyz'].shape[0]} neural points",
                    "rays_per_gpu": R, "precision": args.precision, "parallelism": f"ray-shard x{world} + all-gather"},
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                     "traffic": None, "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
+                     "traffic": hbm_traffic(args.config, args.precision), "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
                      "flops_per_step": flops_step, "device_ms_per_step": dev_ms / args.steps},
     }
 
@@ -154,6 +154,17 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_traffic(config: str, precision: str):
+    """HBM GB per step from the committed rocprofv3 PMC passes of this same command (profiles/r1_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  None when no committed measurement matches the workload."""
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+    if config != "c2" or precision != "bf16x3" or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {"GB_per_step": d["fetch_GB_per_step_x2_gfx950_correction"] + d["write_GB_per_step"], "source": "profiles/r1_hbm_traffic.json"}
 
 
 def cpu_baseline(cfg, frame, rays, weights, budget_s: float = 20.0):
