@@ -97,9 +97,9 @@ struct GemmDim { int K, N, Kpad, Npad; bool bias; };
 
 struct Layout {
   GemmDim g[G_COUNT];
-  size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bias[G_COUNT];
+  size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bias[G_COUNT];
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_bias, blw, dec_mfma;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];
   int un_c[U_COUNT], un_l[U_COUNT];
   size_t total;
@@ -151,6 +151,7 @@ Layout make_layout(const nl_config* c) {
     L.b32[i] = take(n * 4);
     L.bhi[i] = take(n * 2);
     L.blo[i] = take(n * 2);
+    L.bst[i] = take(nl_tgemm_stream_bytes(L.g[i].Kpad, L.g[i].N));
     L.bias[i] = take((size_t)L.g[i].Npad * 4);
   }
   L.rd_w = take(4 * (64 + 16 + 27 * 16 + 27));
@@ -169,6 +170,7 @@ Layout make_layout(const nl_config* c) {
   L.dec_mfma = take(nl_mv_decoder_pack_bytes());
   L.pt_bias = take(4 * 3 * (size_t)W);
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
+  L.zeros = take(4096);
   L.total = off;
   return L;
 }
@@ -183,7 +185,7 @@ __device__ __forceinline__ unsigned short pk_f2bf(float x) {
 // dst[k0+k][n] (f32 [Kpad][Npad]) and bf16 hi/lo [n][Kpad] <- src[off + n*ld_n + k*ld_k], k < kc, n < N
 __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld_n, int ld_k, int kc, int N, int k0,
                                   float* __restrict__ b32, unsigned short* __restrict__ bhi, unsigned short* __restrict__ blo,
-                                  int Kpad, int Npad) {
+                                  int Kpad, int Npad, unsigned short* __restrict__ bst, int nrts, int n0) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kc * N) return;
   int k = i / N, n = i - k * N;
@@ -192,7 +194,13 @@ __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld
   unsigned short h = pk_f2bf(v);
   float hf = __uint_as_float(((unsigned int)h) << 16);
   bhi[(size_t)n * Kpad + k0 + k] = h;
-  blo[(size_t)n * Kpad + k0 + k] = pk_f2bf(v - hf);
+  const unsigned short l = pk_f2bf(v - hf);
+  blo[(size_t)n * Kpad + k0 + k] = l;
+  // weight stream of tgemm.hip: chunk (32 k) = [part hi/lo][k-step][row tile][lane = (n&31) + 32*((k>>3)&1)][k&7]
+  const int kk = k0 + k, ng = n0 + n;
+  const size_t e = (size_t)(kk >> 5) * (4 * nrts * 512) + ((size_t)(((kk >> 4) & 1) * nrts + (ng >> 5)) * 64 + (ng & 31) + 32 * ((kk >> 3) & 1)) * 8 + (kk & 7);
+  bst[e] = h;
+  bst[e + (size_t)2 * nrts * 512] = l;
 }
 
 // [32][8] = rgb(3) | vis(1) | angle(4) columns of rgb_blending_mlp.0.weight (32, W+F+5), then its bias[32]
@@ -220,7 +228,8 @@ struct Packer {
     const GemmDim& d = L->g[g];
     int n = kc * d.N;
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, off, ld_n, ld_k, kc, d.N, k0,
-                       (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad);
+                       (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad,
+                       (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0);
   }
   void copy(const float* src, size_t dst_off, int n) {
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), n);
@@ -279,7 +288,7 @@ struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; }
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
 struct HdBufs { float *sigma, *fth, *hc, *wsum, *blA, *rgb_s; };
 
-constexpr int LDG = 396, LDX = 288;
+constexpr int LDG = 416, LDX = 288;   // LDG: mv_stats zero-fills columns 2F+3 .. LDG-1, so out_fc's K is a whole number of 32-wide chunks
 
 void carve_mv(Bump& b, const nl_config* c, int V, int64_t N, MvBufs& m) {
   m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N);
@@ -340,7 +349,9 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   NlGemmArgs a;
   memset(&a, 0, sizeof(a));
   int ksum = 0;
+  for (int i = 0; i < NL_GEMM_MAX_SEG; ++i) a.kstart[i] = 0x7fffffff;
   for (int i = 0; i < nseg; ++i) {
+    a.kstart[i] = ksum;
     a.seg[i].ptr = segs[i].ptr; a.seg[i].ld = segs[i].ld; a.seg[i].k = segs[i].k; a.seg[i].ioff = segs[i].ioff;
     a.seg[i].rdiv = segs[i].rdiv > 0 ? segs[i].rdiv : 1;
     a.seg[i].vec = ((((size_t)segs[i].ptr) & 15) == 0 && (segs[i].ld & 3) == 0) ? 1 : 0;
@@ -350,7 +361,8 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   if (ksum != ((d.K + 31) & ~31)) return NL_ERR_BAD_ARG;
   a.nseg = nseg; a.M = (int)M; a.K = d.K; a.N = d.N; a.Kpad = d.Kpad; a.Npad = d.Npad;
   if (x.c->precision == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
-  else { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; }
+  else { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; a.Bst = x.pk + x.L.bst[g]; }
+  a.zeros = x.p<float>(x.L.zeros);
   a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
   a.C = C; a.ldc = ldc; a.act = act;
   a.So = So; a.Li = Li; a.Lo = Lo; a.ostride = ostride; a.ooff = ooff;
@@ -405,7 +417,7 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
   else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x.p<char>(x.L.dec_mfma), xyz, N, m.vis, m.dd, x.c->precision == NL_PREC_BF16X3, x.st));
   NL_TRY(nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, f->pfeat,
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
-  SegSpec s0{m.g393, LDG, 2 * (f->C + 3) + 3, 0, 1};
+  SegSpec s0{m.g393, LDG, (int)nl_align_up(2 * (f->C + 3) + 3, 32), 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
   SegSpec s1{m.t64, 64, 64, 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC2, &s1, 1, N, G, x.c->W, NL_ACT_ELU));
@@ -576,7 +588,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
       hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(nel, 256)), dim3(256), 0, st, w, 0, W, 1, W, 128, 0,
                          (float*)((char*)packed + L.b32[G_KV]) + half * 128,
                          (unsigned short*)((char*)packed + L.bhi[G_KV]) + (size_t)half * 128 * d.Kpad,
-                         (unsigned short*)((char*)packed + L.blo[G_KV]) + (size_t)half * 128 * d.Kpad, d.Kpad, d.Npad);
+                         (unsigned short*)((char*)packed + L.blo[G_KV]) + (size_t)half * 128 * d.Kpad, d.Kpad, d.Npad,
+                         (unsigned short*)((char*)packed + L.bst[G_KV]), nl_tgemm_nrt(d.N), half * 128);
     }
   }
   P.linear(G_Q, t[T_WQ], nullptr);

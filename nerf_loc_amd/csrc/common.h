@@ -48,6 +48,14 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ------------------------------------------------------------------ XCD-aware block order
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  nl_xcd_block() turns the hardware block id into a
+// logical one such that every XCD works through ONE contiguous eighth of the index space: neighbouring samples of a ray
+// (which tap neighbouring texels / share KNN leaves and table rows) then meet in the same L2.  Launch nl_xcd_grid(G)
+// blocks (a multiple of 8); logical ids >= G exit through the kernel's ordinary bounds check.
+__device__ __forceinline__ unsigned nl_xcd_block() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+static inline unsigned nl_xcd_grid(int64_t G) { return (unsigned)((G + 7) / 8 * 8); }
+
 // ------------------------------------------------------------------ camera block passed by value (kernarg -> SGPRs)
 struct NlViews {
   float P1[NL_MAX_VIEWS][12];   // Projector rows 0..2 (ibrnet.py:183)
@@ -86,6 +94,9 @@ struct NlGemmArgs {
   int Kpad, Npad;       // padded sizes of B
   const void* B;        // packed weights: f32 [Kpad][Npad]  or bf16 hi/lo [Npad][Kpad] (see pack.hip)
   const void* Blo;      // bf16x3 only
+  const void* Bst;      // bf16 hi/lo weight stream in A-fragment chunk order (tgemm.hip), or null
+  const float* zeros;   // >= 512 zero floats (source row of conv halos / rows beyond M in tgemm.hip)
+  int kstart[NL_GEMM_MAX_SEG];   // first k of each segment in the padded K space; INT_MAX for unused slots
   const float* bias;    // [N] or null
   float* C;
   int ldc;
@@ -96,3 +107,8 @@ struct NlGemmArgs {
 };
 
 int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);
+// streaming transposed GEMM (tgemm.hip): bf16 modes, N <= 256, 16-B aligned segments
+int nl_tgemm_nrt(int N);
+size_t nl_tgemm_stream_bytes(int Kpad, int N);
+bool nl_tgemm_supported(const NlGemmArgs& a, int precision);
+int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   __shared__ unsigned s_front[4][2][FRONT_CAP];
   __shared__ int s_leaf_s[4][LEAF_CAP], s_leaf_l[4][LEAF_CAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+  const int n = __builtin_amdgcn_readfirstlane(nl_xcd_block() * 4 + wv);
   if (n >= N) return;
   QueryCtx c;
   c.org0 = gpp->origin[0]; c.org1 = gpp->origin[1]; c.org2 = gpp->origin[2];
@@ -388,7 +388,7 @@ int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* i
     return NL_OK;
   }
   if (K < 1 || K > 8) return NL_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)nl_cdiv(N, 4));
+  dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
   if (K == 1)
     hipLaunchKernelGGL(knn_wave_kernel<1>, grid, dim3(256), 0, st, xyz, (int)N, g->params, g->starts, g->sorted, K, idx, d2);
   else

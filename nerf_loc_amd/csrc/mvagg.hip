@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
                                                        const float* __restrict__ blw /*[32][8] = W[rgb3|vis1|ang4], then bias[32]*/,
                                                        float* __restrict__ bl1 /*(N*V,32) or null*/, float* __restrict__ rgbv /*(N*V,4) or null*/) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = nl_xcd_block() * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int V = vw.V;
   const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
@@ -464,7 +464,7 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
                        int* valid_s, const float* pfeat, const float* blw, float* bl1, float* rgbv, hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)nl_cdiv(N, 4));
+  dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
   if (vw.V <= 4)
     hipLaunchKernelGGL(mv_stats_kernel<4>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
   else if (vw.V <= 8)

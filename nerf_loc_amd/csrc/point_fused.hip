@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
   constexpr int NC = L1_CHUNKS + 3 * NRT;   // chunks of the whole chain: L1 | L2 | L3 | KV
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31, kk = j & 7;
-  const int n = blockIdx.x * 16 + wave * 4 + (j >> 3);
+  const int n = nl_xcd_block() * 16 + wave * 4 + (j >> 3);
   const bool live = n < a.N;
   const int nn = live ? n : a.N - 1;
   const char* wptr = (const char*)a.wstream;
@@ -482,7 +482,7 @@ bool nl_point_fused_supported(int W, int precision) {
 
 int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipStream_t st) {
   if (a.N <= 0) return NL_OK;
-  dim3 grid((unsigned)nl_cdiv(a.N, 16));
+  dim3 grid(nl_xcd_grid(nl_cdiv(a.N, 16)));
   const bool x3 = precision == NL_PREC_BF16X3;
 #define NL_PF(NRT)                                                                                           \
   do {                                                                                                       \

@@ -1,0 +1,230 @@
+// Streaming transposed segment-GEMM (bf16 / bf16x3 modes): the same contract as gemm.hip's kernels
+//   C[out_row(m), n] = act( sum_seg sum_k A_seg[in_row_seg(m), k] * B[koff_seg + k, n] + bias[n] )
+// but organised like point_fused.hip instead of a classic LDS-tiled GEMM:
+//   * D^T = W . X^T : the WEIGHTS are the MFMA A operand, streamed from L2 into an LDS ring with LDS-DMA
+//     (global_load_lds_dwordx4) in chunks of 32 k whose global image is already the A-fragment order (one conflict-free
+//     ds_read_b128 per fragment); every chunk is shared by all waves of the workgroup.
+//   * the ACTIVATIONS are the B operand: a wave owns 32 output rows, lane (j, hh) fetches the 8 floats of row j it needs
+//     for a k-step (conv taps / concat / phase mapping = address arithmetic) with LDS-DMA as well, into a private 4-KB
+//     piece of the ring slot, LA chunks ahead, reads them back (own lane's 16 B) and splits them to bf16 hi/lo in
+//     registers.  No load in the loop has a register destination, so the only vmcnt waits are the counted ones below.
+//   * all N <= 256 output columns of a row live in one wave's accumulators (N/32 tiles of 32x32), so X is read once.
+//   * one counted s_waitcnt vmcnt(N) + one raw s_barrier per chunk; every global load is unconditional (clamped address,
+//     zeroed afterwards) so the number of outstanding loads per chunk is a compile-time constant.
+#include <utility>
+#include "common.h"
+
+typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ void tg_glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void tg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+template <int... Is, class F>
+__device__ __forceinline__ void tg_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void tg_static_for(F&& f) {
+  tg_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <bool X3>
+__device__ __forceinline__ void tg_split8(const float (&v)[8], tg_bf16x8& hi, tg_bf16x8& lo) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    __bf16 h = (__bf16)v[t];
+    hi[t] = h;
+    if (X3) lo[t] = (__bf16)(v[t] - (float)h);
+  }
+}
+
+// chunk c (k-space [32c, 32c+32)) lies in exactly one segment (every segment is a multiple of 32 wide here);
+// kstart[] are the segments' first k (INT_MAX for unused slots) -> branch-free, wave-uniform lookup
+__device__ __forceinline__ int tg_find_seg(const NlGemmArgs& a, int k0) {
+  int s = 0;
+#pragma unroll
+  for (int j = 1; j < NL_GEMM_MAX_SEG; ++j) s += (k0 >= a.kstart[j]) ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(s);
+}
+
+template <int NRT, int NW, bool X3, int LA>
+__global__ __launch_bounds__(64 * NW, 1) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
+                                                            const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
+  constexpr int PARTS = X3 ? 2 : 1;
+  constexpr int PIECES = PARTS * 2 * NRT;   // 1-KB LDS-DMA pieces of weights per chunk
+  constexpr int NDMA = PIECES / NW;         // per wave
+  static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
+  constexpr int NBUF = LA + 1;
+  constexpr int CH16 = 4 * NRT * 64;        // uint4 per chunk in the global stream (hi and lo parts are always stored)
+  constexpr int SLOT16 = (PIECES + 4 * NW) * 64;   // uint4 per ring slot: weights, then raw activations [piece (ks, e)][wave][lane]
+  constexpr int NLD = NDMA + 4;             // LDS-DMA instructions a wave issues per chunk
+  static_assert((NBUF * SLOT16 + NRT * 8) * 16 <= 160 * 1024, "LDS budget");
+  // ONE __shared__ object (see point_fused.hip): ring, then NRT*32 bias floats
+  __shared__ uint4 lds_all[NBUF * SLOT16 + NRT * 8];
+  // 2-D view: slot indices are compile-time constants everywhere below, which lets the compiler prove that the LDS-DMA
+  // writes of one slot never alias the ds_reads of another (a runtime slot index costs a vmcnt(0) before every ds_read)
+  uint4 (*ring)[SLOT16] = reinterpret_cast<uint4 (*)[SLOT16]>(lds_all);
+  float* sbias = reinterpret_cast<float*>(lds_all + NBUF * SLOT16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31, w64 = tid & ~63;
+  const int m = blockIdx.x * (32 * NW) + 32 * wave + j;
+  const bool mok = m < a.M;
+  int q = 0, t = 0;
+  if (a.So > 0) { q = m / a.So; t = m - q * a.So; }
+  const int NC = a.Kpad >> 5;
+
+  for (int i = tid; i < NRT * 32; i += 64 * NW) sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
+
+  // LDS-DMA of chunk c into ring slot `slot`: this wave's share of the weight pieces, then its own activation fragments:
+  // 2 k-steps x 8 floats of this lane's source row, piece (ks, e) = 64 lanes x 16 B in lane order.  Conv halo rows and
+  // rows >= M read a device zero page instead: no masking arithmetic and a constant number of loads per chunk.
+  auto stage = [&](int c, auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
+    const char* src = p_bst + (size_t)c * (CH16 * 16);
+#pragma unroll
+    for (int jj = 0; jj < NDMA; ++jj)   // piece wave + NW*jj; LDS offsets are written in terms of tid so that their range is known
+      tg_glds16(src + (size_t)(w64 + NW * 64 * jj + lane) * 16, &ring[slot][w64 + NW * 64 * jj]);
+    const int k0 = 32 * c;
+    const int s = tg_find_seg(a, k0);
+    const NlGemmSeg& sg = a.seg[s];
+    const int kbase = k0 - a.kstart[s];
+    bool ok = mok;
+    int row = m;
+    if (a.So > 0) {
+      const int i = t + sg.ioff;
+      ok = ok && i >= 0 && i < a.Li;
+      row = q * a.Li + i;
+    }
+    const float* p = (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + 8 * hh;
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) tg_glds16(p + 16 * (pc >> 1) + 4 * (pc & 1), &ring[slot][(PIECES + NW * pc) * 64 + w64]);
+  };
+
+  tg_f32x16 acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+
+  // one chunk: 2 k-steps x NRT row tiles x (3 | 1) MFMAs; A fragments are read two (k-step, tile) pairs ahead
+  auto compute = [&](auto SLOT) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
+    const uint4* L = ring[slot];
+    tg_bf16x8 bh[2], bl[2];
+    {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // (read through the same vector type as the A fragments: the loads then carry the alias metadata that keeps the
+        //  compiler from draining vmcnt(0) before an LDS read that follows an LDS-DMA)
+        typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
+        const tg_f32x4 r0 = __builtin_bit_cast(tg_f32x4, __builtin_bit_cast(tg_bf16x8, ring[slot][(PIECES + NW * (2 * ks)) * 64 + tid]));
+        const tg_f32x4 r1 = __builtin_bit_cast(tg_f32x4, __builtin_bit_cast(tg_bf16x8, ring[slot][(PIECES + NW * (2 * ks + 1)) * 64 + tid]));
+        const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+        tg_split8<X3>(v, bh[ks], bl[ks]);
+      }
+    }
+    constexpr int nt = 2 * NRT;
+    auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
+      const int ks = tt / NRT, rt = tt - ks * NRT;
+      ah = __builtin_bit_cast(tg_bf16x8, L[((0 * 2 + ks) * NRT + rt) * 64 + lane]);
+      if (X3) al = __builtin_bit_cast(tg_bf16x8, L[((1 * 2 + ks) * NRT + rt) * 64 + lane]);
+    };
+    tg_bf16x8 ah[3], al[3];
+    ldA(0, ah[0], al[0]);
+    ldA(1, ah[1], al[1]);
+#pragma unroll
+    for (int tt = 0; tt < nt; ++tt) {
+      if (tt + 2 < nt) ldA(tt + 2, ah[(tt + 2) % 3], al[(tt + 2) % 3]);
+      const int ks = tt / NRT, rt = tt - ks * NRT;
+      if (X3) {
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], acc[rt], 0, 0, 0);
+      }
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Chunks past the end are loaded again from the last real chunk (never used) so that every step of the pipeline issues
+  // exactly NLD loads and the counted wait is a compile-time constant.
+  tg_static_for<LA>([&](auto U) __attribute__((always_inline)) {
+    constexpr int u = decltype(U)::value;
+    stage(u < NC ? u : NC - 1, U);
+  });
+  for (int g0 = 0; g0 < NC; g0 += NBUF) {
+    tg_static_for<NBUF>([&](auto U) __attribute__((always_inline)) {
+      constexpr int u = decltype(U)::value;   // chunk g lives in ring slot g % NBUF = u
+      const int g = g0 + u;
+      if (g < NC) {
+        // chunk g (this wave's LDS-DMA) has landed once only the LA-1 younger chunks are in flight
+        tg_wait_vmcnt<(LA - 1) * NLD>();
+        __builtin_amdgcn_s_barrier();
+        // slot (g+LA) % NBUF held chunk g-1: every wave is past it
+        stage(g + LA < NC ? g + LA : NC - 1, std::integral_constant<int, (u + LA) % NBUF>{});
+        compute(U);
+      }
+    });
+  }
+  tg_wait_vmcnt<0>();
+
+  // epilogue: C/D layout col = lane&31 (= this lane's output row), reg r = 4*gq + e <-> n = 32*rt + 8*gq + 4*hh + e
+  if (!mok) return;
+  size_t orow;
+  if (a.So > 0) orow = (size_t)(q * a.Lo + t * a.ostride + a.ooff) * a.ldc;
+  else orow = (size_t)m * a.ldc;
+  float* crow = p_c + orow;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = 32 * rt + 8 * gq + 4 * hh;
+      if (n < a.N) {   // N % 4 == 0 and ldc % 4 == 0 are launch preconditions
+        const float4 b4 = *(const float4*)(sbias + n);
+        float4 v;
+        v.x = nl_act(acc[rt][4 * gq + 0] + b4.x, a.act);
+        v.y = nl_act(acc[rt][4 * gq + 1] + b4.y, a.act);
+        v.z = nl_act(acc[rt][4 * gq + 2] + b4.z, a.act);
+        v.w = nl_act(acc[rt][4 * gq + 3] + b4.w, a.act);
+        *(float4*)(crow + n) = v;
+      }
+    }
+}
+
+}  // namespace
+
+// stream layout helpers (also used by the packer in abi.hip)
+int nl_tgemm_nrt(int N) { return N <= 64 ? 2 : (N <= 128 ? 4 : 8); }
+size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 * nl_tgemm_nrt(N) * 1024; }
+
+bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
+  if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
+  for (int s = 0; s < a.nseg; ++s) {
+    const NlGemmSeg& g = a.seg[s];
+    if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k) return false;
+  }
+  return true;
+}
+
+int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
+  const bool x3 = precision == NL_PREC_BF16X3;
+  const int nrt = nl_tgemm_nrt(a.N);
+#define NL_TG(NRT, NW, X3, LA)                                                                               \
+  do {                                                                                                       \
+    dim3 grid((unsigned)nl_cdiv(a.M, 32 * NW));                                                              \
+    hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, LA>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);                      \
+  } while (0)
+  if (nrt == 8) { if (x3) NL_TG(8, 4, true, 2); else NL_TG(8, 4, false, 3); }
+  else if (nrt == 4) { if (x3) NL_TG(4, 4, true, 3); else NL_TG(4, 4, false, 4); }
+  else { if (x3) NL_TG(2, 4, true, 5); else NL_TG(2, 4, false, 6); }
+#undef NL_TG
+  return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
