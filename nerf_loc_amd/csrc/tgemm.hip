@@ -1,16 +1,16 @@
 // Streaming transposed segment-GEMM (bf16 / bf16x3 modes): the same contract as gemm.hip's kernels
 //   C[out_row(m), n] = act( sum_seg sum_k A_seg[in_row_seg(m), k] * B[koff_seg + k, n] + bias[n] )
 // but organised like point_fused.hip instead of a classic LDS-tiled GEMM:
-//   * D^T = W . X^T : the WEIGHTS are the MFMA A operand, streamed from L2 into an LDS ring with LDS-DMA
-//     (global_load_lds_dwordx4) in chunks of 32 k whose global image is already the A-fragment order (one conflict-free
-//     ds_read_b128 per fragment); every chunk is shared by all waves of the workgroup.
-//   * the ACTIVATIONS are the B operand: a wave owns 32 output rows, lane (j, hh) fetches the 8 floats of row j it needs
-//     for a k-step (conv taps / concat / phase mapping = address arithmetic) with LDS-DMA as well, into a private 4-KB
-//     piece of the ring slot, LA chunks ahead, reads them back (own lane's 16 B) and splits them to bf16 hi/lo in
-//     registers.  No load in the loop has a register destination, so the only vmcnt waits are the counted ones below.
+//   * D^T = W . X^T : the WEIGHTS are the MFMA A operand, streamed from L2 through registers into a double-buffered LDS
+//     slot in chunks of 32 k whose global image is already the A-fragment order (coalesced 16-B loads, one conflict-free
+//     ds_read_b128 per fragment); every chunk is shared by all waves of the workgroup.  (An LDS-DMA ring measured the
+//     same speed for N = 256 and slower for N <= 128.)
+//   * the ACTIVATIONS are the B operand and never touch LDS: a wave owns 32 output rows, lane (j, hh) fetches the 8 floats
+//     of row j it needs for a k-step straight from global memory (conv taps / concat / phase mapping = address arithmetic)
+//     one chunk ahead and splits them to bf16 hi/lo in registers.
 //   * all N <= 256 output columns of a row live in one wave's accumulators (N/32 tiles of 32x32), so X is read once.
-//   * one counted s_waitcnt vmcnt(N) + one raw s_barrier per chunk; every global load is unconditional (clamped address,
-//     zeroed afterwards) so the number of outstanding loads per chunk is a compile-time constant.
+//   * <= 256 registers and 64 KB of LDS: two workgroups per CU, which run out of phase and hide each other's memory
+//     latency, conversion VALU and barrier time behind MFMAs; no data-dependent control flow around the MFMAs.
 #include <utility>
 #include "common.h"
 
@@ -55,27 +55,22 @@ __device__ __forceinline__ int tg_find_seg(const NlGemmArgs& a, int k0) {
   return __builtin_amdgcn_readfirstlane(s);
 }
 
-template <int NRT, int NW, bool X3, int LA>
-__global__ __launch_bounds__(64 * NW, 1) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
+template <int NRT, int NW, bool X3>
+__global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
                                                             const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
   constexpr int PARTS = X3 ? 2 : 1;
-  constexpr int PIECES = PARTS * 2 * NRT;   // 1-KB LDS-DMA pieces of weights per chunk
-  constexpr int NDMA = PIECES / NW;         // per wave
+  constexpr int PIECES = PARTS * 2 * NRT;   // 1-KB pieces of weights per chunk
+  constexpr int NPW = PIECES / NW;          // pieces staged by each wave
   static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
-  constexpr int NBUF = LA + 1;
-  constexpr int CH16 = 4 * NRT * 64;        // uint4 per chunk in the global stream (hi and lo parts are always stored)
-  constexpr int SLOT16 = (PIECES + 4 * NW) * 64;   // uint4 per ring slot: weights, then raw activations [piece (ks, e)][wave][lane]
-  constexpr int NLD = NDMA + 4;             // LDS-DMA instructions a wave issues per chunk
-  static_assert((NBUF * SLOT16 + NRT * 8) * 16 <= 160 * 1024, "LDS budget");
-  // ONE __shared__ object (see point_fused.hip): ring, then NRT*32 bias floats
-  __shared__ uint4 lds_all[NBUF * SLOT16 + NRT * 8];
-  // 2-D view: slot indices are compile-time constants everywhere below, which lets the compiler prove that the LDS-DMA
-  // writes of one slot never alias the ds_reads of another (a runtime slot index costs a vmcnt(0) before every ds_read)
-  uint4 (*ring)[SLOT16] = reinterpret_cast<uint4 (*)[SLOT16]>(lds_all);
-  float* sbias = reinterpret_cast<float*>(lds_all + NBUF * SLOT16);
+  constexpr int CH16 = 4 * NRT * 64;        // 16-B units per chunk in the global stream (hi and lo parts are always stored)
+  constexpr int SLOT16 = PIECES * 64;       // 16-B units per LDS slot
+  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8];
+  // native vector element type everywhere (struct-typed uint4 arrays in registers do not survive SROA)
+  tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
+  float* sbias = reinterpret_cast<float*>(lds_all + 2 * SLOT16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hh = lane >> 5, j = lane & 31, w64 = tid & ~63;
+  const int hh = lane >> 5, j = lane & 31;
   const int m = blockIdx.x * (32 * NW) + 32 * wave + j;
   const bool mok = m < a.M;
   int q = 0, t = 0;
@@ -84,15 +79,20 @@ __global__ __launch_bounds__(64 * NW, 1) void tgemm_kernel(const NlGemmArgs a, c
 
   for (int i = tid; i < NRT * 32; i += 64 * NW) sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
 
-  // LDS-DMA of chunk c into ring slot `slot`: this wave's share of the weight pieces, then its own activation fragments:
-  // 2 k-steps x 8 floats of this lane's source row, piece (ks, e) = 64 lanes x 16 B in lane order.  Conv halo rows and
-  // rows >= M read a device zero page instead: no masking arithmetic and a constant number of loads per chunk.
-  auto stage = [&](int c, auto SLOT) __attribute__((always_inline)) {
-    constexpr int slot = decltype(SLOT)::value;
-    const char* src = p_bst + (size_t)c * (CH16 * 16);
+  // weights of chunk c: this wave's NPW pieces, 16 B per lane, fully coalesced
+  auto load_w = [&](int c, tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
+    const tg_bf16x8* src = reinterpret_cast<const tg_bf16x8*>(p_bst) + (size_t)c * CH16;
 #pragma unroll
-    for (int jj = 0; jj < NDMA; ++jj)   // piece wave + NW*jj; LDS offsets are written in terms of tid so that their range is known
-      tg_glds16(src + (size_t)(w64 + NW * 64 * jj + lane) * 16, &ring[slot][w64 + NW * 64 * jj]);
+    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[(wave + NW * jj) * 64 + lane];
+  };
+  auto store_w = [&](auto SLOT, const tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT)::value;
+#pragma unroll
+    for (int jj = 0; jj < NPW; ++jj) ring[slot][(wave + NW * jj) * 64 + lane] = w[jj];
+  };
+  // activation fragments of chunk c: 2 k-steps x 8 floats of this lane's source row, straight into registers.  Conv halo
+  // rows and rows >= M read a device zero page instead (no masking arithmetic).
+  auto load_act = [&](int c, float4 (&raw)[4]) __attribute__((always_inline)) {
     const int k0 = 32 * c;
     const int s = tg_find_seg(a, k0);
     const NlGemmSeg& sg = a.seg[s];
@@ -106,7 +106,15 @@ __global__ __launch_bounds__(64 * NW, 1) void tgemm_kernel(const NlGemmArgs a, c
     }
     const float* p = (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + 8 * hh;
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) tg_glds16(p + 16 * (pc >> 1) + 4 * (pc & 1), &ring[slot][(PIECES + NW * pc) * 64 + w64]);
+    for (int pc = 0; pc < 4; ++pc) raw[pc] = *(const float4*)(p + 16 * (pc >> 1) + 4 * (pc & 1));
+  };
+  auto convert = [&](const float4 (&raw)[4], tg_bf16x8 (&bh)[2], tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float v[8] = {raw[2 * ks].x, raw[2 * ks].y, raw[2 * ks].z, raw[2 * ks].w,
+                          raw[2 * ks + 1].x, raw[2 * ks + 1].y, raw[2 * ks + 1].z, raw[2 * ks + 1].w};
+      tg_split8<X3>(v, bh[ks], bl[ks]);
+    }
   };
 
   tg_f32x16 acc[NRT];
@@ -116,27 +124,14 @@ __global__ __launch_bounds__(64 * NW, 1) void tgemm_kernel(const NlGemmArgs a, c
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
   // one chunk: 2 k-steps x NRT row tiles x (3 | 1) MFMAs; A fragments are read two (k-step, tile) pairs ahead
-  auto compute = [&](auto SLOT) __attribute__((always_inline)) {
+  auto compute = [&](auto SLOT, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
     constexpr int slot = decltype(SLOT)::value;
-    const uint4* L = ring[slot];
-    tg_bf16x8 bh[2], bl[2];
-    {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        // (read through the same vector type as the A fragments: the loads then carry the alias metadata that keeps the
-        //  compiler from draining vmcnt(0) before an LDS read that follows an LDS-DMA)
-        typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
-        const tg_f32x4 r0 = __builtin_bit_cast(tg_f32x4, __builtin_bit_cast(tg_bf16x8, ring[slot][(PIECES + NW * (2 * ks)) * 64 + tid]));
-        const tg_f32x4 r1 = __builtin_bit_cast(tg_f32x4, __builtin_bit_cast(tg_bf16x8, ring[slot][(PIECES + NW * (2 * ks + 1)) * 64 + tid]));
-        const float v[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-        tg_split8<X3>(v, bh[ks], bl[ks]);
-      }
-    }
+    const tg_bf16x8* L = ring[slot];
     constexpr int nt = 2 * NRT;
     auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
       const int ks = tt / NRT, rt = tt - ks * NRT;
-      ah = __builtin_bit_cast(tg_bf16x8, L[((0 * 2 + ks) * NRT + rt) * 64 + lane]);
-      if (X3) al = __builtin_bit_cast(tg_bf16x8, L[((1 * 2 + ks) * NRT + rt) * 64 + lane]);
+      ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
+      if (X3) al = L[((1 * 2 + ks) * NRT + rt) * 64 + lane];
     };
     tg_bf16x8 ah[3], al[3];
     ldA(0, ah[0], al[0]);
@@ -154,27 +149,34 @@ __global__ __launch_bounds__(64 * NW, 1) void tgemm_kernel(const NlGemmArgs a, c
     }
   };
 
-  // Chunks past the end are loaded again from the last real chunk (never used) so that every step of the pipeline issues
-  // exactly NLD loads and the counted wait is a compile-time constant.
-  tg_static_for<LA>([&](auto U) __attribute__((always_inline)) {
+  // Register-staged pipeline, one chunk ahead, two workgroups per CU (<= 256 registers): while chunk g is multiplied out of
+  // LDS slot g%2, chunk g+1's weights and activation fragments are in flight to registers; afterwards the weights go to
+  // slot (g+1)%2 — every wave left that slot before the previous barrier.  The second workgroup of the CU runs the same
+  // loop out of phase and covers this one's latencies, VALU and barrier time with its MFMAs.
+  // The chunk past the end re-loads the last real chunk (never used): no data-dependent control flow around the MFMAs
+  // (the accumulators must stay in AGPRs).
+  tg_bf16x8 wreg[NPW];
+  float4 raw[4];
+  auto clampc = [&](int c) { return c < NC ? c : NC - 1; };
+  load_act(0, raw); load_w(0, wreg);
+  store_w(std::integral_constant<int, 0>{}, wreg);
+  __syncthreads();
+  auto step = [&](auto U, int g) __attribute__((always_inline)) {
     constexpr int u = decltype(U)::value;
-    stage(u < NC ? u : NC - 1, U);
-  });
-  for (int g0 = 0; g0 < NC; g0 += NBUF) {
-    tg_static_for<NBUF>([&](auto U) __attribute__((always_inline)) {
-      constexpr int u = decltype(U)::value;   // chunk g lives in ring slot g % NBUF = u
-      const int g = g0 + u;
-      if (g < NC) {
-        // chunk g (this wave's LDS-DMA) has landed once only the LA-1 younger chunks are in flight
-        tg_wait_vmcnt<(LA - 1) * NLD>();
-        __builtin_amdgcn_s_barrier();
-        // slot (g+LA) % NBUF held chunk g-1: every wave is past it
-        stage(g + LA < NC ? g + LA : NC - 1, std::integral_constant<int, (u + LA) % NBUF>{});
-        compute(U);
-      }
-    });
+    tg_bf16x8 bh[2], bl[2];
+    convert(raw, bh, bl);
+    load_act(clampc(g + 1), raw);
+    load_w(clampc(g + 1), wreg);
+    compute(U, bh, bl);
+    store_w(std::integral_constant<int, 1 - u>{}, wreg);
+    __syncthreads();
+  };
+  int g0 = 0;
+  for (; g0 + 1 < NC; g0 += 2) {
+    step(std::integral_constant<int, 0>{}, g0);
+    step(std::integral_constant<int, 1>{}, g0 + 1);
   }
-  tg_wait_vmcnt<0>();
+  if (g0 < NC) step(std::integral_constant<int, 0>{}, g0);
 
   // epilogue: C/D layout col = lane&31 (= this lane's output row), reg r = 4*gq + e <-> n = 32*rt + 8*gq + 4*hh + e
   if (!mok) return;
@@ -217,14 +219,14 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
 int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   const bool x3 = precision == NL_PREC_BF16X3;
   const int nrt = nl_tgemm_nrt(a.N);
-#define NL_TG(NRT, NW, X3, LA)                                                                               \
+#define NL_TG(NRT, NW, X3)                                                                                  \
   do {                                                                                                       \
     dim3 grid((unsigned)nl_cdiv(a.M, 32 * NW));                                                              \
-    hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, LA>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);                      \
+    hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias); \
   } while (0)
-  if (nrt == 8) { if (x3) NL_TG(8, 4, true, 2); else NL_TG(8, 4, false, 3); }
-  else if (nrt == 4) { if (x3) NL_TG(4, 4, true, 3); else NL_TG(4, 4, false, 4); }
-  else { if (x3) NL_TG(2, 4, true, 5); else NL_TG(2, 4, false, 6); }
+  if (nrt == 8) { if (x3) NL_TG(8, 4, true); else NL_TG(8, 4, false); }
+  else if (nrt == 4) { if (x3) NL_TG(4, 4, true); else NL_TG(4, 4, false); }
+  else { if (x3) NL_TG(2, 4, true); else NL_TG(2, 4, false); }
 #undef NL_TG
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
