@@ -213,6 +213,14 @@ __global__ void pack_blw_kernel(const float* __restrict__ w, const float* __rest
   } else if (i < 288) dst[i] = b[i - 256];
 }
 
+// dst[l][c] = src[c][l]: LayerNorm([C, L]) affine tables, stored position-major like the activations
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cc, int L) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cc * L) return;
+  const int l = i / Cc, c = i - l * Cc;
+  dst[i] = src[(size_t)c * L + l];
+}
+
 __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -233,6 +241,9 @@ struct Packer {
   }
   void copy(const float* src, size_t dst_off, int n) {
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), n);
+  }
+  void transpose(const float* src, size_t dst_off, int Cc, int Lp) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)nl_cdiv(Cc * Lp, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), Cc, Lp);
   }
   void linear(int g, const float* w, const float* b) {  // torch (out, in)
     block(g, 0, w, 0, L->g[g].K, 1, L->g[g].K);
@@ -603,8 +614,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.convT(G_T1E, G_T1O, un[20], un[21], 128, 32);
   P.conv3(G_CONVOUT, un[24], un[25], W + 32);
   for (int u = 0; u < U_COUNT; ++u) {
-    P.copy(un[4 * u + 2], L.un_g[u], L.un_c[u] * L.un_l[u]);
-    P.copy(un[4 * u + 3], L.un_b[u], L.un_c[u] * L.un_l[u]);
+    P.transpose(un[4 * u + 2], L.un_g[u], L.un_c[u], L.un_l[u]);   // (C, L) -> (L, C)
+    P.transpose(un[4 * u + 3], L.un_b[u], L.un_c[u], L.un_l[u]);
   }
   P.linear(G_FEAT0, t[T_F0W], t[T_F0B]);
   P.block(G_FEAT2, 0, t[T_F2W], 0, W, 1, W);

@@ -10,7 +10,7 @@ namespace {
 
 // one block per ray: in (L, Cc) -> out (L, Cc) = ELU(LN(in)) ; pooled (L/2, Cc) = max over position pairs (optional)
 __global__ __launch_bounds__(256) void ln_slab_elu_kernel(const float* __restrict__ in, int L, int Cc,
-                                                          const float* __restrict__ gamma /*(Cc,L)*/, const float* __restrict__ beta,
+                                                          const float* __restrict__ gamma /*(L,Cc): position-major like the slab*/, const float* __restrict__ beta,
                                                           float eps, float* __restrict__ out, float* __restrict__ pooled) {
   __shared__ float red[8];
   const int r = blockIdx.x;
@@ -46,16 +46,13 @@ __global__ __launch_bounds__(256) void ln_slab_elu_kernel(const float* __restric
     for (int i = tid; i < half; i += 256) {
       const int p = i / Cc, c = i - p * Cc;
       const int l0 = 2 * p, l1 = 2 * p + 1;
-      float a = nl_elu((x[l0 * Cc + c] - mean) * rstd * gamma[c * L + l0] + beta[c * L + l0]);
-      float b = nl_elu((x[l1 * Cc + c] - mean) * rstd * gamma[c * L + l1] + beta[c * L + l1]);
+      float a = nl_elu((x[l0 * Cc + c] - mean) * rstd * gamma[l0 * Cc + c] + beta[l0 * Cc + c]);
+      float b = nl_elu((x[l1 * Cc + c] - mean) * rstd * gamma[l1 * Cc + c] + beta[l1 * Cc + c]);
       if (out) { out[(size_t)r * n + l0 * Cc + c] = a; out[(size_t)r * n + l1 * Cc + c] = b; }
       pooled[(size_t)r * half + i] = fmaxf(a, b);
     }
   } else {
-    for (int i = tid; i < n; i += 256) {
-      const int l = i / Cc, c = i - l * Cc;
-      out[(size_t)r * n + i] = nl_elu((x[i] - mean) * rstd * gamma[c * L + l] + beta[c * L + l]);
-    }
+    for (int i = tid; i < n; i += 256) out[(size_t)r * n + i] = nl_elu((x[i] - mean) * rstd * gamma[i] + beta[i]);
   }
 }
 
