@@ -355,8 +355,11 @@ struct Ctx {
 
 struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; };
 
+struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; };   // out: destination when fused
+
+// fills the launch descriptor; *fused says whether the optional row epilogue will run inside the GEMM (else the caller runs it)
 int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
-             int So = 0, int Li = 0, int Lo = 0, int ostride = 1, int ooff = 0) {
+             int So = 0, int Li = 0, int Lo = 0, int ostride = 1, int ooff = 0, const RowEpi* epi = nullptr, bool* fused = nullptr) {
   NlGemmArgs a;
   memset(&a, 0, sizeof(a));
   int ksum = 0;
@@ -377,6 +380,13 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
   a.C = C; a.ldc = ldc; a.act = act;
   a.So = So; a.Li = Li; a.Lo = Lo; a.ostride = ostride; a.ooff = ooff;
+  if (fused) *fused = false;
+  if (epi) {
+    a.epi = NL_EPI_LNROW; a.ep_res = epi->res; a.ep_ldres = epi->ldres; a.ep_gamma = epi->gamma; a.ep_beta = epi->beta;
+    a.ep_scale = epi->scale; a.ep_eps = epi->eps;
+    if (nl_tgemm_supported(a, x.c->precision)) { a.C = epi->out; if (fused) *fused = true; }
+    else a.epi = NL_EPI_NONE;
+  }
   return nl_gemm_launch(a, x.c->precision, x.st);
 }
 
@@ -464,8 +474,11 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
   }
   SegSpec so{p.O, 128, 128, 0, 1};
-  NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE));
-  NL_TRY(nl_launch_ln_agg(p.FCo, G, N, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, p.wscale, FA, x.st));
+  // fc + residual + LayerNorm + aggregation scale: inside the GEMM's epilogue when the streaming kernel takes it
+  const RowEpi ep{G, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), p.wscale, 1e-6f, FA};
+  bool fused = false;
+  NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE, 0, 0, 0, 1, 0, &ep, &fused));
+  if (!fused) NL_TRY(nl_launch_ln_agg(p.FCo, G, N, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, p.wscale, FA, x.st));
   return NL_OK;
 }
 

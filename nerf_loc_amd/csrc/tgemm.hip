@@ -55,7 +55,7 @@ __device__ __forceinline__ int tg_find_seg(const NlGemmArgs& a, int k0) {
   return __builtin_amdgcn_readfirstlane(s);
 }
 
-template <int NRT, int NW, bool X3>
+template <int NRT, int NW, bool X3, int EPI>
 __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
                                                             const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
   constexpr int PARTS = X3 ? 2 : 1;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
   constexpr int CH16 = 4 * NRT * 64;        // 16-B units per chunk in the global stream (hi and lo parts are always stored)
   constexpr int SLOT16 = PIECES * 64;       // 16-B units per LDS slot
-  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8];
+  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8 * (EPI == NL_EPI_LNROW ? 3 : 1)];
   // native vector element type everywhere (struct-typed uint4 arrays in registers do not survive SROA)
   tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
   float* sbias = reinterpret_cast<float*>(lds_all + 2 * SLOT16);
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   if (a.So > 0) { q = m / a.So; t = m - q * a.So; }
   const int NC = a.Kpad >> 5;
 
-  for (int i = tid; i < NRT * 32; i += 64 * NW) sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
+  for (int i = tid; i < NRT * 32; i += 64 * NW) {
+    sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
+    if (EPI == NL_EPI_LNROW) { sbias[NRT * 32 + i] = a.ep_gamma[i]; sbias[2 * NRT * 32 + i] = a.ep_beta[i]; }   // N == 32 * NRT
+  }
 
   // weights of chunk c: this wave's NPW pieces, 16 B per lane, fully coalesced
   auto load_w = [&](int c, tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
@@ -184,6 +187,47 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   if (a.So > 0) orow = (size_t)(q * a.Lo + t * a.ostride + a.ooff) * a.ldc;
   else orow = (size_t)m * a.ldc;
   float* crow = p_c + orow;
+  if constexpr (EPI == NL_EPI_LNROW) {
+    // LayerNorm over the N = 32*NRT outputs of this lane's row (the other half of the row lives in lane ^ 32), after adding
+    // the residual row; two-pass mean / variance like torch
+    const float* rrow = a.ep_res + (size_t)m * a.ep_ldres;
+    float s1 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = 32 * rt + 8 * gq + 4 * hh;
+        const float4 b4 = *(const float4*)(sbias + n);
+        const float4 r4 = *(const float4*)(rrow + n);
+        acc[rt][4 * gq + 0] += b4.x + r4.x; acc[rt][4 * gq + 1] += b4.y + r4.y;
+        acc[rt][4 * gq + 2] += b4.z + r4.z; acc[rt][4 * gq + 3] += b4.w + r4.w;
+        s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 / (float)(32 * NRT);
+    float s2 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.f / sqrtf(s2 / (float)(32 * NRT) + a.ep_eps);
+    const float sc = a.ep_scale ? a.ep_scale[m] : 1.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = 32 * rt + 8 * gq + 4 * hh;
+        const float4 g4 = *(const float4*)(sbias + NRT * 32 + n), be4 = *(const float4*)(sbias + 2 * NRT * 32 + n);
+        float4 v;
+        v.x = ((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x) * sc;
+        v.y = ((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y) * sc;
+        v.z = ((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z) * sc;
+        v.w = ((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w) * sc;
+        *(float4*)(crow + n) = v;
+      }
+    return;
+  }
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -209,6 +253,7 @@ size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 *
 
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
+  if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
     if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k) return false;
@@ -222,7 +267,10 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
 #define NL_TG(NRT, NW, X3)                                                                                  \
   do {                                                                                                       \
     dim3 grid((unsigned)nl_cdiv(a.M, 32 * NW));                                                              \
-    hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias); \
+    if (a.epi == NL_EPI_LNROW)                                                                               \
+      hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, NL_EPI_LNROW>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias); \
+    else                                                                                                     \
+      hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, NL_EPI_NONE>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);  \
   } while (0)
   if (nrt == 8) { if (x3) NL_TG(8, 4, true); else NL_TG(8, 4, false); }
   else if (nrt == 4) { if (x3) NL_TG(4, 4, true); else NL_TG(4, 4, false); }
