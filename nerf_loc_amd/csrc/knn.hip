@@ -14,11 +14,11 @@
 //            holds >= K points is entered; the node where this stops (<= 8(K-1) points unless a fine cell is
 //            dense) is scanned, giving an upper bound U on the K-th neighbour's dist2.
 //   phase 2  breadth-first descent from the root, 8 nodes x 8 children per step, keeping children with points and
-//            mindist2(q, child box) <= U (boxes widened by a rounding slack); small / fine nodes become leaf ranges
-//            that are flattened with a wave prefix sum and scanned 64 candidates at a time (coalesced float4
-//            loads); the K best keys live replicated in registers and are updated by a wave-min selection loop;
-//            U tightens as soon as K real candidates are known.
-// Typical cost is ~1.5k wave instructions per query, independent of how far the query is from the cloud.
+//            mindist2(q, child box) <= U (boxes widened by a rounding slack); nodes with <= 16 points become leaves
+//            and are scanned four at a time (one per 16-lane slot); the K best keys are wave-uniform (SGPRs) and are
+//            updated by a selection loop built on DPP wave-min reductions; U tightens as soon as K real candidates
+//            are known.
+// The kernel is VALU-issue bound (not memory bound): the design goal is few vector instructions per query.
 #include "common.h"
 
 namespace {
@@ -131,25 +131,64 @@ __global__ void knn_scatter_kernel(const float* __restrict__ xyz, int M, const i
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    u64 t = __shfl_xor(v, o, 64);
-    v = t < v ? t : v;
-  }
-  return v;
+// ---- wave-uniform primitives -------------------------------------------------------------------------------------
+// Wave-wide unsigned min as 6 DPP-modified v_min_u32 (row_shr 1/2/4/8 scan inside each row of 16, then row_bcast:15 and
+// row_bcast:31 carry the row totals up) + one v_readlane: the result is wave-uniform (an SGPR).  The __shfl-based
+// butterflies this replaces were ds_bpermute round trips plus address arithmetic.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_umin(unsigned v) {
+  const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, ROWMASK, 0xf, false);
+  return t < v ? t : v;
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+  v = dpp_umin<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_umin<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_umin<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_umin<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_umin<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+  v = dpp_umin<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// The K best (dist2 bits, idx) keys, ascending, one per LANE (lane k < K holds the k-th best; other lanes hold the "none"
+// key).  An insert is then a handful of lane-parallel instructions whatever K is: every lane compares the new key with
+// its own entry and with its left neighbour's (one DPP row_shr:1 each) and keeps / takes the neighbour's / takes the new
+// key.  The admission threshold (the K-th best) is cached wave-uniformly.
 template <int K>
-__device__ __forceinline__ void insert_sorted(u64 (&best)[K], u64 key) {
-  // caller guarantees key < best[K-1]
-  best[K - 1] = key;
-#pragma unroll
-  for (int i = K - 1; i > 0; --i) {
-    u64 a = best[i - 1], b = best[i];
-    bool sw = b < a;
-    best[i - 1] = sw ? b : a;
-    best[i] = sw ? a : b;
+struct BestK {
+  unsigned d, i;     // this lane's entry
+  unsigned td, ti;   // entry K-1, wave-uniform
+  __device__ __forceinline__ void clear() { d = i = td = ti = 0xffffffffu; }
+  __device__ __forceinline__ bool full() const { return ti != 0xffffffffu; }
+  // caller guarantees (nd, ni) < (td, ti); nd, ni wave-uniform
+  __device__ __forceinline__ void insert(unsigned nd, unsigned ni) {
+    // left neighbour's entry; lane 0 (and every row start) sees (0, 0), which no key sorts before
+    const unsigned pd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x111, 0xf, 0xf, false);
+    const unsigned pi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)i, 0x111, 0xf, 0xf, false);
+    const bool lt_me = nd < d || (nd == d && ni < i);
+    const bool lt_prev = nd < pd || (nd == pd && ni < pi);
+    d = lt_me ? (lt_prev ? pd : nd) : d;
+    i = lt_me ? (lt_prev ? pi : ni) : i;
+    td = (unsigned)__builtin_amdgcn_readlane((int)d, K - 1);
+    ti = (unsigned)__builtin_amdgcn_readlane((int)i, K - 1);
+  }
+  __device__ __forceinline__ unsigned idx_at(int k) const { return (unsigned)__builtin_amdgcn_readlane((int)i, k); }
+};
+
+// Merge one candidate per lane (kd = bits(dist2), ki = idx; 0xffffffff/0xffffffff = none) into the best list.
+template <int K>
+__device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigned ki) {
+  while (true) {
+    const bool cont = kd < best.td || (kd == best.td && ki < best.ti);
+    if (__ballot(cont) == 0ull) break;
+    const unsigned dmin = wave_umin(cont ? kd : 0xffffffffu);
+    const bool tie = cont && kd == dmin;
+    const u64 tm = __ballot(tie);
+    unsigned imin;
+    if (__popcll(tm) == 1) imin = (unsigned)__builtin_amdgcn_readlane((int)ki, __builtin_ctzll(tm));
+    else imin = wave_umin(tie ? ki : 0xffffffffu);
+    best.insert(dmin, imin);
+    if (tie && ki == imin) { kd = 0xffffffffu; ki = 0xffffffffu; }
   }
 }
 
@@ -176,57 +215,42 @@ __device__ __forceinline__ float node_mindist2(const QueryCtx& c, unsigned m, in
   return dx * dx + dy * dy + dz * dz;
 }
 
-// Scan up to 32 point ranges (lane r < 32 holds (rs, len)) into the replicated best-K list.
+// candidate key of sorted[pos] for this lane (valid lanes only), with phase-1 survivors filtered out (DEDUPE: phase 2
+// revisits them; indices are unique per point)
 template <int K, bool DEDUPE>
-__device__ __forceinline__ void scan_ranges(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, u64 (&best)[K]) {
-  int pin = len;
+__device__ __forceinline__ void candidate(const QueryCtx& c, const float4* __restrict__ sorted, bool valid, int pos, const BestK<K>& best,
+                                          unsigned& kd, unsigned& ki) {
+  kd = 0xffffffffu; ki = 0xffffffffu;
+  if (valid) {
+    const float4 p = sorted[pos];
+    const float ddx = c.qx - p.x, ddy = c.qy - p.y, ddz = c.qz - p.z;
+    float d = __fmul_rn(ddx, ddx);
+    d = __fadd_rn(d, __fmul_rn(ddy, ddy));
+    d = __fadd_rn(d, __fmul_rn(ddz, ddz));
+    kd = __float_as_uint(d);
+    ki = (unsigned)__float_as_int(p.w);
+    if (DEDUPE) {
+      bool dup = false;
 #pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    int t = __shfl_up(pin, o, 64);
-    if (lane >= o) pin += t;
+      for (int k = 0; k < K; ++k) dup |= (ki == best.idx_at(k));
+      if (dup) { kd = 0xffffffffu; ki = 0xffffffffu; }
+    }
   }
-  const int T = __shfl(pin, 31, 64);
-  for (int base = 0; base < T; base += 64) {
-    const int i = base + lane;
-    int r = 0;  // r = #ranges whose inclusive prefix <= i
-#pragma unroll
-    for (int b = 16; b > 0; b >>= 1) {
-      const int t = r + b;
-      const int v = __shfl(pin, t - 1, 64);
-      if (i >= v) r = t;
-    }
-    r = r > 31 ? 31 : r;
-    const int pv = __shfl(pin, r > 0 ? r - 1 : 0, 64);   // shuffles must run on all lanes
-    const int pe = r > 0 ? pv : 0;
-    const int sr = __shfl(rs, r, 64);
-    u64 key = ~0ull;
-    if (i < T) {
-      const float4 p = sorted[sr + (i - pe)];
-      const float ddx = c.qx - p.x, ddy = c.qy - p.y, ddz = c.qz - p.z;
-      float d = __fmul_rn(ddx, ddx);
-      d = __fadd_rn(d, __fmul_rn(ddy, ddy));
-      d = __fadd_rn(d, __fmul_rn(ddz, ddz));
-      key = ((u64)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-      if (DEDUPE) {   // phase 2 revisits the points phase 1 already selected: keys are unique per point
-        bool dup = false;
-#pragma unroll
-        for (int i = 0; i < K; ++i) dup |= (key == best[i]);
-        if (dup) key = ~0ull;
-      }
-    }
-    while (true) {   // wave-level selection
-      const bool cont = key < best[K - 1];
-      if (__ballot(cont) == 0ull) break;
-      const u64 mk = wave_min_u64(cont ? key : ~0ull);
-      insert_sorted<K>(best, mk);
-      if (key == mk) key = ~0ull;
-    }
+}
+
+// one contiguous range [rs, rs+len) (wave-uniform), 64 candidates at a time
+template <int K, bool DEDUPE>
+__device__ __forceinline__ void scan_range(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, BestK<K>& best) {
+  for (int base = 0; base < len; base += 64) {
+    unsigned kd, ki;
+    candidate<K, DEDUPE>(c, sorted, base + lane < len, rs + base + lane, best, kd, ki);
+    select_into<K>(best, kd, ki);
   }
 }
 
 constexpr int FRONT_CAP = 256;   // frontier entries per wave (nodes kept as leaves beyond that)
 constexpr int LEAF_CAP = 128;
-constexpr int LEAF_COUNT_MAX = 16;  // nodes with <= this many points are scanned instead of expanded
+constexpr int LEAF_COUNT_MAX = 16;  // nodes with <= this many points are scanned instead of expanded; also the slot width
 
 template <int K>
 __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__ q, int N, const NlGridParams* __restrict__ gpp,
@@ -242,9 +266,8 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   c.cell = gpp->cell; c.slack = 1e-3f * c.cell;
   c.qx = q[3 * (size_t)n]; c.qy = q[3 * (size_t)n + 1]; c.qz = q[3 * (size_t)n + 2];
 
-  u64 best[K];
-#pragma unroll
-  for (int i = 0; i < K; ++i) best[i] = ~0ull;
+  BestK<K> best;
+  best.clear();
 
   // ---------------------------------------------------------------- phase 1: greedy descent -> upper bound U
   unsigned m = 0;
@@ -257,18 +280,16 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       const int cnt = starts[(mc + 1) << sh] - starts[mc << sh];
       if (cnt >= K) key = (__float_as_uint(node_mindist2(c, mc, L - 1)) & ~7u) | (unsigned)lane;
     }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o, 64));
-    key = (unsigned)__shfl((int)key, 0, 64);
+    key = wave_umin(key);
     if (key == 0xffffffffu) break;
     m = (m << 3) | (key & 7u);
     --L;
   }
   {
     const int rs0 = starts[m << (3 * L)], len0 = starts[(m + 1) << (3 * L)] - rs0;
-    scan_ranges<K, false>(c, sorted, lane == 0 ? rs0 : 0, lane == 0 ? len0 : 0, lane, best);
+    scan_range<K, false>(c, sorted, rs0, len0, lane, best);
   }
-  float U = best[K - 1] != ~0ull ? __uint_as_float((unsigned)(best[K - 1] >> 32)) : 3.4e38f;
+  float U = best.full() ? __uint_as_float(best.td) : 3.4e38f;
 
   // ---------------------------------------------------------------- phase 2: pruned breadth-first descent
   unsigned* front = s_front[wv][0];
@@ -279,14 +300,18 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   if (lane == 0) front[0] = 0u;
   const u64 lt_mask = (1ull << lane) - 1ull;
 
+  // leaves hold <= 16 points each: four leaves per 64-lane batch, one per 16-lane slot (no prefix sums, no index search)
   auto flush_leaves = [&]() {
-    for (int b = 0; b < nleaf; b += 32) {
-      const int i = b + lane;
-      const bool ok = lane < 32 && i < nleaf;
-      scan_ranges<K, true>(c, sorted, ok ? leaf_s[i] : 0, ok ? leaf_l[i] : 0, lane, best);
+    for (int b = 0; b < nleaf; b += 4) {
+      const int e = b + (lane >> 4);
+      const bool ok = e < nleaf;
+      const int rs = ok ? leaf_s[e] : 0, ln = ok ? leaf_l[e] : 0;
+      unsigned kd, ki;
+      candidate<K, true>(c, sorted, (lane & 15) < ln, rs + (lane & 15), best, kd, ki);
+      select_into<K>(best, kd, ki);
     }
     nleaf = 0;
-    if (best[K - 1] != ~0ull) U = fminf(U, __uint_as_float((unsigned)(best[K - 1] >> 32)));
+    if (best.full()) U = fminf(U, __uint_as_float(best.td));
   };
 
   for (L = GRID_BITS; L > 0; --L) {
@@ -313,11 +338,20 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       const bool spill = inner && pi >= room;
       if (inner && !spill) nextf[nnext + pi] = mc;
       nnext += ci < room ? ci : room;
+      // ranges wider than a slot (dense fine cells, spilled inner nodes) are rare: scanned right away, one by one
       const bool lf = leaf || spill;
-      const u64 ml = __ballot(lf);
+      u64 mbig = __ballot(lf && cnt > LEAF_COUNT_MAX);
+      while (mbig) {
+        const int src = __builtin_ctzll(mbig);
+        mbig &= mbig - 1;
+        scan_range<K, true>(c, sorted, __builtin_amdgcn_readlane(rs, src), __builtin_amdgcn_readlane(cnt, src), lane, best);
+        if (best.full()) U = fminf(U, __uint_as_float(best.td));
+      }
+      const bool small = lf && cnt <= LEAF_COUNT_MAX;
+      const u64 ml = __ballot(small);
       const int cl_ = __popcll(ml);
       if (nleaf + cl_ > LEAF_CAP) flush_leaves();
-      if (lf) { const int p = nleaf + __popcll(ml & lt_mask); leaf_s[p] = rs; leaf_l[p] = cnt; }
+      if (small) { const int p = nleaf + __popcll(ml & lt_mask); leaf_s[p] = rs; leaf_l[p] = cnt; }
       nleaf += cl_;
       if (nleaf >= 32) flush_leaves();
     }
@@ -328,12 +362,10 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   if (nleaf > 0) flush_leaves();
 
   if (lane < Kout && lane < K) {
-    u64 b = best[0];
-#pragma unroll
-    for (int k = 1; k < K; ++k) b = lane == k ? best[k] : b;
-    const bool ok = b != ~0ull;
-    idx_out[(size_t)n * Kout + lane] = ok ? (int)(unsigned)(b & 0xffffffffull) : 0;
-    d2_out[(size_t)n * Kout + lane] = ok ? __uint_as_float((unsigned)(b >> 32)) : 0.f;
+    const unsigned bd = best.d, bi = best.i;   // lane k holds the k-th best
+    const bool ok = bi != 0xffffffffu;
+    idx_out[(size_t)n * Kout + lane] = ok ? (int)bi : 0;
+    d2_out[(size_t)n * Kout + lane] = ok ? __uint_as_float(bd) : 0.f;
   }
 }
 
