@@ -150,25 +150,38 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+  const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+  return t > v ? t : v;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  v = dpp_umax<0x111, 0xf>(v); v = dpp_umax<0x112, 0xf>(v); v = dpp_umax<0x114, 0xf>(v); v = dpp_umax<0x118, 0xf>(v);
+  v = dpp_umax<0x142, 0xa>(v); v = dpp_umax<0x143, 0xc>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // The K best (dist2 bits, idx) keys, ascending, one per LANE (lane k < K holds the k-th best; other lanes hold the "none"
 // key).  An insert is then a handful of lane-parallel instructions whatever K is: every lane compares the new key with
 // its own entry and with its left neighbour's (one DPP row_shr:1 each) and keeps / takes the neighbour's / takes the new
 // key.  The admission threshold (the K-th best) is cached wave-uniformly.
 template <int K>
 struct BestK {
-  unsigned d, i;     // this lane's entry
+  unsigned d, i, p;  // this lane's entry; p = position of the point in the sorted array
   unsigned td, ti;   // entry K-1, wave-uniform
-  __device__ __forceinline__ void clear() { d = i = td = ti = 0xffffffffu; }
+  __device__ __forceinline__ void clear() { d = i = td = ti = 0xffffffffu; p = 0; }
   __device__ __forceinline__ bool full() const { return ti != 0xffffffffu; }
   // caller guarantees (nd, ni) < (td, ti); nd, ni wave-uniform
-  __device__ __forceinline__ void insert(unsigned nd, unsigned ni) {
+  __device__ __forceinline__ void insert(unsigned nd, unsigned ni, unsigned np) {
     // left neighbour's entry; lane 0 (and every row start) sees (0, 0), which no key sorts before
     const unsigned pd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x111, 0xf, 0xf, false);
     const unsigned pi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)i, 0x111, 0xf, 0xf, false);
+    const unsigned pp = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0x111, 0xf, 0xf, false);
     const bool lt_me = nd < d || (nd == d && ni < i);
     const bool lt_prev = nd < pd || (nd == pd && ni < pi);
     d = lt_me ? (lt_prev ? pd : nd) : d;
     i = lt_me ? (lt_prev ? pi : ni) : i;
+    p = lt_me ? (lt_prev ? pp : np) : p;
     td = (unsigned)__builtin_amdgcn_readlane((int)d, K - 1);
     ti = (unsigned)__builtin_amdgcn_readlane((int)i, K - 1);
   }
@@ -177,7 +190,7 @@ struct BestK {
 
 // Merge one candidate per lane (kd = bits(dist2), ki = idx; 0xffffffff/0xffffffff = none) into the best list.
 template <int K>
-__device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigned ki) {
+__device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigned ki, unsigned kp) {
   while (true) {
     const bool cont = kd < best.td || (kd == best.td && ki < best.ti);
     if (__ballot(cont) == 0ull) break;
@@ -185,9 +198,13 @@ __device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigne
     const bool tie = cont && kd == dmin;
     const u64 tm = __ballot(tie);
     unsigned imin;
-    if (__popcll(tm) == 1) imin = (unsigned)__builtin_amdgcn_readlane((int)ki, __builtin_ctzll(tm));
-    else imin = wave_umin(tie ? ki : 0xffffffffu);
-    best.insert(dmin, imin);
+    int src = __builtin_ctzll(tm);
+    if (__popcll(tm) == 1) imin = (unsigned)__builtin_amdgcn_readlane((int)ki, src);
+    else {
+      imin = wave_umin(tie ? ki : 0xffffffffu);
+      src = __builtin_ctzll(__ballot(tie && ki == imin));
+    }
+    best.insert(dmin, imin, (unsigned)__builtin_amdgcn_readlane((int)kp, src));
     if (tie && ki == imin) { kd = 0xffffffffu; ki = 0xffffffffu; }
   }
 }
@@ -244,52 +261,69 @@ __device__ __forceinline__ void scan_range(const QueryCtx& c, const float4* __re
   for (int base = 0; base < len; base += 64) {
     unsigned kd, ki;
     candidate<K, DEDUPE>(c, sorted, base + lane < len, rs + base + lane, best, kd, ki);
-    select_into<K>(best, kd, ki);
+    select_into<K>(best, kd, ki, (unsigned)(rs + base + lane));
   }
 }
 
 constexpr int FRONT_CAP = 256;   // frontier entries per wave (nodes kept as leaves beyond that)
 constexpr int LEAF_CAP = 128;
-constexpr int LEAF_COUNT_MAX = 16;  // nodes with <= this many points are scanned instead of expanded; also the slot width
+constexpr int LEAF_COUNT_MAX = 8;   // nodes with <= this many points are scanned instead of expanded; also the slot width
 
-template <int K>
+template <int K, int SPW>
 __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__ q, int N, const NlGridParams* __restrict__ gpp,
                                                        const int* __restrict__ starts, const float4* __restrict__ sorted,
                                                        int Kout, int* __restrict__ idx_out, float* __restrict__ d2_out) {
   __shared__ unsigned s_front[4][2][FRONT_CAP];
   __shared__ int s_leaf_s[4][LEAF_CAP], s_leaf_l[4][LEAF_CAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int n = __builtin_amdgcn_readfirstlane(nl_xcd_block() * 4 + wv);
-  if (n >= N) return;
+  const int n0 = __builtin_amdgcn_readfirstlane((nl_xcd_block() * 4 + wv) * SPW);
   QueryCtx c;
   c.org0 = gpp->origin[0]; c.org1 = gpp->origin[1]; c.org2 = gpp->origin[2];
   c.cell = gpp->cell; c.slack = 1e-3f * c.cell;
+  bool prev_full = false;   // the previous query of this wave found K neighbours, whose sorted-array positions are
+  unsigned ppos = 0;        // in ppos (lane k < K)
+
+  // A wave answers SPW consecutive queries (neighbouring samples of a ray).  Only the first one pays for phase 1: the K
+  // neighbours of the previous query, re-measured from this one, give the bound instead.
+  for (int sq = 0; sq < SPW; ++sq) {
+  const int n = n0 + sq;
+  if (n >= N) return;
   c.qx = q[3 * (size_t)n]; c.qy = q[3 * (size_t)n + 1]; c.qz = q[3 * (size_t)n + 2];
 
   BestK<K> best;
   best.clear();
-
-  // ---------------------------------------------------------------- phase 1: greedy descent -> upper bound U
-  unsigned m = 0;
-  int L = GRID_BITS;
-  while (L > 0) {
-    unsigned key = 0xffffffffu;
-    if (lane < 8) {
-      const unsigned mc = (m << 3) | (unsigned)lane;
-      const int sh = 3 * (L - 1);
-      const int cnt = starts[(mc + 1) << sh] - starts[mc << sh];
-      if (cnt >= K) key = (__float_as_uint(node_mindist2(c, mc, L - 1)) & ~7u) | (unsigned)lane;
+  float U;
+  if (!prev_full) {
+    // -------------------------------------------------------------- phase 1: greedy descent -> upper bound U
+    unsigned m = 0;
+    int L = GRID_BITS;
+    while (L > 0) {
+      unsigned key = 0xffffffffu;
+      if (lane < 8) {
+        const unsigned mc = (m << 3) | (unsigned)lane;
+        const int sh = 3 * (L - 1);
+        const int cnt = starts[(mc + 1) << sh] - starts[mc << sh];
+        if (cnt >= K) key = (__float_as_uint(node_mindist2(c, mc, L - 1)) & ~7u) | (unsigned)lane;
+      }
+      key = wave_umin(key);
+      if (key == 0xffffffffu) break;
+      m = (m << 3) | (key & 7u);
+      --L;
     }
-    key = wave_umin(key);
-    if (key == 0xffffffffu) break;
-    m = (m << 3) | (key & 7u);
-    --L;
-  }
-  {
     const int rs0 = starts[m << (3 * L)], len0 = starts[(m + 1) << (3 * L)] - rs0;
     scan_range<K, false>(c, sorted, rs0, len0, lane, best);
+    U = best.full() ? __uint_as_float(best.td) : 3.4e38f;
+  } else {
+    // upper bound from the previous query's neighbours (lane k < K re-measures its k-th one): the largest of their K
+    // distances to this query bounds this query's K-th distance, and is usually within a few percent of it
+    float dprev = 0.f;
+    if (lane < K) {
+      const float4 pt = sorted[ppos];
+      const float ddx = c.qx - pt.x, ddy = c.qy - pt.y, ddz = c.qz - pt.z;
+      dprev = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
+    }
+    U = __uint_as_float(wave_umax(__float_as_uint(dprev)));
   }
-  float U = best.full() ? __uint_as_float(best.td) : 3.4e38f;
 
   // ---------------------------------------------------------------- phase 2: pruned breadth-first descent
   unsigned* front = s_front[wv][0];
@@ -302,19 +336,20 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
 
   // leaves hold <= 16 points each: four leaves per 64-lane batch, one per 16-lane slot (no prefix sums, no index search)
   auto flush_leaves = [&]() {
-    for (int b = 0; b < nleaf; b += 4) {
-      const int e = b + (lane >> 4);
+    constexpr int SL = LEAF_COUNT_MAX;   // lanes per slot
+    for (int b = 0; b < nleaf; b += 64 / SL) {
+      const int e = b + lane / SL;
       const bool ok = e < nleaf;
       const int rs = ok ? leaf_s[e] : 0, ln = ok ? leaf_l[e] : 0;
       unsigned kd, ki;
-      candidate<K, true>(c, sorted, (lane & 15) < ln, rs + (lane & 15), best, kd, ki);
-      select_into<K>(best, kd, ki);
+      candidate<K, true>(c, sorted, (lane % SL) < ln, rs + (lane % SL), best, kd, ki);
+      select_into<K>(best, kd, ki, (unsigned)(rs + (lane % SL)));
     }
     nleaf = 0;
     if (best.full()) U = fminf(U, __uint_as_float(best.td));
   };
 
-  for (L = GRID_BITS; L > 0; --L) {
+  for (int L = GRID_BITS; L > 0; --L) {
     int nnext = 0;
     const int sh = 3 * (L - 1);
     for (int base = 0; base < nfront; base += 8) {
@@ -367,6 +402,9 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
     idx_out[(size_t)n * Kout + lane] = ok ? (int)bi : 0;
     d2_out[(size_t)n * Kout + lane] = ok ? __uint_as_float(bd) : 0.f;
   }
+  prev_full = best.full();
+  ppos = best.p;
+  }   // queries of this wave
 }
 
 }  // namespace
@@ -420,11 +458,12 @@ int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* i
     return NL_OK;
   }
   if (K < 1 || K > 8) return NL_ERR_UNSUPPORTED;
-  dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
+  constexpr int SPW = 4;
+  dim3 grid(nl_xcd_grid(nl_cdiv(N, 4 * SPW)));
   if (K == 1)
-    hipLaunchKernelGGL(knn_wave_kernel<1>, grid, dim3(256), 0, st, xyz, (int)N, g->params, g->starts, g->sorted, K, idx, d2);
+    hipLaunchKernelGGL((knn_wave_kernel<1, SPW>), grid, dim3(256), 0, st, xyz, (int)N, g->params, g->starts, g->sorted, K, idx, d2);
   else
-    hipLaunchKernelGGL(knn_wave_kernel<8>, grid, dim3(256), 0, st, xyz, (int)N, g->params, g->starts, g->sorted, K, idx, d2);
+    hipLaunchKernelGGL((knn_wave_kernel<8, SPW>), grid, dim3(256), 0, st, xyz, (int)N, g->params, g->starts, g->sorted, K, idx, d2);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
