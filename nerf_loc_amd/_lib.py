@@ -14,7 +14,8 @@ import torch  # noqa: F401  -- MUST precede CDLL: torch bundles its own libamdhi
 # would be foreign to our kernels.  Importing torch first makes the dynamic loader resolve our DT_NEEDED to its copy.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnerfloc_render.so")
+# NERFLOC_LIB: developer override used for same-box A/B timing of two builds of the library
+LIB_PATH = os.environ.get("NERFLOC_LIB") or os.path.join(_HERE, "csrc", "libnerfloc_render.so")
 
 NL_OK = 0
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2

@@ -287,7 +287,15 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
       for (int s = 0; s < 2; ++s) {
         float v[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { float x = acc[rt][8 * s + t]; v[t] = fmaxf(x, 0.01f * x); }
+        for (int t = 0; t < 8; t += 2) {
+          // LeakyReLU = max(x, 0.01 x): packed multiply, and a bare v_max_f32 (fmaxf() adds a canonicalising v_max x,x per
+          // element, which is one instruction in six of this epilogue; NaN ordering is irrelevant here)
+          typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+          const pf_f32x2 x2 = {acc[rt][8 * s + t], acc[rt][8 * s + t + 1]};
+          const pf_f32x2 y2 = x2 * 0.01f;
+          asm("v_max_f32 %0, %1, %2" : "=v"(v[t]) : "v"(x2[0]), "v"(y2[0]));
+          asm("v_max_f32 %0, %1, %2" : "=v"(v[t + 1]) : "v"(x2[1]), "v"(y2[1]));
+        }
         split8<X3>(v, fh[2 * rt + s], fl[2 * rt + s]);
       }
   };
