@@ -355,7 +355,7 @@ struct Ctx {
 
 struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; };
 
-struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; };   // out: destination when fused
+struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0; };   // out: destination when fused
 
 // fills the launch descriptor; *fused says whether the optional row epilogue will run inside the GEMM (else the caller runs it)
 int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
@@ -382,7 +382,7 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   a.So = So; a.Li = Li; a.Lo = Lo; a.ostride = ostride; a.ooff = ooff;
   if (fused) *fused = false;
   if (epi) {
-    a.epi = NL_EPI_LNROW; a.ep_res = epi->res; a.ep_ldres = epi->ldres; a.ep_gamma = epi->gamma; a.ep_beta = epi->beta;
+    a.epi = epi->kind; a.ep_pool = epi->pool; a.ep_res = epi->res; a.ep_ldres = epi->ldres; a.ep_gamma = epi->gamma; a.ep_beta = epi->beta;
     a.ep_scale = epi->scale; a.ep_eps = epi->eps;
     if (nl_tgemm_supported(a, x.c->precision)) { a.C = epi->out; if (fused) *fused = true; }
     else a.epi = NL_EPI_NONE;
@@ -489,8 +489,10 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   const float eps = 1e-5f;
   {  // conv1: W -> 64 over S
     SegSpec s[3] = {{in, W, W, -1, 1}, {in, W, W, 0, 1}, {in, W, W, 1, 1}};
-    NL_TRY(run_gemm(x, G_CONV1, s, 3, R * S, u.r1, 64, NL_ACT_NONE, S, S, S));
-    NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
+    const RowEpi ep{nullptr, 0, g(U_CONV1), b(U_CONV1), nullptr, eps, u.c1, NL_EPI_LNSLAB, 1};   // LN + ELU + MaxPool inside the GEMM when one workgroup = one ray
+    bool fused = false;
+    NL_TRY(run_gemm(x, G_CONV1, s, 3, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
+    if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
   }
   {  // conv2: 64 -> 128 over S/2
     SegSpec s[3] = {{u.c1, 64, 64, -1, 1}, {u.c1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}};
@@ -528,8 +530,10 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   }
   {  // conv_out on cat[in, x2]
     SegSpec s[6] = {{in, W, W, -1, 1}, {u.x2, 32, 32, -1, 1}, {in, W, W, 0, 1}, {u.x2, 32, 32, 0, 1}, {in, W, W, 1, 1}, {u.x2, 32, 32, 1, 1}};
-    NL_TRY(run_gemm(x, G_CONVOUT, s, 6, R * S, u.outr, W, NL_ACT_NONE, S, S, S));
-    NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
+    const RowEpi ep{nullptr, 0, g(U_OUT), b(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
+    bool fused = false;
+    NL_TRY(run_gemm(x, G_CONVOUT, s, 6, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
+    if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
   }
   return NL_OK;
 }

@@ -104,13 +104,15 @@ struct NlGemmArgs {
   // row mapping: So==0 plain (out row = m); else r=m/So, t=m%So, in row = r*Li + t + ioff (valid 0<=t+ioff<Li),
   // out row = r*Lo + t*ostride + ooff
   int So, Li, Lo, ostride, ooff;
-  // optional fused row epilogue (tgemm.hip only; epi = NL_EPI_LNROW): out = (LayerNorm(acc + res[m]; eps) * gamma + beta) * scale[m]
-  int epi;
+  // optional fused epilogues (tgemm.hip only)
+  //   NL_EPI_LNROW : out = (LayerNorm_row(acc + res[m]; eps) * gamma[n] + beta[n]) * scale[m]
+  //   NL_EPI_LNSLAB: out = ELU(LayerNorm over the whole (So x N) slab of one ray * gamma[t][n] + beta[t][n]); ep_pool: MaxPool(2) along the ray
+  int epi; int ep_pool;
   const float* ep_res; int ep_ldres;
   const float* ep_gamma; const float* ep_beta; const float* ep_scale;
   float ep_eps;
 };
-enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1 };
+enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1, NL_EPI_LNSLAB = 2 };
 
 int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);
 // streaming transposed GEMM (tgemm.hip): bf16 modes, N <= 256, 16-B aligned segments

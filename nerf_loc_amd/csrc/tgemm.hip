@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
   constexpr int CH16 = 4 * NRT * 64;        // 16-B units per chunk in the global stream (hi and lo parts are always stored)
   constexpr int SLOT16 = PIECES * 64;       // 16-B units per LDS slot
-  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8 * (EPI == NL_EPI_LNROW ? 3 : 1)];
+  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8 * (EPI == NL_EPI_LNROW ? 3 : 1) + (EPI == NL_EPI_LNSLAB ? 8 : 0)];
   // native vector element type everywhere (struct-typed uint4 arrays in registers do not survive SROA)
   tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
   float* sbias = reinterpret_cast<float*>(lds_all + 2 * SLOT16);
@@ -88,8 +88,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 #pragma unroll
     for (int jj = 0; jj < NPW; ++jj) w[jj] = src[(wave + NW * jj) * 64 + lane];
   };
-  auto store_w = [&](auto SLOT, const tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
-    constexpr int slot = decltype(SLOT)::value;
+  auto store_w = [&](int slot, const tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
 #pragma unroll
     for (int jj = 0; jj < NPW; ++jj) ring[slot][(wave + NW * jj) * 64 + lane] = w[jj];
   };
@@ -127,8 +126,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
   // one chunk: 2 k-steps x NRT row tiles x (3 | 1) MFMAs; A fragments are read two (k-step, tile) pairs ahead
-  auto compute = [&](auto SLOT, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
-    constexpr int slot = decltype(SLOT)::value;
+  auto compute = [&](int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
     const tg_bf16x8* L = ring[slot];
     constexpr int nt = 2 * NRT;
     auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
@@ -162,26 +160,85 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   float4 raw[4];
   auto clampc = [&](int c) { return c < NC ? c : NC - 1; };
   load_act(0, raw); load_w(0, wreg);
-  store_w(std::integral_constant<int, 0>{}, wreg);
+  store_w(0, wreg);
   __syncthreads();
-  auto step = [&](auto U, int g) __attribute__((always_inline)) {
-    constexpr int u = decltype(U)::value;
+  for (int g = 0; g < NC; ++g) {   // one straight-line body, no control flow around the MFMAs (accumulators stay put)
     tg_bf16x8 bh[2], bl[2];
     convert(raw, bh, bl);
     load_act(clampc(g + 1), raw);
     load_w(clampc(g + 1), wreg);
-    compute(U, bh, bl);
-    store_w(std::integral_constant<int, 1 - u>{}, wreg);
+    compute(g & 1, bh, bl);
+    store_w((g + 1) & 1, wreg);
     __syncthreads();
-  };
-  int g0 = 0;
-  for (; g0 + 1 < NC; g0 += 2) {
-    step(std::integral_constant<int, 0>{}, g0);
-    step(std::integral_constant<int, 1>{}, g0 + 1);
   }
-  if (g0 < NC) step(std::integral_constant<int, 0>{}, g0);
 
   // epilogue: C/D layout col = lane&31 (= this lane's output row), reg r = 4*gq + e <-> n = 32*rt + 8*gq + 4*hh + e
+  if constexpr (EPI == NL_EPI_LNSLAB) {
+    // The workgroup's 32*NW rows are exactly one ray (launch precondition: So == 32*NW, M % So == 0): LayerNorm over the
+    // ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional MaxPool(2) along the ray.
+    float* red = sbias + NRT * 32;   // [2][NW] partial sums
+    float s1 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = 32 * rt + 8 * gq + 4 * hh;
+        if (n < a.N) {
+          const float4 b4 = *(const float4*)(sbias + n);
+          acc[rt][4 * gq + 0] += b4.x; acc[rt][4 * gq + 1] += b4.y; acc[rt][4 * gq + 2] += b4.z; acc[rt][4 * gq + 3] += b4.w;
+          s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+        }
+      }
+    s1 = wave_sum(s1);
+    if (lane == 0) red[wave] = s1;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w];
+    const float cnt = (float)(32 * NW) * (float)a.N;
+    const float mean = tot / cnt;
+    float s2 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        if (32 * rt + 8 * gq + 4 * hh < a.N) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = acc[rt][4 * gq + e] - mean; s2 += d * d; }
+        }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[NW + wave] = s2;
+    __syncthreads();
+    float tot2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot2 += red[NW + w];
+    const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
+    const float* grow = a.ep_gamma + (size_t)t * a.N;
+    const float* brow = a.ep_beta + (size_t)t * a.N;
+    const bool pool = a.ep_pool != 0;
+    float* orow_p = p_c + (size_t)(pool ? q * (a.So / 2) + (t >> 1) : m) * a.ldc;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = 32 * rt + 8 * gq + 4 * hh;
+        if (n < a.N) {
+          const float4 g4 = *(const float4*)(grow + n), be4 = *(const float4*)(brow + n);
+          float4 v;
+          v.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
+          v.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
+          v.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
+          v.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
+          if (pool) {   // positions 2p, 2p+1 are neighbouring lanes
+            v.x = fmaxf(v.x, __shfl_xor(v.x, 1, 64)); v.y = fmaxf(v.y, __shfl_xor(v.y, 1, 64));
+            v.z = fmaxf(v.z, __shfl_xor(v.z, 1, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, 1, 64));
+          }
+          if (!pool || !(j & 1)) *(float4*)(orow_p + n) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the gamma/beta loads of later tiles from being hoisted (register budget)
+      }
+    return;
+  }
   if (!mok) return;
   size_t orow;
   if (a.So > 0) orow = (size_t)(q * a.Lo + t * a.ostride + a.ooff) * a.ldc;
@@ -254,6 +311,7 @@ size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 *
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
+  if (a.epi == NL_EPI_LNSLAB && (a.So != 128 || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
     if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k) return false;
@@ -269,6 +327,8 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
     dim3 grid((unsigned)nl_cdiv(a.M, 32 * NW));                                                              \
     if (a.epi == NL_EPI_LNROW)                                                                               \
       hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, NL_EPI_LNROW>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias); \
+    else if (a.epi == NL_EPI_LNSLAB)                                                                         \
+      hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, NL_EPI_LNSLAB>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias); \
     else                                                                                                     \
       hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, NL_EPI_NONE>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);  \
   } while (0)
