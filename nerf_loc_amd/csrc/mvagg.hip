@@ -259,7 +259,7 @@ __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_re
 // the feature map and the image (validity folded into zero weights + clamped offsets, so phase-B loads are unconditional),
 // view-angle features, visibility weight.  Phase B: unrolled loop over views; the per-view scalars come from
 // v_readlane with a constant lane (-> SGPRs), lanes span channels (64 lanes x 3 floats = one 768-B texel row per tap).
-template <int VT>
+template <int VT, bool V4>
 __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
                                                        const float* __restrict__ images /*(V,3,H,W)*/,
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
@@ -336,26 +336,37 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
 #pragma unroll
   for (int i = 0; i < 8; ++i) bwr[i] = (bl1 && lane < 32) ? blw[lane * 8 + i] : 0.f;
   if (bl1 && lane < 32) bbias = blw[256 + lane];
-  float xv[VT][4];
+  float xv[VT][5];   // [0..3]: feature channels (V4: 4*lane+j; else lane+64j for j<3), [4]: rgb plane `lane` (lanes 0..2)
   const int lch = lane < 3 ? lane : 0;
 #pragma unroll
   for (int v = 0; v < VT; ++v) {
-    xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = 0.f;
+    xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = xv[v][4] = 0.f;
     if (v < V) {
       const float w0 = rl(a_fw[0], v), w1 = rl(a_fw[1], v), w2 = rl(a_fw[2], v), w3 = rl(a_fw[3], v);
       const int o0 = rli(a_fo[0], v), o1 = rli(a_fo[1], v), o2 = rli(a_fo[2], v), o3 = rli(a_fo[3], v);
       const float* fb = feat + (size_t)v * vw.h * vw.w * C;
+      if constexpr (V4) {   // lanes 0..C/4-1 take 4 consecutive channels each: one 16-B load per tap instead of three 4-B ones
+        if (4 * lane < C) {
+          const float4 t0 = *(const float4*)(fb + (size_t)o0 * C + 4 * lane), t1 = *(const float4*)(fb + (size_t)o1 * C + 4 * lane);
+          const float4 t2 = *(const float4*)(fb + (size_t)o2 * C + 4 * lane), t3 = *(const float4*)(fb + (size_t)o3 * C + 4 * lane);
+          xv[v][0] = t0.x * w0 + t1.x * w1 + t2.x * w2 + t3.x * w3;
+          xv[v][1] = t0.y * w0 + t1.y * w1 + t2.y * w2 + t3.y * w3;
+          xv[v][2] = t0.z * w0 + t1.z * w1 + t2.z * w2 + t3.z * w3;
+          xv[v][3] = t0.w * w0 + t1.w * w1 + t2.w * w2 + t3.w * w3;
+        }
+      } else {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int ch = lane + 64 * j;
-        if (ch < C) xv[v][j] = fb[(size_t)o0 * C + ch] * w0 + fb[(size_t)o1 * C + ch] * w1 + fb[(size_t)o2 * C + ch] * w2 + fb[(size_t)o3 * C + ch] * w3;
+        for (int j = 0; j < 3; ++j) {
+          const int ch = lane + 64 * j;
+          if (ch < C) xv[v][j] = fb[(size_t)o0 * C + ch] * w0 + fb[(size_t)o1 * C + ch] * w1 + fb[(size_t)o2 * C + ch] * w2 + fb[(size_t)o3 * C + ch] * w3;
+        }
       }
       {
         const float i0 = rl(a_iw[0], v), i1 = rl(a_iw[1], v), i2 = rl(a_iw[2], v), i3 = rl(a_iw[3], v);
         const int q0 = rli(a_io[0], v), q1 = rli(a_io[1], v), q2 = rli(a_io[2], v), q3 = rli(a_io[3], v);
         const float* ib = images + ((size_t)v * 3 + lch) * vw.H * vw.Wimg;
         const float val = ib[q0] * i0 + ib[q1] * i1 + ib[q2] * i2 + ib[q3] * i3;
-        xv[v][3] = lane < 3 ? val : 0.f;
+        xv[v][4] = lane < 3 ? val : 0.f;
       }
       const float s_vis = rl(a_vis, v);
       if (bl1) {
@@ -363,23 +374,23 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
         //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap); plus rgb / visibility / angle columns + bias
         const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32 + (lane & 31);
         const float pv = pb[(size_t)o0 * 32] * w0 + pb[(size_t)o1 * 32] * w1 + pb[(size_t)o2 * 32] * w2 + pb[(size_t)o3 * 32] * w3;
-        const float r = rl(xv[v][3], 0), g = rl(xv[v][3], 1), bb = rl(xv[v][3], 2);
+        const float r = rl(xv[v][4], 0), g = rl(xv[v][4], 1), bb = rl(xv[v][4], 2);
         float o = pv + bbias;
         o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
         o = fmaf(bwr[3], s_vis, o);
         o = fmaf(bwr[4], rl(a_ang[0], v), o); o = fmaf(bwr[5], rl(a_ang[1], v), o);
         o = fmaf(bwr[6], rl(a_ang[2], v), o); o = fmaf(bwr[7], rl(a_ang[3], v), o);
         if (lane < 32) bl1[((size_t)n * V + v) * 32 + lane] = o;
-        if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][3] : s_vis;
+        if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][4] : s_vis;
       }
       if (rgb_feat) {   // stage API only: materialise the raw multi-view projection and [vis, angle]
         float* row = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int ch = lane + 64 * j;
+        for (int j = 0; j < (V4 ? 4 : 3); ++j) {
+          const int ch = V4 ? 4 * lane + j : lane + 64 * j;
           if (ch < C) row[3 + ch] = xv[v][j];
         }
-        if (lane < 3) row[lane] = xv[v][3];
+        if (lane < 3) row[lane] = xv[v][4];
         if (lane == 3) row[F] = 0.f;
         if (lane == 0 && vis_ang) {
           float* va = vis_ang + ((size_t)n * V + v) * 8;
@@ -395,7 +406,8 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
   for (int v = 0; v < VT; ++v) wg[v] = v < V ? rl(a_wgt, v) : 0.f;
   float* g = g393 + (size_t)n * ldg;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 5; ++j) {
+    if (!V4 && j == 3) continue;   // the scalar layout has three feature slots
     float mean = 0.f;
 #pragma unroll
     for (int v = 0; v < VT; ++v) mean += xv[v][j] * wg[v];
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
 #pragma unroll
     for (int v = 0; v < VT; ++v) { float d = xv[v][j] - mean; var += wg[v] * (d * d); }
     int pos = -1;
-    if (j < 3) { int ch = lane + 64 * j; if (ch < C) pos = 3 + ch; }
+    if (j < 4) { const int ch = V4 ? 4 * lane + j : lane + 64 * j; if (ch < C) pos = 3 + ch; }
     else if (lane < 3) pos = lane;
     if (pos >= 0) { g[pos] = mean; g[F + pos] = var; }
   }
@@ -465,14 +477,15 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
+  const bool v4 = (C % 4 == 0) && ((((size_t)feat) & 15) == 0);   // 16-B channel groups
   if (vw.V <= 4)
-    hipLaunchKernelGGL(mv_stats_kernel<4>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<4, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<4, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   else if (vw.V <= 8)
-    hipLaunchKernelGGL(mv_stats_kernel<8>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<8, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<8, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   else if (vw.V <= 10)
-    hipLaunchKernelGGL(mv_stats_kernel<10>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<10, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<10, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   else
-    hipLaunchKernelGGL(mv_stats_kernel<16>, grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv);
+    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<16, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<16, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
