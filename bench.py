@@ -122,6 +122,17 @@ def main():
 
     wall, dev_ms = timed(args.steps, args.warmup)
     ms_per_step = wall * 1e3 / args.steps
+
+    # dominant kernel (fused neural-point kernel): HIP events around each of its launches, on the
+    # stream it is launched on, over a second pass of the same steps (the events themselves are outside `value`)
+    import ctypes as ct
+    from nerf_loc_amd import _lib
+    lib = _lib.load()
+    lib.nl_profile_begin()
+    for _ in range(args.steps):
+        step()
+    fused_ms, launches = ct.c_float(0), ct.c_int(0)
+    _lib.check(lib.nl_profile_end(ct.byref(fused_ms), ct.byref(launches)), "nl_profile_end")
     value = world * R * args.steps / wall
     flops_step = 2.0 * algorithmic_mac_per_sample(cfg.W, cfg.V, cfg.C) * R * S
     ach = flops_step / (dev_ms * 1e-3 / args.steps) / 1e12
@@ -137,6 +148,19 @@ def main():
                      "traffic": hbm_traffic(args.config, args.precision), "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
                      "flops_per_step": flops_step, "device_ms_per_step": dev_ms / args.steps},
     }
+    if launches.value > 0:
+        K, F, W = 8, cfg.C + 3, cfg.W
+        mac_alg = K * (496 + (F + 90) * W + 2 * W * W + 2 * 128 * W) + 16384      # a9 ray_diff_fc, a10 base_mlp, k/v projection, a11 attention (SURVEY §8d terms)
+        mac_exec = K * (96 * W + 2 * W * W + 256 * W)                               # what the kernel multiplies (feature columns come from the per-frame table T)
+        samples_per_launch = R * S * args.steps / launches.value
+        sec = fused_ms.value * 1e-3 / launches.value
+        alg = 2.0 * mac_alg * samples_per_launch / sec / 1e12
+        result["roofline"]["dominant_kernel"] = {
+            "name": "point_fused_kernel", "launches": launches.value, "avg_ms": fused_ms.value / launches.value,
+            "share_of_step": fused_ms.value / args.steps / (dev_ms / args.steps),
+            "achieved": alg, "frac": alg / PEAK_BF16_TFLOPS, "unit": "TFLOP/s (algorithmic, SURVEY §8d)",
+            "executed_mfma_TFLOPs": 2.0 * mac_exec * (3 if args.precision == "bf16x3" else 1) * samples_per_launch / sec / 1e12,
+        }
 
     if args.also and world == 1:
         extra = {}

@@ -106,6 +106,13 @@ const char* nl_strerror(int status);
 int nl_num_weights(void);
 const char* nl_weight_name(int i);
 
+/* Measurement hook (no reference counterpart): between nl_profile_begin and nl_profile_end every launch of the dominant
+ * kernel (the fused neural-point kernel, rows a9-a11) made through this library is bracketed by HIP events on its own
+ * stream; nl_profile_end synchronises, returns the summed device time in ms and the number of launches, and disarms.
+ * bench.py uses it for roofline.dominant_kernel. */
+int nl_profile_begin(void);
+int nl_profile_end(float* fused_ms, int* launches);
+
 /* ---- weights ---------------------------------------------------------------------------------- */
 size_t nl_packed_weights_bytes(const nl_config* cfg);
 /* tensors[i] = DEVICE pointer of state_dict[nl_weight_name(i)] (fp32, contiguous, torch layout). */

@@ -50,6 +50,8 @@ _P, _I, _L, _Z, _F = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _CFG, _DESC, _OUT = C.POINTER(NlConfig), C.POINTER(NlFrameDesc), C.POINTER(NlRenderOut)
 SYMBOLS = [
     ("nl_abi_version", _I, []),
+    ("nl_profile_begin", _I, []),
+    ("nl_profile_end", _I, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     ("nl_strerror", C.c_char_p, [_I]),
     ("nl_num_weights", _I, []),
     ("nl_weight_name", C.c_char_p, [_I]),

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <vector>
 #include "common.h"
 
 // ---- launchers implemented in the other translation units -------------------------------------------
@@ -430,6 +431,21 @@ int ensure_ptt(const Ctx& x, const nl_frame* fc) {
   return NL_OK;
 }
 
+// ---- measurement hook: HIP events around the dominant kernel (nl_profile_begin / nl_profile_end) -----------------
+struct ProfState { bool on = false; std::vector<hipEvent_t> ev; int used = 0; };
+ProfState g_prof;
+bool prof_arm(hipEvent_t* e0, hipEvent_t* e1) {
+  if (!g_prof.on) return false;
+  if (g_prof.used + 2 > (int)g_prof.ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+    g_prof.ev.push_back(a); g_prof.ev.push_back(b);
+  }
+  *e0 = g_prof.ev[g_prof.used]; *e1 = g_prof.ev[g_prof.used + 1];
+  g_prof.used += 2;
+  return true;
+}
+
 int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
           float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m) {
   const NlViews vw = with_query(f, qc);
@@ -459,7 +475,10 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
     a.wstream = x.p<uint4>(x.L.pt_stream); a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
     a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));
+    if (pe1) NL_CHECK_HIP(hipEventRecord(pe1, x.st));
   } else {
     if (!p.X) return NL_ERR_UNSUPPORTED;
     NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, f->M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir,
@@ -574,6 +593,20 @@ Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
 extern "C" {
 
 int nl_abi_version(void) { return NL_ABI_VERSION; }
+
+int nl_profile_begin(void) { g_prof.on = true; g_prof.used = 0; return NL_OK; }
+int nl_profile_end(float* fused_ms, int* launches) {
+  float tot = 0.f;
+  for (int i = 0; i + 1 < g_prof.used; i += 2) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return NL_ERR_HIP;
+    tot += ms;
+  }
+  if (fused_ms) *fused_ms = tot;
+  if (launches) *launches = g_prof.used / 2;
+  g_prof.on = false; g_prof.used = 0;
+  return NL_OK;
+}
 
 const char* nl_strerror(int s) {
   switch (s) {
