@@ -356,7 +356,8 @@ struct Ctx {
 
 struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; };
 
-struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0; };   // out: destination when fused
+struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0;
+                const float* sig_w = nullptr; const float* sig_b = nullptr; float* sig_out = nullptr; };   // out: destination when fused
 
 // fills the launch descriptor; *fused says whether the optional row epilogue will run inside the GEMM (else the caller runs it)
 int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
@@ -385,6 +386,7 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   if (epi) {
     a.epi = epi->kind; a.ep_pool = epi->pool; a.ep_res = epi->res; a.ep_ldres = epi->ldres; a.ep_gamma = epi->gamma; a.ep_beta = epi->beta;
     a.ep_scale = epi->scale; a.ep_eps = epi->eps;
+    a.ep_sig_w = epi->sig_w; a.ep_sig_b = epi->sig_b; a.ep_sig_out = epi->sig_out;
     if (nl_tgemm_supported(a, x.c->precision)) { a.C = epi->out; if (fused) *fused = true; }
     else a.epi = NL_EPI_NONE;
   }
@@ -501,7 +503,9 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   return NL_OK;
 }
 
-int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u) {
+// sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and
+// *sigma_done is set; otherwise the caller runs sigma_kernel on geo
+int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr) {
   const int W = x.c->W, S = x.c->S;
   auto g = [&](int i) { return x.p<float>(x.L.un_g[i]); };
   auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
@@ -549,19 +553,21 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   }
   {  // conv_out on cat[in, x2]
     SegSpec s[6] = {{in, W, W, -1, 1}, {u.x2, 32, 32, -1, 1}, {in, W, W, 0, 1}, {u.x2, 32, 32, 0, 1}, {in, W, W, 1, 1}, {u.x2, 32, 32, 1, 1}};
-    const RowEpi ep{nullptr, 0, g(U_OUT), b(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
+    RowEpi ep{nullptr, 0, g(U_OUT), b(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
+    if (sigma_out) { ep.sig_w = x.p<float>(x.L.sig_w); ep.sig_b = x.p<float>(x.L.sig_b); ep.sig_out = sigma_out; }
     bool fused = false;
     NL_TRY(run_gemm(x, G_CONVOUT, s, 6, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
+    if (sigma_done) *sigma_done = fused && sigma_out;
   }
   return NL_OK;
 }
 
 int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
-             const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h) {
+             const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false) {
   const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
-  NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
+  if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
   const bool want_feat = out->feat != nullptr;
   if (want_feat) {
     SegSpec s0{FA, W, W, 0, 1};
@@ -871,8 +877,9 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
     NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt));
-    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd));
+    bool have_sigma = false;
+    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

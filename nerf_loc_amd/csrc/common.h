@@ -111,6 +111,8 @@ struct NlGemmArgs {
   const float* ep_res; int ep_ldres;
   const float* ep_gamma; const float* ep_beta; const float* ep_scale;
   float ep_eps;
+  // NL_EPI_LNSLAB only, optional: sigma[m] = softplus(ep_sig_w . out_row + ep_sig_b[0]) (model.py:525) from the values in registers
+  const float* ep_sig_w; const float* ep_sig_b; float* ep_sig_out;
 };
 enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1, NL_EPI_LNSLAB = 2 };
 

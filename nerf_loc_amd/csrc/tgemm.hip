@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     const float* brow = a.ep_beta + (size_t)t * a.N;
     const bool pool = a.ep_pool != 0;
     float* orow_p = p_c + (size_t)(pool ? q * (a.So / 2) + (t >> 1) : m) * a.ldc;
+    float sg = 0.f;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -234,9 +235,17 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
             v.z = fmaxf(v.z, __shfl_xor(v.z, 1, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, 1, 64));
           }
           if (!pool || !(j & 1)) *(float4*)(orow_p + n) = v;
+          if (a.ep_sig_w) {
+            const float4 w4 = *(const float4*)(a.ep_sig_w + n);
+            sg = fmaf(v.x, w4.x, sg); sg = fmaf(v.y, w4.y, sg); sg = fmaf(v.z, w4.z, sg); sg = fmaf(v.w, w4.w, sg);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the gamma/beta loads of later tiles from being hoisted (register budget)
       }
+    if (a.ep_sig_w) {   // the density head rides along: the other half of the row is in lane ^ 32
+      sg += __shfl_xor(sg, 32, 64);
+      if (hh == 0) a.ep_sig_out[m] = nl_softplus(sg + a.ep_sig_b[0]);
+    }
     return;
   }
   if (!mok) return;
