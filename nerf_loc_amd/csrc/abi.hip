@@ -848,7 +848,7 @@ size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V) { return 
 size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
   if (!cfg_ok(cfg)) return 0;
   int64_t rc = R < 1 ? 1 : R;
-  const int64_t cap = (1 << 17) / cfg->S > 0 ? (1 << 17) / cfg->S : 1;  // ~131k samples per chunk
+  const int64_t cap = (1 << 20) / cfg->S > 0 ? (1 << 20) / cfg->S : 1;  // ~1M samples per chunk (~12 GB of workspace at W=256, V=10): small grids in the U-Net fill the chip only at this size
   if (rc > cap) rc = cap;
   return render_bytes(cfg, V, rc);
 }
