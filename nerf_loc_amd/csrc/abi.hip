@@ -767,12 +767,14 @@ int nl_frame_destroy(nl_frame* f) {
 
 // ---- stages ----------------------------------------------------------------------------------------------
 int nl_knn(const nl_frame* f, const float* xyz, int64_t N, int K, int32_t* idx, float* d2, void* stream) {
+  if (N == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!f || !xyz || !idx || !d2 || N < 0 || K < 1 || K > NL_KNN_MAX_K) return NL_ERR_BAD_ARG;
   return nl_knn_search(&f->grid, xyz, N, K, idx, d2, (hipStream_t)stream);
 }
 
 int nl_sample_points(const float* o, const float* d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out,
                      float* xyz, void* stream) {
+  if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!o || !d || !xyz || R < 0 || S < 1) return NL_ERR_BAD_ARG;
   return nl_launch_sample_points(o, d, R, S, near_, far_, z_in, z_out, xyz, (hipStream_t)stream);
 }
@@ -785,6 +787,7 @@ size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
 int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, int64_t N,
                     float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s, float* blend1, float* rgbv, void* ws,
                     size_t ws_bytes, void* stream) {
+  if (N == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !valid_s || !ws || N < 0 || (blend1 && !rgbv)) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_mv_aggregate_workspace_bytes(cfg, f->views.V, N)) return NL_ERR_WORKSPACE;
   Bump b{(char*)ws, 0}; MvBufs m; carve_mv(b, cfg, f->views.V, N, m);
@@ -800,6 +803,7 @@ size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N) {
 int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
                  const float* mv_feat, int64_t N, int K, float* feature_agg, int32_t* knn_idx, float* knn_d2, void* ws, size_t ws_bytes,
                  void* stream) {
+  if (N == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !feature_agg || !ws || N < 0 || K < 1 || K > 8) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_point_mlp_workspace_bytes(cfg, N)) return NL_ERR_WORKSPACE;
   Bump b{(char*)ws, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p, true);
@@ -816,6 +820,7 @@ size_t nl_ray_unet_workspace_bytes(const nl_config* cfg, int64_t R) {
 }
 
 int nl_ray_unet(const nl_config* cfg, const void* packed, const float* xin, int64_t R, float* geo, void* ws, size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !xin || !geo || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_ray_unet_workspace_bytes(cfg, R)) return NL_ERR_WORKSPACE;
   Bump b{(char*)ws, 0}; UnBufs u; carve_un(b, cfg, R, u);
@@ -831,6 +836,7 @@ size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R
 int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const float* z, const float* FA, const float* geo,
                        const float* blend1, const float* rgbv, const int32_t* valid_s, int64_t R, int white,
                        const nl_render_out* out, void* ws, size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !z || !FA || !geo || !blend1 || !rgbv || !out || !ws || R < 0 || V < 1 || V > NL_MAX_VIEWS) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_heads_composite_workspace_bytes(cfg, V, R)) return NL_ERR_WORKSPACE;
   Bump b{(char*)ws, 0}; HdBufs h; carve_hd(b, cfg, V, R, h);
@@ -856,6 +862,7 @@ size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
 int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
                    const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
                    size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !qc || !rays_o || !rays_d || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, S = cfg->S, W = cfg->W;
   // largest ray chunk whose buffers fit the workspace
@@ -895,6 +902,7 @@ size_t nl_coarse_weights_workspace_bytes(int V, int64_t R, int Sc) {
 
 int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* f, const float* w2c_kinv, const float* pix,
                       const float* zc, int64_t R, int Sc, float* weights, float* depth_coarse, void* ws, size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !w2c_kinv || !pix || !zc || !weights || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_coarse_weights_workspace_bytes(f->views.V, R, Sc)) return NL_ERR_WORKSPACE;
   const size_t part = nl_align_up((size_t)f->views.V * R * Sc * 4, 256);
@@ -906,6 +914,7 @@ int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* 
 
 int nl_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R, float* z_out,
                   void* stream) {
+  if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!zc || !wc || !u || !zb || !z_out || R < 0) return NL_ERR_BAD_ARG;
   return nl_launch_sample_pdf(zc, wc, Sc, u, Ni, zb, Sb, R, z_out, (hipStream_t)stream);
 }

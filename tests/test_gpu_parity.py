@@ -220,3 +220,27 @@ def test_full_size_sampled_rays_match_oracle_c2(c2):
     assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
     for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
         assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 1e-4, (k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
+# ------------------------------------------------------------------ empty and ragged ray batches
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_empty_and_ragged_ray_batches(precision):
+    """R = 0 returns empty outputs; R = 1, 3 and a size that is not a multiple of any tile (37) reproduce the same rays
+    rendered inside a larger batch (the renderer treats rays independently: rows of a 32/128-row tile that do not exist
+    must not leak into the ones that do)."""
+    name = "c1"
+    cfg, _ = CASES[name]
+    case = build_case(name)
+    r = _renderer(case, precision)
+    o, d = case["rays"]["rays_o"], case["rays"]["rays_d"]
+    qc = case["frame"]["pose"][:3, 3]
+    full = r.render_rays(o, d, qc, z_vals=_z(cfg, cfg.R))
+    empty = r.render_rays(o[:0], d[:0], qc, z_vals=_z(cfg, 0))
+    for k, v in empty.items():
+        assert v.shape[0] == 0, k
+    for n in (1, 3, 37):
+        n = min(n, cfg.R)
+        part = r.render_rays(o[:n], d[:n], qc, z_vals=_z(cfg, n))
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(part[k].cpu().numpy(), full[k][:n].cpu().numpy()) < (2e-6 if precision == "fp32" else 2e-5), (n, k)
+        assert torch.equal(part["mask"], full["mask"][:n])
