@@ -260,7 +260,7 @@ __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_re
 // view-angle features, visibility weight.  Phase B: unrolled loop over views; the per-view scalars come from
 // v_readlane with a constant lane (-> SGPRs), lanes span channels (64 lanes x 3 floats = one 768-B texel row per tap).
 template <int VT, bool V4>
-__global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
+__global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
                                                        const float* __restrict__ images /*(V,3,H,W)*/,
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
                                                        const float* __restrict__ xyz, int N,
@@ -338,65 +338,93 @@ __global__ __launch_bounds__(256) void mv_stats_kernel(const NlViews vw, const f
   if (bl1 && lane < 32) bbias = blw[256 + lane];
   float xv[VT][5];   // [0..3]: feature channels (V4: 4*lane+j; else lane+64j for j<3), [4]: rgb plane `lane` (lanes 0..2)
   const int lch = lane < 3 ? lane : 0;
+  // The view loop is software-pipelined by hand: all 12 taps of view v+1 (feature map, image, blend-projected map) are
+  // issued before view v is reduced, so a wave has one view of loads in flight while it computes (left to itself the
+  // compiler emits load -> wait -> use three times per view: 30 dependent memory round trips per sample).
+  struct ViewTaps { float4 f[4]; float fs[3][4]; float im[4]; float pf[4]; };
+  const unsigned lane4 = 4u * (unsigned)lane, lane31 = (unsigned)lane & 31u, lplane = (unsigned)lch * (unsigned)(vw.H * vw.Wimg);
+  auto issue = [&](int v) __attribute__((always_inline)) {
+    ViewTaps t;
+    const int o[4] = {rli(a_fo[0], v), rli(a_fo[1], v), rli(a_fo[2], v), rli(a_fo[3], v)};
+    const float* fb = feat + (size_t)v * vw.h * vw.w * C;
+    if constexpr (V4) {
 #pragma unroll
-  for (int v = 0; v < VT; ++v) {
-    xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = xv[v][4] = 0.f;
-    if (v < V) {
-      const float w0 = rl(a_fw[0], v), w1 = rl(a_fw[1], v), w2 = rl(a_fw[2], v), w3 = rl(a_fw[3], v);
-      const int o0 = rli(a_fo[0], v), o1 = rli(a_fo[1], v), o2 = rli(a_fo[2], v), o3 = rli(a_fo[3], v);
-      const float* fb = feat + (size_t)v * vw.h * vw.w * C;
-      if constexpr (V4) {   // lanes 0..C/4-1 take 4 consecutive channels each: one 16-B load per tap instead of three 4-B ones
-        if (4 * lane < C) {
-          const float4 t0 = *(const float4*)(fb + (size_t)o0 * C + 4 * lane), t1 = *(const float4*)(fb + (size_t)o1 * C + 4 * lane);
-          const float4 t2 = *(const float4*)(fb + (size_t)o2 * C + 4 * lane), t3 = *(const float4*)(fb + (size_t)o3 * C + 4 * lane);
-          xv[v][0] = t0.x * w0 + t1.x * w1 + t2.x * w2 + t3.x * w3;
-          xv[v][1] = t0.y * w0 + t1.y * w1 + t2.y * w2 + t3.y * w3;
-          xv[v][2] = t0.z * w0 + t1.z * w1 + t2.z * w2 + t3.z * w3;
-          xv[v][3] = t0.w * w0 + t1.w * w1 + t2.w * w2 + t3.w * w3;
-        }
-      } else {
+      for (int k = 0; k < 4; ++k) t.f[k] = (4 * lane < C) ? *(const float4*)((fb + (size_t)o[k] * C) + lane4) : make_float4(0.f, 0.f, 0.f, 0.f);   // uniform base + 32-bit lane offset
+    } else {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int ch = lane + 64 * j;
-          if (ch < C) xv[v][j] = fb[(size_t)o0 * C + ch] * w0 + fb[(size_t)o1 * C + ch] * w1 + fb[(size_t)o2 * C + ch] * w2 + fb[(size_t)o3 * C + ch] * w3;
-        }
-      }
-      {
-        const float i0 = rl(a_iw[0], v), i1 = rl(a_iw[1], v), i2 = rl(a_iw[2], v), i3 = rl(a_iw[3], v);
-        const int q0 = rli(a_io[0], v), q1 = rli(a_io[1], v), q2 = rli(a_io[2], v), q3 = rli(a_io[3], v);
-        const float* ib = images + ((size_t)v * 3 + lch) * vw.H * vw.Wimg;
-        const float val = ib[q0] * i0 + ib[q1] * i1 + ib[q2] * i2 + ib[q3] * i3;
-        xv[v][4] = lane < 3 ? val : 0.f;
-      }
-      const float s_vis = rl(a_vis, v);
-      if (bl1) {
-        // colour-blend layer 1, per-(sample, view) part, by linearity of the bilinear tap (model.py:532-535):
-        //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap); plus rgb / visibility / angle columns + bias
-        const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32 + (lane & 31);
-        const float pv = pb[(size_t)o0 * 32] * w0 + pb[(size_t)o1 * 32] * w1 + pb[(size_t)o2 * 32] * w2 + pb[(size_t)o3 * 32] * w3;
-        const float r = rl(xv[v][4], 0), g = rl(xv[v][4], 1), bb = rl(xv[v][4], 2);
-        float o = pv + bbias;
-        o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
-        o = fmaf(bwr[3], s_vis, o);
-        o = fmaf(bwr[4], rl(a_ang[0], v), o); o = fmaf(bwr[5], rl(a_ang[1], v), o);
-        o = fmaf(bwr[6], rl(a_ang[2], v), o); o = fmaf(bwr[7], rl(a_ang[3], v), o);
-        if (lane < 32) bl1[((size_t)n * V + v) * 32 + lane] = o;
-        if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][4] : s_vis;
-      }
-      if (rgb_feat) {   // stage API only: materialise the raw multi-view projection and [vis, angle]
-        float* row = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
+      for (int j = 0; j < 3; ++j) {
+        const int ch = lane + 64 * j;
 #pragma unroll
-        for (int j = 0; j < (V4 ? 4 : 3); ++j) {
-          const int ch = V4 ? 4 * lane + j : lane + 64 * j;
-          if (ch < C) row[3 + ch] = xv[v][j];
-        }
-        if (lane < 3) row[lane] = xv[v][4];
-        if (lane == 3) row[F] = 0.f;
-        if (lane == 0 && vis_ang) {
-          float* va = vis_ang + ((size_t)n * V + v) * 8;
-          *(float4*)va = make_float4(s_vis, rl(a_ang[0], v), rl(a_ang[1], v), rl(a_ang[2], v));
-          *(float4*)(va + 4) = make_float4(rl(a_ang[3], v), 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < 4; ++k) t.fs[j][k] = ch < C ? fb[(size_t)o[k] * C + ch] : 0.f;
+      }
+    }
+    const float* ib = images + (size_t)v * 3 * vw.H * vw.Wimg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t.im[k] = (ib + rli(a_io[k], v))[lplane];
+    if (bl1) {
+      const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t.pf[k] = (pb + (size_t)o[k] * 32)[lane31];
+    }
+    return t;
+  };
+  auto finish = [&](int v, const ViewTaps& t) __attribute__((always_inline)) {
+    const float w0 = rl(a_fw[0], v), w1 = rl(a_fw[1], v), w2 = rl(a_fw[2], v), w3 = rl(a_fw[3], v);
+    if constexpr (V4) {
+      xv[v][0] = t.f[0].x * w0 + t.f[1].x * w1 + t.f[2].x * w2 + t.f[3].x * w3;
+      xv[v][1] = t.f[0].y * w0 + t.f[1].y * w1 + t.f[2].y * w2 + t.f[3].y * w3;
+      xv[v][2] = t.f[0].z * w0 + t.f[1].z * w1 + t.f[2].z * w2 + t.f[3].z * w3;
+      xv[v][3] = t.f[0].w * w0 + t.f[1].w * w1 + t.f[2].w * w2 + t.f[3].w * w3;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xv[v][j] = t.fs[j][0] * w0 + t.fs[j][1] * w1 + t.fs[j][2] * w2 + t.fs[j][3] * w3;
+    }
+    {
+      const float i0 = rl(a_iw[0], v), i1 = rl(a_iw[1], v), i2 = rl(a_iw[2], v), i3 = rl(a_iw[3], v);
+      const float val = t.im[0] * i0 + t.im[1] * i1 + t.im[2] * i2 + t.im[3] * i3;
+      xv[v][4] = lane < 3 ? val : 0.f;
+    }
+    const float s_vis = rl(a_vis, v);
+    if (bl1) {
+      // colour-blend layer 1, per-(sample, view) part, by linearity of the bilinear tap (model.py:532-535):
+      //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap); plus rgb / visibility / angle columns + bias
+      const float pv = t.pf[0] * w0 + t.pf[1] * w1 + t.pf[2] * w2 + t.pf[3] * w3;
+      const float r = rl(xv[v][4], 0), g = rl(xv[v][4], 1), bb = rl(xv[v][4], 2);
+      float o = pv + bbias;
+      o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
+      o = fmaf(bwr[3], s_vis, o);
+      o = fmaf(bwr[4], rl(a_ang[0], v), o); o = fmaf(bwr[5], rl(a_ang[1], v), o);
+      o = fmaf(bwr[6], rl(a_ang[2], v), o); o = fmaf(bwr[7], rl(a_ang[3], v), o);
+      if (lane < 32) bl1[((size_t)n * V + v) * 32 + lane] = o;
+      if (lane < 4) rgbv[((size_t)n * V + v) * 4 + lane] = lane < 3 ? xv[v][4] : s_vis;
+    }
+    if (rgb_feat) {   // stage API only: materialise the raw multi-view projection and [vis, angle]
+      float* row = rgb_feat + ((size_t)n * V + v) * NL_FPAD;
+#pragma unroll
+      for (int j = 0; j < (V4 ? 4 : 3); ++j) {
+        const int ch = V4 ? 4 * lane + j : lane + 64 * j;
+        if (ch < C) row[3 + ch] = xv[v][j];
+      }
+      if (lane < 3) row[lane] = xv[v][4];
+      if (lane == 3) row[F] = 0.f;
+      if (lane == 0 && vis_ang) {
+        float* va = vis_ang + ((size_t)n * V + v) * 8;
+        *(float4*)va = make_float4(s_vis, rl(a_ang[0], v), rl(a_ang[1], v), rl(a_ang[2], v));
+        *(float4*)(va + 4) = make_float4(rl(a_ang[3], v), 0.f, 0.f, 0.f);
+      }
+    }
+  };
+#pragma unroll
+  for (int v = 0; v < VT; ++v) xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = xv[v][4] = 0.f;
+  {
+    ViewTaps cur = issue(0);
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        ViewTaps nxt = cur;
+        if (v + 1 < VT && v + 1 < V) nxt = issue(v + 1);
+        finish(v, cur);
+        cur = nxt;
       }
     }
   }
