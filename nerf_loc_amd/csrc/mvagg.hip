@@ -259,7 +259,7 @@ __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_re
 // the feature map and the image (validity folded into zero weights + clamped offsets, so phase-B loads are unconditional),
 // view-angle features, visibility weight.  Phase B: unrolled loop over views; the per-view scalars come from
 // v_readlane with a constant lane (-> SGPRs), lanes span channels (64 lanes x 3 floats = one 768-B texel row per tap).
-template <int VT, bool V4>
+template <int VT, bool V4, bool EXACT>   // EXACT: the frame has exactly VT views (no per-view guards)
 __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
                                                        const float* __restrict__ images /*(V,3,H,W)*/,
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
   const int lane = threadIdx.x & 63;
   const int n = nl_xcd_block() * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
-  const int V = vw.V;
+  const int V = EXACT ? VT : vw.V;
   const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
   const int F = C + 3;
 
@@ -506,14 +506,15 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
   if (C > 192) return NL_ERR_UNSUPPORTED;
   dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
   const bool v4 = (C % 4 == 0) && ((((size_t)feat) & 15) == 0);   // 16-B channel groups
+  const bool ex = vw.V == 4 || vw.V == 8 || vw.V == 10 || vw.V == 16;
   if (vw.V <= 4)
-    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<4, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<4, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
+    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<4, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<4, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<4, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   else if (vw.V <= 8)
-    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<8, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<8, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
+    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<8, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<8, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<8, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   else if (vw.V <= 10)
-    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<10, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<10, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
+    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<10, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<10, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<10, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   else
-    { if (v4) hipLaunchKernelGGL((mv_stats_kernel<16, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<16, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
+    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<16, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<16, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<16, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
