@@ -46,10 +46,8 @@ struct NlPointFusedArgs {
   const float* sp_xyz; const float* sp_dir;
   const uint4* wstream; const float* bias; const float* rd_w;
   int N, M; float inv_span;
-  void* park;
 };
 size_t nl_point_stream_bytes(int W);
-size_t nl_point_fused_park_bytes(void);
 int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
 int nl_pack_ptt(const float* w1, const float* b1, int W, int F, int Kpad, int Npad, float* B32, float* bias, hipStream_t st);
 int nl_launch_wscale(const int* idx, const float* d2, const float* conf, int64_t N, int K, int64_t M, float* wscale, hipStream_t st);
@@ -298,7 +296,7 @@ struct Bump {
 
 // ---- per-stage buffers ---------------------------------------------------------------------------
 struct MvBufs { float *vis, *dd, *g393, *t64; };
-struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; char* park; };
+struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; };
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
 struct HdBufs { float *sigma, *fth, *hc, *wsum, *blA, *rgb_s; };
 
@@ -311,8 +309,7 @@ void carve_mv(Bump& b, const nl_config* c, int V, int64_t N, MvBufs& m) {
 void carve_pt(Bump& b, const nl_config* c, int64_t N, int K, PtBufs& p, bool force_generic = false) {
   const int W = c->W;
   p.idx = b.take<int>((size_t)N * K); p.d2 = b.take<float>((size_t)N * K);
-  p.park = nullptr;
-  if (!force_generic && nl_point_fused_supported(W, c->precision)) { p.X = p.H1 = p.H2 = p.KV = nullptr; p.park = b.take<char>(nl_point_fused_park_bytes()); }
+  if (!force_generic && nl_point_fused_supported(W, c->precision)) { p.X = p.H1 = p.H2 = p.KV = nullptr; }
   else {
     p.X = b.take<float>((size_t)N * K * LDX);
     p.H1 = b.take<float>((size_t)N * K * W); p.H2 = b.take<float>((size_t)N * K * W);
@@ -480,7 +477,6 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
     a.wstream = x.p<uint4>(x.L.pt_stream); a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
     a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
-    a.park = p.park;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));

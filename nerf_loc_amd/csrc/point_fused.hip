@@ -18,7 +18,6 @@
 //   * Layer-1 operands are assembled in registers: pre-split bf16 feature rows are gathered with 16-B loads that
 //     are already B fragments; positional encoding / ray_diff_fc are computed per lane in fp32 and split.
 //   * One wave per SIMD (the kernel lives in the 512-register file): 128 accumulators + up to 152 operand regs.
-#include <stdlib.h>
 #include <utility>
 #include "common.h"
 
@@ -37,7 +36,6 @@ struct NlPointFusedArgs {
   const float* rd_w;       // ray_diff_fc: W0[16][4], b0[16], W2[27][16], b2[27]
   int N, M;
   float inv_span;
-  void* park;              // scratch of nl_point_fused_park_bytes() for the two-workgroups-per-CU variant (or null)
 };
 
 namespace {
@@ -360,307 +358,6 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
   }
 }
 
-// =====================================================================================================================
-// Two-workgroups-per-CU variant.  The one-wave-per-SIMD kernel above needs 128 accumulators + 128 split-activation
-// registers; this one computes every layer in two passes over K — output tiles [0, ort/2) first, then [ort/2, ort) — so
-// 64 accumulators suffice and the kernel fits 256 registers / 67 KB of LDS: two independent workgroups share a CU, run out
-// of phase, and one's epilogues, LDS waits and barriers hide behind the other's MFMAs.  The fragments produced by the
-// first pass of a layer cannot overwrite the layer's input yet (the second pass still reads it): they are parked in a
-// per-workgroup scratch slab (L2-resident, written and read back by the same lane) and restored after the second pass.
-// The weight stream is the same as above; the LDS-DMA simply picks the pieces of the half it is working on (16-KB slots).
-// Persistent workgroups (2 per CU) loop over the 128-row tiles.
-constexpr int NB3 = 4;           // ring slots
-constexpr int SLOT3 = 1024;      // uint4 per slot: [part 2][k-step 2][tile 4][lane 64]
-
-template <int NRT, bool X3>
-__global__ __launch_bounds__(256, 2) void point_fused3_kernel(
-    const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
-    float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
-    const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const float* __restrict__ p_bias,
-    const float* __restrict__ p_rd_w, uint4* __restrict__ p_park, int ntiles, const PfScalars sc) {
-  const float* __restrict__ rd_w = p_rd_w;
-  const PfView a = {p_xyz, p_dir, sc.dir_stride, sc.dir_div, p_idx, p_Q, p_O, p_ptt, p_sp_xyz, p_sp_dir, p_wstream,
-                    p_bias, p_rd_w, sc.N, sc.M, sc.inv_span};
-  __shared__ uint4 lds_all[NB3 * SLOT3 + 192];
-  uint4 (*lds)[SLOT3] = reinterpret_cast<uint4 (*)[SLOT3]>(lds_all);
-  float* sbias = reinterpret_cast<float*>(lds_all + NB3 * SLOT3);
-  constexpr int W = 32 * NRT;
-  constexpr int PARTS = X3 ? 2 : 1;
-  constexpr int NC = L1_CHUNKS + 3 * NRT;
-  constexpr int NQ = 2 * NC;                // half-chunks per tile
-  constexpr int HT = NRT / 2;
-  static_assert(NRT % 2 == 0 && (PARTS * 2 * HT) % 4 == 0, "tile / LDS-DMA split");
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hh = lane >> 5, j = lane & 31, kk = j & 7;
-  for (int i = tid; i < 3 * W; i += 256) sbias[i] = a.bias[i];
-  int l16 = lane * 16;   // byte offset of this lane inside a 1-KB LDS-DMA piece (made opaque per tile, see below)
-  uint4* const parkw = p_park + ((size_t)blockIdx.x * 4 + wave) * (16 * 64);   // wave-uniform base: [frag 16][lane 64]
-  const unsigned ulane = (unsigned)lane;
-
-  // half-chunk q -> (layer, half, chunk of the layer)
-  struct QI { int layer, half, c, g, ort, ht; };
-  auto qinfo = [](int q) constexpr -> QI {
-    QI r{0, 0, 0, 0, NRT, HT};
-    if (q < 2 * L1_CHUNKS) { r.layer = 0; r.half = q / L1_CHUNKS; r.c = q % L1_CHUNKS; r.g = r.c; }
-    else {
-      const int qq = q - 2 * L1_CHUNKS;
-      r.layer = 1 + qq / (2 * NRT);
-      const int w = qq % (2 * NRT);
-      r.half = w / NRT; r.c = w % NRT;
-      r.g = L1_CHUNKS + (r.layer - 1) * NRT + r.c;
-      if (r.layer == 3) { r.ort = 8; r.ht = 4; }
-    }
-    return r;
-  };
-  auto chunk_off = [](int g) constexpr -> size_t {   // byte offset of chunk g in the stream (hi and lo parts always stored)
-    constexpr int nA = L1_CHUNKS + 2 * NRT;
-    return g < nA ? (size_t)g * 4 * NRT * 1024 : (size_t)nA * 4 * NRT * 1024 + (size_t)(g - nA) * 32 * 1024;
-  };
-  auto glds_of = [=](int q) constexpr { return q < NQ ? PARTS * 2 * qinfo(q).ht / 4 : 0; };
-  auto stage = [&](auto Qc) __attribute__((always_inline)) {
-    constexpr int q = decltype(Qc)::value;
-    constexpr QI qi = qinfo(q);
-    const char* src = (const char*)a.wstream + chunk_off(qi.g);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      if (jj < PARTS * 2 * qi.ht / 4) {
-        const int i = wave + 4 * jj;               // piece of the half-chunk: [part][ks][tile of the half]
-        const int pk = i / qi.ht, rt = i - pk * qi.ht;   // pk = part * 2 + ks
-        glds16(src + (size_t)(pk * qi.ort + qi.ht * qi.half + rt) * 1024 + l16, &lds[q % NB3][i * 64]);
-      }
-    }
-  };
-
-  f32x16 acc[4];
-  bf16x8 fh[2 * NRT > L1_KSTEPS ? 2 * NRT : L1_KSTEPS], fl[2 * NRT > L1_KSTEPS ? 2 * NRT : L1_KSTEPS];
-
-  auto compute = [&](int buf, int ht, int nks, const bf16x8 bh0, const bf16x8 bl0, const bf16x8 bh1, const bf16x8 bl1) __attribute__((always_inline)) {
-    const int nt = nks * ht;
-    auto ldA = [&](int t, bf16x8& ah, bf16x8& al) __attribute__((always_inline)) {
-      const int ks = t / ht, rt = t - ks * ht;
-      ah = __builtin_bit_cast(bf16x8, lds[buf][((0 * 2 + ks) * ht + rt) * 64 + lane]);
-      if (X3) al = __builtin_bit_cast(bf16x8, lds[buf][((1 * 2 + ks) * ht + rt) * 64 + lane]);
-    };
-    bf16x8 ah[3], al[3];
-    ldA(0, ah[0], al[0]);
-    if (nt > 1) ldA(1, ah[1], al[1]);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < nt) {
-        if (t + 2 < nt) ldA(t + 2, ah[(t + 2) % 3], al[(t + 2) % 3]);
-        const int ks = t / ht, rt = t - ks * ht;
-        const bf16x8 bh = ks ? bh1 : bh0;
-        const bf16x8 bl = ks ? bl1 : bl0;
-        if (X3) {
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t % 3], bh, acc[rt], 0, 0, 0);
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t % 3], bl, acc[rt], 0, 0, 0);
-        }
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t % 3], bh, acc[rt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  auto lrelu_split = [&](int rt, int s2, bf16x8& oh, bf16x8& ol) __attribute__((always_inline)) {
-    float v[8];
-#pragma unroll
-    for (int t = 0; t < 8; t += 2) {
-      typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
-      const pf_f32x2 x2 = {acc[rt][8 * s2 + t], acc[rt][8 * s2 + t + 1]};
-      const pf_f32x2 y2 = x2 * 0.01f;
-      asm("v_max_f32 %0, %1, %2" : "=v"(v[t]) : "v"(x2[0]), "v"(y2[0]));
-      asm("v_max_f32 %0, %1, %2" : "=v"(v[t + 1]) : "v"(x2[1]), "v"(y2[1]));
-    }
-    split8<X3>(v, oh, ol);
-  };
-  typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));
-  auto park_st = [&](int slot, const bf16x8& v) __attribute__((always_inline)) {
-    __builtin_nontemporal_store(__builtin_bit_cast(pf_u32x4, v), reinterpret_cast<pf_u32x4*>(parkw + slot * 64) + ulane);
-  };
-  auto park_ld = [&](int slot) __attribute__((always_inline)) -> bf16x8 {   // served by L2 (the same lane wrote it)
-    return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const pf_u32x4*>(parkw + slot * 64) + ulane));
-  };
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // opaque to the optimiser: otherwise the ~200 per-piece LDS-DMA source addresses of a tile are loop invariants, get
-    // hoisted out of this persistent loop and spill
-    asm volatile("" : "+v"(l16));
-    const int n = tile * 16 + wave * 4 + (j >> 3);
-    const bool live = n < a.N;
-    const int nn = live ? n : a.N - 1;
-    const bool have = live && kk < a.M && a.M > 0;
-    const int id = a.idx[(size_t)nn * 8 + kk];
-    const char* const tptr = (const char*)(a.ptt + (size_t)(have ? id : a.M) * W + 16 * hh);
-    stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
-    {
-      const float qx = a.xyz[3 * (size_t)nn], qy = a.xyz[3 * (size_t)nn + 1], qz = a.xyz[3 * (size_t)nn + 2];
-      const float px = have ? a.sp_xyz[3 * (size_t)id] : 0.f, py = have ? a.sp_xyz[3 * (size_t)id + 1] : 0.f, pz = have ? a.sp_xyz[3 * (size_t)id + 2] : 0.f;
-      const float off[3] = {(qx - px) * a.inv_span, (qy - py) * a.inv_span, (qz - pz) * a.inv_span};
-      {
-        const size_t dr = (size_t)(nn / a.dir_div) * a.dir_stride;
-        float dx, dy, dz;
-        if (a.dir) { dx = a.dir[dr]; dy = a.dir[dr + 1]; dz = a.dir[dr + 2]; }
-        else {
-          const int i0 = a.idx[(size_t)nn * 8];
-          const bool ok = live && a.M > 0;
-          dx = ok ? a.sp_dir[4 * (size_t)i0] : 0.f; dy = ok ? a.sp_dir[4 * (size_t)i0 + 1] : 0.f; dz = ok ? a.sp_dir[4 * (size_t)i0 + 2] : 0.f;
-        }
-        const float ndx = have ? a.sp_dir[4 * (size_t)id] : 0.f, ndy = have ? a.sp_dir[4 * (size_t)id + 1] : 0.f, ndz = have ? a.sp_dir[4 * (size_t)id + 2] : 0.f;
-        float r0 = dx - ndx, r1 = dy - ndy, r2 = dz - ndz;
-        const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2) + 1e-8f;
-        r0 /= nr; r1 /= nr; r2 /= nr;
-        const float r3 = dx * ndx + dy * ndy + dz * ndz;
-        float hid[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float s = rd_w[64 + i];
-          s = fmaf(rd_w[i * 4 + 0], r0, s); s = fmaf(rd_w[i * 4 + 1], r1, s);
-          s = fmaf(rd_w[i * 4 + 2], r2, s); s = fmaf(rd_w[i * 4 + 3], r3, s);
-          hid[i] = nl_lrelu(s);
-        }
-        const float* __restrict__ w2 = rd_w + 80;
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-          float v[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            float rr[2];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-              const int o = 16 * qs + 8 * h2 + t;
-              if (o < 27) {
-                float s = w2[27 * 16 + o];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s = fmaf(w2[o * 16 + i], hid[i], s);
-                rr[h2] = nl_lrelu(s);
-              } else rr[h2] = 0.f;
-            }
-            v[t] = hh ? rr[1] : rr[0];
-          }
-          split8<X3>(v, fh[4 + qs], fl[4 + qs]);
-        }
-      }
-      {
-        double s = 0.0, c = 1.0;
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) {
-          float v0[8], v1[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int pi = 8 * qs + u;
-            float ps, pc;
-            if (pi < 30) {
-              const int ax = pi / 10, f = pi - 10 * ax;
-              if (f == 0) sincos_d((double)off[ax], s, c);
-              ps = (float)s; pc = (float)c;
-              const double s2 = 2.0 * s * c;
-              c = fma(-2.0 * s, s, 1.0);
-              s = s2;
-            } else if (pi == 30) { ps = off[0]; pc = off[1]; }
-            else { ps = off[2]; pc = 0.f; }
-            if (u < 4) { v0[2 * u] = ps; v0[2 * u + 1] = pc; } else { v1[2 * (u - 4)] = ps; v1[2 * (u - 4) + 1] = pc; }
-          }
-          float v[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) v[t] = hh ? v1[t] : v0[t];
-          split8<X3>(v, fh[qs], fl[qs]);
-        }
-      }
-    }
-
-    float att[4] = {0.f, 0.f, 0.f, 0.f};
-    static_for<NQ>([&](auto Qc) __attribute__((always_inline)) {
-      constexpr int q = decltype(Qc)::value;
-      constexpr QI qi = qinfo(q);
-      constexpr int nks = (qi.layer == 0 && 2 * qi.c + 1 >= L1_KSTEPS) ? 1 : 2;
-      constexpr int nch = qi.layer == 0 ? L1_CHUNKS : NRT;
-      if constexpr (qi.c == 0) {   // accumulators of this pass
-        if constexpr (qi.layer == 0) {   // gathered row of the per-frame table T (= W1_feat . feature + b1), tiles of this half
-#pragma unroll
-          for (int rt = 0; rt < HT; ++rt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 t4 = *(const float4*)(tptr + 4 * (32 * (HT * qi.half + rt) + 4 * g));
-              acc[rt][4 * g] = t4.x; acc[rt][4 * g + 1] = t4.y; acc[rt][4 * g + 2] = t4.z; acc[rt][4 * g + 3] = t4.w;
-            }
-        } else {
-#pragma unroll
-          for (int rt = 0; rt < qi.ht; ++rt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 b = qi.layer < 3 ? *(const float4*)(sbias + qi.layer * W + 32 * (HT * qi.half + rt) + 8 * g + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
-              acc[rt][4 * g] = b.x; acc[rt][4 * g + 1] = b.y; acc[rt][4 * g + 2] = b.z; acc[rt][4 * g + 3] = b.w;
-            }
-        }
-      }
-      // half-chunk q must have landed: at most the LDS-DMA of q+1, q+2 may still be in flight (other loads issued in
-      // between only make this wait more conservative: the counter retires in order)
-      wait_vmcnt<glds_of(q + 1) + glds_of(q + 2)>();
-      __builtin_amdgcn_s_barrier();
-      if constexpr (q + 3 < NQ) stage(std::integral_constant<int, q + 3>{});
-      compute(q % NB3, qi.ht, nks, fh[2 * qi.c], fl[2 * qi.c], fh[2 * qi.c + 1], fl[2 * qi.c + 1]);
-      if constexpr (qi.c == nch - 1) {   // a pass is complete
-        if constexpr (qi.layer < 3) {
-          if constexpr (qi.half == 0) {   // fragments of k-steps [0, 2*HT) of the next layer: park them
-#pragma unroll
-            for (int rt = 0; rt < HT; ++rt)
-#pragma unroll
-              for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 oh, ol;
-                lrelu_split(rt, s2, oh, ol);
-                park_st(2 * (2 * rt + s2), oh);
-                if (X3) park_st(2 * (2 * rt + s2) + 1, ol);
-              }
-          } else {                        // k-steps [2*HT, 4*HT): the layer's input is dead now; then bring back the parked half
-#pragma unroll
-            for (int rt = 0; rt < HT; ++rt)
-#pragma unroll
-              for (int s2 = 0; s2 < 2; ++s2) lrelu_split(rt, s2, fh[2 * HT + 2 * rt + s2], fl[2 * HT + 2 * rt + s2]);
-#pragma unroll
-            for (int i = 0; i < 2 * HT; ++i) { fh[i] = park_ld(2 * i); if (X3) fl[i] = park_ld(2 * i + 1); }
-          }
-        } else if constexpr (qi.half == 0) {   // k-projection (tile = head): softmax weights over the 8 neighbours of a sample
-          const float inv_temp = 1.0f / 5.656854249492381f;
-          const float* qrow = a.Q + (size_t)nn * 128;
-#pragma unroll
-          for (int hd = 0; hd < 4; ++hd) {
-            float p = 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const float4 q4 = *(const float4*)(qrow + 32 * hd + 8 * g + 4 * hh);
-              p = fmaf(q4.x * inv_temp, acc[hd][4 * g], p);
-              p = fmaf(q4.y * inv_temp, acc[hd][4 * g + 1], p);
-              p = fmaf(q4.z * inv_temp, acc[hd][4 * g + 2], p);
-              p = fmaf(q4.w * inv_temp, acc[hd][4 * g + 3], p);
-            }
-            p += __shfl_xor(p, 32, 64);
-            float mx = p;
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
-            const float e = expf(p - mx);
-            float sm = e;
-            sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
-            att[hd] = e / sm;
-          }
-        } else {                                // v-projection -> attention output
-#pragma unroll
-          for (int hd = 0; hd < 4; ++hd)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float o[4];
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                float v = att[hd] * acc[hd][4 * g + t];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-                o[t] = v;
-              }
-              if (live && kk == 0) *(float4*)(a.O + (size_t)n * 128 + 32 * hd + 8 * g + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
-            }
-        }
-      }
-    });
-    __syncthreads();   // the next tile's first LDS-DMA reuses slots that slower waves may still be reading
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------- packing
 __device__ __forceinline__ unsigned short pf_f2bf(float x) {
   unsigned int u = __float_as_uint(x);
@@ -787,8 +484,6 @@ int nl_launch_wscale(const int* idx, const float* d2, const float* conf, int64_t
   return NL_OK;
 }
 
-size_t nl_point_fused_park_bytes(void) { return (size_t)512 * 4 * 16 * 64 * 16; }   // 512 persistent workgroups x 4 waves x 16 KB
-
 bool nl_point_fused_supported(int W, int precision) {
   return precision != NL_PREC_F32 && (W == 64 || W == 128 || W == 256);
 }
@@ -797,16 +492,9 @@ int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipSt
   if (a.N <= 0) return NL_OK;
   dim3 grid(nl_xcd_grid(nl_cdiv(a.N, 16)));
   const bool x3 = precision == NL_PREC_BF16X3;
-  static const bool use_v3 = getenv("NERFLOC_PF3") != nullptr;   // developer switch while the variant is evaluated
 #define NL_PF(NRT)                                                                                           \
   do {                                                                                                       \
     const PfScalars sc{a.dir_stride, a.dir_div, a.N, a.M, a.inv_span};                                       \
-    if (use_v3 && a.park && x3) {                                                                            \
-      const int ntiles = (int)nl_cdiv(a.N, 16);                                                              \
-      hipLaunchKernelGGL((point_fused3_kernel<NRT, true>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, \
-                         a.ptt, a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, (uint4*)a.park, ntiles, sc);  \
-      break;                                                                                                 \
-    }                                                                                                        \
     if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
                                a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                           \
     else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
