@@ -37,15 +37,33 @@ __device__ __forceinline__ float nl_act(float x, int act) {
 }
 
 // ------------------------------------------------------------------ wave helpers (wave64)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions are DPP-modified VALU instructions (one v_add_f32 / v_max_f32 each), not __shfl: a shuffle is a
+// ds_bpermute round trip through the LDS crossbar plus address arithmetic, ~10x the cost.
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float nl_dpp(float v, float old = 0.f) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+// sum / max over aligned groups of 8 lanes, result in all 8: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float nl_sum8(float v) {
+  v += nl_dpp<0xB1>(v); v += nl_dpp<0x4E>(v); v += nl_dpp<0x141>(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float nl_max8(float v) {
+  v = fmaxf(v, nl_dpp<0xB1>(v, v)); v = fmaxf(v, nl_dpp<0x4E>(v, v)); v = fmaxf(v, nl_dpp<0x141>(v, v));
   return v;
+}
+// whole-wave sum / max, result wave-uniform (row_shr 1/2/4/8 scan inside each row of 16, row_bcast:15 / :31 carry the row
+// totals up, lane 63 holds the total)
+__device__ __forceinline__ float wave_sum(float v) {
+  v += nl_dpp<0x111>(v); v += nl_dpp<0x112>(v); v += nl_dpp<0x114>(v); v += nl_dpp<0x118>(v);
+  v += nl_dpp<0x142, 0xa>(v); v += nl_dpp<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  const float ninf = -3.4028235e38f;
+  v = fmaxf(v, nl_dpp<0x111>(v, ninf)); v = fmaxf(v, nl_dpp<0x112>(v, ninf)); v = fmaxf(v, nl_dpp<0x114>(v, ninf)); v = fmaxf(v, nl_dpp<0x118>(v, ninf));
+  v = fmaxf(v, nl_dpp<0x142, 0xa>(v, ninf)); v = fmaxf(v, nl_dpp<0x143, 0xc>(v, ninf));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ------------------------------------------------------------------ XCD-aware block order

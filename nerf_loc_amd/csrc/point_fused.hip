@@ -335,12 +335,9 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
       p = fmaf(q4.w * inv_temp, acc[h][4 * g + 3], p);
     }
     p += __shfl_xor(p, 32, 64);
-    float mx = p;
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    const float mx = nl_max8(p);          // over the 8 neighbours (lanes) of a sample
     const float e = expf(p - mx);
-    float sm = e;
-    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
-    att[h] = e / sm;
+    att[h] = e / nl_sum8(e);
   }
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
@@ -349,9 +346,7 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
       float o[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float v = att[h] * acc[4 + h][4 * g + t];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-        o[t] = v;
+        o[t] = nl_sum8(att[h] * acc[4 + h][4 * g + t]);
       }
       if (live && kk == 0) *(float4*)(a.O + (size_t)n * 128 + 32 * h + 8 * g + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
     }

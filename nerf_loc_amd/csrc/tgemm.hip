@@ -231,8 +231,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
           v.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
           v.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
           if (pool) {   // positions 2p, 2p+1 are neighbouring lanes
-            v.x = fmaxf(v.x, __shfl_xor(v.x, 1, 64)); v.y = fmaxf(v.y, __shfl_xor(v.y, 1, 64));
-            v.z = fmaxf(v.z, __shfl_xor(v.z, 1, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, 1, 64));
+            v.x = fmaxf(v.x, nl_dpp<0xB1>(v.x, v.x)); v.y = fmaxf(v.y, nl_dpp<0xB1>(v.y, v.y));   // quad_perm [1,0,3,2]: lane ^ 1
+            v.z = fmaxf(v.z, nl_dpp<0xB1>(v.z, v.z)); v.w = fmaxf(v.w, nl_dpp<0xB1>(v.w, v.w));
           }
           if (!pool || !(j & 1)) *(float4*)(orow_p + n) = v;
           if (a.ep_sig_w) {
