@@ -251,8 +251,14 @@ struct Packer {
     if (b) copy(b, L->bias[g], L->g[g].N);
   }
   // conv taps over concatenated sources: weight (co, ci, 3); K index = tap-major then source channels
-  void conv3(int g, const float* w, const float* b, int ci) {
-    for (int j = 0; j < 3; ++j) block(g, j * ci, w, j, ci * 3, 3, ci);
+  // K order = per source (channel range [c0, c0 + wd) of the ci input channels), per 32-channel block, per tap: see NlGemmSeg::ntap
+  void conv3(int g, const float* w, const float* b, int ci, const int* widths, int nsrc) {
+    int k0 = 0, c0 = 0;
+    for (int sidx = 0; sidx < nsrc; ++sidx) {
+      for (int cb = 0; cb < widths[sidx] / 32; ++cb)
+        for (int j = 0; j < 3; ++j) { block(g, k0, w, (c0 + 32 * cb) * 3 + j, ci * 3, 3, 32); k0 += 32; }
+      c0 += widths[sidx];
+    }
     copy(b, L->bias[g], L->g[g].N);
   }
   // transposed conv weight (ci, co, 3): even phase uses tap 1; odd phase taps 2 (ioff 0) then 0 (ioff +1)
@@ -354,7 +360,7 @@ struct Ctx {
   template <class T> const T* p(size_t off) const { return (const T*)(pk + off); }
 };
 
-struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; };
+struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; int ntap = 1; };
 
 struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0;
                 const float* sig_w = nullptr; const float* sig_b = nullptr; float* sig_out = nullptr; };   // out: destination when fused
@@ -371,7 +377,9 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.seg[i].ptr = segs[i].ptr; a.seg[i].ld = segs[i].ld; a.seg[i].k = segs[i].k; a.seg[i].ioff = segs[i].ioff;
     a.seg[i].rdiv = segs[i].rdiv > 0 ? segs[i].rdiv : 1;
     a.seg[i].vec = ((((size_t)segs[i].ptr) & 15) == 0 && (segs[i].ld & 3) == 0) ? 1 : 0;
-    ksum += (segs[i].k + 31) & ~31;   // every segment occupies round_up(k, 32) slots of K-space (one k-tile = one segment)
+    a.seg[i].ntap = segs[i].ntap > 1 ? segs[i].ntap : 1;
+    if (a.seg[i].ntap > 1 && (segs[i].k & 31)) return NL_ERR_BAD_ARG;
+    ksum += ((segs[i].k + 31) & ~31) * a.seg[i].ntap;   // every segment occupies round_up(k, 32) slots of K-space (one k-tile = one segment)
   }
   const GemmDim& d = x.L.g[g];
   if (ksum != ((d.K + 31) & ~31)) return NL_ERR_BAD_ARG;
@@ -511,20 +519,20 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
   const float eps = 1e-5f;
   {  // conv1: W -> 64 over S
-    SegSpec s[3] = {{in, W, W, -1, 1}, {in, W, W, 0, 1}, {in, W, W, 1, 1}};
+    SegSpec s[1] = {{in, W, W, 0, 1, 3}};   // 3 taps, interleaved per 32-channel block
     const RowEpi ep{nullptr, 0, g(U_CONV1), b(U_CONV1), nullptr, eps, u.c1, NL_EPI_LNSLAB, 1};   // LN + ELU + MaxPool inside the GEMM when one workgroup = one ray
     bool fused = false;
-    NL_TRY(run_gemm(x, G_CONV1, s, 3, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
+    NL_TRY(run_gemm(x, G_CONV1, s, 1, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
   }
   {  // conv2: 64 -> 128 over S/2
-    SegSpec s[3] = {{u.c1, 64, 64, -1, 1}, {u.c1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}};
-    NL_TRY(run_gemm(x, G_CONV2, s, 3, R * (S / 2), u.r2, 128, NL_ACT_NONE, S / 2, S / 2, S / 2));
+    SegSpec s[1] = {{u.c1, 64, 64, 0, 1, 3}};
+    NL_TRY(run_gemm(x, G_CONV2, s, 1, R * (S / 2), u.r2, 128, NL_ACT_NONE, S / 2, S / 2, S / 2));
     NL_TRY(nl_launch_ln_slab_elu(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, nullptr, u.c2, x.st));
   }
   {  // conv3: 128 -> 128 over S/4
-    SegSpec s[3] = {{u.c2, 128, 128, -1, 1}, {u.c2, 128, 128, 0, 1}, {u.c2, 128, 128, 1, 1}};
-    NL_TRY(run_gemm(x, G_CONV3, s, 3, R * (S / 4), u.r3, 128, NL_ACT_NONE, S / 4, S / 4, S / 4));
+    SegSpec s[1] = {{u.c2, 128, 128, 0, 1, 3}};
+    NL_TRY(run_gemm(x, G_CONV3, s, 1, R * (S / 4), u.r3, 128, NL_ACT_NONE, S / 4, S / 4, S / 4));
     NL_TRY(nl_launch_ln_slab_elu(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, nullptr, u.c3, x.st));
   }
   {  // trans_conv3: S/8 -> S/4
@@ -552,11 +560,11 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
   }
   {  // conv_out on cat[in, x2]
-    SegSpec s[6] = {{in, W, W, -1, 1}, {u.x2, 32, 32, -1, 1}, {in, W, W, 0, 1}, {u.x2, 32, 32, 0, 1}, {in, W, W, 1, 1}, {u.x2, 32, 32, 1, 1}};
+    SegSpec s[2] = {{in, W, W, 0, 1, 3}, {u.x2, 32, 32, 0, 1, 3}};
     RowEpi ep{nullptr, 0, g(U_OUT), b(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
     if (sigma_out) { ep.sig_w = x.p<float>(x.L.sig_w); ep.sig_b = x.p<float>(x.L.sig_b); ep.sig_out = sigma_out; }
     bool fused = false;
-    NL_TRY(run_gemm(x, G_CONVOUT, s, 6, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
+    NL_TRY(run_gemm(x, G_CONVOUT, s, 2, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
     if (sigma_done) *sigma_done = fused && sigma_out;
   }
@@ -662,13 +670,14 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.linear(G_Q, t[T_WQ], nullptr);
   P.linear(G_FC, t[T_FC], nullptr);
   const float* const* un = t + T_UNET;
-  P.conv3(G_CONV1, un[0], un[1], W);
-  P.conv3(G_CONV2, un[4], un[5], 64);
-  P.conv3(G_CONV3, un[8], un[9], 128);
+  { const int w1[1] = {W}, w2[1] = {64}, w3[1] = {128};
+    P.conv3(G_CONV1, un[0], un[1], W, w1, 1);
+    P.conv3(G_CONV2, un[4], un[5], 64, w2, 1);
+    P.conv3(G_CONV3, un[8], un[9], 128, w3, 1); }
   P.convT(G_T3E, G_T3O, un[12], un[13], 128, 128);
   P.convT(G_T2E, G_T2O, un[16], un[17], 256, 64);
   P.convT(G_T1E, G_T1O, un[20], un[21], 128, 32);
-  P.conv3(G_CONVOUT, un[24], un[25], W + 32);
+  { const int wo[2] = {W, 32}; P.conv3(G_CONVOUT, un[24], un[25], W + 32, wo, 2); }
   for (int u = 0; u < U_COUNT; ++u) {
     P.transpose(un[4 * u + 2], L.un_g[u], L.un_c[u], L.un_l[u]);   // (C, L) -> (L, C)
     P.transpose(un[4 * u + 3], L.un_b[u], L.un_c[u], L.un_l[u]);

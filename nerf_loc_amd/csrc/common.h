@@ -104,6 +104,9 @@ struct NlGemmSeg {
   int ioff;          // conv tap offset along the ray (row-mapped modes)
   int rdiv;          // plain mode: source row = m / rdiv (row broadcast), >=1
   int vec;           // 1: rows are 16-B aligned (ptr, ld) so 4 consecutive k may be fetched with one float4 load
+  int ntap;          // 1, or T > 1 (k % 32 == 0): conv taps interleaved per 32-channel block — the segment spans T*k slots of
+                     // K-space ordered [block k/32][tap 0..T-1][32]; tap t reads row offset ioff + t - T/2.  Neighbouring chunks then
+                     // re-read the same rows (+-1), which L1 still holds; tap-major order streams the source T times through L2
 };
 struct NlGemmArgs {
   NlGemmSeg seg[NL_GEMM_MAX_SEG];

@@ -54,9 +54,15 @@ __device__ __forceinline__ RowMap map_row(const NlGemmArgs& a, int m, int rdiv) 
 // 4 consecutive k of one segment for one output row (zero beyond the segment / outside the ray)
 __device__ __forceinline__ float4 load_a4(const NlGemmArgs& a, const RowMap& rm, int s, int kin) {
   const NlGemmSeg& sg = a.seg[s];
+  int ioff = sg.ioff;
+  if (sg.ntap > 1) {   // [32-channel block][tap][32]
+    const int cc = kin >> 5, cb = cc / sg.ntap;
+    ioff += cc - cb * sg.ntap - (sg.ntap >> 1);
+    kin = (cb << 5) + (kin & 31);
+  }
   int row;
   if (a.So > 0) {
-    int i = rm.t + sg.ioff;
+    int i = rm.t + ioff;
     if (i < 0 || i >= a.Li) return make_float4(0.f, 0.f, 0.f, 0.f);
     row = rm.base + i;
   } else {
@@ -78,7 +84,7 @@ __device__ __forceinline__ float4 load_a4(const NlGemmArgs& a, const RowMap& rm,
 __device__ __forceinline__ int find_seg(const NlGemmArgs& a, int k0, int& kbase) {
   int s = -1, acc = 0;
   for (int j = 0; j < a.nseg; ++j) {
-    const int kp = (a.seg[j].k + 31) & ~31;
+    const int kp = ((a.seg[j].k + 31) & ~31) * a.seg[j].ntap;
     if (s < 0 && k0 < acc + kp) { s = j; kbase = k0 - acc; }
     acc += kp;
   }

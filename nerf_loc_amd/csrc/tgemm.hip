@@ -98,11 +98,17 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     const int k0 = 32 * c;
     const int s = tg_find_seg(a, k0);
     const NlGemmSeg& sg = a.seg[s];
-    const int kbase = k0 - a.kstart[s];
+    int kbase = k0 - a.kstart[s];
+    int ioff = sg.ioff;
+    if (sg.ntap > 1) {   // [32-channel block][tap][32]: chunk cc of the segment = (block cc / ntap, tap cc % ntap)
+      const int cc = kbase >> 5, cb = cc / sg.ntap;
+      ioff += cc - cb * sg.ntap - (sg.ntap >> 1);
+      kbase = cb << 5;
+    }
     bool ok = mok;
     int row = m;
     if (a.So > 0) {
-      const int i = t + sg.ioff;
+      const int i = t + ioff;
       ok = ok && i >= 0 && i < a.Li;
       row = q * a.Li + i;
     }
@@ -323,7 +329,7 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (a.epi == NL_EPI_LNSLAB && (a.So != 128 || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
-    if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k) return false;
+    if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k || g.ntap < 1) return false;
   }
   return true;
 }
