@@ -64,7 +64,7 @@ def test_bf16_throughput_mode_error_is_reported_not_hidden():
 
 
 @pytest.mark.parametrize("n,m,K,kind", [(5000, 3000, 8, "cloud"), (4096, 20000, 8, "sheets"), (2000, 5, 8, "few"), (3000, 700, 1, "cloud"),
-                                         (2000, 900, 8, "lattice"), (1500, 1, 8, "one"), (1000, 2000, 8, "far")])
+                                         (2000, 900, 8, "lattice"), (1500, 1, 8, "one"), (1000, 2000, 8, "far"), (1003, 4000, 8, "cloud"), (37, 500, 1, "cloud")])
 def test_knn_exact_vs_oracle(n, m, K, kind):
     from nerf_loc_amd.renderer import HipRenderer
     from oracle import render_oracle as orc
