@@ -209,23 +209,15 @@ __device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigne
   }
 }
 
-__device__ __forceinline__ unsigned compact1by2(unsigned x) {
-  x &= 0x09249249u;
-  x = (x ^ (x >> 2)) & 0x030C30C3u;
-  x = (x ^ (x >> 4)) & 0x0300F00Fu;
-  x = (x ^ (x >> 8)) & 0x030000FFu;
-  x = (x ^ (x >> 16)) & 0x3ffu;
-  return x;
-}
-
 struct QueryCtx {
   float qx, qy, qz, org0, org1, org2, cell, slack;
 };
 
-// squared distance from the query to the (slack-widened) box of node (m, level L)
-__device__ __forceinline__ float node_mindist2(const QueryCtx& c, unsigned m, int L) {
+// squared distance from the query to the (slack-widened) box of the level-L node with integer cell coordinates (cx, cy, cz);
+// the search carries node coordinates next to the Morton code, so no code is ever decoded
+__device__ __forceinline__ float node_mindist2(const QueryCtx& c, unsigned cx, unsigned cy, unsigned cz, int L) {
   const float cl = c.cell * (float)(1 << L);
-  const float x0 = c.org0 + (float)compact1by2(m) * cl, y0 = c.org1 + (float)compact1by2(m >> 1) * cl, z0 = c.org2 + (float)compact1by2(m >> 2) * cl;
+  const float x0 = c.org0 + (float)cx * cl, y0 = c.org1 + (float)cy * cl, z0 = c.org2 + (float)cz * cl;
   const float dx = fmaxf(fmaxf(x0 - c.qx, c.qx - (x0 + cl)) - c.slack, 0.f);
   const float dy = fmaxf(fmaxf(y0 - c.qy, c.qy - (y0 + cl)) - c.slack, 0.f);
   const float dz = fmaxf(fmaxf(z0 - c.qz, c.qz - (z0 + cl)) - c.slack, 0.f);
@@ -273,7 +265,7 @@ template <int K, int SPW>
 __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__ q, int N, const NlGridParams* __restrict__ gpp,
                                                        const int* __restrict__ starts, const float4* __restrict__ sorted,
                                                        int Kout, int* __restrict__ idx_out, float* __restrict__ d2_out) {
-  __shared__ unsigned s_front[4][2][FRONT_CAP];
+  __shared__ unsigned s_front[4][2][FRONT_CAP], s_fxyz[4][2][FRONT_CAP];   // Morton prefix; cell coordinates x | y << 10 | z << 20
   __shared__ int s_leaf_s[4][LEAF_CAP], s_leaf_l[4][LEAF_CAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n0 = __builtin_amdgcn_readfirstlane((nl_xcd_block() * 4 + wv) * SPW);
@@ -295,7 +287,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   float U;
   if (!prev_full) {
     // -------------------------------------------------------------- phase 1: greedy descent -> upper bound U
-    unsigned m = 0;
+    unsigned m = 0, mx = 0, my = 0, mz = 0;   // Morton prefix and cell coordinates of the node being descended (wave-uniform)
     int L = GRID_BITS;
     while (L > 0) {
       unsigned key = 0xffffffffu;
@@ -303,11 +295,14 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
         const unsigned mc = (m << 3) | (unsigned)lane;
         const int sh = 3 * (L - 1);
         const int cnt = starts[(mc + 1) << sh] - starts[mc << sh];
-        if (cnt >= K) key = (__float_as_uint(node_mindist2(c, mc, L - 1)) & ~7u) | (unsigned)lane;
+        if (cnt >= K)
+          key = (__float_as_uint(node_mindist2(c, 2 * mx + (lane & 1), 2 * my + ((lane >> 1) & 1), 2 * mz + ((lane >> 2) & 1), L - 1)) & ~7u) | (unsigned)lane;
       }
       key = wave_umin(key);
       if (key == 0xffffffffu) break;
-      m = (m << 3) | (key & 7u);
+      const unsigned ch = key & 7u;
+      m = (m << 3) | ch;
+      mx = 2 * mx + (ch & 1); my = 2 * my + ((ch >> 1) & 1); mz = 2 * mz + ((ch >> 2) & 1);
       --L;
     }
     const int rs0 = starts[m << (3 * L)], len0 = starts[(m + 1) << (3 * L)] - rs0;
@@ -328,10 +323,12 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   // ---------------------------------------------------------------- phase 2: pruned breadth-first descent
   unsigned* front = s_front[wv][0];
   unsigned* nextf = s_front[wv][1];
+  unsigned* fxyz = s_fxyz[wv][0];
+  unsigned* nextx = s_fxyz[wv][1];
   int* leaf_s = s_leaf_s[wv];
   int* leaf_l = s_leaf_l[wv];
   int nfront = 1, nleaf = 0;
-  if (lane == 0) front[0] = 0u;
+  if (lane == 0) { front[0] = 0u; fxyz[0] = 0u; }
   const u64 lt_mask = (1ull << lane) - 1ull;
 
   // leaves hold <= 16 points each: four leaves per 64-lane batch, one per 16-lane slot (no prefix sums, no index search)
@@ -355,13 +352,16 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
     for (int base = 0; base < nfront; base += 8) {
       const int ni = base + (lane >> 3);
       bool keep = false, leaf = false;
-      unsigned mc = 0;
+      unsigned mc = 0, cxyz = 0;
       int rs = 0, cnt = 0;
       if (ni < nfront) {
         mc = (front[ni] << 3) | (unsigned)(lane & 7);
+        const unsigned pxyz = fxyz[ni];
+        const unsigned cx = 2 * (pxyz & 1023u) + (lane & 1), cy = 2 * ((pxyz >> 10) & 1023u) + ((lane >> 1) & 1), cz = 2 * (pxyz >> 20) + ((lane >> 2) & 1);
+        cxyz = cx | (cy << 10) | (cz << 20);
         rs = starts[mc << sh];
         cnt = starts[(mc + 1) << sh] - rs;
-        keep = cnt > 0 && node_mindist2(c, mc, L - 1) <= U * 1.000001f;   // '<=' keeps exact ties; margin covers fp32 rounding
+        keep = cnt > 0 && node_mindist2(c, cx, cy, cz, L - 1) <= U * 1.000001f;   // '<=' keeps exact ties; margin covers fp32 rounding
         leaf = keep && (L - 1 == 0 || cnt <= LEAF_COUNT_MAX);
       }
       const bool inner = keep && !leaf;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       const int room = FRONT_CAP - nnext;
       const int pi = __popcll(mi & lt_mask);
       const bool spill = inner && pi >= room;
-      if (inner && !spill) nextf[nnext + pi] = mc;
+      if (inner && !spill) { nextf[nnext + pi] = mc; nextx[nnext + pi] = cxyz; }
       nnext += ci < room ? ci : room;
       // ranges wider than a slot (dense fine cells, spilled inner nodes) are rare: scanned right away, one by one
       const bool lf = leaf || spill;
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       if (nleaf >= 32) flush_leaves();
     }
     unsigned* t = front; front = nextf; nextf = t;
+    t = fxyz; fxyz = nextx; nextx = t;
     nfront = nnext;
     if (nfront == 0) break;
   }
