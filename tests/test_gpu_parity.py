@@ -244,3 +244,25 @@ def test_empty_and_ragged_ray_batches(precision):
         for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
             assert rel_err(part[k].cpu().numpy(), full[k][:n].cpu().numpy()) < (2e-6 if precision == "fp32" else 2e-5), (n, k)
         assert torch.equal(part["mask"], full["mask"][:n])
+
+
+# ------------------------------------------------------------------ view-count specialisations of the multi-view gather
+@pytest.mark.parametrize("V", [8, 12, 16])
+def test_view_count_variants_match_oracle(V):
+    """mv_stats is specialised per view-count bucket (4 / 8 / 10 / 16, exact or guarded); the golden cases cover V = 3, 4, 5 and
+    10 — this checks the remaining kernels (exact 8, guarded 16 via V = 12, exact 16) against the oracle on a tiny scene."""
+    from oracle import render_oracle as orc
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    cfg = CASES["tiny_full"][0].replace(name=f"tiny_v{V}", V=V, seed=100 + V)
+    frame = make_frame(cfg)
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+    params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    rays_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in case["rays"].items()}
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(frame), rays_t, cfg.S)
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=_z(cfg, cfg.R))
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (V, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
