@@ -28,12 +28,11 @@ def _grid_sample_pts(feats, pts, h=None, w=None, padding_mode="zeros", align_cor
 
 def _project(pts, Rt, Ks, h, w):
     """depth_fusion.py:78-126 — NeuRay projection of pts (n,3) into every view: pix (V,n,2), depth (V,n,1), valid (V,n)."""
-    hp = torch.cat([pts, torch.ones(pts.shape[0], 1, device=pts.device)], 1)
-    KRt = Ks @ Rt
-    last = torch.zeros(Rt.shape[0], 1, 4, device=pts.device)
-    last[:, :, 3] = 1.0
-    Hm = torch.cat([KRt, last], 1)
-    cam = (Hm[:, None] @ hp[None, :, :, None])[:, :, :3, 0]
+    KRt = Ks @ Rt                                                                    # (V,3,4)
+    # rows 0-2 of [K Rt; 0 0 0 1] . [x y z 1]^T for every (view, point) as four broadcast multiply-adds.  (The literal
+    # form, a (V,1,4,4) @ (1,n,4,1) matmul, becomes V*n = 5e5 batched 4x4 GEMMs: 59 ms of the 136-ms frame setup on ROCm.)
+    x, y, z = pts[None, :, 0:1], pts[None, :, 1:2], pts[None, :, 2:3]
+    cam = ((KRt[:, None, :, 0] * x + KRt[:, None, :, 1] * y) + KRt[:, None, :, 2] * z) + KRt[:, None, :, 3]
     depth = cam[:, :, 2:].clone()
     bad = depth.abs() < 1e-4
     depth[bad] = 1e-3
