@@ -39,6 +39,12 @@ for _ in range(3):
 t_batch = min(ts)
 if len(sys.argv) > 2 and sys.argv[2] == 'setuponly':
     print(f'{cfg.name}: per-frame setup {1e3*(t_first-t_batch):.1f} ms'); sys.exit(0)
+pts = net.support_neural_points["fine"]["xyz"][:1024].contiguous()
+def tq(fn, n=10):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print(f"{cfg.name}: descriptor queries of 1024 points: query_fine {tq(lambda: net.query_fine(data, pts)):.2f} ms, query_coarse {tq(lambda: net.query_coarse(data, pts)):.2f} ms")
 torch.cuda.synchronize(); t0 = time.perf_counter(); img = net.render_image(data); torch.cuda.synchronize(); t_img = time.perf_counter() - t0
 print(f"{cfg.name}: setup + first {cfg.R}-ray batch {t_first*1e3:.1f} ms; warm batch {t_batch*1e3:.1f} ms -> per-frame setup {1e3*(t_first-t_batch):.1f} ms; "
       f"render_image {cfg.H}x{cfg.Wimg} = {cfg.H*cfg.Wimg} rays in {t_img*1e3:.1f} ms ({cfg.H*cfg.Wimg/t_img/1e3:.0f} k rays/s through the module)")
