@@ -4,6 +4,8 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 
 // ---- launchers implemented in the other translation units -------------------------------------------
@@ -282,9 +284,9 @@ struct nl_frame {
   int64_t M;
   NlKnnGrid grid;
   float* ptt;               // [(M+1)][W] table T (see G_PTT), built lazily per (frame, weights); row M = bias
-  const void* ptt_for;
+  const void* ptt_for; uint64_t ptt_gen;
   float* pfeat;             // (V,h,w,32) feature maps projected through the blend layer's feature columns
-  const void* pfeat_for;    // packed weights pfeat was computed with (lazily, first render of the frame)
+  const void* pfeat_for; uint64_t pfeat_gen;   // packed weights (address + pack generation) pfeat was computed with (lazily, first render of the frame)
   float* views_dev;         // device copy of the per-view matrices: [16][12] proj_ibr rows, then [16][3] camera centres
   float views_host[16 * 15];
 };
@@ -409,24 +411,42 @@ NlViews with_query(const nl_frame* f, const float* qc) {
   return v;
 }
 
+// Every nl_pack_weights call stamps its destination with a fresh generation number (host-side registry keyed by the blob's
+// address): the per-frame tables derived from the weights are rebuilt when a blob is RE-packed in place, not only when another
+// blob is used.
+std::mutex g_gen_mu;
+std::unordered_map<const void*, uint64_t> g_pack_gen;
+uint64_t g_gen_next = 1;
+uint64_t pack_generation(const void* pk) {
+  std::lock_guard<std::mutex> lk(g_gen_mu);
+  auto it = g_pack_gen.find(pk);
+  return it == g_pack_gen.end() ? 0 : it->second;
+}
+void bump_generation(const void* pk) {
+  std::lock_guard<std::mutex> lk(g_gen_mu);
+  g_pack_gen[pk] = g_gen_next++;
+}
+
 // per-frame projection of the support feature maps through the blend layer (exact fp32 MFMA), done once per (frame, weights)
 int ensure_pfeat(const Ctx& x, const nl_frame* fc) {
   nl_frame* f = const_cast<nl_frame*>(fc);
-  if (f->pfeat_for == (const void*)x.pk) return NL_OK;
+  const uint64_t gen = pack_generation(x.pk);
+  if (f->pfeat_for == (const void*)x.pk && f->pfeat_gen == gen) return NL_OK;
   nl_config c32 = *x.c;
   c32.precision = NL_PREC_F32;
   Ctx x32 = x;
   x32.c = &c32;
   SegSpec s{f->feat, f->C, f->C, 0, 1};
   NL_TRY(run_gemm(x32, G_BLENDP, &s, 1, (int64_t)f->views.V * f->views.h * f->views.w, f->pfeat, 32, NL_ACT_NONE));
-  f->pfeat_for = (const void*)x.pk;
+  f->pfeat_for = (const void*)x.pk; f->pfeat_gen = gen;
   return NL_OK;
 }
 
 // per-frame table T for the fused point kernel (exact fp32 MFMA), once per (frame, weights)
 int ensure_ptt(const Ctx& x, const nl_frame* fc) {
   nl_frame* f = const_cast<nl_frame*>(fc);
-  if (f->ptt_for == (const void*)x.pk) return NL_OK;
+  const uint64_t gen = pack_generation(x.pk);
+  if (f->ptt_for == (const void*)x.pk && f->ptt_gen == gen) return NL_OK;
   const int W = x.c->W, F = f->C + 3;
   nl_config c32 = *x.c;
   c32.precision = NL_PREC_F32;
@@ -437,7 +457,7 @@ int ensure_ptt(const Ctx& x, const nl_frame* fc) {
     NL_TRY(run_gemm(x32, G_PTT, &s, 1, f->M, f->ptt, W, NL_ACT_NONE));
   }
   NL_CHECK_HIP(hipMemcpyAsync(f->ptt + (size_t)f->M * W, x.pk + x.L.bias[G_PTT], sizeof(float) * W, hipMemcpyDeviceToDevice, x.st));
-  f->ptt_for = (const void*)x.pk;
+  f->ptt_for = (const void*)x.pk; f->ptt_gen = gen;
   return NL_OK;
 }
 
@@ -645,6 +665,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   const Layout L = make_layout(cfg);
   if (bytes < L.total) return NL_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  bump_generation(packed);
   NL_CHECK_HIP(hipMemsetAsync(packed, 0, L.total, st));
   Packer P{t, (char*)packed, &L, st};
   const int W = cfg->W, C = cfg->C, F = C + 3;
@@ -753,9 +774,9 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
   {
     char* p = (char*)mem + nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M);
     f->ptt = (float*)p;
-    f->ptt_for = nullptr;
+    f->ptt_for = nullptr; f->ptt_gen = 0;
     f->pfeat = (float*)(p + nl_align_up((size_t)(d->M + 1) * cfg->W * 4, 256));
-    f->pfeat_for = nullptr;
+    f->pfeat_for = nullptr; f->pfeat_gen = 0;
     f->views_dev = (float*)((char*)f->pfeat + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256));
     memset(f->views_host, 0, sizeof(f->views_host));
     for (int v = 0; v < d->V; ++v) {

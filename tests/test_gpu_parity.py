@@ -267,3 +267,22 @@ def test_view_count_variants_match_oracle(V):
         assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
         for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
             assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (V, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
+def test_repacking_weights_in_place_refreshes_per_frame_tables():
+    """The per-frame tables (T = sp_feature . W1, blend-projected maps) are derived from the weights: loading other weights into the
+    SAME packed buffer while a frame is set must rebuild them."""
+    name = "c1"
+    cfg, _ = CASES[name]
+    case = build_case(name)
+    r = _renderer(case, "bf16x3")
+    o, d, qc = case["rays"]["rays_o"], case["rays"]["rays_d"], case["frame"]["pose"][:3, 3]
+    a = r.render_rays(o, d, qc, z_vals=_z(cfg, cfg.R))
+    w2 = {k: (v * 1.25 if k in ("base_mlp.0.weight", "rgb_blending_mlp.0.weight") else v) for k, v in case["weights"].items()}
+    r.load_weights({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w2.items()})    # same packed buffer, frame untouched
+    b = r.render_rays(o, d, qc, z_vals=_z(cfg, cfg.R))
+    case2 = dict(case); case2["weights"] = w2
+    fresh = _renderer(case2, "bf16x3").render_rays(o, d, qc, z_vals=_z(cfg, cfg.R))
+    assert rel_err(a["rgb"].cpu().numpy(), b["rgb"].cpu().numpy()) > 1e-4, "the weight change must be visible"
+    for k in ("rgb", "depth", "feat"):
+        assert torch.equal(b[k], fresh[k]), k
