@@ -120,6 +120,10 @@ int nl_pack_weights(const nl_config* cfg, const float* const* tensors, int n_ten
                     void* packed, size_t packed_bytes, void* stream);
 
 /* ---- per-frame state --------------------------------------------------------------------------- */
+/* A frame keeps the DEVICE pointers of the descriptor (images, feature maps, support points: they must stay alive and unchanged
+ * while the frame is used — call nl_frame_create again when the data changes) plus tables derived from them in frame_mem
+ * (visibility maps repacked, KNN grid, and — built lazily on the first render with a given packed-weights blob and rebuilt when
+ * that blob is re-packed — the per-point table T and the blend-projected feature maps). */
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* desc);
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* desc, void* frame_mem, size_t frame_bytes,
                     void* stream, nl_frame** out);
