@@ -119,6 +119,27 @@ size_t nl_packed_weights_bytes(const nl_config* cfg);
 int nl_pack_weights(const nl_config* cfg, const float* const* tensors, int n_tensors,
                     void* packed, size_t packed_bytes, void* stream);
 
+/* ---- per-frame setup ---------------------------------------------------------- */
+/* Workspace for the two setup calls below (stride = 1 for nl_cross_view_features). */
+size_t nl_setup_workspace_bytes(int V, int H, int W, int stride);
+/* DepthFusionNet's hand-made input (conditional_nerf/depth_fusion.py:150-227 depth2pts3d + get_diff_feats +
+ * extract_depth_for_init, assembled at :269-278): cnn_in (V,12,H,W) = [rgb 3 | normalised inverse depth 1 | masked mean of the
+ * cross-view colour difference 3 | its variance 3 | mean and variance of the inverse-depth difference 2].  imgs (V,3,H,W),
+ * depths (V,H,W) metric, Ks (V,3,3), c2w (V,4,4), all fp32 device pointers; V <= 16.  Replaces ~60 framework ops over
+ * (V, V*H*W, c) intermediates. */
+int nl_cross_view_features(const float* imgs, const float* depths, const float* Ks, const float* c2w, int V, int H, int W,
+                           float near_, float far_, float* cnn_in, void* workspace, size_t workspace_bytes, void* stream);
+/* ConditionalNeRF.backproject_support_frame (conditional_nerf/model.py:203-265; get_rays utils.py:56-70): every pixel with
+ * depth > 0 of the nearest-resized (H/stride, W/stride) depth map of every view becomes one row of the support tables, in the
+ * reference's order (view, row, column).  feats (V,fh,fw,C) channels-last at the level's resolution.  Tables (capacity rows):
+ * feature (.,3+C) = [rgb | feature], xyz (.,3) world, xyz_ref (.,3) in view 0's camera, direction (.,4) = unit viewing ray in
+ * the world frame + depth.  *m_out (HOST) receives the number of rows; if it exceeds capacity nothing is written and
+ * NL_ERR_WORKSPACE is returned (capacity = V*(H/stride)*(W/stride) always suffices).  Synchronises the stream once (the
+ * reference synchronises once per view in nonzero()). */
+int nl_backproject_support(const float* imgs, const float* feats, const float* depths, const float* Ks, const float* c2w,
+                           int V, int H, int W, int fh, int fw, int C, int stride, int64_t capacity, float* feature, float* xyz,
+                           float* xyz_ref, float* direction, int64_t* m_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-frame state --------------------------------------------------------------------------- */
 /* A frame keeps the DEVICE pointers of the descriptor (images, feature maps, support points: they must stay alive and unchanged
  * while the frame is used — call nl_frame_create again when the data changes) plus tables derived from them in frame_mem

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERFLOC_LIB") or os.path.join(_HERE, "csrc", "libnerfloc_render.so")
 
 NL_OK = 0
+NL_ERR_BAD_ARG, NL_ERR_UNSUPPORTED, NL_ERR_WORKSPACE, NL_ERR_HIP, NL_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 MAX_VIEWS = 16
@@ -76,6 +77,9 @@ SYMBOLS = [
     ("nl_render_rays_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_render_rays_min_workspace_bytes", _Z, [_CFG, _I]),
     ("nl_render_rays", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P]),
+    ("nl_setup_workspace_bytes", _Z, [_I, _I, _I, _I]),
+    ("nl_cross_view_features", _I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _Z, _P]),
+    ("nl_backproject_support", _I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, C.POINTER(_L), _P, _Z, _P]),
 ]
 
 _lib = None

@@ -8,8 +8,10 @@ names/shapes, so `pl/model.py:33-41`-style checkpoint loading
 What runs where
   * everything per ray / per sample (rows a2-a20 of SURVEY.md §8) runs in libnerfloc_render.so (HIP, gfx950) through
     `HipRenderer`; there is NO PyTorch fallback for it — without the library or a GPU these methods raise.
-  * per-frame setup (row a21: back-projection, `DepthFusionNet`, `confidence_mlp`, `keypoint_head`) and the tiny
-    descriptor projections stay on PyTorch-ROCm, like the 2-D backbone (north_star).
+  * per-frame setup (row a21): back-projection of the support views and DepthFusionNet's cross-view consistency input run in
+    the library too (`frame_setup.py`: `nl_backproject_support`, `nl_cross_view_features`); the per-frame CNN itself
+    (`DepthFusionNet.encode`, MIOpen convolutions), `confidence_mlp`, `keypoint_head` and the tiny descriptor projections stay on
+    PyTorch-ROCm, like the 2-D backbone (north_star).
   * training-time pieces that need autograd through the renderer (`compute_render_loss`, `beta`) are "next rows"
      and raise NotImplementedError.
 """
@@ -24,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .depth_fusion import DepthFusionNet
+from .frame_setup import backproject_support
 from .renderer import HipRenderer
 
 
@@ -204,30 +207,11 @@ class ConditionalNeRF(nn.Module):
                                                     data["topk_Ks"], data["topk_poses"], data["depth_range"][0])
         return agg.vis_featmaps
 
-    # ------------------------------------------------------------------ per-frame setup (a21, PyTorch)
+    # ------------------------------------------------------------------ per-frame setup (a21)
     def backproject_support_frame(self, imgs, feats, depths, Ks, c2ws, stride=1):
-        """model.py:203-265."""
-        refs, worlds, descs, dirs = [], [], [], []
-        w2c_ref = c2ws[0].inverse()
-        for img, feat, depth, K, c2w in zip(imgs, feats, depths, Ks, c2ws):
-            H, W = int(img.shape[-2] / stride), int(img.shape[-1] / stride)
-            K = K.clone()
-            K[:2] /= stride
-            depth = F.interpolate(depth[None, None], size=(H, W)).squeeze()
-            img = F.interpolate(img[None], size=(H, W)).squeeze().permute(1, 2, 0)
-            v, u = torch.nonzero(depth > 0, as_tuple=True)
-            z = depth[v, u]
-            uv1 = torch.stack([u, v, torch.ones_like(u)], 0).float()
-            cam = torch.matmul(K.inverse(), uv1) * z
-            cam_h = torch.cat([cam, torch.ones_like(cam[:1])])
-            world = torch.matmul(c2w[:3, :3], cam) + c2w[:3, 3:]
-            ref = torch.matmul(torch.matmul(w2c_ref, c2w), cam_h)[:3]
-            _, rd = get_rays(H, W, K, c2w)
-            refs.append(ref.T)
-            worlds.append(world.T)
-            descs.append(torch.cat([img[v, u], feat[v, u]], 1))
-            dirs.append(torch.cat([rd[v, u], z.view(-1, 1)], 1))
-        return torch.cat(descs), torch.cat(worlds), torch.cat(refs), torch.cat(dirs)
+        """model.py:203-265 on the HIP library (`nl_backproject_support`: count / scan / fill, reference row order) ->
+        (feature (M,3+C), xyz world, xyz in view 0's camera, direction + depth)."""
+        return backproject_support(imgs, feats, depths, Ks, c2ws, int(stride))
 
     def estimate_neural_points_confidence(self, points, data, level_feat):
         """model.py:137-142: confidence_mlp(multiview aggregate at the support points) — aggregate on HIP, MLP on torch."""

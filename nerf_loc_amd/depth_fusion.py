@@ -2,7 +2,7 @@
 
 Own PyTorch restatement of the reference's per-frame CNN so that reference checkpoints load by name:
 `DepthFusionNet` (conditional_nerf/depth_fusion.py:239-282) = cross-view depth/colour consistency features
-(:163-207) -> `ResEncoder` (conditional_nerf/neuray_ops.py:164-239) + a 2-layer depth skip -> 32-channel map at 1/4
+(:163-207; on the HIP library, `nl_cross_view_features`) -> `ResEncoder` (conditional_nerf/neuray_ops.py:164-239) + a 2-layer depth skip -> 32-channel map at 1/4
 resolution.  It runs once per query frame (not per ray); its output is what `nl_frame_create` receives as
 `vis_featmaps`.  Module/parameter names mirror the reference's state_dict (72 tensors under
 `multiview_aggregator.depth_fusion.*`).
@@ -12,75 +12,6 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-
-
-def _grid_sample_pts(feats, pts, h=None, w=None, padding_mode="zeros", align_corners=False):
-    """neuray_ops.py:14-36 — pts (b,n,2) in pixels of an (h,w) image -> (b,n,f)."""
-    _, _, ch, cw = feats.shape
-    if h is None and w is None:
-        h, w = ch, cw
-    gx = pts[:, :, 0] / (w - 1) * 2 - 1
-    gy = pts[:, :, 1] / (h - 1) * 2 - 1
-    grid = torch.stack([gx, gy], -1).unsqueeze(1)
-    out = F.grid_sample(feats, grid, mode="bilinear", padding_mode=padding_mode, align_corners=align_corners)
-    return out.squeeze(2).permute(0, 2, 1)
-
-
-def _project(pts, Rt, Ks, h, w):
-    """depth_fusion.py:78-126 — NeuRay projection of pts (n,3) into every view: pix (V,n,2), depth (V,n,1), valid (V,n)."""
-    KRt = Ks @ Rt                                                                    # (V,3,4)
-    # rows 0-2 of [K Rt; 0 0 0 1] . [x y z 1]^T for every (view, point) as four broadcast multiply-adds.  (The literal
-    # form, a (V,1,4,4) @ (1,n,4,1) matmul, becomes V*n = 5e5 batched 4x4 GEMMs: 59 ms of the 136-ms frame setup on ROCm.)
-    x, y, z = pts[None, :, 0:1], pts[None, :, 1:2], pts[None, :, 2:3]
-    cam = ((KRt[:, None, :, 0] * x + KRt[:, None, :, 1] * y) + KRt[:, None, :, 2] * z) + KRt[:, None, :, 3]
-    depth = cam[:, :, 2:].clone()
-    bad = depth.abs() < 1e-4
-    depth[bad] = 1e-3
-    pix = cam[:, :, :2] / depth
-    outside = (pix[..., 0] < -0.5) | (pix[..., 0] >= w - 0.5) | (pix[..., 1] < -0.5) | (pix[..., 1] >= h - 0.5)
-    return pix, depth, (~bad[..., 0]) & (~outside)
-
-
-def _masked_mean_var(x, mask, dim):
-    """neuray_ops.py:38-43."""
-    mask = mask.float()
-    s = torch.clamp_min(mask.sum(dim, keepdim=True), 1e-4)
-    mean = (x * mask).sum(dim, keepdim=True) / s
-    var = ((x - mean) ** 2 * mask).sum(dim, keepdim=True) / s
-    return mean, var
-
-
-def cross_view_consistency(imgs, depth_norm, Ks, Rt, depth_range):
-    """depth_fusion.py:150-207 (depth2pts3d + get_diff_feats): re-project every view's depth into every other view and
-    summarise colour / inverse-depth disagreement -> (V,8,h,w)."""
-    V, _, h, w = imgs.shape
-    near = depth_range[:, 0][:, None, None, None]
-    far = depth_range[:, 1][:, None, None, None]
-    ni, fi = -1 / near, -1 / far
-    depth = -1 / (depth_norm * (fi - ni) + ni)
-    ys, xs = torch.meshgrid(torch.arange(h, device=imgs.device), torch.arange(w, device=imgs.device), indexing="ij")
-    coords = torch.stack([xs, ys, torch.ones_like(xs)], -1).float()[None]           # 1,h,w,3 = (x, y, 1)
-    pts = (depth.permute(0, 2, 3, 1).unsqueeze(-1) * coords.unsqueeze(-2)).reshape(V, h * w, 3).permute(0, 2, 1)
-    pts = torch.inverse(Ks) @ pts
-    R = Rt[:, :3, :3].permute(0, 2, 1)
-    t = -R @ Rt[:, :3, 3:]
-    pts = (R @ pts + t).permute(0, 2, 1).reshape(-1, 3)                              # world points of all views
-    pix, prj_depth, valid = _project(pts, Rt, Ks, h, w)
-    d_int = _grid_sample_pts(depth, pix, padding_mode="border", align_corners=True)
-    c_int = _grid_sample_pts(imgs, pix, padding_mode="border", align_corners=True)
-    rgb_diff = (c_int - imgs.permute(0, 2, 3, 1).reshape(1, V * h * w, 3)).abs()
-    d_int = torch.clamp(d_int, min=1e-5)
-    prj_depth = torch.clamp(prj_depth, min=1e-5)
-    d_diff = (-1 / d_int + 1 / prj_depth).abs()
-    ni2, fi2 = -1 / depth_range[:, 0][:, None, None], -1 / depth_range[:, 1][:, None, None]
-    d_diff = torch.clamp(d_diff / (fi2 - ni2), max=1.5)
-    m = valid.float().unsqueeze(-1)
-    dm, dv = _masked_mean_var(d_diff, m, 0)
-    cm, cv = _masked_mean_var(rgb_diff, m, 0)
-
-    def fold(x, c):
-        return x.reshape(V, h, w, c).permute(0, 3, 1, 2)
-    return torch.cat([fold(cm, 3), fold(cv, 3), fold(dm, 1), fold(dv, 1)], 1)
 
 
 def _conv3x3(i, o, stride=1):
@@ -185,13 +116,13 @@ class DepthFusionNet(nn.Module):
         self.out_channels = 32
 
     def forward(self, imgs, feats, depths, Ks, poses, depth_range):
-        V = imgs.shape[0]
-        dr = depth_range.view(1, 2).repeat(V, 1).float()
-        near = dr[:, 0][:, None, None, None]
-        far = dr[:, 1][:, None, None, None]
-        ni, fi = -1 / near, -1 / far
-        d = torch.clamp(depths.unsqueeze(1), min=1e-5)
-        d = torch.clamp((-1 / d - ni) / (fi - ni), min=0, max=1.0)      # extract_depth_for_init (:209-227)
-        diff = cross_view_consistency(imgs, d, Ks, poses.inverse()[:, :3], dr)
-        x = self.fuse_net(torch.cat([imgs, d, diff], 1))
-        return self.conv_out(torch.cat([self.depth_skip(d), x], 1))
+        """The hand-made input channels (normalised inverse depth + cross-view consistency statistics, reference :150-227) come
+        from the HIP library in one pass; the CNN is PyTorch-ROCm (MIOpen)."""
+        from .frame_setup import cross_view_features
+        near, far = [float(x) for x in depth_range.reshape(-1)[:2]]
+        return self.encode(cross_view_features(imgs, depths, Ks, poses, near, far))
+
+    def encode(self, cnn_in):
+        """(V,12,H,W) = [rgb | normalised inverse depth | 8 consistency channels] -> (V,32,H/4,W/4) (reference :279-282)."""
+        x = self.fuse_net(cnn_in)
+        return self.conv_out(torch.cat([self.depth_skip(cnn_in[:, 3:4]), x], 1))

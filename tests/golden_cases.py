@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from nerf_loc_amd.synth import SceneConfig, make_frame, make_rays, make_u, make_weights
+from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_u, make_weights
 
 TINY = SceneConfig("tiny", R=16, S=16, W=32, V=3, H=32, Wimg=40, seed=11)
 
@@ -46,3 +46,28 @@ def build_case(name: str):
         # half of the rays start far outside every frustum -> <=8 valid samples -> mask False
         rays["rays_o"][::2] += np.array([0, 50.0, 0], np.float32)
     return {"cfg": cfg, "frame": frame, "rays": rays, "weights": make_weights(cfg), "u": make_u(cfg)}
+
+
+# Per-frame setup cases (row a21): the whole `data` dict the reference's pose estimator hands over, DepthFusionNet weights included.
+SETUP_CASES = {
+    "setup": SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21),
+    # ragged support depth: ~35 % of the pixels invalid (0), a few negative, one view with no valid depth at all —
+    # nonzero()'s order and the empty-view path of backproject_support_frame (model.py:231)
+    "setup_holes": SceneConfig("setup_holes", R=24, S=16, W=32, V=4, H=48, Wimg=64, seed=22),
+}
+
+
+def build_setup_case(name: str):
+    """-> dict(cfg, frame, rays, weights) for per-frame setup case `name`."""
+    cfg = SETUP_CASES[name]
+    frame = add_setup_inputs(cfg, make_frame(cfg))
+    if name == "setup_holes":
+        rng = np.random.default_rng(99)
+        d = frame["topk_depths"].copy()
+        d[rng.random(d.shape) < 0.35] = 0.0
+        d[rng.random(d.shape) < 0.02] = -1.0
+        d[2] = 0.0
+        frame["topk_depths"] = d
+    weights = dict(make_weights(cfg))
+    weights.update(make_depth_fusion_weights(cfg.seed))
+    return {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": weights}

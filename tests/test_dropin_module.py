@@ -39,32 +39,47 @@ def test_state_dict_contract_equals_reference():
     net.load_state_dict(_weights(CFG), strict=True)
 
 
-def test_depth_fusion_matches_reference_vis_featmaps():
+def test_depth_fusion_cnn_matches_reference_vis_featmaps():
+    """The per-frame CNN (PyTorch) on the oracle's restatement of its hand-made input; on the GPU that input comes from
+    nl_cross_view_features (tests/test_gpu_setup.py)."""
     from nerf_loc_amd.depth_fusion import DepthFusionNet
+    from oracle import setup_oracle as sorc
     g = load_golden("setup")
     frame = add_setup_inputs(CFG, make_frame(CFG))
     net = DepthFusionNet().eval()
     pre = "multiview_aggregator.depth_fusion."
     net.load_state_dict({k[len(pre):]: v for k, v in _weights(CFG).items() if k.startswith(pre)}, strict=True)
     t = torch.from_numpy
+    near, far = [float(x) for x in frame["depth_range"][0]]
     with torch.no_grad():
-        out = net(t(frame["topk_images"]), None, t(frame["topk_depths"]), t(frame["topk_Ks"]), t(frame["topk_poses"]), t(frame["depth_range"][0]))
+        out = net.encode(sorc.cnn_input(t(frame["topk_images"]), t(frame["topk_depths"]), t(frame["topk_Ks"]), t(frame["topk_poses"]), near, far))
     assert out.shape == g["vis_featmaps"].shape
     assert rel_err(out.numpy(), g["vis_featmaps"]) < 2e-5
 
 
+def test_per_frame_setup_has_no_cpu_path():
+    from nerf_loc_amd.frame_setup import backproject_support, cross_view_features
+    frame = add_setup_inputs(CFG, make_frame(CFG))
+    t = torch.from_numpy
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cross_view_features(t(frame["topk_images"]), t(frame["topk_depths"]), t(frame["topk_Ks"]), t(frame["topk_poses"]), 1.0, 5.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        backproject_support(t(frame["topk_images"]), t(frame["feat_fine_src"]), t(frame["topk_depths"]), t(frame["topk_Ks"]), t(frame["topk_poses"]), 4)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 2e-4)])
-def test_dropin_end_to_end_matches_reference(precision, tol):
+@pytest.mark.parametrize("case_name,precision,tol", [("setup", "fp32", 1e-4), ("setup", "bf16x3", 2e-4), ("setup_holes", "bf16x3", 2e-4)])
+def test_dropin_end_to_end_matches_reference(case_name, precision, tol):
     """Same calls the reference's pose estimator makes: caches reset -> render_rays builds the frame (DepthFusionNet,
     back-projection, confidence) and renders; then descriptor queries.  Tolerance: setup (CNN on ROCm vs CPU) + renderer."""
     from nerf_loc_amd.conditional_nerf import ConditionalNeRF
-    g = load_golden("setup")
-    frame = add_setup_inputs(CFG, make_frame(CFG))
-    rays = make_rays(CFG, frame)
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case(case_name)
+    CFG, frame, rays = case["cfg"], case["frame"], case["rays"]
+    g = load_golden(case_name)
     dev = torch.device("cuda:0")
     net = ConditionalNeRF(_args(CFG), precision=precision).to(dev).eval()
-    net.load_state_dict(_weights(CFG), strict=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
     data = {k: torch.from_numpy(frame[k]).to(dev) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src",
                                                            "depth_range", "K", "pose")}
     data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8})

@@ -1,0 +1,159 @@
+"""Per-frame setup on the HIP library through the C-ABI: `nl_cross_view_features` and
+`nl_backproject_support` against the reference's goldens (tools/gen_golden.py setup) and, at sizes the goldens do not cover,
+against oracle/setup_oracle.py on the same seeded inputs.
+
+Bar: row order / counts / copied descriptors bit-exact; fp32 geometry 1e-6; consistency statistics per channel within
+max(1e-4, 3 x the reference's own fp32 rounding error) of the reference (max-rel-to-max), where the reference's rounding error is
+measured against a float64 evaluation of the same formulas (`_float64_truth`).  Why the second term: the synthetic images and the
+holed depth maps are white noise, so a bilinear sample moves by ~1 unit per pixel of coordinate error, and fp32 pixel coordinates
+(~1e2) carry ~1e-5 of rounding: the reference itself is only 2e-5 ... 1.6e-4 accurate on these channels, and two fp32
+implementations with different product orders (the library inverts its matrices in double and fixes the order; torch uses LAPACK
+and BLAS) cannot agree better than that.  The oracle (same arithmetic as the reference) is pinned at 2e-5 on every channel in
+tests/test_oracle_golden.py."""
+import ctypes as ct
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_cases import build_setup_case
+from tests.util import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _float64_truth(imgs, depths, Ks, poses, near, far):
+    from oracle import setup_oracle as sorc
+    torch.set_default_dtype(torch.float64)
+    try:
+        return sorc.cnn_input(*[torch.as_tensor(a).double() for a in (imgs, depths, Ks, poses)], near, far).numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def _channel_tolerances(ref, truth):
+    """per channel: max(1e-4, 3 x |ref - truth|_max / |truth|_max)."""
+    return [max(1e-4, 3 * rel_err(ref[:, c], truth[:, c])) for c in range(ref.shape[1])]
+
+
+
+def _dev(frame):
+    return {k: torch.from_numpy(v).to(DEV) for k, v in frame.items() if isinstance(v, np.ndarray)}
+
+
+def _random_frame(V, H, W, C, stride, seed, hole=0.3):
+    """Posed views around a slab of depth ~3 with invalid pixels; feature maps at the level's resolution."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    imgs = rng.random((V, 3, H, W), dtype=f32)
+    depths = (2.5 + rng.random((V, H, W), dtype=f32)).astype(f32)
+    depths[rng.random((V, H, W)) < hole] = 0.0
+    Ks = np.tile(np.array([[0.9 * W, 0, W / 2 - 0.3], [0, 0.9 * W, H / 2 + 0.2], [0, 0, 1]], f32), (V, 1, 1))
+    Ks[:, 0, 0] *= (1 + 0.05 * rng.standard_normal(V)).astype(f32)
+    poses = np.tile(np.eye(4, dtype=f32), (V, 1, 1))
+    for v in range(V):
+        a = 0.15 * rng.standard_normal(3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+        poses[v, :3, :3] = (Rz @ Ry @ Rx).astype(f32)
+        poses[v, :3, 3] = (0.4 * rng.standard_normal(3)).astype(f32)
+    feats = rng.standard_normal((V, H // stride, W // stride, C), dtype=f32)
+    return {"imgs": imgs, "depths": depths, "Ks": Ks, "poses": poses, "feats": feats}
+
+
+@pytest.mark.parametrize("name", ["setup", "setup_holes"])
+def test_cross_view_features_match_reference_golden(name):
+    from nerf_loc_amd.frame_setup import cross_view_features
+    case = build_setup_case(name)
+    g = load_golden(name)
+    d = _dev(case["frame"])
+    near, far = [float(x) for x in case["frame"]["depth_range"][0]]
+    x = cross_view_features(d["topk_images"], d["topk_depths"], d["topk_Ks"], d["topk_poses"], near, far).cpu().numpy()
+    assert np.array_equal(x[:, :3], case["frame"]["topk_images"])
+    fr = case["frame"]
+    truth = _float64_truth(fr["topk_images"], fr["topk_depths"], fr["topk_Ks"], fr["topk_poses"], near, far)[:, 3:]
+    tol = _channel_tolerances(g["cnn_in_geo"], truth)
+    for c in range(9):
+        assert rel_err(x[:, 3 + c], g["cnn_in_geo"][:, c]) < tol[c], (c, rel_err(x[:, 3 + c], g["cnn_in_geo"][:, c]), tol[c])
+        assert rel_err(x[:, 3 + c], truth[:, c]) < tol[c], "as accurate as the reference against the exact value"
+
+
+@pytest.mark.parametrize("name", ["setup", "setup_holes"])
+def test_backproject_support_matches_reference_golden(name):
+    from nerf_loc_amd.frame_setup import backproject_support
+    case = build_setup_case(name)
+    g = load_golden(name)
+    d = _dev(case["frame"])
+    for level, stride in (("fine", 4), ("coarse", 8)):
+        feat, xyz, ref, dirs = [t.cpu().numpy() for t in backproject_support(d["topk_images"], d[f"feat_{level}_src"], d["topk_depths"],
+                                                                             d["topk_Ks"], d["topk_poses"], stride)]
+        assert xyz.shape == g[f"{level}_xyz"].shape, "number of valid depth pixels"
+        assert np.array_equal(dirs[:, 3], g[f"{level}_direction"][:, 3]), "row order: the depth column is a copy"
+        assert rel_err(xyz, g[f"{level}_xyz"]) < 1e-6
+        assert rel_err(ref, g[f"{level}_xyz_ndc"]) < 1e-6
+        assert rel_err(dirs, g[f"{level}_direction"]) < 1e-6
+        if level == "coarse":
+            assert np.array_equal(feat, g["coarse_feature"])
+        else:
+            assert np.array_equal(feat[:, :8], g["fine_feature_head"])
+            assert np.allclose(feat.astype(np.float64).sum(1), g["fine_feature_rowsum"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("V,H,W,C,stride,seed", [(10, 256, 336, 192, 4, 1), (10, 256, 336, 192, 8, 2), (5, 50, 70, 16, 4, 3), (1, 37, 129, 8, 1, 4),
+                                                 (16, 64, 80, 192, 3, 5)])
+def test_setup_kernels_match_oracle_at_other_sizes(V, H, W, C, stride, seed):
+    """BASELINE config-2 frame size, sizes that do not divide by the stride (nearest-neighbour resampling indices), one view, 16 views."""
+    from nerf_loc_amd.frame_setup import backproject_support, cross_view_features
+    from oracle import setup_oracle as sorc
+    f = _random_frame(V, H, W, C, stride, seed)
+    t = {k: torch.from_numpy(v) for k, v in f.items()}
+    d = {k: v.to(DEV) for k, v in t.items()}
+    want = sorc.backproject_support_frame(t["imgs"], t["feats"], t["depths"], t["Ks"], t["poses"], stride)
+    got = backproject_support(d["imgs"], d["feats"], d["depths"], d["Ks"], d["poses"], stride)
+    assert got[0].shape == want[0].shape
+    assert torch.equal(got[0].cpu(), want[0]), "descriptor rows are copies"
+    assert torch.equal(got[3][:, 3].cpu(), want[3][:, 3])
+    for a, b in zip(got[1:], want[1:]):
+        assert rel_err(a.cpu().numpy(), b.numpy()) < 1e-6
+    x = cross_view_features(d["imgs"], d["depths"], d["Ks"], d["poses"], 2.0, 6.0).cpu().numpy()
+    ref = sorc.cnn_input(t["imgs"], t["depths"], t["Ks"], t["poses"], 2.0, 6.0).numpy()
+    assert np.array_equal(x[:, :3], f["imgs"])
+    if V == 1:   # a view re-projected into itself: every statistic is rounding noise around 0 (variances exactly 0)
+        assert np.abs(x[:, 4:] - ref[:, 4:]).max() < 1e-4 and np.array_equal(x[:, 7:10], ref[:, 7:10])
+        assert rel_err(x[:, 3], ref[:, 3]) < 1e-6
+        return
+    tol = _channel_tolerances(ref, _float64_truth(f["imgs"], f["depths"], f["Ks"], f["poses"], 2.0, 6.0))
+    for c in range(3, 12):
+        # a pixel whose projection lands within rounding of an image border flips its in-image flag: allow 1 in 50 000
+        err = np.abs(x[:, c] - ref[:, c]) / max(np.abs(ref[:, c]).max(), 1e-30)
+        assert (err > tol[c]).mean() < 2e-5, (c, float(err.max()), float((err > tol[c]).mean()), tol[c])
+
+
+def test_backproject_edge_cases():
+    from nerf_loc_amd import _lib as L
+    from nerf_loc_amd.frame_setup import backproject_support
+    f = _random_frame(3, 32, 48, 8, 4, 7)
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in f.items()}
+    # no valid depth anywhere -> empty tables, like torch.cat of empty pieces
+    out = backproject_support(d["imgs"], d["feats"], torch.zeros_like(d["depths"]), d["Ks"], d["poses"], 4)
+    assert [tuple(t.shape) for t in out] == [(0, 11), (0, 3), (0, 3), (0, 4)]
+    # tables smaller than the number of valid pixels -> NL_ERR_WORKSPACE and the required row count
+    lib = L.load()
+    V, H, W, C, s = 3, 32, 48, 8, 4
+    ws = torch.empty(lib.nl_setup_workspace_bytes(V, H, W, s), dtype=torch.uint8, device=DEV)
+    full = backproject_support(d["imgs"], d["feats"], d["depths"], d["Ks"], d["poses"], 4)
+    M = full[0].shape[0]
+    cap = M - 1
+    bufs = [torch.full((cap, n), -7.0, device=DEV) for n in (3 + C, 3, 3, 4)]
+    m = ct.c_int64(0)
+    st = lib.nl_backproject_support(d["imgs"].data_ptr(), d["feats"].data_ptr(), d["depths"].data_ptr(), d["Ks"].data_ptr(), d["poses"].data_ptr(),
+                                    V, H, W, H // s, W // s, C, s, cap, *[b.data_ptr() for b in bufs], ct.byref(m), ws.data_ptr(), ws.numel(), None)
+    torch.cuda.synchronize()
+    assert st == L.NL_ERR_WORKSPACE and m.value == M
+    assert all(bool((b == -7.0).all()) for b in bufs), "nothing is written when the tables are too small"
+    assert lib.nl_backproject_support(None, d["feats"].data_ptr(), d["depths"].data_ptr(), d["Ks"].data_ptr(), d["poses"].data_ptr(),
+                                      V, H, W, H // s, W // s, C, s, cap, *[b.data_ptr() for b in bufs], ct.byref(m), ws.data_ptr(), ws.numel(), None) == L.NL_ERR_BAD_ARG
+    assert lib.nl_cross_view_features(d["imgs"].data_ptr(), d["depths"].data_ptr(), d["Ks"].data_ptr(), d["poses"].data_ptr(), 17, H, W, 1.0, 5.0,
+                                      bufs[0].data_ptr(), ws.data_ptr(), ws.numel(), None) == L.NL_ERR_UNSUPPORTED

@@ -56,3 +56,41 @@ def test_get_rays_and_points_2d_to_rays():
     r = orc.points_2d_to_rays(torch.from_numpy(case["rays"]["pixel_coordinates"]), cfg.H, cfg.Wimg, K, pose)
     assert rel_err(r["rays_d"].numpy(), case["rays"]["rays_d"]) < 1e-6
     assert np.allclose(np.linalg.norm(r["rays_d"].numpy(), axis=1), 1.0, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- per-frame setup (row a21)
+@pytest.mark.parametrize("name", ["setup", "setup_holes"])
+def test_setup_oracle_matches_reference_golden(name):
+    """oracle/setup_oracle.py vs the reference's own DepthFusionNet input and support tables."""
+    from oracle import setup_oracle as sorc
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case(name)
+    g = load_golden(name)
+    f = {k: torch.from_numpy(v) for k, v in case["frame"].items() if isinstance(v, np.ndarray)}
+    near, far = [float(x) for x in case["frame"]["depth_range"][0]]
+    x = sorc.cnn_input(f["topk_images"], f["topk_depths"], f["topk_Ks"], f["topk_poses"], near, far)
+    assert np.array_equal(x[:, :3].numpy(), case["frame"]["topk_images"])
+    for c in range(9):  # channel by channel: the variances are ~100x smaller than the means
+        assert rel_err(x[:, 3 + c].numpy(), g["cnn_in_geo"][:, c]) < TOL, (c, rel_err(x[:, 3 + c].numpy(), g["cnn_in_geo"][:, c]))
+    for level, stride in (("fine", 4), ("coarse", 8)):
+        feat, xyz, ref, dirs = sorc.backproject_support_frame(f["topk_images"], f[f"feat_{level}_src"], f["topk_depths"], f["topk_Ks"],
+                                                              f["topk_poses"], stride)
+        assert xyz.shape == g[f"{level}_xyz"].shape
+        assert rel_err(xyz.numpy(), g[f"{level}_xyz"]) < 1e-6
+        assert rel_err(ref.numpy(), g[f"{level}_xyz_ndc"]) < 1e-6
+        assert rel_err(dirs.numpy(), g[f"{level}_direction"]) < 1e-6
+        if level == "coarse":
+            assert np.array_equal(feat.numpy(), g["coarse_feature"])
+        else:
+            assert np.array_equal(feat[:, :8].numpy(), g["fine_feature_head"])
+            assert np.allclose(feat.double().sum(1).numpy(), g["fine_feature_rowsum"], rtol=0, atol=1e-9)
+
+
+def test_setup_holes_case_is_ragged():
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case("setup_holes")
+    d = case["frame"]["topk_depths"]
+    assert (d[2] <= 0).all() and (d < 0).any() and 0.2 < (d == 0).mean() < 0.7
+    g = load_golden("setup_holes")
+    V, H, W = d.shape
+    assert 0 < len(g["fine_xyz"]) < V * (H // 4) * (W // 4)

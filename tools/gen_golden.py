@@ -181,12 +181,129 @@ def run_case(model_mod, ku, name):
           f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
 
 
-def run_setup_case(model_mod):
+def run_setup_case(model_mod, name="setup"):
+    """Per-frame setup (a21) + end-to-end render through the reference, with seeded DepthFusionNet weights."""
+    import json
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case(name)
+    cfg, frame, rays, weights = case["cfg"], case["frame"], case["rays"], case["weights"]
+    net = model_mod.ConditionalNeRF(ref_args(cfg)).eval()
+    sd = net.state_dict()
+    ours = {k: t(v) for k, v in weights.items()}
+    path_keys = {k for k in sd if "depth_fusion" not in k}
+    assert path_keys == set(ours), (sorted(path_keys ^ set(ours)))
+    for k in ours:
+        assert tuple(sd[k].shape) == tuple(ours[k].shape), (k, sd[k].shape, ours[k].shape)
+    net.load_state_dict(ours, strict=False)
+
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "depth_range", "K", "pose")}
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "white_bkgd": bool(frame["white_bkgd"])})
+    net.support_neural_points = {"fine": {k: t(v) for k, v in frame["support_fine"].items()}}
+    net.multiview_aggregator.vis_featmaps = t(frame["vis_featmaps"])
+    ray_d = {"rays_o": t(rays["rays_o"]), "rays_d": t(rays["rays_d"]), "depth_range": t(rays["depth_range"]),
+             "pixel_coordinates": t(rays["pixel_coordinates"]), "K": t(rays["K"]), "pose": t(rays["pose"]), "H": cfg.H, "W": cfg.Wimg}
+
+    inter = {}
+    # capture intermediates by wrapping (not editing) reference callables
+    orig_query = net.query
+
+    def query_spy(*a, **k):
+        out = orig_query(*a, **k)
+        inter["feature_agg"] = out["feature_agg"].detach().clone()
+        inter["multiview_visibility"] = out["multiview_visibility"].detach().squeeze(-1).clone()
+        return out
+    net.query = query_spy
+    orig_mv = net.multiview_aggregator.forward
+
+    def mv_spy(*a, **k):
+        out = orig_mv(*a, **k)
+        inter["multiview_feature_agg"] = out[0].detach().clone()
+        return out
+    net.multiview_aggregator.forward = mv_spy
+    orig_knn = model_mod.knn_points
+
+    def knn_spy(*a, **k):
+        out = orig_knn(*a, **k)
+        if k.get("K", 1) == 8:
+            inter["knn_d2"] = out.dists[0].detach().clone()
+            inter["knn_idx"] = out.idx[0].detach().clone()
+        return out
+    model_mod.knn_points = knn_spy
+    orig_sigma = net.sigma_mlp.forward
+
+    def sigma_spy(x):
+        out = orig_sigma(x)
+        inter["sigma"] = out.detach().clone()
+        return out
+    net.sigma_mlp.forward = sigma_spy
+    orig_unet = net.ray_unet.forward
+
+    def unet_spy(x):
+        out = orig_unet(x)
+        inter["geo"] = out.detach().permute(0, 2, 1).reshape(-1, out.shape[1]).clone()
+        return out
+    net.ray_unet.forward = unet_spy
+
+    orig_rand = torch.rand
+    if cfg.N_importance > 0:
+        def rand_fixed(*shape, **kw):
+            assert tuple(shape) == tuple(u.shape), (shape, u.shape)
+            return t(u).clone()
+        torch.rand = rand_fixed
+    try:
+        with torch.no_grad():
+            out = net.render_rays(data, ray_d)
+    finally:
+        torch.rand = orig_rand
+        model_mod.knn_points = orig_knn
+
+    save = {k: v.numpy() for k, v in out.items()}
+    R, S = cfg.R, cfg.S_total
+    save["sigma"] = inter["sigma"].view(R, S).numpy()
+    save["knn_d2"] = inter["knn_d2"].numpy()
+    save["knn_idx"] = inter["knn_idx"].numpy().astype(np.int32)
+    if CASES[name][1]:
+        save["feature_agg"] = inter["feature_agg"].numpy()
+        save["multiview_feature_agg"] = inter["multiview_feature_agg"].numpy()
+        save["multiview_visibility"] = inter["multiview_visibility"].numpy()
+        save["geo"] = inter["geo"].numpy()
+    else:  # subsample the (N, W) intermediates to keep fixtures small
+        sel = np.arange(0, R * S, 37)
+        save["rows"] = sel.astype(np.int32)
+        save["feature_agg"] = inter["feature_agg"].numpy()[sel]
+        save["multiview_feature_agg"] = inter["multiview_feature_agg"].numpy()[sel]
+        save["geo"] = inter["geo"].numpy()[sel]
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **save)
+    msk = save["mask"]
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) rays={R} S={S} mask_true={int(msk.sum())}/{R} "
+          f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
+
+
+def punch_holes(frame, seed):
+    """Ragged support depth for the `setup_holes` case: ~35 % of the pixels invalid (0), a few negative, one view with no valid
+    depth at all — nonzero()'s order and the empty-view path of backproject_support_frame (model.py:231)."""
+    rng = np.random.default_rng(seed)
+    d = frame["topk_depths"].copy()
+    d[rng.random(d.shape) < 0.35] = 0.0
+    d[rng.random(d.shape) < 0.02] = -1.0
+    d[2] = 0.0
+    frame = dict(frame)
+    frame["topk_depths"] = d
+    return frame
+
+
+def run_setup_case(model_mod, name="setup"):
     """Per-frame setup (a21) + end-to-end render through the reference, with seeded DepthFusionNet weights."""
     import json
     from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_weights
-    cfg = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
-    frame = add_setup_inputs(cfg, make_frame(cfg))
+    if name == "setup":
+        cfg = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
+        frame = add_setup_inputs(cfg, make_frame(cfg))
+    else:
+        cfg = SceneConfig("setup_holes", R=24, S=16, W=32, V=4, H=48, Wimg=64, seed=22)
+        frame = punch_holes(add_setup_inputs(cfg, make_frame(cfg)), 99)
     rays = make_rays(cfg, frame)
     weights = dict(make_weights(cfg))
     weights.update(make_depth_fusion_weights(cfg.seed))
@@ -200,34 +317,46 @@ def run_setup_case(model_mod):
     data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8, "scene": "s", "filename": "f"})
     ray_d = {"rays_o": t(rays["rays_o"]), "rays_d": t(rays["rays_d"]), "depth_range": t(rays["depth_range"]),
              "pixel_coordinates": t(rays["pixel_coordinates"]), "K": t(rays["K"]), "pose": t(rays["pose"]), "H": cfg.H, "W": cfg.Wimg}
+    cnn_in = {}
+    hook = net.multiview_aggregator.depth_fusion.fuse_net.register_forward_pre_hook(lambda m, a: cnn_in.__setitem__("x", a[0].detach().clone()))
     with torch.no_grad():
         out = net.render_rays(data, ray_d)
         pts = net.support_neural_points["fine"]["xyz"][::5][:64].contiguous() + 0.003
         desc_f, _, _ = net.query_fine(data, pts)
         desc_c, _, _ = net.query_coarse(data, pts)
+    hook.remove()
     sp = net.support_neural_points
     save = {k: v.numpy() for k, v in out.items()}
     save.update({"vis_featmaps": net.multiview_aggregator.vis_featmaps.numpy(), "fine_xyz": sp["fine"]["xyz"].numpy(),
                  "fine_confidence": sp["fine"]["confidence"].numpy(), "fine_direction": sp["fine"]["direction"].numpy(),
                  "fine_feature_head": sp["fine"]["feature"][:, :8].numpy(), "coarse_xyz": sp["coarse"]["xyz"].numpy(),
                  "coarse_keypoint_score": sp["coarse"]["keypoint_score"].numpy(), "query_pts": pts.numpy(),
-                 "desc_fine": desc_f.numpy(), "desc_coarse": desc_c.numpy()})
-    path = os.path.join(ROOT, "tests", "golden", "setup.npz")
+                 "desc_fine": desc_f.numpy(), "desc_coarse": desc_c.numpy(),
+                 # a21 on HIP: the CNN's hand-made input channels (3 = normalised inverse depth, 4-11 = cross-view statistics; 0-2 are the
+                 # images themselves) and the remaining support-table columns
+                 "cnn_in_geo": cnn_in["x"][:, 3:].numpy(), "fine_xyz_ndc": sp["fine"]["xyz_ndc"].numpy(),
+                 "fine_feature_rowsum": sp["fine"]["feature"].double().sum(1).numpy(), "coarse_xyz_ndc": sp["coarse"]["xyz_ndc"].numpy(),
+                 "coarse_direction": sp["coarse"]["direction"].numpy(), "coarse_feature": sp["coarse"]["feature"].numpy()})
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
     np.savez_compressed(path, **save)
-    with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract.json"), "w") as fh:
-        json.dump({k: list(v.shape) for k, v in sd.items()}, fh, indent=0, sort_keys=True)
-    print(f"setup: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB), M_fine={len(sp['fine']['xyz'])}, conf range=({float(sp['fine']['confidence'].min()):.3f},{float(sp['fine']['confidence'].max()):.3f})")
+    if name == "setup":
+        with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract.json"), "w") as fh:
+            json.dump({k: list(v.shape) for k, v in sd.items()}, fh, indent=0, sort_keys=True)
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB), M_fine={len(sp['fine']['xyz'])}, M_coarse={len(sp['coarse']['xyz'])}, "
+          f"conf range=({float(sp['fine']['confidence'].min()):.3f},{float(sp['fine']['confidence'].max()):.3f})")
 
 
 def main():
     model_mod, ku = install_shims()
     if len(sys.argv) > 1 and sys.argv[1] == "setup":
-        return run_setup_case(model_mod)
+        run_setup_case(model_mod, "setup")
+        return run_setup_case(model_mod, "setup_holes")
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
     if not sys.argv[1:]:
-        run_setup_case(model_mod)
+        run_setup_case(model_mod, "setup")
+        run_setup_case(model_mod, "setup_holes")
 
 
 if __name__ == "__main__":
