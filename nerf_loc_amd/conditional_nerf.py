@@ -347,14 +347,12 @@ class ConditionalNeRF(nn.Module):
         o, d = o.reshape(-1, 3), d.reshape(-1, 3)
         uu, vv = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
         pix = torch.stack([uu.t().reshape(-1), vv.t().reshape(-1)], 1).to(K.device)
-        chunk = self.args.render.chunk
-        parts: Dict[str, list] = {}
-        for i in range(0, o.shape[0], chunk):
-            ret = self.render_rays(data, {"pixel_coordinates": pix[i:i + chunk], "K": K, "pose": pose, "H": H, "W": W,
-                                          "rays_o": o[i:i + chunk], "rays_d": d[i:i + chunk], "depth_range": data["depth_range"][0]})
-            for k, v in ret.items():
-                parts.setdefault(k, []).append(v)
-        out = {k: torch.cat(v, 0).view(H, W, -1) for k, v in parts.items()}
+        # The reference loops over `render.chunk` rays to bound its activation memory (model.py:615-633); here the library bounds it
+        # itself (nl_render_rays walks the batch in pieces of <= 2^20 samples inside one call), and rays are independent, so the
+        # whole image goes down in one call: same result, no per-chunk host work.
+        ret = self.render_rays(data, {"pixel_coordinates": pix, "K": K, "pose": pose, "H": H, "W": W, "rays_o": o, "rays_d": d,
+                                      "depth_range": data["depth_range"][0]})
+        out = {k: v.view(H, W, -1) for k, v in ret.items()}
         if "target_mask" in data:
             out["rgb"] = out["rgb"] * data["target_mask"][:, :, None].float()
         return out

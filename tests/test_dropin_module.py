@@ -102,11 +102,17 @@ def test_dropin_end_to_end_matches_reference(case_name, precision, tol):
     desc_c, _, _ = net.query_coarse(data, pts)
     assert rel_err(desc_f.detach().cpu().numpy(), g["desc_fine"]) < tol
     assert rel_err(desc_c.detach().cpu().numpy(), g["desc_coarse"]) < tol
-    # render_image: chunk loop + reshape (model.py:602-639)
-    net.args.render.chunk = 500
+    # render_image (model.py:602-639): all pixels in one library call; a pixel's result does not depend on the batch it is in
     img = net.render_image(data)
     assert img["rgb"].shape == (CFG.H, CFG.Wimg, 3) and img["weights"].shape == (CFG.H, CFG.Wimg, CFG.S)
     assert torch.isfinite(img["rgb"]).all()
+    pts2d = torch.tensor([[0., 0.], [5., 3.], [CFG.Wimg - 1., CFG.H - 1.], [17., 20.], [40., 9.]], device=dev)
+    sub = net.points_2d_to_rays(pts2d, CFG.H, CFG.Wimg, data["K"], data["pose"])
+    sub["depth_range"] = data["depth_range"][0]
+    part = net.render_rays(data, sub)
+    for k in ("rgb", "depth", "weights", "feat"):
+        want = img[k][pts2d[:, 1].long(), pts2d[:, 0].long()]
+        assert torch.equal(part[k].view(want.shape), want), k
     # the caller's per-frame cache reset is honoured (nerf_pose_estimator.py:289-290)
     net.support_neural_points = None
     net.multiview_aggregator.vis_featmaps = None
