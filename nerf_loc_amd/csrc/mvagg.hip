@@ -252,6 +252,19 @@ __global__ void pack_mv_decoder_kernel(const float* __restrict__ dec /* packed V
   } else if (i < 8192 + 520) { const int e = i - 8192 - 512; of[512 + e] = dec[(e >> 1) * DEC_STRIDE + 2176 + (e & 1)]; }   // b4
 }
 
+// The four tap offsets of one bilinear sample in one register: offset of the (clamped) north-west texel in bits 0-29, whether the
+// east column / south row is a different texel in bits 30 / 31.  Taps outside the map are clamped onto a valid texel; their
+// weights are zero.  unpack_taps runs on the scalar unit (the packed word comes from v_readlane).
+__device__ __forceinline__ unsigned pack_taps(const nlmv::Taps& t, int w, int h) {
+  const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
+  const int y0 = min(max(t.y0, 0), h - 1), y1 = min(max(t.y0 + 1, 0), h - 1);
+  return (unsigned)(y0 * w + x0) | ((unsigned)(x1 - x0) << 30) | ((unsigned)(y1 - y0) << 31);
+}
+__device__ __forceinline__ void unpack_taps(unsigned pk, int w, int (&o)[4]) {
+  const int base = (int)(pk & 0x3fffffffu), dx = (int)((pk >> 30) & 1u), dy = (pk >> 31) ? w : 0;
+  o[0] = base; o[1] = base + dx; o[2] = base + dy; o[3] = base + dy + dx;
+}
+
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
@@ -260,7 +273,7 @@ __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_re
 // view-angle features, visibility weight.  Phase B: unrolled loop over views; the per-view scalars come from
 // v_readlane with a constant lane (-> SGPRs), lanes span channels (64 lanes x 3 floats = one 768-B texel row per tap).
 template <int VT, bool V4, bool EXACT>   // EXACT: the frame has exactly VT views (no per-view guards)
-__global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
+__global__ __launch_bounds__(256, VT <= 8 ? 4 : 3) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
                                                        const float* __restrict__ images /*(V,3,H,W)*/,
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
                                                        const float* __restrict__ xyz, int N,
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
   const int vl = lane < V ? lane : 0;
   const bool vact = lane < V;
   float a_fw[4], a_iw[4];   // tap weights (nw, ne, sw, se), zero where the tap is outside
-  int a_fo[4], a_io[4];     // clamped tap offsets: feature map in texels, image in pixels
+  unsigned a_fo, a_io;      // packed clamped tap offsets (pack_taps): feature map in texels, image in pixels
   float a_ang[4], a_vis, a_dd, a_wgt;
   int cnt1;
   {
@@ -299,15 +312,13 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
     const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
     {
       const Taps t = make_taps<true, false>(xn, yn, vw.w, vw.h);
-      const int x0 = t.mw ? t.x0 : 0, x1 = t.me ? t.x0 + 1 : 0, y0 = t.mn ? t.y0 : 0, y1 = t.ms ? t.y0 + 1 : 0;
-      a_fo[0] = y0 * vw.w + x0; a_fo[1] = y0 * vw.w + x1; a_fo[2] = y1 * vw.w + x0; a_fo[3] = y1 * vw.w + x1;
+      a_fo = pack_taps(t, vw.w, vw.h);
       a_fw[0] = (t.mn && t.mw) ? t.nw : 0.f; a_fw[1] = (t.mn && t.me) ? t.ne : 0.f;
       a_fw[2] = (t.ms && t.mw) ? t.sw : 0.f; a_fw[3] = (t.ms && t.me) ? t.se : 0.f;
     }
     {
       const Taps t = make_taps<true, false>(xn, yn, vw.Wimg, vw.H);
-      const int x0 = t.mw ? t.x0 : 0, x1 = t.me ? t.x0 + 1 : 0, y0 = t.mn ? t.y0 : 0, y1 = t.ms ? t.y0 + 1 : 0;
-      a_io[0] = y0 * vw.Wimg + x0; a_io[1] = y0 * vw.Wimg + x1; a_io[2] = y1 * vw.Wimg + x0; a_io[3] = y1 * vw.Wimg + x1;
+      a_io = pack_taps(t, vw.Wimg, vw.H);
       a_iw[0] = (t.mn && t.mw) ? t.nw : 0.f; a_iw[1] = (t.mn && t.me) ? t.ne : 0.f;
       a_iw[2] = (t.ms && t.mw) ? t.sw : 0.f; a_iw[3] = (t.ms && t.me) ? t.se : 0.f;
     }
@@ -342,14 +353,17 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
   // issued before view v is reduced, so a wave has one view of loads in flight while it computes (left to itself the
   // compiler emits load -> wait -> use three times per view: 30 dependent memory round trips per sample).
   struct ViewTaps { float4 f[4]; float fs[3][4]; float im[4]; float pf[4]; };
-  const unsigned lane4 = 4u * (unsigned)lane, lane31 = (unsigned)lane & 31u, lplane = (unsigned)lch * (unsigned)(vw.H * vw.Wimg);
+  // lanes past the last channel group re-read the last one (their results are never stored): no exec-masked loads, no zero fills
+  const unsigned lane4 = V4 ? (unsigned)min(4 * lane, C - 4) : 0u, lane31 = (unsigned)lane & 31u, lplane = (unsigned)lch * (unsigned)(vw.H * vw.Wimg);
   auto issue = [&](int v) __attribute__((always_inline)) {
     ViewTaps t;
-    const int o[4] = {rli(a_fo[0], v), rli(a_fo[1], v), rli(a_fo[2], v), rli(a_fo[3], v)};
+    int o[4], oi[4];
+    unpack_taps((unsigned)rli((int)a_fo, v), vw.w, o);
+    unpack_taps((unsigned)rli((int)a_io, v), vw.Wimg, oi);
     const float* fb = feat + (size_t)v * vw.h * vw.w * C;
     if constexpr (V4) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t.f[k] = (4 * lane < C) ? *(const float4*)((fb + (size_t)o[k] * C) + lane4) : make_float4(0.f, 0.f, 0.f, 0.f);   // uniform base + 32-bit lane offset
+      for (int k = 0; k < 4; ++k) t.f[k] = *(const float4*)((fb + (size_t)o[k] * C) + lane4);   // uniform base + 32-bit lane offset
     } else {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
     }
     const float* ib = images + (size_t)v * 3 * vw.H * vw.Wimg;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t.im[k] = (ib + rli(a_io[k], v))[lplane];
+    for (int k = 0; k < 4; ++k) t.im[k] = (ib + oi[k])[lplane];
     if (bl1) {
       const float* pb = pfeat + (size_t)v * vw.h * vw.w * 32;
 #pragma unroll
@@ -371,24 +385,26 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
   auto finish = [&](int v, const ViewTaps& t) __attribute__((always_inline)) {
     const float w0 = rl(a_fw[0], v), w1 = rl(a_fw[1], v), w2 = rl(a_fw[2], v), w3 = rl(a_fw[3], v);
     if constexpr (V4) {
-      xv[v][0] = t.f[0].x * w0 + t.f[1].x * w1 + t.f[2].x * w2 + t.f[3].x * w3;
-      xv[v][1] = t.f[0].y * w0 + t.f[1].y * w1 + t.f[2].y * w2 + t.f[3].y * w3;
-      xv[v][2] = t.f[0].z * w0 + t.f[1].z * w1 + t.f[2].z * w2 + t.f[3].z * w3;
-      xv[v][3] = t.f[0].w * w0 + t.f[1].w * w1 + t.f[2].w * w2 + t.f[3].w * w3;
+      // explicit fma chains: the file is built with -ffp-contract=off (the bit-exact kernels need it), which would cost 7
+      // instructions per bilinear tap sum instead of 4
+      xv[v][0] = fmaf(t.f[3].x, w3, fmaf(t.f[2].x, w2, fmaf(t.f[1].x, w1, t.f[0].x * w0)));
+      xv[v][1] = fmaf(t.f[3].y, w3, fmaf(t.f[2].y, w2, fmaf(t.f[1].y, w1, t.f[0].y * w0)));
+      xv[v][2] = fmaf(t.f[3].z, w3, fmaf(t.f[2].z, w2, fmaf(t.f[1].z, w1, t.f[0].z * w0)));
+      xv[v][3] = fmaf(t.f[3].w, w3, fmaf(t.f[2].w, w2, fmaf(t.f[1].w, w1, t.f[0].w * w0)));
     } else {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) xv[v][j] = t.fs[j][0] * w0 + t.fs[j][1] * w1 + t.fs[j][2] * w2 + t.fs[j][3] * w3;
+      for (int j = 0; j < 3; ++j) xv[v][j] = fmaf(t.fs[j][3], w3, fmaf(t.fs[j][2], w2, fmaf(t.fs[j][1], w1, t.fs[j][0] * w0)));
     }
     {
       const float i0 = rl(a_iw[0], v), i1 = rl(a_iw[1], v), i2 = rl(a_iw[2], v), i3 = rl(a_iw[3], v);
-      const float val = t.im[0] * i0 + t.im[1] * i1 + t.im[2] * i2 + t.im[3] * i3;
+      const float val = fmaf(t.im[3], i3, fmaf(t.im[2], i2, fmaf(t.im[1], i1, t.im[0] * i0)));
       xv[v][4] = lane < 3 ? val : 0.f;
     }
     const float s_vis = rl(a_vis, v);
     if (bl1) {
       // colour-blend layer 1, per-(sample, view) part, by linearity of the bilinear tap (model.py:532-535):
       //   W[:, feat] . bilinear(featmap) == bilinear(W[:, feat] . featmap); plus rgb / visibility / angle columns + bias
-      const float pv = t.pf[0] * w0 + t.pf[1] * w1 + t.pf[2] * w2 + t.pf[3] * w3;
+      const float pv = fmaf(t.pf[3], w3, fmaf(t.pf[2], w2, fmaf(t.pf[1], w1, t.pf[0] * w0)));
       const float r = rl(xv[v][4], 0), g = rl(xv[v][4], 1), bb = rl(xv[v][4], 2);
       float o = pv + bbias;
       o = fmaf(bwr[0], r, o); o = fmaf(bwr[1], g, o); o = fmaf(bwr[2], bb, o);
@@ -438,10 +454,10 @@ __global__ __launch_bounds__(256, 4) void mv_stats_kernel(const NlViews vw, cons
     if (!V4 && j == 3) continue;   // the scalar layout has three feature slots
     float mean = 0.f;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) mean += xv[v][j] * wg[v];
+    for (int v = 0; v < VT; ++v) mean = fmaf(xv[v][j], wg[v], mean);
     float var = 0.f;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) { float d = xv[v][j] - mean; var += wg[v] * (d * d); }
+    for (int v = 0; v < VT; ++v) { float d = xv[v][j] - mean; var = fmaf(wg[v] * d, d, var); }
     int pos = -1;
     if (j < 4) { const int ch = V4 ? 4 * lane + j : lane + 64 * j; if (ch < C) pos = 3 + ch; }
     else if (lane < 3) pos = lane;
