@@ -308,18 +308,21 @@ struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; }
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
 struct HdBufs { float *sigma, *fth, *hc, *wsum, *blA, *rgb_s; };
 
-constexpr int LDG = 416, LDX = 288;   // LDG: mv_stats zero-fills columns 2F+3 .. LDG-1, so out_fc's K is a whole number of 32-wide chunks
+// leading dimensions of the two feature-width-dependent staging rows (416 and 288 at C = 192).  LDG: mv_stats zero-fills columns
+// 2F+3 .. LDG-1, so out_fc's K is a whole number of 32-wide chunks; LDX: [posenc 63 | ray_diff 27 | F] padded likewise
+inline int ldg_of(int C) { return (int)nl_align_up(2 * (C + 3) + 3, 32); }
+inline int ldx_of(int C) { return (int)nl_align_up(C + 3 + 90, 32); }
 
 void carve_mv(Bump& b, const nl_config* c, int V, int64_t N, MvBufs& m) {
   m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N);
-  m.g393 = b.take<float>((size_t)N * LDG); m.t64 = b.take<float>((size_t)N * 64);
+  m.g393 = b.take<float>((size_t)N * ldg_of(c->C)); m.t64 = b.take<float>((size_t)N * 64);
 }
 void carve_pt(Bump& b, const nl_config* c, int64_t N, int K, PtBufs& p, bool force_generic = false) {
   const int W = c->W;
   p.idx = b.take<int>((size_t)N * K); p.d2 = b.take<float>((size_t)N * K);
   if (!force_generic && nl_point_fused_supported(W, c->precision)) { p.X = p.H1 = p.H2 = p.KV = nullptr; }
   else {
-    p.X = b.take<float>((size_t)N * K * LDX);
+    p.X = b.take<float>((size_t)N * K * ldx_of(c->C));
     p.H1 = b.take<float>((size_t)N * K * W); p.H2 = b.take<float>((size_t)N * K * W);
     p.KV = b.take<float>((size_t)N * K * 256);
   }
@@ -482,9 +485,9 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
   if (bl1) NL_TRY(ensure_pfeat(x, f));
   if (x.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
   else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x.p<char>(x.L.dec_mfma), xyz, N, m.vis, m.dd, x.c->precision == NL_PREC_BF16X3, x.st));
-  NL_TRY(nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, LDG, rgb_feat, vis_ang, valid_s, f->pfeat,
+  NL_TRY(nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, ldg_of(f->C), rgb_feat, vis_ang, valid_s, f->pfeat,
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
-  SegSpec s0{m.g393, LDG, (int)nl_align_up(2 * (f->C + 3) + 3, 32), 0, 1};
+  SegSpec s0{m.g393, ldg_of(f->C), ldg_of(f->C), 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
   SegSpec s1{m.t64, 64, 64, 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC2, &s1, 1, N, G, x.c->W, NL_ACT_ELU));
@@ -512,9 +515,9 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   } else {
     if (!p.X) return NL_ERR_UNSUPPORTED;
     NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, f->M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir,
-                                  x.p<float>(x.L.rd_w), 1.f / (f->views.far_ - f->views.near_), p.X, LDX, p.wscale, x.st));
+                                  x.p<float>(x.L.rd_w), 1.f / (f->views.far_ - f->views.near_), p.X, ldx_of(f->C), p.wscale, x.st));
     const int64_t MK = N * K;
-    SegSpec sx{p.X, LDX, F + 90, 0, 1};
+    SegSpec sx{p.X, ldx_of(f->C), F + 90, 0, 1};
     NL_TRY(run_gemm(x, G_BASE0, &sx, 1, MK, p.H1, W, NL_ACT_LRELU));
     SegSpec s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1};
     NL_TRY(run_gemm(x, G_BASE2, &s1, 1, MK, p.H2, W, NL_ACT_LRELU));

@@ -269,6 +269,70 @@ def test_view_count_variants_match_oracle(V):
             assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (V, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
 
 
+@pytest.mark.parametrize("C,W", [(64, 32), (128, 64), (61, 32), (100, 128), (61, 256)])
+def test_feature_width_variants_match_oracle(C, W):
+    """backbone2d_fpn_dim is 192 in every shipped reference config, but it is a config field: narrower maps, and a width that is
+    not a multiple of 4 (scalar-load path of the multi-view gather, unaligned GEMM segments), with the staged (W = 32) and the fused
+    (W = 64 / 128 / 256) neural-point kernels, against the oracle on a tiny scene."""
+    from oracle import render_oracle as orc
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    cfg = CASES["tiny_full"][0].replace(name=f"tiny_c{C}", C=C, W=W, seed=200 + C)
+    frame = make_frame(cfg)
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+    params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    rays_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in case["rays"].items()}
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(frame), rays_t, cfg.S)
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=_z(cfg, cfg.R))
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (C, W, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
+@pytest.mark.parametrize("W,S,R", [(96, 24, 16), (160, 40, 9), (224, 8, 33), (32, 256, 5), (192, 72, 7)])
+def test_hidden_width_and_sample_count_variants_match_oracle(W, S, R):
+    """nl_config accepts every hidden width that is a multiple of 32 up to 256 and every sample count that is a multiple of 8 up to
+    256 (three stride-2 U-Net levels); the goldens cover W = 32 / 64 / 128 / 256 and S = 16 / 32 / 64 / 128 only."""
+    from oracle import render_oracle as orc
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    cfg = CASES["tiny_full"][0].replace(name=f"tiny_w{W}s{S}", W=W, S=S, R=R, seed=300 + W + S)
+    frame = make_frame(cfg)
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+    params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    rays_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in case["rays"].items()}
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(frame), rays_t, cfg.S)
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=_z(cfg, cfg.R))
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (W, S, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
+@pytest.mark.parametrize("H,Wimg,V", [(50, 70, 3), (31, 45, 2), (120, 160, 6)])
+def test_image_size_variants_match_oracle(H, Wimg, V):
+    """Image sizes that are not multiples of 4 (feature maps at floor(H/4) x floor(W/4)): projection, in-bounds tests and the three
+    bilinear conventions with odd extents."""
+    from oracle import render_oracle as orc
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    cfg = CASES["tiny_full"][0].replace(name=f"tiny_{H}x{Wimg}", H=H, Wimg=Wimg, V=V, seed=400 + H)
+    frame = make_frame(cfg)
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+    params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    rays_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in case["rays"].items()}
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(frame), rays_t, cfg.S)
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=_z(cfg, cfg.R))
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (H, Wimg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
 def test_repacking_weights_in_place_refreshes_per_frame_tables():
     """The per-frame tables (T = sp_feature . W1, blend-projected maps) are derived from the weights: loading other weights into the
     SAME packed buffer while a frame is set must rebuild them."""
