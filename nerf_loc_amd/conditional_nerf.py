@@ -167,14 +167,16 @@ class ConditionalNeRF(nn.Module):
             raise RuntimeError("ConditionalNeRF's ray path runs only on a HIP device (no CPU fallback); move the module to cuda")
         r = self._renderers.get(level)
         if r is None:
-            if "feat_mlp.0.weight" not in self.state_dict():
-                raise NotImplementedError("render.render_feature=False is not supported by the HIP path")
             r = HipRenderer(self.W, self.C, self.S, self._precision, device=dev)
             self._renderers[level] = r
             self._weights_version = -1
         ver = sum(p._version for p in self.parameters())
         if ver != self._weights_version or not r._weights_loaded:
-            sd = self.state_dict()
+            sd = dict(self.state_dict())
+            if "feat_mlp.0.weight" not in sd:   # render.render_feature=False (model.py:84-89): the head does not exist and is never evaluated
+                z = next(self.parameters()).new_zeros
+                sd.update({"feat_mlp.0.weight": z(self.W, self.W), "feat_mlp.0.bias": z(self.W), "feat_mlp.2.weight": z(self.C, self.W),
+                           "feat_mlp.2.bias": z(self.C)})
             for rr in self._renderers.values():
                 rr.load_weights(sd)
             self._weights_version = ver

@@ -130,3 +130,30 @@ def test_dropin_training_paths_raise_clearly():
     net.train()
     with pytest.raises(NotImplementedError):
         net.render_rays({}, {})
+
+
+@pytest.mark.gpu
+def test_dropin_without_feature_rendering():
+    """render.render_feature=False (model.py:84-89, 594-598): no feat_mlp in the state_dict, no 'feat' in the outputs, everything else
+    unchanged."""
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case("setup")
+    cfg, frame, rays = case["cfg"], case["frame"], case["rays"]
+    dev = torch.device("cuda:0")
+    data = {k: torch.from_numpy(frame[k]).to(dev) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src",
+                                                           "depth_range", "K", "pose")}
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8})
+    rd = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in rays.items()}
+    outs = []
+    for render_feature in (True, False):
+        args = _args(cfg)
+        args.render.render_feature = render_feature
+        net = ConditionalNeRF(args, precision="bf16x3").to(dev).eval()
+        w = {k: torch.from_numpy(v) for k, v in case["weights"].items() if render_feature or not k.startswith("feat_mlp.")}
+        net.load_state_dict(w, strict=True)
+        outs.append(net.render_rays(data, rd))
+    assert "feat" in outs[0] and "feat" not in outs[1]
+    assert torch.equal(outs[0]["mask"], outs[1]["mask"])
+    for k in ("rgb", "depth", "weights", "depth_uncertainty"):   # two module instances: MIOpen may pick another algorithm for the per-frame CNN
+        assert rel_err(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy()) < 1e-5, k
