@@ -273,7 +273,7 @@ __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_re
 // view-angle features, visibility weight.  Phase B: unrolled loop over views; the per-view scalars come from
 // v_readlane with a constant lane (-> SGPRs), lanes span channels (64 lanes x 3 floats = one 768-B texel row per tap).
 template <int VT, bool V4, bool EXACT>   // EXACT: the frame has exactly VT views (no per-view guards)
-__global__ __launch_bounds__(256, VT <= 8 ? 4 : 3) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
+__global__ __launch_bounds__(256, VT <= 4 ? 4 : (VT <= 10 ? 3 : 2)) void mv_stats_kernel(const NlViews vw, const float* __restrict__ viewsdev /*[16][12] P1, then [16][3] cam*/,
                                                        const float* __restrict__ images /*(V,3,H,W)*/,
                                                        const float* __restrict__ feat /*(V,h,w,C)*/, int C,
                                                        const float* __restrict__ xyz, int N,
@@ -433,14 +433,18 @@ __global__ __launch_bounds__(256, VT <= 8 ? 4 : 3) void mv_stats_kernel(const Nl
 #pragma unroll
   for (int v = 0; v < VT; ++v) xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = xv[v][4] = 0.f;
   {
+    // two views of taps in flight ahead of the one being reduced (the kernel waits on memory, not on the vector unit)
     ViewTaps cur = issue(0);
+    ViewTaps nxt = cur;
+    if (1 < VT && 1 < V) nxt = issue(1);
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
       if (v < V) {
-        ViewTaps nxt = cur;
-        if (v + 1 < VT && v + 1 < V) nxt = issue(v + 1);
+        ViewTaps nx2 = nxt;
+        if (v + 2 < VT && v + 2 < V) nx2 = issue(v + 2);
         finish(v, cur);
         cur = nxt;
+        nxt = nx2;
       }
     }
   }
@@ -470,6 +474,242 @@ __global__ __launch_bounds__(256, VT <= 8 ? 4 : 3) void mv_stats_kernel(const Nl
     float var = 0.f;
 #pragma unroll
     for (int v = 0; v < VT; ++v) { if (v < V) { float d = rl(a_dd, v) - mean; var += wg[v] * (d * d); } }
+    g[2 * F] = mean;
+    g[2 * F + 1] = var;
+    g[2 * F + 2] = wsum / (float)V;
+    for (int p = 2 * F + 3; p < ldg; ++p) g[p] = 0.f;
+    valid_s[n] = cnt1 > 1 ? 1 : 0;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// mv_stats8_kernel: the same computation as mv_stats_kernel with EIGHT CONSECUTIVE SAMPLES PER WAVE (lane = 8 * sample + j).
+// Why: mv_stats_kernel gives a whole wave to one sample (lanes = channels), so every bilinear tap is its own 768-byte row fetch —
+// 30 KB through the vector L1 per sample, 16 GB per batch, and knock-outs show that this data path (not vector instructions, not
+// latency alone) is what the kernel waits on.  Consecutive samples of a ray project onto almost the same texels of a support view
+// (the feature map has a quarter of the image resolution), so here one load instruction serves the same 128-byte channel chunk of
+// the taps of 8 neighbouring samples: lanes that hit the same texel share its cache line, and the per-(sample, view) scalar work
+// (projection, tap weights, angle features) is done by one lane instead of being replicated over a wave.
+//   phase A   lane (s, j) handles view j (and j + 8): projection, packed tap offsets + weights for the feature map and the image,
+//             view-angle features, visibility -> one 20-dword slot per (sample, view) in LDS (wave-private, no block barrier)
+//   phase B   for every 32-channel chunk: lane (s, j) owns channels 32 i + 4 j .. + 3 of sample s: unrolled loop over the views
+//             (taps of two views in flight), then the visibility-weighted mean / variance over the views
+//   image     lanes j < 3 own one colour plane each; the tapped colours go to the LDS slot for the blend layer
+//   blend     (model.py:532-535, per-(sample, view) part) lane (s, j) owns 4 of the 32 hidden units
+constexpr int MS8_SLOT = 20;   // 0 feature taps (packed), 1 image taps (packed), 2-5 feature tap weights, 6-9 image tap weights,
+                               // 10-13 angle features, 14 visibility, 15 depth difference, 16 weight, 17-19 tapped rgb
+
+template <int VT>
+__global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
+                                                        const float* __restrict__ feat, int C, const float* __restrict__ xyz, int N,
+                                                        const float* __restrict__ vis_in, const float* __restrict__ dd_in,
+                                                        float* __restrict__ g393, int ldg, int* __restrict__ valid_s,
+                                                        const float* __restrict__ pfeat, const float* __restrict__ blw,
+                                                        float* __restrict__ bl1, float* __restrict__ rgbv) {
+  extern __shared__ float ms8_lds[];   // [4 waves][8 samples][VT][MS8_SLOT]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = lane >> 3, j = lane & 7;
+  const int V = vw.V;
+  const int n0 = (nl_xcd_block() * 4 + wave) * 8;
+  if (n0 >= N) return;
+  const int n = n0 + s;
+  const bool live = n < N;
+  const int nn = live ? n : N - 1;
+  float* slot0 = ms8_lds + (size_t)((wave * 8 + s) * VT) * MS8_SLOT;
+  const int F = C + 3;
+
+  // ---------------------------------------------------------------- phase A (lane = (sample, view))
+  int cnt1 = 0;
+  {
+    const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
+    float tq[3] = {vw.qcam[0] - X, vw.qcam[1] - Y, vw.qcam[2] - Z};
+    const float nq = sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f;
+    tq[0] /= nq; tq[1] /= nq; tq[2] /= nq;
+#pragma unroll
+    for (int vv = 0; vv < VT; vv += 8) {
+      const int v = vv + j;
+      const bool vact = v < V;
+      const int vl = vact ? v : 0;
+      const float4 p0 = *(const float4*)(viewsdev + 12 * vl), p1 = *(const float4*)(viewsdev + 12 * vl + 4), p2 = *(const float4*)(viewsdev + 12 * vl + 8);
+      const float cx = fmaf(p0.z, Z, fmaf(p0.y, Y, p0.x * X)) + p0.w;
+      const float cy = fmaf(p1.z, Z, fmaf(p1.y, Y, p1.x * X)) + p1.w;
+      const float cz = fmaf(p2.z, Z, fmaf(p2.y, Y, p2.x * X)) + p2.w;
+      const float zc = fmaxf(cz, 1e-8f);
+      float px = cx / zc, py = cy / zc;
+      px = fminf(fmaxf(px, -1e6f), 1e6f);
+      py = fminf(fmaxf(py, -1e6f), 1e6f);
+      const bool m1 = vact && (px <= (float)vw.Wimg - 1.f) && (px >= 0.f) && (py <= (float)vw.H - 1.f) && (py >= 0.f) && (cz > 0.f);
+      const unsigned long long bm = __ballot(m1);
+      cnt1 += __popc((unsigned)(bm >> (8 * s)) & 0xffu);
+      const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
+      const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
+      const Taps tf = make_taps<true, false>(xn, yn, vw.w, vw.h);
+      const Taps ti = make_taps<true, false>(xn, yn, vw.Wimg, vw.H);
+      // view-angle features (ibrnet.py:144-167)
+      float tt[3] = {viewsdev[192 + 3 * vl] - X, viewsdev[192 + 3 * vl + 1] - Y, viewsdev[192 + 3 * vl + 2] - Z};
+      const float nt = sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f;
+      tt[0] /= nt; tt[1] /= nt; tt[2] /= nt;
+      const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+      const float nd = fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
+      if (v < VT) {
+        float* sl = slot0 + v * MS8_SLOT;
+        sl[0] = __uint_as_float(pack_taps(tf, vw.w, vw.h));
+        sl[1] = __uint_as_float(pack_taps(ti, vw.Wimg, vw.H));
+        *(float4*)(sl + 2) = make_float4((tf.mn && tf.mw) ? tf.nw : 0.f, (tf.mn && tf.me) ? tf.ne : 0.f, (tf.ms && tf.mw) ? tf.sw : 0.f,
+                                         (tf.ms && tf.me) ? tf.se : 0.f);
+        *(float4*)(sl + 6) = make_float4((ti.mn && ti.mw) ? ti.nw : 0.f, (ti.mn && ti.me) ? ti.ne : 0.f, (ti.ms && ti.mw) ? ti.sw : 0.f,
+                                         (ti.ms && ti.me) ? ti.se : 0.f);
+        *(float4*)(sl + 10) = make_float4(df[0] / nd, df[1] / nd, df[2] / nd, tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2]);
+        sl[14] = vact ? vis_in[(size_t)vl * N + nn] : 0.f;
+        sl[15] = vact ? dd_in[(size_t)vl * N + nn] : 0.f;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // weight = vis / (sum_v vis + 1e-8): sequential sum over views like the reference's reduction
+  float wg[VT];
+  {
+    float vsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) vsum += v < V ? slot0[v * MS8_SLOT + 14] : 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) wg[v] = v < V ? slot0[v * MS8_SLOT + 14] / (vsum + 1e-8f) : 0.f;
+  }
+  float* g = g393 + (size_t)nn * ldg;
+  struct Tap4 { float4 t[4]; };
+  const size_t fmap = (size_t)vw.h * vw.w;
+
+  // ---------------------------------------------------------------- phase B: feature chunks of 32 channels
+  const int nchunk = (C + 31) >> 5;
+  for (int i = 0; i < nchunk; ++i) {
+    const int ch = 32 * i + 4 * j;
+    const bool chv = ch < C;
+    const unsigned cho = chv ? (unsigned)ch : 0u;
+    auto issue = [&](int v) __attribute__((always_inline)) {
+      Tap4 r;
+      int o[4];
+      unpack_taps(__float_as_uint(slot0[v * MS8_SLOT]), vw.w, o);
+      const float* fb = feat + (size_t)v * fmap * C;   // uniform base + 32-bit lane offset
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.t[k] = *(const float4*)(fb + ((unsigned)o[k] * (unsigned)C + cho));
+      return r;
+    };
+    float xv[VT][4];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) xv[v][0] = xv[v][1] = xv[v][2] = xv[v][3] = 0.f;
+    Tap4 cur = issue(0), nxt = cur;
+    if (1 < VT && 1 < V) nxt = issue(1);
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        Tap4 nx2 = nxt;
+        if (v + 2 < VT && v + 2 < V) nx2 = issue(v + 2);
+        const float4 w = *(const float4*)(slot0 + v * MS8_SLOT + 2);
+        xv[v][0] = fmaf(cur.t[3].x, w.w, fmaf(cur.t[2].x, w.z, fmaf(cur.t[1].x, w.y, cur.t[0].x * w.x)));
+        xv[v][1] = fmaf(cur.t[3].y, w.w, fmaf(cur.t[2].y, w.z, fmaf(cur.t[1].y, w.y, cur.t[0].y * w.x)));
+        xv[v][2] = fmaf(cur.t[3].z, w.w, fmaf(cur.t[2].z, w.z, fmaf(cur.t[1].z, w.y, cur.t[0].z * w.x)));
+        xv[v][3] = fmaf(cur.t[3].w, w.w, fmaf(cur.t[2].w, w.z, fmaf(cur.t[1].w, w.y, cur.t[0].w * w.x)));
+        cur = nxt;
+        nxt = nx2;
+      }
+    }
+    // visibility-weighted mean / variance over views (ibrnet.py:8-12)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float mean = 0.f;
+#pragma unroll
+      for (int v = 0; v < VT; ++v) mean = fmaf(xv[v][c], wg[v], mean);
+      float var = 0.f;
+#pragma unroll
+      for (int v = 0; v < VT; ++v) { const float d = xv[v][c] - mean; var = fmaf(wg[v] * d, d, var); }
+      if (live && chv) { g[3 + ch + c] = mean; g[F + 3 + ch + c] = var; }
+    }
+  }
+
+  // ---------------------------------------------------------------- image taps (lanes j < 3: one colour plane each)
+  {
+    const unsigned plane = (unsigned)(j < 3 ? j : 0) * (unsigned)(vw.H * vw.Wimg);
+    float xi[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      xi[v] = 0.f;
+      if (v < V) {
+        int o[4];
+        unpack_taps(__float_as_uint(slot0[v * MS8_SLOT + 1]), vw.Wimg, o);
+        const float* ib = images + (size_t)v * 3 * vw.H * vw.Wimg;
+        const float4 w = *(const float4*)(slot0 + v * MS8_SLOT + 6);
+        const float a = ib[plane + (unsigned)o[0]], b = ib[plane + (unsigned)o[1]], c = ib[plane + (unsigned)o[2]], d = ib[plane + (unsigned)o[3]];
+        xi[v] = fmaf(d, w.w, fmaf(c, w.z, fmaf(b, w.y, a * w.x)));
+        if (j < 3) slot0[v * MS8_SLOT + 17 + j] = xi[v];
+      }
+    }
+    float mean = 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) mean = fmaf(xi[v], wg[v], mean);
+    float var = 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) { const float d = xi[v] - mean; var = fmaf(wg[v] * d, d, var); }
+    if (live && j < 3) { g[j] = mean; g[F + j] = var; }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---------------------------------------------------------------- colour-blend layer 1, per-(sample, view) part
+  if (bl1) {
+    float bw[4][8], bb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 lo = *(const float4*)(blw + (4 * j + c) * 8), hi = *(const float4*)(blw + (4 * j + c) * 8 + 4);
+      bw[c][0] = lo.x; bw[c][1] = lo.y; bw[c][2] = lo.z; bw[c][3] = lo.w; bw[c][4] = hi.x; bw[c][5] = hi.y; bw[c][6] = hi.z; bw[c][7] = hi.w;
+      bb[c] = blw[256 + 4 * j + c];
+    }
+    auto issue = [&](int v) __attribute__((always_inline)) {
+      Tap4 r;
+      int o[4];
+      unpack_taps(__float_as_uint(slot0[v * MS8_SLOT]), vw.w, o);
+      const float* pb = pfeat + (size_t)v * fmap * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r.t[k] = *(const float4*)(pb + ((unsigned)o[k] * 32u + 4u * (unsigned)j));
+      return r;
+    };
+    Tap4 cur = issue(0);
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        Tap4 nxt = cur;
+        if (v + 1 < VT && v + 1 < V) nxt = issue(v + 1);
+        const float* sl = slot0 + v * MS8_SLOT;
+        const float4 w = *(const float4*)(sl + 2), ang = *(const float4*)(sl + 10);
+        const float s_vis = sl[14], r = sl[17], gg = sl[18], b = sl[19];
+        const float pv[4] = {fmaf(cur.t[3].x, w.w, fmaf(cur.t[2].x, w.z, fmaf(cur.t[1].x, w.y, cur.t[0].x * w.x))),
+                             fmaf(cur.t[3].y, w.w, fmaf(cur.t[2].y, w.z, fmaf(cur.t[1].y, w.y, cur.t[0].y * w.x))),
+                             fmaf(cur.t[3].z, w.w, fmaf(cur.t[2].z, w.z, fmaf(cur.t[1].z, w.y, cur.t[0].z * w.x))),
+                             fmaf(cur.t[3].w, w.w, fmaf(cur.t[2].w, w.z, fmaf(cur.t[1].w, w.y, cur.t[0].w * w.x)))};
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float a = pv[c] + bb[c];
+          a = fmaf(bw[c][0], r, a); a = fmaf(bw[c][1], gg, a); a = fmaf(bw[c][2], b, a);
+          a = fmaf(bw[c][3], s_vis, a);
+          a = fmaf(bw[c][4], ang.x, a); a = fmaf(bw[c][5], ang.y, a); a = fmaf(bw[c][6], ang.z, a); a = fmaf(bw[c][7], ang.w, a);
+          o[c] = a;
+        }
+        if (live) {
+          *(float4*)(bl1 + ((size_t)n * V + v) * 32 + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
+          if (j == 0) *(float4*)(rgbv + ((size_t)n * V + v) * 4) = make_float4(r, gg, b, s_vis);
+        }
+        cur = nxt;
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- depth-difference statistics, padding, valid flag
+  if (live && j == 0) {
+    float mean = 0.f, wsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) { if (v < V) { mean += slot0[v * MS8_SLOT + 15] * wg[v]; wsum += wg[v]; } }
+    float var = 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) { if (v < V) { const float d = slot0[v * MS8_SLOT + 15] - mean; var += wg[v] * (d * d); } }
     g[2 * F] = mean;
     g[2 * F + 1] = var;
     g[2 * F + 2] = wsum / (float)V;
@@ -520,8 +760,17 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
                        int* valid_s, const float* pfeat, const float* blw, float* bl1, float* rgbv, hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
-  dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
   const bool v4 = (C % 4 == 0) && ((((size_t)feat) & 15) == 0);   // 16-B channel groups
+  if (v4 && !rgb_feat && !vis_ang && !getenv("NERFLOC_MVSTATS_WAVE")) {   // everything but the stage API: eight samples per wave
+    dim3 grid8(nl_xcd_grid(nl_cdiv(N, 32)));
+#define NL_MS8(VT) hipLaunchKernelGGL((mv_stats8_kernel<VT>), grid8, dim3(256), sizeof(float) * 4 * 8 * VT * MS8_SLOT, st, vw, viewsdev, images, feat, C, \
+                                      xyz, (int)N, vis_in, dd_in, g393, ldg, valid_s, pfeat, blw, bl1, rgbv)
+    if (vw.V <= 4) NL_MS8(4); else if (vw.V <= 8) NL_MS8(8); else if (vw.V <= 10) NL_MS8(10); else NL_MS8(16);
+#undef NL_MS8
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+  }
+  dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
   const bool ex = vw.V == 4 || vw.V == 8 || vw.V == 10 || vw.V == 16;
   if (vw.V <= 4)
     { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<4, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<4, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<4, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
