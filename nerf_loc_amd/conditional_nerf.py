@@ -218,7 +218,7 @@ class ConditionalNeRF(nn.Module):
     def estimate_neural_points_confidence(self, points, data, level_feat):
         """model.py:137-142: confidence_mlp(multiview aggregate at the support points) — aggregate on HIP, MLP on torch."""
         r = self._renderers["fine"]
-        mv, _, _, _ = r.mv_aggregate(points, data["pose"][:3, 3] if "pose" in data else torch.zeros(3))
+        mv, _, _, _ = r.mv_aggregate(points, data["pose"][:3, 3] if "pose" in data else torch.zeros(3), want_raw=False)
         return self.confidence_mlp(mv)
 
     @torch.no_grad()

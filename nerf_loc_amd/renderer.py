@@ -189,15 +189,22 @@ class HipRenderer:
         L.check(self.lib.nl_sample_points(o.data_ptr(), d.data_ptr(), R, self.S, self.near, self.far, _ptr(z), zo.data_ptr(), xyz.data_ptr(), self._stream()), "nl_sample_points")
         return zo, xyz
 
-    def mv_aggregate(self, xyz, query_center):
+    def mv_aggregate(self, xyz, query_center, want_raw: bool = True):
+        """nl_mv_aggregate.  want_raw=False skips the raw per-view tensors (rgb_feat, vis_ang come back as None) — the form the
+        fused render path uses, which selects the eight-samples-per-wave gather kernel."""
         self._ready()
         x = _dev_f32(xyz, self.device)
         N, V = x.shape[0], self.V
         qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
         mv = torch.empty(N, self.W, device=self.device)
+        valid = torch.empty(N, dtype=torch.int32, device=self.device)
+        if not want_raw:
+            ws = self._workspace(self.lib.nl_mv_aggregate_workspace_bytes(ct.byref(self.cfg), V, N))
+            L.check(self.lib.nl_mv_aggregate(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), N, mv.data_ptr(),
+                                             None, None, valid.data_ptr(), None, None, ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate")
+            return mv, None, None, valid
         rgb_feat = torch.empty(N * V, 196, device=self.device)
         vis_ang = torch.empty(N * V, 8, device=self.device)
-        valid = torch.empty(N, dtype=torch.int32, device=self.device)
         ws = self._workspace(self.lib.nl_mv_aggregate_workspace_bytes(ct.byref(self.cfg), V, N))
         L.check(self.lib.nl_mv_aggregate(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), N, mv.data_ptr(),
                                          rgb_feat.data_ptr(), vis_ang.data_ptr(), valid.data_ptr(), None, None, ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate")

@@ -333,6 +333,23 @@ def test_image_size_variants_match_oracle(H, Wimg, V):
             assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (H, Wimg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
 
 
+@pytest.mark.parametrize("N", [1, 7, 37, 1003])
+def test_multiview_gather_kernels_agree_on_ragged_point_sets(N):
+    """The render path's gather kernel (eight samples per wave) against the stage-API kernel (one sample per wave, pinned on the
+    goldens) on point sets whose size is not a multiple of 8 and whose points are unrelated to each other."""
+    name = "w128s64"
+    case = build_case(name)
+    r = _renderer(case, "fp32")
+    rng = np.random.default_rng(N)
+    sp = case["frame"]["support_fine"]["xyz"]
+    pts = (sp[rng.integers(0, len(sp), N)] + 0.05 * rng.standard_normal((N, 3))).astype(np.float32)
+    qc = case["frame"]["pose"][:3, 3]
+    mv_a, _, _, valid_a = r.mv_aggregate(pts, qc, want_raw=True)
+    mv_b, _, _, valid_b = r.mv_aggregate(pts, qc, want_raw=False)
+    assert torch.equal(valid_a, valid_b)
+    assert rel_err(mv_b.cpu().numpy(), mv_a.cpu().numpy()) < 1e-5
+
+
 def test_repacking_weights_in_place_refreshes_per_frame_tables():
     """The per-frame tables (T = sp_feature . W1, blend-projected maps) are derived from the weights: loading other weights into the
     SAME packed buffer while a frame is set must rebuild them."""
