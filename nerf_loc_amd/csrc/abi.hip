@@ -550,13 +550,17 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   }
   {  // conv2: 64 -> 128 over S/2
     SegSpec s[1] = {{u.c1, 64, 64, 0, 1, 3}};
-    NL_TRY(run_gemm(x, G_CONV2, s, 1, R * (S / 2), u.r2, 128, NL_ACT_NONE, S / 2, S / 2, S / 2));
-    NL_TRY(nl_launch_ln_slab_elu(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, nullptr, u.c2, x.st));
+    const RowEpi ep{nullptr, 0, g(U_CONV2), b(U_CONV2), nullptr, eps, u.c2, NL_EPI_LNSLAB, 1};   // two rays per workgroup at S = 128
+    bool fused = false;
+    NL_TRY(run_gemm(x, G_CONV2, s, 1, R * (S / 2), u.r2, 128, NL_ACT_NONE, S / 2, S / 2, S / 2, 1, 0, &ep, &fused));
+    if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, nullptr, u.c2, x.st));
   }
   {  // conv3: 128 -> 128 over S/4
     SegSpec s[1] = {{u.c2, 128, 128, 0, 1, 3}};
-    NL_TRY(run_gemm(x, G_CONV3, s, 1, R * (S / 4), u.r3, 128, NL_ACT_NONE, S / 4, S / 4, S / 4));
-    NL_TRY(nl_launch_ln_slab_elu(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, nullptr, u.c3, x.st));
+    const RowEpi ep{nullptr, 0, g(U_CONV3), b(U_CONV3), nullptr, eps, u.c3, NL_EPI_LNSLAB, 1};   // one ray per wave at S = 128
+    bool fused = false;
+    NL_TRY(run_gemm(x, G_CONV3, s, 1, R * (S / 4), u.r3, 128, NL_ACT_NONE, S / 4, S / 4, S / 4, 1, 0, &ep, &fused));
+    if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, nullptr, u.c3, x.st));
   }
   {  // trans_conv3: S/8 -> S/4
     const int Li = S / 8, Lo = S / 4;

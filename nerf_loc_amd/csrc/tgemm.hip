@@ -180,9 +180,12 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 
   // epilogue: C/D layout col = lane&31 (= this lane's output row), reg r = 4*gq + e <-> n = 32*rt + 8*gq + 4*hh + e
   if constexpr (EPI == NL_EPI_LNSLAB) {
-    // The workgroup's 32*NW rows are exactly one ray (launch precondition: So == 32*NW, M % So == 0): LayerNorm over the
-    // ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional MaxPool(2) along the ray.
+    // The workgroup's 32*NW rows are one, two or four whole rays (launch precondition: So in {128, 64, 32}, M % So == 0; `wpr`
+    // waves per ray): LayerNorm over each ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional
+    // MaxPool(2) along the ray.  A trailing workgroup may hold rays past M: their statistics are computed on zero rows and
+    // nothing of them is stored.
     float* red = sbias + NRT * 32;   // [2][NW] partial sums
+    const int wpr = a.So >> 5, gb = (wave / wpr) * wpr;
     float s1 = 0.f;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
@@ -200,8 +203,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) tot += red[w];
-    const float cnt = (float)(32 * NW) * (float)a.N;
+    for (int w = 0; w < NW; ++w) tot += w < wpr ? red[gb + (w < wpr ? w : 0)] : 0.f;
+    const float cnt = (float)a.So * (float)a.N;
     const float mean = tot / cnt;
     float s2 = 0.f;
 #pragma unroll
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     __syncthreads();
     float tot2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) tot2 += red[NW + w];
+    for (int w = 0; w < NW; ++w) tot2 += w < wpr ? red[NW + gb + (w < wpr ? w : 0)] : 0.f;
     const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
     const float* grow = a.ep_gamma + (size_t)t * a.N;
     const float* brow = a.ep_beta + (size_t)t * a.N;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
             v.x = fmaxf(v.x, nl_dpp<0xB1>(v.x, v.x)); v.y = fmaxf(v.y, nl_dpp<0xB1>(v.y, v.y));   // quad_perm [1,0,3,2]: lane ^ 1
             v.z = fmaxf(v.z, nl_dpp<0xB1>(v.z, v.z)); v.w = fmaxf(v.w, nl_dpp<0xB1>(v.w, v.w));
           }
-          if (!pool || !(j & 1)) *(float4*)(orow_p + n) = v;
+          if (mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;
           if (a.ep_sig_w) {
             const float4 w4 = *(const float4*)(a.ep_sig_w + n);
             sg = fmaf(v.x, w4.x, sg); sg = fmaf(v.y, w4.y, sg); sg = fmaf(v.z, w4.z, sg); sg = fmaf(v.w, w4.w, sg);
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       }
     if (a.ep_sig_w) {   // the density head rides along: the other half of the row is in lane ^ 32
       sg += __shfl_xor(sg, 32, 64);
-      if (hh == 0) a.ep_sig_out[m] = nl_softplus(sg + a.ep_sig_b[0]);
+      if (hh == 0 && mok) a.ep_sig_out[m] = nl_softplus(sg + a.ep_sig_b[0]);
     }
     return;
   }
@@ -326,7 +329,7 @@ size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 *
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
-  if (a.epi == NL_EPI_LNSLAB && (a.So != 128 || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
+  if (a.epi == NL_EPI_LNSLAB && ((a.So != 128 && a.So != 64 && a.So != 32) || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
     if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k || g.ntap < 1) return false;
