@@ -99,6 +99,15 @@ __global__ __launch_bounds__(256) void mv_vis_mfma_kernel(const NlViews vw, cons
     const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
     float px, py, depth;
     const bool valid = project_neuray(vw.P2[v], X, Y, Z, vw.Wimg, vw.H, px, py, depth);
+    if (__ballot(valid && live) == 0ull) {
+      // none of the tile's 32 samples projects into this view: visibility is exactly 0 for all of them and the depth difference
+      // is only ever used multiplied by that weight (mv_stats) — skip the decoders (wave-uniform branch)
+      if (live && hh == 0) {
+        vis_out[(size_t)v * N + n] = 0.f;
+        dd_out[(size_t)v * N + n] = 0.f;
+      }
+      continue;
+    }
     // bilinear (border, align_corners=False) tap of this lane's 16 channels: {8hh..8hh+7} and {16+8hh..16+8hh+7}
     float x0[8], x1[8];
     {
