@@ -139,62 +139,57 @@ __global__ __launch_bounds__(256) void mv_vis_mfma_kernel(const NlViews vw, cons
     mv_bf16x8 xh[2], xl[2];
     mv_split8<X3>(x0, xh[0], xl[0]);
     mv_split8<X3>(x1, xh[1], xl[1]);
-    // ---- layer 1: 32 -> 4 x 32
-    mv_f32x16 acc[4];
+    // ---- the four decoders one after the other (32 -> 32 -> 32 -> 1 | 2): only one decoder's 2 x 16 accumulators are live at a
+    // time, which is what lets four waves share a SIMD (all four at once: 128 accumulators, two waves)
+    float o[4][2];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < 4; ++d) {
+      // layer 1
+      mv_f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *(const float4*)(b1 + 32 * d + 8 * g + 4 * hh);
-        acc[d][4 * g] = b.x; acc[d][4 * g + 1] = b.y; acc[d][4 * g + 2] = b.z; acc[d][4 * g + 3] = b.w;
+        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
       }
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int q = 0; q < 2; ++q) {
         const mv_bf16x8 ah = __builtin_bit_cast(mv_bf16x8, sw[MVD_W1 + (q * 4 + d) * 64 + lane]);
         if (X3) {
           const mv_bf16x8 al = __builtin_bit_cast(mv_bf16x8, sw[MVD_W1 + 512 + (q * 4 + d) * 64 + lane]);
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[q], acc[d], 0, 0, 0);
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[q], acc[d], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[q], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[q], acc, 0, 0, 0);
         }
-        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[q], acc[d], 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[q], acc, 0, 0, 0);
       }
-    // ---- ELU -> layer 2 (per decoder 32 -> 32), K order = accumulator register order
-    mv_f32x16 acc2[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
+      // ELU -> layer 2 (32 -> 32), K order = accumulator register order
       mv_bf16x8 gh[2], gl[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         float vv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) vv[t] = nl_elu_fast(acc[d][8 * s + t]);
+        for (int t = 0; t < 8; ++t) vv[t] = nl_elu_fast(acc[8 * s + t]);
         mv_split8<X3>(vv, gh[s], gl[s]);
       }
+      mv_f32x16 acc2;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *(const float4*)(b2 + 32 * d + 8 * g + 4 * hh);
-        acc2[d][4 * g] = b.x; acc2[d][4 * g + 1] = b.y; acc2[d][4 * g + 2] = b.z; acc2[d][4 * g + 3] = b.w;
+        acc2[4 * g] = b.x; acc2[4 * g + 1] = b.y; acc2[4 * g + 2] = b.z; acc2[4 * g + 3] = b.w;
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const mv_bf16x8 ah = __builtin_bit_cast(mv_bf16x8, sw[MVD_W2 + (d * 2 + s) * 64 + lane]);
         if (X3) {
           const mv_bf16x8 al = __builtin_bit_cast(mv_bf16x8, sw[MVD_W2 + 512 + (d * 2 + s) * 64 + lane]);
-          acc2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s], acc2[d], 0, 0, 0);
-          acc2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s], acc2[d], 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s], acc2, 0, 0, 0);
         }
-        acc2[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s], acc2[d], 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s], acc2, 0, 0, 0);
       }
-    }
-    // ---- ELU -> 6 output units (VALU dot over this lane's 16 hidden values + the other half's via shuffle)
-    float o[4][2];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
+      // ELU -> output units (VALU dot over this lane's 16 hidden values + the other half's via shuffle)
       float h2[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) h2[r] = nl_elu_fast(acc2[d][r]);
+      for (int r = 0; r < 16; ++r) h2[r] = nl_elu_fast(acc2[r]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         float p = 0.f;
