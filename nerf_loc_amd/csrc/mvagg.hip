@@ -767,7 +767,8 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   const bool v4 = (C % 4 == 0) && ((((size_t)feat) & 15) == 0);   // 16-B channel groups
-  if (v4 && !rgb_feat && !vis_ang && !getenv("NERFLOC_MVSTATS_WAVE")) {   // everything but the stage API: eight samples per wave
+  static const bool force_wave = getenv("NERFLOC_MVSTATS_WAVE") != nullptr;   // debugging / A-B switch: one sample per wave everywhere
+  if (v4 && !rgb_feat && !vis_ang && !force_wave) {   // everything but the stage API: eight samples per wave
     dim3 grid8(nl_xcd_grid(nl_cdiv(N, 32)));
 #define NL_MS8(VT) hipLaunchKernelGGL((mv_stats8_kernel<VT>), grid8, dim3(256), sizeof(float) * 4 * 8 * VT * MS8_SLOT, st, vw, viewsdev, images, feat, C, \
                                       xyz, (int)N, vis_in, dd_in, g393, ldg, valid_s, pfeat, blw, bl1, rgbv)
