@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"])
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="run the N>1 collective path on one GPU (single-rank RCCL group): a functional check")
     ap.add_argument("--also", default="bf16", help="comma list of extra precisions timed after the headline (''=none)")
     args = ap.parse_args()
 
@@ -65,13 +66,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    gather = world > 1 or args.force_gather   # --force-gather: exercise the collective path on one GPU (single-rank RCCL group)
+    if gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from nerf_loc_amd.renderer import HipRenderer
-    from nerf_loc_amd.sharding import gather_ray_outputs
+    from nerf_loc_amd.sharding import gather_ray_outputs_async
 
     cfg = CONFIGS[args.config]
     R = args.rays or cfg.R
@@ -91,15 +97,31 @@ def main():
     z = z.expand(R, S).contiguous().to(dev)
     qc = frame["pose"][:3, 3]
 
+    # N > 1: every step ends with ONE all-gather of the packed per-ray outputs.  It is started asynchronously (RCCL's stream) and
+    # collected one step later, so the xGMI transfer of batch i overlaps the kernels of batch i + 1; drain() collects the last one
+    # inside the timed region, so K timed steps = K renders + K completed gathers.
+    pending = [None]
+
     def step():
         out = rnd.render_rays(o, d, qc, z_vals=z, white_bkgd=cfg.white_bkgd)
-        if world > 1:
-            out = gather_ray_outputs(out, dist)
+        if gather:
+            prev = pending[0]
+            pending[0] = gather_ray_outputs_async(out, dist)
+            if prev is not None:
+                out = prev.result()
         return out
+
+    def drain():
+        if pending[0] is not None:
+            res = pending[0].result()
+            pending[0] = None
+            return res
+        return None
 
     def timed(steps, warmup):
         for _ in range(warmup):
             step()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -108,6 +130,7 @@ def main():
         ev0.record()
         for _ in range(steps):
             step()
+        drain()
         ev1.record()
         torch.cuda.synchronize()
         if world > 1:
@@ -131,6 +154,7 @@ def main():
     lib.nl_profile_begin()
     for _ in range(args.steps):
         step()
+    drain()
     fused_ms, launches = ct.c_float(0), ct.c_int(0)
     _lib.check(lib.nl_profile_end(ct.byref(fused_ms), ct.byref(launches)), "nl_profile_end")
     value = world * R * args.steps / wall
@@ -174,10 +198,19 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights)
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which a pipe flushes only at exit: every rank pushes it out
+    # now, then rank 0 prints the JSON line as the last thing on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if gather:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 def hbm_traffic(config: str, precision: str):

@@ -44,9 +44,27 @@ def unpack_outputs(buf: torch.Tensor, layout: list) -> Dict[str, torch.Tensor]:
     return out
 
 
-def gather_ray_outputs(out: Dict[str, torch.Tensor], dist, counts=None) -> Dict[str, torch.Tensor]:
-    """All-gather per-ray outputs of every rank, in rank order.  `counts` = rays per rank when uneven:
-    shards are zero-padded to the largest one so a single fixed-size collective serves both backends."""
+class PendingGather:
+    """An all-gather in flight (RCCL runs it on its own stream): `result()` makes the current stream wait for it and unpacks."""
+
+    def __init__(self, work, full, buf, layout, counts, even):
+        self.work, self.full, self.buf, self.layout, self.counts, self.even = work, full, buf, layout, counts, even
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        full = self.full
+        if not self.even:
+            rows = self.buf.shape[0]
+            full = torch.cat([full[r * rows: r * rows + c] for r, c in enumerate(self.counts)], 0)
+        return unpack_outputs(full, self.layout)
+
+
+def gather_ray_outputs_async(out: Dict[str, torch.Tensor], dist, counts=None) -> PendingGather:
+    """Start the all-gather of the per-ray outputs of every rank (rank order) and return at once, so that the caller can launch the
+    next batch's kernels while the collective runs — xGMI transfers and compute overlap on separate streams.  `counts` = rays per
+    rank when uneven: shards are zero-padded to the largest one so a single fixed-size collective serves both backends."""
     world = dist.get_world_size()
     buf, layout = pack_outputs(out)
     even = counts is None or len(set(counts)) == 1
@@ -56,9 +74,12 @@ def gather_ray_outputs(out: Dict[str, torch.Tensor], dist, counts=None) -> Dict[
             buf = torch.cat([buf, buf.new_zeros(pad, buf.shape[1])], 0)
     full = torch.empty(world * buf.shape[0], buf.shape[1], dtype=buf.dtype, device=buf.device)
     if buf.is_cuda:
-        dist.all_gather_into_tensor(full, buf)
+        work = dist.all_gather_into_tensor(full, buf, async_op=True)
     else:
-        dist.all_gather(list(full.chunk(world, 0)), buf)
-    if not even:
-        full = torch.cat([full[r * buf.shape[0]: r * buf.shape[0] + c] for r, c in enumerate(counts)], 0)
-    return unpack_outputs(full, layout)
+        work = dist.all_gather(list(full.chunk(world, 0)), buf, async_op=True)
+    return PendingGather(work, full, buf, layout, counts, even)
+
+
+def gather_ray_outputs(out: Dict[str, torch.Tensor], dist, counts=None) -> Dict[str, torch.Tensor]:
+    """All-gather per-ray outputs of every rank, in rank order (blocking form of gather_ray_outputs_async)."""
+    return gather_ray_outputs_async(out, dist, counts).result()

@@ -5,7 +5,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nerf_loc_amd.sharding import gather_ray_outputs, pack_outputs, shard_range, unpack_outputs
+from nerf_loc_amd.sharding import gather_ray_outputs, gather_ray_outputs_async, pack_outputs, shard_range, unpack_outputs
 
 
 def test_shard_range_partitions_exactly():
@@ -42,6 +42,13 @@ def _worker(rank, world, port, uneven, q):
     counts = [shard_range(R, r, world)[1] - shard_range(R, r, world)[0] for r in range(world)]
     got = gather_ray_outputs(mine, dist, counts if uneven else None)
     ok = all(torch.equal(got[k], full[k]) for k in full)
+    # pipelined form used by bench.py: two gathers in flight order, collected one step late
+    first = gather_ray_outputs_async(mine, dist, counts if uneven else None)
+    mine2 = {k: (~v if v.dtype == torch.bool else v * 2) for k, v in mine.items()}
+    second = gather_ray_outputs_async(mine2, dist, counts if uneven else None)
+    got1, got2 = first.result(), second.result()
+    ok = ok and all(torch.equal(got1[k], full[k]) for k in full)
+    ok = ok and all(torch.equal(got2[k], (~full[k] if full[k].dtype == torch.bool else full[k] * 2)) for k in full)
     q.put((rank, ok))
     dist.destroy_process_group()
 
