@@ -140,6 +140,12 @@ int nl_backproject_support(const float* imgs, const float* feats, const float* d
                            int V, int H, int W, int fh, int fw, int C, int stride, int64_t capacity, float* feature, float* xyz,
                            float* xyz_ref, float* direction, int64_t* m_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Row a1 — get_rays (conditional_nerf/utils.py:56-70) and points_2d_to_rays (conditional_nerf/model.py:687-700): pixel ->
+ * ray origin (camera centre) and unit direction in the world frame.  K (3,3) and c2w (4,4) are DEVICE pointers.  uv == NULL: the
+ * whole H x W grid in row-major pixel order (R must be H*W); otherwise uv (R,2) = (x, y) pixel positions, truncated towards zero
+ * like the reference's .long() look-up into the ray grid. */
+int nl_get_rays(const float* K, const float* c2w, const float* uv, int H, int W, int64_t R, float* rays_o, float* rays_d, void* stream);
+
 /* ---- per-frame state --------------------------------------------------------------------------- */
 /* A frame keeps the DEVICE pointers of the descriptor (images, feature maps, support points: they must stay alive and unchanged
  * while the frame is used — call nl_frame_create again when the data changes) plus tables derived from them in frame_mem

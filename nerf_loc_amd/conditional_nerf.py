@@ -8,6 +8,7 @@ names/shapes, so `pl/model.py:33-41`-style checkpoint loading
 What runs where
   * everything per ray / per sample (rows a2-a20 of SURVEY.md §8) runs in libnerfloc_render.so (HIP, gfx950) through
     `HipRenderer`; there is NO PyTorch fallback for it — without the library or a GPU these methods raise.
+  * ray generation (row a1: `get_rays`, `points_2d_to_rays`) is `nl_get_rays`.
   * per-frame setup (row a21): back-projection of the support views and DepthFusionNet's cross-view consistency input run in
     the library too (`frame_setup.py`: `nl_backproject_support`, `nl_cross_view_features`); the per-frame CNN itself
     (`DepthFusionNet.encode`, MIOpen convolutions), `confidence_mlp`, `keypoint_head` and the tiny descriptor projections stay on
@@ -27,6 +28,7 @@ import torch.nn.functional as F
 
 from .depth_fusion import DepthFusionNet
 from .frame_setup import backproject_support
+from .frame_setup import get_rays as _hip_get_rays
 from .renderer import HipRenderer
 
 
@@ -109,13 +111,8 @@ class _RayUnetParams(nn.Module):
 
 
 def get_rays(H, W, K, c2w):
-    """conditional_nerf/utils.py:56-70 (host-side torch, 'a1')."""
-    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
-    i, j = i.t().to(K.device), j.t().to(K.device)
-    dirs = torch.stack([(i - K[0][2]) / K[0][0], (j - K[1][2]) / K[1][1], torch.ones_like(i)], -1)
-    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
-    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
-    return c2w[:3, -1].expand(rays_d.shape), rays_d
+    """conditional_nerf/utils.py:56-70 on the HIP library (`nl_get_rays`, row a1) -> (rays_o, rays_d), each (H,W,3)."""
+    return _hip_get_rays(H, W, K, c2w)
 
 
 class ConditionalNeRF(nn.Module):
@@ -364,9 +361,8 @@ class ConditionalNeRF(nn.Module):
 
     def points_2d_to_rays(self, pts2d, H, W, K, pose):
         """model.py:687-700."""
-        x, y = pts2d[:, 0].long(), pts2d[:, 1].long()
-        o, d = get_rays(H, W, K, pose)
-        return {"pose": pose, "K": K, "H": H, "W": W, "pixel_coordinates": pts2d, "rays_o": o[y, x], "rays_d": d[y, x]}
+        o, d = _hip_get_rays(H, W, K, pose, uv=pts2d)   # only the requested pixels (the reference builds the whole grid and indexes it)
+        return {"pose": pose, "K": K, "H": H, "W": W, "pixel_coordinates": pts2d, "rays_o": o, "rays_d": d}
 
     def sample_rays(self, n_rays, H, W, K, pose, mask=None):
         """model.py:702-713."""

@@ -286,6 +286,25 @@ __global__ __launch_bounds__(256) void bp_fill_kernel(const float* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ ray generation (row a1)
+// get_rays (conditional_nerf/utils.py:56-70) for the whole pixel grid (uv == null: ray r = pixel (r % W, r / W)) or
+// points_2d_to_rays (model.py:687-700) for a list of pixel positions (truncated towards zero like .long()).
+__global__ void rays_kernel(const float* __restrict__ K, const float* __restrict__ c2w, const float* __restrict__ uv, int W, int64_t R,
+                            float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float u, v;
+  if (uv) { u = (float)(long long)uv[2 * r]; v = (float)(long long)uv[2 * r + 1]; }
+  else { u = (float)(r % W); v = (float)(r / W); }
+  const float d0 = (u - K[2]) / K[0], d1 = (v - K[5]) / K[4];
+  float rd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rd[i] = (d0 * c2w[4 * i] + d1 * c2w[4 * i + 1]) + c2w[4 * i + 2];
+  const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { rays_d[3 * r + i] = rd[i] / nrm; rays_o[3 * r + i] = c2w[4 * i + 3]; }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C-ABI
@@ -337,5 +356,12 @@ int nl_backproject_support(const float* imgs, const float* feats, const float* d
   if (total == 0) return NL_OK;
   bp_fill_kernel<<<rows, 256, 0, st>>>(imgs, feats, depths, vm, rowoff, H, W, Hs, Ws, fh, fw, C, sy, sx, (int)capacity, feature, xyz, xyz_ref,
                                        direction);
+  return hipGetLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+
+int nl_get_rays(const float* K, const float* c2w, const float* uv, int H, int W, int64_t R, float* rays_o, float* rays_d, void* stream) {
+  if (R == 0) return NL_OK;
+  if (!K || !c2w || !rays_o || !rays_d || R < 0 || H < 1 || W < 1 || (!uv && R != (int64_t)H * W)) return NL_ERR_BAD_ARG;
+  rays_kernel<<<(unsigned)((R + 255) / 256), 256, 0, (hipStream_t)stream>>>(K, c2w, uv, W, R, rays_o, rays_d);
   return hipGetLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }

@@ -60,3 +60,17 @@ def backproject_support(imgs: torch.Tensor, feats: torch.Tensor, depths: torch.T
     ws.record_stream(torch.cuda.current_stream(dev))
     M = int(m.value)
     return feature[:M], xyz[:M], ref[:M], direction[:M]
+
+
+def get_rays(H: int, W: int, K: torch.Tensor, c2w: torch.Tensor, uv: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """conditional_nerf/utils.py:56-70 (whole grid -> (H,W,3) tensors) or model.py:687-700 (uv (R,2) pixel positions -> (R,3))."""
+    lib = L.load()
+    K, c2w = _f32(K, "K"), _f32(c2w, "pose")
+    R = H * W if uv is None else uv.shape[0]
+    o = torch.empty(R, 3, dtype=torch.float32, device=K.device)
+    d = torch.empty(R, 3, dtype=torch.float32, device=K.device)
+    uvp = None if uv is None else _f32(uv, "pts2d")
+    st = torch.cuda.current_stream(K.device).cuda_stream
+    L.check(lib.nl_get_rays(K.data_ptr(), c2w.data_ptr(), None if uvp is None else uvp.data_ptr(), int(H), int(W), R, o.data_ptr(), d.data_ptr(), st),
+            "nl_get_rays")
+    return (o.view(H, W, 3), d.view(H, W, 3)) if uv is None else (o, d)

@@ -157,3 +157,29 @@ def test_backproject_edge_cases():
                                       V, H, W, H // s, W // s, C, s, cap, *[b.data_ptr() for b in bufs], ct.byref(m), ws.data_ptr(), ws.numel(), None) == L.NL_ERR_BAD_ARG
     assert lib.nl_cross_view_features(d["imgs"].data_ptr(), d["depths"].data_ptr(), d["Ks"].data_ptr(), d["poses"].data_ptr(), 17, H, W, 1.0, 5.0,
                                       bufs[0].data_ptr(), ws.data_ptr(), ws.numel(), None) == L.NL_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("H,W", [(32, 48), (256, 336), (37, 129)])
+def test_get_rays_matches_oracle(H, W):
+    """Row a1: nl_get_rays against the oracle's get_rays / points_2d_to_rays (fp32: 1e-6; origins are copies)."""
+    from nerf_loc_amd.frame_setup import get_rays
+    from oracle import render_oracle as orc
+    f = _random_frame(2, H, W, 8, 4, 11)
+    K, pose = torch.from_numpy(f["Ks"][1]), torch.from_numpy(f["poses"][1])
+    o_ref, d_ref = orc.get_rays(H, W, K, pose)
+    o, d = get_rays(H, W, K.to(DEV), pose.to(DEV))
+    assert o.shape == (H, W, 3) and d.shape == (H, W, 3)
+    assert torch.equal(o.cpu(), o_ref.expand(H, W, 3).contiguous())
+    assert rel_err(d.cpu().numpy(), d_ref.numpy()) < 1e-6
+    assert float((d.norm(dim=-1) - 1).abs().max()) < 1e-6
+    rng = np.random.default_rng(H)
+    pts = torch.from_numpy(np.stack([rng.uniform(0, W - 1e-3, 257), rng.uniform(0, H - 1e-3, 257)], 1).astype(np.float32))
+    want = orc.points_2d_to_rays(pts, H, W, K, pose)
+    o2, d2 = get_rays(H, W, K.to(DEV), pose.to(DEV), uv=pts.to(DEV))
+    assert torch.equal(o2.cpu(), want["rays_o"].contiguous())
+    assert rel_err(d2.cpu().numpy(), want["rays_d"].numpy()) < 1e-6
+    # fractional positions are truncated, not rounded (model.py:690-691): the same rays as the grid at the truncated pixel
+    x, y = pts[:, 0].long(), pts[:, 1].long()
+    assert torch.equal(d2.cpu(), d.cpu()[y, x])
+    e = get_rays(H, W, K.to(DEV), pose.to(DEV), uv=torch.empty(0, 2, device=DEV))
+    assert e[0].shape == (0, 3)
