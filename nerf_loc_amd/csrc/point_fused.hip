@@ -43,9 +43,12 @@ namespace {
 constexpr int L1_KSTEPS = 6;    // 4 posenc + 2 ray_diff_fc k-steps (K = 96); the 195 feature columns come from the per-frame table T
 constexpr int L1_CHUNKS = 3;
 
+// LDS-DMA of 16 B per lane; the immediate offset OFF is added to BOTH addresses, so four consecutive 1-KB pieces share one
+// scalar base and one M0 value
+template <int OFF>
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)l, 16, OFF, 0);
 }
 
 template <bool X3>
@@ -128,9 +131,18 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
   auto stage = [&](int g) __attribute__((always_inline)) {
     const int ort = ort_of(g);
     const int nkb = PARTS * 2 * ort;
+    // wave w moves the contiguous pieces [w * nkb/4, (w+1) * nkb/4): groups of four share base + M0 through the immediate offset
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      if (jj < nkb / 4) { const int i = wave + 4 * jj; glds16(wptr + (size_t)i * 1024 + lane * 16, &lds[g % NBUF][i * 64]); }
+    for (int q4 = 0; q4 < 2; ++q4) {
+      if (4 * q4 < nkb / 4) {
+        const int i = wave * (nkb / 4) + 4 * q4;
+        const char* gp = wptr + (size_t)i * 1024 + lane * 16;
+        uint4* lp = &lds[g % NBUF][i * 64];
+        glds16<0>(gp, lp);
+        if (4 * q4 + 1 < nkb / 4) glds16<1024>(gp, lp);
+        if (4 * q4 + 2 < nkb / 4) glds16<2048>(gp, lp);
+        if (4 * q4 + 3 < nkb / 4) glds16<3072>(gp, lp);
+      }
     }
     wptr += (size_t)4 * ort * 1024;
   };
