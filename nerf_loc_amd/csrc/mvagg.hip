@@ -581,6 +581,14 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
 #pragma unroll
     for (int v = 0; v < VT; ++v) wg[v] = v < V ? slot0[v * MS8_SLOT + 14] / (vsum + 1e-8f) : 0.f;
   }
+  // Views in which none of the wave's 8 samples is visible (weight exactly 0 for all of them) contribute nothing to any statistic
+  // and their blend logits are masked out (vis == 0): their feature-map taps are not fetched at all (wave-uniform branches).  The
+  // colour taps stay: a sample that no view sees is blended as the plain mean of the tapped colours (softmax of equal logits).
+  unsigned vmask = 0;
+#pragma unroll
+  for (int v = 0; v < VT; ++v)
+    if (v < V && __ballot(slot0[v * MS8_SLOT + 14] != 0.f) != 0ull) vmask |= 1u << v;
+  auto active = [&](int v) { return ((vmask >> v) & 1u) != 0u; };
   float* g = g393 + (size_t)nn * ldg;
   struct Tap4 { float4 t[4]; };
   const size_t fmap = (size_t)vw.h * vw.w;
@@ -593,6 +601,7 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
     const unsigned cho = chv ? (unsigned)ch : 0u;
     auto issue = [&](int v) __attribute__((always_inline)) {
       Tap4 r;
+      if (!active(v)) { r.t[0] = r.t[1] = r.t[2] = r.t[3] = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
       int o[4];
       unpack_taps(__float_as_uint(slot0[v * MS8_SLOT]), vw.w, o);
       const float* fb = feat + (size_t)v * fmap * C;   // uniform base + 32-bit lane offset
@@ -610,11 +619,13 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
       if (v < V) {
         Tap4 nx2 = nxt;
         if (v + 2 < VT && v + 2 < V) nx2 = issue(v + 2);
-        const float4 w = *(const float4*)(slot0 + v * MS8_SLOT + 2);
-        xv[v][0] = fmaf(cur.t[3].x, w.w, fmaf(cur.t[2].x, w.z, fmaf(cur.t[1].x, w.y, cur.t[0].x * w.x)));
-        xv[v][1] = fmaf(cur.t[3].y, w.w, fmaf(cur.t[2].y, w.z, fmaf(cur.t[1].y, w.y, cur.t[0].y * w.x)));
-        xv[v][2] = fmaf(cur.t[3].z, w.w, fmaf(cur.t[2].z, w.z, fmaf(cur.t[1].z, w.y, cur.t[0].z * w.x)));
-        xv[v][3] = fmaf(cur.t[3].w, w.w, fmaf(cur.t[2].w, w.z, fmaf(cur.t[1].w, w.y, cur.t[0].w * w.x)));
+        if (active(v)) {
+          const float4 w = *(const float4*)(slot0 + v * MS8_SLOT + 2);
+          xv[v][0] = fmaf(cur.t[3].x, w.w, fmaf(cur.t[2].x, w.z, fmaf(cur.t[1].x, w.y, cur.t[0].x * w.x)));
+          xv[v][1] = fmaf(cur.t[3].y, w.w, fmaf(cur.t[2].y, w.z, fmaf(cur.t[1].y, w.y, cur.t[0].y * w.x)));
+          xv[v][2] = fmaf(cur.t[3].z, w.w, fmaf(cur.t[2].z, w.z, fmaf(cur.t[1].z, w.y, cur.t[0].z * w.x)));
+          xv[v][3] = fmaf(cur.t[3].w, w.w, fmaf(cur.t[2].w, w.z, fmaf(cur.t[1].w, w.y, cur.t[0].w * w.x)));
+        }
         cur = nxt;
         nxt = nx2;
       }
@@ -639,7 +650,7 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
       xi[v] = 0.f;
-      if (v < V) {
+      if (v < V) {   // also for invisible views: when no view at all sees a sample the blend falls back to the plain mean of the colours
         int o[4];
         unpack_taps(__float_as_uint(slot0[v * MS8_SLOT + 1]), vw.Wimg, o);
         const float* ib = images + (size_t)v * 3 * vw.H * vw.Wimg;
@@ -670,6 +681,7 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
     }
     auto issue = [&](int v) __attribute__((always_inline)) {
       Tap4 r;
+      if (!active(v)) { r.t[0] = r.t[1] = r.t[2] = r.t[3] = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
       int o[4];
       unpack_taps(__float_as_uint(slot0[v * MS8_SLOT]), vw.w, o);
       const float* pb = pfeat + (size_t)v * fmap * 32;
@@ -683,6 +695,14 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
       if (v < V) {
         Tap4 nxt = cur;
         if (v + 1 < VT && v + 1 < V) nxt = issue(v + 1);
+        if (!active(v)) {   // logit masked out downstream (vis == 0 for all 8 samples): finite placeholder, no taps, no arithmetic
+          if (live) {
+            *(float4*)(bl1 + ((size_t)n * V + v) * 32 + 4 * j) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j == 0) *(float4*)(rgbv + ((size_t)n * V + v) * 4) = make_float4(slot0[v * MS8_SLOT + 17], slot0[v * MS8_SLOT + 18], slot0[v * MS8_SLOT + 19], 0.f);
+          }
+          cur = nxt;
+          continue;
+        }
         const float* sl = slot0 + v * MS8_SLOT;
         const float4 w = *(const float4*)(sl + 2), ang = *(const float4*)(sl + 10);
         const float s_vis = sl[14], r = sl[17], gg = sl[18], b = sl[19];
