@@ -350,6 +350,36 @@ def test_multiview_gather_kernels_agree_on_ragged_point_sets(N):
     assert rel_err(mv_b.cpu().numpy(), mv_a.cpu().numpy()) < 1e-5
 
 
+def _random_cfg(seed):
+    rng = np.random.default_rng(1000 + seed)
+    return CASES["tiny_full"][0].replace(
+        name=f"rand{seed}", seed=500 + seed, W=int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256])), S=int(8 * rng.integers(1, 9)),
+        V=int(rng.integers(1, 17)), C=int(rng.choice([8, 20, 36, 64, 100, 132, 192, 33, 77])), R=int(rng.integers(1, 41)),
+        H=int(rng.integers(24, 101)), Wimg=int(rng.integers(24, 101)), white_bkgd=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configs_match_oracle(seed):
+    """Seeded random (W, S, V, C, R, H, Wimg, white_bkgd) combinations — one view, 16 views, tiny feature maps, odd channel counts,
+    single rays — against the oracle; which kernels run (fused / staged point MLP, 8-samples-per-wave / per-sample gather, fused /
+    separate LayerNorm) depends on the draw."""
+    from oracle import render_oracle as orc
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    cfg = _random_cfg(seed)
+    frame = make_frame(cfg)
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+    params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    rays_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in case["rays"].items()}
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(frame), rays_t, cfg.S, white_bkgd=cfg.white_bkgd)
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=_z(cfg, cfg.R), white_bkgd=cfg.white_bkgd)
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy()), cfg
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (cfg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
 def test_repacking_weights_in_place_refreshes_per_frame_tables():
     """The per-frame tables (T = sp_feature . W1, blend-projected maps) are derived from the weights: loading other weights into the
     SAME packed buffer while a frame is set must rebuild them."""
