@@ -163,6 +163,34 @@ def test_hierarchical_branch_matches_reference_golden():
         assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_hierarchical_configs_match_oracle(seed):
+    """a20 at seeded random sizes (base / importance sample counts, 1-16 views, image size): coarse weights -> sample_pdf with given
+    uniforms -> merge / sort -> render, against the oracle's hierarchical render."""
+    from oracle import render_oracle as orc
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    rng = np.random.default_rng(7000 + seed)
+    cfg = CASES["tiny_full"][0].replace(name=f"hrand{seed}", seed=700 + seed, W=int(rng.choice([32, 64, 128])), S=int(8 * rng.integers(1, 5)),
+                                        N_importance=int(8 * rng.integers(1, 5)), V=int(rng.integers(1, 17)), R=int(rng.integers(1, 25)),
+                                        H=int(rng.integers(24, 81)), Wimg=int(rng.integers(24, 81)))
+    frame = make_frame(cfg)
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+    u = rng.random((cfg.R, cfg.N_importance), dtype=np.float32)
+    params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    rays_t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in case["rays"].items()}
+    with torch.no_grad():
+        ref = orc.render_rays(params, orc.to_torch(frame), rays_t, cfg.S, cfg.N_importance, u=torch.from_numpy(u))
+    for precision in ("fp32", "bf16x3"):
+        r = _renderer(case, precision)
+        zb = orc.sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, cfg.S).contiguous()
+        z, depth_coarse, _ = r.hierarchical_depths(case["rays"]["pixel_coordinates"], frame["K"], frame["pose"], zb, u)
+        assert rel_err(depth_coarse.cpu().numpy(), ref["depth_coarse"].numpy()) < 2e-5, cfg
+        out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=z)
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy()), cfg
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 3 * TOL[precision], (cfg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+
+
 # ------------------------------------------------------------------ full-size (BASELINE config 2) properties
 @pytest.fixture(scope="module")
 def c2():
