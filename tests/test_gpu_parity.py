@@ -65,7 +65,8 @@ def test_bf16_throughput_mode_error_is_reported_not_hidden(name):
 
 
 @pytest.mark.parametrize("n,m,K,kind", [(5000, 3000, 8, "cloud"), (4096, 20000, 8, "sheets"), (2000, 5, 8, "few"), (3000, 700, 1, "cloud"),
-                                         (2000, 900, 8, "lattice"), (1500, 1, 8, "one"), (1000, 2000, 8, "far"), (1003, 4000, 8, "cloud"), (37, 500, 1, "cloud")])
+                                         (2000, 900, 8, "lattice"), (1500, 1, 8, "one"), (1000, 2000, 8, "far"), (1003, 4000, 8, "cloud"), (37, 500, 1, "cloud"),
+                                         (4096, 6000, 8, "rays"), (600, 300, 8, "dupes"), (1500, 4000, 8, "aniso"), (1200, 9, 8, "rays")])
 def test_knn_exact_vs_oracle(n, m, K, kind):
     from nerf_loc_amd.renderer import HipRenderer
     from oracle import render_oracle as orc
@@ -79,6 +80,18 @@ def test_knn_exact_vs_oracle(n, m, K, kind):
         q = (np.round(q * 3) / 3).astype(np.float32)
     if kind == "far":
         q[::2] += np.array([40.0, -25.0, 10.0], np.float32)
+    if kind == "rays":      # consecutive queries march along rays: the path that seeds a query's bound from its predecessor's neighbours
+        o = rng.standard_normal((n // 64 + 1, 3)) * 0.3
+        d = rng.standard_normal((n // 64 + 1, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        t = np.linspace(-2.5, 2.5, 64)
+        q = (o[:, None, :] + d[:, None, :] * t[None, :, None]).reshape(-1, 3)[:n].astype(np.float32)
+    if kind == "dupes":     # every point is one of 7 locations: ties everywhere, resolved by index
+        p = p[rng.integers(0, 7, m)]
+        q[: n // 2] = p[rng.integers(0, m, n // 2)]
+    if kind == "aniso":     # a slab: 1e3 units wide, 1e-3 thick
+        p = (p * np.array([300.0, 20.0, 3e-4], np.float32)).astype(np.float32)
+        q = (q * np.array([200.0, 15.0, 5e-4], np.float32)).astype(np.float32)
     case = build_case("tiny_full")
     case["frame"]["support_fine"] = {"xyz": p, "feature": np.zeros((m, 195), np.float32), "confidence": np.ones((m, 1), np.float32),
                                      "direction": np.zeros((m, 4), np.float32)}
