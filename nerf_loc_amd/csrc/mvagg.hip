@@ -798,15 +798,22 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
     return NL_OK;
   }
   dim3 grid(nl_xcd_grid(nl_cdiv(N, 4)));
-  const bool ex = vw.V == 4 || vw.V == 8 || vw.V == 10 || vw.V == 16;
-  if (vw.V <= 4)
-    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<4, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<4, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<4, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
-  else if (vw.V <= 8)
-    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<8, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<8, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<8, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
-  else if (vw.V <= 10)
-    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<10, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<10, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<10, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
-  else
-    { if (v4 && ex) hipLaunchKernelGGL((mv_stats_kernel<16, true, true>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else if (v4) hipLaunchKernelGGL((mv_stats_kernel<16, true, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); else hipLaunchKernelGGL((mv_stats_kernel<16, false, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv); }
+  const bool ex = vw.V == 4 || vw.V == 8 || vw.V == 10 || vw.V == 16;   // the frame has exactly the bucket's view count
+#define NL_MS1(VT, V4, EX)                                                                                                              \
+  hipLaunchKernelGGL((mv_stats_kernel<VT, V4, EX>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, xyz, (int)N, vis_in, dd_in, \
+                     g393, ldg, rgb_feat, vis_ang, valid_s, pfeat, blw, bl1, rgbv)
+#define NL_MS1_BUCKET(VT)                 \
+  do {                                    \
+    if (v4 && ex) NL_MS1(VT, true, true); \
+    else if (v4) NL_MS1(VT, true, false); \
+    else NL_MS1(VT, false, false);        \
+  } while (0)
+  if (vw.V <= 4) NL_MS1_BUCKET(4);
+  else if (vw.V <= 8) NL_MS1_BUCKET(8);
+  else if (vw.V <= 10) NL_MS1_BUCKET(10);
+  else NL_MS1_BUCKET(16);
+#undef NL_MS1_BUCKET
+#undef NL_MS1
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
