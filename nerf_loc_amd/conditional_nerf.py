@@ -24,7 +24,6 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .depth_fusion import DepthFusionNet
 from .frame_setup import backproject_support

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_weights
+from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_weights
 from tests.util import GOLDEN_DIR, load_golden, rel_err
 
 CFG = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
