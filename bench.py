@@ -63,6 +63,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    # NERFLOC_BENCH_ONE_GPU=1: functional check of the N>1 control flow on a box with one GPU — every rank uses device 0 and the
+    # collective runs over gloo (RCCL refuses two ranks on one device).  Never used for a reported number.
+    one_gpu = os.environ.get("NERFLOC_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -73,6 +78,8 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif one_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 

@@ -73,7 +73,7 @@ def gather_ray_outputs_async(out: Dict[str, torch.Tensor], dist, counts=None) ->
         if pad:
             buf = torch.cat([buf, buf.new_zeros(pad, buf.shape[1])], 0)
     full = torch.empty(world * buf.shape[0], buf.shape[1], dtype=buf.dtype, device=buf.device)
-    if buf.is_cuda:
+    if buf.is_cuda and dist.get_backend() == "nccl":
         work = dist.all_gather_into_tensor(full, buf, async_op=True)
     else:
         work = dist.all_gather(list(full.chunk(world, 0)), buf, async_op=True)
