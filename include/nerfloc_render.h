@@ -35,6 +35,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define NL_ABI_VERSION 1
 #define NL_MAX_VIEWS 16
@@ -209,6 +213,9 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* fra
                    const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd,
                    const nl_render_out* out, void* ws, size_t ws_bytes, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -71,10 +71,22 @@ class MultiviewFeatureAggregator(nn.Module):
         super().__init__()
         self.args = args
         self.depth_fusion = DepthFusionNet(in_channels=in_channels)
+        self._vis_gen = 0
         self.vis_featmaps = None
         self.dist_decoder = MixtureLogisticsDistDecoder()
         self.out_fc = nn.Sequential(nn.Linear((in_channels + 3) * 2 + 2 + 1, hidden_dim), nn.ELU(inplace=True),
                                     nn.Linear(hidden_dim, out_channels), nn.ELU(inplace=True))
+
+    # `vis_featmaps` is a cache the CALLER resets by plain assignment (nerf_pose_estimator.py:290).  Every assignment bumps a
+    # generation counter, which is what the HIP frame tables are keyed on (object ids / data pointers can be reused).
+    @property
+    def vis_featmaps(self):
+        return self.__dict__.get("_vis_featmaps")
+
+    @vis_featmaps.setter
+    def vis_featmaps(self, v):
+        self.__dict__["_vis_featmaps"] = v
+        self.__dict__["_vis_gen"] = self.__dict__.get("_vis_gen", 0) + 1
 
     def compute_ref_depth_loss(self, *a, **k):
         raise NotImplementedError("training loss through the HIP renderer is a next-row item (SURVEY.md §8f-2)")
@@ -115,6 +127,17 @@ def get_rays(H, W, K, c2w):
 
 
 class ConditionalNeRF(nn.Module):
+    # `support_neural_points` is the second cache the caller resets per frame (nerf_pose_estimator.py:289): same generation
+    # counter scheme as MultiviewFeatureAggregator.vis_featmaps.
+    @property
+    def support_neural_points(self):
+        return self.__dict__.get("_support_neural_points")
+
+    @support_neural_points.setter
+    def support_neural_points(self, v):
+        self.__dict__["_support_neural_points"] = v
+        self.__dict__["_sp_gen"] = self.__dict__.get("_sp_gen", 0) + 1
+
     def __init__(self, args, activation_func=None, precision: str = "bf16x3", device: Optional[str] = None):
         super().__init__()
         self.args = copy.deepcopy(args)
@@ -189,11 +212,14 @@ class ConditionalNeRF(nn.Module):
             self.build_support_neural_points(data)
         r = self._renderer(level)
         sp = self.support_neural_points[level]
-        token = (id(sp["xyz"]), id(self.multiview_aggregator.vis_featmaps), data["topk_images"].data_ptr())
+        feat = data["feat_fine_src"] if level == "fine" else data["feat_coarse_src"]
+        near, far = [float(x) for x in data["depth_range"][0]]
+        vis = self._vis_featmaps(data)   # (re)computes the cache first, so its generation is final below
+        # generation counters of the two caller-reset caches + the identity of everything else the tables are built from
+        token = (self._sp_gen, self.multiview_aggregator._vis_gen, data["topk_images"].data_ptr(), feat.data_ptr(),
+                 data["topk_Ks"].data_ptr(), data["topk_poses"].data_ptr(), near, far, id(sp), id(vis))
         if self._frame_token.get(level) != token:
-            feat = data["feat_fine_src"] if level == "fine" else data["feat_coarse_src"]
-            near, far = [float(x) for x in data["depth_range"][0]]
-            r.set_frame(data["topk_images"], feat, self._vis_featmaps(data), data["topk_Ks"], data["topk_poses"], near, far, sp)
+            r.set_frame(data["topk_images"], feat, vis, data["topk_Ks"], data["topk_poses"], near, far, sp)
             self._frame_token[level] = token
         return r
 
@@ -236,7 +262,7 @@ class ConditionalNeRF(nn.Module):
                        "keypoint_score": self.keypoint_head(desc_c[:, 3:])},
             "fine": fine,
         }
-        self._frame_token.pop("fine", None)   # rebuild tables with the real confidence on next use
+        self._frame_token.clear()   # (the assignment above bumped the generation too) every level rebuilds its tables on next use
         if len(pts_c) == 0:
             print(f"Error: zero support_neural_points {d.get('scene')} : {d.get('filename')}")
 
@@ -251,6 +277,7 @@ class ConditionalNeRF(nn.Module):
     def query(self, data, xyz, support_featmaps=None, support_neural_points=None, direction=None, K=8, embed_a=None, target_proj_mat=None):
         """model.py:344-436.  `support_featmaps` / `support_neural_points` select the level exactly like the reference's
         call sites do (fine: model.py:325-331,509-517; coarse: :296-302)."""
+        self._refuse_autograd("query", xyz, direction, data.get("pose"))
         if self.support_neural_points is None:
             self.build_support_neural_points(data)
         level = "coarse" if (support_neural_points is not None and support_neural_points is self.support_neural_points.get("coarse")) else "fine"
@@ -308,6 +335,16 @@ class ConditionalNeRF(nn.Module):
         return torch.cat(out, -1)
 
     # ------------------------------------------------------------------ rendering
+    def _refuse_autograd(self, what, *tensors):
+        """The HIP path returns detached tensors.  pose_optimizer.py:131-160 calls render_rays in eval mode under
+        torch.enable_grad() and back-propagates to the camera pose: fail loudly instead of silently dropping that gradient."""
+        if not torch.is_grad_enabled():
+            return
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.requires_grad:
+                raise NotImplementedError(f"{what}: an input requires grad, but the HIP renderer has no backward pass yet "
+                                          "(SURVEY.md §8f-2); call it under torch.no_grad() or detach the inputs")
+
     def sample_depths(self, N_samples, near, far):
         """model.py:451-458 (tiny, host-side torch like the reference)."""
         t = torch.linspace(0, 1, N_samples, device=near.device)
@@ -315,11 +352,15 @@ class ConditionalNeRF(nn.Module):
             return near * (1 - t) + far * t
         return 1 / (1 / near * (1 - t) + 1 / far * t)
 
-    @torch.no_grad()
     def render_rays(self, data, rays, u: Optional[torch.Tensor] = None):
         """model.py:472-600, eval mode.  `u` optionally fixes sample_pdf's uniform draws (reference: torch.rand)."""
         if self.training:
             raise NotImplementedError("autograd through the HIP renderer (beta / render loss) is a next-row item (SURVEY.md §8f-2)")
+        self._refuse_autograd("render_rays", rays.get("rays_o"), rays.get("rays_d"), rays.get("pose"), data.get("pose"))
+        with torch.no_grad():
+            return self._render_rays(data, rays, u)
+
+    def _render_rays(self, data, rays, u):
         r = self._ensure_frame(data, "fine")
         near, far = rays["depth_range"]
         o, d = rays["rays_o"], rays["rays_d"]
@@ -330,16 +371,21 @@ class ConditionalNeRF(nn.Module):
         if self.args.render.N_importance > 0:
             if u is None:
                 u = torch.rand(R, self.args.render.N_importance, device=o.device)
-            z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u)
+            # the coarse depths use the RAYS' range like the base samples (model.py:489), not the frame's
+            z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=float(near), far=float(far))
         out = r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
                             want_feat=bool(self.args.render.render_feature))
         if depth_coarse is not None:
             out["depth_coarse"] = depth_coarse
         return out
 
-    @torch.no_grad()
     def render_image(self, data):
         """model.py:602-639."""
+        self._refuse_autograd("render_image", data.get("pose"), data.get("K"))
+        with torch.no_grad():
+            return self._render_image(data)
+
+    def _render_image(self, data):
         H, W, K, pose = data["H"], data["W"], data["K"], data["pose"]
         o, d = get_rays(H, W, K, pose)
         o, d = o.reshape(-1, 3), d.reshape(-1, 3)

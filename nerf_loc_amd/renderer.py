@@ -224,7 +224,7 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
-    def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64):
+    def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64, near: Optional[float] = None, far: Optional[float] = None):
         """a20: coarse NeuRay weights along the pixel rays -> inverse-CDF samples (uniforms `u` (R,Ni)) merged with
         z_base (R,Sb) and sorted.  Returns (z_vals (R,Sb+Ni), depth_coarse (R,), weights_coarse (R,n_coarse))."""
         self._ready()
@@ -237,7 +237,9 @@ class HipRenderer:
         Pc = torch.as_tensor(pose).detach().float().cpu()
         cam = torch.cat([Pc[None].inverse()[0, :3].reshape(-1), torch.inverse(Kc).reshape(-1)]).contiguous()  # depth_fusion.py:19-26
         t_lin = torch.linspace(0, 1, n_coarse)
-        zc = (torch.tensor(self.near) * (1 - t_lin) + torch.tensor(self.far) * t_lin).expand(R, n_coarse).contiguous().to(dev)  # model.py:489
+        # model.py:489 samples the coarse depths from rays['depth_range'] (the caller passes it); the frame's range is only the default
+        zn, zf = self.near if near is None else float(near), self.far if far is None else float(far)
+        zc = (torch.tensor(zn) * (1 - t_lin) + torch.tensor(zf) * t_lin).expand(R, n_coarse).contiguous().to(dev)
         wc = torch.empty(R, n_coarse, device=dev)
         dc = torch.empty(R, device=dev)
         zo = torch.empty(R, Sb + Ni, device=dev)

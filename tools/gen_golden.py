@@ -181,106 +181,6 @@ def run_case(model_mod, ku, name):
           f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
 
 
-def run_setup_case(model_mod, name="setup"):
-    """Per-frame setup (a21) + end-to-end render through the reference, with seeded DepthFusionNet weights."""
-    import json
-    from tests.golden_cases import build_setup_case
-    case = build_setup_case(name)
-    cfg, frame, rays, weights = case["cfg"], case["frame"], case["rays"], case["weights"]
-    net = model_mod.ConditionalNeRF(ref_args(cfg)).eval()
-    sd = net.state_dict()
-    ours = {k: t(v) for k, v in weights.items()}
-    path_keys = {k for k in sd if "depth_fusion" not in k}
-    assert path_keys == set(ours), (sorted(path_keys ^ set(ours)))
-    for k in ours:
-        assert tuple(sd[k].shape) == tuple(ours[k].shape), (k, sd[k].shape, ours[k].shape)
-    net.load_state_dict(ours, strict=False)
-
-    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "depth_range", "K", "pose")}
-    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "white_bkgd": bool(frame["white_bkgd"])})
-    net.support_neural_points = {"fine": {k: t(v) for k, v in frame["support_fine"].items()}}
-    net.multiview_aggregator.vis_featmaps = t(frame["vis_featmaps"])
-    ray_d = {"rays_o": t(rays["rays_o"]), "rays_d": t(rays["rays_d"]), "depth_range": t(rays["depth_range"]),
-             "pixel_coordinates": t(rays["pixel_coordinates"]), "K": t(rays["K"]), "pose": t(rays["pose"]), "H": cfg.H, "W": cfg.Wimg}
-
-    inter = {}
-    # capture intermediates by wrapping (not editing) reference callables
-    orig_query = net.query
-
-    def query_spy(*a, **k):
-        out = orig_query(*a, **k)
-        inter["feature_agg"] = out["feature_agg"].detach().clone()
-        inter["multiview_visibility"] = out["multiview_visibility"].detach().squeeze(-1).clone()
-        return out
-    net.query = query_spy
-    orig_mv = net.multiview_aggregator.forward
-
-    def mv_spy(*a, **k):
-        out = orig_mv(*a, **k)
-        inter["multiview_feature_agg"] = out[0].detach().clone()
-        return out
-    net.multiview_aggregator.forward = mv_spy
-    orig_knn = model_mod.knn_points
-
-    def knn_spy(*a, **k):
-        out = orig_knn(*a, **k)
-        if k.get("K", 1) == 8:
-            inter["knn_d2"] = out.dists[0].detach().clone()
-            inter["knn_idx"] = out.idx[0].detach().clone()
-        return out
-    model_mod.knn_points = knn_spy
-    orig_sigma = net.sigma_mlp.forward
-
-    def sigma_spy(x):
-        out = orig_sigma(x)
-        inter["sigma"] = out.detach().clone()
-        return out
-    net.sigma_mlp.forward = sigma_spy
-    orig_unet = net.ray_unet.forward
-
-    def unet_spy(x):
-        out = orig_unet(x)
-        inter["geo"] = out.detach().permute(0, 2, 1).reshape(-1, out.shape[1]).clone()
-        return out
-    net.ray_unet.forward = unet_spy
-
-    orig_rand = torch.rand
-    if cfg.N_importance > 0:
-        def rand_fixed(*shape, **kw):
-            assert tuple(shape) == tuple(u.shape), (shape, u.shape)
-            return t(u).clone()
-        torch.rand = rand_fixed
-    try:
-        with torch.no_grad():
-            out = net.render_rays(data, ray_d)
-    finally:
-        torch.rand = orig_rand
-        model_mod.knn_points = orig_knn
-
-    save = {k: v.numpy() for k, v in out.items()}
-    R, S = cfg.R, cfg.S_total
-    save["sigma"] = inter["sigma"].view(R, S).numpy()
-    save["knn_d2"] = inter["knn_d2"].numpy()
-    save["knn_idx"] = inter["knn_idx"].numpy().astype(np.int32)
-    if CASES[name][1]:
-        save["feature_agg"] = inter["feature_agg"].numpy()
-        save["multiview_feature_agg"] = inter["multiview_feature_agg"].numpy()
-        save["multiview_visibility"] = inter["multiview_visibility"].numpy()
-        save["geo"] = inter["geo"].numpy()
-    else:  # subsample the (N, W) intermediates to keep fixtures small
-        sel = np.arange(0, R * S, 37)
-        save["rows"] = sel.astype(np.int32)
-        save["feature_agg"] = inter["feature_agg"].numpy()[sel]
-        save["multiview_feature_agg"] = inter["multiview_feature_agg"].numpy()[sel]
-        save["geo"] = inter["geo"].numpy()[sel]
-    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
-    np.savez_compressed(path, **save)
-    msk = save["mask"]
-    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) rays={R} S={S} mask_true={int(msk.sum())}/{R} "
-          f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
-
-
 def punch_holes(frame, seed):
     """Ragged support depth for the `setup_holes` case: ~35 % of the pixels invalid (0), a few negative, one view with no valid
     depth at all — nonzero()'s order and the empty-view path of backproject_support_frame (model.py:231)."""
