@@ -41,20 +41,17 @@ int nl_launch_sample_pdf(const float* zc, const float* wc, int Sc, const float* 
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
                         int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst, hipStream_t st);
 
-struct NlPointFusedArgs {
-  const float* xyz; const float* dir; int dir_stride, dir_div;
-  const int* idx; const float* Q; float* O;
-  const float* ptt;
-  const float* sp_xyz; const float* sp_dir;
-  const uint4* wstream; const float* bias; const float* rd_w;
-  int N, M; float inv_span;
-};
 size_t nl_point_stream_bytes(int W);
 int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
 int nl_pack_ptt(const float* w1, const float* b1, int W, int F, int Kpad, int Npad, float* B32, float* bias, hipStream_t st);
 int nl_launch_wscale(const int* idx, const float* d2, const float* conf, int64_t N, int K, int64_t M, float* wscale, hipStream_t st);
 bool nl_point_fused_supported(int W, int precision);
 int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
+size_t nl_point_stream2_bytes(int W);
+int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
+                          const float* rd_w, void* out, int W, int F, hipStream_t st);
+bool nl_point_fused2_supported(int W, int precision);
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 
 namespace {
 
@@ -102,7 +99,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bias[G_COUNT];
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_stream2, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];
   int un_c[U_COUNT], un_l[U_COUNT];
   size_t total;
@@ -173,6 +170,7 @@ Layout make_layout(const nl_config* c) {
   L.dec_mfma = take(nl_mv_decoder_pack_bytes());
   L.pt_bias = take(4 * 3 * (size_t)W);
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
+  L.pt_stream2 = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);
   L.zeros = take(4096);
   L.total = off;
   return L;
@@ -507,10 +505,13 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     a.xyz = xyz; a.dir = dir; a.dir_stride = dir_stride; a.dir_div = dir_div > 0 ? dir_div : 1;
     a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
     a.wstream = x.p<uint4>(x.L.pt_stream); a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
+    a.wstream2 = x.p<uint4>(x.L.pt_stream2);
     a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
-    NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));
+    const bool use_v1 = getenv("NERFLOC_POINT_V1") != nullptr;   // A/B switch for profiling / debugging
+    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) NL_TRY(nl_launch_point_fused2(a, W, x.c->precision, x.st));
+    else NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));
     if (pe1) NL_CHECK_HIP(hipEventRecord(pe1, x.st));
   } else {
     if (!p.X) return NL_ERR_UNSUPPORTED;
@@ -737,6 +738,11 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.copy(t[T_B0B], L.pt_bias, W); P.copy(t[T_B2B], L.pt_bias + 4 * (size_t)W, W); P.copy(t[T_B4B], L.pt_bias + 8 * (size_t)W, W);
   if (W == 64 || W == 128 || W == 256) {
     int rc = nl_pack_point_stream(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], (char*)packed + L.pt_stream, W, F, st);
+    if (rc != NL_OK) return rc;
+  }
+  if (W == 128 || W == 256) {   // rd_w was filled by the copies above (same stream)
+    int rc = nl_pack_point_stream2(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], t[T_B2B], t[T_B4B], (const float*)((char*)packed + L.rd_w),
+                                   (char*)packed + L.pt_stream2, W, F, st);
     if (rc != NL_OK) return rc;
   }
   NL_LAUNCH_CHECK();

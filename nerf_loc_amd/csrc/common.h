@@ -95,6 +95,22 @@ struct NlGridParams {
   int ncells;
 };
 
+// ------------------------------------------------------------------ fused neural-point kernels (point_fused.hip, point_fused2.hip)
+struct NlPointFusedArgs {
+  const float* xyz; const float* dir; int dir_stride, dir_div;
+  const int* idx;          // (N,8) neighbour indices
+  const float* Q;          // (N,128) query projection (w_qs . mv_feat)
+  float* O;                // (N,128) attention output
+  const float* ptt;        // [(M+1)][W] per-frame table T = sp_feature . W1[:, :F]^T + b1 in accumulator order; row M = b1 only
+  const float* sp_xyz; const float* sp_dir;
+  const uint4* wstream;    // packed weight stream (v1: pack_point_stream_kernel)
+  const float* bias;       // [3][W] base_mlp biases
+  const float* rd_w;       // ray_diff_fc: W0[16][4], b0[16], W2[27][16], b2[27]
+  int N, M;
+  float inv_span;
+  const uint4* wstream2;   // v2 stream (pack_point_stream2_kernel): row-tile-major chunks + resident block
+};
+
 // ------------------------------------------------------------------ generic segment GEMM (gemm.hip)
 #define NL_GEMM_MAX_SEG 6
 struct NlGemmSeg {

@@ -24,19 +24,6 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct NlPointFusedArgs {
-  const float* xyz; const float* dir; int dir_stride, dir_div;
-  const int* idx;          // (N,8) neighbour indices
-  const float* Q;          // (N,128) query projection (w_qs . mv_feat)
-  float* O;                // (N,128) attention output
-  const float* ptt;        // [(M+1)][W] per-frame table T = sp_feature . W1[:, :F]^T + b1 in accumulator order; row M = b1 only
-  const float* sp_xyz; const float* sp_dir;
-  const uint4* wstream;    // packed weight stream (pack_point_stream_kernel)
-  const float* bias;       // [3][W] base_mlp biases
-  const float* rd_w;       // ray_diff_fc: W0[16][4], b0[16], W2[27][16], b2[27]
-  int N, M;
-  float inv_span;
-};
 
 namespace {
 

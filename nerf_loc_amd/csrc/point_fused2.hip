@@ -1,0 +1,618 @@
+// Fused neural-point branch, second generation — the MFMA roofline kernel.
+//
+//   per (sample, neighbour) row:  [feature(195) | posenc(63) | ray_diff_fc(27)]            model.py:394-409
+//       -> base_mlp 285->W->W->W (LeakyReLU)                                                model.py:63-71
+//       -> k/v projections W->128+128                                                       ibrnet.py:98-99
+//   per sample: 4-head attention of the (precomputed) query over its 8 neighbours -> O (N,128)  ibrnet.py:28-45,104
+//
+// What changed against point_fused.hip (kept for W = 64) and why — measured with tools/ubench/mfma_fill.hip / mfma_rowtile.hip:
+// one wave per SIMD hides <= 5 plain VALU instructions (or 2-3 v_cvt_pk_bf16_f32, 8 cycles each, or 2 ds_read_b128, 16 cycles
+// of LDS bandwidth each) in the 32-cycle issue shadow of every v_mfma_f32_32x32x16_bf16, but ONLY if they sit between the MFMAs
+// in program order.  The first kernel ran K-outer / row-tile-inner, so all 128 accumulators of a layer finished together and
+// the LeakyReLU + bf16 hi/lo split of the whole layer (and the operand assembly, the LDS-DMA bursts, the attention) ran with the
+// matrix pipe idle: 38 % MFMA-busy.  Here every layer is OUTPUT-STATIONARY:
+//   * a chunk of the weight stream is one 32-row output tile x all K (32 KB in bf16x3) instead of 2 k-steps x all row tiles;
+//     the wave accumulates ONE tile (16 registers) over the whole K of the layer;
+//   * while tile rt accumulates, the epilogue of tile rt-1 (+bias / +table row, LeakyReLU, hi/lo split -> B fragments of the next
+//     layer), the LDS-DMA pieces of the chunk three ahead and the A-fragment reads two k-steps ahead are issued a few
+//     instructions at a time after each MFMA (`fill`), fenced with sched_barrier so the compiler keeps that order;
+//   * the k / v projections finish one attention head (= one row tile) at a time, so the softmax over the 8 neighbours and the
+//     weighted sums run in the shadow of the next head's MFMAs; 128 accumulators are never live;
+//   * activations of layer L (128 VGPRs as hi/lo bf16 fragments) and of layer L+1 (128, being produced) are both register
+//     resident: ~2 x 128 + 2 x 16 accumulators + fragments, one wave per SIMD (512-register file);
+//   * the workgroups are persistent (one per CU, XCD-contiguous tile order): the weight ring keeps streaming across tiles,
+//     so only the first tile of a workgroup waits for LDS-DMA latency;
+//   * ray_diff_fc (4 -> 16 -> 27) runs on the matrix pipe too (6 MFMAs) and each half-wave computes only the positional-encoding
+//     octaves of its own k-slots (half 0: octaves 0-4, half 1: 5-9; three fp64 sin/cos + four fp64 double-angle steps per axis).
+#include <utility>
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NBUF = 4;   // LDS ring slots; chunk c lives in slot c % 4, chunks c+1 .. c+3 are in flight while c is consumed
+
+template <int NRT, bool X3>
+struct Geo {
+  static constexpr int W = 32 * NRT, PARTS = X3 ? 2 : 1, MPK = X3 ? 3 : 1;   // MPK: MFMAs per k-step
+  static constexpr int KSL = 2 * NRT;        // k-steps of the wide layers (K = W)
+  static constexpr int KS1 = 6;              // layer 1: 4 positional-encoding + 2 ray_diff_fc k-steps (K = 96)
+  static constexpr int KS1I = X3 ? 6 : 8;    // k-steps COPIED per part for a layer-1 chunk (bf16: 8 so that the pieces divide by 4 waves)
+  static constexpr int NC = 3 * NRT + 8;     // chunks (= output row tiles) per tile: L1 | L2 | L3 | K heads 0-3, V heads 0-3
+  static constexpr int SLOT = PARTS * KSL * 64;   // ring slot in uint4
+  static constexpr int cm(int g) { return ((g % NC) + NC) % NC; }
+  static constexpr int layer(int g) { return cm(g) < NRT ? 0 : cm(g) < 2 * NRT ? 1 : cm(g) < 3 * NRT ? 2 : 3; }
+  static constexpr int rt(int g) { return cm(g) < 3 * NRT ? cm(g) % NRT : cm(g) - 3 * NRT; }
+  static constexpr int nks(int g) { return layer(g) == 0 ? KS1 : KSL; }
+  static constexpr int ksi(int g) { return layer(g) == 0 ? KS1I : KSL; }       // k-steps per part in the LDS image
+  static constexpr int ppw(int g) { return PARTS * ksi(g) / 4; }               // LDS-DMA pieces (1 KB) per wave
+  static constexpr int gkb(int g) {   // offset of chunk g in the global stream, in KB; the stream always holds both parts
+    int o = 0;
+    for (int i = 0; i < cm(g); ++i) o += 2 * nks(i);
+    return o;
+  }
+  static constexpr int cumks(int g) {
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += nks(i);
+    return o;
+  }
+  static constexpr int STREAM_KB = 2 * (NRT * KS1 + (2 * NRT + 8) * KSL);
+  static constexpr int RES_RD = NBUF * SLOT;                 // resident: ray_diff_fc A fragments [layer][part][64] uint4
+  static constexpr int RES_BIAS = RES_RD + 2 * PARTS * 64;   // resident: biases in accumulator order, floats [rd1 32 | rd2 32 | L2 W | L3 W]
+  static constexpr int LDS_U4 = RES_BIAS + (64 + 2 * W) / 4;
+  // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
+  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 9 : 20); }
+  static constexpr int RL = cumks(NC) % 3 == 0 ? 3 : 4;   // A-fragment register ring (3 k-steps are live)
+  static constexpr int rpos(int runks) { return runks % RL; }
+  static_assert(NC % NBUF == 0 && cumks(NC) % RL == 0, "ring positions must be tile-periodic");
+  static_assert((PARTS * KS1I) % 4 == 0 && (PARTS * KSL) % 4 == 0, "pieces per wave");
+};
+
+template <int OFF>
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, OFF, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: every index is a constant expression
+  static_for_impl(std::make_integer_sequence<int, (N > 0 ? N : 0)>{}, static_cast<F&&>(f));
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // low half = bf16(a), high half = bf16(b), round to nearest even
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {   // bare v_max_f32 (fmaxf adds a canonicalising v_max x,x)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// hi/lo split of a pair: hi = bf16(v), lo = bf16(v - float(hi))
+template <bool X3>
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+  hi = cvt_pk_bf16(v0, v1);
+  if (X3) {
+    const float f0 = __uint_as_float(hi << 16), f1 = __uint_as_float(hi & 0xffff0000u);
+    lo = cvt_pk_bf16(v0 - f0, v1 - f1);
+  }
+}
+
+// branch-free sin/cos in fp64 (|x| up to ~1e5): Cody-Waite reduction to [-pi/4, pi/4] + Taylor (error < 1e-11)
+__device__ __forceinline__ void sincos_d(double x, double& s, double& c) {
+  const double kd = rint(x * 0.63661977236758134308);
+  const int k = (int)kd;
+  double r = fma(-kd, 1.5707963267948966, x);
+  r = fma(-kd, 6.123233995736766e-17, r);
+  const double r2 = r * r;
+  const double ps = r + r * r2 * (-1.0 / 6 + r2 * (1.0 / 120 + r2 * (-1.0 / 5040 + r2 * (1.0 / 362880 + r2 * (-1.0 / 39916800)))));
+  const double pc = 1.0 + r2 * (-0.5 + r2 * (1.0 / 24 + r2 * (-1.0 / 720 + r2 * (1.0 / 40320 + r2 * (-1.0 / 3628800 + r2 * (1.0 / 479001600))))));
+  const bool sw = k & 1;
+  const double ss = sw ? pc : ps, cc = sw ? ps : pc;
+  s = (k & 2) ? -ss : ss;
+  c = ((k + 1) & 2) ? -cc : cc;
+}
+
+struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; int N, M; float inv_span; int ntiles; unsigned t_bytes; };
+
+template <int NRT, bool X3>
+__global__ __launch_bounds__(256, 1) void point_fused2_kernel(
+    const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
+    float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
+    const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const Pf2Scalars sc) {
+  using GG = Geo<NRT, X3>;
+  constexpr int W = GG::W, PARTS = GG::PARTS, MPK = GG::MPK, NC = GG::NC, SLOT = GG::SLOT;
+  // ONE __shared__ object, read through ONE native vector type with compile-time slot indices: hipcc then keeps the alias
+  // information that lets SIInsertWaitcnts leave LDS reads alone while LDS-DMA writes are in flight
+  __shared__ uint4 lds_all[GG::LDS_U4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31, kk = j & 7;
+  const unsigned nwg = gridDim.x;
+  int tile = (int)nl_xcd_block();
+  if (tile >= sc.ntiles) return;
+
+  // ---------------------------------------------------------------- resident block: ray_diff_fc fragments + bias tables
+  {
+    const uint4* src = p_wstream + (size_t)GG::STREAM_KB * 64;
+    for (int i = tid; i < 2 * PARTS * 64; i += 256) lds_all[GG::RES_RD + i] = src[(i / (PARTS * 64)) * 128 + i % (PARTS * 64)];
+    for (int i = tid; i < (64 + 2 * W) / 4; i += 256) lds_all[GG::RES_BIAS + i] = src[256 + i];
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- weight stream: piece p = 4 i + wave of a chunk
+  // All memory traffic of the tile loop goes through BUFFER instructions.  (a) LDS-DMA issued as global_load_lds is a FLAT
+  // instruction that touches two address spaces; while one is pending SIInsertWaitcnts turns every wait for an ordinary load
+  // into vmcnt(0) — eight full drains of the weight ring per tile.  buffer_load ... lds is counted like any other load, so
+  // the compiler's waits stay exact.  (b) voffset is one VGPR for all pieces, the piece offset is a scalar: no per-piece
+  // 64-bit addresses to hoist out of the loop (LICM did: 450 registers / SGPR spills).  (c) out-of-range offsets are dropped
+  // by the bounds check: predicated stores without EXEC juggling or branches.
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p_wstream, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p_ptt, 0, (int)sc.t_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)p_Q, 0, sc.N * 512, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)p_O, 0, sc.N * 512, 0x00020000);
+  const unsigned wvoff = wave * 1024 + lane * 16;   // piece p = 4 i + wave of a chunk
+  uint4* lw = lds_all + wave * 64;
+  unsigned soff = 0;                                // running stream offset of the next piece (scalar)
+  auto dma_piece = [&](auto Cc, auto Ic) __attribute__((always_inline)) {
+    constexpr int c = GG::cm(decltype(Cc)::value), i = decltype(Ic)::value;
+    constexpr int want = GG::gkb(c) * 1024 + i * 4096;
+    constexpr int prev = i == 0 ? GG::gkb(c - 1) * 1024 + (GG::ppw(c - 1) - 1) * 4096 : want - 4096;   // gkb wraps: chunk -1 = NC-1
+    soff += (unsigned)(want - prev);   // pieces are issued in stream order: one scalar add per piece
+    asm volatile("" : "+s"(soff));     // opaque, so that the offsets are not re-materialised (and hoisted) as 225 constants
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + (c % NBUF) * SLOT + i * 256), 16, wvoff, soff, 0, 0);
+  };
+
+  // ---------------------------------------------------------------- register state
+  // Activations as B fragments (hi / lo), ping-pong between layers, and the layer-1 operands of the current tile.  Kept as SCALAR
+  // dwords (assembled into a 4-dword operand at the MFMA): a fragment is written one dword at a time, and with vector-typed
+  // storage every such insert keeps the whole old vector alive in the compiler's eyes — both ping-pong halves then stay live
+  // around the tile loop (512 registers + 290 spills instead of ~400)
+  unsigned Xh[2][2 * NRT][4], Xl[2][2 * NRT][4];
+  unsigned Ph[GG::KS1][4], Pl[GG::KS1][4];
+  u32x4 frh[GG::RL], frl[GG::RL];         // A-fragment ring, position = (running k-step) % RL
+  // accumulator of chunk c = acc[c & 3].  Four, because the accumulator is INITIALISED by loads that must be in flight early:
+  // while region G accumulates into acc[G & 3] and the epilogue of G-1 drains acc[(G-1) & 3], the bias slice of chunk G+1
+  // (LDS) and the table-row slice of layer-1 chunk G+2 (a gather from the per-frame table T) land in the other two
+  f32x16 acc[4];
+  f32x4 Qr[4];                            // query of the head being scored
+  float att[4] = {0.f, 0.f, 0.f, 0.f};
+  float ev0 = 0.f, ev1 = 0.f, ap = 0.f, amx = 0.f, aee = 0.f, ase = 0.f;
+  unsigned ehi = 0;
+  float ov[4];
+  unsigned ooff_cur = 0x80000000u, ooff_prev = 0x80000000u;   // byte offset of the lane's slice of O; out of range (= dropped) for lanes that do not store
+  unsigned toff = 0, qoff = 0;                                // byte offsets of the lane's table row / query slice
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* sres = reinterpret_cast<const float*>(lds_all + GG::RES_BIAS);
+
+  auto mfma = [](const u32x4& a, const u32x4& b, const f32x16& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+
+  // LeakyReLU + split of a finished pair -> dword `d` of the destination fragments
+  auto finish_pair = [&](float v0, float v1, unsigned& dh, unsigned& dl) __attribute__((always_inline)) {
+    v0 = vmax(v0, v0 * 0.01f); v1 = vmax(v1, v1 * 0.01f);
+    unsigned h = 0, l = 0;
+    split2<X3>(v0, v1, h, l);
+    dh = h;
+    if (X3) dl = l;
+  };
+  auto frag4 = [](const unsigned (&d)[4]) __attribute__((always_inline)) { return u32x4{d[0], d[1], d[2], d[3]}; };
+
+  // ---------------------------------------------------------------- tile prologue: layer-1 operands (model.py:394-409)
+  auto prologue = [&](int t) __attribute__((always_inline)) {
+    const int n = t * 16 + wave * 4 + (j >> 3);
+    const bool live = n < sc.N;
+    const int nn = live ? n : sc.N - 1;
+    ooff_cur = (live && kk == 0) ? (unsigned)nn * 512u + 16u * hh : 0x80000000u;
+    const bool have = live && kk < sc.M && sc.M > 0;   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
+    const int id = p_idx[(size_t)nn * 8 + kk];
+    toff = (unsigned)(have ? id : sc.M) * (unsigned)(W * 4) + 64u * hh;   // row M holds the bias alone
+    qoff = (unsigned)nn * 512u + 16u * hh;
+    const float qx = p_xyz[3 * (size_t)nn], qy = p_xyz[3 * (size_t)nn + 1], qz = p_xyz[3 * (size_t)nn + 2];
+    const float px = have ? p_sp_xyz[3 * (size_t)id] : 0.f, py = have ? p_sp_xyz[3 * (size_t)id + 1] : 0.f, pz = have ? p_sp_xyz[3 * (size_t)id + 2] : 0.f;
+    const float off[3] = {(qx - px) * sc.inv_span, (qy - py) * sc.inv_span, (qz - pz) * sc.inv_span};
+    // ---- ray direction difference (model.py:396-399) -> ray_diff_fc (model.py:36-39) on the matrix pipe
+    {
+      float dx, dy, dz;
+      if (p_dir) {
+        const unsigned ray = sc.dir_div == 1 ? (unsigned)nn : (__umulhi((unsigned)nn, sc.dir_magic) >> sc.dir_shift);
+        const size_t dr = (size_t)ray * sc.dir_stride;
+        dx = p_dir[dr]; dy = p_dir[dr + 1]; dz = p_dir[dr + 2];
+      } else {   // model.py:391-392: the nearest neighbour's direction
+        const int i0 = p_idx[(size_t)nn * 8];
+        const bool ok = live && sc.M > 0;
+        dx = ok ? p_sp_dir[4 * (size_t)i0] : 0.f; dy = ok ? p_sp_dir[4 * (size_t)i0 + 1] : 0.f; dz = ok ? p_sp_dir[4 * (size_t)i0 + 2] : 0.f;
+      }
+      const float ndx = have ? p_sp_dir[4 * (size_t)id] : 0.f, ndy = have ? p_sp_dir[4 * (size_t)id + 1] : 0.f, ndz = have ? p_sp_dir[4 * (size_t)id + 2] : 0.f;
+      float r0 = dx - ndx, r1 = dy - ndy, r2 = dz - ndz;
+      const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2) + 1e-8f;
+      r0 /= nr; r1 /= nr; r2 /= nr;
+      const float r3 = dx * ndx + dy * ndy + dz * ndz;
+      // B fragment of the first layer: k-slots 0..3 of half 0
+      u32x4 bh = {0, 0, 0, 0}, bl = {0, 0, 0, 0};
+      {
+        unsigned h0 = 0, l0 = 0, h1 = 0, l1 = 0;
+        split2<X3>(r0, r1, h0, l0); split2<X3>(r2, r3, h1, l1);
+        bh[0] = hh ? 0u : h0; bh[1] = hh ? 0u : h1;
+        if (X3) { bl[0] = hh ? 0u : l0; bl[1] = hh ? 0u : l1; }
+      }
+      auto rd_layer = [&](auto Lc, const u32x4& xh, const u32x4& xl) __attribute__((always_inline)) {
+        constexpr int l = decltype(Lc)::value;
+        const u32x4 ah = __builtin_bit_cast(u32x4, lds_all[GG::RES_RD + (l * PARTS + 0) * 64 + lane]);
+        f32x16 a;
+        if (X3) {
+          const u32x4 al = __builtin_bit_cast(u32x4, lds_all[GG::RES_RD + (l * PARTS + (PARTS - 1)) * 64 + lane]);
+          a = mfma(al, xh, zero16);
+          a = mfma(ah, xl, a);
+          a = mfma(ah, xh, a);
+        } else a = mfma(ah, xh, zero16);
+        return a;
+      };
+      const f32x16 a1 = rd_layer(std::integral_constant<int, 0>{}, bh, bl);
+      unsigned hidh[4] = {0, 0, 0, 0}, hidl[4] = {0, 0, 0, 0};
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sres + 16 * hh), b1 = *reinterpret_cast<const f32x4*>(sres + 16 * hh + 4);
+        finish_pair(a1[0] + b0[0], a1[1] + b0[1], hidh[0], hidl[0]);
+        finish_pair(a1[2] + b0[2], a1[3] + b0[3], hidh[1], hidl[1]);
+        finish_pair(a1[4] + b1[0], a1[5] + b1[1], hidh[2], hidl[2]);
+        finish_pair(a1[6] + b1[2], a1[7] + b1[3], hidh[3], hidl[3]);
+      }
+      const f32x16 a2 = rd_layer(std::integral_constant<int, 1>{}, frag4(hidh), frag4(hidl));
+      static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(Gc)::value;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sres + 32 + 16 * hh + 4 * g);
+        finish_pair(a2[4 * g] + b[0], a2[4 * g + 1] + b[1], Ph[4 + g / 2][(2 * g) & 3], Pl[4 + g / 2][(2 * g) & 3]);
+        finish_pair(a2[4 * g + 2] + b[2], a2[4 * g + 3] + b[3], Ph[4 + g / 2][(2 * g + 1) & 3], Pl[4 + g / 2][(2 * g + 1) & 3]);
+      });
+    }
+    // ---- positional encoding (utils.py:5-35).  Half hh owns octaves 5 hh .. 5 hh + 4 of every axis: value e = 10 a + 2 f' + comp
+    // (comp 0 = sin, 1 = cos), then e = 30, 31 = raw (x, y) for half 0 and (z, 0) for half 1.  One accurate fp64 evaluation per
+    // axis at the half's first octave + the double-angle recurrence in fp64 (abs error < 1e-12: correctly rounded in fp32).
+    {
+      const double scale = hh ? 32.0 : 1.0;
+      float v[32];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double s, c;
+        sincos_d((double)off[a] * scale, s, c);
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+          v[10 * a + 2 * f] = (float)s; v[10 * a + 2 * f + 1] = (float)c;
+          if (f < 4) {
+            const double s2 = 2.0 * s * c;
+            c = fma(-2.0 * s, s, 1.0);
+            s = s2;
+          }
+        }
+      }
+      v[30] = hh ? off[2] : off[0]; v[31] = hh ? 0.f : off[1];
+      static_for<16>([&](auto Pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(Pc)::value;
+        unsigned h = 0, l = 0;
+        split2<X3>(v[2 * p], v[2 * p + 1], h, l);
+        Ph[p / 4][p & 3] = h;
+        if (X3) Pl[p / 4][p & 3] = l;
+      });
+    }
+  };
+  auto load_T = [&](auto Cc) __attribute__((always_inline)) {   // table-row slice of layer-1 chunk c = initial value of its accumulator
+    constexpr int c = decltype(Cc)::value;
+    static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(Gc)::value;
+      const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, toff + (32 * GG::rt(c) + 4 * g) * 4, 0, 0));
+      acc[c & 3][4 * g] = t4[0]; acc[c & 3][4 * g + 1] = t4[1]; acc[c & 3][4 * g + 2] = t4[2]; acc[c & 3][4 * g + 3] = t4[3];
+    });
+  };
+  auto load_bias = [&](auto Cc) __attribute__((always_inline)) {   // bias slice of layer-2/3 chunk c = initial value of its accumulator
+    constexpr int c = GG::cm(decltype(Cc)::value);
+    static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(Gc)::value;
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(sres + 64 + (GG::layer(c) - 1) * W + 32 * GG::rt(c) + 16 * hh + 4 * g);
+      acc[c & 3][4 * g] = t4[0]; acc[c & 3][4 * g + 1] = t4[1]; acc[c & 3][4 * g + 2] = t4[2]; acc[c & 3][4 * g + 3] = t4[3];
+    });
+  };
+
+  // A fragments of running k-step t of region G (t >= nks(G): chunk G+1) -> ring position
+  auto read_frag = [&](auto Gc, auto Tc, auto Pc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value, t = decltype(Tc)::value, part = decltype(Pc)::value;
+    constexpr int c = t >= GG::nks(G) ? GG::cm(G + 1) : GG::cm(G), ks = t >= GG::nks(G) ? t - GG::nks(G) : t;
+    constexpr int pos = GG::rpos(GG::cumks(GG::cm(G)) + t);
+    const u32x4 v = __builtin_bit_cast(u32x4, lds_all[(c % NBUF) * SLOT + (part * GG::ksi(c) + ks) * 64 + lane]);
+    if (part == 0) frh[pos] = v; else frl[pos] = v;
+  };
+
+  // ---------------------------------------------------------------- epilogue micro-steps of chunk C, run inside region C+1
+  auto epi_step = [&](auto Cc, auto Ec, auto PrevC) __attribute__((always_inline)) {
+    constexpr int C = GG::cm(decltype(Cc)::value), E = decltype(Ec)::value;
+    constexpr bool PREV = decltype(PrevC)::value;   // chunk of the previous tile (its V head 3 finishes inside the next tile's first region)
+    constexpr int L = GG::layer(C), RT = GG::rt(C), AB = C & 3;
+    if constexpr (L < 3) {
+      constexpr int SPP = X3 ? 2 : 1;
+      constexpr int p = E / SPP, sub = E % SPP;
+      constexpr int out = L & 1;   // L1 -> X[0], L2 -> X[1], L3 -> X[0]
+      constexpr int fo = 2 * RT + (p >> 2), d = p & 3;
+      if constexpr (sub == 0) {
+        ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
+        ev0 = vmax(ev0, ev0 * 0.01f); ev1 = vmax(ev1, ev1 * 0.01f);   // LeakyReLU
+        ehi = cvt_pk_bf16(ev0, ev1);
+        Xh[out][fo][d] = ehi;
+      } else {
+        const float f0 = __uint_as_float(ehi << 16), f1 = __uint_as_float(ehi & 0xffff0000u);
+        Xl[out][fo][d] = cvt_pk_bf16(ev0 - f0, ev1 - f1);
+      }
+    } else if constexpr (RT < 4) {   // k projection of head RT: scores, softmax over the 8 neighbours (lanes) of a sample
+      if constexpr (E < 4) {
+        if constexpr (E == 0) ap = Qr[0][0] * acc[AB][0]; else ap = fmaf(Qr[E][0], acc[AB][4 * E], ap);
+        ap = fmaf(Qr[E][1], acc[AB][4 * E + 1], ap);
+        ap = fmaf(Qr[E][2], acc[AB][4 * E + 2], ap);
+        ap = fmaf(Qr[E][3], acc[AB][4 * E + 3], ap);
+      } else if constexpr (E == 4) {
+        ap += __shfl_xor(ap, 32, 64);
+        ap *= 1.0f / 5.656854249492381f;   // temperature sqrt(d_k) (ibrnet.py:84)
+      } else if constexpr (E == 5) amx = nl_max8(ap);
+      else if constexpr (E == 6) aee = expf(ap - amx);
+      else if constexpr (E == 7) ase = nl_sum8(aee);
+      else att[RT] = aee / ase;
+    } else {   // v projection of head RT-4: attention-weighted sum over the 8 neighbours
+      constexpr int h = RT - 4, g = E / 5, i = E % 5;
+      if constexpr (i < 4) ov[i] = nl_sum8(att[h] * acc[AB][4 * g + i]);
+      else {
+        // one lane per (sample, half) stores; the other lanes carry an out-of-range offset and are dropped by the buffer bounds
+        // check — a source-level `if` would cut the tile body into basic blocks at every store
+        const unsigned oo = PREV ? ooff_prev : ooff_cur;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{ov[0], ov[1], ov[2], ov[3]}), rO, oo + 4 * (32 * h + 8 * g), 0, 0);
+      }
+    }
+  };
+
+  // everything that is issued in the shadow of MFMA slot K of region G
+  auto fill = [&](auto Gc, auto Kc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value, K = decltype(Kc)::value;
+    constexpr int NKS = GG::nks(G), NS = MPK * NKS, NSD = MPK * (NKS - 1);
+    // LDS-DMA pieces of chunk G+3 (its slot held chunk G-1, which every wave left behind at the previous barrier)
+    if constexpr (K < NSD) {
+      constexpr int ND = GG::ppw(G + 3), d0 = K * ND / NSD, d1 = (K + 1) * ND / NSD;
+      static_for<d1 - d0>([&](auto Ic) __attribute__((always_inline)) { dma_piece(std::integral_constant<int, G + 3>{}, std::integral_constant<int, d0 + decltype(Ic)::value>{}); });
+    }
+    // accumulator initial values: table rows of the layer-1 chunk two regions ahead (a gather), bias of the next layer-2/3 chunk (LDS)
+    if constexpr (K == 0 && GG::layer(G + 2) == 0 && G + 2 < NC) load_T(std::integral_constant<int, G + 2>{});
+    if constexpr (K == NS / 2 && (GG::layer(G + 1) == 1 || GG::layer(G + 1) == 2)) load_bias(std::integral_constant<int, G + 1>{});
+    // query slice of the head whose k projection this region computes (scored in the next region)
+    if constexpr (K == NS / 2 && GG::layer(G) == 3 && GG::rt(G) < 4) {
+      static_for<4>([&](auto Gq) __attribute__((always_inline)) {
+        constexpr int g = decltype(Gq)::value;
+        Qr[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, qoff + (32 * GG::rt(G) + 8 * g) * 4, 0, 0));
+      });
+    }
+    // epilogue of the previous chunk
+    {
+      // A layer's last row tile is finished inside the first region of the NEXT layer, which consumes the fragments it produces
+      // in its last two k-step groups (operands are assembled at the start of a group): layer epilogues end one group early
+      constexpr int NE = GG::epi_steps(G - 1), NSE = GG::layer(G - 1) < 3 ? NSD : NS;
+      if constexpr (K < NSE) {
+        constexpr int e0 = K * NE / NSE, e1 = (K + 1) * NE / NSE;
+        static_for<e1 - e0>([&](auto Ec) __attribute__((always_inline)) {
+          epi_step(std::integral_constant<int, G - 1>{}, std::integral_constant<int, e0 + decltype(Ec)::value>{}, std::integral_constant<bool, G == 0>{});
+        });
+      }
+    }
+  };
+
+  // ---------------------------------------------------------------- one region = one output row tile accumulated over all K
+  auto region = [&](auto Gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value;
+    constexpr int L = GG::layer(G), NKS = GG::nks(G), AB = G & 3, CK = GG::cumks(G);
+    constexpr bool ZI = L == 3;   // k / v projections have no bias: the first MFMA takes C = 0
+    static_for<NKS>([&](auto Kc) __attribute__((always_inline)) {
+      constexpr int ks = decltype(Kc)::value, pos = GG::rpos(CK + ks);
+      if constexpr (ks == NKS - 1) {
+        // chunk G+1 must have landed (only the pieces of G+2, G+3 may still fly) and every wave must be through with chunk G's
+        // slot reads; its last fragments are in registers already
+        wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      auto bsel = [&](auto Hi) __attribute__((always_inline)) {
+        if constexpr (L == 0) { if constexpr (decltype(Hi)::value) return frag4(Ph[ks]); else return frag4(Pl[ks]); }
+        else { if constexpr (decltype(Hi)::value) return frag4(Xh[(L + 1) & 1][ks]); else return frag4(Xl[(L + 1) & 1][ks]); }
+      };
+      const u32x4 bh = bsel(std::true_type{});
+      u32x4 bl = bh;
+      if constexpr (X3) bl = bsel(std::false_type{});
+      static_for<MPK>([&](auto Mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(Mc)::value, K = MPK * ks + m;
+        // A fragments two k-steps ahead; the first two of the next chunk wait for the barrier of the last group
+        if constexpr (ks + 2 < NKS) {
+          if constexpr (m == 0) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
+          if constexpr (X3 && m == 1) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 1>{});
+        } else if constexpr (ks == NKS - 1) {
+          if constexpr (m == 0) {
+            read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
+            if constexpr (X3) read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 1>{});
+            if constexpr (!X3) read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+          }
+          if constexpr (X3 && m == 1) {
+            read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+            read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 1>{});
+          }
+        }
+        if constexpr (X3) {
+          if constexpr (m == 0) acc[AB] = mfma(frl[pos], bh, (ZI && ks == 0) ? zero16 : acc[AB]);
+          else if constexpr (m == 1) acc[AB] = mfma(frh[pos], bl, acc[AB]);
+          else acc[AB] = mfma(frh[pos], bh, acc[AB]);
+        } else acc[AB] = mfma(frh[pos], bh, (ZI && ks == 0) ? zero16 : acc[AB]);
+        fill(Gc, std::integral_constant<int, K>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+
+  // ---------------------------------------------------------------- pipeline start
+  soff = (unsigned)(GG::gkb(NC - 1) * 1024 + (GG::ppw(NC - 1) - 1) * 4096);   // the "previous piece" of the very first one
+  static_for<3>([&](auto Cc) __attribute__((always_inline)) {
+    static_for<GG::ppw(decltype(Cc)::value)>([&](auto Ic) __attribute__((always_inline)) { dma_piece(Cc, Ic); });
+  });
+  prologue(tile);
+  load_T(std::integral_constant<int, 0>{}); load_T(std::integral_constant<int, 1>{});
+  wait_vmcnt<GG::ppw(1) + GG::ppw(2)>();   // conservative: the prologue's own loads are younger than every piece
+  __builtin_amdgcn_s_barrier();
+  read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1)>{}, std::integral_constant<int, 0>{});
+  read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1) + 1>{}, std::integral_constant<int, 0>{});
+  if constexpr (X3) {
+    read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1)>{}, std::integral_constant<int, 1>{});
+    read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1) + 1>{}, std::integral_constant<int, 1>{});
+  }
+
+  for (;;) {
+    static_for<NC>(region);
+    ooff_prev = ooff_cur;
+    tile += (int)nwg;
+    if (tile >= sc.ntiles) break;
+    prologue(tile);
+    load_T(std::integral_constant<int, 0>{}); load_T(std::integral_constant<int, 1>{});
+  }
+  // the last v head of the last tile
+  static_for<20>([&](auto Ec) __attribute__((always_inline)) { epi_step(std::integral_constant<int, NC - 1>{}, Ec, std::integral_constant<bool, true>{}); });
+  wait_vmcnt<0>();   // LDS-DMA prefetched for a tile that does not exist must land before the LDS is handed to another workgroup
+}
+
+// ---------------------------------------------------------------------------------------------------- packing
+__device__ __forceinline__ unsigned short pf2_f2bf(float x) {
+  unsigned int u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ int pf2_m(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }   // accumulator register -> row of the 32x32 tile
+
+// Stream: chunk (layer, rt) = [part hi/lo][k-step][lane][8 bf16] in A-fragment order (lane: out row 32 rt + (lane & 31), k-slots
+// 8 (lane >> 5) + t); then the resident block: ray_diff_fc fragments [layer][part][lane][8] (4 KB) and the bias tables (floats).
+__global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                          const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ b2,
+                                          const float* __restrict__ b3, const float* __restrict__ rd_w, unsigned short* __restrict__ out,
+                                          int NRT, int F) {
+  const int W = 32 * NRT, KSL = 2 * NRT;
+  const long long n_l1 = (long long)NRT * 6 * 512, n_lw = (long long)NRT * KSL * 512, n_kv = (long long)8 * KSL * 512;
+  const long long total = n_l1 + 2 * n_lw + n_kv;   // (chunk, k-step, lane, t) elements of one part
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) {
+    int layer; long long r = e;
+    if (r < n_l1) layer = 0; else if ((r -= n_l1) < n_lw) layer = 1; else if ((r -= n_lw) < n_lw) layer = 2; else { r -= n_lw; layer = 3; }
+    const int nks = layer == 0 ? 6 : KSL;
+    const int t = (int)(r & 7), lane = (int)((r >> 3) & 63);
+    long long r2 = r >> 9;
+    const int ks = (int)(r2 % nks), rt = (int)(r2 / nks);
+    const int hh = lane >> 5, orow = 32 * rt + (lane & 31);
+    float v = 0.f;
+    if (layer == 0) {
+      int col = -1;
+      if (ks < 4) {
+        const int ee = 8 * ks + t;
+        if (ee < 30) { const int a = ee / 10, rem = ee - 10 * a, f = (rem >> 1) + 5 * hh, comp = rem & 1; col = F + 3 + 6 * f + 3 * comp + a; }
+        else if (ee == 30) col = hh ? F + 2 : F;
+        else col = hh ? -1 : F + 1;
+      } else { const int o = pf2_m(8 * (ks - 4) + t, hh); col = o < 27 ? F + 63 + o : -1; }
+      if (col >= 0) v = w1[(size_t)orow * (F + 90) + col];
+    } else {
+      const int fin = 32 * (ks >> 1) + pf2_m(8 * (ks & 1) + t, hh);
+      if (layer == 1) v = w2[(size_t)orow * W + fin];
+      else if (layer == 2) v = w3[(size_t)orow * W + fin];
+      else v = orow < 128 ? wk[(size_t)orow * W + fin] : wv[(size_t)(orow - 128) * W + fin];
+    }
+    long long base;   // chunk base in bf16 elements (a chunk holds 2 parts x nks x 512)
+    if (layer == 0) base = (long long)rt * 2 * 6 * 512;
+    else base = (long long)NRT * 2 * 6 * 512 + ((long long)(layer - 1) * NRT + rt) * 2 * KSL * 512;
+    const long long in_part = ((long long)ks * 64 + lane) * 8 + t;
+    const unsigned short h = pf2_f2bf(v);
+    out[base + in_part] = h;
+    out[base + (long long)nks * 512 + in_part] = pf2_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+  }
+  // resident block
+  const long long res = 2LL * (NRT * 6 + (2 * NRT + 8) * KSL) * 512;   // bf16 elements of the stream
+  if (e < 2 * 512) {   // ray_diff_fc fragments: rd_w = W0[16][4], b0[16], W2[27][16], b2[27]
+    const int l = (int)(e >> 9), t = (int)(e & 7), lane = (int)((e >> 3) & 63), i = lane & 31, hh = lane >> 5;
+    float v = 0.f;
+    if (l == 0) { if (i < 16 && hh == 0 && t < 4) v = rd_w[i * 4 + t]; }
+    else if (i < 27) v = rd_w[80 + i * 16 + pf2_m(t, hh)];
+    const unsigned short h = pf2_f2bf(v);
+    out[res + (long long)l * 1024 + lane * 8 + t] = h;
+    out[res + (long long)l * 1024 + 512 + lane * 8 + t] = pf2_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+  }
+  if (e < 64 + 2 * W) {   // bias tables in accumulator order [rt][hh][r]
+    float* bt = reinterpret_cast<float*>(out + res + 2048);
+    const int i = (int)e;
+    float v;
+    if (i < 64) { const int l = i >> 5, hh = (i >> 4) & 1, m = pf2_m(i & 15, hh); v = l == 0 ? (m < 16 ? rd_w[64 + m] : 0.f) : (m < 27 ? rd_w[80 + 432 + m] : 0.f); }
+    else { const int q = i - 64, l = q / W, c = q - l * W, rt = c >> 5, hh = (c >> 4) & 1, f = 32 * rt + pf2_m(c & 15, hh); v = l == 0 ? b2[f] : b3[f]; }
+    bt[i] = v;
+  }
+}
+
+int g_num_cu = 0;
+
+}  // namespace
+
+size_t nl_point_stream2_bytes(int W) {
+  const int NRT = W / 32;
+  return (size_t)2 * (NRT * 6 + (2 * NRT + 8) * 2 * NRT) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + 4096;   // + slack: bf16 L1 chunks copy 8 k-steps
+}
+
+int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
+                          const float* rd_w, void* out, int W, int F, hipStream_t st) {
+  const int NRT = W / 32;
+  const long long total = ((long long)NRT * 6 + (2LL * NRT + 8) * 2 * NRT) * 512;
+  hipLaunchKernelGGL(pack_point_stream2_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv, b2, b3, rd_w,
+                     (unsigned short*)out, NRT, F);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+bool nl_point_fused2_supported(int W, int precision) { return precision != NL_PREC_F32 && (W == 128 || W == 256); }
+
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st) {
+  if (a.N <= 0) return NL_OK;
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
+    g_num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+  }
+  Pf2Scalars sc;
+  sc.dir_stride = a.dir_stride; sc.dir_div = a.dir_div > 0 ? a.dir_div : 1; sc.dir_magic = 0; sc.dir_shift = 0;
+  if (sc.dir_div > 1) {   // n / d for n < 2^31 as mulhi(n, ceil(2^(31+s) / d)) >> (s - 1), s = ceil(log2 d)
+    int s = 0;
+    while ((1ll << s) < sc.dir_div) ++s;
+    sc.dir_magic = (unsigned)(((1ull << (31 + s)) + (unsigned long long)sc.dir_div - 1) / (unsigned long long)sc.dir_div);
+    sc.dir_shift = s - 1;
+  }
+  sc.N = a.N; sc.M = a.M; sc.inv_span = a.inv_span; sc.ntiles = (int)nl_cdiv(a.N, 16);
+  if ((int64_t)a.N * 512 > 0x7fffffffll || ((int64_t)a.M + 1) * W * 4 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  sc.t_bytes = (unsigned)(((int64_t)a.M + 1) * W * 4);
+  const int nwg = sc.ntiles < g_num_cu ? (int)nl_xcd_grid(sc.ntiles) : g_num_cu;
+  dim3 grid(nwg);
+  const bool x3 = precision == NL_PREC_BF16X3;
+#define NL_PF2(NRT)                                                                                                                     \
+  do {                                                                                                                                  \
+    if (x3) hipLaunchKernelGGL((point_fused2_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz, \
+                               a.sp_dir, a.wstream2, sc);                                                                               \
+    else hipLaunchKernelGGL((point_fused2_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,  \
+                            a.sp_dir, a.wstream2, sc);                                                                                  \
+  } while (0)
+  if (W == 256) NL_PF2(8);
+  else if (W == 128) NL_PF2(4);
+  else return NL_ERR_UNSUPPORTED;
+#undef NL_PF2
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
