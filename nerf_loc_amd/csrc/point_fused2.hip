@@ -34,6 +34,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef PF2_KO
+#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention
+#endif
+constexpr int KO = PF2_KO;
+#ifdef PF2_TRACE
+__device__ unsigned long long pf2_trace[256];   // debug: cycle counter at every region start of one tile (block 0, wave 0)
+#endif
 constexpr int NBUF = 4;   // LDS ring slots; chunk c lives in slot c % 4, chunks c+1 .. c+3 are in flight while c is consumed
 
 template <int NRT, bool X3>
@@ -125,7 +132,7 @@ __device__ __forceinline__ void sincos_d(double x, double& s, double& c) {
   c = ((k + 1) & 2) ? -cc : cc;
 }
 
-struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; int N, M; float inv_span; int ntiles; unsigned t_bytes; };
+struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; unsigned dir_one; int N, M; float inv_span; int ntiles; unsigned t_bytes; };
 
 template <int NRT, bool X3>
 __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
@@ -211,107 +218,140 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   auto frag4 = [](const unsigned (&d)[4]) __attribute__((always_inline)) { return u32x4{d[0], d[1], d[2], d[3]}; };
 
   // ---------------------------------------------------------------- tile prologue: layer-1 operands (model.py:394-409)
-  auto prologue = [&](int t) __attribute__((always_inline)) {
-    const int n = t * 16 + wave * 4 + (j >> 3);
-    const bool live = n < sc.N;
-    const int nn = live ? n : sc.N - 1;
-    ooff_cur = (live && kk == 0) ? (unsigned)nn * 512u + 16u * hh : 0x80000000u;
-    const bool have = live && kk < sc.M && sc.M > 0;   // knn_gather zero-fills k >= M (knn_utils.py:211-220)
-    const int id = p_idx[(size_t)nn * 8 + kk];
-    toff = (unsigned)(have ? id : sc.M) * (unsigned)(W * 4) + 64u * hh;   // row M holds the bias alone
-    qoff = (unsigned)nn * 512u + 16u * hh;
-    const float qx = p_xyz[3 * (size_t)nn], qy = p_xyz[3 * (size_t)nn + 1], qz = p_xyz[3 * (size_t)nn + 2];
-    const float px = have ? p_sp_xyz[3 * (size_t)id] : 0.f, py = have ? p_sp_xyz[3 * (size_t)id + 1] : 0.f, pz = have ? p_sp_xyz[3 * (size_t)id + 2] : 0.f;
-    const float off[3] = {(qx - px) * sc.inv_span, (qy - py) * sc.inv_span, (qz - pz) * sc.inv_span};
-    // ---- ray direction difference (model.py:396-399) -> ray_diff_fc (model.py:36-39) on the matrix pipe
-    {
-      float dx, dy, dz;
-      if (p_dir) {
-        const unsigned ray = sc.dir_div == 1 ? (unsigned)nn : (__umulhi((unsigned)nn, sc.dir_magic) >> sc.dir_shift);
-        const size_t dr = (size_t)ray * sc.dir_stride;
-        dx = p_dir[dr]; dy = p_dir[dr + 1]; dz = p_dir[dr + 2];
-      } else {   // model.py:391-392: the nearest neighbour's direction
-        const int i0 = p_idx[(size_t)nn * 8];
-        const bool ok = live && sc.M > 0;
-        dx = ok ? p_sp_dir[4 * (size_t)i0] : 0.f; dy = ok ? p_sp_dir[4 * (size_t)i0 + 1] : 0.f; dz = ok ? p_sp_dir[4 * (size_t)i0 + 2] : 0.f;
-      }
-      const float ndx = have ? p_sp_dir[4 * (size_t)id] : 0.f, ndy = have ? p_sp_dir[4 * (size_t)id + 1] : 0.f, ndz = have ? p_sp_dir[4 * (size_t)id + 2] : 0.f;
-      float r0 = dx - ndx, r1 = dy - ndy, r2 = dz - ndz;
-      const float nr = sqrtf(r0 * r0 + r1 * r1 + r2 * r2) + 1e-8f;
-      r0 /= nr; r1 /= nr; r2 /= nr;
-      const float r3 = dx * ndx + dy * ndy + dz * ndz;
-      // B fragment of the first layer: k-slots 0..3 of half 0
-      u32x4 bh = {0, 0, 0, 0}, bl = {0, 0, 0, 0};
-      {
+  // Written as a list of micro-steps so that the NEXT tile's operands are produced in the MFMA shadow of the current tile's k / v
+  // regions (the other ping-pong half of X is dead there, so the registers are free); the first tile runs the list back to back.
+  // All loads are unconditional: rows that must read as zero (k >= M: knn_gather zero-fill, knn_utils.py:211-220; rows past N)
+  // carry an out-of-range buffer offset.
+  const __amdgpu_buffer_rsrc_t rSX = __builtin_amdgcn_make_buffer_rsrc((void*)p_sp_xyz, 0, sc.M * 12, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rSD = __builtin_amdgcn_make_buffer_rsrc((void*)p_sp_dir, 0, sc.M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)p_dir, 0, p_dir ? 0x7fffffff : 0, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  int pn_tile = tile, pn_nn = 0, pn_id = 0;
+  unsigned pn_ooff = OOB, pn_toff = 0, pn_qoff = 0;
+  bool pn_have = false, pn_live = false;
+  float pq[3], pdv[3], pdv0[3], pp[3], pnd[3], poff[3], prd[4];
+  unsigned rdbh[2] = {0, 0}, rdbl[2] = {0, 0}, hidh[4] = {0, 0, 0, 0}, hidl[4] = {0, 0, 0, 0};
+  f32x16 pa = zero16;
+  f32x4 pb[4];
+  double sx[3], skd[3], sr[3], sr2[3], su[3], sw[3], ss[3], scs[3];
+  int skq[3];
+  constexpr int NPL = 2, NPC = 55, NPRO = NPL + NPC;   // load steps, compute steps
+  auto pro_step = [&](auto Ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(Ic)::value;
+    if constexpr (I == 0) {   // ---- loads that depend on the tile number only
+      const int n = pn_tile * 16 + wave * 4 + (j >> 3);
+      const bool live = n < sc.N;
+      pn_nn = live ? n : sc.N - 1;
+      pn_ooff = (live && kk == 0) ? (unsigned)pn_nn * 512u + 16u * hh : OOB;
+      pn_qoff = (unsigned)pn_nn * 512u + 16u * hh;
+      pn_live = live;
+      pn_have = live && kk < sc.M && sc.M > 0;
+      pn_id = p_idx[(size_t)pn_nn * 8 + kk];
+      pq[0] = p_xyz[3 * (size_t)pn_nn]; pq[1] = p_xyz[3 * (size_t)pn_nn + 1]; pq[2] = p_xyz[3 * (size_t)pn_nn + 2];
+      const unsigned ray = (__umulhi((unsigned)pn_nn, sc.dir_magic) >> sc.dir_shift) + (unsigned)pn_nn * sc.dir_one;   // branch-free n / dir_div
+      const unsigned dro = ray * (unsigned)sc.dir_stride * 4u;   // out of range (reads 0) when there is no direction array
+      pdv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, dro, 0, 0));
+      pdv[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, dro + 4, 0, 0));
+      pdv[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, dro + 8, 0, 0));
+    } else if constexpr (I == 1) {   // ---- gathers that depend on the neighbour index
+      pn_toff = (unsigned)(pn_have ? pn_id : sc.M) * (unsigned)(W * 4) + 64u * hh;   // row M holds the bias alone
+      const unsigned so = pn_have ? (unsigned)pn_id : OOB / 16;
+      pp[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSX, so * 12, 0, 0));
+      pp[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSX, so * 12 + 4, 0, 0));
+      pp[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rSX, so * 12 + 8, 0, 0));
+      const f32x4 nd = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rSD, so * 16, 0, 0));
+      pnd[0] = nd[0]; pnd[1] = nd[1]; pnd[2] = nd[2];
+      // model.py:391-392: without a direction array the nearest neighbour's direction is used (first lane of the sample's 8)
+      const int i0 = __shfl(pn_id, lane & ~7, 64);
+      const bool ok0 = !p_dir && pn_live && sc.M > 0;
+      const unsigned so0 = ok0 ? (unsigned)i0 * 16u : OOB;
+      const f32x4 d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rSD, so0, 0, 0));
+      pdv0[0] = d0[0]; pdv0[1] = d0[1]; pdv0[2] = d0[2];
+    } else {
+      constexpr int C = I - NPL;
+      if constexpr (C == 0) {
+        pdv[0] += pdv0[0]; pdv[1] += pdv0[1]; pdv[2] += pdv0[2];   // exactly one of the two sources is non-zero
+        poff[0] = (pq[0] - pp[0]) * sc.inv_span; poff[1] = (pq[1] - pp[1]) * sc.inv_span; poff[2] = (pq[2] - pp[2]) * sc.inv_span;
+        prd[0] = pdv[0] - pnd[0]; prd[1] = pdv[1] - pnd[1]; prd[2] = pdv[2] - pnd[2];
+        prd[3] = pdv[0] * pnd[0] + pdv[1] * pnd[1] + pdv[2] * pnd[2];
+      } else if constexpr (C == 1) {
+        pq[0] = sqrtf(prd[0] * prd[0] + prd[1] * prd[1] + prd[2] * prd[2]) + 1e-8f;   // pq[0] is free now: the norm
+      } else if constexpr (C == 2) { prd[0] /= pq[0]; prd[1] /= pq[0]; }
+      else if constexpr (C == 3) {
+        prd[2] /= pq[0];
         unsigned h0 = 0, l0 = 0, h1 = 0, l1 = 0;
-        split2<X3>(r0, r1, h0, l0); split2<X3>(r2, r3, h1, l1);
-        bh[0] = hh ? 0u : h0; bh[1] = hh ? 0u : h1;
-        if (X3) { bl[0] = hh ? 0u : l0; bl[1] = hh ? 0u : l1; }
-      }
-      auto rd_layer = [&](auto Lc, const u32x4& xh, const u32x4& xl) __attribute__((always_inline)) {
-        constexpr int l = decltype(Lc)::value;
+        split2<X3>(prd[0], prd[1], h0, l0); split2<X3>(prd[2], prd[3], h1, l1);
+        rdbh[0] = hh ? 0u : h0; rdbh[1] = hh ? 0u : h1;   // k-slots 0..3 of half 0
+        if (X3) { rdbl[0] = hh ? 0u : l0; rdbl[1] = hh ? 0u : l1; }
+      } else if constexpr (C == 4 || C == 7) {   // ray_diff_fc layers on the matrix pipe (model.py:36-39)
+        constexpr int l = C == 4 ? 0 : 1;
+        const u32x4 xh = l == 0 ? u32x4{rdbh[0], rdbh[1], 0u, 0u} : frag4(hidh);
+        const u32x4 xl = l == 0 ? u32x4{rdbl[0], rdbl[1], 0u, 0u} : frag4(hidl);
         const u32x4 ah = __builtin_bit_cast(u32x4, lds_all[GG::RES_RD + (l * PARTS + 0) * 64 + lane]);
-        f32x16 a;
         if (X3) {
           const u32x4 al = __builtin_bit_cast(u32x4, lds_all[GG::RES_RD + (l * PARTS + (PARTS - 1)) * 64 + lane]);
-          a = mfma(al, xh, zero16);
-          a = mfma(ah, xl, a);
-          a = mfma(ah, xh, a);
-        } else a = mfma(ah, xh, zero16);
-        return a;
-      };
-      const f32x16 a1 = rd_layer(std::integral_constant<int, 0>{}, bh, bl);
-      unsigned hidh[4] = {0, 0, 0, 0}, hidl[4] = {0, 0, 0, 0};
-      {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sres + 16 * hh), b1 = *reinterpret_cast<const f32x4*>(sres + 16 * hh + 4);
-        finish_pair(a1[0] + b0[0], a1[1] + b0[1], hidh[0], hidl[0]);
-        finish_pair(a1[2] + b0[2], a1[3] + b0[3], hidh[1], hidl[1]);
-        finish_pair(a1[4] + b1[0], a1[5] + b1[1], hidh[2], hidl[2]);
-        finish_pair(a1[6] + b1[2], a1[7] + b1[3], hidh[3], hidl[3]);
-      }
-      const f32x16 a2 = rd_layer(std::integral_constant<int, 1>{}, frag4(hidh), frag4(hidl));
-      static_for<4>([&](auto Gc) __attribute__((always_inline)) {
-        constexpr int g = decltype(Gc)::value;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(sres + 32 + 16 * hh + 4 * g);
-        finish_pair(a2[4 * g] + b[0], a2[4 * g + 1] + b[1], Ph[4 + g / 2][(2 * g) & 3], Pl[4 + g / 2][(2 * g) & 3]);
-        finish_pair(a2[4 * g + 2] + b[2], a2[4 * g + 3] + b[3], Ph[4 + g / 2][(2 * g + 1) & 3], Pl[4 + g / 2][(2 * g + 1) & 3]);
-      });
-    }
-    // ---- positional encoding (utils.py:5-35).  Half hh owns octaves 5 hh .. 5 hh + 4 of every axis: value e = 10 a + 2 f' + comp
-    // (comp 0 = sin, 1 = cos), then e = 30, 31 = raw (x, y) for half 0 and (z, 0) for half 1.  One accurate fp64 evaluation per
-    // axis at the half's first octave + the double-angle recurrence in fp64 (abs error < 1e-12: correctly rounded in fp32).
-    {
-      const double scale = hh ? 32.0 : 1.0;
-      float v[32];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        double s, c;
-        sincos_d((double)off[a] * scale, s, c);
-#pragma unroll
-        for (int f = 0; f < 5; ++f) {
-          v[10 * a + 2 * f] = (float)s; v[10 * a + 2 * f + 1] = (float)c;
-          if (f < 4) {
-            const double s2 = 2.0 * s * c;
-            c = fma(-2.0 * s, s, 1.0);
-            s = s2;
-          }
+          pa = mfma(al, xh, zero16);
+          pa = mfma(ah, xl, pa);
+          pa = mfma(ah, xh, pa);
+        } else pa = mfma(ah, xh, zero16);
+        static_for<l == 0 ? 2 : 4>([&](auto Gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(Gc)::value;
+          pb[g] = *reinterpret_cast<const f32x4*>(sres + 32 * l + 16 * hh + 4 * g);
+        });
+      } else if constexpr (C == 5 || C == 6) {   // hidden layer: registers 0..7 = units m(r, hh) < 16
+        constexpr int g = C - 5;
+        finish_pair(pa[4 * g] + pb[g][0], pa[4 * g + 1] + pb[g][1], hidh[2 * g], hidl[2 * g]);
+        finish_pair(pa[4 * g + 2] + pb[g][2], pa[4 * g + 3] + pb[g][3], hidh[2 * g + 1], hidl[2 * g + 1]);
+      } else if constexpr (C >= 8 && C <= 11) {   // output layer -> k-steps 4, 5
+        constexpr int g = C - 8;
+        finish_pair(pa[4 * g] + pb[g][0], pa[4 * g + 1] + pb[g][1], Ph[4 + g / 2][(2 * g) & 3], Pl[4 + g / 2][(2 * g) & 3]);
+        finish_pair(pa[4 * g + 2] + pb[g][2], pa[4 * g + 3] + pb[g][3], Ph[4 + g / 2][(2 * g + 1) & 3], Pl[4 + g / 2][(2 * g + 1) & 3]);
+      } else if constexpr (C >= 12 && C < 39) {
+        // ---- positional encoding (utils.py:5-35).  Half hh owns octaves 5 hh .. 5 hh + 4 of every axis: value e = 10 a + 2 f' + comp
+        // (comp 0 = sin, 1 = cos), then e = 30, 31 = raw (x, y) for half 0 and (z, 0) for half 1.  One accurate fp64 evaluation per
+        // axis at the half's first octave (Cody-Waite to [-pi/4, pi/4] + Taylor, error < 1e-11) + the double-angle recurrence in
+        // fp64 (abs error < 1e-12: correctly rounded in fp32).  Nine sub-steps per axis, the three axes interleaved.
+        constexpr int x = (C - 12) / 3, a = (C - 12) % 3;
+        if constexpr (x == 0) { sx[a] = (double)poff[a] * (hh ? 32.0 : 1.0); skd[a] = rint(sx[a] * 0.63661977236758134308); }
+        else if constexpr (x == 1) { sr[a] = fma(-skd[a], 1.5707963267948966, sx[a]); sr[a] = fma(-skd[a], 6.123233995736766e-17, sr[a]); }
+        else if constexpr (x == 2) { sr2[a] = sr[a] * sr[a]; skq[a] = (int)skd[a]; su[a] = fma(sr2[a], -1.0 / 39916800, 1.0 / 362880); }
+        else if constexpr (x == 3) { su[a] = fma(sr2[a], su[a], -1.0 / 5040); su[a] = fma(sr2[a], su[a], 1.0 / 120); }
+        else if constexpr (x == 4) { su[a] = fma(sr2[a], su[a], -1.0 / 6); sw[a] = fma(sr2[a], 1.0 / 479001600, -1.0 / 3628800); }
+        else if constexpr (x == 5) { sw[a] = fma(sr2[a], sw[a], 1.0 / 40320); sw[a] = fma(sr2[a], sw[a], -1.0 / 720); }
+        else if constexpr (x == 6) { sw[a] = fma(sr2[a], sw[a], 1.0 / 24); sw[a] = fma(sr2[a], sw[a], -0.5); }
+        else if constexpr (x == 7) { su[a] = fma(sr[a] * sr2[a], su[a], sr[a]); sw[a] = fma(sr2[a], sw[a], 1.0); }
+        else {
+          const bool swp = skq[a] & 1;
+          const double s1 = swp ? sw[a] : su[a], c1 = swp ? su[a] : sw[a];
+          ss[a] = (skq[a] & 2) ? -s1 : s1;
+          scs[a] = ((skq[a] + 1) & 2) ? -c1 : c1;
         }
-      }
-      v[30] = hh ? off[2] : off[0]; v[31] = hh ? 0.f : off[1];
-      static_for<16>([&](auto Pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(Pc)::value;
+      } else if constexpr (C >= 39 && C < 54) {
+        constexpr int f = (C - 39) / 3, a = (C - 39) % 3, p = 5 * a + f;
         unsigned h = 0, l = 0;
-        split2<X3>(v[2 * p], v[2 * p + 1], h, l);
+        split2<X3>((float)ss[a], (float)scs[a], h, l);
         Ph[p / 4][p & 3] = h;
         if (X3) Pl[p / 4][p & 3] = l;
-      });
+        if constexpr (f < 4) {
+          const double s2 = 2.0 * ss[a] * scs[a];
+          scs[a] = fma(-2.0 * ss[a], ss[a], 1.0);
+          ss[a] = s2;
+        }
+      } else {
+        unsigned h = 0, l = 0;
+        split2<X3>(hh ? poff[2] : poff[0], hh ? 0.f : poff[1], h, l);
+        Ph[3][3] = h;
+        if (X3) Pl[3][3] = l;
+      }
     }
   };
-  auto load_T = [&](auto Cc) __attribute__((always_inline)) {   // table-row slice of layer-1 chunk c = initial value of its accumulator
+  // prologue compute steps of region G: the six k / v regions K0 .. V1 share them evenly
+  auto pro_lo = [](int g) constexpr { return g < 3 * NRT ? 0 : g >= 3 * NRT + 6 ? NPC : (g - 3 * NRT) * NPC / 6; };
+  auto load_T = [&](auto Cc, unsigned tof) __attribute__((always_inline)) {   // table-row slice of layer-1 chunk c = initial value of its accumulator
     constexpr int c = decltype(Cc)::value;
     static_for<4>([&](auto Gc) __attribute__((always_inline)) {
       constexpr int g = decltype(Gc)::value;
-      const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, toff + (32 * GG::rt(c) + 4 * g) * 4, 0, 0));
+      const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, tof + (32 * GG::rt(c) + 4 * g) * 4, 0, 0));
       acc[c & 3][4 * g] = t4[0]; acc[c & 3][4 * g + 1] = t4[1]; acc[c & 3][4 * g + 2] = t4[2]; acc[c & 3][4 * g + 3] = t4[3];
     });
   };
@@ -382,12 +422,24 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     constexpr int G = decltype(Gc)::value, K = decltype(Kc)::value;
     constexpr int NKS = GG::nks(G), NS = MPK * NKS, NSD = MPK * (NKS - 1);
     // LDS-DMA pieces of chunk G+3 (its slot held chunk G-1, which every wave left behind at the previous barrier)
-    if constexpr (K < NSD) {
+    if constexpr (K < NSD && !(KO & 4)) {
       constexpr int ND = GG::ppw(G + 3), d0 = K * ND / NSD, d1 = (K + 1) * ND / NSD;
       static_for<d1 - d0>([&](auto Ic) __attribute__((always_inline)) { dma_piece(std::integral_constant<int, G + 3>{}, std::integral_constant<int, d0 + decltype(Ic)::value>{}); });
     }
     // accumulator initial values: table rows of the layer-1 chunk two regions ahead (a gather), bias of the next layer-2/3 chunk (LDS)
-    if constexpr (K == 0 && GG::layer(G + 2) == 0 && G + 2 < NC) load_T(std::integral_constant<int, G + 2>{});
+    if constexpr (K == 0 && GG::layer(G + 2) == 0) {
+      if constexpr (G + 2 < NC) load_T(std::integral_constant<int, G + 2>{}, toff);
+      else load_T(std::integral_constant<int, G + 2 - NC>{}, pn_toff);   // the next tile's first two row tiles
+    }
+    // the next tile's prologue: tile-number loads at the start of layer 3, neighbour gathers half a layer later, arithmetic under k / v
+    if constexpr (!(KO & 1)) {
+      if constexpr (K == 0 && G == 2 * NRT) pro_step(std::integral_constant<int, 0>{});
+      if constexpr (K == 0 && G == 2 * NRT + NRT / 2) pro_step(std::integral_constant<int, 1>{});
+      if constexpr (G >= 3 * NRT && G < 3 * NRT + 6) {
+        constexpr int lo = pro_lo(G), cnt = pro_lo(G + 1) - lo, c0 = K * cnt / NS, c1 = (K + 1) * cnt / NS;
+        static_for<c1 - c0>([&](auto Ic) __attribute__((always_inline)) { pro_step(std::integral_constant<int, NPL + lo + c0 + decltype(Ic)::value>{}); });
+      }
+    }
     if constexpr (K == NS / 2 && (GG::layer(G + 1) == 1 || GG::layer(G + 1) == 2)) load_bias(std::integral_constant<int, G + 1>{});
     // query slice of the head whose k projection this region computes (scored in the next region)
     if constexpr (K == NS / 2 && GG::layer(G) == 3 && GG::rt(G) < 4) {
@@ -401,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       // A layer's last row tile is finished inside the first region of the NEXT layer, which consumes the fragments it produces
       // in its last two k-step groups (operands are assembled at the start of a group): layer epilogues end one group early
       constexpr int NE = GG::epi_steps(G - 1), NSE = GG::layer(G - 1) < 3 ? NSD : NS;
-      if constexpr (K < NSE) {
+      if constexpr (K < NSE && !((KO & 2) && GG::layer(G - 1) < 3) && !((KO & 8) && GG::layer(G - 1) == 3)) {
         constexpr int e0 = K * NE / NSE, e1 = (K + 1) * NE / NSE;
         static_for<e1 - e0>([&](auto Ec) __attribute__((always_inline)) {
           epi_step(std::integral_constant<int, G - 1>{}, std::integral_constant<int, e0 + decltype(Ec)::value>{}, std::integral_constant<bool, G == 0>{});
@@ -411,8 +463,16 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   };
 
   // ---------------------------------------------------------------- one region = one output row tile accumulated over all K
+  int trace_it = 0;
+  (void)trace_it;
   auto region = [&](auto Gc) __attribute__((always_inline)) {
     constexpr int G = decltype(Gc)::value;
+#ifdef PF2_TRACE
+    if (blockIdx.x == 0 && wave == 0 && trace_it < 4) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) pf2_trace[trace_it * 64 + G] = t;
+    }
+#endif
     constexpr int L = GG::layer(G), NKS = GG::nks(G), AB = G & 3, CK = GG::cumks(G);
     constexpr bool ZI = L == 3;   // k / v projections have no bias: the first MFMA takes C = 0
     static_for<NKS>([&](auto Kc) __attribute__((always_inline)) {
@@ -420,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       if constexpr (ks == NKS - 1) {
         // chunk G+1 must have landed (only the pieces of G+2, G+3 may still fly) and every wave must be through with chunk G's
         // slot reads; its last fragments are in registers already
-        wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
+        if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
@@ -464,8 +524,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   static_for<3>([&](auto Cc) __attribute__((always_inline)) {
     static_for<GG::ppw(decltype(Cc)::value)>([&](auto Ic) __attribute__((always_inline)) { dma_piece(Cc, Ic); });
   });
-  prologue(tile);
-  load_T(std::integral_constant<int, 0>{}); load_T(std::integral_constant<int, 1>{});
+  static_for<NPRO>(pro_step);   // the first tile's prologue, back to back
+  toff = pn_toff; qoff = pn_qoff; ooff_cur = pn_ooff;
+  load_T(std::integral_constant<int, 0>{}, toff); load_T(std::integral_constant<int, 1>{}, toff);
   wait_vmcnt<GG::ppw(1) + GG::ppw(2)>();   // conservative: the prologue's own loads are younger than every piece
   __builtin_amdgcn_s_barrier();
   read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1)>{}, std::integral_constant<int, 0>{});
@@ -476,12 +537,18 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   }
 
   for (;;) {
+    pn_tile = tile + (int)nwg;   // rows past N are clamped inside the steps: the last tile prepares a tile that is never computed
     static_for<NC>(region);
-    ooff_prev = ooff_cur;
-    tile += (int)nwg;
+#ifdef PF2_TRACE
+    if (blockIdx.x == 0 && wave == 0 && trace_it < 4) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) pf2_trace[trace_it * 64 + NC] = t;
+    }
+    ++trace_it;
+#endif
+    ooff_prev = ooff_cur; ooff_cur = pn_ooff; toff = pn_toff; qoff = pn_qoff;
+    tile = pn_tile;
     if (tile >= sc.ntiles) break;
-    prologue(tile);
-    load_T(std::integral_constant<int, 0>{}); load_T(std::integral_constant<int, 1>{});
   }
   // the last v head of the last tile
   static_for<20>([&](auto Ec) __attribute__((always_inline)) { epi_step(std::integral_constant<int, NC - 1>{}, Ec, std::integral_constant<bool, true>{}); });
@@ -578,6 +645,12 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
   return NL_OK;
 }
 
+#ifdef PF2_TRACE
+extern "C" __attribute__((visibility("default"))) int nl_debug_pf2_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pf2_trace), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
+
 bool nl_point_fused2_supported(int W, int precision) { return precision != NL_PREC_F32 && (W == 128 || W == 256); }
 
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st) {
@@ -589,7 +662,7 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
     g_num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
   }
   Pf2Scalars sc;
-  sc.dir_stride = a.dir_stride; sc.dir_div = a.dir_div > 0 ? a.dir_div : 1; sc.dir_magic = 0; sc.dir_shift = 0;
+  sc.dir_stride = a.dir_stride; sc.dir_div = a.dir_div > 0 ? a.dir_div : 1; sc.dir_magic = 0; sc.dir_shift = 0; sc.dir_one = sc.dir_div == 1 ? 1u : 0u;   // divisor 1: magic 0 (mulhi = 0) + n * 1
   if (sc.dir_div > 1) {   // n / d for n < 2^31 as mulhi(n, ceil(2^(31+s) / d)) >> (s - 1), s = ceil(log2 d)
     int s = 0;
     while ((1ll << s) < sc.dir_div) ++s;
@@ -610,7 +683,9 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
                             a.sp_dir, a.wstream2, sc);                                                                                  \
   } while (0)
   if (W == 256) NL_PF2(8);
+#if PF2_KO == 0
   else if (W == 128) NL_PF2(4);
+#endif
   else return NL_ERR_UNSUPPORTED;
 #undef NL_PF2
   NL_LAUNCH_CHECK();
