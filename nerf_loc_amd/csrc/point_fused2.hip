@@ -70,9 +70,10 @@ struct Geo {
   static constexpr int STREAM_KB = 2 * (NRT * KS1 + (2 * NRT + 8) * KSL);
   static constexpr int RES_RD = NBUF * SLOT;                 // resident: ray_diff_fc A fragments [layer][part][64] uint4
   static constexpr int RES_BIAS = RES_RD + 2 * PARTS * 64;   // resident: biases in accumulator order, floats [rd1 32 | rd2 32 | L2 W | L3 W]
-  static constexpr int LDS_U4 = RES_BIAS + (64 + 2 * W) / 4;
+  static constexpr int RES_ATT = RES_BIAS + (64 + 2 * W) / 4;   // attention weights [wave][head][32 rows] floats (wave-private)
+  static constexpr int LDS_U4 = RES_ATT + 4 * 4 * 32 / 4;
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
-  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 9 : 20); }
+  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 10 : 10); }
   static constexpr int RL = cumks(NC) % 3 == 0 ? 3 : 4;   // A-fragment register ring (3 k-steps are live)
   static constexpr int rpos(int runks) { return runks % RL; }
   static_assert(NC % NBUF == 0 && cumks(NC) % RL == 0, "ring positions must be tile-periodic");
@@ -106,6 +107,20 @@ __device__ __forceinline__ float vmax(float a, float b) {   // bare v_max_f32 (f
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
+}
+// LeakyReLU of a pair + its bf16 hi word, one statement (no compiler-inserted boundary nops between the five instructions)
+__device__ __forceinline__ unsigned lrelu_hi2(float& v0, float& v1) {
+  unsigned hi; float t0, t1;
+  asm("v_mul_f32 %3, 0x3c23d70a, %1\n\tv_mul_f32 %4, 0x3c23d70a, %2\n\tv_max_f32 %1, %1, %3\n\tv_max_f32 %2, %2, %4\n\tv_cvt_pk_bf16_f32 %0, %1, %2"
+      : "=&v"(hi), "+v"(v0), "+v"(v1), "=&v"(t0), "=&v"(t1));
+  return hi;
+}
+// lo word of a pair: bf16(v - float(hi))
+__device__ __forceinline__ unsigned lo2(float v0, float v1, unsigned hi) {
+  unsigned lo; float t0, t1;
+  asm("v_lshlrev_b32 %1, 16, %5\n\tv_and_b32 %2, 0xffff0000, %5\n\tv_sub_f32 %1, %3, %1\n\tv_sub_f32 %2, %4, %2\n\tv_cvt_pk_bf16_f32 %0, %1, %2"
+      : "=&v"(lo), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi));
+  return lo;
 }
 // hi/lo split of a pair: hi = bf16(v), lo = bf16(v - float(hi))
 template <bool X3>
@@ -198,10 +213,12 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   float ev0 = 0.f, ev1 = 0.f, ap = 0.f, amx = 0.f, aee = 0.f, ase = 0.f;
   unsigned ehi = 0;
   float ov[4];
+  f32x4 aw[4];
   unsigned ooff_cur = 0x80000000u, ooff_prev = 0x80000000u;   // byte offset of the lane's slice of O; out of range (= dropped) for lanes that do not store
   unsigned toff = 0, qoff = 0;                                // byte offsets of the lane's table row / query slice
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* sres = reinterpret_cast<const float*>(lds_all + GG::RES_BIAS);
+  float* satt = reinterpret_cast<float*>(lds_all + GG::RES_ATT) + wave * 128;
 
   auto mfma = [](const u32x4& a, const u32x4& b, const f32x16& c) __attribute__((always_inline)) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -242,7 +259,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       const int n = pn_tile * 16 + wave * 4 + (j >> 3);
       const bool live = n < sc.N;
       pn_nn = live ? n : sc.N - 1;
-      pn_ooff = (live && kk == 0) ? (unsigned)pn_nn * 512u + 16u * hh : OOB;
+      // O slice of the transposed v heads: lane = output dim (lane & 31) of the wave's four samples, half 0 stores
+      pn_ooff = hh ? OOB : (unsigned)(pn_tile * 16 + wave * 4) * 512u + 4u * j;
       pn_qoff = (unsigned)pn_nn * 512u + 16u * hh;
       pn_live = live;
       pn_have = live && kk < sc.M && sc.M > 0;
@@ -385,13 +403,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       constexpr int fo = 2 * RT + (p >> 2), d = p & 3;
       if constexpr (sub == 0) {
         ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
-        ev0 = vmax(ev0, ev0 * 0.01f); ev1 = vmax(ev1, ev1 * 0.01f);   // LeakyReLU
-        ehi = cvt_pk_bf16(ev0, ev1);
+        ehi = lrelu_hi2(ev0, ev1);
         Xh[out][fo][d] = ehi;
-      } else {
-        const float f0 = __uint_as_float(ehi << 16), f1 = __uint_as_float(ehi & 0xffff0000u);
-        Xl[out][fo][d] = cvt_pk_bf16(ev0 - f0, ev1 - f1);
-      }
+      } else Xl[out][fo][d] = lo2(ev0, ev1, ehi);
     } else if constexpr (RT < 4) {   // k projection of head RT: scores, softmax over the 8 neighbours (lanes) of a sample
       if constexpr (E < 4) {
         if constexpr (E == 0) ap = Qr[0][0] * acc[AB][0]; else ap = fmaf(Qr[E][0], acc[AB][4 * E], ap);
@@ -404,15 +418,31 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       } else if constexpr (E == 5) amx = nl_max8(ap);
       else if constexpr (E == 6) aee = expf(ap - amx);
       else if constexpr (E == 7) ase = nl_sum8(aee);
-      else att[RT] = aee / ase;
-    } else {   // v projection of head RT-4: attention-weighted sum over the 8 neighbours
-      constexpr int h = RT - 4, g = E / 5, i = E % 5;
-      if constexpr (i < 4) ov[i] = nl_sum8(att[h] * acc[AB][4 * g + i]);
-      else {
-        // one lane per (sample, half) stores; the other lanes carry an out-of-range offset and are dropped by the buffer bounds
-        // check — a source-level `if` would cut the tile body into basic blocks at every store
-        const unsigned oo = PREV ? ooff_prev : ooff_cur;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{ov[0], ov[1], ov[2], ov[3]}), rO, oo + 4 * (32 * h + 8 * g), 0, 0);
+      else if constexpr (E == 8) att[RT] = aee / ase;
+      else satt[RT * 32 + j] = att[RT];   // both halves hold the same value; every lane writes (no divergent store, no branch)
+    } else {
+      // v projection of head h, computed TRANSPOSED (activations = A operand): lane = output dim n, registers = neighbour rows
+      // m(r, hh) = (r & 3) + 8 (r >> 2) + 4 hh, i.e. sample r >> 2, neighbours (r & 3) + 4 hh.  The attention-weighted sum over the
+      // 8 neighbours is 4 FMAs per sample in the lane + one cross-half add, instead of a 3-step DPP reduction per value.
+      constexpr int h = RT - 4;
+      if constexpr (E < 4) aw[E] = *reinterpret_cast<const f32x4*>(satt + h * 32 + 8 * E + 4 * hh);   // weights of sample E's neighbours 4 hh .. 4 hh + 3
+      else if constexpr (E < 8) {
+        constexpr int sI = E - 4;
+        float o = aw[sI][0] * acc[AB][4 * sI];
+        o = fmaf(aw[sI][1], acc[AB][4 * sI + 1], o);
+        o = fmaf(aw[sI][2], acc[AB][4 * sI + 2], o);
+        o = fmaf(aw[sI][3], acc[AB][4 * sI + 3], o);
+        ov[sI] = o;
+      } else if constexpr (E == 8) {
+        ov[0] += __shfl_xor(ov[0], 32, 64); ov[1] += __shfl_xor(ov[1], 32, 64);
+        ov[2] += __shfl_xor(ov[2], 32, 64); ov[3] += __shfl_xor(ov[3], 32, 64);
+      } else {
+        // lanes of half 0 store dim n of the wave's 4 samples; half 1 and samples past N are out of range (dropped by the bounds check)
+        const unsigned oo = (PREV ? ooff_prev : ooff_cur) + 4 * 32 * h;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[0]), rO, oo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[1]), rO, oo + 512, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[2]), rO, oo + 1024, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[3]), rO, oo + 1536, 0, 0);
       }
     }
   };
@@ -508,11 +538,13 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
             read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 1>{});
           }
         }
+        constexpr bool TR = L == 3 && GG::rt(G) >= 4;   // v heads: D = X . Wv^T (rows = neighbour rows) instead of D^T
+        auto mm = [&](const u32x4& wf, const u32x4& xf, const f32x16& c) __attribute__((always_inline)) { return TR ? mfma(xf, wf, c) : mfma(wf, xf, c); };
         if constexpr (X3) {
-          if constexpr (m == 0) acc[AB] = mfma(frl[pos], bh, (ZI && ks == 0) ? zero16 : acc[AB]);
-          else if constexpr (m == 1) acc[AB] = mfma(frh[pos], bl, acc[AB]);
-          else acc[AB] = mfma(frh[pos], bh, acc[AB]);
-        } else acc[AB] = mfma(frh[pos], bh, (ZI && ks == 0) ? zero16 : acc[AB]);
+          if constexpr (m == 0) acc[AB] = mm(frl[pos], bh, (ZI && ks == 0) ? zero16 : acc[AB]);
+          else if constexpr (m == 1) acc[AB] = mm(frh[pos], bl, acc[AB]);
+          else acc[AB] = mm(frh[pos], bh, acc[AB]);
+        } else acc[AB] = mm(frh[pos], bh, (ZI && ks == 0) ? zero16 : acc[AB]);
         fill(Gc, std::integral_constant<int, K>{});
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     if (tile >= sc.ntiles) break;
   }
   // the last v head of the last tile
-  static_for<20>([&](auto Ec) __attribute__((always_inline)) { epi_step(std::integral_constant<int, NC - 1>{}, Ec, std::integral_constant<bool, true>{}); });
+  static_for<GG::epi_steps(NC - 1)>([&](auto Ec) __attribute__((always_inline)) { epi_step(std::integral_constant<int, NC - 1>{}, Ec, std::integral_constant<bool, true>{}); });
   wait_vmcnt<0>();   // LDS-DMA prefetched for a tile that does not exist must land before the LDS is handed to another workgroup
 }
 
