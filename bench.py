@@ -4,11 +4,14 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2] [--precision bf16x3]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one `render_rays` pass (rows a2-a18 of SURVEY.md §8) over one batch of R rays whose inputs are
-already resident in HBM; per-frame setup (weight packing, KNN grid, map repack) is outside the timed region,
-like the reference's cached `support_neural_points` / `vis_featmaps`.  With N>1 every rank renders its own
-R-ray shard of the same frame (weak scaling) and the per-ray outputs are joined by ONE RCCL all-gather inside
-the timed step.  Rank 0 prints one JSON line.
+A "step" = one `render_rays` pass (rows a2-a18 of SURVEY.md §8; for a hierarchical config also row a20: the coarse NeuRay
+pass + inverse-CDF resampling) over one batch of R rays whose inputs are already resident in HBM; per-frame setup (weight
+packing, KNN grid, map repack) is outside the timed region, like the reference's cached `support_neural_points` /
+`vis_featmaps`.  With N>1 the per-ray outputs are joined by ONE RCCL all-gather inside the timed step, and
+  --scaling weak   (default for c1/c2/c5): every rank renders its own R-ray batch of the same frame; value = N * R / step;
+  --scaling strong (default for c3/c4, BASELINE's "one batch sharded over 2/4/8 GPUs"): ONE R-ray batch, rank r renders
+                   shard_range(R, r, N); value = R / step.
+Rank 0 prints one JSON line.
 
 `roofline`: bound = MFMA; achieved = ALGORITHMIC flops of one step (SURVEY.md §8(d) formula: GEMM/conv MACs x2,
 q-projection counted once) / mean step duration from HIP events on the launch stream; peak = 2.5 PFLOP/s dense bf16
@@ -53,7 +56,9 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the N>1 collective path on one GPU (single-rank RCCL group): a functional check")
-    ap.add_argument("--also", default="bf16", help="comma list of extra precisions timed after the headline (''=none)")
+    ap.add_argument("--also", default="bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: strong for c3/c4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,13 +89,26 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from nerf_loc_amd.renderer import HipRenderer
-    from nerf_loc_amd.sharding import gather_ray_outputs_async
+    from nerf_loc_amd.sharding import gather_ray_outputs_async, shard_range
+    from nerf_loc_amd.synth import make_u
 
     cfg = CONFIGS[args.config]
-    R = args.rays or cfg.R
+    R = args.rays or cfg.R            # weak: rays per rank; strong: rays of the one batch
     S = cfg.S_total
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if args.config in ("c3", "c4") else "weak")
     frame = make_frame(cfg)
-    rays = make_rays(cfg, frame, R=R, seed_offset=1000 + rank)  # every rank its own shard of pixels
+    counts = None
+    if scaling == "strong" and world > 1:
+        rays = make_rays(cfg, frame, R=R, seed_offset=1000)   # the SAME batch on every rank ...
+        lo, hi = shard_range(R, rank, world)                   # ... of which this rank renders a contiguous range
+        counts = [shard_range(R, r, world)[1] - shard_range(R, r, world)[0] for r in range(world)]
+        rays = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == R else v) for k, v in rays.items()}
+        u_all = make_u(cfg, R)[lo:hi] if cfg.N_importance > 0 else None
+        R_local = hi - lo
+    else:
+        rays = make_rays(cfg, frame, R=R, seed_offset=1000 + rank)  # every rank its own batch of pixels
+        u_all = make_u(cfg, R) if cfg.N_importance > 0 else None
+        R_local = R
     weights = make_weights(cfg)
 
     rnd = HipRenderer(cfg.W, cfg.C, S, args.precision, device=f"cuda:{local_rank}")
@@ -99,10 +117,16 @@ def main():
                   cfg.near, cfg.far, frame["support_fine"])
     o = torch.from_numpy(rays["rays_o"]).to(dev)
     d = torch.from_numpy(rays["rays_d"]).to(dev)
-    t_lin = torch.linspace(0, 1, S)
+    Sb = cfg.S                        # base samples (model.py:483-484); hierarchical configs add N_importance resampled depths
+    t_lin = torch.linspace(0, 1, Sb)
     z = torch.tensor(cfg.near, dtype=torch.float32) * (1 - t_lin) + torch.tensor(cfg.far, dtype=torch.float32) * t_lin  # model.py:451-458
-    z = z.expand(R, S).contiguous().to(dev)
+    z = z.expand(R_local, Sb).contiguous().to(dev)
     qc = frame["pose"][:3, 3]
+    hier = cfg.N_importance > 0
+    if hier:   # model.py:487-496: coarse NeuRay weights along the pixel rays -> sample_pdf with FIXED uniforms -> sort(cat)
+        pix = torch.from_numpy(rays["pixel_coordinates"]).to(dev)
+        u_dev = torch.from_numpy(u_all).to(dev)
+        Kq, pose_q = torch.from_numpy(rays["K"]), torch.from_numpy(rays["pose"])
 
     # N > 1: every step ends with ONE all-gather of the packed per-ray outputs.  It is started asynchronously (RCCL's stream) and
     # collected one step later, so the xGMI transfer of batch i overlaps the kernels of batch i + 1; drain() collects the last one
@@ -110,10 +134,15 @@ def main():
     pending = [None]
 
     def step():
-        out = rnd.render_rays(o, d, qc, z_vals=z, white_bkgd=cfg.white_bkgd)
+        zz = z
+        if hier:
+            zz, depth_coarse, _ = rnd.hierarchical_depths(pix, Kq, pose_q, z, u_dev, near=cfg.near, far=cfg.far)
+        out = rnd.render_rays(o, d, qc, z_vals=zz, white_bkgd=cfg.white_bkgd)
+        if hier:
+            out["depth_coarse"] = depth_coarse
         if gather:
             prev = pending[0]
-            pending[0] = gather_ray_outputs_async(out, dist)
+            pending[0] = gather_ray_outputs_async(out, dist, counts)
             if prev is not None:
                 out = prev.result()
         return out
@@ -164,17 +193,22 @@ def main():
     drain()
     fused_ms, launches = ct.c_float(0), ct.c_int(0)
     _lib.check(lib.nl_profile_end(ct.byref(fused_ms), ct.byref(launches)), "nl_profile_end")
-    value = world * R * args.steps / wall
-    flops_step = 2.0 * algorithmic_mac_per_sample(cfg.W, cfg.V, cfg.C) * R * S
+    total_rays = R if (scaling == "strong" and world > 1) else world * R     # rays all ranks rendered per step
+    value = total_rays * args.steps / wall
+    # algorithmic flops of what THIS rank computes per step (+ the coarse pass of a hierarchical config: 64 x V x 8384 MAC per ray)
+    flops_step = 2.0 * algorithmic_mac_per_sample(cfg.W, cfg.V, cfg.C) * R_local * S + (2.0 * 64 * cfg.V * 8384 * R_local if hier else 0.0)
     ach = flops_step / (dev_ms * 1e-3 / args.steps) / 1e12
     result = {
         "metric": baseline_metric(), "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
+        "scaling": scaling, "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
                                                             "bf16": "bf16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
-        "config": {"workload": f"{cfg.name}: {R} rays x {S} samples, W={cfg.W}, V={cfg.V} views {cfg.H}x{cfg.Wimg}, M={frame['support_fine']['xyz'].shape[0]} neural points",
-                   "rays_per_gpu": R, "precision": args.precision, "parallelism": f"ray-shard x{world} + all-gather"},
+        "config": {"workload": f"{cfg.name}: {total_rays} rays x {S} samples" + (f" (64 coarse + {cfg.S} + {cfg.N_importance} resampled)" if hier else "")
+                               + f", W={cfg.W}, V={cfg.V} views {cfg.H}x{cfg.Wimg}, M={frame['support_fine']['xyz'].shape[0]} neural points",
+                   "rays_per_gpu": R_local, "precision": args.precision,
+                   "parallelism": f"ray-shard x{dist.get_world_size() if dist is not None else 1} ({scaling})"
+                                  + (f" + {dist.get_backend()} all-gather" if gather else "")},
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                      "traffic": hbm_traffic(args.config, args.precision), "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
                      "flops_per_step": flops_step, "device_ms_per_step": dev_ms / args.steps},
@@ -183,11 +217,11 @@ def main():
         K, F, W = 8, cfg.C + 3, cfg.W
         mac_alg = K * (496 + (F + 90) * W + 2 * W * W + 2 * 128 * W) + 16384      # a9 ray_diff_fc, a10 base_mlp, k/v projection, a11 attention (SURVEY §8d terms)
         mac_exec = K * (96 * W + 2 * W * W + 256 * W)                               # what the kernel multiplies (feature columns come from the per-frame table T)
-        samples_per_launch = R * S * args.steps / launches.value
+        samples_per_launch = R_local * S * args.steps / launches.value
         sec = fused_ms.value * 1e-3 / launches.value
         alg = 2.0 * mac_alg * samples_per_launch / sec / 1e12
         result["roofline"]["dominant_kernel"] = {
-            "name": "point_fused_kernel", "launches": launches.value, "avg_ms": fused_ms.value / launches.value,
+            "name": "point_fused2_kernel", "launches": launches.value, "avg_ms": fused_ms.value / launches.value,
             "share_of_step": fused_ms.value / args.steps / (dev_ms / args.steps),
             "achieved": alg, "frac": alg / PEAK_BF16_TFLOPS, "unit": "TFLOP/s (algorithmic, SURVEY §8d)",
             "executed_mfma_TFLOPs": 2.0 * mac_exec * (3 if args.precision == "bf16x3" else 1) * samples_per_launch / sec / 1e12,
@@ -199,12 +233,14 @@ def main():
             rnd.set_precision(p)
             w2, d2 = timed(max(3, args.steps // 2), 2)
             n2 = max(3, args.steps // 2)
-            extra[p] = {"rays_per_s": R * n2 / w2, "ms_per_step": w2 * 1e3 / n2, "roofline_frac": flops_step / (d2 * 1e-3 / n2) / 1e12 / PEAK_BF16_TFLOPS}
+            extra[p] = {"rays_per_s": R * n2 / w2, "ms_per_step": w2 * 1e3 / n2, "roofline_frac": flops_step / (d2 * 1e-3 / n2) / 1e12 / PEAK_BF16_TFLOPS,
+                        "note": {"bf16": "single bf16 MFMA per product: throughput mode, does NOT meet 1e-4", "fp32": "f32-input MFMA, generic kernels: strictest parity mode",
+                                 "bf16x3": "parity mode"}[p]}
         rnd.set_precision(args.precision)
         result["other_precisions"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights)
+        result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights, u_all)
     # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which a pipe flushes only at exit: every rank pushes it out
     # now, then rank 0 prints the JSON line as the last thing on stdout
     try:
@@ -229,18 +265,34 @@ def baseline_metric() -> str:
         return "rendered rays/sec (4096 rays×128 samples, 256-wide MLP) at 1/2/4/8 MI355X"
 
 
+def sources_sha() -> str:
+    """Fingerprint of the kernel sources a measurement belongs to (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nerf_loc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "nerf_loc_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(config: str, precision: str):
-    """HBM GB per step from the committed rocprofv3 PMC passes of this same command (profiles/r1_hbm_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  None when no committed measurement matches the workload."""
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-    if config != "c2" or precision != "bf16x3" or not os.path.exists(path):
-        return None
-    d = json.load(open(path))
-    return {"GB_per_step": d["fetch_GB_per_step_x2_gfx950_correction"] + d["write_GB_per_step"], "source": "profiles/r1_hbm_traffic.json"}
+    """HBM GB per step from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs
+    by tools/hbm_traffic.py; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  A constant read from a committed
+    file, NOT measured in this run: it carries the fingerprint of the kernel sources it was measured on and says whether that is
+    the build being benchmarked.  None when no committed measurement matches the workload."""
+    for name in ("r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if config != "c2" or precision != "bf16x3" or not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        sha = d.get("sources_sha")
+        return {"GB_per_step": d["fetch_GB_per_step_x2_gfx950_correction"] + d["write_GB_per_step"], "write_GB_per_step": d["write_GB_per_step"],
+                "source": f"profiles/{name} (separate rocprofv3 --pmc passes, not this run)", "measured_on_sources": sha,
+                "matches_this_build": (sha == sources_sha()) if sha else False}
+    return None
 
 
-def cpu_baseline(cfg, frame, rays, weights, budget_s: float = 20.0):
+def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 18.0):
     """Time the CPU oracle (port of the reference's PyTorch path) on a bounded ray sample of the same workload.
 
     Threads: torch intra-op parallelism saturates around 8-64 threads on this path and collapses beyond (measured on the
@@ -253,12 +305,13 @@ def cpu_baseline(cfg, frame, rays, weights, budget_s: float = 20.0):
     p = {k: torch.from_numpy(v) for k, v in weights.items()}
     fr = orc.to_torch(frame)
 
-    def run(lo, hi, timers=None):
+    def run(lo, hi, timers=None, nthreads=threads):
         sub = {k: (torch.from_numpy(v[lo:hi]) if k in ("rays_o", "rays_d", "pixel_coordinates") else (torch.from_numpy(v) if isinstance(v, np.ndarray) else v))
                for k, v in rays.items()}
+        uu = None if u_all is None else torch.from_numpy(u_all[lo:hi])   # fixed uniforms for sample_pdf (reference: torch.rand)
         t0 = time.perf_counter()
         with torch.no_grad():
-            orc.render_rays(p, fr, sub, cfg.S, cfg.N_importance, knn_threads=threads, timers=timers)
+            orc.render_rays(p, fr, sub, cfg.S, cfg.N_importance, u=uu, knn_threads=nthreads, timers=timers)
         return time.perf_counter() - t0
 
     run(0, 16)                          # warm-up (first-touch, thread pool)
@@ -270,8 +323,18 @@ def cpu_baseline(cfg, frame, rays, weights, budget_s: float = 20.0):
         n = min(256, total - done)
         t_all += run(done, done + n, timers)
         done += n
+    # the same path at other thread counts (64 rays each): intra-op parallelism saturates early on this path
+    sweep = {}
+    for nt in (8, 64):
+        if nt <= cores and nt != threads:
+            torch.set_num_threads(nt)
+            run(0, 16, nthreads=nt)
+            sweep[str(nt)] = round(64 / run(0, 64, nthreads=nt), 1)
+    torch.set_num_threads(threads)
+    sweep[str(threads)] = round(total / t_all, 1)
     return {"value": total / t_all, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{total} rays x {cfg.S_total} samples of the same workload in 256-ray chunks, {t_all:.1f} s, {threads} of {cores} host cores",
+            "rays_per_s_by_threads": sweep,
             "stage_seconds": {k: round(v, 3) for k, v in timers.items()}}
 
 

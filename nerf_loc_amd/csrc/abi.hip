@@ -537,7 +537,10 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
 
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and
 // *sigma_done is set; otherwise the caller runs sigma_kernel on geo
-int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr) {
+// need_geo == false: the caller only wants the density (model.py:525 is the sole consumer of the U-Net's output); when the density
+// head runs inside conv_out's epilogue the (N, W) output rows are then never written (0.5 GB per config-2 batch)
+int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr,
+            bool need_geo = true) {
   const int W = x.c->W, S = x.c->S;
   auto g = [&](int i) { return x.p<float>(x.L.un_g[i]); };
   auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
@@ -592,6 +595,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     RowEpi ep{nullptr, 0, g(U_OUT), b(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
     if (sigma_out) { ep.sig_w = x.p<float>(x.L.sig_w); ep.sig_b = x.p<float>(x.L.sig_b); ep.sig_out = sigma_out; }
     bool fused = false;
+    if (!need_geo && sigma_out) ep.out = nullptr;   // (the unfused fallback below still writes `geo`)
     NL_TRY(run_gemm(x, G_CONVOUT, s, 2, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
     if (sigma_done) *sigma_done = fused && sigma_out;
@@ -928,7 +932,7 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt));
     bool have_sigma = false;
-    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma));
+    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
     NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
             v.x = fmaxf(v.x, nl_dpp<0xB1>(v.x, v.x)); v.y = fmaxf(v.y, nl_dpp<0xB1>(v.y, v.y));   // quad_perm [1,0,3,2]: lane ^ 1
             v.z = fmaxf(v.z, nl_dpp<0xB1>(v.z, v.z)); v.w = fmaxf(v.w, nl_dpp<0xB1>(v.w, v.w));
           }
-          if (mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;
+          if (p_c && mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;   // p_c == null: only the density head's output is wanted
           if (a.ep_sig_w) {
             const float4 w4 = *(const float4*)(a.ep_sig_w + n);
             sg = fmaf(v.x, w4.x, sg); sg = fmaf(v.y, w4.y, sg); sg = fmaf(v.z, w4.z, sg); sg = fmaf(v.w, w4.w, sg);

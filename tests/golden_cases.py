@@ -20,6 +20,10 @@ CASES = {
     "hier": (TINY.replace(name="hier", S=16, N_importance=16, seed=16), True),
     "w128s64": (SceneConfig("w128s64", R=32, S=64, W=128, V=10, H=64, Wimg=80, seed=17), False),
     "w256s128": (SceneConfig("w256s128", R=24, S=128, W=256, V=10, H=64, Wimg=80, seed=18), False),
+    # BASELINE config 4's shape class: 192 samples per ray, outdoor depth range (posenc arguments up to 2^9 x 25 / 24.75), 4:7 views
+    "s192out": (SceneConfig("s192out", R=12, S=192, W=256, V=10, H=64, Wimg=112, near=0.25, far=25.0, seed=19), False),
+    # BASELINE config 5's shape class: hierarchical 64 coarse + 64 + 128 resampled = 192 samples, 16 views
+    "hier192": (SceneConfig("hier192", R=12, S=64, N_importance=128, W=256, V=16, H=64, Wimg=64, seed=20), False),
 }
 
 

@@ -1,0 +1,106 @@
+"""Every BASELINE.json configuration on the GPU against the CPU oracle (run with `pytest -m gpu`).
+
+c2 has its own full-size tests in test_gpu_parity.py.  Here: c3 (8192 x 128), c4 (16384 x 192, 256x448 views, outdoor depth range
+0.25 / 25) and c5 (hierarchical 64 coarse + 64 + 128 resampled, 16 views): a sample of the rays of the full-size workload against
+`oracle.render_rays` at BASELINE's 1e-4 (max-rel-to-max AND L2-relative), plus size-independent properties of the WHOLE batch
+(finite, weights sum to 1, depth inside the range, determinism, invariance of a ray's result to the batch it is rendered in)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import l2_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+KEYS = ("rgb", "depth", "weights", "depth_uncertainty", "feat")
+
+
+def _scene(name):
+    from nerf_loc_amd.synth import CONFIGS, make_frame, make_rays, make_u, make_weights
+    cfg = CONFIGS[name]
+    frame = make_frame(cfg)
+    return {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg), "u": make_u(cfg)}
+
+
+def _renderer(sc, precision):
+    from nerf_loc_amd.renderer import HipRenderer
+    cfg, fr = sc["cfg"], sc["frame"]
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in sc["weights"].items()})
+    r.set_frame(fr["topk_images"], fr["feat_fine_src"], fr["vis_featmaps"], fr["topk_Ks"], fr["topk_poses"], cfg.near, cfg.far, fr["support_fine"])
+    return r
+
+
+def _zbase(cfg, R):
+    from oracle.render_oracle import sample_depths
+    return sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(R, cfg.S).contiguous()
+
+
+def _render(r, sc, sel=None, precision_note=""):
+    cfg = sc["cfg"]
+    o, d = sc["rays"]["rays_o"], sc["rays"]["rays_d"]
+    pix, u = sc["rays"]["pixel_coordinates"], sc["u"]
+    if sel is not None:
+        o, d, pix, u = o[sel], d[sel], pix[sel], u[sel]
+    z = _zbase(cfg, len(o))
+    extra = {}
+    if cfg.N_importance > 0:
+        z, dc, _ = r.hierarchical_depths(pix, sc["frame"]["K"], sc["frame"]["pose"], z, u, near=cfg.near, far=cfg.far)
+        extra["depth_coarse"] = dc
+    out = r.render_rays(o, d, sc["frame"]["pose"][:3, 3], z_vals=z, white_bkgd=cfg.white_bkgd)
+    out.update(extra)
+    return out
+
+
+def _oracle(sc, sel, threads=16):
+    from oracle import render_oracle as orc
+    cfg = sc["cfg"]
+    params = {k: torch.from_numpy(v) for k, v in sc["weights"].items()}
+    sub = {k: (torch.from_numpy(v[sel]) if k in ("rays_o", "rays_d", "pixel_coordinates") else (torch.from_numpy(v) if isinstance(v, np.ndarray) else v))
+           for k, v in sc["rays"].items()}
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        return orc.render_rays(params, orc.to_torch(sc["frame"]), sub, cfg.S, cfg.N_importance, u=torch.from_numpy(sc["u"][sel]), knn_threads=threads)
+
+
+@pytest.fixture(scope="module", params=["c3", "c4", "c5"])
+def scene(request):
+    return _scene(request.param)
+
+
+def test_sampled_rays_of_the_full_workload_match_oracle(scene):
+    cfg = scene["cfg"]
+    n = 48 if cfg.S_total > 128 else 64
+    sel = np.arange(0, cfg.R, cfg.R // n)[:n]
+    ref = _oracle(scene, sel)
+    r = _renderer(scene, "bf16x3")
+    out = _render(r, scene, sel)
+    assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+    keys = KEYS + (("depth_coarse",) if cfg.N_importance > 0 else ())
+    errs = {k: (rel_err(out[k].cpu().numpy(), ref[k].numpy()), l2_rel(out[k].cpu().numpy(), ref[k].numpy())) for k in keys}
+    assert all(e[0] < 1e-4 and e[1] < 1e-4 for e in errs.values()), (cfg.name, errs)
+    # throughput mode (single bf16 MFMA per product): does NOT meet 1e-4 — its error is measured and bounded, not hidden
+    r.set_precision("bf16")
+    fast = _render(r, scene, sel)
+    e16 = {k: rel_err(fast[k].cpu().numpy(), ref[k].numpy()) for k in KEYS}
+    print(f"\n{cfg.name} bf16x3 (max-rel, l2-rel): {errs}\n{cfg.name} bf16 max-rel: {e16}")
+    assert max(e16.values()) < 3e-2, (cfg.name, e16)
+
+
+def test_full_size_batch_properties(scene):
+    cfg = scene["cfg"]
+    r = _renderer(scene, "bf16x3")
+    a = _render(r, scene)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert torch.isfinite(a[k]).all(), k
+    assert a["rgb"].shape == (cfg.R, 3) and a["weights"].shape == (cfg.R, cfg.S_total)
+    assert float((a["weights"].sum(1) - 1).abs().max()) < 1e-4          # last delta = 1e2 makes every ray opaque (model.py:544-553)
+    assert float(a["depth"].min()) >= cfg.near - 1e-3 and float(a["depth"].max()) <= cfg.far + 1e-3
+    b = _render(r, scene)
+    for k in KEYS:
+        assert torch.equal(a[k], b[k]), ("determinism", k)
+    # a ray's result does not depend on the batch it is rendered in (what ray-range sharding over GPUs relies on)
+    sel = np.arange(cfg.R // 2 - 100, cfg.R // 2 + 100)
+    c = _render(r, scene, sel)
+    for k in KEYS:
+        assert torch.equal(a[k][torch.from_numpy(sel).to(a[k].device)], c[k]), ("shard invariance", k)

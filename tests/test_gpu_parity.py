@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests.golden_cases import CASES, build_case
-from tests.util import load_golden, oracle_inputs, rel_err
+from tests.util import l2_rel, load_golden, oracle_inputs, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -46,9 +46,12 @@ def test_render_rays_matches_reference_golden(name, precision):
     tol = TOL[precision]
     for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat", "sigma"):
         assert rel_err(o[k], g[k]) < tol, (k, rel_err(o[k], g[k]))
+        # max-rel-to-max says nothing about the small entries (most `weights`, `depth_uncertainty`): an L2-relative bound as well
+        assert l2_rel(o[k], g[k]) < tol, (k, "l2", l2_rel(o[k], g[k]))
     rows = g["rows"] if "rows" in g else slice(None)
     for k, gk in (("mv_feature_agg", "multiview_feature_agg"), ("feature_agg", "feature_agg"), ("geo", "geo")):
         assert rel_err(o[k][rows], g[gk]) < tol, (k, rel_err(o[k][rows], g[gk]))
+        assert l2_rel(o[k][rows], g[gk]) < tol, (k, "l2", l2_rel(o[k][rows], g[gk]))
 
 
 @pytest.mark.parametrize("name", ["c1", "w256s128"])
@@ -153,26 +156,41 @@ def test_descriptor_query_direction_falls_back_to_nearest_neighbour():
     assert rel_err(fa.cpu().numpy(), qd["feature_agg"].numpy()) < 5e-5
 
 
-def test_hierarchical_branch_matches_reference_golden():
-    """a20: coarse NeuRay weights -> sample_pdf (recipe uniforms) -> merge/sort -> render, vs the reference golden."""
+HIER = [n for n in CASES if CASES[n][0].N_importance > 0]
+
+
+@pytest.mark.parametrize("name", HIER)
+def test_hierarchical_branch_matches_reference_golden(name):
+    """a20: coarse NeuRay weights -> sample_pdf (recipe uniforms) -> merge/sort -> render, vs the reference golden, at BASELINE's
+    1e-4.  Two stages own the error and are bounded separately: (1) the depths z — the HIP coarse pass against the oracle's,
+    relative to the depth span; (2) the renderer alone, fed the ORACLE's depths.  The end-to-end path (HIP depths into the HIP
+    renderer) is then held to 1e-4 as well, and if it ever exceeds it the message says which stage moved."""
     from oracle import render_oracle as orc
-    cfg, _ = CASES["hier"]
-    case = build_case("hier")
-    g = load_golden("hier")
+    cfg, _ = CASES[name]
+    case = build_case(name)
+    g = load_golden(name)
     params, frame, rays = oracle_inputs(case)
+    u = torch.from_numpy(case["u"])
+    with torch.no_grad():
+        zb = orc.sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, cfg.S).contiguous()
+        zc = orc.sample_depths(64, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, 64).contiguous()
+        wc_o = orc.predict_weights_from_neuray(params, frame, rays, zc)
+        zf = orc.sample_pdf(0.5 * (zc[:, :-1] + zc[:, 1:]), wc_o[:, 1:-1], cfg.N_importance, u)
+        z_o = torch.sort(torch.cat([zb, zf], -1), -1)[0]
     for precision in ("fp32", "bf16x3"):
         r = _renderer(case, precision)
-        zb = orc.sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, cfg.S).contiguous()
         z, depth_coarse, wc = r.hierarchical_depths(case["rays"]["pixel_coordinates"], case["frame"]["K"], case["frame"]["pose"], zb, case["u"])
-        with torch.no_grad():
-            zc = orc.sample_depths(64, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, 64).contiguous()
-            wc_o = orc.predict_weights_from_neuray(params, frame, rays, zc)
         assert rel_err(wc.cpu().numpy(), wc_o.numpy()) < 2e-5
         assert rel_err(depth_coarse.cpu().numpy(), g["depth_coarse"]) < 2e-5
+        z_err = float((z.cpu() - z_o).abs().max()) / (cfg.far - cfg.near)
+        assert z_err < 2e-5, ("stage 1 (depths)", precision, z_err)
+        tol = TOL[precision]
+        alone = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], case["frame"]["pose"][:3, 3], z_vals=z_o, intermediates=True)
+        e_alone = {k: rel_err(alone[k].cpu().numpy(), g[k]) for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat", "sigma")}
+        assert max(e_alone.values()) < tol, ("stage 2 (renderer on the oracle's depths)", precision, e_alone)
         out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], case["frame"]["pose"][:3, 3], z_vals=z, intermediates=True)
-        tol = TOL[precision] * 3   # z itself carries the coarse pass' rounding; still far inside 1e-3
-        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat", "sigma"):
-            assert rel_err(out[k].cpu().numpy(), g[k]) < tol, (precision, k, rel_err(out[k].cpu().numpy(), g[k]))
+        e_e2e = {k: rel_err(out[k].cpu().numpy(), g[k]) for k in e_alone}
+        assert max(e_e2e.values()) < 1e-4, ("end to end (BASELINE's bar)", precision, e_e2e, "renderer alone", e_alone, "depths", z_err)
         assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
 
 
@@ -201,7 +219,7 @@ def test_random_hierarchical_configs_match_oracle(seed):
         out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=z)
         assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy()), cfg
         for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
-            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 3 * TOL[precision], (cfg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 1e-4, (cfg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
 
 
 # ------------------------------------------------------------------ full-size (BASELINE config 2) properties
@@ -418,7 +436,7 @@ def test_random_configs_match_oracle(seed):
         out = r.render_rays(case["rays"]["rays_o"], case["rays"]["rays_d"], frame["pose"][:3, 3], z_vals=_z(cfg, cfg.R), white_bkgd=cfg.white_bkgd)
         assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy()), cfg
         for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
-            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < TOL[precision], (cfg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 1e-4, (cfg, precision, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
 
 
 def test_repacking_weights_in_place_refreshes_per_frame_tables():

@@ -71,3 +71,35 @@ def test_two_rank_gather_even():
 
 def test_two_rank_gather_uneven():
     _run(True, 29612)
+
+
+def _strong_worker(rank, world, port, q):
+    """bench.py --scaling strong: every rank builds the SAME batch, renders shard_range(R, rank, world) of it, one gather joins them."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R = 37   # uneven over 2 ranks
+    g = torch.Generator().manual_seed(3)
+    rays_o, rays_d = torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g)
+
+    def fake_render(o, d):   # any per-ray function: a ray's result must not depend on the batch it is rendered in
+        return {"rgb": o * d, "depth": (o * d).sum(1), "weights": torch.stack([o[:, 0], d[:, 1], o[:, 2] * d[:, 0]], 1),
+                "mask": o[:, 0] > d[:, 0], "depth_uncertainty": o.sum(1), "feat": torch.cat([o, d], 1)}
+    lo, hi = shard_range(R, rank, world)
+    counts = [shard_range(R, r, world)[1] - shard_range(R, r, world)[0] for r in range(world)]
+    got = gather_ray_outputs(fake_render(rays_o[lo:hi], rays_d[lo:hi]), dist, counts)
+    full = fake_render(rays_o, rays_d)
+    q.put((rank, all(torch.equal(got[k], full[k]) for k in full) and sum(counts) == R))
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_split_reassembles_the_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_strong_worker, args=(r, 2, 29561, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
