@@ -236,10 +236,19 @@ class HipRenderer:
         Kc = torch.as_tensor(K).detach().float().cpu()
         Pc = torch.as_tensor(pose).detach().float().cpu()
         cam = torch.cat([Pc[None].inverse()[0, :3].reshape(-1), torch.inverse(Kc).reshape(-1)]).contiguous()  # depth_fusion.py:19-26
-        t_lin = torch.linspace(0, 1, n_coarse)
-        # model.py:489 samples the coarse depths from rays['depth_range'] (the caller passes it); the frame's range is only the default
+        # model.py:489 samples the coarse depths from rays['depth_range'] (the caller passes it); the frame's range is only the default.
+        # The 64 values are formed once on the host exactly like the reference forms them and kept on the device: no per-call
+        # host arithmetic or host-to-device copy on the render path.
         zn, zf = self.near if near is None else float(near), self.far if far is None else float(far)
-        zc = (torch.tensor(zn) * (1 - t_lin) + torch.tensor(zf) * t_lin).expand(R, n_coarse).contiguous().to(dev)
+        key = (n_coarse, zn, zf)
+        zrow = getattr(self, "_zc_rows", {}).get(key)
+        if zrow is None:
+            t_lin = torch.linspace(0, 1, n_coarse)
+            zrow = (torch.tensor(zn) * (1 - t_lin) + torch.tensor(zf) * t_lin).to(dev)
+            if not hasattr(self, "_zc_rows"):
+                self._zc_rows = {}
+            self._zc_rows[key] = zrow
+        zc = zrow.expand(R, n_coarse).contiguous()
         wc = torch.empty(R, n_coarse, device=dev)
         dc = torch.empty(R, device=dev)
         zo = torch.empty(R, Sb + Ni, device=dev)
