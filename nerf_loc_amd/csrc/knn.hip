@@ -228,7 +228,7 @@ __device__ __forceinline__ float node_mindist2(const QueryCtx& c, unsigned cx, u
 // revisits them; indices are unique per point)
 template <int K, bool DEDUPE>
 __device__ __forceinline__ void candidate(const QueryCtx& c, const float4* __restrict__ sorted, bool valid, int pos, const BestK<K>& best,
-                                          unsigned& kd, unsigned& ki) {
+                                          unsigned& kd, unsigned& ki, bool dedupe_now = true, unsigned ubits = 0xffffffffu) {
   kd = 0xffffffffu; ki = 0xffffffffu;
   if (valid) {
     const float4 p = sorted[pos];
@@ -238,7 +238,9 @@ __device__ __forceinline__ void candidate(const QueryCtx& c, const float4* __res
     d = __fadd_rn(d, __fmul_rn(ddz, ddz));
     kd = __float_as_uint(d);
     ki = (unsigned)__float_as_int(p.w);
-    if (DEDUPE) {
+    // U bounds the K-th distance from above: a point beyond it cannot be among the K nearest ('<=' keeps exact ties)
+    if (kd > ubits) { kd = 0xffffffffu; ki = 0xffffffffu; }
+    if (DEDUPE && dedupe_now) {   // wave-uniform: only a query whose list was pre-filled by phase 1 revisits points
       bool dup = false;
 #pragma unroll
       for (int k = 0; k < K; ++k) dup |= (ki == best.idx_at(k));
@@ -249,10 +251,11 @@ __device__ __forceinline__ void candidate(const QueryCtx& c, const float4* __res
 
 // one contiguous range [rs, rs+len) (wave-uniform), 64 candidates at a time
 template <int K, bool DEDUPE>
-__device__ __forceinline__ void scan_range(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, BestK<K>& best) {
+__device__ __forceinline__ void scan_range(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, BestK<K>& best,
+                                           bool dedupe_now = true, unsigned ubits = 0xffffffffu) {
   for (int base = 0; base < len; base += 64) {
     unsigned kd, ki;
-    candidate<K, DEDUPE>(c, sorted, base + lane < len, rs + base + lane, best, kd, ki);
+    candidate<K, DEDUPE>(c, sorted, base + lane < len, rs + base + lane, best, kd, ki, dedupe_now, ubits);
     select_into<K>(best, kd, ki, (unsigned)(rs + base + lane));
   }
 }
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   BestK<K> best;
   best.clear();
   float U;
+  const bool dedupe_now = !prev_full;   // phase 1 below pre-fills the list; otherwise it starts empty and no point is seen twice
   if (!prev_full) {
     // -------------------------------------------------------------- phase 1: greedy descent -> upper bound U
     unsigned m = 0, mx = 0, my = 0, mz = 0;   // Morton prefix and cell coordinates of the node being descended (wave-uniform)
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       const bool ok = e < nleaf;
       const int rs = ok ? leaf_s[e] : 0, ln = ok ? leaf_l[e] : 0;
       unsigned kd, ki;
-      candidate<K, true>(c, sorted, (lane % SL) < ln, rs + (lane % SL), best, kd, ki);
+      candidate<K, true>(c, sorted, (lane % SL) < ln, rs + (lane % SL), best, kd, ki, dedupe_now, __float_as_uint(U));
       select_into<K>(best, kd, ki, (unsigned)(rs + (lane % SL)));
     }
     nleaf = 0;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       while (mbig) {
         const int src = __builtin_ctzll(mbig);
         mbig &= mbig - 1;
-        scan_range<K, true>(c, sorted, __builtin_amdgcn_readlane(rs, src), __builtin_amdgcn_readlane(cnt, src), lane, best);
+        scan_range<K, true>(c, sorted, __builtin_amdgcn_readlane(rs, src), __builtin_amdgcn_readlane(cnt, src), lane, best, dedupe_now, __float_as_uint(U));
         if (best.full()) U = fminf(U, __uint_as_float(best.td));
       }
       const bool small = lf && cnt <= LEAF_COUNT_MAX;
