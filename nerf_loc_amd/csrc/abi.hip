@@ -462,6 +462,32 @@ int ensure_ptt(const Ctx& x, const nl_frame* fc) {
   return NL_OK;
 }
 
+// ---- side streams of the fused render path ------------------------------------------------------------------------
+// nl_render_rays forks two independent branches off the caller's stream and joins them again (events, graph-capturable):
+//   * the exact KNN (VALU-issue bound) runs beside the multi-view gather kernels (waiting on bilinear taps), both only need xyz;
+//   * the colour / feature heads' GEMMs + the blend tail (need feature_agg only) run beside the ray U-Net's chain of small,
+//     latency-bound launches.
+// Streams and events are created lazily, once per device, and live for the process (the only library-global state besides
+// the pack-generation registry; like the reference module the library is not re-entrant).  NERFLOC_SERIAL=1 keeps everything on
+// the caller's stream (debugging / A-B timing).
+struct SideStreams { hipStream_t s[2]; hipEvent_t e[4]; bool ok = false, tried = false; };
+SideStreams g_side[16];
+SideStreams* side_streams() {
+  static const bool serial = getenv("NERFLOC_SERIAL") != nullptr;
+  if (serial) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStreams& S = g_side[dev];
+  if (!S.tried) {
+    S.tried = true;
+    bool ok = true;
+    for (int i = 0; i < 2; ++i) ok = ok && hipStreamCreateWithFlags(&S.s[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&S.e[i], hipEventDisableTiming) == hipSuccess;
+    S.ok = ok;
+  }
+  return S.ok ? &S : nullptr;
+}
+
 // ---- measurement hook: HIP events around the dominant kernel (nl_profile_begin / nl_profile_end) -----------------
 struct ProfState { bool on = false; std::vector<hipEvent_t> ev; int used = 0; };
 ProfState g_prof;
@@ -492,15 +518,18 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
   return NL_OK;
 }
 
+// knn_done != null: the caller already ran the KNN (+ the aggregation scale) on a side stream and hands over the event to wait for
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
-             float* FA, const PtBufs& p) {
+             float* FA, const PtBufs& p, hipEvent_t knn_done = nullptr) {
   const int W = x.c->W, F = f->C + 3;
-  NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
+  const bool fused_path = K == 8 && nl_point_fused_supported(W, x.c->precision);
+  if (!knn_done) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
   SegSpec sg{G, W, W, 0, 1};
   NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
-  if (K == 8 && nl_point_fused_supported(W, x.c->precision)) {
+  if (knn_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, knn_done, 0));
+  if (fused_path) {
     NL_TRY(ensure_ptt(x, f));
-    NL_TRY(nl_launch_wscale(p.idx, p.d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
+    if (!knn_done) NL_TRY(nl_launch_wscale(p.idx, p.d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
     NlPointFusedArgs a;
     a.xyz = xyz; a.dir = dir; a.dir_stride = dir_stride; a.dir_div = dir_div > 0 ? dir_div : 1;
     a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
@@ -603,20 +632,28 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   return NL_OK;
 }
 
-int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
-             const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false) {
-  const int W = x.c->W, S = x.c->S, C = x.c->C;
-  const int64_t N = R * S;
-  if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
-  const bool want_feat = out->feat != nullptr;
-  if (want_feat) {
+// the part of the heads that needs feature_agg only (not the density): feat_mlp.0, the per-sample blend projection, the blend tail
+int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const float* rgbv, int64_t N, bool want_feat, const HdBufs& h, int parts = 7) {
+  const int W = x.c->W;
+  if (want_feat && (parts & 1)) {
     SegSpec s0{FA, W, W, 0, 1};
     NL_TRY(run_gemm(x, G_FEAT0, &s0, 1, N, h.fth, W, NL_ACT_LRELU));
   }
   SegSpec sa{FA, W, W, 0, 1};
-  NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
-  NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
-                         x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
+  if (parts & 2) NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
+  if (parts & 4) NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
+                                        x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
+  return NL_OK;
+}
+
+int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
+             const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false,
+             bool pre_done = false) {
+  const int W = x.c->W, S = x.c->S, C = x.c->C;
+  const int64_t N = R * S;
+  if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
+  const bool want_feat = out->feat != nullptr;
+  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h));
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
                              want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st));
   if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
@@ -923,17 +960,48 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
   const int64_t RC = lo;
   Bump b{(char*)ws, 0}; RenderBufs rb; carve_render(b, cfg, V, RC, rb);
   Ctx x = make_ctx(cfg, packed, stream);
+  SideStreams* side = side_streams();
+  // bit 0 = KNN fork (default), bit 1 = heads fork.  The heads fork is OFF by default: it measured < 0.5 % (every kernel of that
+  // phase fills the chip on its own) and the blend tail (a scratch-using VALU kernel) gave run-to-run different colours when it
+  // ran beside the U-Net's kernels on another queue — not worth chasing for that gain.
+  static const int side_mask = getenv("NERFLOC_SIDE") ? atoi(getenv("NERFLOC_SIDE")) : 1;
   for (int64_t r0 = 0; r0 < R; r0 += RC) {
     const int64_t rc = (R - r0 < RC) ? R - r0 : RC;
     const int64_t N = rc * S;
     NL_TRY(nl_launch_sample_points(rays_o + 3 * r0, rays_d + 3 * r0, rc, S, f->views.near_, f->views.far_,
                                    z_vals ? z_vals + r0 * S : nullptr, rb.z, rb.xyz, x.st));
+    // ---- fork 1: exact KNN + aggregation scale on a side stream, beside the multi-view gather kernels (both need xyz only)
+    hipEvent_t knn_done = nullptr;
+    if (side && (side_mask & 1) && nl_point_fused_supported(W, cfg->precision)) {
+      NL_CHECK_HIP(hipEventRecord(side->e[0], x.st));
+      NL_CHECK_HIP(hipStreamWaitEvent(side->s[0], side->e[0], 0));
+      NL_TRY(nl_knn_search(&f->grid, rb.xyz, N, 8, rb.pt.idx, rb.pt.d2, side->s[0]));
+      NL_TRY(nl_launch_wscale(rb.pt.idx, rb.pt.d2, f->sp_conf, N, 8, f->M, rb.pt.wscale, side->s[0]));
+      NL_CHECK_HIP(hipEventRecord(side->e[1], side->s[0]));
+      knn_done = side->e[1];
+    }
     NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
-    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt));
+    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, knn_done));
+    // ---- fork 2: heads that need feature_agg only, beside the ray U-Net
+    bool pre_done = false;
+    int pre_parts = 0;
+    if (side && (side_mask & 2)) {
+      NL_CHECK_HIP(hipEventRecord(side->e[2], x.st));
+      NL_CHECK_HIP(hipStreamWaitEvent(side->s[1], side->e[2], 0));
+      Ctx xs = x;
+      xs.st = side->s[1];
+      static const int parts = getenv("NERFLOC_PARTS") ? atoi(getenv("NERFLOC_PARTS")) : 7;
+      NL_TRY(do_heads_pre(xs, V, rb.FA, rb.bl1, rb.rgbv, N, out->feat != nullptr, rb.hd, parts));
+      NL_CHECK_HIP(hipEventRecord(side->e[3], side->s[1]));
+      pre_parts = parts;
+      pre_done = true;
+    }
     bool have_sigma = false;
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma));
+    if (pre_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, side->e[3], 0));
+    if (pre_done && pre_parts != 7) NL_TRY(do_heads_pre(x, V, rb.FA, rb.bl1, rb.rgbv, N, out->feat != nullptr, rb.hd, 7 & ~pre_parts));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, pre_done));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
