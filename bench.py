@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the N>1 collective path on one GPU (single-rank RCCL group): a functional check")
     ap.add_argument("--also", default="bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
+    ap.add_argument("--early-term-eps", type=float, default=-1.0,
+                    help="early-termination compositing threshold (nl_render_opts); default: 1e-5 for c5 (BASELINE names it there), 0 = off otherwise")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: strong for c3/c4)")
     args = ap.parse_args()
@@ -123,6 +125,7 @@ def main():
     z = z.expand(R_local, Sb).contiguous().to(dev)
     qc = frame["pose"][:3, 3]
     hier = cfg.N_importance > 0
+    et_eps = args.early_term_eps if args.early_term_eps >= 0 else (1e-5 if args.config == "c5" else 0.0)
     if hier:   # model.py:487-496: coarse NeuRay weights along the pixel rays -> sample_pdf with FIXED uniforms -> sort(cat)
         pix = torch.from_numpy(rays["pixel_coordinates"]).to(dev)
         u_dev = torch.from_numpy(u_all).to(dev)
@@ -137,7 +140,7 @@ def main():
         zz = z
         if hier:
             zz, depth_coarse, _ = rnd.hierarchical_depths(pix, Kq, pose_q, z, u_dev, near=cfg.near, far=cfg.far)
-        out = rnd.render_rays(o, d, qc, z_vals=zz, white_bkgd=cfg.white_bkgd)
+        out = rnd.render_rays(o, d, qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps)
         if hier:
             out["depth_coarse"] = depth_coarse
         if gather:
@@ -207,6 +210,7 @@ def main():
         "config": {"workload": f"{cfg.name}: {total_rays} rays x {S} samples" + (f" (64 coarse + {cfg.S} + {cfg.N_importance} resampled)" if hier else "")
                                + f", W={cfg.W}, V={cfg.V} views {cfg.H}x{cfg.Wimg}, M={frame['support_fine']['xyz'].shape[0]} neural points",
                    "rays_per_gpu": R_local, "precision": args.precision,
+                   "early_term_eps": et_eps,   # random-init weights give a thin medium: nothing terminates early, the option only costs its two tiny kernels
                    "parallelism": f"ray-shard x{dist.get_world_size() if dist is not None else 1} ({scaling})"
                                   + (f" + {dist.get_backend()} all-gather" if gather else "")},
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,

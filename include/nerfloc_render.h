@@ -208,10 +208,26 @@ int nl_sample_pdf(const float* z_coarse, const float* weights_coarse, int Sc, co
 /* ---- the fused path ----------------------------------------------------------------------------- */
 size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R);   /* recommended size */
 size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V);          /* one-ray-chunk minimum */
+/* Options of nl_render_rays_ex.  early_term_eps > 0 enables early-termination compositing (BASELINE.json config 5; the reference
+ * has no such switch): along every ray the colour blend (model.py:528-538), feat_mlp (model.py:595) and the compositing reads of
+ * the samples behind the point where the transmittance T (model.py:549-552) falls below eps are skipped; their total compositing
+ * weight is < eps, so rgb / feat change by < eps * max|value| (weights, depth, depth_uncertainty and mask are computed from all
+ * samples and do not change at all).  0 = off = nl_render_rays.  The density itself cannot be skipped: the ray U-Net
+ * (ray_unet.py:55-69) runs along the whole ray. */
+typedef struct nl_render_opts {
+  float early_term_eps;   /* 0 (off) or in (0, 1): e.g. 1e-5 keeps BASELINE's 1e-4 with a wide margin */
+  int32_t reserved[7];    /* must be 0 */
+} nl_render_opts;
+
 /* rays_o, rays_d (R,3); z_vals (R,S) or NULL to generate linspace(near,far,S) (model.py:451-458,483-484). */
 int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,
                    const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd,
                    const nl_render_out* out, void* ws, size_t ws_bytes, void* stream);
+
+/* nl_render_rays with options (opts == NULL: identical to nl_render_rays). */
+int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,
+                      const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd,
+                      const nl_render_out* out, void* ws, size_t ws_bytes, void* stream, const nl_render_opts* opts);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

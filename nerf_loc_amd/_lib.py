@@ -46,6 +46,10 @@ class NlRenderOut(C.Structure):
         "sigma", "feature_agg", "mv_feature_agg", "geo", "knn_idx", "knn_d2")]
 
 
+class NlRenderOpts(C.Structure):
+    _fields_ = [("early_term_eps", C.c_float), ("reserved", C.c_int32 * 7)]
+
+
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)
 _P, _I, _L, _Z, _F = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _CFG, _DESC, _OUT = C.POINTER(NlConfig), C.POINTER(NlFrameDesc), C.POINTER(NlRenderOut)
@@ -77,6 +81,7 @@ SYMBOLS = [
     ("nl_render_rays_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_render_rays_min_workspace_bytes", _Z, [_CFG, _I]),
     ("nl_render_rays", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P]),
+    ("nl_render_rays_ex", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P, C.POINTER(NlRenderOpts)]),
     ("nl_setup_workspace_bytes", _Z, [_I, _I, _I, _I]),
     ("nl_cross_view_features", _I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _Z, _P]),
     ("nl_get_rays", _I, [_P, _P, _P, _I, _I, _L, _P, _P, _P]),

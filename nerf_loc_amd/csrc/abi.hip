@@ -32,14 +32,16 @@ int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const fl
 int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
-int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st);
+int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st,
+                    const int* n_alive = nullptr, int S = 1);
+int nl_launch_termination(const float* z_vals, const float* sigma, int64_t R, int S, float eps, int* n_alive, int* tile_list, int* tile_count, hipStream_t st);
 int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const float* pix,
                              const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask, float* weights,
                              float* depth_coarse, hipStream_t st);
 int nl_launch_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R,
                          float* z_out, hipStream_t st);
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
-                        int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst, hipStream_t st);
+                        int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst, hipStream_t st, const int* n_alive = nullptr);
 
 size_t nl_point_stream_bytes(int W);
 int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
@@ -304,7 +306,7 @@ struct Bump {
 struct MvBufs { float *vis, *dd, *g393, *t64; };
 struct PtBufs { int* idx; float *d2, *X, *H1, *H2, *KV, *Q, *O, *FCo, *wscale; };
 struct UnBufs { float *r1, *c1, *r2, *c2, *r3, *c3, *x0r, *x0, *x1r, *x1, *x2r, *x2, *outr; };
-struct HdBufs { float *sigma, *fth, *hc, *wsum, *blA, *rgb_s; };
+struct HdBufs { float *sigma, *fth, *hc, *wsum, *blA, *rgb_s; int *n_alive, *tile_list, *tile_count; };
 
 // leading dimensions of the two feature-width-dependent staging rows (416 and 288 at C = 192).  LDG: mv_stats zero-fills columns
 // 2F+3 .. LDG-1, so out_fc's K is a whole number of 32-wide chunks; LDX: [posenc 63 | ray_diff 27 | F] padded likewise
@@ -341,6 +343,7 @@ void carve_hd(Bump& b, const nl_config* c, int V, int64_t R, HdBufs& h) {
   const size_t N = (size_t)R * c->S;
   h.sigma = b.take<float>(N); h.fth = b.take<float>(N * c->W); h.hc = b.take<float>((size_t)R * c->W); h.wsum = b.take<float>((size_t)R);
   h.blA = b.take<float>(N * 32); h.rgb_s = b.take<float>(N * 3);
+  h.n_alive = b.take<int>((size_t)R); h.tile_list = b.take<int>(N / 32 + 2); h.tile_count = b.take<int>(1);
 }
 
 struct RenderBufs {
@@ -365,14 +368,17 @@ struct Ctx {
 
 struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; int ntap = 1; };
 
+struct TileMap { const int* map; const int* count; };
 struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0;
                 const float* sig_w = nullptr; const float* sig_b = nullptr; float* sig_out = nullptr; };   // out: destination when fused
 
 // fills the launch descriptor; *fused says whether the optional row epilogue will run inside the GEMM (else the caller runs it)
 int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
-             int So = 0, int Li = 0, int Lo = 0, int ostride = 1, int ooff = 0, const RowEpi* epi = nullptr, bool* fused = nullptr) {
+             int So = 0, int Li = 0, int Lo = 0, int ostride = 1, int ooff = 0, const RowEpi* epi = nullptr, bool* fused = nullptr,
+             const TileMap* tiles = nullptr) {
   NlGemmArgs a;
   memset(&a, 0, sizeof(a));
+  if (tiles) { a.tile_map = tiles->map; a.tile_count = tiles->count; }
   int ksum = 0;
   for (int i = 0; i < NL_GEMM_MAX_SEG; ++i) a.kstart[i] = 0x7fffffff;
   for (int i = 0; i < nseg; ++i) {
@@ -401,6 +407,7 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     if (nl_tgemm_supported(a, x.c->precision)) { a.C = epi->out; if (fused) *fused = true; }
     else a.epi = NL_EPI_NONE;
   }
+  if (tiles && !nl_tgemm_supported(a, x.c->precision)) { a.tile_map = nullptr; a.tile_count = nullptr; }   // generic kernels compute every row
   return nl_gemm_launch(a, x.c->precision, x.st);
 }
 
@@ -633,29 +640,34 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
 }
 
 // the part of the heads that needs feature_agg only (not the density): feat_mlp.0, the per-sample blend projection, the blend tail
-int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const float* rgbv, int64_t N, bool want_feat, const HdBufs& h, int parts = 7) {
+// term == true: n_alive / tile_list of `h` are valid (nl_launch_termination ran): dead samples are skipped
+int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const float* rgbv, int64_t N, bool want_feat, const HdBufs& h, int parts = 7,
+                 bool term = false) {
   const int W = x.c->W;
   if (want_feat && (parts & 1)) {
     SegSpec s0{FA, W, W, 0, 1};
-    NL_TRY(run_gemm(x, G_FEAT0, &s0, 1, N, h.fth, W, NL_ACT_LRELU));
+    const TileMap tm{h.tile_list, h.tile_count};
+    NL_TRY(run_gemm(x, G_FEAT0, &s0, 1, N, h.fth, W, NL_ACT_LRELU, 0, 0, 0, 1, 0, nullptr, nullptr, term ? &tm : nullptr));
   }
   SegSpec sa{FA, W, W, 0, 1};
   if (parts & 2) NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
   if (parts & 4) NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
-                                        x.p<float>(x.L.bl4_b), h.rgb_s, x.st));
+                                        x.p<float>(x.L.bl4_b), h.rgb_s, x.st, term ? h.n_alive : nullptr, x.c->S));
   return NL_OK;
 }
 
 int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
              const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false,
-             bool pre_done = false) {
+             bool pre_done = false, float term_eps = 0.f) {
   const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
   if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
   const bool want_feat = out->feat != nullptr;
-  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h));
+  const bool term = term_eps > 0.f && !pre_done;
+  if (term) NL_TRY(nl_launch_termination(z, h.sigma, R, S, term_eps, h.n_alive, h.tile_list, h.tile_count, x.st));
+  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7, term));
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
-                             want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st));
+                             want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st, term ? h.n_alive : nullptr));
   if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
     SegSpec s1[2] = {{h.hc, W, W, 0, 1}, {h.wsum, 1, 1, 0, 1}};
     NL_TRY(run_gemm(x, G_FEAT2, s1, 2, R, out->feat + ray0 * C, C, NL_ACT_NONE));
@@ -946,7 +958,15 @@ size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
 int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
                    const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
                    size_t ws_bytes, void* stream) {
+  return nl_render_rays_ex(cfg, packed, f, qc, rays_o, rays_d, z_vals, R, white, out, ws, ws_bytes, stream, nullptr);
+}
+
+int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
+                      const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
+                      size_t ws_bytes, void* stream, const nl_render_opts* opts) {
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
+  const float term_eps = opts ? opts->early_term_eps : 0.f;
+  if (term_eps < 0.f || term_eps >= 1.f) return NL_ERR_BAD_ARG;
   if (!cfg_ok(cfg) || !packed || !f || !qc || !rays_o || !rays_d || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, S = cfg->S, W = cfg->W;
   // largest ray chunk whose buffers fit the workspace
@@ -986,7 +1006,7 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
     // ---- fork 2: heads that need feature_agg only, beside the ray U-Net
     bool pre_done = false;
     int pre_parts = 0;
-    if (side && (side_mask & 2)) {
+    if (side && (side_mask & 2) && term_eps == 0.f) {
       NL_CHECK_HIP(hipEventRecord(side->e[2], x.st));
       NL_CHECK_HIP(hipStreamWaitEvent(side->s[1], side->e[2], 0));
       Ctx xs = x;
@@ -1001,7 +1021,7 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
     if (pre_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, side->e[3], 0));
     if (pre_done && pre_parts != 7) NL_TRY(do_heads_pre(x, V, rb.FA, rb.bl1, rb.rgbv, N, out->feat != nullptr, rb.hd, 7 & ~pre_parts));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, pre_done));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, pre_done, term_eps));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

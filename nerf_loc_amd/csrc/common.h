@@ -150,6 +150,9 @@ struct NlGemmArgs {
   float ep_eps;
   // NL_EPI_LNSLAB only, optional: sigma[m] = softplus(ep_sig_w . out_row + ep_sig_b[0]) (model.py:525) from the values in registers
   const float* ep_sig_w; const float* ep_sig_b; float* ep_sig_out;
+  // optional (tgemm.hip, plain row mapping, no fused epilogue): only the 32-row tiles listed in tile_map[0 .. *tile_count) are computed
+  // (early termination: rows of dead samples are neither read nor written)
+  const int* tile_map; const int* tile_count;
 };
 enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1, NL_EPI_LNSLAB = 2 };
 

@@ -40,9 +40,13 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA
                                                     int N, int V,
                                                     const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
                                                     const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
-                                                    float* __restrict__ rgb_s) {
+                                                    float* __restrict__ rgb_s, const int* __restrict__ n_alive, int S) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  if (n_alive) {   // early termination: the sample lies behind the point where the ray's transmittance fell below eps
+    const int r = n / S;
+    if (n - r * S >= n_alive[r]) { rgb_s[3 * (size_t)n] = 0.f; rgb_s[3 * (size_t)n + 1] = 0.f; rgb_s[3 * (size_t)n + 2] = 0.f; return; }
+  }
   float lg[NL_MAX_VIEWS];
   float mx = -3.4e38f;
   float xa[32];   // per-sample part of layer 1 (feature_agg columns of rgb_blending_mlp.0)
@@ -93,11 +97,13 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
                                                         const int* __restrict__ valid_s, int R, int S, int C, int white_bkgd,
                                                         float* __restrict__ o_rgb, float* __restrict__ o_depth,
                                                         float* __restrict__ o_w, unsigned char* __restrict__ o_mask,
-                                                        float* __restrict__ o_unc, float* __restrict__ o_feat, float* __restrict__ o_wsum) {
+                                                        float* __restrict__ o_unc, float* __restrict__ o_feat, float* __restrict__ o_wsum,
+                                                        const int* __restrict__ n_alive) {
   __shared__ float wsh[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wv;
   if (r >= R) return;
+  const int na = n_alive ? n_alive[r] : S;   // early termination: colours / features of samples >= na are not evaluated (their weight is < eps)
   const float* z = z_vals + (size_t)r * S;
   float zs[CH], al[CH];
   float prod = 1.f;
@@ -132,8 +138,10 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
       T *= (1.f - al[j]);
       wsum += w[j];
       dsum += w[j] * zs[j];
-      const float* c = rgb_s + 3 * ((size_t)r * S + s);
-      cr += w[j] * c[0]; cg += w[j] * c[1]; cb += w[j] * c[2];
+      if (s < na) {
+        const float* c = rgb_s + 3 * ((size_t)r * S + s);
+        cr += w[j] * c[0]; cg += w[j] * c[1]; cb += w[j] * c[2];
+      }
       if (o_w) o_w[(size_t)r * S + s] = w[j];
       wsh[wv][s] = w[j];
     } else w[j] = 0.f;
@@ -165,13 +173,78 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
       const int c = c0 + lane;
       float acc = 0.f;
       if (c < C)
-        for (int s = 0; s < S; ++s) acc = fmaf(wsh[wv][s], ft[((size_t)r * S + s) * C + c], acc);
+        for (int s = 0; s < na; ++s) acc = fmaf(wsh[wv][s], ft[((size_t)r * S + s) * C + c], acc);
       if (c < C) o_feat[(size_t)r * C + c] = acc;
     }
   }
 }
 
+// Early termination (BASELINE config 5 / SURVEY §8f-4).  The density needs the whole ray (the U-Net runs along it), so only what
+// comes AFTER it can be skipped: the colour blend tail, feat_mlp.0's rows and the per-sample reads of the compositing.  One wave
+// per ray: n_alive[r] = number of leading samples whose transmittance T_s (exclusive cumprod of 1 - alpha, model.py:549-552) is
+// >= eps.  T is non-increasing, so the dropped samples are a suffix and their total weight is < eps.
+template <int CH>
+__global__ __launch_bounds__(256) void term_kernel(const float* __restrict__ z_vals, const float* __restrict__ sigma, int R, int S, float eps,
+                                                   int* __restrict__ n_alive) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wv;
+  if (r >= R) return;
+  const float* z = z_vals + (size_t)r * S;
+  float al[CH];
+  float prod = 1.f;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) {
+      const float delta = (s + 1 < S) ? z[s + 1] - z[s] : 1e2f;
+      al[j] = 1.f - expf(-delta * sigma[(size_t)r * S + s]);
+      prod *= (1.f - al[j]);
+    } else al[j] = 0.f;
+  }
+  float inc = prod;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc *= t;
+  }
+  float T = __shfl_up(inc, 1, 64);
+  if (lane == 0) T = 1.f;
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) { cnt += T >= eps ? 1 : 0; T *= (1.f - al[j]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) n_alive[r] = cnt;
+}
+
+// compact list of the 32-row tiles of (R*S) that hold at least one live sample (order arbitrary: every tile is computed independently)
+__global__ void tile_list_kernel(const int* __restrict__ n_alive, int R, int S, int ntiles, int* __restrict__ tile_list, int* __restrict__ count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const int r0 = (32 * t) / S, s0 = 32 * t - r0 * S;
+  const bool alive = s0 < n_alive[r0] || s0 + 32 > S;   // a tile that runs into the next ray holds that ray's first samples (always live)
+  if (alive) tile_list[atomicAdd(count, 1)] = t;
+}
+
 }  // namespace
+
+int nl_launch_termination(const float* z_vals, const float* sigma, int64_t R, int S, float eps, int* n_alive, int* tile_list, int* tile_count,
+                          hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  if (S > 256) return NL_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)nl_cdiv(R, 4));
+#define NL_TERM(CH) hipLaunchKernelGGL(term_kernel<CH>, grid, dim3(256), 0, st, z_vals, sigma, (int)R, S, eps, n_alive)
+  if (S <= 64) NL_TERM(1); else if (S <= 128) NL_TERM(2); else if (S <= 192) NL_TERM(3); else NL_TERM(4);
+#undef NL_TERM
+  NL_CHECK_HIP(hipMemsetAsync(tile_count, 0, sizeof(int), st));
+  const int ntiles = (int)nl_cdiv(R * S, 32);
+  hipLaunchKernelGGL(tile_list_kernel, dim3((unsigned)nl_cdiv(ntiles, 256)), dim3(256), 0, st, n_alive, (int)R, S, ntiles, tile_list, tile_count);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
 
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_,
                             const float* z_in, float* z_out, float* xyz, hipStream_t st) {
@@ -190,9 +263,9 @@ int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const fl
 }
 
 int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2,
-                    const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st) {
+                    const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st, const int* n_alive, int S) {
   if (N <= 0) return NL_OK;
-  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgbv, (int)N, V, w2, b2, w4, b4, rgb_s);
+  hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgbv, (int)N, V, w2, b2, w4, b4, rgb_s, n_alive, S);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
@@ -200,7 +273,7 @@ int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t
 // `ft` (R*S, C) is composited into feat_dst (R, C) (any channel count; the caller passes feat_mlp's hidden layer, see abi.hip)
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s,
                         int64_t R, int S, int C, int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst,
-                        hipStream_t st) {
+                        hipStream_t st, const int* n_alive) {
   if (R <= 0) return NL_OK;
   if (S > 256) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(R, 4));
@@ -210,7 +283,7 @@ int nl_launch_composite(const float* z_vals, const float* sigma, const float* rg
   unsigned char* o_mask = out->mask ? out->mask + ray0 : nullptr;
   float* o_unc = out->depth_uncertainty ? out->depth_uncertainty + ray0 : nullptr;
 #define NL_COMP(CH) hipLaunchKernelGGL(composite_kernel<CH>, grid, dim3(256), 0, st, z_vals, sigma, rgb_s, ft, valid_s, (int)R, S, C, \
-                                       white_bkgd, o_rgb, o_depth, o_w, o_mask, o_unc, feat_dst, wsum_dst)
+                                       white_bkgd, o_rgb, o_depth, o_w, o_mask, o_unc, feat_dst, wsum_dst, n_alive)
   if (S <= 64) NL_COMP(1);
   else if (S <= 128) NL_COMP(2);
   else if (S <= 192) NL_COMP(3);

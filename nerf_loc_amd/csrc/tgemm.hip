@@ -71,7 +71,13 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31;
-  const int m = blockIdx.x * (32 * NW) + 32 * wave + j;
+  int tile = blockIdx.x * NW + wave;
+  if (a.tile_map) {   // compacted tile list: workgroups past the end leave before any barrier; a partial last workgroup repeats its last tile
+    const int nt = *a.tile_count;
+    if ((int)blockIdx.x * NW >= nt) return;
+    tile = a.tile_map[tile < nt ? tile : nt - 1];
+  }
+  const int m = tile * 32 + j;
   const bool mok = m < a.M;
   int q = 0, t = 0;
   if (a.So > 0) { q = m / a.So; t = m - q * a.So; }
@@ -327,6 +333,7 @@ int nl_tgemm_nrt(int N) { return N <= 64 ? 2 : (N <= 128 ? 4 : 8); }
 size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 * nl_tgemm_nrt(N) * 1024; }
 
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
+  if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
   if (a.epi == NL_EPI_LNSLAB && ((a.So != 128 && a.So != 64 && a.So != 32) || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;

@@ -140,7 +140,9 @@ class HipRenderer:
 
     # ------------------------------------------------------------------ fused path
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
-                    intermediates: bool = False, want_feat: bool = True) -> Dict[str, torch.Tensor]:
+                    intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0) -> Dict[str, torch.Tensor]:
+        """early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
+        ray's transmittance falls below eps are not evaluated (rgb / feat move by < eps * max|value|; everything else is unchanged)."""
         self._ready()
         dev = self.device
         o, d = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev)
@@ -163,8 +165,11 @@ class HipRenderer:
             setattr(ro, k, t.data_ptr())
         need = self._ws_request or self.lib.nl_render_rays_workspace_bytes(ct.byref(self.cfg), self.V, R)
         ws = self._workspace(need)
-        L.check(self.lib.nl_render_rays(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(),
-                                        _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream()), "nl_render_rays")
+        opts = L.NlRenderOpts()
+        opts.early_term_eps = float(early_term_eps)
+        L.check(self.lib.nl_render_rays_ex(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(),
+                                           _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream(),
+                                           ct.byref(opts) if early_term_eps > 0 else None), "nl_render_rays")
         out["mask"] = out["mask"].bool()
         if intermediates:
             out["sigma"] = out["sigma"].view(R, S)

@@ -104,3 +104,37 @@ def test_full_size_batch_properties(scene):
     c = _render(r, scene, sel)
     for k in KEYS:
         assert torch.equal(a[k][torch.from_numpy(sel).to(a[k].device)], c[k]), ("shard invariance", k)
+
+
+@pytest.mark.parametrize("name", ["c2", "c5"])
+def test_early_termination_keeps_parity_and_skips_work(name):
+    """BASELINE config 5 names early-termination compositing.  With eps = 1e-5 the colours / features of the samples behind the point
+    where a ray's transmittance falls below eps are not evaluated: weights, depth, depth_uncertainty and mask are bit-identical,
+    rgb / feat move by less than eps * max|value| (far inside 1e-4), and a real share of the samples is skipped."""
+    sc = _scene(name)
+    cfg = sc["cfg"]
+    # random-init weights give a thin medium (alpha ~ 0.03 per sample: no ray ever gets opaque before its last sample), so the
+    # density head's bias is raised to make surfaces: sigma ~ 8 -> transmittance below 1e-5 after a few dozen samples
+    sc["weights"] = dict(sc["weights"])
+    sc["weights"]["sigma_mlp.0.bias"] = sc["weights"]["sigma_mlp.0.bias"] + 8.0
+    r = _renderer(sc, "bf16x3")
+    sel = np.arange(0, cfg.R, 4)
+    o, d = sc["rays"]["rays_o"][sel], sc["rays"]["rays_d"][sel]
+    z = _zbase(cfg, len(sel))
+    if cfg.N_importance > 0:
+        z, _, _ = r.hierarchical_depths(sc["rays"]["pixel_coordinates"][sel], sc["frame"]["K"], sc["frame"]["pose"], z, sc["u"][sel], near=cfg.near, far=cfg.far)
+    qc = sc["frame"]["pose"][:3, 3]
+    full = r.render_rays(o, d, qc, z_vals=z)
+    eps = 1e-5
+    et = r.render_rays(o, d, qc, z_vals=z, early_term_eps=eps)
+    for k in ("weights", "depth", "depth_uncertainty", "mask"):
+        assert torch.equal(full[k], et[k]), k
+    e_rgb = float((full["rgb"] - et["rgb"]).abs().max())
+    e_feat = float((full["feat"] - et["feat"]).abs().max()) / float(full["feat"].abs().max())
+    assert e_rgb < 1e-5 and e_feat < 2e-5, (e_rgb, e_feat)
+    # share of samples whose transmittance is already below eps (what the option skips)
+    w = full["weights"]
+    T = 1.0 - torch.cumsum(w, 1) + w            # transmittance before each sample (sum of the later weights incl. itself, weights sum to 1)
+    skipped = float((T < eps).float().mean())
+    print(f"\n{name}: early termination eps={eps}: {100 * skipped:.1f} % of the samples skipped, |d rgb| {e_rgb:.2e}, rel |d feat| {e_feat:.2e}")
+    assert skipped > 0.02
