@@ -91,7 +91,7 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -134,6 +134,11 @@ Layout make_layout(const nl_config* c) {
   set(G_T2O, 512, 64, true);
   set(G_T1E, 128, 32, true);
   set(G_T1O, 256, 32, true);
+  // both output phases of a stride-2 transposed convolution as ONE GEMM: K = [x[m] | x[m+1]], N = [even outputs | odd outputs]
+  // (the even phase's second K half is zero: 33 % more MACs for half the launches and one pass over the activations)
+  set(G_T3M, 256, 256, true);
+  set(G_T2M, 512, 128, true);
+  set(G_T1M, 256, 64, true);
   set(G_CONVOUT, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
   // feat_mlp's last Linear is applied AFTER compositing (it is linear): K = [composited hidden (W) | sum of weights (1)],
@@ -264,6 +269,22 @@ struct Packer {
     copy(b, L->bias[g], L->g[g].N);
   }
   // transposed conv weight (ci, co, 3): even phase uses tap 1; odd phase taps 2 (ioff 0) then 0 (ioff +1)
+  // merged phases (see G_T3M): columns [0, co) = even phase (tap 1 on x[m]), [co, 2 co) = odd phase (tap 2 on x[m], tap 0 on x[m+1])
+  void convT_merged(int g, const float* w, const float* b, int ci, int co) {
+    const GemmDim& d = L->g[g];
+    auto win = [&](int k0, int tap, int n0) {
+      const int n = ci * co;
+      hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, w, tap, 3, co * 3, ci, co, k0,
+                         (float*)(base + L->b32[g]) + n0, (unsigned short*)(base + L->bhi[g]) + (size_t)n0 * d.Kpad,
+                         (unsigned short*)(base + L->blo[g]) + (size_t)n0 * d.Kpad, d.Kpad, d.Npad, (unsigned short*)(base + L->bst[g]),
+                         nl_tgemm_nrt(d.N), n0);
+    };
+    win(0, 1, 0);
+    win(0, 2, co);
+    win(ci, 0, co);
+    copy(b, L->bias[g], co);
+    copy(b, L->bias[g] + 4 * (size_t)co, co);
+  }
   void convT(int ge, int go, const float* w, const float* b, int ci, int co) {
     block(ge, 0, w, 1, 3, co * 3, ci);
     block(go, 0, w, 2, 3, co * 3, ci);
@@ -578,6 +599,9 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
 int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr,
             bool need_geo = true) {
   const int W = x.c->W, S = x.c->S;
+  // the two phases of every transposed convolution as one launch (bf16 modes; the fp32 kernels keep the separate phases)
+  static const bool no_merge = getenv("NERFLOC_NO_TMERGE") != nullptr;
+  const bool merged = x.c->precision != NL_PREC_F32 && !no_merge;
   auto g = [&](int i) { return x.p<float>(x.L.un_g[i]); };
   auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
   const float eps = 1e-5f;
@@ -604,26 +628,35 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   }
   {  // trans_conv3: S/8 -> S/4
     const int Li = S / 8, Lo = S / 4;
-    SegSpec e[1] = {{u.c3, 128, 128, 0, 1}};
-    NL_TRY(run_gemm(x, G_T3E, e, 1, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 0));
     SegSpec o[2] = {{u.c3, 128, 128, 0, 1}, {u.c3, 128, 128, 1, 1}};
-    NL_TRY(run_gemm(x, G_T3O, o, 2, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    if (merged) NL_TRY(run_gemm(x, G_T3M, o, 2, R * Li, u.x0r, 256, NL_ACT_NONE, Li, Li, Li, 1, 0));   // row m = output positions 2m, 2m+1
+    else {
+      SegSpec e[1] = {{u.c3, 128, 128, 0, 1}};
+      NL_TRY(run_gemm(x, G_T3E, e, 1, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 0));
+      NL_TRY(run_gemm(x, G_T3O, o, 2, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    }
     NL_TRY(nl_launch_ln_slab_elu(u.x0r, R, Lo, 128, g(U_T3), b(U_T3), eps, u.x0, nullptr, x.st));
   }
   {  // trans_conv2 on cat[c2, x0]: S/4 -> S/2
     const int Li = S / 4, Lo = S / 2;
-    SegSpec e[2] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}};
-    NL_TRY(run_gemm(x, G_T2E, e, 2, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 0));
     SegSpec o[4] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}, {u.c2, 128, 128, 1, 1}, {u.x0, 128, 128, 1, 1}};
-    NL_TRY(run_gemm(x, G_T2O, o, 4, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    if (merged) NL_TRY(run_gemm(x, G_T2M, o, 4, R * Li, u.x1r, 128, NL_ACT_NONE, Li, Li, Li, 1, 0));
+    else {
+      SegSpec e[2] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}};
+      NL_TRY(run_gemm(x, G_T2E, e, 2, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 0));
+      NL_TRY(run_gemm(x, G_T2O, o, 4, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    }
     NL_TRY(nl_launch_ln_slab_elu(u.x1r, R, Lo, 64, g(U_T2), b(U_T2), eps, u.x1, nullptr, x.st));
   }
   {  // trans_conv1 on cat[c1, x1]: S/2 -> S
     const int Li = S / 2, Lo = S;
-    SegSpec e[2] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}};
-    NL_TRY(run_gemm(x, G_T1E, e, 2, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 0));
     SegSpec o[4] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}, {u.x1, 64, 64, 1, 1}};
-    NL_TRY(run_gemm(x, G_T1O, o, 4, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    if (merged) NL_TRY(run_gemm(x, G_T1M, o, 4, R * Li, u.x2r, 64, NL_ACT_NONE, Li, Li, Li, 1, 0));
+    else {
+      SegSpec e[2] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}};
+      NL_TRY(run_gemm(x, G_T1E, e, 2, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 0));
+      NL_TRY(run_gemm(x, G_T1O, o, 4, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 1));
+    }
     NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
   }
   {  // conv_out on cat[in, x2]
@@ -759,6 +792,9 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.convT(G_T3E, G_T3O, un[12], un[13], 128, 128);
   P.convT(G_T2E, G_T2O, un[16], un[17], 256, 64);
   P.convT(G_T1E, G_T1O, un[20], un[21], 128, 32);
+  P.convT_merged(G_T3M, un[12], un[13], 128, 128);
+  P.convT_merged(G_T2M, un[16], un[17], 256, 64);
+  P.convT_merged(G_T1M, un[20], un[21], 128, 32);
   { const int wo[2] = {W, 32}; P.conv3(G_CONVOUT, un[24], un[25], W + 32, wo, 2); }
   for (int u = 0; u < U_COUNT; ++u) {
     P.transpose(un[4 * u + 2], L.un_g[u], L.un_c[u], L.un_l[u]);   // (C, L) -> (L, C)
