@@ -53,6 +53,9 @@ size_t nl_point_stream2_bytes(int W);
 int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
                           const float* rd_w, void* out, int W, int F, hipStream_t st);
 bool nl_point_fused2_supported(int W, int precision);
+int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* st_fc,
+                           const void* st_f0, const void* st_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
+                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 
 namespace {
@@ -91,7 +94,7 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -139,6 +142,9 @@ Layout make_layout(const nl_config* c) {
   set(G_T3M, 256, 256, true);
   set(G_T2M, 512, 128, true);
   set(G_T1M, 256, 64, true);
+  // feat_mlp.0 and the blend projection with K in ACCUMULATOR order, for the per-sample chain kernel (tgemm.hip: sample_chain_kernel)
+  set(G_FEAT0P, W, W, true);
+  set(G_BLENDAP, W, 32, false);
   set(G_CONVOUT, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
   // feat_mlp's last Linear is applied AFTER compositing (it is linear): K = [composited hidden (W) | sum of weights (1)],
@@ -193,11 +199,15 @@ __device__ __forceinline__ unsigned short pk_f2bf(float x) {
 // dst[k0+k][n] (f32 [Kpad][Npad]) and bf16 hi/lo [n][Kpad] <- src[off + n*ld_n + k*ld_k], k < kc, n < N
 __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld_n, int ld_k, int kc, int N, int k0,
                                   float* __restrict__ b32, unsigned short* __restrict__ bhi, unsigned short* __restrict__ blo,
-                                  int Kpad, int Npad, unsigned short* __restrict__ bst, int nrts, int n0) {
+                                  int Kpad, int Npad, unsigned short* __restrict__ bst, int nrts, int n0, int perm = 0) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kc * N) return;
   int k = i / N, n = i - k * N;
-  float v = src[off + (size_t)n * ld_n + (size_t)k * ld_k];
+  // perm (k0 == 0 only): K position k of the packed matrix holds source column 32 c + m(8 ks + t, hh) for k = 32 c + 16 ks + 8 hh + t,
+  // m(r, hh) = (r & 3) + 8 (r >> 2) + 4 hh — the order in which a 32x32 accumulator tile hands its rows to the next MFMA as B operand
+  int ksrc = k;
+  if (perm) { const int r = 8 * ((k >> 4) & 1) + (k & 7), hh = (k >> 3) & 1; ksrc = (k & ~31) + (r & 3) + 8 * (r >> 2) + 4 * hh; }
+  float v = src[off + (size_t)n * ld_n + (size_t)ksrc * ld_k];
   b32[(size_t)(k0 + k) * Npad + n] = v;
   unsigned short h = pk_f2bf(v);
   float hf = __uint_as_float(((unsigned int)h) << 16);
@@ -240,12 +250,12 @@ struct Packer {
   const Layout* L;
   hipStream_t st;
   int rc = NL_OK;
-  void block(int g, int k0, const float* src, int off, int ld_n, int ld_k, int kc) {
+  void block(int g, int k0, const float* src, int off, int ld_n, int ld_k, int kc, int perm = 0) {
     const GemmDim& d = L->g[g];
     int n = kc * d.N;
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, off, ld_n, ld_k, kc, d.N, k0,
                        (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad,
-                       (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0);
+                       (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0, perm);
   }
   void copy(const float* src, size_t dst_off, int n) {
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), n);
@@ -547,8 +557,11 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
 }
 
 // knn_done != null: the caller already ran the KNN (+ the aggregation scale) on a side stream and hands over the event to wait for
+// chain != null (fused render path, W = 256, bf16 modes): fc + LayerNorm + scale, feat_mlp.0 (chain->fth, may be null) and the blend
+// projection (chain->blA) run as ONE kernel that keeps feature_agg in registers between them; *chain->done says whether it did
+struct ChainOut { float* fth; float* blA; bool* done; };
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
-             float* FA, const PtBufs& p, hipEvent_t knn_done = nullptr) {
+             float* FA, const PtBufs& p, hipEvent_t knn_done = nullptr, const ChainOut* chain = nullptr) {
   const int W = x.c->W, F = f->C + 3;
   const bool fused_path = K == 8 && nl_point_fused_supported(W, x.c->precision);
   if (!knn_done) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
@@ -582,6 +595,14 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     NL_TRY(run_gemm(x, G_BASE4, &s2, 1, MK, p.H1, W, NL_ACT_LRELU));
     NL_TRY(run_gemm(x, G_KV, &s1, 1, MK, p.KV, 256, NL_ACT_NONE));
     NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
+  }
+  static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
+  if (chain && chain->done) *chain->done = false;
+  if (chain && !no_chain && W == 256 && x.c->precision != NL_PREC_F32) {
+    NL_TRY(nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk + x.L.bst[G_FC], x.pk + x.L.bst[G_FEAT0P],
+                                  x.pk + x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st));
+    if (chain->done) *chain->done = true;
+    return NL_OK;
   }
   SegSpec so{p.O, 128, 128, 0, 1};
   // fc + residual + LayerNorm + aggregation scale: inside the GEMM's epilogue when the streaming kernel takes it
@@ -691,14 +712,14 @@ int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const f
 
 int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
              const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false,
-             bool pre_done = false, float term_eps = 0.f) {
+             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0) {
   const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
   if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
   const bool want_feat = out->feat != nullptr;
   const bool term = term_eps > 0.f && !pre_done;
   if (term) NL_TRY(nl_launch_termination(z, h.sigma, R, S, term_eps, h.n_alive, h.tile_list, h.tile_count, x.st));
-  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7, term));
+  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7 & ~chain_parts, term));   // chain_parts: what the chain kernel already produced
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
                              want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st, term ? h.n_alive : nullptr));
   if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
@@ -804,6 +825,11 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.block(G_FEAT2, 0, t[T_F2W], 0, W, 1, W);
   P.block(G_FEAT2, W, t[T_F2B], 0, 1, 0, 1);   // bias as the K-row that meets the weight-sum column
   P.block(G_BLENDA, 0, t[T_BL0W], 0, W + F + 5, 1, W);
+  if (W % 32 == 0) {   // accumulator-order copies for the chain kernel
+    P.block(G_FEAT0P, 0, t[T_F0W], 0, W, 1, W, 1);
+    P.copy(t[T_F0B], L.bias[G_FEAT0P], W);
+    P.block(G_BLENDAP, 0, t[T_BL0W], 0, W + F + 5, 1, W, 1);
+  }
   P.block(G_BLENDP, 0, t[T_BL0W], W + 3, W + F + 5, 1, C);
   if (nl_pack_ptt(t[T_B0W], t[T_B0B], W, F, L.g[G_PTT].Kpad, L.g[G_PTT].Npad, (float*)((char*)packed + L.b32[G_PTT]),
                   (float*)((char*)packed + L.bias[G_PTT]), st) != NL_OK) return NL_ERR_HIP;
@@ -1038,11 +1064,16 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     }
     NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
-    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, knn_done));
+    // with early termination feat_mlp.0 runs later, over the live tiles only; otherwise the chain kernel produces it right here
+    bool chain_done = false;
+    const bool want_feat = out->feat != nullptr;
+    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done};
+    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, knn_done, &chain));
+    const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
     // ---- fork 2: heads that need feature_agg only, beside the ray U-Net
     bool pre_done = false;
     int pre_parts = 0;
-    if (side && (side_mask & 2) && term_eps == 0.f) {
+    if (side && (side_mask & 2) && term_eps == 0.f && !chain_done) {
       NL_CHECK_HIP(hipEventRecord(side->e[2], x.st));
       NL_CHECK_HIP(hipStreamWaitEvent(side->s[1], side->e[2], 0));
       Ctx xs = x;
@@ -1057,7 +1088,7 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
     if (pre_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, side->e[3], 0));
     if (pre_done && pre_parts != 7) NL_TRY(do_heads_pre(x, V, rb.FA, rb.bl1, rb.rgbv, N, out->feat != nullptr, rb.hd, 7 & ~pre_parts));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, pre_done, term_eps));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, pre_done, term_eps, chain_parts));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

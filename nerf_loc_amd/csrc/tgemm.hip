@@ -326,6 +326,196 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     }
 }
 
+
+// ====================================================================================================================
+// Per-sample chain after the neural-point branch (W = 256):   feature_agg = LayerNorm(fc(O) + G) * wscale     (ibrnet.py:110-117,
+//   model.py:419-427)  ->  feat_mlp.0 + LeakyReLU (model.py:85-89)  and  the feature_agg columns of rgb_blending_mlp.0 (model.py:532).
+// As three launches feature_agg (N x W fp32) is written once and read back twice (1.07 GB per config-2 batch) by kernels that are
+// HBM-bound.  Here a wave keeps its 32 rows: the LayerNorm output stays in the accumulator registers, is split to bf16 hi/lo in place
+// and IS the B operand of the next two products (their weight streams are packed with K in accumulator order, like the fused
+// neural-point kernel); feature_agg is still written (the ray U-Net reads it), but never read back here.  One workgroup per CU
+// (the two activation sets + 128 accumulators need the 512-register file); the K-outer chunk pipeline of tgemm_kernel otherwise.
+struct NlChainArgs {
+  const float* O; const float* G; const float* wscale; const float* gamma; const float* beta; float eps;
+  const char* st_fc; const char* st_f0; const char* st_ba; const float* bias_f0;
+  float* FA; float* fth; float* blA;
+  int M;
+};
+
+template <bool X3>
+__global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a) {
+  constexpr int NW = 4, PARTS = X3 ? 2 : 1;
+  constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per LDS slot (sized for 8 row tiles)
+  __shared__ uint4 lds_all[2 * SLOT16 + 3 * 64];
+  tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
+  float* stab = reinterpret_cast<float*>(lds_all + 2 * SLOT16);   // gamma | beta | feat_mlp.0 bias
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31;
+  const int m = blockIdx.x * (32 * NW) + 32 * wave + j;
+  const bool mok = m < a.M;
+  const int mm = mok ? m : a.M - 1;
+  for (int i = tid; i < 256; i += 256) { stab[i] = a.gamma[i]; stab[256 + i] = a.beta[i]; stab[512 + i] = a.bias_f0 ? a.bias_f0[i] : 0.f; }
+
+  tg_f32x16 acc[8];
+  // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of LDS slot `slot`
+  auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
+    constexpr int NRT = decltype(Nc)::value, nt = 2 * NRT;
+    const tg_bf16x8* L = ring[slot];
+    auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
+      const int ks = tt / NRT, rt = tt - ks * NRT;
+      ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
+      if (X3) al = L[((1 * 2 + ks) * NRT + rt) * 64 + lane];
+    };
+    tg_bf16x8 ah[3], al[3];
+    ldA(0, ah[0], al[0]);
+    ldA(1, ah[1], al[1]);
+#pragma unroll
+    for (int tt = 0; tt < nt; ++tt) {
+      if (tt + 2 < nt) ldA(tt + 2, ah[(tt + 2) % 3], al[(tt + 2) % 3]);
+      const int ks = tt / NRT, rt = tt - ks * NRT;
+      if (X3) {
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], acc[rt], 0, 0, 0);
+      }
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // weights of chunk c of a stream with NRT row tiles: every wave stages its share through registers (coalesced 16-B loads)
+  auto load_w = [&](auto Nc, const char* st, int c, tg_bf16x8 (&w)[PARTS * 4]) __attribute__((always_inline)) {
+    constexpr int NRT = decltype(Nc)::value, NPW = PARTS * 2 * NRT / NW;
+    const tg_bf16x8* src = reinterpret_cast<const tg_bf16x8*>(st) + (size_t)c * (4 * NRT * 64);
+#pragma unroll
+    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[(wave + NW * jj) * 64 + lane];
+  };
+  auto store_w = [&](auto Nc, int slot, const tg_bf16x8 (&w)[PARTS * 4]) __attribute__((always_inline)) {
+    constexpr int NRT = decltype(Nc)::value, NPW = PARTS * 2 * NRT / NW;
+#pragma unroll
+    for (int jj = 0; jj < NPW; ++jj) ring[slot][(wave + NW * jj) * 64 + lane] = w[jj];
+  };
+  using N8 = std::integral_constant<int, 8>;
+  using N2 = std::integral_constant<int, 2>;
+  tg_bf16x8 wreg[PARTS * 4];
+
+  // ---------------------------------------------------------------- stage 1: fc (K = 128) on the attention output
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  auto load_o = [&](int c, float4 (&raw)[4]) __attribute__((always_inline)) {
+    const float* p = a.O + (size_t)mm * 128 + 32 * c + 8 * hh;
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) raw[pc] = *(const float4*)(p + 16 * (pc >> 1) + 4 * (pc & 1));
+  };
+  {
+    float4 raw[4];
+    load_o(0, raw); load_w(N8{}, a.st_fc, 0, wreg);
+    store_w(N8{}, 0, wreg);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      tg_bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float v[8] = {raw[2 * ks].x, raw[2 * ks].y, raw[2 * ks].z, raw[2 * ks].w, raw[2 * ks + 1].x, raw[2 * ks + 1].y, raw[2 * ks + 1].z, raw[2 * ks + 1].w};
+        tg_split8<X3>(v, bh[ks], bl[ks]);
+      }
+      if (g + 1 < 4) { load_o(g + 1, raw); load_w(N8{}, a.st_fc, g + 1, wreg); }
+      else load_w(N8{}, a.st_f0, 0, wreg);   // the next stage's first chunk
+      compute(N8{}, g & 1, bh, bl);
+      store_w(N8{}, (g + 1) & 1, wreg);
+      __syncthreads();
+    }
+  }
+  // ---------------------------------------------------------------- residual + LayerNorm(row) + aggregation scale -> feature_agg (and the next B operand)
+  tg_bf16x8 Xh[16], Xl[16];
+  {
+    const float* rrow = a.G + (size_t)mm * 256;
+    float s1 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 r4 = *(const float4*)(rrow + 32 * rt + 8 * gq + 4 * hh);
+        acc[rt][4 * gq + 0] += r4.x; acc[rt][4 * gq + 1] += r4.y; acc[rt][4 * gq + 2] += r4.z; acc[rt][4 * gq + 3] += r4.w;
+        s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 / 256.f;
+    float s2 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.f / sqrtf(s2 / 256.f + a.eps);
+    const float sc = a.wscale[mm];
+    float* crow = a.FA + (size_t)mm * 256;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+      float v[16];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = 32 * rt + 8 * gq + 4 * hh;
+        const float4 g4 = *(const float4*)(stab + n), be4 = *(const float4*)(stab + 256 + n);
+        v[4 * gq + 0] = ((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x) * sc;
+        v[4 * gq + 1] = ((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y) * sc;
+        v[4 * gq + 2] = ((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z) * sc;
+        v[4 * gq + 3] = ((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w) * sc;
+        if (mok) *(float4*)(crow + n) = make_float4(v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]);
+      }
+      // accumulator registers 8 s .. 8 s + 7 of row tile rt = k-slots of k-step 2 rt + s in accumulator order
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI) {
+        const float u[8] = {v[8 * sI], v[8 * sI + 1], v[8 * sI + 2], v[8 * sI + 3], v[8 * sI + 4], v[8 * sI + 5], v[8 * sI + 6], v[8 * sI + 7]};
+        tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
+      }
+    }
+  }
+  // ---------------------------------------------------------------- stage 2: feat_mlp.0 (K = 256 in accumulator order), stage 3: blend projection (N = 32)
+  auto from_x = [&](auto Nc, const char* st, const char* st_next, bool more) __attribute__((always_inline)) {
+    constexpr int NRT = decltype(Nc)::value;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+    tg_static_for<8>([&](auto Gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(Gc)::value;
+      const tg_bf16x8 bh[2] = {Xh[2 * g], Xh[2 * g + 1]};
+      const tg_bf16x8 bl[2] = {Xl[2 * g], Xl[2 * g + 1]};
+      if constexpr (g + 1 < 8) load_w(Nc, st, g + 1, wreg);
+      compute(Nc, g & 1, bh, bl);
+      if constexpr (g + 1 < 8) store_w(Nc, (g + 1) & 1, wreg);
+      __syncthreads();
+    });
+    (void)st_next; (void)more;
+  };
+  if (a.fth) {
+    from_x(N8{}, a.st_f0, nullptr, false);   // (its first chunk was staged at the end of stage 1)
+    float* frow = a.fth + (size_t)mm * 256;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = 32 * rt + 8 * gq + 4 * hh;
+        const float4 b4 = *(const float4*)(stab + 512 + n);
+        if (mok) *(float4*)(frow + n) = make_float4(nl_lrelu(acc[rt][4 * gq] + b4.x), nl_lrelu(acc[rt][4 * gq + 1] + b4.y),
+                                                    nl_lrelu(acc[rt][4 * gq + 2] + b4.z), nl_lrelu(acc[rt][4 * gq + 3] + b4.w));
+      }
+  }
+  // the blend projection's first chunk: slot 0 is free again (the last chunk of the previous stage sat in slot 1 and everyone is past the barrier)
+  load_w(N2{}, a.st_ba, 0, wreg);
+  store_w(N2{}, 0, wreg);
+  __syncthreads();
+  from_x(N2{}, a.st_ba, nullptr, false);
+  if (mok) {
+    float* brow = a.blA + (size_t)m * 32;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      *(float4*)(brow + 8 * gq + 4 * hh) = make_float4(acc[0][4 * gq], acc[0][4 * gq + 1], acc[0][4 * gq + 2], acc[0][4 * gq + 3]);
+  }
+}
+
 }  // namespace
 
 // stream layout helpers (also used by the packer in abi.hip)
@@ -361,5 +551,16 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   else if (nrt == 4) { if (x3) NL_TG(4, 4, true); else NL_TG(4, 4, false); }
   else { if (x3) NL_TG(2, 4, true); else NL_TG(2, 4, false); }
 #undef NL_TG
+  return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+
+int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* st_fc,
+                           const void* st_f0, const void* st_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
+                           hipStream_t st) {
+  if (M <= 0) return NL_OK;
+  NlChainArgs a{O, G, wscale, gamma, beta, eps, (const char*)st_fc, (const char*)st_f0, (const char*)st_ba, bias_f0, FA, fth, blA, (int)M};
+  dim3 grid((unsigned)nl_cdiv(M, 128));
+  if (precision == NL_PREC_BF16X3) hipLaunchKernelGGL((sample_chain_kernel<true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((sample_chain_kernel<false>), grid, dim3(256), 0, st, a);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
