@@ -53,8 +53,8 @@ size_t nl_point_stream2_bytes(int W);
 int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
                           const float* rd_w, void* out, int W, int F, hipStream_t st);
 bool nl_point_fused2_supported(int W, int precision);
-int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* st_fc,
-                           const void* st_f0, const void* st_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
+int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
+                           size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
                            hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 
@@ -599,8 +599,8 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
   if (chain && chain->done) *chain->done = false;
   if (chain && !no_chain && W == 256 && x.c->precision != NL_PREC_F32) {
-    NL_TRY(nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk + x.L.bst[G_FC], x.pk + x.L.bst[G_FEAT0P],
-                                  x.pk + x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st));
+    NL_TRY(nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_FC], x.L.bst[G_FEAT0P],
+                                  x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st));
     if (chain->done) *chain->done = true;
     return NL_OK;
   }

@@ -337,27 +337,99 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 // (the two activation sets + 128 accumulators need the 512-register file); the K-outer chunk pipeline of tgemm_kernel otherwise.
 struct NlChainArgs {
   const float* O; const float* G; const float* wscale; const float* gamma; const float* beta; float eps;
-  const char* st_fc; const char* st_f0; const char* st_ba; const float* bias_f0;
+  const char* wbase; unsigned off_fc, off_f0, off_ba;   // the three weight streams as byte offsets into one packed blob
+  const float* bias_f0;
   float* FA; float* fth; float* blA;
   int M;
 };
 
-template <bool X3>
-__global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a) {
-  constexpr int NW = 4, PARTS = X3 ? 2 : 1;
-  constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per LDS slot (sized for 8 row tiles)
-  __shared__ uint4 lds_all[2 * SLOT16 + 3 * 64];
+typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
+
+// 20 weight chunks per 128-row tile: fc 0..3 | feat_mlp.0 4..11 | blend projection 12..19; 32 k each
+struct ChainGeo {
+  static constexpr int NCH = 20;
+  static constexpr int cm(int c) { return ((c % NCH) + NCH) % NCH; }
+  static constexpr int stage(int c) { return cm(c) < 4 ? 0 : cm(c) < 12 ? 1 : 2; }
+  static constexpr int nrt(int c) { return stage(c) == 2 ? 2 : 8; }
+  static constexpr int idx(int c) { return stage(c) == 0 ? cm(c) : stage(c) == 1 ? cm(c) - 4 : cm(c) - 12; }
+  // VMEM operations other than LDS-DMA pieces issued after chunk c's MFMAs and before the next chunk's wait (per lane-instruction):
+  // after the fc: wscale load + 32 feature_agg stores; after feat_mlp.0: 32 stores; in the first blend chunk: the next tile's 16
+  // attention-output loads + 32 residual loads; after the blend projection: 4 stores.  Waits count them: vmcnt retires in issue order.
+  static constexpr int post(int c, bool feat) { return cm(c) == 3 ? 33 : cm(c) == 11 ? (feat ? 32 : 0) : cm(c) == 12 ? 16 + 32 : cm(c) == 19 ? 4 : 0; }
+};
+
+template <bool X3, bool FEAT>
+__global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a, const int ntiles) {
+  constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = ChainGeo::NCH, NB = 4;
+  constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per ring slot (sized for 8 row tiles)
+  __shared__ uint4 lds_all[NB * SLOT16 + 3 * 64];
   tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
-  float* stab = reinterpret_cast<float*>(lds_all + 2 * SLOT16);   // gamma | beta | feat_mlp.0 bias
+  float* stab = reinterpret_cast<float*>(lds_all + NB * SLOT16);   // gamma | beta | feat_mlp.0 bias
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31;
-  const int m = blockIdx.x * (32 * NW) + 32 * wave + j;
-  const bool mok = m < a.M;
-  const int mm = mok ? m : a.M - 1;
+  int tile = (int)nl_xcd_block();
+  if (tile >= ntiles) return;
+  // stores go through buffer descriptors: rows past M carry an out-of-range offset and are dropped, so every store instruction is
+  // always issued and the vmcnt bookkeeping below is exact
+  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)a.FA, 0, a.M * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rFT = __builtin_amdgcn_make_buffer_rsrc((void*)(FEAT ? a.fth : a.FA), 0, a.M * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBL = __builtin_amdgcn_make_buffer_rsrc((void*)a.blA, 0, a.M * 128, 0x00020000);
   for (int i = tid; i < 256; i += 256) { stab[i] = a.gamma[i]; stab[256 + i] = a.beta[i]; stab[512 + i] = a.bias_f0 ? a.bias_f0[i] : 0.f; }
 
+  // weight chunks by LDS-DMA into a 4-slot ring, three chunks ahead (buffer form: see point_fused2.hip); piece p = 4 i + wave
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wbase, 0, 0x7fffffff, 0x00020000);
+  const unsigned wvoff = wave * 1024 + lane * 16;
+  uint4* lw = lds_all + wave * 64;
+  auto ppw = [](int c) constexpr { return PARTS * 2 * ChainGeo::nrt(c) / NW; };
+  auto dma_chunk = [&](auto Cc) __attribute__((always_inline)) {
+    constexpr int c = ChainGeo::cm(decltype(Cc)::value), st = ChainGeo::stage(c), nrt = ChainGeo::nrt(c);
+    unsigned so = (st == 0 ? a.off_fc : st == 1 ? a.off_f0 : a.off_ba) + (unsigned)(ChainGeo::idx(c) * 4 * nrt * 1024);
+    tg_static_for<ppw(c)>([&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      unsigned s2 = so + i * 4096;
+      asm volatile("" : "+s"(s2));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + (c % NB) * SLOT16 + i * 256), 16, wvoff, s2, 0, 0);
+    });
+  };
+
   tg_f32x16 acc[8];
-  // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of LDS slot `slot`
+  tg_bf16x8 Xh[16], Xl[16];
+  tg_f32x4 oraw[16];
+  int m = 0, mm = 0;
+  bool mok = false;
+  // attention output rows (fc's B operand: 8 k-steps x 8 floats per lane) and the residual rows as fc's accumulator init
+  // The blend projection only uses accumulators 0 and 1: the next tile's inputs are fetched while it runs — residual rows of row
+  // tiles 2..7 straight into their accumulators, those of row tiles 0, 1 into `gtmp` (moved over when the projection is stored).
+  tg_f32x4 gtmp[8];
+  auto load_tile_inputs = [&](int t) __attribute__((always_inline)) {
+    m = t * 128 + 32 * wave + j;
+    mok = m < a.M;
+    mm = mok ? m : a.M - 1;
+    const float* p = a.O + (size_t)mm * 128 + 8 * hh;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oraw[i] = *reinterpret_cast<const tg_f32x4*>(p + 16 * (i >> 1) + 4 * (i & 1));
+    const float* rrow = a.G + (size_t)mm * 256 + 4 * hh;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const tg_f32x4 r4 = *reinterpret_cast<const tg_f32x4*>(rrow + 32 * rt + 8 * gq);
+        if (rt < 2) gtmp[4 * rt + gq] = r4;
+        else { acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3]; }
+      }
+  };
+  auto adopt_gtmp = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const tg_f32x4 r4 = gtmp[4 * rt + gq];
+        acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3];
+      }
+  };
+
+  // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`
   auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
     constexpr int NRT = decltype(Nc)::value, nt = 2 * NRT;
     const tg_bf16x8* L = ring[slot];
@@ -381,139 +453,113 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // weights of chunk c of a stream with NRT row tiles: every wave stages its share through registers (coalesced 16-B loads)
-  auto load_w = [&](auto Nc, const char* st, int c, tg_bf16x8 (&w)[PARTS * 4]) __attribute__((always_inline)) {
-    constexpr int NRT = decltype(Nc)::value, NPW = PARTS * 2 * NRT / NW;
-    const tg_bf16x8* src = reinterpret_cast<const tg_bf16x8*>(st) + (size_t)c * (4 * NRT * 64);
-#pragma unroll
-    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[(wave + NW * jj) * 64 + lane];
-  };
-  auto store_w = [&](auto Nc, int slot, const tg_bf16x8 (&w)[PARTS * 4]) __attribute__((always_inline)) {
-    constexpr int NRT = decltype(Nc)::value, NPW = PARTS * 2 * NRT / NW;
-#pragma unroll
-    for (int jj = 0; jj < NPW; ++jj) ring[slot][(wave + NW * jj) * 64 + lane] = w[jj];
-  };
-  using N8 = std::integral_constant<int, 8>;
-  using N2 = std::integral_constant<int, 2>;
-  tg_bf16x8 wreg[PARTS * 4];
 
-  // ---------------------------------------------------------------- stage 1: fc (K = 128) on the attention output
-#pragma unroll
-  for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-  auto load_o = [&](int c, float4 (&raw)[4]) __attribute__((always_inline)) {
-    const float* p = a.O + (size_t)mm * 128 + 32 * c + 8 * hh;
-#pragma unroll
-    for (int pc = 0; pc < 4; ++pc) raw[pc] = *(const float4*)(p + 16 * (pc >> 1) + 4 * (pc & 1));
-  };
-  {
-    float4 raw[4];
-    load_o(0, raw); load_w(N8{}, a.st_fc, 0, wreg);
-    store_w(N8{}, 0, wreg);
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
+  // ---------------------------------------------------------------- pipeline start
+  dma_chunk(std::integral_constant<int, 0>{}); dma_chunk(std::integral_constant<int, 1>{}); dma_chunk(std::integral_constant<int, 2>{});
+  load_tile_inputs(tile);
+  adopt_gtmp();
+  __syncthreads();   // stab
+
+  for (;;) {
+    const bool mok_c = mok;
+    const int m_c = m, mm_c = mm;
+    const int tile_next = tile + (int)gridDim.x;
+    tg_static_for<NCH>([&](auto Cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(Cc)::value, st = ChainGeo::stage(c), g = ChainGeo::idx(c);
+      // chunk c must have landed: younger operations are the pieces of chunks c+1, c+2 and the epilogue traffic issued since chunk c-3
+      // (the first iteration has issued fewer: a conservative wait)
+      constexpr int younger = ppw(c + 1) + ppw(c + 2) + ChainGeo::post(c - 3, FEAT) + ChainGeo::post(c - 2, FEAT) + ChainGeo::post(c - 1, FEAT);
+      tg_wait_vmcnt<(younger < 63 ? younger : 63)>();
+      __builtin_amdgcn_s_barrier();
+      dma_chunk(std::integral_constant<int, c + 3>{});   // its slot held chunk c-1, which every wave has left
+      if constexpr (c == 12) load_tile_inputs(tile_next < ntiles ? tile_next : tile);   // (always issued: the wait counts stay exact)
       tg_bf16x8 bh[2], bl[2];
+      if constexpr (st == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const float v[8] = {raw[2 * ks].x, raw[2 * ks].y, raw[2 * ks].z, raw[2 * ks].w, raw[2 * ks + 1].x, raw[2 * ks + 1].y, raw[2 * ks + 1].z, raw[2 * ks + 1].w};
-        tg_split8<X3>(v, bh[ks], bl[ks]);
+        for (int ks = 0; ks < 2; ++ks) {
+          const tg_f32x4 u0 = oraw[4 * g + 2 * ks], u1 = oraw[4 * g + 2 * ks + 1];
+          const float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+          tg_split8<X3>(v, bh[ks], bl[ks]);
+        }
+        compute(std::integral_constant<int, 8>{}, c % NB, bh, bl);
+      } else {
+        bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1];
+        if constexpr (st == 1) { if constexpr (FEAT) compute(std::integral_constant<int, 8>{}, c % NB, bh, bl); }
+        else compute(std::integral_constant<int, 2>{}, c % NB, bh, bl);
       }
-      if (g + 1 < 4) { load_o(g + 1, raw); load_w(N8{}, a.st_fc, g + 1, wreg); }
-      else load_w(N8{}, a.st_f0, 0, wreg);   // the next stage's first chunk
-      compute(N8{}, g & 1, bh, bl);
-      store_w(N8{}, (g + 1) & 1, wreg);
-      __syncthreads();
-    }
-  }
-  // ---------------------------------------------------------------- residual + LayerNorm(row) + aggregation scale -> feature_agg (and the next B operand)
-  tg_bf16x8 Xh[16], Xl[16];
-  {
-    const float* rrow = a.G + (size_t)mm * 256;
-    float s1 = 0.f;
+      if constexpr (c == 3) {
+        // ---- (fc + residual) -> LayerNorm(row) * aggregation scale -> feature_agg, kept as the next products' B operand
+        float s1 = 0.f;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+        for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const float4 r4 = *(const float4*)(rrow + 32 * rt + 8 * gq + 4 * hh);
-        acc[rt][4 * gq + 0] += r4.x; acc[rt][4 * gq + 1] += r4.y; acc[rt][4 * gq + 2] += r4.z; acc[rt][4 * gq + 3] += r4.w;
-        s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+          for (int r = 0; r < 16; r += 4) s1 += (acc[rt][r] + acc[rt][r + 1]) + (acc[rt][r + 2] + acc[rt][r + 3]);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 / 256.f;
+        float s2 = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = 1.f / sqrtf(s2 / 256.f + a.eps);
+        const float sc = a.wscale[mm_c];
+        const unsigned crow = mok_c ? (unsigned)m_c * 1024u + 16u * hh : 0x80000000u;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+          float v[16];
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int n = 32 * rt + 8 * gq + 4 * hh;
+            const float4 g4 = *(const float4*)(stab + n), be4 = *(const float4*)(stab + 256 + n);
+            v[4 * gq + 0] = ((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x) * sc;
+            v[4 * gq + 1] = ((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y) * sc;
+            v[4 * gq + 2] = ((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z) * sc;
+            v[4 * gq + 3] = ((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w) * sc;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]}), rFA,
+                                                   crow + (32 * rt + 8 * gq) * 4, 0, 0);
+          }
+#pragma unroll
+          for (int sI = 0; sI < 2; ++sI) {   // accumulator registers 8 s .. 8 s + 7 of row tile rt = k-step 2 rt + s in accumulator order
+            const float u[8] = {v[8 * sI], v[8 * sI + 1], v[8 * sI + 2], v[8 * sI + 3], v[8 * sI + 4], v[8 * sI + 5], v[8 * sI + 6], v[8 * sI + 7]};
+            tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+        }
       }
-    s1 += __shfl_xor(s1, 32, 64);
-    const float mean = s1 / 256.f;
-    float s2 = 0.f;
+      if constexpr (c == 11) {
+        if constexpr (FEAT) {
+          const unsigned frow = mok_c ? (unsigned)m_c * 1024u + 16u * hh : 0x80000000u;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+          for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
-    s2 += __shfl_xor(s2, 32, 64);
-    const float rstd = 1.f / sqrtf(s2 / 256.f + a.eps);
-    const float sc = a.wscale[mm];
-    float* crow = a.FA + (size_t)mm * 256;
+            for (int gq = 0; gq < 4; ++gq) {
+              const int n = 32 * rt + 8 * gq + 4 * hh;
+              const float4 b4 = *(const float4*)(stab + 512 + n);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{nl_lrelu(acc[rt][4 * gq] + b4.x), nl_lrelu(acc[rt][4 * gq + 1] + b4.y),
+                                                                                         nl_lrelu(acc[rt][4 * gq + 2] + b4.z), nl_lrelu(acc[rt][4 * gq + 3] + b4.w)}),
+                                                     rFT, frow + (32 * rt + 8 * gq) * 4, 0, 0);
+            }
+        }
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      float v[16];
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int n = 32 * rt + 8 * gq + 4 * hh;
-        const float4 g4 = *(const float4*)(stab + n), be4 = *(const float4*)(stab + 256 + n);
-        v[4 * gq + 0] = ((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x) * sc;
-        v[4 * gq + 1] = ((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y) * sc;
-        v[4 * gq + 2] = ((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z) * sc;
-        v[4 * gq + 3] = ((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w) * sc;
-        if (mok) *(float4*)(crow + n) = make_float4(v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]);
+          for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
       }
-      // accumulator registers 8 s .. 8 s + 7 of row tile rt = k-slots of k-step 2 rt + s in accumulator order
-#pragma unroll
-      for (int sI = 0; sI < 2; ++sI) {
-        const float u[8] = {v[8 * sI], v[8 * sI + 1], v[8 * sI + 2], v[8 * sI + 3], v[8 * sI + 4], v[8 * sI + 5], v[8 * sI + 6], v[8 * sI + 7]};
-        tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
-      }
-    }
-  }
-  // ---------------------------------------------------------------- stage 2: feat_mlp.0 (K = 256 in accumulator order), stage 3: blend projection (N = 32)
-  auto from_x = [&](auto Nc, const char* st, const char* st_next, bool more) __attribute__((always_inline)) {
-    constexpr int NRT = decltype(Nc)::value;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-    tg_static_for<8>([&](auto Gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(Gc)::value;
-      const tg_bf16x8 bh[2] = {Xh[2 * g], Xh[2 * g + 1]};
-      const tg_bf16x8 bl[2] = {Xl[2 * g], Xl[2 * g + 1]};
-      if constexpr (g + 1 < 8) load_w(Nc, st, g + 1, wreg);
-      compute(Nc, g & 1, bh, bl);
-      if constexpr (g + 1 < 8) store_w(Nc, (g + 1) & 1, wreg);
-      __syncthreads();
     });
-    (void)st_next; (void)more;
-  };
-  if (a.fth) {
-    from_x(N8{}, a.st_f0, nullptr, false);   // (its first chunk was staged at the end of stage 1)
-    float* frow = a.fth + (size_t)mm * 256;
+    {
+      const unsigned brow = mok_c ? (unsigned)m_c * 128u + 16u * hh : 0x80000000u;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int n = 32 * rt + 8 * gq + 4 * hh;
-        const float4 b4 = *(const float4*)(stab + 512 + n);
-        if (mok) *(float4*)(frow + n) = make_float4(nl_lrelu(acc[rt][4 * gq] + b4.x), nl_lrelu(acc[rt][4 * gq + 1] + b4.y),
-                                                    nl_lrelu(acc[rt][4 * gq + 2] + b4.z), nl_lrelu(acc[rt][4 * gq + 3] + b4.w));
-      }
+      for (int gq = 0; gq < 4; ++gq)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{acc[0][4 * gq], acc[0][4 * gq + 1], acc[0][4 * gq + 2], acc[0][4 * gq + 3]}), rBL,
+                                               brow + 32 * gq, 0, 0);
+    }
+    adopt_gtmp();
+    tile = tile_next;
+    if (tile >= ntiles) break;
   }
-  // the blend projection's first chunk: slot 0 is free again (the last chunk of the previous stage sat in slot 1 and everyone is past the barrier)
-  load_w(N2{}, a.st_ba, 0, wreg);
-  store_w(N2{}, 0, wreg);
-  __syncthreads();
-  from_x(N2{}, a.st_ba, nullptr, false);
-  if (mok) {
-    float* brow = a.blA + (size_t)m * 32;
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq)
-      *(float4*)(brow + 8 * gq + 4 * hh) = make_float4(acc[0][4 * gq], acc[0][4 * gq + 1], acc[0][4 * gq + 2], acc[0][4 * gq + 3]);
-  }
+  tg_wait_vmcnt<0>();   // LDS-DMA prefetched past the last tile must land before the LDS goes to another workgroup
 }
 
 }  // namespace
@@ -554,13 +600,25 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
 
-int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* st_fc,
-                           const void* st_f0, const void* st_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
+int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
+                           size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
                            hipStream_t st) {
   if (M <= 0) return NL_OK;
-  NlChainArgs a{O, G, wscale, gamma, beta, eps, (const char*)st_fc, (const char*)st_f0, (const char*)st_ba, bias_f0, FA, fth, blA, (int)M};
-  dim3 grid((unsigned)nl_cdiv(M, 128));
-  if (precision == NL_PREC_BF16X3) hipLaunchKernelGGL((sample_chain_kernel<true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((sample_chain_kernel<false>), grid, dim3(256), 0, st, a);
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
+    num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+  }
+  NlChainArgs a{O, G, wscale, gamma, beta, eps, (const char*)wbase, (unsigned)off_fc, (unsigned)off_f0, (unsigned)off_ba, bias_f0, FA, fth, blA, (int)M};
+  const int ntiles = (int)nl_cdiv(M, 128);
+  dim3 grid(ntiles < num_cu ? nl_xcd_grid(ntiles) : num_cu);
+  if ((int64_t)M * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  const bool x3 = precision == NL_PREC_BF16X3;
+  if (x3 && fth) hipLaunchKernelGGL((sample_chain_kernel<true, true>), grid, dim3(256), 0, st, a, ntiles);
+  else if (x3) hipLaunchKernelGGL((sample_chain_kernel<true, false>), grid, dim3(256), 0, st, a, ntiles);
+  else if (fth) hipLaunchKernelGGL((sample_chain_kernel<false, true>), grid, dim3(256), 0, st, a, ntiles);
+  else hipLaunchKernelGGL((sample_chain_kernel<false, false>), grid, dim3(256), 0, st, a, ntiles);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
