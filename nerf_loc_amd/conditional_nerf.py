@@ -13,8 +13,9 @@ What runs where
     the library too (`frame_setup.py`: `nl_backproject_support`, `nl_cross_view_features`); the per-frame CNN itself
     (`DepthFusionNet.encode`, MIOpen convolutions), `confidence_mlp`, `keypoint_head` and the tiny descriptor projections stay on
     PyTorch-ROCm, like the 2-D backbone (north_star).
-  * training-time pieces that need autograd through the renderer (`compute_render_loss`, `beta`) are "next rows"
-     and raise NotImplementedError.
+  * training-time pieces that need autograd THROUGH THE RENDERER (`compute_render_loss`, `beta`, PoseOptimizer's gradient) are
+    "next rows"  and raise NotImplementedError; the depth supervision of the per-frame CNN
+    (`multiview_aggregator.compute_ref_depth_loss`) never touches the renderer and is implemented with autograd.
 """
 from __future__ import annotations
 
@@ -88,8 +89,39 @@ class MultiviewFeatureAggregator(nn.Module):
         self.__dict__["_vis_featmaps"] = v
         self.__dict__["_vis_gen"] = self.__dict__.get("_vis_gen", 0) + 1
 
-    def compute_ref_depth_loss(self, *a, **k):
-        raise NotImplementedError("training loss through the HIP renderer is a next-row item (SURVEY.md §8f-2)")
+    # ---- training-time depth supervision of the per-frame CNN (multiview_aggregator.py:39-61).  Everything here lives on the
+    # PyTorch-ROCm side (DepthFusionNet + the 32-32-32-2 mean decoder): it is differentiable through autograd like the reference; the
+    # only library call is the CNN's hand-made input (`nl_cross_view_features`), which has no parameters.
+    def predict_ref_depths(self, intrinsics, extrinsics, images, featmaps, depths, depth_range, cnn_in=None):
+        """-> (V, H/4, W/4) predicted depths of the support views.  `cnn_in` (V,12,H,W) optionally supplies DepthFusionNet's input
+        (tests without a GPU); otherwise it comes from the HIP library."""
+        vis = self.vis_featmaps
+        if vis is None or (torch.is_grad_enabled() and not vis.requires_grad and any(p.requires_grad for p in self.depth_fusion.parameters())):
+            vis = self.depth_fusion.encode(cnn_in) if cnn_in is not None else self.depth_fusion(images, featmaps, depths, intrinsics, extrinsics, depth_range)
+            self.vis_featmaps = vis
+        dr = depth_range.view(1, 2).repeat(vis.shape[0], 1).float()
+        V, C, h, w = vis.shape
+        mean = self.dist_decoder.mean_decoder(vis.view(V, C, -1).permute(0, 2, 1))      # (V, N, 2)   visibility_decoder.py:187-189
+        near, far = dr[:, 0][:, None, None], dr[:, 1][:, None, None]                      # visibility_decoder.py:140-148
+        near_inv, far_inv = -1 / near, -1 / far
+        depth = -1 / (mean * (far_inv - near_inv) + near_inv)
+        depth = depth.clamp(near.min(), far.max())
+        return depth[:, :, 0].view(V, h, w)
+
+    def compute_ref_depth_loss(self, intrinsics, extrinsics, images, featmaps, depths, depths_gt, depth_range, cnn_in=None):
+        """multiview_aggregator.py:50-61: L2 between the inverse-normalised predicted and ground-truth support depths (valid pixels)."""
+        import torch.nn.functional as F
+        near, far = depth_range
+        pred = self.predict_ref_depths(intrinsics, extrinsics, images, featmaps, depths, depth_range, cnn_in=cnn_in)
+        V, h, w = pred.shape
+        gt = F.interpolate(depths_gt.unsqueeze(1), size=(h, w)).view(V, -1)
+        mask = gt > 0
+
+        def inv_norm(d):   # losses.py:15-21
+            near_inv, far_inv = -1 / near, -1 / far
+            d = -1 / torch.clamp(d, min=1e-5)
+            return torch.clamp((d - near_inv) / (far_inv - near_inv), min=0, max=1.0)
+        return ((inv_norm(gt) - inv_norm(pred.view(V, -1)))[mask] ** 2).mean()
 
 
 class _MHAParams(nn.Module):

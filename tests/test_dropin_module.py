@@ -241,3 +241,56 @@ def test_dropin_without_feature_rendering():
     assert torch.equal(outs[0]["mask"], outs[1]["mask"])
     for k in ("rgb", "depth", "weights", "depth_uncertainty"):   # two module instances: MIOpen may pick another algorithm for the per-frame CNN
         assert rel_err(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy()) < 1e-5, k
+
+
+@pytest.mark.parametrize("case_name", ["setup", "setup_holes"])
+def test_ref_depth_loss_and_gradients_match_reference(case_name):
+    """`multiview_aggregator.compute_ref_depth_loss` (multiview_aggregator.py:50-61; called in training at nerf_pose_estimator.py:352):
+    loss value and the gradients of the parameters it reaches (per-frame CNN + mean decoder) against the reference's autograd.  The CNN's
+    hand-made input comes from the oracle here (CPU test); on the GPU the same call takes it from nl_cross_view_features."""
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    from oracle import setup_oracle as sorc
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case(case_name)
+    cfg, frame = case["cfg"], case["frame"]
+    g = load_golden(case_name)
+    net = ConditionalNeRF(_args(cfg)).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    t = torch.from_numpy
+    near, far = [float(x) for x in frame["depth_range"][0]]
+    cnn_in = sorc.cnn_input(t(frame["topk_images"]), t(frame["topk_depths"]), t(frame["topk_Ks"]), t(frame["topk_poses"]), near, far)
+    agg = net.multiview_aggregator
+    agg.vis_featmaps = None
+    loss = agg.compute_ref_depth_loss(t(frame["topk_Ks"]), t(frame["topk_poses"]), t(frame["topk_images"]), t(frame["feat_fine_src"]).permute(0, 3, 1, 2),
+                                      t(frame["topk_depths"]), t(g["ref_depth_gt"]), t(frame["depth_range"])[0], cnn_in=cnn_in)
+    assert abs(float(loss) - float(g["ref_depth_loss"])) < 2e-5 * abs(float(g["ref_depth_loss"])) + 1e-9
+    loss.backward()
+    named = dict(net.named_parameters())
+    for key, pname in (("grad_mean_decoder_4_w", "multiview_aggregator.dist_decoder.mean_decoder.4.weight"),
+                       ("grad_mean_decoder_0_w", "multiview_aggregator.dist_decoder.mean_decoder.0.weight"),
+                       ("grad_df_conv_out_w", "multiview_aggregator.depth_fusion.conv_out.weight"),
+                       ("grad_df_conv1_w", "multiview_aggregator.depth_fusion.fuse_net.conv1.weight")):
+        assert rel_err(named[pname].grad.numpy(), g[key]) < 1e-4, (key, rel_err(named[pname].grad.numpy(), g[key]))
+    # the renderer's parameters are not reached by this loss
+    assert named["base_mlp.0.weight"].grad is None
+
+
+@pytest.mark.gpu
+def test_ref_depth_loss_on_the_gpu_matches_reference():
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case("setup")
+    cfg, frame = case["cfg"], case["frame"]
+    g = load_golden("setup")
+    dev = torch.device("cuda:0")
+    net = ConditionalNeRF(_args(cfg)).to(dev).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+    agg = net.multiview_aggregator
+    agg.vis_featmaps = None
+    loss = agg.compute_ref_depth_loss(t(frame["topk_Ks"]), t(frame["topk_poses"]), t(frame["topk_images"]), t(frame["feat_fine_src"]).permute(0, 3, 1, 2),
+                                      t(frame["topk_depths"]), t(g["ref_depth_gt"]), t(frame["depth_range"])[0])
+    assert abs(float(loss) - float(g["ref_depth_loss"])) < 1e-4 * abs(float(g["ref_depth_loss"]))
+    loss.backward()
+    grad = dict(net.named_parameters())["multiview_aggregator.dist_decoder.mean_decoder.4.weight"].grad
+    assert rel_err(grad.cpu().numpy(), g["grad_mean_decoder_4_w"]) < 2e-4

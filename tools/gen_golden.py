@@ -237,6 +237,24 @@ def run_setup_case(model_mod, name="setup"):
                  "cnn_in_geo": cnn_in["x"][:, 3:].numpy(), "fine_xyz_ndc": sp["fine"]["xyz_ndc"].numpy(),
                  "fine_feature_rowsum": sp["fine"]["feature"].double().sum(1).numpy(), "coarse_xyz_ndc": sp["coarse"]["xyz_ndc"].numpy(),
                  "coarse_direction": sp["coarse"]["direction"].numpy(), "coarse_feature": sp["coarse"]["feature"].numpy()})
+    # training-time depth supervision (multiview_aggregator.py:50-61): loss value + gradients of the parameters it reaches, with the
+    # ground-truth depths a seeded perturbation of the support depths (a few invalid pixels)
+    rng = np.random.default_rng(cfg.seed + 500)
+    gt = frame["topk_depths"] * (1.0 + 0.05 * rng.standard_normal(frame["topk_depths"].shape).astype(np.float32))
+    gt[rng.random(gt.shape) < 0.1] = 0.0
+    net.multiview_aggregator.vis_featmaps = None
+    net.zero_grad()
+    with torch.enable_grad():
+        loss = net.multiview_aggregator.compute_ref_depth_loss(data["topk_Ks"], data["topk_poses"], data["topk_images"],
+                                                               data["feat_fine_src"].permute(0, 3, 1, 2), data["topk_depths"], t(gt), data["depth_range"][0])
+        loss.backward()
+    named = dict(net.named_parameters())
+    save.update({"ref_depth_gt": gt, "ref_depth_loss": np.float64(loss.item()),
+                 "grad_mean_decoder_4_w": named["multiview_aggregator.dist_decoder.mean_decoder.4.weight"].grad.numpy(),
+                 "grad_mean_decoder_0_w": named["multiview_aggregator.dist_decoder.mean_decoder.0.weight"].grad.numpy(),
+                 "grad_df_conv_out_w": named["multiview_aggregator.depth_fusion.conv_out.weight"].grad.numpy(),
+                 "grad_df_conv1_w": named["multiview_aggregator.depth_fusion.fuse_net.conv1.weight"].grad.numpy()})
+    net.multiview_aggregator.vis_featmaps = None
     path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
     np.savez_compressed(path, **save)
     if name == "setup":
