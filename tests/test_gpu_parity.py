@@ -156,6 +156,21 @@ def test_descriptor_query_direction_falls_back_to_nearest_neighbour():
     assert rel_err(fa.cpu().numpy(), qd["feature_agg"].numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("name", ["w128s64", "w256s128"])
+def test_descriptor_query_direction_fallback_on_the_fused_kernels(name):
+    """The same fallback through the fused neural-point kernels (W = 128 / 256, bf16x3): without a direction array every lane takes the
+    direction of its sample's nearest neighbour (first of the 8 lanes of the sample), and k >= M rows read as zero."""
+    from oracle import render_oracle as orc
+    case = build_case(name)
+    params, frame, rays = oracle_inputs(case)
+    r = _renderer(case, "bf16x3")
+    xyz = frame["support_fine"]["xyz"][::5][:333].clone() + 0.007     # 333: not a multiple of the 16-sample tile
+    with torch.no_grad():
+        qd = orc.query(params, frame, xyz, None)
+    fa, d2, idx = r.point_mlp(xyz, None, qd["multiview_feature_agg"])
+    assert rel_err(fa.cpu().numpy(), qd["feature_agg"].numpy()) < 1e-4
+
+
 HIER = [n for n in CASES if CASES[n][0].N_importance > 0]
 
 
