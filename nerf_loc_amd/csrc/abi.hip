@@ -650,35 +650,43 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   {  // trans_conv3: S/8 -> S/4
     const int Li = S / 8, Lo = S / 4;
     SegSpec o[2] = {{u.c3, 128, 128, 0, 1}, {u.c3, 128, 128, 1, 1}};
-    if (merged) NL_TRY(run_gemm(x, G_T3M, o, 2, R * Li, u.x0r, 256, NL_ACT_NONE, Li, Li, Li, 1, 0));   // row m = output positions 2m, 2m+1
+    bool tfused = false;
+    // row m = output positions 2m, 2m+1: the (Li x 2 co) view of the merged output IS the ray's (Lo x co) slab, so LayerNorm([C, L]) + ELU
+    // ride in the GEMM's epilogue (the affine tables are stored position-major: same memory either way)
+    const RowEpi ept3{nullptr, 0, g(U_T3), b(U_T3), nullptr, eps, u.x0, NL_EPI_LNSLAB, 0};
+    if (merged) NL_TRY(run_gemm(x, G_T3M, o, 2, R * Li, u.x0r, 256, NL_ACT_NONE, Li, Li, Li, 1, 0, &ept3, &tfused));
     else {
       SegSpec e[1] = {{u.c3, 128, 128, 0, 1}};
       NL_TRY(run_gemm(x, G_T3E, e, 1, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 0));
       NL_TRY(run_gemm(x, G_T3O, o, 2, R * Li, u.x0r, 128, NL_ACT_NONE, Li, Li, Lo, 2, 1));
     }
-    NL_TRY(nl_launch_ln_slab_elu(u.x0r, R, Lo, 128, g(U_T3), b(U_T3), eps, u.x0, nullptr, x.st));
+    if (!tfused) NL_TRY(nl_launch_ln_slab_elu(u.x0r, R, Lo, 128, g(U_T3), b(U_T3), eps, u.x0, nullptr, x.st));
   }
   {  // trans_conv2 on cat[c2, x0]: S/4 -> S/2
     const int Li = S / 4, Lo = S / 2;
     SegSpec o[4] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}, {u.c2, 128, 128, 1, 1}, {u.x0, 128, 128, 1, 1}};
-    if (merged) NL_TRY(run_gemm(x, G_T2M, o, 4, R * Li, u.x1r, 128, NL_ACT_NONE, Li, Li, Li, 1, 0));
+    bool tfused = false;
+    const RowEpi ept2{nullptr, 0, g(U_T2), b(U_T2), nullptr, eps, u.x1, NL_EPI_LNSLAB, 0};
+    if (merged) NL_TRY(run_gemm(x, G_T2M, o, 4, R * Li, u.x1r, 128, NL_ACT_NONE, Li, Li, Li, 1, 0, &ept2, &tfused));
     else {
       SegSpec e[2] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}};
       NL_TRY(run_gemm(x, G_T2E, e, 2, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 0));
       NL_TRY(run_gemm(x, G_T2O, o, 4, R * Li, u.x1r, 64, NL_ACT_NONE, Li, Li, Lo, 2, 1));
     }
-    NL_TRY(nl_launch_ln_slab_elu(u.x1r, R, Lo, 64, g(U_T2), b(U_T2), eps, u.x1, nullptr, x.st));
+    if (!tfused) NL_TRY(nl_launch_ln_slab_elu(u.x1r, R, Lo, 64, g(U_T2), b(U_T2), eps, u.x1, nullptr, x.st));
   }
   {  // trans_conv1 on cat[c1, x1]: S/2 -> S
     const int Li = S / 2, Lo = S;
     SegSpec o[4] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}, {u.x1, 64, 64, 1, 1}};
-    if (merged) NL_TRY(run_gemm(x, G_T1M, o, 4, R * Li, u.x2r, 64, NL_ACT_NONE, Li, Li, Li, 1, 0));
+    bool tfused = false;
+    const RowEpi ept1{nullptr, 0, g(U_T1), b(U_T1), nullptr, eps, u.x2, NL_EPI_LNSLAB, 0};
+    if (merged) NL_TRY(run_gemm(x, G_T1M, o, 4, R * Li, u.x2r, 64, NL_ACT_NONE, Li, Li, Li, 1, 0, &ept1, &tfused));
     else {
       SegSpec e[2] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}};
       NL_TRY(run_gemm(x, G_T1E, e, 2, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 0));
       NL_TRY(run_gemm(x, G_T1O, o, 4, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 1));
     }
-    NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
+    if (!tfused) NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
   }
   {  // conv_out on cat[in, x2]
     SegSpec s[2] = {{in, W, W, 0, 1, 3}, {u.x2, 32, 32, 0, 1, 3}};

@@ -186,12 +186,12 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 
   // epilogue: C/D layout col = lane&31 (= this lane's output row), reg r = 4*gq + e <-> n = 32*rt + 8*gq + 4*hh + e
   if constexpr (EPI == NL_EPI_LNSLAB) {
-    // The workgroup's 32*NW rows are one, two or four whole rays (launch precondition: So in {128, 64, 32}, M % So == 0; `wpr`
-    // waves per ray): LayerNorm over each ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional
+    // The workgroup's 32*NW rows are one, two, four or eight whole rays (launch precondition: So in {128, 64, 32, 16}, M % So == 0; `wpr`
+    // waves per ray, or two rays per wave for So = 16): LayerNorm over each ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional
     // MaxPool(2) along the ray.  A trailing workgroup may hold rays past M: their statistics are computed on zero rows and
     // nothing of them is stored.
     float* red = sbias + NRT * 32;   // [2][NW] partial sums
-    const int wpr = a.So >> 5, gb = (wave / wpr) * wpr;
+    const int wpr = a.So >= 32 ? a.So >> 5 : 1, gb = (wave / wpr) * wpr;
     float s1 = 0.f;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
@@ -204,12 +204,21 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
           s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
         }
       }
-    s1 = wave_sum(s1);
-    if (lane == 0) red[wave] = s1;
-    __syncthreads();
+    // a ray of 16 rows is half a wave (lanes j = 0..15 or 16..31 of both halves hh): summed with four DPP permutations inside the
+    // 16-lane row + the partner row 32 lanes away; no LDS round trip
+    auto ray16_sum = [](float v) __attribute__((always_inline)) {
+      v += nl_dpp<0xB1>(v); v += nl_dpp<0x4E>(v); v += nl_dpp<0x141>(v); v += nl_dpp<0x140>(v);   // quad_perm x2, row_half_mirror, row_mirror
+      return v + __shfl_xor(v, 32, 64);
+    };
     float tot = 0.f;
+    if (a.So == 16) tot = ray16_sum(s1);
+    else {
+      s1 = wave_sum(s1);
+      if (lane == 0) red[wave] = s1;
+      __syncthreads();
 #pragma unroll
-    for (int w = 0; w < NW; ++w) tot += w < wpr ? red[gb + (w < wpr ? w : 0)] : 0.f;
+      for (int w = 0; w < NW; ++w) tot += w < wpr ? red[gb + (w < wpr ? w : 0)] : 0.f;
+    }
     const float cnt = (float)a.So * (float)a.N;
     const float mean = tot / cnt;
     float s2 = 0.f;
@@ -221,12 +230,15 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float d = acc[rt][4 * gq + e] - mean; s2 += d * d; }
         }
-    s2 = wave_sum(s2);
-    if (lane == 0) red[NW + wave] = s2;
-    __syncthreads();
     float tot2 = 0.f;
+    if (a.So == 16) tot2 = ray16_sum(s2);
+    else {
+      s2 = wave_sum(s2);
+      if (lane == 0) red[NW + wave] = s2;
+      __syncthreads();
 #pragma unroll
-    for (int w = 0; w < NW; ++w) tot2 += w < wpr ? red[NW + gb + (w < wpr ? w : 0)] : 0.f;
+      for (int w = 0; w < NW; ++w) tot2 += w < wpr ? red[NW + gb + (w < wpr ? w : 0)] : 0.f;
+    }
     const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
     const float* grow = a.ep_gamma + (size_t)t * a.N;
     const float* brow = a.ep_beta + (size_t)t * a.N;
@@ -572,7 +584,7 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
-  if (a.epi == NL_EPI_LNSLAB && ((a.So != 128 && a.So != 64 && a.So != 32) || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
+  if (a.epi == NL_EPI_LNSLAB && ((a.So != 128 && a.So != 64 && a.So != 32 && a.So != 16) || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
     if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k || g.ntap < 1) return false;
