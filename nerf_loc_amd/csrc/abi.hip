@@ -580,8 +580,10 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     const bool use_v1 = getenv("NERFLOC_POINT_V1") != nullptr;   // A/B switch for profiling / debugging
-    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) NL_TRY(nl_launch_point_fused2(a, W, x.c->precision, x.st));
-    else NL_TRY(nl_launch_point_fused(a, W, x.c->precision, x.st));
+    int rc2 = NL_ERR_UNSUPPORTED;
+    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st);
+    if (rc2 == NL_ERR_UNSUPPORTED) rc2 = nl_launch_point_fused(a, W, x.c->precision, x.st);   // (e.g. more rows than 32-bit buffer offsets reach)
+    NL_TRY(rc2);
     if (pe1) NL_CHECK_HIP(hipEventRecord(pe1, x.st));
   } else {
     if (!p.X) return NL_ERR_UNSUPPORTED;
@@ -599,10 +601,13 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
   if (chain && chain->done) *chain->done = false;
   if (chain && !no_chain && W == 256 && x.c->precision != NL_PREC_F32) {
-    NL_TRY(nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_FC], x.L.bst[G_FEAT0P],
-                                  x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st));
-    if (chain->done) *chain->done = true;
-    return NL_OK;
+    const int rcc = nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_FC], x.L.bst[G_FEAT0P],
+                                           x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st);
+    if (rcc == NL_OK) {
+      if (chain->done) *chain->done = true;
+      return NL_OK;
+    }
+    if (rcc != NL_ERR_UNSUPPORTED) return rcc;   // unsupported size: the separate launches below
   }
   SegSpec so{p.O, 128, 128, 0, 1};
   // fc + residual + LayerNorm + aggregation scale: inside the GEMM's epilogue when the streaming kernel takes it
@@ -1047,7 +1052,11 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     int64_t mid = (lo + hi + 1) / 2;
     if (render_bytes(cfg, V, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
   }
-  const int64_t RC = lo;
+  int64_t RC = lo;
+  {   // the buffer-addressed kernels use 32-bit byte offsets: at most 2^21 samples per chunk (twice the recommended workspace's chunk)
+    const int64_t cap = ((int64_t)1 << 21) / S > 0 ? ((int64_t)1 << 21) / S : 1;
+    if (RC > cap) RC = cap;
+  }
   Bump b{(char*)ws, 0}; RenderBufs rb; carve_render(b, cfg, V, RC, rb);
   Ctx x = make_ctx(cfg, packed, stream);
   SideStreams* side = side_streams();
