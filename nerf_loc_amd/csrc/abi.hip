@@ -55,7 +55,9 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
 bool nl_point_fused2_supported(int W, int precision);
 int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
                            size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
-                           hipStream_t st);
+                           hipStream_t st, const float* T64, size_t off_g2, const float* bias_g2);
+int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
+                          hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 
 namespace {
@@ -94,7 +96,7 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_QP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -145,6 +147,7 @@ Layout make_layout(const nl_config* c) {
   // feat_mlp.0 and the blend projection with K in ACCUMULATOR order, for the per-sample chain kernel (tgemm.hip: sample_chain_kernel)
   set(G_FEAT0P, W, W, true);
   set(G_BLENDAP, W, 32, false);
+  set(G_QP, W, 128, false);
   set(G_CONVOUT, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
   // feat_mlp's last Linear is applied AFTER compositing (it is linear): K = [composited hidden (W) | sum of weights (1)],
@@ -542,7 +545,7 @@ bool prof_arm(hipEvent_t* e0, hipEvent_t* e1) {
 }
 
 int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
-          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m) {
+          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m, bool skip_g = false) {
   const NlViews vw = with_query(f, qc);
   if (bl1) NL_TRY(ensure_pfeat(x, f));
   if (x.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
@@ -551,6 +554,7 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
   SegSpec s0{m.g393, ldg_of(f->C), ldg_of(f->C), 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
+  if (skip_g) return NL_OK;   // the consumers recompute G from the hidden rows (sample_chain_kernel MODE 1, 2)
   SegSpec s1{m.t64, 64, 64, 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC2, &s1, 1, N, G, x.c->W, NL_ACT_ELU));
   return NL_OK;
@@ -559,14 +563,20 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
 // knn_done != null: the caller already ran the KNN (+ the aggregation scale) on a side stream and hands over the event to wait for
 // chain != null (fused render path, W = 256, bf16 modes): fc + LayerNorm + scale, feat_mlp.0 (chain->fth, may be null) and the blend
 // projection (chain->blA) run as ONE kernel that keeps feature_agg in registers between them; *chain->done says whether it did
-struct ChainOut { float* fth; float* blA; bool* done; };
+// chain->t64 != null: G was not materialised (do_mv(skip_g)); the query rows and the chain recompute it from out_fc's hidden rows
+struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; };
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
              float* FA, const PtBufs& p, hipEvent_t knn_done = nullptr, const ChainOut* chain = nullptr) {
   const int W = x.c->W, F = f->C + 3;
   const bool fused_path = K == 8 && nl_point_fused_supported(W, x.c->precision);
   if (!knn_done) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
-  SegSpec sg{G, W, W, 0, 1};
-  NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
+  const float* t64 = chain ? chain->t64 : nullptr;
+  if (t64) {
+    NL_TRY(nl_launch_query_chain(t64, x.pk, x.L.bst[G_OUTFC2], x.p<float>(x.L.bias[G_OUTFC2]), x.L.bst[G_QP], p.Q, N, x.c->precision, x.st));
+  } else {
+    SegSpec sg{G, W, W, 0, 1};
+    NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
+  }
   if (knn_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, knn_done, 0));
   if (fused_path) {
     NL_TRY(ensure_ptt(x, f));
@@ -600,15 +610,17 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   }
   static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
   if (chain && chain->done) *chain->done = false;
-  if (chain && !no_chain && W == 256 && x.c->precision != NL_PREC_F32) {
+  if (chain && (t64 || !no_chain) && W == 256 && x.c->precision != NL_PREC_F32) {
     const int rcc = nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_FC], x.L.bst[G_FEAT0P],
-                                           x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st);
+                                           x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st,
+                                           t64, x.L.bst[G_OUTFC2], t64 ? x.p<float>(x.L.bias[G_OUTFC2]) : nullptr);
     if (rcc == NL_OK) {
       if (chain->done) *chain->done = true;
       return NL_OK;
     }
-    if (rcc != NL_ERR_UNSUPPORTED) return rcc;   // unsupported size: the separate launches below
+    if (rcc != NL_ERR_UNSUPPORTED || t64) return rcc;   // unsupported size: the separate launches below (they need G)
   }
+  if (t64) return NL_ERR_UNSUPPORTED;
   SegSpec so{p.O, 128, 128, 0, 1};
   // fc + residual + LayerNorm + aggregation scale: inside the GEMM's epilogue when the streaming kernel takes it
   const RowEpi ep{G, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), p.wscale, 1e-6f, FA};
@@ -842,6 +854,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     P.block(G_FEAT0P, 0, t[T_F0W], 0, W, 1, W, 1);
     P.copy(t[T_F0B], L.bias[G_FEAT0P], W);
     P.block(G_BLENDAP, 0, t[T_BL0W], 0, W + F + 5, 1, W, 1);
+    P.block(G_QP, 0, t[T_WQ], 0, W, 1, W, 1);
   }
   P.block(G_BLENDP, 0, t[T_BL0W], W + 3, W + F + 5, 1, C);
   if (nl_pack_ptt(t[T_B0W], t[T_B0B], W, F, L.g[G_PTT].Kpad, L.g[G_PTT].Npad, (float*)((char*)packed + L.b32[G_PTT]),
@@ -1079,12 +1092,17 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
       NL_CHECK_HIP(hipEventRecord(side->e[1], side->s[0]));
       knn_done = side->e[1];
     }
-    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv));
+    // G (N x W) stays unmaterialised when every consumer can recompute it from out_fc's 64-wide hidden rows
+    static const bool keep_g = getenv("NERFLOC_KEEP_G") != nullptr || getenv("NERFLOC_NO_CHAIN") != nullptr;
+    static const bool dbg_force = getenv("NERFLOC_FORCE_SKIP_G") != nullptr;
+    const bool skip_g = !keep_g && W == 256 && cfg->precision != NL_PREC_F32 && (!out->mv_feature_agg || dbg_force) && N * 1024 <= 0x7fffffffll &&
+                        nl_point_fused_supported(W, cfg->precision);
+    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, skip_g));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     // with early termination feat_mlp.0 runs later, over the live tiles only; otherwise the chain kernel produces it right here
     bool chain_done = false;
     const bool want_feat = out->feat != nullptr;
-    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done};
+    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, skip_g ? rb.mv.t64 : nullptr};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, knn_done, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
     // ---- fork 2: heads that need feature_agg only, beside the ray U-Net

@@ -347,56 +347,89 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 // and IS the B operand of the next two products (their weight streams are packed with K in accumulator order, like the fused
 // neural-point kernel); feature_agg is still written (the ray U-Net reads it), but never read back here.  One workgroup per CU
 // (the two activation sets + 128 accumulators need the 512-register file); the K-outer chunk pipeline of tgemm_kernel otherwise.
+//
+// The kernel runs one of three chunk programs (MODE):
+//   0: fc | feat_mlp.0 | blend projection, the residual rows G = multiview feature (N x W) read from memory
+//   1: out_fc.2 | fc | feat_mlp.0 | blend projection: G = ELU(out_fc.2(t64)) (ibrnet.py:104-106 `out_fc`) is recomputed from the 64-wide
+//      hidden rows and lands in the accumulators fc continues on — G is never written or read (0.5 GB + 0.5 GB per config-2 batch)
+//   2: out_fc.2 | w_qs: the attention query rows Q = w_qs(G) (model.py:391-396) from the same recomputed G, for the neural-point kernel
 struct NlChainArgs {
   const float* O; const float* G; const float* wscale; const float* gamma; const float* beta; float eps;
-  const char* wbase; unsigned off_fc, off_f0, off_ba;   // the three weight streams as byte offsets into one packed blob
+  const char* wbase; unsigned off_fc, off_f0, off_ba;   // weight streams as byte offsets into one packed blob
   const float* bias_f0;
   float* FA; float* fth; float* blA;
   int M;
+  const float* T64; unsigned off_g2, off_q; const float* bias_g2; float* Q;   // MODE 1, 2
 };
 
 typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
 
-// 20 weight chunks per 128-row tile: fc 0..3 | feat_mlp.0 4..11 | blend projection 12..19; 32 k each
+enum { CK_G2 = 0, CK_FC, CK_F0, CK_BL, CK_Q, CK_NOP };
+
+// weight chunks (32 k each) per 128-row tile, e.g. MODE 0: fc 0..3 | feat_mlp.0 4..11 | blend projection 12..19
+template <int MODE>
 struct ChainGeo {
-  static constexpr int NCH = 20;
+  static constexpr int NST = MODE == 0 ? 3 : MODE == 1 ? 4 : 2;
+  static constexpr int kind_at(int s) {
+    return MODE == 0 ? (s == 0 ? CK_FC : s == 1 ? CK_F0 : CK_BL) : MODE == 1 ? (s == 0 ? CK_G2 : s == 1 ? CK_FC : s == 2 ? CK_F0 : CK_BL) : (s == 0 ? CK_G2 : CK_Q);
+  }
+  static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : 8; }
+  static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : k == CK_BL ? 2 : k == CK_Q ? 4 : 8; }
+  static constexpr int start(int s) { int c = 0; for (int i = 0; i < s; ++i) c += nch_k(kind_at(i)); return c; }
+  // the ring slot of a chunk is c % 4 at compile time: programs are padded with empty chunks (barrier only) to a multiple of 4
+  static constexpr int NREAL = start(NST), NCH = (NREAL + 3) / 4 * 4;
   static constexpr int cm(int c) { return ((c % NCH) + NCH) % NCH; }
-  static constexpr int stage(int c) { return cm(c) < 4 ? 0 : cm(c) < 12 ? 1 : 2; }
-  static constexpr int nrt(int c) { return stage(c) == 2 ? 2 : 8; }
-  static constexpr int idx(int c) { return stage(c) == 0 ? cm(c) : stage(c) == 1 ? cm(c) - 4 : cm(c) - 12; }
-  // VMEM operations other than LDS-DMA pieces issued after chunk c's MFMAs and before the next chunk's wait (per lane-instruction):
-  // after the fc: wscale load + 32 feature_agg stores; after feat_mlp.0: 32 stores; in the first blend chunk: the next tile's 16
-  // attention-output loads + 32 residual loads; after the blend projection: 4 stores.  Waits count them: vmcnt retires in issue order.
-  static constexpr int post(int c, bool feat) { return cm(c) == 3 ? 33 : cm(c) == 11 ? (feat ? 32 : 0) : cm(c) == 12 ? 16 + 32 : cm(c) == 19 ? 4 : 0; }
+  static constexpr int spos(int c) { int s = 0; for (int i = 1; i < NST; ++i) if (cm(c) >= start(i)) s = i; return s; }
+  static constexpr int kind(int c) { return cm(c) >= NREAL ? CK_NOP : kind_at(spos(c)); }
+  static constexpr int idx(int c) { return cm(c) - start(spos(c)); }
+  static constexpr int nrt(int c) { return nrt_k(kind(c)); }
+  static constexpr bool last(int c) { return kind(c) != CK_NOP && idx(c) == nch_k(kind(c)) - 1; }
+  // the next tile's input rows are fetched in the first chunk of the last stage (MODE 0: 16 attention-output + 32 residual loads;
+  // MODE 1: 16 + 8 hidden-row loads; MODE 2: 8)
+  static constexpr int PF = start(NST - 1);
+  static constexpr int NPF = MODE == 0 ? 48 : MODE == 1 ? 24 : 8;
+  // VMEM operations other than LDS-DMA pieces issued in chunk c's slot, after its own pieces went out (per lane-instruction): the
+  // prefetch above; after the fc: wscale load + 32 feature_agg stores; after feat_mlp.0: 32 stores; after the blend projection: 4
+  // stores; after w_qs: 16 stores.  Waits count them: vmcnt retires in issue order.
+  static constexpr int post(int c, bool feat) {
+    int n = cm(c) == PF ? NPF : 0;
+    if (last(c)) { const int k = kind(c); n += k == CK_FC ? 33 : k == CK_F0 ? (feat ? 32 : 0) : k == CK_BL ? 4 : k == CK_Q ? 16 : 0; }
+    return n;
+  }
 };
 
-template <bool X3, bool FEAT>
+template <bool X3, bool FEAT, int MODE>
 __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a, const int ntiles) {
-  constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = ChainGeo::NCH, NB = 4;
+  using Geo = ChainGeo<MODE>;
+  constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = Geo::NCH, NB = 4;
   constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per ring slot (sized for 8 row tiles)
-  __shared__ uint4 lds_all[NB * SLOT16 + 3 * 64];
+  __shared__ uint4 lds_all[NB * SLOT16 + 4 * 64];
   tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
-  float* stab = reinterpret_cast<float*>(lds_all + NB * SLOT16);   // gamma | beta | feat_mlp.0 bias
+  float* stab = reinterpret_cast<float*>(lds_all + NB * SLOT16);   // gamma | beta | feat_mlp.0 bias | out_fc.2 bias
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31;
   int tile = (int)nl_xcd_block();
   if (tile >= ntiles) return;
   // stores go through buffer descriptors: rows past M carry an out-of-range offset and are dropped, so every store instruction is
   // always issued and the vmcnt bookkeeping below is exact
-  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)a.FA, 0, a.M * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 2 ? a.Q : a.FA), 0, a.M * (MODE == 2 ? 512 : 1024), 0x00020000);
   const __amdgpu_buffer_rsrc_t rFT = __builtin_amdgcn_make_buffer_rsrc((void*)(FEAT ? a.fth : a.FA), 0, a.M * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBL = __builtin_amdgcn_make_buffer_rsrc((void*)a.blA, 0, a.M * 128, 0x00020000);
-  for (int i = tid; i < 256; i += 256) { stab[i] = a.gamma[i]; stab[256 + i] = a.beta[i]; stab[512 + i] = a.bias_f0 ? a.bias_f0[i] : 0.f; }
+  for (int i = tid; i < 256; i += 256) {
+    if (MODE != 2) { stab[i] = a.gamma[i]; stab[256 + i] = a.beta[i]; stab[512 + i] = a.bias_f0 ? a.bias_f0[i] : 0.f; }
+    if (MODE != 0) stab[768 + i] = a.bias_g2[i];
+  }
 
   // weight chunks by LDS-DMA into a 4-slot ring, three chunks ahead (buffer form: see point_fused2.hip); piece p = 4 i + wave
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wbase, 0, 0x7fffffff, 0x00020000);
   const unsigned wvoff = wave * 1024 + lane * 16;
   uint4* lw = lds_all + wave * 64;
-  auto ppw = [](int c) constexpr { return PARTS * 2 * ChainGeo::nrt(c) / NW; };
+  auto ppw = [](int c) constexpr { return PARTS * 2 * Geo::nrt(c) / NW; };
   auto dma_chunk = [&](auto Cc) __attribute__((always_inline)) {
-    constexpr int c = ChainGeo::cm(decltype(Cc)::value), st = ChainGeo::stage(c), nrt = ChainGeo::nrt(c);
-    unsigned so = (st == 0 ? a.off_fc : st == 1 ? a.off_f0 : a.off_ba) + (unsigned)(ChainGeo::idx(c) * 4 * nrt * 1024);
+    constexpr int c = Geo::cm(decltype(Cc)::value), kd = Geo::kind(c), nrt = Geo::nrt(c);
+    unsigned so = (kd == CK_FC ? a.off_fc : kd == CK_F0 ? a.off_f0 : kd == CK_BL ? a.off_ba : kd == CK_G2 ? a.off_g2 : a.off_q) +
+                  (unsigned)(Geo::idx(c) * 4 * nrt * 1024);
     tg_static_for<ppw(c)>([&](auto Ic) __attribute__((always_inline)) {
       constexpr int i = decltype(Ic)::value;
       unsigned s2 = so + i * 4096;
@@ -407,38 +440,50 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
 
   tg_f32x16 acc[8];
   tg_bf16x8 Xh[16], Xl[16];
-  tg_f32x4 oraw[16];
+  tg_f32x4 oraw[MODE == 2 ? 1 : 16];
+  tg_f32x4 traw[MODE == 0 ? 1 : 8];
   int m = 0, mm = 0;
   bool mok = false;
-  // attention output rows (fc's B operand: 8 k-steps x 8 floats per lane) and the residual rows as fc's accumulator init
+  // MODE 0: attention output rows (fc's B operand: 8 k-steps x 8 floats per lane) and the residual rows as fc's accumulator init.
   // The blend projection only uses accumulators 0 and 1: the next tile's inputs are fetched while it runs — residual rows of row
   // tiles 2..7 straight into their accumulators, those of row tiles 0, 1 into `gtmp` (moved over when the projection is stored).
-  tg_f32x4 gtmp[8];
+  // MODE 1, 2: the 64-wide hidden rows (out_fc.2's B operand: 4 k-steps x 8 floats per lane) instead of the residual rows.
+  tg_f32x4 gtmp[MODE == 0 ? 8 : 1];
   auto load_tile_inputs = [&](int t) __attribute__((always_inline)) {
     m = t * 128 + 32 * wave + j;
     mok = m < a.M;
     mm = mok ? m : a.M - 1;
-    const float* p = a.O + (size_t)mm * 128 + 8 * hh;
+    if constexpr (MODE != 2) {
+      const float* p = a.O + (size_t)mm * 128 + 8 * hh;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) oraw[i] = *reinterpret_cast<const tg_f32x4*>(p + 16 * (i >> 1) + 4 * (i & 1));
-    const float* rrow = a.G + (size_t)mm * 256 + 4 * hh;
+      for (int i = 0; i < 16; ++i) oraw[i] = *reinterpret_cast<const tg_f32x4*>(p + 16 * (i >> 1) + 4 * (i & 1));
+    }
+    if constexpr (MODE == 0) {
+      const float* rrow = a.G + (size_t)mm * 256 + 4 * hh;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+      for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const tg_f32x4 r4 = *reinterpret_cast<const tg_f32x4*>(rrow + 32 * rt + 8 * gq);
-        if (rt < 2) gtmp[4 * rt + gq] = r4;
-        else { acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3]; }
-      }
+        for (int gq = 0; gq < 4; ++gq) {
+          const tg_f32x4 r4 = *reinterpret_cast<const tg_f32x4*>(rrow + 32 * rt + 8 * gq);
+          if (rt < 2) gtmp[4 * rt + gq] = r4;
+          else { acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3]; }
+        }
+    } else {
+      const float* p = a.T64 + (size_t)mm * 64 + 8 * hh;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) traw[i] = *reinterpret_cast<const tg_f32x4*>(p + 16 * (i >> 1) + 4 * (i & 1));
+    }
   };
   auto adopt_gtmp = [&]() __attribute__((always_inline)) {
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const tg_f32x4 r4 = gtmp[4 * rt + gq];
-        acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3];
-      }
+        for (int gq = 0; gq < 4; ++gq) {
+          const tg_f32x4 r4 = gtmp[4 * rt + gq];
+          acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3];
+        }
+    }
   };
 
   // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`
@@ -465,41 +510,76 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto zero_acc = [&](auto N0, auto N1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rt = decltype(N0)::value; rt < decltype(N1)::value; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  };
+  using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I8 = std::integral_constant<int, 8>;
 
   // ---------------------------------------------------------------- pipeline start
   dma_chunk(std::integral_constant<int, 0>{}); dma_chunk(std::integral_constant<int, 1>{}); dma_chunk(std::integral_constant<int, 2>{});
+  if constexpr (MODE != 0) zero_acc(I0{}, I8{});
   load_tile_inputs(tile);
   adopt_gtmp();
-  __syncthreads();   // stab
+  tg_wait_vmcnt<0>();   // the first pass of the counted waits below assumes nothing older is in flight
+  __syncthreads();      // stab
 
   for (;;) {
     const bool mok_c = mok;
     const int m_c = m, mm_c = mm;
     const int tile_next = tile + (int)gridDim.x;
     tg_static_for<NCH>([&](auto Cc) __attribute__((always_inline)) {
-      constexpr int c = decltype(Cc)::value, st = ChainGeo::stage(c), g = ChainGeo::idx(c);
-      // chunk c must have landed: younger operations are the pieces of chunks c+1, c+2 and the epilogue traffic issued since chunk c-3
-      // (the first iteration has issued fewer: a conservative wait)
-      constexpr int younger = ppw(c + 1) + ppw(c + 2) + ChainGeo::post(c - 3, FEAT) + ChainGeo::post(c - 2, FEAT) + ChainGeo::post(c - 1, FEAT);
+      constexpr int c = decltype(Cc)::value, kd = Geo::kind(c), g = Geo::idx(c);
+      // chunk c must have landed: younger operations are the pieces of chunks c+1, c+2 and the other traffic issued since chunk c-3
+      constexpr int younger = ppw(c + 1) + ppw(c + 2) + Geo::post(c - 3, FEAT) + Geo::post(c - 2, FEAT) + Geo::post(c - 1, FEAT);
       tg_wait_vmcnt<(younger < 63 ? younger : 63)>();
       __builtin_amdgcn_s_barrier();
       dma_chunk(std::integral_constant<int, c + 3>{});   // its slot held chunk c-1, which every wave has left
-      if constexpr (c == 12) load_tile_inputs(tile_next < ntiles ? tile_next : tile);   // (always issued: the wait counts stay exact)
+      if constexpr (c == Geo::PF) load_tile_inputs(tile_next < ntiles ? tile_next : tile);   // (always issued: the wait counts stay exact)
       tg_bf16x8 bh[2], bl[2];
-      if constexpr (st == 0) {
+      if constexpr (kd == CK_FC || kd == CK_G2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const tg_f32x4 u0 = oraw[4 * g + 2 * ks], u1 = oraw[4 * g + 2 * ks + 1];
+          tg_f32x4 u0, u1;
+          if constexpr (kd == CK_FC) { u0 = oraw[(4 * g + 2 * ks) % (MODE == 2 ? 1 : 16)]; u1 = oraw[(4 * g + 2 * ks + 1) % (MODE == 2 ? 1 : 16)]; }
+          else { u0 = traw[(4 * g + 2 * ks) % (MODE == 0 ? 1 : 8)]; u1 = traw[(4 * g + 2 * ks + 1) % (MODE == 0 ? 1 : 8)]; }
           const float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
           tg_split8<X3>(v, bh[ks], bl[ks]);
         }
-        compute(std::integral_constant<int, 8>{}, c % NB, bh, bl);
-      } else {
+        compute(I8{}, c % NB, bh, bl);
+      } else if constexpr (kd != CK_NOP) {
         bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1];
-        if constexpr (st == 1) { if constexpr (FEAT) compute(std::integral_constant<int, 8>{}, c % NB, bh, bl); }
-        else compute(std::integral_constant<int, 2>{}, c % NB, bh, bl);
+        if constexpr (kd == CK_F0) { if constexpr (FEAT) compute(I8{}, c % NB, bh, bl); }
+        else if constexpr (kd == CK_BL) compute(I2{}, c % NB, bh, bl);
+        else if constexpr (kd == CK_Q) compute(std::integral_constant<int, 4>{}, c % NB, bh, bl);
       }
-      if constexpr (c == 3) {
+      if constexpr (kd == CK_G2 && Geo::last(c)) {
+        // ---- G = ELU(out_fc.2 + bias): stays in the accumulators as fc's residual (MODE 1) | becomes w_qs' B operand (MODE 2)
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const float4 b4 = *(const float4*)(stab + 768 + 32 * rt + 8 * gq + 4 * hh);
+            acc[rt][4 * gq + 0] = nl_elu_fast(acc[rt][4 * gq + 0] + b4.x);
+            acc[rt][4 * gq + 1] = nl_elu_fast(acc[rt][4 * gq + 1] + b4.y);
+            acc[rt][4 * gq + 2] = nl_elu_fast(acc[rt][4 * gq + 2] + b4.z);
+            acc[rt][4 * gq + 3] = nl_elu_fast(acc[rt][4 * gq + 3] + b4.w);
+          }
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) {
+              const float u[8] = {acc[rt][8 * sI], acc[rt][8 * sI + 1], acc[rt][8 * sI + 2], acc[rt][8 * sI + 3],
+                                  acc[rt][8 * sI + 4], acc[rt][8 * sI + 5], acc[rt][8 * sI + 6], acc[rt][8 * sI + 7]};
+              tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+          }
+        }
+      }
+      if constexpr (kd == CK_FC && Geo::last(c)) {
         // ---- (fc + residual) -> LayerNorm(row) * aggregation scale -> feature_agg, kept as the next products' B operand
         float s1 = 0.f;
 #pragma unroll
@@ -540,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
         }
       }
-      if constexpr (c == 11) {
+      if constexpr (kd == CK_F0 && Geo::last(c)) {
         if constexpr (FEAT) {
           const unsigned frow = mok_c ? (unsigned)m_c * 1024u + 16u * hh : 0x80000000u;
 #pragma unroll
@@ -554,20 +634,28 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
                                                      rFT, frow + (32 * rt + 8 * gq) * 4, 0, 0);
             }
         }
+        // MODE 0: row tiles 2..7 are about to receive the next tile's residual rows; MODE 1: the next tile starts from zeros
+        if constexpr (MODE == 0) zero_acc(I0{}, I2{}); else zero_acc(I0{}, I8{});
+      }
+      if constexpr (kd == CK_Q && Geo::last(c)) {
+        const unsigned qrow = mok_c ? (unsigned)m_c * 512u + 16u * hh : 0x80000000u;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+          for (int gq = 0; gq < 4; ++gq)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{acc[rt][4 * gq], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3]}),
+                                                   rFA, qrow + (32 * rt + 8 * gq) * 4, 0, 0);
+        zero_acc(I0{}, std::integral_constant<int, 4>{});
+      }
+      if constexpr (kd == CK_BL && Geo::last(c)) {
+        const unsigned brow = mok_c ? (unsigned)m_c * 128u + 16u * hh : 0x80000000u;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{acc[0][4 * gq], acc[0][4 * gq + 1], acc[0][4 * gq + 2], acc[0][4 * gq + 3]}), rBL,
+                                                 brow + 32 * gq, 0, 0);
+        if constexpr (MODE == 0) adopt_gtmp(); else zero_acc(I0{}, I2{});
       }
     });
-    {
-      const unsigned brow = mok_c ? (unsigned)m_c * 128u + 16u * hh : 0x80000000u;
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{acc[0][4 * gq], acc[0][4 * gq + 1], acc[0][4 * gq + 2], acc[0][4 * gq + 3]}), rBL,
-                                               brow + 32 * gq, 0, 0);
-    }
-    adopt_gtmp();
     tile = tile_next;
     if (tile >= ntiles) break;
   }
@@ -612,10 +700,8 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
 
-int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
-                           size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
-                           hipStream_t st) {
-  if (M <= 0) return NL_OK;
+namespace {
+int chain_grid(int ntiles, dim3* grid) {
   static int num_cu = 0;
   if (num_cu == 0) {
     int dev = 0;
@@ -623,14 +709,47 @@ int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
     num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
   }
-  NlChainArgs a{O, G, wscale, gamma, beta, eps, (const char*)wbase, (unsigned)off_fc, (unsigned)off_f0, (unsigned)off_ba, bias_f0, FA, fth, blA, (int)M};
-  const int ntiles = (int)nl_cdiv(M, 128);
-  dim3 grid(ntiles < num_cu ? nl_xcd_grid(ntiles) : num_cu);
+  *grid = dim3(ntiles < num_cu ? nl_xcd_grid(ntiles) : num_cu);
+  return NL_OK;
+}
+}  // namespace
+
+// T64 != null: G is not read — it is recomputed from the 64-wide out_fc hidden rows (weight stream off_g2, bias bias_g2)
+int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
+                           size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
+                           hipStream_t st, const float* T64, size_t off_g2, const float* bias_g2) {
+  if (M <= 0) return NL_OK;
   if ((int64_t)M * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  const int ntiles = (int)nl_cdiv(M, 128);
+  dim3 grid;
+  if (chain_grid(ntiles, &grid) != NL_OK) return NL_ERR_HIP;
+  NlChainArgs a{O, G, wscale, gamma, beta, eps, (const char*)wbase, (unsigned)off_fc, (unsigned)off_f0, (unsigned)off_ba, bias_f0, FA, fth, blA, (int)M,
+                T64, (unsigned)off_g2, 0u, bias_g2, nullptr};
   const bool x3 = precision == NL_PREC_BF16X3;
-  if (x3 && fth) hipLaunchKernelGGL((sample_chain_kernel<true, true>), grid, dim3(256), 0, st, a, ntiles);
-  else if (x3) hipLaunchKernelGGL((sample_chain_kernel<true, false>), grid, dim3(256), 0, st, a, ntiles);
-  else if (fth) hipLaunchKernelGGL((sample_chain_kernel<false, true>), grid, dim3(256), 0, st, a, ntiles);
-  else hipLaunchKernelGGL((sample_chain_kernel<false, false>), grid, dim3(256), 0, st, a, ntiles);
+#define NL_CH(X3, FEAT)                                                                                              \
+  do {                                                                                                               \
+    if (T64) hipLaunchKernelGGL((sample_chain_kernel<X3, FEAT, 1>), grid, dim3(256), 0, st, a, ntiles);              \
+    else hipLaunchKernelGGL((sample_chain_kernel<X3, FEAT, 0>), grid, dim3(256), 0, st, a, ntiles);                  \
+  } while (0)
+  if (x3 && fth) NL_CH(true, true);
+  else if (x3) NL_CH(true, false);
+  else if (fth) NL_CH(false, true);
+  else NL_CH(false, false);
+#undef NL_CH
+  return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+
+// Q = w_qs(ELU(out_fc.2(t64))): the attention query rows without materialising the multiview feature rows (model.py:391-396)
+int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
+                          hipStream_t st) {
+  if (M <= 0) return NL_OK;
+  if ((int64_t)M * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;
+  const int ntiles = (int)nl_cdiv(M, 128);
+  dim3 grid;
+  if (chain_grid(ntiles, &grid) != NL_OK) return NL_ERR_HIP;
+  NlChainArgs a{};
+  a.wbase = (const char*)wbase; a.M = (int)M; a.T64 = T64; a.off_g2 = (unsigned)off_g2; a.off_q = (unsigned)off_q; a.bias_g2 = bias_g2; a.Q = Q;
+  if (precision == NL_PREC_BF16X3) hipLaunchKernelGGL((sample_chain_kernel<true, false, 2>), grid, dim3(256), 0, st, a, ntiles);
+  else hipLaunchKernelGGL((sample_chain_kernel<false, false, 2>), grid, dim3(256), 0, st, a, ntiles);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
