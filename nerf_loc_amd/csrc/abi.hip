@@ -53,9 +53,9 @@ size_t nl_point_stream2_bytes(int W);
 int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
                           const float* rd_w, void* out, int W, int F, hipStream_t st);
 bool nl_point_fused2_supported(int W, int precision);
-int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
-                           size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
-                           hipStream_t st, const float* T64, size_t off_g2, const float* bias_g2);
+int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
+                           size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
+                           float* blA, int64_t M, int precision, hipStream_t st);
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
@@ -554,16 +554,16 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
   SegSpec s0{m.g393, ldg_of(f->C), ldg_of(f->C), 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
-  if (skip_g) return NL_OK;   // the consumers recompute G from the hidden rows (sample_chain_kernel MODE 1, 2)
+  if (skip_g) return NL_OK;   // the consumers recompute G from the hidden rows (sample_chain_kernel)
   SegSpec s1{m.t64, 64, 64, 0, 1};
   NL_TRY(run_gemm(x, G_OUTFC2, &s1, 1, N, G, x.c->W, NL_ACT_ELU));
   return NL_OK;
 }
 
 // knn_done != null: the caller already ran the KNN (+ the aggregation scale) on a side stream and hands over the event to wait for
-// chain != null (fused render path, W = 256, bf16 modes): fc + LayerNorm + scale, feat_mlp.0 (chain->fth, may be null) and the blend
-// projection (chain->blA) run as ONE kernel that keeps feature_agg in registers between them; *chain->done says whether it did
-// chain->t64 != null: G was not materialised (do_mv(skip_g)); the query rows and the chain recompute it from out_fc's hidden rows
+// chain != null && chain->t64 != null (fused render path, W = 256, bf16 modes): the query rows before the branch and fc + LayerNorm +
+// scale, feat_mlp.0 (chain->fth, may be null) and the blend projection (chain->blA) after it run as two chain kernels that recompute
+// the multiview feature rows G from out_fc's hidden rows t64 (G is then not read here and need not exist); *chain->done reports it
 struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; };
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
              float* FA, const PtBufs& p, hipEvent_t knn_done = nullptr, const ChainOut* chain = nullptr) {
@@ -608,19 +608,14 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     NL_TRY(run_gemm(x, G_KV, &s1, 1, MK, p.KV, 256, NL_ACT_NONE));
     NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
   }
-  static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
   if (chain && chain->done) *chain->done = false;
-  if (chain && (t64 || !no_chain) && W == 256 && x.c->precision != NL_PREC_F32) {
-    const int rcc = nl_launch_sample_chain(p.O, G, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_FC], x.L.bst[G_FEAT0P],
-                                           x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st,
-                                           t64, x.L.bst[G_OUTFC2], t64 ? x.p<float>(x.L.bias[G_OUTFC2]) : nullptr);
-    if (rcc == NL_OK) {
-      if (chain->done) *chain->done = true;
-      return NL_OK;
-    }
-    if (rcc != NL_ERR_UNSUPPORTED || t64) return rcc;   // unsupported size: the separate launches below (they need G)
+  if (t64) {   // (the caller checked W, precision and the 32-bit offset range before leaving G unmaterialised)
+    NL_TRY(nl_launch_sample_chain(p.O, t64, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_OUTFC2],
+                                  x.p<float>(x.L.bias[G_OUTFC2]), x.L.bst[G_FC], x.L.bst[G_FEAT0P], x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA,
+                                  chain->fth, chain->blA, N, x.c->precision, x.st));
+    if (chain->done) *chain->done = true;
+    return NL_OK;
   }
-  if (t64) return NL_ERR_UNSUPPORTED;
   SegSpec so{p.O, 128, 128, 0, 1};
   // fc + residual + LayerNorm + aggregation scale: inside the GEMM's epilogue when the streaming kernel takes it
   const RowEpi ep{G, W, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), p.wscale, 1e-6f, FA};
@@ -1092,17 +1087,16 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
       NL_CHECK_HIP(hipEventRecord(side->e[1], side->s[0]));
       knn_done = side->e[1];
     }
-    // G (N x W) stays unmaterialised when every consumer can recompute it from out_fc's 64-wide hidden rows
-    static const bool keep_g = getenv("NERFLOC_KEEP_G") != nullptr || getenv("NERFLOC_NO_CHAIN") != nullptr;
-    static const bool dbg_force = getenv("NERFLOC_FORCE_SKIP_G") != nullptr;
-    const bool skip_g = !keep_g && W == 256 && cfg->precision != NL_PREC_F32 && (!out->mv_feature_agg || dbg_force) && N * 1024 <= 0x7fffffffll &&
-                        nl_point_fused_supported(W, cfg->precision);
-    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, skip_g));
+    // the chain kernels recompute the multiview feature rows G (N x W) from out_fc's 64-wide hidden rows: G is only materialised for
+    // the stage output or when the separate launches run instead (NERFLOC_NO_CHAIN: A/B switch)
+    static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
+    const bool use_chain = !no_chain && W == 256 && cfg->precision != NL_PREC_F32 && N * 1024 <= 0x7fffffffll && nl_point_fused_supported(W, cfg->precision);
+    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     // with early termination feat_mlp.0 runs later, over the live tiles only; otherwise the chain kernel produces it right here
     bool chain_done = false;
     const bool want_feat = out->feat != nullptr;
-    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, skip_g ? rb.mv.t64 : nullptr};
+    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, knn_done, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
     // ---- fork 2: heads that need feature_agg only, beside the ray U-Net

@@ -340,44 +340,60 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 
 
 // ====================================================================================================================
-// Per-sample chain after the neural-point branch (W = 256):   feature_agg = LayerNorm(fc(O) + G) * wscale     (ibrnet.py:110-117,
-//   model.py:419-427)  ->  feat_mlp.0 + LeakyReLU (model.py:85-89)  and  the feature_agg columns of rgb_blending_mlp.0 (model.py:532).
-// As three launches feature_agg (N x W fp32) is written once and read back twice (1.07 GB per config-2 batch) by kernels that are
-// HBM-bound.  Here a wave keeps its 32 rows: the LayerNorm output stays in the accumulator registers, is split to bf16 hi/lo in place
-// and IS the B operand of the next two products (their weight streams are packed with K in accumulator order, like the fused
-// neural-point kernel); feature_agg is still written (the ray U-Net reads it), but never read back here.  One workgroup per CU
-// (the two activation sets + 128 accumulators need the 512-register file); the K-outer chunk pipeline of tgemm_kernel otherwise.
+// Per-sample chains around the neural-point branch (W = 256), one persistent workgroup per CU, a wave keeps its 32 rows:
+//   chain (after the branch):  G = ELU(out_fc.2(t64))  (ibrnet.py:104-106)  ->  feature_agg = LayerNorm(fc(O) + G) * wscale  (ibrnet.py:
+//     110-117, model.py:419-427)  ->  feat_mlp.0 + LeakyReLU (model.py:85-89)  and the feature_agg columns of rgb_blending_mlp.0 (model.py:532)
+//   query (before the branch):  G as above  ->  Q = w_qs(G)  (model.py:391-396)
+// G (N x W) is recomputed from out_fc's 64-wide hidden rows in both and never written or read; the LayerNorm output stays in the
+// accumulator registers, is split to bf16 hi/lo in place and IS the B operand of the next two products (their weight streams are packed
+// with K in accumulator order, like the fused neural-point kernel); feature_agg is written (the ray U-Net reads it), never read back.
+// The K-outer chunk pipeline of tgemm_kernel otherwise, with the weights by buffer LDS-DMA into a 4-slot ring.
 //
-// The kernel runs one of three chunk programs (MODE):
-//   0: fc | feat_mlp.0 | blend projection, the residual rows G = multiview feature (N x W) read from memory
-//   1: out_fc.2 | fc | feat_mlp.0 | blend projection: G = ELU(out_fc.2(t64)) (ibrnet.py:104-106 `out_fc`) is recomputed from the 64-wide
-//      hidden rows and lands in the accumulators fc continues on — G is never written or read (0.5 GB + 0.5 GB per config-2 batch)
-//   2: out_fc.2 | w_qs: the attention query rows Q = w_qs(G) (model.py:391-396) from the same recomputed G, for the neural-point kernel
+// Memory instructions are scheduled, not issued where the data becomes available.  A CU takes one 16-byte-per-lane row store per ~70
+// cycles and one row load (lane = row: 64 cache lines) per ~64 (tools/ubench/vmem_issue.hip), and its 4 waves run in step: issued as
+// bursts (32 stores after an epilogue, 24 loads for the next tile) every wave stood behind the queue for ~300 cycles per instruction,
+// ~35 % of a tile, while the matrix pipes idled; HBM was never the limit (dropping every store at the bounds check changed nothing).
+// With >= 12 MFMAs (or as much VALU work) between two of a wave's instructions the same traffic is free, so each one has a slot:
+//   chain:  out_fc.2 / fc chunks 0..3: 4 attention-row loads each between their MFMAs | ELU epilogue, fc chunks 2, 3 and the first half
+//           of the LayerNorm epilogue: the 24 feat_mlp.0-output stores the PREVIOUS tile left | second half of the LayerNorm epilogue
+//           and feat_mlp.0's chunks: the 32 feature_agg stores + the NEXT tile's 8 hidden-row loads | feat_mlp.0's epilogue and the first
+//           blend chunks: its first 8 output stores.  Rows wait in `fa` (feature_agg after the LayerNorm, feat_mlp.0's output later).
+//   query:  out_fc.2 and w_qs chunks 0..3: the previous tile's 16 query-row stores | w_qs chunks 4..7: the next tile's hidden-row loads
 struct NlChainArgs {
-  const float* O; const float* G; const float* wscale; const float* gamma; const float* beta; float eps;
-  const char* wbase; unsigned off_fc, off_f0, off_ba;   // weight streams as byte offsets into one packed blob
-  const float* bias_f0;
-  float* FA; float* fth; float* blA;
+  const float* O; const float* T64; const float* wscale; const float* gamma; const float* beta; float eps;
+  const char* wbase; unsigned off_g2, off_fc, off_f0, off_ba, off_q;   // weight streams as byte offsets into one packed blob
+  const float* bias_g2; const float* bias_f0;
+  float* FA; float* fth; float* blA; float* Q;
   int M;
-  const float* T64; unsigned off_g2, off_q; const float* bias_g2; float* Q;   // MODE 1, 2
 };
 
 typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
 
 enum { CK_G2 = 0, CK_FC, CK_F0, CK_BL, CK_Q, CK_NOP };
+#ifdef CHAIN_TRACE   // debug build (tools/chain_trace.py): cycle counter of block 0, wave 0 at [kernel][tile][chunk][before wait | after barrier | end of slot]
+__device__ unsigned long long chain_trace[2 * 4 * 96];
+#define CHAIN_T(k)                                                                                                  \
+  do {                                                                                                              \
+    if (blockIdx.x == 0 && wave == 0 && trace_it < 4) {                                                             \
+      const unsigned long long t_ = __builtin_readcyclecounter();                                                   \
+      if (lane == 0) chain_trace[((QUERY ? 1 : 0) * 4 + trace_it) * 96 + 3 * c + (k)] = t_;                         \
+    }                                                                                                               \
+  } while (0)
+#else
+#define CHAIN_T(k)
+#endif
 
-// weight chunks (32 k each) per 128-row tile, e.g. MODE 0: fc 0..3 | feat_mlp.0 4..11 | blend projection 12..19
-template <int MODE>
+// weight chunks (32 k each) per 128-row tile: chain = out_fc.2 0,1 | fc 2..5 | feat_mlp.0 6..13 | blend projection 14..21 | 2 empty;
+// query = out_fc.2 0,1 | w_qs 2..9 | 2 empty.  (The ring slot of a chunk is c % 4 at compile time: programs are padded with empty
+// chunks — barrier only — to a multiple of 4.)
+template <bool QUERY>
 struct ChainGeo {
-  static constexpr int NST = MODE == 0 ? 3 : MODE == 1 ? 4 : 2;
-  static constexpr int kind_at(int s) {
-    return MODE == 0 ? (s == 0 ? CK_FC : s == 1 ? CK_F0 : CK_BL) : MODE == 1 ? (s == 0 ? CK_G2 : s == 1 ? CK_FC : s == 2 ? CK_F0 : CK_BL) : (s == 0 ? CK_G2 : CK_Q);
-  }
+  static constexpr int NST = QUERY ? 2 : 4;
+  static constexpr int kind_at(int s) { return QUERY ? (s == 0 ? CK_G2 : CK_Q) : (s == 0 ? CK_G2 : s == 1 ? CK_FC : s == 2 ? CK_F0 : CK_BL); }
   static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : 8; }
   static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : k == CK_BL ? 2 : k == CK_Q ? 4 : 8; }
   static constexpr int start(int s) { int c = 0; for (int i = 0; i < s; ++i) c += nch_k(kind_at(i)); return c; }
-  // the ring slot of a chunk is c % 4 at compile time: programs are padded with empty chunks (barrier only) to a multiple of 4
   static constexpr int NREAL = start(NST), NCH = (NREAL + 3) / 4 * 4;
   static constexpr int cm(int c) { return ((c % NCH) + NCH) % NCH; }
   static constexpr int spos(int c) { int s = 0; for (int i = 1; i < NST; ++i) if (cm(c) >= start(i)) s = i; return s; }
@@ -385,23 +401,22 @@ struct ChainGeo {
   static constexpr int idx(int c) { return cm(c) - start(spos(c)); }
   static constexpr int nrt(int c) { return nrt_k(kind(c)); }
   static constexpr bool last(int c) { return kind(c) != CK_NOP && idx(c) == nch_k(kind(c)) - 1; }
-  // the next tile's input rows are fetched in the first chunk of the last stage (MODE 0: 16 attention-output + 32 residual loads;
-  // MODE 1: 16 + 8 hidden-row loads; MODE 2: 8)
-  static constexpr int PF = start(NST - 1);
-  static constexpr int NPF = MODE == 0 ? 48 : MODE == 1 ? 24 : 8;
-  // VMEM operations other than LDS-DMA pieces issued in chunk c's slot, after its own pieces went out (per lane-instruction): the
-  // prefetch above; after the fc: wscale load + 32 feature_agg stores; after feat_mlp.0: 32 stores; after the blend projection: 4
-  // stores; after w_qs: 16 stores.  Waits count them: vmcnt retires in issue order.
+  // VMEM operations other than LDS-DMA pieces issued in chunk c's slot after its own pieces went out (the memory schedule above, per
+  // lane-instruction).  Waits count them: vmcnt retires in issue order.
   static constexpr int post(int c, bool feat) {
-    int n = cm(c) == PF ? NPF : 0;
-    if (last(c)) { const int k = kind(c); n += k == CK_FC ? 33 : k == CK_F0 ? (feat ? 32 : 0) : k == CK_BL ? 4 : k == CK_Q ? 16 : 0; }
-    return n;
+    const int k = kind(c), i = idx(c);
+    if (QUERY) return k == CK_G2 ? 4 : k == CK_Q ? 2 : 0;
+    if (k == CK_G2) return 4 + (i == 1 && feat ? 8 : 0);                    // attention rows | ELU epilogue: previous tile's rows 8..15
+    if (k == CK_FC) return (i < 2 ? 4 : feat ? 4 : 0) + (i == 3 ? 1 + 8 + (feat ? 8 : 0) : 0);   // + scale, LayerNorm epilogue
+    if (k == CK_F0) return 4 + (i == 7 && feat ? 6 : 0);                    // 3 feature_agg + 1 hidden-row | epilogue: own rows 0..5
+    if (k == CK_BL) return (i < 2 && feat ? 1 : 0) + (i == 7 ? 4 : 0);      // own rows 6, 7 | blend projection rows
+    return 0;
   }
 };
 
-template <bool X3, bool FEAT, int MODE>
+template <bool X3, bool FEAT, bool QUERY>
 __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a, const int ntiles) {
-  using Geo = ChainGeo<MODE>;
+  using Geo = ChainGeo<QUERY>;
   constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = Geo::NCH, NB = 4;
   constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per ring slot (sized for 8 row tiles)
   __shared__ uint4 lds_all[NB * SLOT16 + 4 * 64];
@@ -411,14 +426,15 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
   const int hh = lane >> 5, j = lane & 31;
   int tile = (int)nl_xcd_block();
   if (tile >= ntiles) return;
-  // stores go through buffer descriptors: rows past M carry an out-of-range offset and are dropped, so every store instruction is
-  // always issued and the vmcnt bookkeeping below is exact
-  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 2 ? a.Q : a.FA), 0, a.M * (MODE == 2 ? 512 : 1024), 0x00020000);
+  // stores go through buffer descriptors: rows past M (and the deferred stores of the tile before the first) carry an out-of-range
+  // offset and are dropped, so every store instruction is always issued and the vmcnt bookkeeping below is exact
+  constexpr unsigned DROP = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)(QUERY ? a.Q : a.FA), 0, a.M * (QUERY ? 512 : 1024), 0x00020000);
   const __amdgpu_buffer_rsrc_t rFT = __builtin_amdgcn_make_buffer_rsrc((void*)(FEAT ? a.fth : a.FA), 0, a.M * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBL = __builtin_amdgcn_make_buffer_rsrc((void*)a.blA, 0, a.M * 128, 0x00020000);
   for (int i = tid; i < 256; i += 256) {
-    if (MODE != 2) { stab[i] = a.gamma[i]; stab[256 + i] = a.beta[i]; stab[512 + i] = a.bias_f0 ? a.bias_f0[i] : 0.f; }
-    if (MODE != 0) stab[768 + i] = a.bias_g2[i];
+    if (!QUERY) { stab[i] = a.gamma[i]; stab[256 + i] = a.beta[i]; stab[512 + i] = a.bias_f0 ? a.bias_f0[i] : 0.f; }
+    stab[768 + i] = a.bias_g2[i];
   }
 
   // weight chunks by LDS-DMA into a 4-slot ring, three chunks ahead (buffer form: see point_fused2.hip); piece p = 4 i + wave
@@ -439,55 +455,32 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
   };
 
   tg_f32x16 acc[8];
+  tg_f32x16 qacc[QUERY ? 4 : 1];           // query: w_qs accumulates beside G, whose row tiles are converted while it runs
   tg_bf16x8 Xh[16], Xl[16];
-  tg_f32x4 oraw[MODE == 2 ? 1 : 16];
-  tg_f32x4 traw[MODE == 0 ? 1 : 8];
-  int m = 0, mm = 0;
-  bool mok = false;
-  // MODE 0: attention output rows (fc's B operand: 8 k-steps x 8 floats per lane) and the residual rows as fc's accumulator init.
-  // The blend projection only uses accumulators 0 and 1: the next tile's inputs are fetched while it runs — residual rows of row
-  // tiles 2..7 straight into their accumulators, those of row tiles 0, 1 into `gtmp` (moved over when the projection is stored).
-  // MODE 1, 2: the 64-wide hidden rows (out_fc.2's B operand: 4 k-steps x 8 floats per lane) instead of the residual rows.
-  tg_f32x4 gtmp[MODE == 0 ? 8 : 1];
-  auto load_tile_inputs = [&](int t) __attribute__((always_inline)) {
+  tg_f32x4 oraw[QUERY ? 1 : 16];           // attention output rows: fc's B operand, 8 k-steps x 8 floats per lane
+  tg_f32x4 traw[8];                        // out_fc hidden rows: out_fc.2's B operand, 4 k-steps x 8 floats per lane
+  float fa[QUERY ? 4 : 8][16];             // rows waiting for their scheduled stores (chain: feature_agg, then feat_mlp.0's output; query: Q)
+  auto row_of = [&](int t, int& m, int& mm, bool& mok) __attribute__((always_inline)) {
     m = t * 128 + 32 * wave + j;
     mok = m < a.M;
     mm = mok ? m : a.M - 1;
-    if constexpr (MODE != 2) {
-      const float* p = a.O + (size_t)mm * 128 + 8 * hh;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) oraw[i] = *reinterpret_cast<const tg_f32x4*>(p + 16 * (i >> 1) + 4 * (i & 1));
-    }
-    if constexpr (MODE == 0) {
-      const float* rrow = a.G + (size_t)mm * 256 + 4 * hh;
-#pragma unroll
-      for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const tg_f32x4 r4 = *reinterpret_cast<const tg_f32x4*>(rrow + 32 * rt + 8 * gq);
-          if (rt < 2) gtmp[4 * rt + gq] = r4;
-          else { acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3]; }
-        }
-    } else {
-      const float* p = a.T64 + (size_t)mm * 64 + 8 * hh;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) traw[i] = *reinterpret_cast<const tg_f32x4*>(p + 16 * (i >> 1) + 4 * (i & 1));
-    }
   };
-  auto adopt_gtmp = [&]() __attribute__((always_inline)) {
-    if constexpr (MODE == 0) {
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const tg_f32x4 r4 = gtmp[4 * rt + gq];
-          acc[rt][4 * gq] = r4[0]; acc[rt][4 * gq + 1] = r4[1]; acc[rt][4 * gq + 2] = r4[2]; acc[rt][4 * gq + 3] = r4[3];
-        }
-    }
+  // (the indices below are compile-time constants after unrolling: every caller sits in an unrolled loop or a static_for)
+  auto load_traw = [&](int i, int mm) __attribute__((always_inline)) {
+    traw[i] = *reinterpret_cast<const tg_f32x4*>(a.T64 + (size_t)mm * 64 + 8 * hh + 16 * (i >> 1) + 4 * (i & 1));
+  };
+  auto load_oraw = [&](int i, int mm) __attribute__((always_inline)) {
+    oraw[i % (QUERY ? 1 : 16)] = *reinterpret_cast<const tg_f32x4*>(a.O + (size_t)mm * 128 + 8 * hh + 16 * (i >> 1) + 4 * (i & 1));
+  };
+  // row store q (0..31 | 0..15) of `fa`: 16 B of row tile q / 4 at columns 8 (q % 4) + 4 hh
+  auto store_fa = [&](int q, __amdgpu_buffer_rsrc_t rsrc, unsigned rowoff) __attribute__((always_inline)) {
+    const int rt = q >> 2, gq = q & 3, rtc = rt % (QUERY ? 4 : 8);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{fa[rtc][4 * gq], fa[rtc][4 * gq + 1], fa[rtc][4 * gq + 2], fa[rtc][4 * gq + 3]}), rsrc,
+                                           rowoff + (32 * rt + 8 * gq) * 4, 0, 0);
   };
 
-  // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`
-  auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
+  // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`; filler(step) runs between the MFMA groups
+  auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2], auto& dst, auto&& filler) __attribute__((always_inline)) {
     constexpr int NRT = decltype(Nc)::value, nt = 2 * NRT;
     const tg_bf16x8* L = ring[slot];
     auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
@@ -503,11 +496,33 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
       if (tt + 2 < nt) ldA(tt + 2, ah[(tt + 2) % 3], al[(tt + 2) % 3]);
       const int ks = tt / NRT, rt = tt - ks * NRT;
       if (X3) {
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt % 3], bh[ks], acc[rt], 0, 0, 0);
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], acc[rt], 0, 0, 0);
+        dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt % 3], bh[ks], dst[rt], 0, 0, 0);
+        dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], dst[rt], 0, 0, 0);
       }
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+      dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], dst[rt], 0, 0, 0);
+      filler(tt);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto no_fill = [](int) __attribute__((always_inline)) {};
+  // G = ELU(out_fc.2 + bias) of row tile rt, in 7 steps: 4 x 4 values | 2 x bf16 split into k-steps 2 rt, 2 rt + 1 (query only) | clear
+  auto g2_epilogue_step = [&](auto Rt, int step) __attribute__((always_inline)) {
+    constexpr int rt = decltype(Rt)::value;
+    if (step < 4) {
+      const int gq = step;
+      const float4 b4 = *(const float4*)(stab + 768 + 32 * rt + 8 * gq + 4 * hh);
+      acc[rt][4 * gq + 0] = nl_elu_fast(acc[rt][4 * gq + 0] + b4.x);
+      acc[rt][4 * gq + 1] = nl_elu_fast(acc[rt][4 * gq + 1] + b4.y);
+      acc[rt][4 * gq + 2] = nl_elu_fast(acc[rt][4 * gq + 2] + b4.z);
+      acc[rt][4 * gq + 3] = nl_elu_fast(acc[rt][4 * gq + 3] + b4.w);
+    } else if (QUERY && step < 6) {
+      const int sI = step - 4;
+      const float u[8] = {acc[rt][8 * sI], acc[rt][8 * sI + 1], acc[rt][8 * sI + 2], acc[rt][8 * sI + 3],
+                          acc[rt][8 * sI + 4], acc[rt][8 * sI + 5], acc[rt][8 * sI + 6], acc[rt][8 * sI + 7]};
+      tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
+    } else if (QUERY && step == 6) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
     }
   };
   auto zero_acc = [&](auto N0, auto N1) __attribute__((always_inline)) {
@@ -516,71 +531,102 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
   };
-  using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I8 = std::integral_constant<int, 8>;
+  using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
 
   // ---------------------------------------------------------------- pipeline start
-  dma_chunk(std::integral_constant<int, 0>{}); dma_chunk(std::integral_constant<int, 1>{}); dma_chunk(std::integral_constant<int, 2>{});
-  if constexpr (MODE != 0) zero_acc(I0{}, I8{});
-  load_tile_inputs(tile);
-  adopt_gtmp();
+  dma_chunk(I0{}); dma_chunk(std::integral_constant<int, 1>{}); dma_chunk(I2{});
+  zero_acc(I0{}, I8{});
+#pragma unroll
+  for (int rt = 0; rt < (QUERY ? 4 : 1); ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qacc[rt][r] = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < (QUERY ? 4 : 8); ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fa[rt][r] = 0.f;
+  int m_c, mm_c; bool mok_c;
+  row_of(tile, m_c, mm_c, mok_c);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) load_traw(i, mm_c);
+#ifdef CHAIN_TRACE
+  int trace_it = 0;
+#endif
+  unsigned prev_row = DROP;   // byte offset of this lane's row in the previous tile's deferred stores
   tg_wait_vmcnt<0>();   // the first pass of the counted waits below assumes nothing older is in flight
   __syncthreads();      // stab
 
   for (;;) {
-    const bool mok_c = mok;
-    const int m_c = m, mm_c = mm;
     const int tile_next = tile + (int)gridDim.x;
+    int m_n, mm_n; bool mok_n;
+    row_of(tile_next < ntiles ? tile_next : tile, m_n, mm_n, mok_n);
+    const unsigned row1k = mok_c ? (unsigned)m_c * 1024u + 16u * hh : DROP;   // this lane's row in the (N, 256) outputs
     tg_static_for<NCH>([&](auto Cc) __attribute__((always_inline)) {
       constexpr int c = decltype(Cc)::value, kd = Geo::kind(c), g = Geo::idx(c);
       // chunk c must have landed: younger operations are the pieces of chunks c+1, c+2 and the other traffic issued since chunk c-3
       constexpr int younger = ppw(c + 1) + ppw(c + 2) + Geo::post(c - 3, FEAT) + Geo::post(c - 2, FEAT) + Geo::post(c - 1, FEAT);
+      CHAIN_T(0);
       tg_wait_vmcnt<(younger < 63 ? younger : 63)>();
       __builtin_amdgcn_s_barrier();
+      CHAIN_T(1);
       dma_chunk(std::integral_constant<int, c + 3>{});   // its slot held chunk c-1, which every wave has left
-      if constexpr (c == Geo::PF) load_tile_inputs(tile_next < ntiles ? tile_next : tile);   // (always issued: the wait counts stay exact)
+      // ---- this slot's share of the row traffic: operation k of the slot goes out after MFMA group 4 k + 1 (always issued: the wait
+      // counts stay exact)
+      auto mem_op = [&](int k) __attribute__((always_inline)) {
+        if constexpr (QUERY) {
+          if constexpr (kd == CK_G2) store_fa(4 * g + k, rFA, prev_row);                       // previous tile's rows 0..7
+          else if constexpr (g < 4) store_fa(8 + 2 * g + k, rFA, prev_row);                    // 8..15
+          else load_traw(2 * (g - 4) + k, mm_n);
+        } else {
+          if constexpr (kd == CK_G2) load_oraw(4 * g + k, mm_c);
+          else if constexpr (kd == CK_FC && g < 2) load_oraw(8 + 4 * g + k, mm_c);
+          else if constexpr (kd == CK_FC) { if constexpr (FEAT) store_fa(16 + 4 * (g - 2) + k, rFT, prev_row); }   // previous tile's rows 16..23
+          else if constexpr (kd == CK_F0) { if (k < 3) store_fa(8 + 3 * g + k, rFA, row1k); else load_traw(g, mm_n); }
+        }
+      };
+      auto mem_fill = [&](int tt) __attribute__((always_inline)) { if ((tt & 3) == 1) mem_op(tt >> 2); };
+      if constexpr (kd == CK_BL && FEAT && g < 2) store_fa(6 + g, rFT, row1k);
+      if constexpr (kd == CK_F0 && !FEAT) {   // no feat_mlp.0 MFMAs to hide behind: the slot's operations in one go
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mem_op(k);
+      }
+
       tg_bf16x8 bh[2], bl[2];
       if constexpr (kd == CK_FC || kd == CK_G2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           tg_f32x4 u0, u1;
-          if constexpr (kd == CK_FC) { u0 = oraw[(4 * g + 2 * ks) % (MODE == 2 ? 1 : 16)]; u1 = oraw[(4 * g + 2 * ks + 1) % (MODE == 2 ? 1 : 16)]; }
-          else { u0 = traw[(4 * g + 2 * ks) % (MODE == 0 ? 1 : 8)]; u1 = traw[(4 * g + 2 * ks + 1) % (MODE == 0 ? 1 : 8)]; }
+          if constexpr (kd == CK_FC) { u0 = oraw[(4 * g + 2 * ks) % (QUERY ? 1 : 16)]; u1 = oraw[(4 * g + 2 * ks + 1) % (QUERY ? 1 : 16)]; }
+          else { u0 = traw[4 * g + 2 * ks]; u1 = traw[4 * g + 2 * ks + 1]; }
           const float v[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
           tg_split8<X3>(v, bh[ks], bl[ks]);
         }
-        compute(I8{}, c % NB, bh, bl);
+        compute(I8{}, c % NB, bh, bl, acc, mem_fill);
       } else if constexpr (kd != CK_NOP) {
         bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1];
-        if constexpr (kd == CK_F0) { if constexpr (FEAT) compute(I8{}, c % NB, bh, bl); }
-        else if constexpr (kd == CK_BL) compute(I2{}, c % NB, bh, bl);
-        else if constexpr (kd == CK_Q) compute(std::integral_constant<int, 4>{}, c % NB, bh, bl);
+        if constexpr (kd == CK_F0) { if constexpr (FEAT) compute(I8{}, c % NB, bh, bl, acc, mem_fill); }
+        else if constexpr (kd == CK_BL) compute(I2{}, c % NB, bh, bl, acc, no_fill);
+        else if constexpr (g + 1 < 8)   // w_qs chunk g (k-steps of G's row tile g): row tile g + 1 is converted between its MFMAs
+          compute(I4{}, c % NB, bh, bl, qacc, [&](int tt) __attribute__((always_inline)) { g2_epilogue_step(std::integral_constant<int, (g + 1) % 8>{}, tt); mem_fill(tt); });
+        else compute(I4{}, c % NB, bh, bl, qacc, mem_fill);
       }
+
       if constexpr (kd == CK_G2 && Geo::last(c)) {
-        // ---- G = ELU(out_fc.2 + bias): stays in the accumulators as fc's residual (MODE 1) | becomes w_qs' B operand (MODE 2)
+        if constexpr (QUERY) {
 #pragma unroll
-        for (int rt = 0; rt < 8; ++rt) {
+          for (int step = 0; step < 7; ++step) g2_epilogue_step(I0{}, step);
+        } else {   // G stays in the accumulators: fc continues on it (the residual of ibrnet.py:112)
+          tg_static_for<8>([&](auto Rt) __attribute__((always_inline)) {
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const float4 b4 = *(const float4*)(stab + 768 + 32 * rt + 8 * gq + 4 * hh);
-            acc[rt][4 * gq + 0] = nl_elu_fast(acc[rt][4 * gq + 0] + b4.x);
-            acc[rt][4 * gq + 1] = nl_elu_fast(acc[rt][4 * gq + 1] + b4.y);
-            acc[rt][4 * gq + 2] = nl_elu_fast(acc[rt][4 * gq + 2] + b4.z);
-            acc[rt][4 * gq + 3] = nl_elu_fast(acc[rt][4 * gq + 3] + b4.w);
-          }
-          if constexpr (MODE == 2) {
-#pragma unroll
-            for (int sI = 0; sI < 2; ++sI) {
-              const float u[8] = {acc[rt][8 * sI], acc[rt][8 * sI + 1], acc[rt][8 * sI + 2], acc[rt][8 * sI + 3],
-                                  acc[rt][8 * sI + 4], acc[rt][8 * sI + 5], acc[rt][8 * sI + 6], acc[rt][8 * sI + 7]};
-              tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-          }
+            for (int step = 0; step < 4; ++step) g2_epilogue_step(Rt, step);
+            if constexpr (FEAT) store_fa(8 + decltype(Rt)::value, rFT, prev_row);
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
       }
       if constexpr (kd == CK_FC && Geo::last(c)) {
-        // ---- (fc + residual) -> LayerNorm(row) * aggregation scale -> feature_agg, kept as the next products' B operand
+        // ---- (fc + residual) -> LayerNorm(row) * aggregation scale -> feature_agg: into `fa` for the scheduled stores, and split
+        // to bf16 as the next products' B operand
         float s1 = 0.f;
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt)
@@ -596,10 +642,9 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
         s2 += __shfl_xor(s2, 32, 64);
         const float rstd = 1.f / sqrtf(s2 / 256.f + a.eps);
         const float sc = a.wscale[mm_c];
-        const unsigned crow = mok_c ? (unsigned)m_c * 1024u + 16u * hh : 0x80000000u;
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) {
-          float v[16];
+          float (&v)[16] = fa[rt % (QUERY ? 4 : 8)];
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const int n = 32 * rt + 8 * gq + 4 * hh;
@@ -608,8 +653,6 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
             v[4 * gq + 1] = ((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y) * sc;
             v[4 * gq + 2] = ((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z) * sc;
             v[4 * gq + 3] = ((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w) * sc;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]}), rFA,
-                                                   crow + (32 * rt + 8 * gq) * 4, 0, 0);
           }
 #pragma unroll
           for (int sI = 0; sI < 2; ++sI) {   // accumulator registers 8 s .. 8 s + 7 of row tile rt = k-step 2 rt + s in accumulator order
@@ -618,46 +661,63 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+          // row tiles 0..3: the previous tile's last rows (they sit in fa[6], fa[7], overwritten in iterations 6, 7); 4..7: this tile's first
+          if (rt < 4) { if constexpr (FEAT) { store_fa(24 + 2 * rt, rFT, prev_row); store_fa(25 + 2 * rt, rFT, prev_row); } }
+          else { store_fa(2 * (rt - 4), rFA, row1k); store_fa(2 * (rt - 4) + 1, rFA, row1k); }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (kd == CK_F0 && Geo::last(c)) {
+        // ---- feat_mlp.0's rows (bias + LeakyReLU) replace feature_agg in `fa` (its last store went out in front of this chunk)
         if constexpr (FEAT) {
-          const unsigned frow = mok_c ? (unsigned)m_c * 1024u + 16u * hh : 0x80000000u;
 #pragma unroll
-          for (int rt = 0; rt < 8; ++rt)
+          for (int rt = 0; rt < 8; ++rt) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
               const int n = 32 * rt + 8 * gq + 4 * hh;
               const float4 b4 = *(const float4*)(stab + 512 + n);
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{nl_lrelu(acc[rt][4 * gq] + b4.x), nl_lrelu(acc[rt][4 * gq + 1] + b4.y),
-                                                                                         nl_lrelu(acc[rt][4 * gq + 2] + b4.z), nl_lrelu(acc[rt][4 * gq + 3] + b4.w)}),
-                                                     rFT, frow + (32 * rt + 8 * gq) * 4, 0, 0);
+              float (&v)[16] = fa[rt % (QUERY ? 4 : 8)];
+              v[4 * gq] = nl_lrelu(acc[rt][4 * gq] + b4.x); v[4 * gq + 1] = nl_lrelu(acc[rt][4 * gq + 1] + b4.y);
+              v[4 * gq + 2] = nl_lrelu(acc[rt][4 * gq + 2] + b4.z); v[4 * gq + 3] = nl_lrelu(acc[rt][4 * gq + 3] + b4.w);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+            if (rt >= 2) store_fa(rt - 2, rFT, row1k);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-        // MODE 0: row tiles 2..7 are about to receive the next tile's residual rows; MODE 1: the next tile starts from zeros
-        if constexpr (MODE == 0) zero_acc(I0{}, I2{}); else zero_acc(I0{}, I8{});
-      }
-      if constexpr (kd == CK_Q && Geo::last(c)) {
-        const unsigned qrow = mok_c ? (unsigned)m_c * 512u + 16u * hh : 0x80000000u;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{acc[rt][4 * gq], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3]}),
-                                                   rFA, qrow + (32 * rt + 8 * gq) * 4, 0, 0);
-        zero_acc(I0{}, std::integral_constant<int, 4>{});
       }
       if constexpr (kd == CK_BL && Geo::last(c)) {
-        const unsigned brow = mok_c ? (unsigned)m_c * 128u + 16u * hh : 0x80000000u;
+        const unsigned brow = mok_c ? (unsigned)m_c * 128u + 16u * hh : DROP;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, tg_f32x4{acc[0][4 * gq], acc[0][4 * gq + 1], acc[0][4 * gq + 2], acc[0][4 * gq + 3]}), rBL,
                                                  brow + 32 * gq, 0, 0);
-        if constexpr (MODE == 0) adopt_gtmp(); else zero_acc(I0{}, I2{});
+        zero_acc(I0{}, I2{});
       }
+      if constexpr (kd == CK_Q && Geo::last(c)) {   // (the previous tile's query rows left `fa` in chunks 0..7)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { fa[rt % (QUERY ? 4 : 8)][r] = qacc[rt % (QUERY ? 4 : 1)][r]; qacc[rt % (QUERY ? 4 : 1)][r] = 0.f; }
+      }
+      CHAIN_T(2);
     });
+#ifdef CHAIN_TRACE
+    ++trace_it;
+#endif
+    prev_row = QUERY ? (mok_c ? (unsigned)m_c * 512u + 16u * hh : DROP) : row1k;
+    m_c = m_n; mm_c = mm_n; mok_c = mok_n;
     tile = tile_next;
     if (tile >= ntiles) break;
+  }
+  // the last tile's deferred rows
+  if constexpr (QUERY) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) store_fa(q, rFA, prev_row);
+  } else if constexpr (FEAT) {
+#pragma unroll
+    for (int q = 8; q < 32; ++q) store_fa(q, rFT, prev_row);
   }
   tg_wait_vmcnt<0>();   // LDS-DMA prefetched past the last tile must land before the LDS goes to another workgroup
 }
@@ -700,6 +760,12 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
 
+#ifdef CHAIN_TRACE
+extern "C" __attribute__((visibility("default"))) int nl_debug_chain_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(chain_trace), sizeof(unsigned long long) * 2 * 4 * 96) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace {
 int chain_grid(int ntiles, dim3* grid) {
   static int num_cu = 0;
@@ -714,28 +780,24 @@ int chain_grid(int ntiles, dim3* grid) {
 }
 }  // namespace
 
-// T64 != null: G is not read — it is recomputed from the 64-wide out_fc hidden rows (weight stream off_g2, bias bias_g2)
-int nl_launch_sample_chain(const float* O, const float* G, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
-                           size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth, float* blA, int64_t M, int precision,
-                           hipStream_t st, const float* T64, size_t off_g2, const float* bias_g2) {
+// feature_agg (+ feat_mlp.0's rows when fth != null, + the blend projection) from the attention rows O and out_fc's hidden rows T64
+int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
+                           size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
+                           float* blA, int64_t M, int precision, hipStream_t st) {
   if (M <= 0) return NL_OK;
   if ((int64_t)M * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   const int ntiles = (int)nl_cdiv(M, 128);
   dim3 grid;
   if (chain_grid(ntiles, &grid) != NL_OK) return NL_ERR_HIP;
-  NlChainArgs a{O, G, wscale, gamma, beta, eps, (const char*)wbase, (unsigned)off_fc, (unsigned)off_f0, (unsigned)off_ba, bias_f0, FA, fth, blA, (int)M,
-                T64, (unsigned)off_g2, 0u, bias_g2, nullptr};
+  NlChainArgs a{};
+  a.O = O; a.T64 = T64; a.wscale = wscale; a.gamma = gamma; a.beta = beta; a.eps = eps; a.wbase = (const char*)wbase;
+  a.off_g2 = (unsigned)off_g2; a.off_fc = (unsigned)off_fc; a.off_f0 = (unsigned)off_f0; a.off_ba = (unsigned)off_ba;
+  a.bias_g2 = bias_g2; a.bias_f0 = bias_f0; a.FA = FA; a.fth = fth; a.blA = blA; a.M = (int)M;
   const bool x3 = precision == NL_PREC_BF16X3;
-#define NL_CH(X3, FEAT)                                                                                              \
-  do {                                                                                                               \
-    if (T64) hipLaunchKernelGGL((sample_chain_kernel<X3, FEAT, 1>), grid, dim3(256), 0, st, a, ntiles);              \
-    else hipLaunchKernelGGL((sample_chain_kernel<X3, FEAT, 0>), grid, dim3(256), 0, st, a, ntiles);                  \
-  } while (0)
-  if (x3 && fth) NL_CH(true, true);
-  else if (x3) NL_CH(true, false);
-  else if (fth) NL_CH(false, true);
-  else NL_CH(false, false);
-#undef NL_CH
+  if (x3 && fth) hipLaunchKernelGGL((sample_chain_kernel<true, true, false>), grid, dim3(256), 0, st, a, ntiles);
+  else if (x3) hipLaunchKernelGGL((sample_chain_kernel<true, false, false>), grid, dim3(256), 0, st, a, ntiles);
+  else if (fth) hipLaunchKernelGGL((sample_chain_kernel<false, true, false>), grid, dim3(256), 0, st, a, ntiles);
+  else hipLaunchKernelGGL((sample_chain_kernel<false, false, false>), grid, dim3(256), 0, st, a, ntiles);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
 
@@ -749,7 +811,7 @@ int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, co
   if (chain_grid(ntiles, &grid) != NL_OK) return NL_ERR_HIP;
   NlChainArgs a{};
   a.wbase = (const char*)wbase; a.M = (int)M; a.T64 = T64; a.off_g2 = (unsigned)off_g2; a.off_q = (unsigned)off_q; a.bias_g2 = bias_g2; a.Q = Q;
-  if (precision == NL_PREC_BF16X3) hipLaunchKernelGGL((sample_chain_kernel<true, false, 2>), grid, dim3(256), 0, st, a, ntiles);
-  else hipLaunchKernelGGL((sample_chain_kernel<false, false, 2>), grid, dim3(256), 0, st, a, ntiles);
+  if (precision == NL_PREC_BF16X3) hipLaunchKernelGGL((sample_chain_kernel<true, false, true>), grid, dim3(256), 0, st, a, ntiles);
+  else hipLaunchKernelGGL((sample_chain_kernel<false, false, true>), grid, dim3(256), 0, st, a, ntiles);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }

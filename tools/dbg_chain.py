@@ -1,4 +1,4 @@
-"""Debug: render with G materialised (NERFLOC_KEEP_G=1) vs recomputed; run as two subprocesses, compare intermediates."""
+"""Debug: the chain kernels (default) against the separate launches (NERFLOC_NO_CHAIN=1); two subprocesses, compares intermediates."""
 import os, sys, subprocess
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,12 +19,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else "64"
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
-for tag, env in (("keep", {"NERFLOC_KEEP_G": "1"}), ("new", {"NERFLOC_FORCE_SKIP_G": "1"})):
+for tag, env in (("keep", {"NERFLOC_NO_CHAIN": "1"}), ("new", {})):
     e = dict(os.environ); e.update(env)
     subprocess.check_call([sys.executable, __file__, "child", f"/tmp/dbg_{tag}.npz", n, prec], env=e)
 a, b = np.load("/tmp/dbg_keep.npz"), np.load("/tmp/dbg_new.npz")
 for k in a.files:
-    if k == "mv_feature_agg": continue
     x, y = a[k], b[k]
     err = np.abs(x - y)
     print(k, x.shape, "max abs", err.max(), "ref max", np.abs(x).max(), "nan", np.isnan(y).sum())
