@@ -29,6 +29,7 @@ import torch.nn as nn
 from .depth_fusion import DepthFusionNet
 from .frame_setup import backproject_support
 from .frame_setup import get_rays as _hip_get_rays
+from . import diff_render
 from .renderer import HipRenderer
 
 
@@ -367,15 +368,16 @@ class ConditionalNeRF(nn.Module):
         return torch.cat(out, -1)
 
     # ------------------------------------------------------------------ rendering
+    @staticmethod
+    def _wants_grad(*tensors) -> bool:
+        return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
     def _refuse_autograd(self, what, *tensors):
-        """The HIP path returns detached tensors.  pose_optimizer.py:131-160 calls render_rays in eval mode under
-        torch.enable_grad() and back-propagates to the camera pose: fail loudly instead of silently dropping that gradient."""
-        if not torch.is_grad_enabled():
-            return
-        for t in tensors:
-            if isinstance(t, torch.Tensor) and t.requires_grad:
-                raise NotImplementedError(f"{what}: an input requires grad, but the HIP renderer has no backward pass yet "
-                                          "(SURVEY.md §8f-2); call it under torch.no_grad() or detach the inputs")
+        """The HIP kernels return detached tensors: entry points without a gradient path fail loudly instead of silently dropping
+        the gradient (render_rays and points_2d_to_rays have one: nerf_loc_amd/diff_render.py)."""
+        if self._wants_grad(*tensors):
+            raise NotImplementedError(f"{what}: an input requires grad, but this entry point has no gradient path "
+                                      "(SURVEY.md §8f-2); call it under torch.no_grad() or detach the inputs")
 
     def sample_depths(self, N_samples, near, far):
         """model.py:451-458 (tiny, host-side torch like the reference)."""
@@ -387,10 +389,43 @@ class ConditionalNeRF(nn.Module):
     def render_rays(self, data, rays, u: Optional[torch.Tensor] = None):
         """model.py:472-600, eval mode.  `u` optionally fixes sample_pdf's uniform draws (reference: torch.rand)."""
         if self.training:
-            raise NotImplementedError("autograd through the HIP renderer (beta / render loss) is a next-row item (SURVEY.md §8f-2)")
-        self._refuse_autograd("render_rays", rays.get("rays_o"), rays.get("rays_d"), rays.get("pose"), data.get("pose"))
+            raise NotImplementedError("training through the renderer (beta / render loss w.r.t. the weights) is a next-row item (SURVEY.md §8f-2)")
+        if self._wants_grad(rays.get("rays_o"), rays.get("rays_d"), rays.get("pose"), data.get("pose")):
+            return self._render_rays_grad(data, rays, u)
         with torch.no_grad():
             return self._render_rays(data, rays, u)
+
+    def _render_rays_grad(self, data, rays, u):
+        """pose_optimizer.py:131-160 calls render_rays in eval mode under torch.enable_grad() and back-propagates a photometric loss to
+        the camera pose.  This is that case: the differentiable eager path of nerf_loc_amd/diff_render.py (fp32 autograd on the GPU)
+        with the exact KNN and the hierarchical depths from the HIP library; gradients flow to rays_o / rays_d / data['pose'], the
+        network weights are constants (PoseOptimizer optimises the pose only).  Checked against the reference's autograd in
+        tests/test_diff_render.py."""
+        r = self._ensure_frame(data, "fine")
+        near, far = rays["depth_range"]
+        o, d = rays["rays_o"], rays["rays_d"]
+        R, N = o.shape[0], self.args.render.N_samples
+        z = self.sample_depths(N, near, far).expand(R, N).contiguous()
+        depth_coarse = None
+        if self.args.render.N_importance > 0:   # the resampled depths carry no gradient in the reference either (model.py:495 detaches)
+            with torch.no_grad():
+                if u is None:
+                    u = torch.rand(R, self.args.render.N_importance, device=o.device)
+                z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"].detach(), z, u,
+                                                           near=float(near), far=float(far))
+        fnear, ffar = [float(x) for x in data["depth_range"][0]]
+        sp = self.support_neural_points["fine"]
+        fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"], "feat_fine_src": data["feat_fine_src"],
+              "vis_featmaps": self._vis_featmaps(data), "near": fnear, "far": ffar,
+              "support": {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")}}
+        p = {k: v.detach() for k, v in self.state_dict().items()}
+        out = diff_render.render_rays_diff(p, fr, o, d, z.to(o.dtype), data["pose"], lambda q: r.knn(q, 8)[1],
+                                           white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)))
+        if not self.args.render.render_feature:
+            out.pop("feat")
+        if depth_coarse is not None:
+            out["depth_coarse"] = depth_coarse
+        return out
 
     def _render_rays(self, data, rays, u):
         r = self._ensure_frame(data, "fine")
@@ -438,7 +473,10 @@ class ConditionalNeRF(nn.Module):
 
     def points_2d_to_rays(self, pts2d, H, W, K, pose):
         """model.py:687-700."""
-        o, d = _hip_get_rays(H, W, K, pose, uv=pts2d)   # only the requested pixels (the reference builds the whole grid and indexes it)
+        if self._wants_grad(pose, K):   # differentiable w.r.t. the pose (pose_optimizer.py:136)
+            o, d = diff_render.rays_from_pose(pts2d, K, pose)
+        else:
+            o, d = _hip_get_rays(H, W, K, pose, uv=pts2d)   # only the requested pixels (the reference builds the whole grid and indexes it)
         return {"pose": pose, "K": K, "H": H, "W": W, "pixel_coordinates": pts2d, "rays_o": o, "rays_d": d}
 
     def sample_rays(self, n_rays, H, W, K, pose, mask=None):

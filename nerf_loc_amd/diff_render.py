@@ -1,0 +1,224 @@
+"""Gradient path of the conditional-NeRF renderer.
+
+The HIP renderer (`renderer.HipRenderer`) is forward-only.  The one caller of the reference that differentiates through `render_rays`
+is `PoseOptimizer` (pose_optimizer.py:131-168): 512 rays x <= 50 Adam steps on an se(3) vector, loss = masked MSE of the rendered
+feature (or colour) against the query image's, gradient to the camera pose only — every network weight is frozen.  At that size the
+render is ~65 k samples, so the gradient path is written as fp32 PyTorch ops with autograd on the tensors' device (the GPU in
+production), NOT as hand-written backward kernels; the exact K-nearest-neighbour search, which is not differentiable (indices) and
+is the one step eager PyTorch cannot do at this size, stays the HIP kernel (`HipRenderer.knn`).  `ConditionalNeRF.render_rays`
+routes here only when autograd is enabled and an input requires grad; the inference path never touches this module.
+
+Every function cites the reference lines it follows (paths relative to /root/reference/nerf_loc/models/).  Parity: the gradients of
+both PoseOptimizer losses w.r.t. the pose and the rays are checked against the reference's own autograd (tests/golden/grad_*.npz,
+made by tools/gen_golden.py) in tests/test_diff_render.py.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+def rays_from_pose(uv: Tensor, K: Tensor, pose: Tensor):
+    """conditional_nerf/utils.py:56-70 + model.py:687-700 for the selected pixels only (integer-truncated pixel coordinates):
+    unit directions rotated by the camera-to-world pose, origin = its translation.  Differentiable w.r.t. `pose`."""
+    x, y = uv[:, 0].long().to(pose.dtype), uv[:, 1].long().to(pose.dtype)
+    cam = torch.stack([(x - K[0, 2]) / K[0, 0], (y - K[1, 2]) / K[1, 1], torch.ones_like(x)], -1)
+    d = (cam[:, None, :] * pose[:3, :3]).sum(-1)
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    return pose[:3, 3].expand(d.shape), d
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.01)
+
+
+def _lin(p, name, x, bias=True):
+    return F.linear(x, p[f"{name}.weight"], p[f"{name}.bias"] if bias else None)
+
+
+def _mlp3(p, pre, x):
+    return _lin(p, f"{pre}.4", F.elu(_lin(p, f"{pre}.2", F.elu(_lin(p, f"{pre}.0", x)))))
+
+
+def _posenc(x: Tensor, n_freqs: int = 10) -> Tensor:
+    """conditional_nerf/utils.py:5-35."""
+    out = [x]
+    for i in range(n_freqs):
+        out += [torch.sin(x * 2.0 ** i), torch.cos(x * 2.0 ** i)]
+    return torch.cat(out, -1)
+
+
+def _mv_aggregate(p, fr, xyz: Tensor):
+    """multiview_aggregator.py:156-222 (+ ibrnet.py:169-231, depth_fusion.py:60-147, visibility_decoder.py:64-148):
+    per-view bilinear taps, NeuRay visibility, visibility-weighted mean / variance, out_fc.
+    -> (G (N, W), rgb_feat (N, V, 3 + C), vis (N, V, 1), mask1 (N, V))"""
+    Ks, poses, images = fr["topk_Ks"], fr["topk_poses"], fr["topk_images"]
+    featmaps = fr["feat_fine_src"].permute(0, 3, 1, 2)
+    V, (H, W) = images.shape[0], images.shape[-2:]
+    dev, dt = xyz.device, xyz.dtype
+    w2c = torch.inverse(poses)
+    xyz_h = torch.cat([xyz, torch.ones_like(xyz[:, :1])], -1)
+    # Projector (ibrnet.py:169-231): K4 . w2c, pixel clamp +-1e6, in front, closed in-image interval; both maps are addressed with
+    # coordinates normalised by the full-resolution (W - 1, H - 1), zeros padding, align_corners = True
+    K4 = torch.eye(4, device=dev, dtype=dt).repeat(V, 1, 1)
+    K4[:, :3, :3] = Ks
+    proj = torch.einsum("vij,nj->vni", K4.bmm(w2c), xyz_h)
+    pix = torch.clamp(proj[..., :2] / torch.clamp(proj[..., 2:3], min=1e-8), min=-1e6, max=1e6)
+    grid = (2 * pix / torch.tensor([W - 1.0, H - 1.0], device=dev, dtype=dt) - 1.0).unsqueeze(2)
+    rgb = F.grid_sample(images, grid, align_corners=True).squeeze(-1).permute(2, 0, 1)
+    feat = F.grid_sample(featmaps, grid, align_corners=True).squeeze(-1).permute(2, 0, 1)
+    inb = (pix[..., 0] <= W - 1.0) & (pix[..., 0] >= 0) & (pix[..., 1] <= H - 1.0) & (pix[..., 1] >= 0)
+    mask1 = (inb & (proj[..., 2] > 0)).permute(1, 0)
+    rgb_feat = torch.cat([rgb, feat], -1)
+    # NeuRay-convention projection for the visibility features (depth_fusion.py:78-147): |z| < 1e-4 -> 1e-3 (invalid), half-open image test
+    cam = torch.einsum("vij,nj->vni", Ks.bmm(w2c[:, :3]), xyz_h)
+    depth = cam[..., 2:]
+    bad = depth.abs() < 1e-4
+    depth = torch.where(bad, torch.full_like(depth, 1e-3), depth)
+    pv = cam[..., :2] / depth
+    outside = (pv[..., 0] < -0.5) | (pv[..., 0] >= W - 0.5) | (pv[..., 1] < -0.5) | (pv[..., 1] >= H - 0.5)
+    valid = ((~bad[..., 0]) & (~outside)).to(dt).unsqueeze(-1)
+    vf = fr["vis_featmaps"]
+    g2 = torch.stack([pv[..., 0] / (W - 1) * 2 - 1, pv[..., 1] / (H - 1) * 2 - 1], -1).unsqueeze(1)
+    rf = F.grid_sample(vf, g2, mode="bilinear", padding_mode="border", align_corners=(vf.shape[-2] == H and vf.shape[-1] == W))
+    rf = rf.squeeze(2).permute(0, 2, 1) * valid
+    # mixture-of-logistics decoders (visibility_decoder.py:64-138)
+    pre = "multiview_aggregator.dist_decoder"
+    mean = F.softplus(_mlp3(p, f"{pre}.mean_decoder", rf))
+    var = F.softplus(_mlp3(p, f"{pre}.var_decoder", rf)) + 0.05
+    aw = torch.sigmoid(_mlp3(p, f"{pre}.aw_decoder", rf))
+    vis0 = torch.sigmoid(_mlp3(p, f"{pre}.vis_decoder", rf))
+    near, far = fr["near"], fr["far"]
+    ni, fi = -1.0 / near, -1.0 / far
+    ref_d = (-1.0 / (mean[..., 0] * (fi - ni) + ni)).clamp(near, far)
+    ddiff = (depth[..., 0] - ref_d).abs() / (far - near)
+    dn = (-1.0 / torch.clamp(depth, min=1e-5) - ni) / (fi - ni)
+    cdf = (0.5 + 0.5 * torch.tanh((dn - mean) * var)) * vis0
+    vis = (torch.sum((1 - cdf) * torch.cat([aw, 1 - aw], -1), -1, keepdim=True) * valid).permute(1, 0, 2)     # (N, V, 1)
+    ddiff = ddiff.unsqueeze(-1).permute(1, 0, 2)
+    wgt = vis / (torch.sum(vis, dim=1, keepdim=True) + 1e-8)
+
+    def mean_var(x):   # ibrnet.py:8-12
+        m = torch.sum(x * wgt, dim=1, keepdim=True)
+        return m, torch.sum(wgt * (x - m) ** 2, dim=1, keepdim=True)
+
+    m1, v1 = mean_var(rgb_feat)
+    m2, v2 = mean_var(ddiff)
+    g = torch.cat([torch.cat([m1, v1, m2, v2], -1).squeeze(1), wgt.mean(dim=1)], -1)
+    G = F.elu(_lin(p, "multiview_aggregator.out_fc.2", F.elu(_lin(p, "multiview_aggregator.out_fc.0", g))))
+    return G, rgb_feat, vis, mask1
+
+
+def _point_branch(p, fr, xyz: Tensor, dirs: Tensor, G: Tensor, idx: Tensor):
+    """conditional_nerf/model.py:344-436 + ibrnet.py:89-119: K = 8 neural points per sample (indices given), relative-position /
+    ray-difference encoding, 3-layer MLP, 4-head attention with the multi-view feature as query, distance x confidence x learnt weights."""
+    sp = fr["support"]
+    K = idx.shape[1]
+    if sp["xyz"].shape[0] < K:
+        raise NotImplementedError("gradient path: fewer support points than K (the reference zero-fills the missing neighbours)")
+    nb_xyz, nb_feat, nb_conf, nb_dir = sp["xyz"][idx], sp["feature"][idx], sp["confidence"][idx], sp["direction"][idx]
+    off = xyz[:, None, :] - nb_xyz
+    d2 = (off * off).sum(-1)     # = the KNN op's squared distances; its backward (knn_cpu.cpp:68-117) is 2 (p1 - p2) grad, as autograd gives here
+    rd = dirs[:, None, :] - nb_dir[..., :3]
+    rd = rd / (torch.norm(rd, dim=-1, keepdim=True) + 1e-8)
+    rd = torch.cat([rd, torch.sum(dirs[:, None, :] * nb_dir[..., :3], dim=-1, keepdim=True)], -1)
+    a = _lrelu(_lin(p, "ray_diff_fc.2", _lrelu(_lin(p, "ray_diff_fc.0", rd))))
+    x = torch.cat([nb_feat, _posenc(off / (fr["far"] - fr["near"])), a], -1)
+    for i in (0, 2, 4):
+        x = _lrelu(_lin(p, f"base_mlp.{i}", x))
+    pre, H4, dk = "base_mlp_attn", 4, 32
+    N = x.shape[0]
+    q = G.unsqueeze(1).expand(-1, K, -1)
+    qq = _lin(p, f"{pre}.w_qs", q, False).view(N, K, H4, dk).transpose(1, 2)
+    kk = _lin(p, f"{pre}.w_ks", x, False).view(N, K, H4, dk).transpose(1, 2)
+    vv = _lin(p, f"{pre}.w_vs", x, False).view(N, K, H4, dk).transpose(1, 2)
+    att = F.softmax(torch.matmul(qq / dk ** 0.5, kk.transpose(2, 3)), dim=-1)
+    o = torch.matmul(att, vv).transpose(1, 2).reshape(N, K, -1)
+    o = _lin(p, f"{pre}.fc", o, False) + q
+    feat = F.layer_norm(o, (o.shape[-1],), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], eps=1e-6)
+    lg = _lin(p, "base_mlp_agg_weight.2", _lrelu(_lin(p, "base_mlp_agg_weight.0", feat))).squeeze(-1)
+    w = 1.0 / torch.clamp(d2.sqrt(), min=1e-8) * F.softmax(lg, dim=1) * nb_conf.squeeze(-1)
+    w = w / torch.clamp(w.sum(dim=1, keepdim=True), min=1e-8)
+    return (feat * w.unsqueeze(-1)).sum(dim=1)
+
+
+def _ray_unet(p, x: Tensor) -> Tensor:
+    """conditional_nerf/ray_unet.py:5-69 — x (R, W, S) -> (R, W, S)."""
+    def block(name, t, transposed=False):
+        w, b = p[f"ray_unet.{name}.0.weight"], p[f"ray_unet.{name}.0.bias"]
+        t = F.conv_transpose1d(t, w, b, stride=2, padding=1, output_padding=1) if transposed else F.conv1d(t, w, b, stride=1, padding=1)
+        g, be = p[f"ray_unet.{name}.1.weight"], p[f"ray_unet.{name}.1.bias"]
+        return F.elu(F.layer_norm(t, tuple(g.shape), g, be, eps=1e-5))
+
+    c1 = F.max_pool1d(block("conv1", x), 2)
+    c2 = F.max_pool1d(block("conv2", c1), 2)
+    c3 = F.max_pool1d(block("conv3", c2), 2)
+    x0 = block("trans_conv3", c3, True)
+    x1 = block("trans_conv2", torch.cat([c2, x0], 1), True)
+    x2 = block("trans_conv1", torch.cat([c1, x1], 1), True)
+    return block("conv_out", torch.cat([x, x2], 1))
+
+
+def _view_angles(xyz: Tensor, query_center: Tensor, view_centers: Tensor) -> Tensor:
+    """ibrnet.py:144-167 — (N, V, 4): unit difference of the unit rays to the query / support cameras, and their dot product."""
+    tq = query_center.view(1, 1, 3) - xyz.unsqueeze(1)
+    tq = tq / (torch.norm(tq, dim=-1, keepdim=True) + 1e-6)
+    tv = view_centers.unsqueeze(0) - xyz.unsqueeze(1)
+    tv = tv / (torch.norm(tv, dim=-1, keepdim=True) + 1e-6)
+    diff = tq - tv
+    return torch.cat([diff / torch.clamp(torch.norm(diff, dim=-1, keepdim=True), min=1e-6), torch.sum(tq * tv, dim=-1, keepdim=True)], -1)
+
+
+def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, query_pose: Tensor,
+                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False) -> Dict[str, Tensor]:
+    """conditional_nerf/model.py:472-600 (eval mode) with autograd.  `z_vals` (R, S) are constants of the pose (the hierarchical
+    resampling detaches its weights, model.py:495); `knn_idx(xyz) -> (N, 8) int64` is the exact KNN (no gradient: indices).
+    fr: topk_Ks, topk_poses, topk_images, feat_fine_src, vis_featmaps, near, far (python floats), support {xyz, feature, confidence, direction}."""
+    R, S = z_vals.shape
+    xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
+    dirs = rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3)
+    G, mvf, mvv, mask1 = _mv_aggregate(p, fr, xyz)
+    with torch.no_grad():
+        idx = knn_idx(xyz.detach()).long()
+    agg = _point_branch(p, fr, xyz, dirs, G, idx)
+    W = agg.shape[1]
+    geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
+    sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)
+    V = mvf.shape[1]
+    ang = _view_angles(xyz, query_pose[:3, 3], fr["topk_poses"][:, :3, 3])
+    xb = torch.cat([agg.unsqueeze(1).expand(-1, V, -1), mvf, mvv, ang], -1)
+    for i in (0, 2):
+        xb = _lrelu(_lin(p, f"rgb_blending_mlp.{i}", xb))
+    bw = F.softmax(_lin(p, "rgb_blending_mlp.4", xb).masked_fill(mvv == 0, -1e9), dim=1)
+    rgb_s = torch.sum(mvf[:, :, :3] * bw, dim=1).view(R, S, 3)
+    # front-to-back compositing (model.py:544-553): last interval 1e2
+    deltas = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], 1e2 * torch.ones_like(z_vals[:, :1])], -1)
+    alphas = 1 - torch.exp(-deltas * sigma)
+    T = torch.cumprod(torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas], -1)[:, :-1], -1)
+    wts = alphas * T
+    rgb = (wts[..., None] * rgb_s).sum(1)
+    if white_bkgd:
+        rgb = rgb + (1 - wts.sum(1)[:, None])
+    depth = (wts * z_vals).sum(1)
+    ft = _lin(p, "feat_mlp.2", _lrelu(_lin(p, "feat_mlp.0", agg)))
+    feat = (wts[..., None] * ft.view(R, S, -1)).sum(1)
+    valid = (mask1.view(R, S, V).sum(2) > 1).float().sum(1) > 8
+    return {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid,
+            "depth_uncertainty": (wts * (z_vals - depth[:, None]) ** 2).sum(1)}
+
+
+def knn_bruteforce(points: Tensor, K: int = 8, chunk: int = 4096) -> Callable[[Tensor], Tensor]:
+    """Exact KNN by chunked distance matrices — the CPU / no-extension stand-in for `HipRenderer.knn` (small problems, tests).
+    Ties: lower index first (knn_cpu.cpp:39-52 sorts (dist, idx) pairs)."""
+    def f(q: Tensor) -> Tensor:
+        out = []
+        for i in range(0, q.shape[0], chunk):
+            d = ((q[i:i + chunk, None, :] - points[None]) ** 2).sum(-1)
+            key = torch.argsort(d, dim=1, stable=True)[:, :K]
+            out.append(key)
+        return torch.cat(out, 0)
+    return f

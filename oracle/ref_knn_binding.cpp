@@ -19,3 +19,22 @@ extern "C" int ref_knn_cpu(const float* q, int64_t n, const float* p, int64_t m,
   std::memcpy(out_d2, d.data_ptr<float>(), sizeof(float) * n * K);
   return 0;
 }
+
+// KNearestNeighborBackwardCpu (knn_cpu.cpp:68-117): gradients of the squared distances w.r.t. both point sets
+std::tuple<at::Tensor, at::Tensor> KNearestNeighborBackwardCpu(const at::Tensor& p1, const at::Tensor& p2, const at::Tensor& lengths1,
+                                                               const at::Tensor& lengths2, const at::Tensor& idxs, const at::Tensor& grad_dists);
+
+extern "C" int ref_knn_backward_cpu(const float* q, int64_t n, const float* p, int64_t m, int K, const int64_t* idx, const float* grad_d2,
+                                    float* grad_q, float* grad_p) {
+  auto fopt = torch::TensorOptions().dtype(torch::kFloat32);
+  at::Tensor p1 = torch::from_blob(const_cast<float*>(q), {1, n, 3}, fopt);
+  at::Tensor p2 = torch::from_blob(const_cast<float*>(p), {1, m, 3}, fopt);
+  at::Tensor ix = torch::from_blob(const_cast<int64_t*>(idx), {1, n, K}, torch::TensorOptions().dtype(torch::kInt64));
+  at::Tensor gd = torch::from_blob(const_cast<float*>(grad_d2), {1, n, K}, fopt);
+  at::Tensor l1 = torch::full({1}, n, torch::kInt64), l2 = torch::full({1}, m, torch::kInt64);
+  auto r = KNearestNeighborBackwardCpu(p1, p2, l1, l2, ix, gd);
+  at::Tensor g1 = std::get<0>(r).contiguous(), g2 = std::get<1>(r).contiguous();
+  std::memcpy(grad_q, g1.data_ptr<float>(), sizeof(float) * n * 3);
+  std::memcpy(grad_p, g2.data_ptr<float>(), sizeof(float) * m * 3);
+  return 0;
+}

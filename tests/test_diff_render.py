@@ -1,0 +1,119 @@
+"""Gradient path (nerf_loc_amd.diff_render) against the REFERENCE's own autograd: tests/golden/grad_*.npz hold the two
+PoseOptimizer losses (pose_optimizer.py:146-153) and their gradients w.r.t. the camera pose and the rays, made by tools/gen_golden.py
+(reference imported in the build container, its KNN backward = the reference's knn_cpu.cpp compiled in place)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_loc_amd import diff_render as dr
+from tests.golden_cases import build_case
+from tests.util import rel_err
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+GRAD_CASES = {"grad_tiny": ("tiny_full", 16), "grad_c1": ("c1", 40)}   # = tools/gen_golden.py GRAD_CASES
+
+
+def _targets(n, C, seed):   # = tools/gen_golden.py grad_targets
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, C)).astype(np.float32), rng.random((n, 3)).astype(np.float32)
+
+
+def _setup(gname, device):
+    name, n = GRAD_CASES[gname]
+    case = build_case(name)
+    cfg, frame, rays = case["cfg"], case["frame"], case["rays"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    p = {k: t(v) for k, v in case["weights"].items()}
+    fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
+    fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}})
+    tf, trgb = _targets(n, cfg.C, cfg.seed + 1000)
+    return cfg, fr, p, t(frame["pose"]), t(rays["K"]), t(rays["pixel_coordinates"])[:n], t(tf), t(trgb), n
+
+
+def _as(x, dt):
+    if isinstance(x, dict):
+        return {k: _as(v, dt) for k, v in x.items()}
+    return x.to(dt) if torch.is_tensor(x) and x.is_floating_point() else x
+
+
+def _losses_and_grads(cfg, fr, p, pose0, K, uv, tf, trgb, knn, dt=torch.float32):
+    fr, p, K, uv, tf, trgb = _as(fr, dt), _as(p, dt), K.to(dt), uv.to(dt), tf.to(dt), trgb.to(dt)
+    pose = pose0.to(dt).clone().requires_grad_(True)
+    o, d = dr.rays_from_pose(uv, K, pose)
+    o, d = o + 0, d + 0
+    z = (cfg.near * (1 - torch.linspace(0, 1, cfg.S)) + cfg.far * torch.linspace(0, 1, cfg.S)).to(pose0.device).to(dt).expand(len(uv), cfg.S).contiguous()
+    out = dr.render_rays_diff(p, fr, o, d, z, pose, knn)
+    m = out["mask"].unsqueeze(1)
+    lf = torch.mean(((out["feat"] - tf) * m) ** 2)
+    lr = torch.mean(((out["rgb"] - trgb) * m) ** 2)
+    gf = torch.autograd.grad(lf, [pose, o, d], retain_graph=True)
+    gr = torch.autograd.grad(lr, [pose, o, d])
+    return out, lf, lr, gf, gr
+
+
+def _check(gname, out, lf, lr, gf, gr, tol):
+    g = np.load(os.path.join(GOLD, f"{gname}.npz"))
+    assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
+    errs = {"feat": rel_err(out["feat"].detach().cpu().numpy(), g["feat"]), "rgb": rel_err(out["rgb"].detach().cpu().numpy(), g["rgb"]),
+            "loss_feat": abs(float(lf.detach()) - float(g["loss_feat"])) / float(g["loss_feat"]),
+            "loss_rgb": abs(float(lr.detach()) - float(g["loss_rgb"])) / float(g["loss_rgb"])}
+    for tag, gs in (("gfeat", gf), ("grgb", gr)):
+        for nm, v in zip(("pose", "rays_o", "rays_d"), gs):
+            errs[f"{tag}_{nm}"] = rel_err(v.cpu().numpy(), g[f"{tag}_{nm}"])
+    assert all(e < tol for e in errs.values()), (gname, errs)
+    return errs
+
+
+@pytest.mark.parametrize("gname", list(GRAD_CASES))
+def test_pose_gradients_match_reference_autograd_cpu(gname):
+    cfg, fr, p, pose, K, uv, tf, trgb, n = _setup(gname, "cpu")
+    out, lf, lr, gf, gr = _losses_and_grads(cfg, fr, p, pose, K, uv, tf, trgb, dr.knn_bruteforce(fr["support"]["xyz"]))
+    errs = _check(gname, out, lf, lr, gf, gr, 2e-4)
+    print(gname, errs)
+
+
+def test_rays_from_pose_matches_the_ray_grid():
+    from oracle.render_oracle import points_2d_to_rays
+    case = build_case("tiny_full")
+    cfg, frame, rays = case["cfg"], case["frame"], case["rays"]
+    uv, K, pose = torch.from_numpy(rays["pixel_coordinates"]), torch.from_numpy(rays["K"]), torch.from_numpy(frame["pose"])
+    o, d = dr.rays_from_pose(uv, K, pose)
+    ref = points_2d_to_rays(uv, cfg.H, cfg.Wimg, K, pose)
+    assert torch.allclose(o, ref["rays_o"]) and torch.allclose(d, ref["rays_d"], atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gname", list(GRAD_CASES))
+def test_pose_gradients_match_reference_autograd_gpu(gname):
+    """Same check on the GPU with the HIP KNN, plus the gradient path's forward against the HIP renderer's."""
+    from nerf_loc_amd.renderer import HipRenderer
+    name, n = GRAD_CASES[gname]
+    case = build_case(name)
+    cfg, frame = case["cfg"], case["frame"]
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "fp32")
+    r.load_weights({k: torch.from_numpy(v) for k, v in case["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far,
+                frame["support_fine"])
+    cfg, fr, p, pose, K, uv, tf, trgb, n = _setup(gname, "cuda:0")
+    knn = lambda q: r.knn(q, 8)[1]
+    out, lf, lr, gf, gr = _losses_and_grads(cfg, fr, p, pose, K, uv, tf, trgb, knn)
+    # The reference's fp32 gradient itself carries ~1e-3 of rounding error (positional encoding up to 2^9 x, LayerNorms): the same graph
+    # evaluated in fp64 differs from the golden by 1.1e-3 (grad_tiny, rays_d) / 5e-4 (grad_c1), while the CPU test above — the
+    # reference's own arithmetic — agrees to 1e-6.  Other fp32 arithmetic (the GPU's) can only be held to that conditioning: 3e-3 here,
+    # and it must be at least as close to the fp64 gradient as the reference's is (factor 2 of slack).
+    errs = _check(gname, out, lf, lr, gf, gr, 3e-3)
+    _, _, _, gf64, gr64 = _losses_and_grads(cfg, fr, p, pose, K, uv, tf, trgb, knn, torch.float64)
+    g = np.load(os.path.join(GOLD, f"{gname}.npz"))
+    for tag, ours, ref64 in (("gfeat", gf, gf64), ("grgb", gr, gr64)):
+        for nm, v, v64 in zip(("pose", "rays_o", "rays_d"), ours, ref64):
+            e_ours = rel_err(v.cpu().numpy(), v64.cpu().numpy())
+            e_ref = rel_err(g[f"{tag}_{nm}"], v64.cpu().numpy())
+            assert e_ours < max(2 * e_ref, 1e-5), (tag, nm, e_ours, e_ref)
+    with torch.no_grad():
+        o, d = dr.rays_from_pose(uv, K, pose)
+        hip = r.render_rays(o, d, pose[:3, 3])
+    e = {k: rel_err(out[k].detach().cpu().numpy(), hip[k].cpu().numpy()) for k in ("rgb", "feat", "depth", "weights")}
+    print(gname, errs, e)
+    assert max(e.values()) < 1e-4, e

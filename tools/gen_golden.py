@@ -61,8 +61,22 @@ def install_shims():
         lib.ref_knn_cpu(q.ctypes.data, n, p.ctypes.data, m, K, d2.ctypes.data, idx.ctypes.data)
         return torch.from_numpy(idx), torch.from_numpy(d2)
 
+    lib.ref_knn_backward_cpu.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+
+    def knn_points_backward(p1, p2, l1, l2, idx, grad_dists):   # the reference's KNearestNeighborBackwardCpu (knn_cpu.cpp:68-117)
+        q = np.ascontiguousarray(p1[0].detach().numpy(), np.float32)
+        p = np.ascontiguousarray(p2[0].detach().numpy(), np.float32)
+        ix = np.ascontiguousarray(idx[0].numpy(), np.int64)
+        gd = np.ascontiguousarray(grad_dists[0].numpy(), np.float32)
+        gq, gp = np.zeros_like(q), np.zeros_like(p)
+        lib.ref_knn_backward_cpu(q.ctypes.data, q.shape[0], p.ctypes.data, p.shape[0], ix.shape[1], ix.ctypes.data, gd.ctypes.data,
+                                 gq.ctypes.data, gp.ctypes.data)
+        return torch.from_numpy(gq)[None], torch.from_numpy(gp)[None]
+
     native = types.ModuleType("nerf_loc.models.ops.knn.knn")
     native.knn_points_idx = knn_points_idx
+    native.knn_points_backward = knn_points_backward
     sys.modules["nerf_loc.models.ops.knn.knn"] = native
     ku = importlib.import_module("nerf_loc.models.ops.knn.knn_utils")
     p3, p3o = types.ModuleType("pytorch3d"), types.ModuleType("pytorch3d.ops")
@@ -181,6 +195,51 @@ def run_case(model_mod, ku, name):
           f"wsum[min,max]=({save['weights'].sum(1).min():.3f},{save['weights'].sum(1).max():.3f})")
 
 
+# Gradient cases (pose_optimizer.py:131-160): the reference's own autograd through render_rays, rays built from the
+# camera pose by points_2d_to_rays, for the two photometric losses PoseOptimizer minimises.  name -> (render case, rays used)
+GRAD_CASES = {"grad_tiny": ("tiny_full", 16), "grad_c1": ("c1", 40)}
+
+
+def grad_targets(n, C, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, C)).astype(np.float32), rng.random((n, 3)).astype(np.float32)
+
+
+def run_grad_case(model_mod, ku, gname):
+    name, n = GRAD_CASES[gname]
+    case = build_case(name)
+    cfg, frame, rays, weights = case["cfg"], case["frame"], case["rays"], case["weights"]
+    net = model_mod.ConditionalNeRF(ref_args(cfg)).eval()
+    net.load_state_dict({k: t(v) for k, v in weights.items()}, strict=False)
+    for q in net.parameters():
+        q.requires_grad_(False)
+    pose = t(frame["pose"]).clone().requires_grad_(True)
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "depth_range", "K")}
+    data.update({"pose": pose, "embedding_a": None, "H": frame["H"], "W": frame["W"], "white_bkgd": bool(frame["white_bkgd"])})
+    net.support_neural_points = {"fine": {k: t(v) for k, v in frame["support_fine"].items()}}
+    net.multiview_aggregator.vis_featmaps = t(frame["vis_featmaps"])
+    uv = t(rays["pixel_coordinates"])[:n]
+    tf, trgb = grad_targets(n, cfg.C, cfg.seed + 1000)
+    with torch.enable_grad():
+        rd = net.points_2d_to_rays(uv, cfg.H, cfg.Wimg, t(rays["K"]), pose)
+        rd["depth_range"] = t(rays["depth_range"])
+        ro, rdir = rd["rays_o"], rd["rays_d"]
+        out = net.render_rays(data, rd)
+        m = out["mask"].unsqueeze(1)
+        loss_f = torch.mean(((out["feat"] - t(tf)) * m) ** 2)      # pose_optimizer.py:146-149 (use_feat)
+        loss_r = torch.mean(((out["rgb"] - t(trgb)) * m) ** 2)     # pose_optimizer.py:150-153
+        gf = torch.autograd.grad(loss_f, [pose, ro, rdir], retain_graph=True)
+        gr = torch.autograd.grad(loss_r, [pose, ro, rdir])
+    save = {"loss_feat": loss_f.detach().numpy(), "loss_rgb": loss_r.detach().numpy(), "mask": out["mask"].numpy(),
+            "feat": out["feat"].detach().numpy(), "rgb": out["rgb"].detach().numpy(),
+            "gfeat_pose": gf[0].numpy(), "gfeat_rays_o": gf[1].numpy(), "gfeat_rays_d": gf[2].numpy(),
+            "grgb_pose": gr[0].numpy(), "grgb_rays_o": gr[1].numpy(), "grgb_rays_d": gr[2].numpy()}
+    path = os.path.join(ROOT, "tests", "golden", f"{gname}.npz")
+    np.savez_compressed(path, **save)
+    print(f"{gname}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) rays={n} mask_true={int(save['mask'].sum())} loss_feat={float(loss_f.detach()):.6f} "
+          f"loss_rgb={float(loss_r.detach()):.6f} |dLf/dpose|={float(gf[0].abs().max()):.4e} |dLr/dpose|={float(gr[0].abs().max()):.4e}")
+
+
 def punch_holes(frame, seed):
     """Ragged support depth for the `setup_holes` case: ~35 % of the pixels invalid (0), a few negative, one view with no valid
     depth at all — nonzero()'s order and the empty-view path of backproject_support_frame (model.py:231)."""
@@ -269,12 +328,18 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "setup":
         run_setup_case(model_mod, "setup")
         return run_setup_case(model_mod, "setup_holes")
+    if len(sys.argv) > 1 and sys.argv[1] == "grad":
+        for g in GRAD_CASES:
+            run_grad_case(model_mod, ku, g)
+        return
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
     if not sys.argv[1:]:
         run_setup_case(model_mod, "setup")
         run_setup_case(model_mod, "setup_holes")
+        for g in GRAD_CASES:
+            run_grad_case(model_mod, ku, g)
 
 
 if __name__ == "__main__":
