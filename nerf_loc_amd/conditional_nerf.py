@@ -25,6 +25,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .depth_fusion import DepthFusionNet
 from .frame_setup import backproject_support
@@ -388,20 +389,42 @@ class ConditionalNeRF(nn.Module):
 
     def render_rays(self, data, rays, u: Optional[torch.Tensor] = None):
         """model.py:472-600, eval mode.  `u` optionally fixes sample_pdf's uniform draws (reference: torch.rand)."""
-        if self.training:
-            raise NotImplementedError("training through the renderer (beta / render loss w.r.t. the weights) is a next-row item (SURVEY.md §8f-2)")
+        if self.training:   # model.py:587-592: the training render carries `beta` and its graph reaches the weights
+            return self._render_rays_grad(data, rays, u, train=True)
         if self._wants_grad(rays.get("rays_o"), rays.get("rays_d"), rays.get("pose"), data.get("pose")):
             return self._render_rays_grad(data, rays, u)
         with torch.no_grad():
             return self._render_rays(data, rays, u)
 
-    def _render_rays_grad(self, data, rays, u):
-        """pose_optimizer.py:131-160 calls render_rays in eval mode under torch.enable_grad() and back-propagates a photometric loss to
-        the camera pose.  This is that case: the differentiable eager path of nerf_loc_amd/diff_render.py (fp32 autograd on the GPU)
-        with the exact KNN and the hierarchical depths from the HIP library; gradients flow to rays_o / rays_d / data['pose'], the
-        network weights are constants (PoseOptimizer optimises the pose only).  Checked against the reference's autograd in
-        tests/test_diff_render.py."""
-        r = self._ensure_frame(data, "fine")
+    def _render_rays_grad(self, data, rays, u, train=False):
+        """The two callers that differentiate through render_rays, on the eager path of nerf_loc_amd/diff_render.py (fp32 autograd on the
+        GPU) with the exact KNN and the hierarchical depths from the HIP library:
+        * pose_optimizer.py:131-160 (eval mode under torch.enable_grad()): gradients to rays_o / rays_d / data['pose']; the network
+          weights are constants (PoseOptimizer optimises the pose only);
+        * compute_render_loss (train mode): the parameters keep their graph, the per-frame caches are rebuilt WITH their graphs like
+          the reference's (fine support table: features gathered from the feature maps, confidence_mlp on the aggregate;
+          DepthFusionNet maps), `beta` is returned.
+        Both are checked against the reference's autograd in tests/test_diff_render.py."""
+        fnear, ffar = [float(x) for x in data["depth_range"][0]]
+        if train:
+            if self.args.use_depth_supervision and self.args.render.N_importance > 0:
+                raise NotImplementedError("depth_coarse carries no graph on this path: depth supervision of the hierarchical branch is not available")
+            p = {**dict(self.named_buffers()), **dict(self.named_parameters())}
+            if self.support_neural_points is None:
+                self.build_support_neural_points(data)   # both levels on the HIP library (no graph): the coarse level for the other callers
+            agg = self.multiview_aggregator
+            if agg.vis_featmaps is None or not agg.vis_featmaps.requires_grad:
+                agg.vis_featmaps = agg.depth_fusion(data["topk_images"], data["feat_fine_src"].permute(0, 3, 1, 2), data["topk_depths"],
+                                                    data["topk_Ks"], data["topk_poses"], data["depth_range"][0])
+            fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"],
+                  "feat_fine_src": data["feat_fine_src"], "vis_featmaps": agg.vis_featmaps, "near": fnear, "far": ffar}
+            fr["support"] = diff_render.support_tables_diff(p, fr, data["topk_depths"], int(data["stride_fine"]))
+            r = self._renderer("fine")   # the KNN grid over exactly these points
+            r.set_frame(data["topk_images"], data["feat_fine_src"].detach(), agg.vis_featmaps.detach(), data["topk_Ks"], data["topk_poses"], fnear, ffar,
+                        {k: v.detach() for k, v in fr["support"].items()})
+            self._frame_token.pop("fine", None)
+        else:
+            r = self._ensure_frame(data, "fine")
         near, far = rays["depth_range"]
         o, d = rays["rays_o"], rays["rays_d"]
         R, N = o.shape[0], self.args.render.N_samples
@@ -413,14 +436,15 @@ class ConditionalNeRF(nn.Module):
                     u = torch.rand(R, self.args.render.N_importance, device=o.device)
                 z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"].detach(), z, u,
                                                            near=float(near), far=float(far))
-        fnear, ffar = [float(x) for x in data["depth_range"][0]]
-        sp = self.support_neural_points["fine"]
-        fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"], "feat_fine_src": data["feat_fine_src"],
-              "vis_featmaps": self._vis_featmaps(data), "near": fnear, "far": ffar,
-              "support": {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")}}
-        p = {k: v.detach() for k, v in self.state_dict().items()}
+        if not train:
+            sp = self.support_neural_points["fine"]
+            fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"], "feat_fine_src": data["feat_fine_src"],
+                  "vis_featmaps": self._vis_featmaps(data), "near": fnear, "far": ffar,
+                  "support": {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")}}
+            p = {k: v.detach() for k, v in self.state_dict().items()}
         out = diff_render.render_rays_diff(p, fr, o, d, z.to(o.dtype), data["pose"], lambda q: r.knn(q, 8)[1],
-                                           white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)))
+                                           white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                                           beta=train and bool(self.args.render.use_render_uncertainty))
         if not self.args.render.render_feature:
             out.pop("feat")
         if depth_coarse is not None:
@@ -469,7 +493,26 @@ class ConditionalNeRF(nn.Module):
         return out
 
     def compute_render_loss(self, data):
-        raise NotImplementedError("compute_render_loss needs the renderer's backward pass (SURVEY.md §8f-2, next row)")
+        """model.py:641-685 (+ losses.py:23-93): one training step's render loss and PSNR on the gradient path (`_render_rays_grad`)."""
+        if "sample_coords" in data:
+            rays = self.points_2d_to_rays(data["sample_coords"], data["H"], data["W"], data["K"], data["pose"])
+        else:
+            rays = self.sample_rays(self.args.render.N_rand, data["H"], data["W"], data["K"], data["pose"], data.get("target_mask", None))
+        uv = rays["pixel_coordinates"].long()
+        targets = {"rgb": data["img"].permute(1, 2, 0)[uv[:, 1], uv[:, 0]]}
+        rays["depth_range"] = data["depth_range"][0]
+        preds = self.render_rays(data, rays)
+        mask = preds["mask"]
+        if self.args.use_depth_supervision:
+            targets.update({"depth_range": data["depth_range"][0], "depth": data["depth"][uv[:, 1], uv[:, 0]]})
+        if self.args.render.render_feature:
+            fmap = F.interpolate(data["feat_pyramid"]["layer1"], size=(data["H"], data["W"]), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+            targets["feat"] = fmap[0, uv[:, 1], uv[:, 0]]
+        if "target_mask" in data:
+            mask = mask & data["target_mask"][uv[:, 1], uv[:, 0]]
+            targets["mask"] = mask
+        loss = diff_render.rendering_loss(preds, targets, use_depth=bool(self.args.use_depth_supervision))
+        return loss, diff_render.masked_psnr(preds["rgb"], targets["rgb"], mask)
 
     def points_2d_to_rays(self, pts2d, H, W, K, pose):
         """model.py:687-700."""

@@ -174,9 +174,11 @@ def _view_angles(xyz: Tensor, query_center: Tensor, view_centers: Tensor) -> Ten
 
 
 def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, query_pose: Tensor,
-                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False) -> Dict[str, Tensor]:
-    """conditional_nerf/model.py:472-600 (eval mode) with autograd.  `z_vals` (R, S) are constants of the pose (the hierarchical
-    resampling detaches its weights, model.py:495); `knn_idx(xyz) -> (N, 8) int64` is the exact KNN (no gradient: indices).
+                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False, beta: bool = False) -> Dict[str, Tensor]:
+    """conditional_nerf/model.py:472-600 with autograd.  `z_vals` (R, S) are constants (the hierarchical resampling detaches its
+    weights, model.py:495); `knn_idx(xyz) -> (N, 8) int64` is the exact KNN (no gradient: indices); beta: the training-mode
+    uncertainty output (model.py:587-592).  Gradients reach whatever requires grad among rays_o / rays_d / query_pose, the
+    parameters `p` and the frame tensors.
     fr: topk_Ks, topk_poses, topk_images, feat_fine_src, vis_featmaps, near, far (python floats), support {xyz, feature, confidence, direction}."""
     R, S = z_vals.shape
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
@@ -207,18 +209,78 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     ft = _lin(p, "feat_mlp.2", _lrelu(_lin(p, "feat_mlp.0", agg)))
     feat = (wts[..., None] * ft.view(R, S, -1)).sum(1)
     valid = (mask1.view(R, S, V).sum(2) > 1).float().sum(1) > 8
-    return {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid,
-            "depth_uncertainty": (wts * (z_vals - depth[:, None]) ** 2).sum(1)}
+    out = {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid,
+           "depth_uncertainty": (wts * (z_vals - depth[:, None]) ** 2).sum(1)}
+    if beta:
+        out["beta"] = (wts * F.softplus(_lin(p, "beta_mlp.0", geo)).view(R, S)).sum(1) + 0.1   # beta_min, model.py:98
+    return out
 
 
-def knn_bruteforce(points: Tensor, K: int = 8, chunk: int = 4096) -> Callable[[Tensor], Tensor]:
-    """Exact KNN by chunked distance matrices — the CPU / no-extension stand-in for `HipRenderer.knn` (small problems, tests).
-    Ties: lower index first (knn_cpu.cpp:39-52 sorts (dist, idx) pairs)."""
-    def f(q: Tensor) -> Tensor:
-        out = []
-        for i in range(0, q.shape[0], chunk):
-            d = ((q[i:i + chunk, None, :] - points[None]) ** 2).sum(-1)
-            key = torch.argsort(d, dim=1, stable=True)[:, :K]
-            out.append(key)
-        return torch.cat(out, 0)
-    return f
+# ----------------------------------------------------------------------------- training step (model.py:641-685)
+def backproject_support_diff(imgs: Tensor, feats: Tensor, depths: Tensor, Ks: Tensor, c2ws: Tensor, stride: int):
+    """conditional_nerf/model.py:203-265 in autograd ops: every valid-depth pixel of every (nearest-resized) support view becomes a
+    neural point.  -> (rgb + feature (M, 3 + C), xyz world, xyz in view 0's camera, unit direction + depth), rows in the reference's
+    order (view, then nonzero()'s row-major pixels).  The gradient reaches `feats` (the 2D backbone's maps)."""
+    desc, world, ref, dirs = [], [], [], []
+    w2c0 = torch.inverse(c2ws[0])
+    for img, feat, depth, K, c2w in zip(imgs, feats, depths, Ks, c2ws):
+        H, W = int(img.shape[-2] / stride), int(img.shape[-1] / stride)
+        K = K.clone()
+        K[:2] = K[:2] / stride
+        depth = F.interpolate(depth[None, None], size=(H, W)).squeeze()
+        img = F.interpolate(img[None], size=(H, W)).squeeze().permute(1, 2, 0)
+        v, u = torch.nonzero(depth > 0, as_tuple=True)
+        z = depth[v, u]
+        cam = torch.matmul(torch.inverse(K), torch.stack([u, v, torch.ones_like(u)], 0).to(z.dtype)) * z
+        world.append((torch.matmul(c2w[:3, :3], cam) + c2w[:3, 3:]).t())
+        ref.append(torch.matmul(torch.matmul(w2c0, c2w), torch.cat([cam, torch.ones_like(cam[:1])]))[:3].t())
+        ray = torch.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(z)], -1)   # utils.py:56-70 at (u, v)
+        ray = (ray[:, None, :] * c2w[:3, :3]).sum(-1)
+        dirs.append(torch.cat([ray / torch.norm(ray, dim=-1, keepdim=True), z.view(-1, 1)], 1))
+        desc.append(torch.cat([img[v, u], feat[v, u]], 1))
+    return torch.cat(desc), torch.cat(world), torch.cat(ref), torch.cat(dirs)
+
+
+def support_tables_diff(p: Dict[str, Tensor], fr: Dict, depths: Tensor, stride: int) -> Dict[str, Tensor]:
+    """The fine-level support table with its graph (model.py:144-201, 137-142): features gathered from the feature maps, confidence =
+    confidence_mlp(multi-view aggregate at the points).  fr as for render_rays_diff, without 'support'."""
+    desc, xyz, _, dirs = backproject_support_diff(fr["topk_images"], fr["feat_fine_src"], depths, fr["topk_Ks"], fr["topk_poses"], stride)
+    G = _mv_aggregate(p, fr, xyz)[0]
+    conf = torch.sigmoid(_lin(p, "confidence_mlp.2", _lrelu(_lin(p, "confidence_mlp.0", G))))
+    return {"xyz": xyz, "feature": desc, "confidence": conf, "direction": dirs}
+
+
+def to_inverse_normalized_depth(depth: Tensor, near, far) -> Tensor:
+    """conditional_nerf/losses.py:15-21."""
+    ni, fi = -1 / near, -1 / far
+    return torch.clamp((-1 / torch.clamp(depth, min=1e-5) - ni) / (fi - ni), min=0, max=1.0)
+
+
+def rendering_loss(pred: Dict[str, Tensor], tgt: Dict, use_depth: bool = False, coef: float = 1.0) -> Tensor:
+    """conditional_nerf/losses.py:23-93 (RenderingLoss, NeRF-W eq. 13): beta-weighted colour loss + log-beta, optional inverse-depth
+    terms, 0.1 x feature MSE — over the rays of the mask."""
+    mask = tgt["mask"].bool() if "mask" in tgt else torch.ones_like(tgt["rgb"][:, 0]).bool()
+    rgb, depth, rgb_t = pred["rgb"][mask], pred["depth"][mask], tgt["rgb"][mask]
+    if "beta" in pred:
+        b = pred["beta"][mask]
+        loss = coef * (((rgb - rgb_t) ** 2 / (2 * b.unsqueeze(1) ** 2)).mean() + 3 + torch.log(b).mean())
+    else:
+        loss = coef * ((rgb - rgb_t) ** 2).mean()
+    if use_depth and "depth" in tgt:
+        td = tgt["depth"][mask]
+        dm = td > 0
+        near, far = tgt["depth_range"]
+        tdn = to_inverse_normalized_depth(td, near, far)
+        loss = loss + coef * (((to_inverse_normalized_depth(depth, near, far) - tdn) ** 2 * dm).sum() / (1e-8 + dm.sum()))
+        if "depth_coarse" in pred:
+            dc = to_inverse_normalized_depth(pred["depth_coarse"][mask], near, far)
+            loss = loss + coef * (((dc - tdn) ** 2 * dm).sum() / (1e-8 + dm.sum()))
+    if "feat" in pred and "feat" in tgt:
+        loss = loss + coef * 0.1 * ((pred["feat"][mask] - tgt["feat"][mask]) ** 2).mean()
+    return loss
+
+
+def masked_psnr(x: Tensor, y: Tensor, mask: Tensor) -> Tensor:
+    """conditional_nerf/utils.py:115-128 (img2mse with mask, mse2psnr)."""
+    mse = torch.sum((x - y) * (x - y) * mask.unsqueeze(-1)) / (torch.sum(mask) * x.shape[-1] + 1e-8)
+    return -10.0 * torch.log(mse) / torch.log(torch.tensor([10.0], device=x.device))

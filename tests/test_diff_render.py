@@ -9,7 +9,7 @@ import torch
 
 from nerf_loc_amd import diff_render as dr
 from tests.golden_cases import build_case
-from tests.util import rel_err
+from tests.util import knn_bruteforce, rel_err
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 GRAD_CASES = {"grad_tiny": ("tiny_full", 16), "grad_c1": ("c1", 40)}   # = tools/gen_golden.py GRAD_CASES
@@ -69,7 +69,7 @@ def _check(gname, out, lf, lr, gf, gr, tol):
 @pytest.mark.parametrize("gname", list(GRAD_CASES))
 def test_pose_gradients_match_reference_autograd_cpu(gname):
     cfg, fr, p, pose, K, uv, tf, trgb, n = _setup(gname, "cpu")
-    out, lf, lr, gf, gr = _losses_and_grads(cfg, fr, p, pose, K, uv, tf, trgb, dr.knn_bruteforce(fr["support"]["xyz"]))
+    out, lf, lr, gf, gr = _losses_and_grads(cfg, fr, p, pose, K, uv, tf, trgb, knn_bruteforce(fr["support"]["xyz"]))
     errs = _check(gname, out, lf, lr, gf, gr, 2e-4)
     print(gname, errs)
 
@@ -117,3 +117,105 @@ def test_pose_gradients_match_reference_autograd_gpu(gname):
     e = {k: rel_err(out[k].detach().cpu().numpy(), hip[k].cpu().numpy()) for k in ("rgb", "feat", "depth", "weights")}
     print(gname, errs, e)
     assert max(e.values()) < 1e-4, e
+
+
+# ----------------------------------------------------------------------------- one training step (compute_render_loss)
+def _train_case(device):
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case("setup")
+    cfg, frame, rays = case["cfg"], case["frame"], case["rays"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
+    data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
+    rng = np.random.default_rng(cfg.seed + 2000)   # = tools/gen_golden.py train_targets
+    img = rng.random((3, cfg.H, cfg.Wimg)).astype(np.float32)
+    pyr = rng.standard_normal((1, cfg.C, cfg.H // 2, cfg.Wimg // 2)).astype(np.float32)
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8,
+                 "sample_coords": t(rays["pixel_coordinates"]), "img": t(img), "feat_pyramid": {"layer1": t(pyr)}})
+    return case, cfg, data, rays
+
+
+def _check_train(loss, psnr, named, gfeat, tol):
+    g = np.load(os.path.join(GOLD, "train_setup.npz"))
+    assert abs(float(loss.detach()) - float(g["loss"])) < tol * abs(float(g["loss"])), (float(loss.detach()), float(g["loss"]))
+    assert abs(float(psnr.detach()) - float(g["psnr"])) < tol * abs(float(g["psnr"]))
+    errs = {"feat_fine_src": rel_err(gfeat.cpu().numpy(), g["grad_feat_fine_src"])}
+    # Tensors whose gradient is mathematically zero (conv biases in front of a BatchNorm, the bias of the softmax logits, ...) hold
+    # rounding noise ~1e-10 in the reference: errors are measured against max(|tensor|, 1e-5 x the step's largest gradient)
+    gmax = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith(("grad:", "gsub:")))
+    n = 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            ours = named[key[5:]].grad.cpu().numpy()
+            errs[key[5:]] = float(np.abs(ours - g[key]).max() / max(np.abs(g[key]).max(), 1e-5 * gmax))
+            n += 1
+        elif key.startswith("gsub:"):
+            full = named[key[5:]].grad.cpu().numpy()
+            errs[key[5:]] = float(np.abs(full.reshape(-1)[::7] - g[key]).max() / max(np.abs(g[key]).max(), 1e-5 * gmax))
+            gn = float(g["gnorm:" + key[5:]])
+            assert abs(np.linalg.norm(full.astype(np.float64)) - gn) < 10 * tol * max(gn, 1e-5 * gmax)
+            n += 1
+    assert n > 150, n   # the step reaches 166 parameter tensors in the reference
+    reached = {k for k, v in named.items() if v.grad is not None and float(v.grad.abs().max()) > 1e-5 * gmax}
+    assert reached == {k.split(":", 1)[1] for k in g.files if k.startswith(("grad:", "gsub:")) and float(np.abs(g[k]).max()) > 1e-5 * gmax}
+    bad = {k: e for k, e in errs.items() if not e < tol}
+    assert not bad, bad
+    return errs
+
+
+def test_training_step_gradients_match_reference_autograd_cpu():
+    """The training step composed from the gradient path's functions (what ConditionalNeRF.compute_render_loss does on the GPU with the
+    HIP KNN), here on the CPU with the brute-force KNN: loss, PSNR and the gradient of every parameter tensor the reference's step
+    reaches (166: all render heads, the aggregator incl. its DepthFusionNet CNN, confidence_mlp through the support table) + of the
+    fine feature maps, against the reference's autograd (tests/golden/train_setup.npz)."""
+    from tests.test_dropin_module import _args
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    case, cfg, data, rays = _train_case("cpu")
+    net = ConditionalNeRF(_args(cfg)).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    p = {**dict(net.named_buffers()), **dict(net.named_parameters())}
+    agg = net.multiview_aggregator
+    # (the CNN's hand-made input channels come from HIP kernels in the product; here from the setup oracle — they carry no graph)
+    from oracle import setup_oracle as sorc
+    vis = agg.depth_fusion.encode(sorc.cnn_input(data["topk_images"], data["topk_depths"], data["topk_Ks"], data["topk_poses"], float(cfg.near), float(cfg.far)))
+    fr = {k: data[k] for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src")}
+    fr.update({"vis_featmaps": vis, "near": float(cfg.near), "far": float(cfg.far)})
+    fr["support"] = dr.support_tables_diff(p, fr, data["topk_depths"], 4)
+    uv = data["sample_coords"]
+    o, d = dr.rays_from_pose(uv, data["K"], data["pose"])
+    lin = torch.linspace(0, 1, cfg.S)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(len(uv), cfg.S).contiguous()
+    preds = dr.render_rays_diff(p, fr, o, d, z, data["pose"], knn_bruteforce(fr["support"]["xyz"].detach()), beta=True)
+    uvl = uv.long()
+    fmap = torch.nn.functional.interpolate(data["feat_pyramid"]["layer1"], size=(cfg.H, cfg.Wimg), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    tgt = {"rgb": data["img"].permute(1, 2, 0)[uvl[:, 1], uvl[:, 0]], "feat": fmap[0, uvl[:, 1], uvl[:, 0]]}
+    loss = dr.rendering_loss(preds, tgt)
+    psnr = dr.masked_psnr(preds["rgb"], tgt["rgb"], preds["mask"])
+    loss.backward()
+    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-4)
+    print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+
+
+@pytest.mark.gpu
+def test_compute_render_loss_through_the_dropin_matches_reference_autograd():
+    """model.py:641-685 on the drop-in module in train() mode on the GPU (HIP KNN, per-frame caches rebuilt with their graphs)."""
+    from tests.test_dropin_module import _args
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    dev = torch.device("cuda:0")
+    case, cfg, data, rays = _train_case(dev)
+    net = ConditionalNeRF(_args(cfg), precision="fp32").to(dev).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    loss, psnr = net.compute_render_loss(data)
+    loss.backward()
+    # (3e-3: the conditioning of the reference's own fp32 gradients under different fp32 arithmetic, see the pose test above)
+    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 3e-3)
+    print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    # an optimiser step on the render heads lowers the loss of the same batch
+    opt = torch.optim.SGD([q for q in net.parameters() if q.grad is not None], lr=1e-3)
+    opt.step()
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    loss2, _ = net.compute_render_loss(data)
+    assert float(loss2.detach()) < float(loss.detach())

@@ -192,17 +192,6 @@ def test_cache_attributes_count_generations():
     assert "support_neural_points" not in net.state_dict() and "_support_neural_points" not in net.state_dict()
 
 
-@pytest.mark.gpu
-def test_dropin_training_paths_raise_clearly():
-    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
-    net = ConditionalNeRF(_args(CFG)).to("cuda:0")
-    with pytest.raises(NotImplementedError):
-        net.compute_render_loss({})
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net.render_rays({}, {})
-
-
 def test_entry_points_without_a_gradient_path_refuse_autograd():
     """The detached HIP outputs must not silently swallow a gradient: entry points that have no gradient path say so (CPU: no renderer
     involved).  render_rays / points_2d_to_rays do have one (next test)."""

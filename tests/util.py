@@ -32,3 +32,17 @@ def oracle_inputs(case):
     rays = to_torch(case["rays"])
     params = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
     return params, frame, rays
+
+
+def knn_bruteforce(points, K: int = 8, chunk: int = 4096):
+    """Exact KNN by chunked distance matrices (tests only: the stand-in for `HipRenderer.knn` where no GPU is present).
+    Ties: lower index first (knn_cpu.cpp:39-52 sorts (dist, idx) pairs).  -> callable q (N, 3) -> idx (N, K) int64"""
+    import torch
+
+    def f(q):
+        out = []
+        for i in range(0, q.shape[0], chunk):
+            d = ((q[i:i + chunk, None, :] - points[None]) ** 2).sum(-1)
+            out.append(torch.argsort(d, dim=1, stable=True)[:, :K])
+        return torch.cat(out, 0)
+    return f

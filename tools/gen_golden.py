@@ -240,6 +240,51 @@ def run_grad_case(model_mod, ku, gname):
           f"loss_rgb={float(loss_r.detach()):.6f} |dLf/dpose|={float(gf[0].abs().max()):.4e} |dLr/dpose|={float(gr[0].abs().max()):.4e}")
 
 
+def train_targets(cfg, seed):
+    """Seeded stand-ins for the query image and its layer-1 feature pyramid level (compute_render_loss's targets)."""
+    rng = np.random.default_rng(seed)
+    return rng.random((3, cfg.H, cfg.Wimg)).astype(np.float32), rng.standard_normal((1, cfg.C, cfg.H // 2, cfg.Wimg // 2)).astype(np.float32)
+
+
+def run_train_case(model_mod, name="train_setup"):
+    """One training step of the reference's render loss (model.py:641-685, losses.py:23-93) in train() mode: per-frame caches rebuilt
+    with their graphs (support table, DepthFusionNet maps), beta head on; loss, psnr and the gradient of EVERY parameter the step
+    reaches + of the fine feature maps (the 2D backbone's share)."""
+    from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_weights
+    cfg = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
+    frame = add_setup_inputs(cfg, make_frame(cfg))
+    rays = make_rays(cfg, frame)
+    weights = dict(make_weights(cfg))
+    weights.update(make_depth_fusion_weights(cfg.seed))
+    net = model_mod.ConditionalNeRF(ref_args(cfg)).train()
+    net.load_state_dict({k: t(v) for k, v in weights.items()}, strict=True)
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
+    data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
+    img, pyr = train_targets(cfg, cfg.seed + 2000)
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8, "scene": "s", "filename": "f",
+                 "sample_coords": t(rays["pixel_coordinates"]), "img": t(img), "feat_pyramid": {"layer1": t(pyr)}})
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    net.zero_grad()
+    with torch.enable_grad():
+        loss, psnr = net.compute_render_loss(data)
+        loss.backward()
+    save = {"loss": np.float64(loss.item()), "psnr": np.float64(psnr.item()), "grad_feat_fine_src": data["feat_fine_src"].grad.numpy()}
+    reached = []
+    for k, v in net.named_parameters():
+        if v.grad is not None and float(v.grad.abs().max()) > 0:
+            gnp = v.grad.numpy()
+            if gnp.size > 8192:   # big convolution kernels: every 7th element + the norm (keeps the fixture small)
+                save["gsub:" + k] = gnp.reshape(-1)[::7].copy()
+                save["gnorm:" + k] = np.float64(np.linalg.norm(gnp.astype(np.float64)))
+            else:
+                save["grad:" + k] = gnp
+            reached.append(k)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **save)
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) loss={loss.item():.6f} psnr={psnr.item():.4f} parameters with gradient: {len(reached)}")
+
+
 def punch_holes(frame, seed):
     """Ragged support depth for the `setup_holes` case: ~35 % of the pixels invalid (0), a few negative, one view with no valid
     depth at all — nonzero()'s order and the empty-view path of backproject_support_frame (model.py:231)."""
@@ -331,7 +376,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "grad":
         for g in GRAD_CASES:
             run_grad_case(model_mod, ku, g)
-        return
+        return run_train_case(model_mod)
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
@@ -340,6 +385,7 @@ def main():
         run_setup_case(model_mod, "setup_holes")
         for g in GRAD_CASES:
             run_grad_case(model_mod, ku, g)
+        run_train_case(model_mod)
 
 
 if __name__ == "__main__":
