@@ -13,9 +13,11 @@ What runs where
     the library too (`frame_setup.py`: `nl_backproject_support`, `nl_cross_view_features`); the per-frame CNN itself
     (`DepthFusionNet.encode`, MIOpen convolutions), `confidence_mlp`, `keypoint_head` and the tiny descriptor projections stay on
     PyTorch-ROCm, like the 2-D backbone (north_star).
-  * training-time pieces that need autograd THROUGH THE RENDERER (`compute_render_loss`, `beta`, PoseOptimizer's gradient) are
-    "next rows"  and raise NotImplementedError; the depth supervision of the per-frame CNN
-    (`multiview_aggregator.compute_ref_depth_loss`) never touches the renderer and is implemented with autograd.
+  * the two callers that differentiate THROUGH THE RENDERER — PoseOptimizer's `render_rays` under enable_grad and
+    training (`compute_render_loss`, train-mode `render_rays` with `beta`) — run on the explicit gradient path of `diff_render.py`
+    (fp32 autograd on the GPU around the HIP KNN), never on a silent fallback of the inference path; `query` / `render_image` refuse
+    inputs that require grad.  The depth supervision of the per-frame CNN (`multiview_aggregator.compute_ref_depth_loss`) never
+    touches the renderer and is implemented with autograd.
 """
 from __future__ import annotations
 
