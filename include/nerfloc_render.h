@@ -215,8 +215,14 @@ size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V);         
  * samples and do not change at all).  0 = off = nl_render_rays.  The density itself cannot be skipped: the ray U-Net
  * (ray_unet.py:55-69) runs along the whole ray. */
 typedef struct nl_render_opts {
-  float early_term_eps;   /* 0 (off) or in (0, 1): e.g. 1e-5 keeps BASELINE's 1e-4 with a wide margin */
-  int32_t reserved[7];    /* must be 0 */
+  float early_term_eps;      /* 0 (off) or in (0, 1): e.g. 1e-5 keeps BASELINE's 1e-4 with a wide margin */
+  int32_t reserved0;         /* must be 0 */
+  /* Several query frames per launch: device pointer to (R, 3) per-ray query camera centres, or NULL.  When set
+   * it replaces `query_center` (which may then be NULL): rays of different query poses against the SAME support frame go down in one
+   * call — the query centre is the only per-query-frame quantity the ray path reads (ibrnet.py:144-167, the view-angle features) —
+   * which amortises the launch chain for small per-frame batches (PoseOptimizer-sized: 512 rays). */
+  const float* ray_centers;
+  int32_t reserved[4];       /* must be 0 */
 } nl_render_opts;
 
 /* rays_o, rays_d (R,3); z_vals (R,S) or NULL to generate linspace(near,far,S) (model.py:451-458,483-484). */

@@ -47,7 +47,7 @@ class NlRenderOut(C.Structure):
 
 
 class NlRenderOpts(C.Structure):
-    _fields_ = [("early_term_eps", C.c_float), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("early_term_eps", C.c_float), ("reserved0", C.c_int32), ("ray_centers", C.c_void_p), ("reserved", C.c_int32 * 4)]
 
 
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)

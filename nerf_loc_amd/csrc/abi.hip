@@ -447,9 +447,11 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
 
 #define NL_TRY(e) do { int _rc = (e); if (_rc != NL_OK) return _rc; } while (0)
 
-NlViews with_query(const nl_frame* f, const float* qc) {
+// qrows != null: per-ray query centres (device, row = sample / S) instead of the one host-side centre qc
+NlViews with_query(const nl_frame* f, const float* qc, const float* qrows = nullptr, int S = 1) {
   NlViews v = f->views;
   v.qcam[0] = qc ? qc[0] : 0.f; v.qcam[1] = qc ? qc[1] : 0.f; v.qcam[2] = qc ? qc[2] : 0.f;
+  v.qrows = qrows; v.qS = S > 0 ? S : 1;
   return v;
 }
 
@@ -545,8 +547,8 @@ bool prof_arm(hipEvent_t* e0, hipEvent_t* e1) {
 }
 
 int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
-          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m, bool skip_g = false) {
-  const NlViews vw = with_query(f, qc);
+          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m, bool skip_g = false, const float* qrows = nullptr, int qS = 1) {
+  const NlViews vw = with_query(f, qc, qrows, qS);
   if (bl1) NL_TRY(ensure_pfeat(x, f));
   if (x.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
   else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x.p<char>(x.L.dec_mfma), xyz, N, m.vis, m.dd, x.c->precision == NL_PREC_BF16X3, x.st));
@@ -1050,7 +1052,8 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   const float term_eps = opts ? opts->early_term_eps : 0.f;
   if (term_eps < 0.f || term_eps >= 1.f) return NL_ERR_BAD_ARG;
-  if (!cfg_ok(cfg) || !packed || !f || !qc || !rays_o || !rays_d || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
+  const float* ray_centers = opts ? opts->ray_centers : nullptr;
+  if (!cfg_ok(cfg) || !packed || !f || (!qc && !ray_centers) || !rays_o || !rays_d || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, S = cfg->S, W = cfg->W;
   // largest ray chunk whose buffers fit the workspace
   const size_t b1 = render_bytes(cfg, V, 1);
@@ -1091,7 +1094,8 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     // the stage output or when the separate launches run instead (NERFLOC_NO_CHAIN: A/B switch)
     static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
     const bool use_chain = !no_chain && W == 256 && cfg->precision != NL_PREC_F32 && N * 1024 <= 0x7fffffffll && nl_point_fused_supported(W, cfg->precision);
-    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg));
+    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg,
+                 ray_centers ? ray_centers + 3 * r0 : nullptr, S));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     // with early termination feat_mlp.0 runs later, over the live tiles only; otherwise the chain kernel produces it right here
     bool chain_done = false;

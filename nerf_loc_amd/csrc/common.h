@@ -80,6 +80,8 @@ struct NlViews {
   float P2[NL_MAX_VIEWS][12];   // NeuRay K@Rt (depth_fusion.py:90)
   float cam[NL_MAX_VIEWS][3];   // support camera centres
   float qcam[3];                // query camera centre
+  const float* qrows;           // optional per-ray query centres (R, 3): sample n belongs to ray n / qS (several query frames per launch)
+  int qS;
   int V, H, Wimg, h, w;   // h,w: feature map; vh,vw: visibility map
   int vh, vw;
   float near_, far_;

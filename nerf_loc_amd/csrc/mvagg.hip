@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256, VT <= 4 ? 4 : (VT <= 10 ? 3 : 2)) void mv_stat
       a_iw[2] = (t.ms && t.mw) ? t.sw : 0.f; a_iw[3] = (t.ms && t.me) ? t.se : 0.f;
     }
     // view-angle features (ibrnet.py:144-167)
-    float tq[3] = {vw.qcam[0] - X, vw.qcam[1] - Y, vw.qcam[2] - Z};
+    float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+    if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(n / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+    float tq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
     const float nq = sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f;
     tq[0] /= nq; tq[1] /= nq; tq[2] /= nq;
     float tt[3] = {viewsdev[192 + 3 * vl] - X, viewsdev[192 + 3 * vl + 1] - Y, viewsdev[192 + 3 * vl + 2] - Z};
@@ -528,7 +530,9 @@ __global__ __launch_bounds__(256) void mv_stats8_kernel(const NlViews vw, const 
   int cnt1 = 0;
   {
     const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
-    float tq[3] = {vw.qcam[0] - X, vw.qcam[1] - Y, vw.qcam[2] - Z};
+    float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+    if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(nn / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+    float tq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
     const float rq = 1.f / (sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f);   // one division per vector (the angle features are not bit-compared)
     tq[0] *= rq; tq[1] *= rq; tq[2] *= rq;
 #pragma unroll

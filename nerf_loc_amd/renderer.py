@@ -142,13 +142,19 @@ class HipRenderer:
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
                     intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0) -> Dict[str, torch.Tensor]:
         """early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
-        ray's transmittance falls below eps are not evaluated (rgb / feat move by < eps * max|value|; everything else is unchanged)."""
+        ray's transmittance falls below eps are not evaluated (rgb / feat move by < eps * max|value|; everything else is unchanged).
+        query_center: (3,) for the whole batch, or (R, 3) per ray — rays of several query frames (poses) against this support frame in
+        one launch (nl_render_opts.ray_centers)."""
         self._ready()
         dev = self.device
         o, d = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev)
         R, S, W = o.shape[0], self.S, self.W
         z = None if z_vals is None else _dev_f32(z_vals, dev)
-        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        qc_t = torch.as_tensor(query_center).detach().float()
+        per_ray = qc_t.dim() == 2
+        if per_ray and tuple(qc_t.shape) != (R, 3):
+            raise ValueError(f"per-ray query centres must have shape ({R}, 3), got {tuple(qc_t.shape)}")
+        qc = qc_t.to(dev).contiguous() if per_ray else qc_t.cpu().contiguous()
         out = {
             "rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
             "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev),
@@ -167,9 +173,11 @@ class HipRenderer:
         ws = self._workspace(need)
         opts = L.NlRenderOpts()
         opts.early_term_eps = float(early_term_eps)
-        L.check(self.lib.nl_render_rays_ex(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(),
-                                           _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream(),
-                                           ct.byref(opts) if early_term_eps > 0 else None), "nl_render_rays")
+        if per_ray:
+            opts.ray_centers = qc.data_ptr()
+        L.check(self.lib.nl_render_rays_ex(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, None if per_ray else qc.data_ptr(), o.data_ptr(),
+                                           d.data_ptr(), _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream(),
+                                           ct.byref(opts) if (early_term_eps > 0 or per_ray) else None), "nl_render_rays")
         out["mask"] = out["mask"].bool()
         if intermediates:
             out["sigma"] = out["sigma"].view(R, S)

@@ -348,3 +348,34 @@ def test_ref_depth_loss_on_the_gpu_matches_reference():
     loss.backward()
     grad = dict(net.named_parameters())["multiview_aggregator.dist_decoder.mean_decoder.4.weight"].grad
     assert rel_err(grad.cpu().numpy(), g["grad_mean_decoder_4_w"]) < 2e-4
+
+
+@pytest.mark.gpu
+def test_several_query_frames_per_launch_equal_separate_calls():
+    """render_rays_frames (nl_render_opts.ray_centers): rays of three query poses against one support frame in ONE library call give what
+    three render_rays calls give."""
+    from tests.golden_cases import build_setup_case
+    dev = torch.device("cuda:0")
+    case = build_setup_case("setup")
+    net, data, rd = _module_and_data(case, dev)
+    cfg = case["cfg"]
+    uv = rd["pixel_coordinates"]
+    frames, singles = [], []
+    for i, shift in enumerate(([0.0, 0.0, 0.0], [0.03, -0.02, 0.01], [-0.05, 0.04, 0.02])):
+        pose = data["pose"].clone()
+        pose[:3, 3] += torch.tensor(shift, device=dev)
+        rays = net.points_2d_to_rays(uv[: 24 - 4 * i], cfg.H, cfg.Wimg, data["K"], pose)   # ragged: 24, 20, 16 rays
+        rays["depth_range"] = rd["depth_range"]
+        frames.append(rays)
+        d_i = dict(data)
+        d_i["pose"] = pose
+        singles.append(net.render_rays(d_i, rays))
+    outs = net.render_rays_frames(data, frames)
+    assert len(outs) == 3
+    for got, want in zip(outs, singles):
+        assert torch.equal(got["mask"], want["mask"])
+        for k in ("rgb", "depth", "weights", "feat", "depth_uncertainty"):
+            assert got[k].shape == want[k].shape
+            assert rel_err(got[k].cpu().numpy(), want[k].cpu().numpy()) < 1e-6, k
+    # the frames do differ from each other (otherwise the centres would not matter)
+    assert rel_err(singles[1]["rgb"][:16].cpu().numpy(), singles[0]["rgb"][:16].cpu().numpy()) > 1e-4
