@@ -365,13 +365,15 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   };
   // prologue compute steps of region G: the six k / v regions K0 .. V1 share them evenly
   auto pro_lo = [](int g) constexpr { return g < 3 * NRT ? 0 : g >= 3 * NRT + 6 ? NPC : (g - 3 * NRT) * NPC / 6; };
-  auto load_T = [&](auto Cc, unsigned tof) __attribute__((always_inline)) {   // table-row slice of layer-1 chunk c = initial value of its accumulator
-    constexpr int c = decltype(Cc)::value;
-    static_for<4>([&](auto Gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(Gc)::value;
-      const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, tof + (32 * GG::rt(c) + 4 * g) * 4, 0, 0));
-      acc[c & 3][4 * g] = t4[0]; acc[c & 3][4 * g + 1] = t4[1]; acc[c & 3][4 * g + 2] = t4[2]; acc[c & 3][4 * g + 3] = t4[3];
-    });
+  // table-row slice of layer-1 chunk c = initial value of its accumulator: four 16-byte gathers (lane = row: each costs the CU's address
+  // unit ~64 cycles, and the four waves issue in step), one per quarter of the region two ahead rather than back to back
+  auto load_Tg = [&](auto Cc, auto Gc, unsigned tof) __attribute__((always_inline)) {
+    constexpr int c = decltype(Cc)::value, g = decltype(Gc)::value;
+    const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rT, tof + (32 * GG::rt(c) + 4 * g) * 4, 0, 0));
+    acc[c & 3][4 * g] = t4[0]; acc[c & 3][4 * g + 1] = t4[1]; acc[c & 3][4 * g + 2] = t4[2]; acc[c & 3][4 * g + 3] = t4[3];
+  };
+  auto load_T = [&](auto Cc, unsigned tof) __attribute__((always_inline)) {
+    static_for<4>([&](auto Gc) __attribute__((always_inline)) { load_Tg(Cc, Gc, tof); });
   };
   auto load_bias = [&](auto Cc) __attribute__((always_inline)) {   // bias slice of layer-2/3 chunk c = initial value of its accumulator
     constexpr int c = GG::cm(decltype(Cc)::value);
@@ -457,9 +459,10 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       static_for<d1 - d0>([&](auto Ic) __attribute__((always_inline)) { dma_piece(std::integral_constant<int, G + 3>{}, std::integral_constant<int, d0 + decltype(Ic)::value>{}); });
     }
     // accumulator initial values: table rows of the layer-1 chunk two regions ahead (a gather), bias of the next layer-2/3 chunk (LDS)
-    if constexpr (K == 0 && GG::layer(G + 2) == 0) {
-      if constexpr (G + 2 < NC) load_T(std::integral_constant<int, G + 2>{}, toff);
-      else load_T(std::integral_constant<int, G + 2 - NC>{}, pn_toff);   // the next tile's first two row tiles
+    if constexpr (GG::layer(G + 2) == 0 && (K == 0 || K == NS / 4 || K == NS / 2 || K == 3 * NS / 4)) {
+      constexpr int g = K == 0 ? 0 : K == NS / 4 ? 1 : K == NS / 2 ? 2 : 3;
+      if constexpr (G + 2 < NC) load_Tg(std::integral_constant<int, G + 2>{}, std::integral_constant<int, g>{}, toff);
+      else load_Tg(std::integral_constant<int, G + 2 - NC>{}, std::integral_constant<int, g>{}, pn_toff);   // the next tile's first two row tiles
     }
     // the next tile's prologue: tile-number loads at the start of layer 3, neighbour gathers half a layer later, arithmetic under k / v
     if constexpr (!(KO & 1)) {
@@ -472,11 +475,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     }
     if constexpr (K == NS / 2 && (GG::layer(G + 1) == 1 || GG::layer(G + 1) == 2)) load_bias(std::integral_constant<int, G + 1>{});
     // query slice of the head whose k projection this region computes (scored in the next region)
-    if constexpr (K == NS / 2 && GG::layer(G) == 3 && GG::rt(G) < 4) {
-      static_for<4>([&](auto Gq) __attribute__((always_inline)) {
-        constexpr int g = decltype(Gq)::value;
-        Qr[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, qoff + (32 * GG::rt(G) + 8 * g) * 4, 0, 0));
-      });
+    if constexpr (GG::layer(G) == 3 && GG::rt(G) < 4 && K >= NS / 2 && (K - NS / 2) % (NS / 8) == 0 && (K - NS / 2) / (NS / 8) < 4) {
+      constexpr int g = (K - NS / 2) / (NS / 8);
+      Qr[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, qoff + (32 * GG::rt(G) + 8 * g) * 4, 0, 0));
     }
     // epilogue of the previous chunk
     {
