@@ -107,8 +107,9 @@ struct Layout {
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bias[G_COUNT];
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
   size_t pt_stream, pt_stream2, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
-  size_t un_g[U_COUNT], un_b[U_COUNT];
-  int un_c[U_COUNT], un_l[U_COUNT];
+  size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
+  size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
+  int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
   size_t total;
 };
 
@@ -181,6 +182,13 @@ Layout make_layout(const nl_config* c) {
     L.un_c[u] = uc[u]; L.un_l[u] = ul[u];
     L.un_g[u] = take(4 * (size_t)uc[u] * ul[u]);
     L.un_b[u] = take(4 * (size_t)uc[u] * ul[u]);
+    // the fused GEMM's view of the slab: a transposed convolution's merged launch has rows = input positions, columns = both phases
+    const bool tr = u == U_T3 || u == U_T2 || u == U_T1;
+    L.un_n[u] = tr ? 2 * uc[u] : uc[u];
+    L.un_so[u] = tr ? ul[u] / 2 : ul[u];
+    const size_t lm = 4 * (size_t)(L.un_so[u] > 32 ? L.un_so[u] : 32) * nl_tgemm_nrt(L.un_n[u]) * 32;
+    L.un_gl[u] = take(lm);
+    L.un_bl[u] = take(lm);
   }
   L.blw = take(4 * (256 + 32));
   L.dec_mfma = take(nl_mv_decoder_pack_bytes());
@@ -242,6 +250,17 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
   dst[i] = src[(size_t)c * L + l];
 }
 
+// LayerNorm affine table (So positions x N channels, position-major) -> the order in which tgemm_kernel's LNSLAB epilogue reads it:
+// [wave of the ray][row tile][gq][lane][4]: lane (j, hh) of wave w holds position (32 w + j) % So, channels 32 rt + 8 gq + 4 hh + 0..3 — one
+// contiguous KB per load instruction instead of 64 rows
+__global__ void ln_lane_major_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int So, int NRT, int total) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int i = e & 3, lane = (e >> 2) & 63, gq = (e >> 8) & 3, rt = (e >> 10) % NRT, wq = e / (1024 * NRT);
+  const int j = lane & 31, hh = lane >> 5, n = 32 * rt + 8 * gq + 4 * hh + i, t = (32 * wq + j) % So;
+  dst[e] = n < N ? src[(size_t)t * N + n] : 0.f;
+}
+
 __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -265,6 +284,11 @@ struct Packer {
   }
   void transpose(const float* src, size_t dst_off, int Cc, int Lp) {
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)nl_cdiv(Cc * Lp, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), Cc, Lp);
+  }
+  void lane_major(size_t src_off, size_t dst_off, int N, int So) {
+    const int nrt = nl_tgemm_nrt(N), total = (So > 32 ? So : 32) * nrt * 32;
+    hipLaunchKernelGGL(ln_lane_major_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, (const float*)(base + src_off), (float*)(base + dst_off),
+                       N, So, nrt, total);
   }
   void linear(int g, const float* w, const float* b) {  // torch (out, in)
     block(g, 0, w, 0, L->g[g].K, 1, L->g[g].K);
@@ -639,24 +663,26 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   const bool merged = x.c->precision != NL_PREC_F32 && !no_merge;
   auto g = [&](int i) { return x.p<float>(x.L.un_g[i]); };
   auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
+  auto gl = [&](int i) { return x.p<float>(x.L.un_gl[i]); };   // accumulator-lane order: what the GEMM's fused LayerNorm reads
+  auto bl = [&](int i) { return x.p<float>(x.L.un_bl[i]); };
   const float eps = 1e-5f;
   {  // conv1: W -> 64 over S
     SegSpec s[1] = {{in, W, W, 0, 1, 3}};   // 3 taps, interleaved per 32-channel block
-    const RowEpi ep{nullptr, 0, g(U_CONV1), b(U_CONV1), nullptr, eps, u.c1, NL_EPI_LNSLAB, 1};   // LN + ELU + MaxPool inside the GEMM when one workgroup = one ray
+    const RowEpi ep{nullptr, 0, gl(U_CONV1), bl(U_CONV1), nullptr, eps, u.c1, NL_EPI_LNSLAB, 1};   // LN + ELU + MaxPool inside the GEMM when one workgroup = one ray
     bool fused = false;
     NL_TRY(run_gemm(x, G_CONV1, s, 1, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
   }
   {  // conv2: 64 -> 128 over S/2
     SegSpec s[1] = {{u.c1, 64, 64, 0, 1, 3}};
-    const RowEpi ep{nullptr, 0, g(U_CONV2), b(U_CONV2), nullptr, eps, u.c2, NL_EPI_LNSLAB, 1};   // two rays per workgroup at S = 128
+    const RowEpi ep{nullptr, 0, gl(U_CONV2), bl(U_CONV2), nullptr, eps, u.c2, NL_EPI_LNSLAB, 1};   // two rays per workgroup at S = 128
     bool fused = false;
     NL_TRY(run_gemm(x, G_CONV2, s, 1, R * (S / 2), u.r2, 128, NL_ACT_NONE, S / 2, S / 2, S / 2, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, nullptr, u.c2, x.st));
   }
   {  // conv3: 128 -> 128 over S/4
     SegSpec s[1] = {{u.c2, 128, 128, 0, 1, 3}};
-    const RowEpi ep{nullptr, 0, g(U_CONV3), b(U_CONV3), nullptr, eps, u.c3, NL_EPI_LNSLAB, 1};   // one ray per wave at S = 128
+    const RowEpi ep{nullptr, 0, gl(U_CONV3), bl(U_CONV3), nullptr, eps, u.c3, NL_EPI_LNSLAB, 1};   // one ray per wave at S = 128
     bool fused = false;
     NL_TRY(run_gemm(x, G_CONV3, s, 1, R * (S / 4), u.r3, 128, NL_ACT_NONE, S / 4, S / 4, S / 4, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, nullptr, u.c3, x.st));
@@ -667,7 +693,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     bool tfused = false;
     // row m = output positions 2m, 2m+1: the (Li x 2 co) view of the merged output IS the ray's (Lo x co) slab, so LayerNorm([C, L]) + ELU
     // ride in the GEMM's epilogue (the affine tables are stored position-major: same memory either way)
-    const RowEpi ept3{nullptr, 0, g(U_T3), b(U_T3), nullptr, eps, u.x0, NL_EPI_LNSLAB, 0};
+    const RowEpi ept3{nullptr, 0, gl(U_T3), bl(U_T3), nullptr, eps, u.x0, NL_EPI_LNSLAB, 0};
     if (merged) NL_TRY(run_gemm(x, G_T3M, o, 2, R * Li, u.x0r, 256, NL_ACT_NONE, Li, Li, Li, 1, 0, &ept3, &tfused));
     else {
       SegSpec e[1] = {{u.c3, 128, 128, 0, 1}};
@@ -680,7 +706,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     const int Li = S / 4, Lo = S / 2;
     SegSpec o[4] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}, {u.c2, 128, 128, 1, 1}, {u.x0, 128, 128, 1, 1}};
     bool tfused = false;
-    const RowEpi ept2{nullptr, 0, g(U_T2), b(U_T2), nullptr, eps, u.x1, NL_EPI_LNSLAB, 0};
+    const RowEpi ept2{nullptr, 0, gl(U_T2), bl(U_T2), nullptr, eps, u.x1, NL_EPI_LNSLAB, 0};
     if (merged) NL_TRY(run_gemm(x, G_T2M, o, 4, R * Li, u.x1r, 128, NL_ACT_NONE, Li, Li, Li, 1, 0, &ept2, &tfused));
     else {
       SegSpec e[2] = {{u.c2, 128, 128, 0, 1}, {u.x0, 128, 128, 0, 1}};
@@ -693,7 +719,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     const int Li = S / 2, Lo = S;
     SegSpec o[4] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}, {u.c1, 64, 64, 1, 1}, {u.x1, 64, 64, 1, 1}};
     bool tfused = false;
-    const RowEpi ept1{nullptr, 0, g(U_T1), b(U_T1), nullptr, eps, u.x2, NL_EPI_LNSLAB, 0};
+    const RowEpi ept1{nullptr, 0, gl(U_T1), bl(U_T1), nullptr, eps, u.x2, NL_EPI_LNSLAB, 0};
     if (merged) NL_TRY(run_gemm(x, G_T1M, o, 4, R * Li, u.x2r, 64, NL_ACT_NONE, Li, Li, Li, 1, 0, &ept1, &tfused));
     else {
       SegSpec e[2] = {{u.c1, 64, 64, 0, 1}, {u.x1, 64, 64, 0, 1}};
@@ -704,7 +730,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   }
   {  // conv_out on cat[in, x2]
     SegSpec s[2] = {{in, W, W, 0, 1, 3}, {u.x2, 32, 32, 0, 1, 3}};
-    RowEpi ep{nullptr, 0, g(U_OUT), b(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
+    RowEpi ep{nullptr, 0, gl(U_OUT), bl(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
     if (sigma_out) { ep.sig_w = x.p<float>(x.L.sig_w); ep.sig_b = x.p<float>(x.L.sig_b); ep.sig_out = sigma_out; }
     bool fused = false;
     if (!need_geo && sigma_out) ep.out = nullptr;   // (the unfused fallback below still writes `geo`)
@@ -842,6 +868,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   for (int u = 0; u < U_COUNT; ++u) {
     P.transpose(un[4 * u + 2], L.un_g[u], L.un_c[u], L.un_l[u]);   // (C, L) -> (L, C)
     P.transpose(un[4 * u + 3], L.un_b[u], L.un_c[u], L.un_l[u]);
+    P.lane_major(L.un_g[u], L.un_gl[u], L.un_n[u], L.un_so[u]);
+    P.lane_major(L.un_b[u], L.un_bl[u], L.un_n[u], L.un_so[u]);
   }
   P.linear(G_FEAT0, t[T_F0W], t[T_F0B]);
   P.block(G_FEAT2, 0, t[T_F2W], 0, W, 1, W);

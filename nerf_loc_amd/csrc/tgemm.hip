@@ -240,18 +240,27 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       for (int w = 0; w < NW; ++w) tot2 += w < wpr ? red[NW + gb + (w < wpr ? w : 0)] : 0.f;
     }
     const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
-    const float* grow = a.ep_gamma + (size_t)t * a.N;
-    const float* brow = a.ep_beta + (size_t)t * a.N;
+    // the affine tables come in accumulator-lane order (abi.hip ln_lane_major_kernel): [wave of the ray][rt][gq][lane][4] — one contiguous
+    // KB per load instruction; a row tile's eight loads are issued one row tile ahead of their use
+    const float* grow = a.ep_gamma + ((size_t)(wave % wpr) * NRT * 4 * 64 + lane) * 4;
+    const float* brow = a.ep_beta + ((size_t)(wave % wpr) * NRT * 4 * 64 + lane) * 4;
+    float4 gbuf[2][4], bbuf[2][4];
+    auto load_gb = [&](int rt, float4 (&gd)[4], float4 (&bd)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) { gd[gq] = *(const float4*)(grow + (rt * 4 + gq) * 256); bd[gq] = *(const float4*)(brow + (rt * 4 + gq) * 256); }
+    };
+    load_gb(0, gbuf[0], bbuf[0]);
     const bool pool = a.ep_pool != 0;
     float* orow_p = p_c + (size_t)(pool ? q * (a.So / 2) + (t >> 1) : m) * a.ldc;
     float sg = 0.f;
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt)
+    for (int rt = 0; rt < NRT; ++rt) {
+      if (rt + 1 < NRT) load_gb(rt + 1, gbuf[(rt + 1) & 1], bbuf[(rt + 1) & 1]);
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = 32 * rt + 8 * gq + 4 * hh;
         if (n < a.N) {
-          const float4 g4 = *(const float4*)(grow + n), be4 = *(const float4*)(brow + n);
+          const float4 g4 = gbuf[rt & 1][gq], be4 = bbuf[rt & 1][gq];
           float4 v;
           v.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
           v.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
@@ -269,6 +278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the gamma/beta loads of later tiles from being hoisted (register budget)
       }
+    }
     if (a.ep_sig_w) {   // the density head rides along: the other half of the row is in lane ^ 32
       sg += __shfl_xor(sg, 32, 64);
       if (hh == 0 && mok) a.ep_sig_out[m] = nl_softplus(sg + a.ep_sig_b[0]);
@@ -566,10 +576,18 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
       // chunk c must have landed: younger operations are the pieces of chunks c+1, c+2 and the other traffic issued since chunk c-3
       constexpr int younger = ppw(c + 1) + ppw(c + 2) + Geo::post(c - 3, FEAT) + Geo::post(c - 2, FEAT) + Geo::post(c - 1, FEAT);
       CHAIN_T(0);
+#ifdef CHAIN_WAIT0
+      tg_wait_vmcnt<0>();
+#else
       tg_wait_vmcnt<(younger < 63 ? younger : 63)>();
+#endif
       __builtin_amdgcn_s_barrier();
       CHAIN_T(1);
       dma_chunk(std::integral_constant<int, c + 3>{});   // its slot held chunk c-1, which every wave has left
+      // The counted waits assume program order = issue order: nothing below may be scheduled in front of these pieces (a row store
+      // hoisted above them made the blend chunk's wait one short in bf16 mode, where a chunk is ONE piece per wave: run-to-run
+      // different colours)
+      __builtin_amdgcn_sched_barrier(0);
       // ---- this slot's share of the row traffic: operation k of the slot goes out after MFMA group 4 k + 1 (always issued: the wait
       // counts stay exact)
       auto mem_op = [&](int k) __attribute__((always_inline)) {
@@ -590,6 +608,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
 #pragma unroll
         for (int k = 0; k < 4; ++k) mem_op(k);
       }
+      __builtin_amdgcn_sched_barrier(0);
 
       tg_bf16x8 bh[2], bl[2];
       if constexpr (kd == CK_FC || kd == CK_G2) {

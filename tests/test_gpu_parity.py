@@ -471,3 +471,27 @@ def test_repacking_weights_in_place_refreshes_per_frame_tables():
     assert rel_err(a["rgb"].cpu().numpy(), b["rgb"].cpu().numpy()) > 1e-4, "the weight change must be visible"
     for k in ("rgb", "depth", "feat"):
         assert torch.equal(b[k], fresh[k]), k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_repeated_renders_are_bit_identical(precision):
+    """The same batch rendered repeatedly gives the same bits in every mode.  (The chain kernels count outstanding memory operations
+    instead of draining them: a row store the compiler scheduled in front of the weight pieces it was counted behind once made the
+    blend projection read a chunk that had not landed — only in bf16 mode, where such a chunk is one piece per wave — and colours
+    differed from run to run.  tools/race_check.py is the long version of this test.)"""
+    from nerf_loc_amd.renderer import HipRenderer
+    case = build_case("w256s128")
+    cfg, frame, rays = case["cfg"], case["frame"], case["rays"]
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in case["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    first = None
+    for _ in range(12):
+        out = r.render_rays(rays["rays_o"], rays["rays_d"], frame["pose"][:3, 3])
+        torch.cuda.synchronize()
+        cur = {k: out[k].clone() for k in ("rgb", "depth", "weights", "feat")}
+        if first is None:
+            first = cur
+        else:
+            for k in cur:
+                assert torch.equal(cur[k], first[k]), (precision, k)
