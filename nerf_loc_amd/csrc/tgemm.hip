@@ -55,6 +55,19 @@ __device__ __forceinline__ int tg_find_seg(const NlGemmArgs& a, int k0) {
   return __builtin_amdgcn_readfirstlane(s);
 }
 
+#ifdef TG_TRACE   // debug build (tools/tg_trace.py): cycle counter of block 0, wave 0 of the NRT = 8 LNSLAB launch: [chunk starts ... | epilogue marks]
+__device__ unsigned long long tg_trace[64];
+#define TG_T(i)                                                                                      \
+  do {                                                                                               \
+    if (NRT == 8 && EPI == NL_EPI_LNSLAB && blockIdx.x == 0 && wave == 0 && a.Kpad > 512) {          \
+      const unsigned long long t_ = __builtin_readcyclecounter();                                    \
+      if (lane == 0) tg_trace[(i)] = t_;                                                             \
+    }                                                                                                \
+  } while (0)
+#else
+#define TG_T(i)
+#endif
+
 template <int NRT, int NW, bool X3, int EPI>
 __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
                                                             const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
   constexpr int CH16 = 4 * NRT * 64;        // 16-B units per chunk in the global stream (hi and lo parts are always stored)
   constexpr int SLOT16 = PIECES * 64;       // 16-B units per LDS slot
-  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8 * (EPI == NL_EPI_LNROW ? 3 : 1) + (EPI == NL_EPI_LNSLAB ? 8 : 0)];
+  __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8 * (EPI == NL_EPI_LNROW ? 3 : EPI == NL_EPI_LNSLAB ? 2 : 1) + (EPI == NL_EPI_LNSLAB ? 8 : 0)];
   // native vector element type everywhere (struct-typed uint4 arrays in registers do not survive SROA)
   tg_bf16x8 (*ring)[SLOT16] = reinterpret_cast<tg_bf16x8 (*)[SLOT16]>(lds_all);
   float* sbias = reinterpret_cast<float*>(lds_all + 2 * SLOT16);
@@ -86,13 +99,15 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   for (int i = tid; i < NRT * 32; i += 64 * NW) {
     sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
     if (EPI == NL_EPI_LNROW) { sbias[NRT * 32 + i] = a.ep_gamma[i]; sbias[2 * NRT * 32 + i] = a.ep_beta[i]; }   // N == 32 * NRT
+    if (EPI == NL_EPI_LNSLAB) sbias[NRT * 32 + 32 + i] = (a.ep_sig_w && i < a.N) ? a.ep_sig_w[i] : 0.f;   // density-head weights (after the 32 floats of `red`)
   }
 
   // weights of chunk c: this wave's NPW pieces, 16 B per lane, fully coalesced
+  auto w_ptr = [&](int c) __attribute__((always_inline)) { return reinterpret_cast<const tg_bf16x8*>(p_bst) + (size_t)c * CH16 + wave * 64 + lane; };
   auto load_w = [&](int c, tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
-    const tg_bf16x8* src = reinterpret_cast<const tg_bf16x8*>(p_bst) + (size_t)c * CH16;
+    const tg_bf16x8* src = w_ptr(c);
 #pragma unroll
-    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[(wave + NW * jj) * 64 + lane];
+    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[NW * jj * 64];
   };
   auto store_w = [&](int slot, const tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
 #pragma unroll
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   };
   // activation fragments of chunk c: 2 k-steps x 8 floats of this lane's source row, straight into registers.  Conv halo
   // rows and rows >= M read a device zero page instead (no masking arithmetic).
-  auto load_act = [&](int c, float4 (&raw)[4]) __attribute__((always_inline)) {
+  auto act_ptr = [&](int c) __attribute__((always_inline)) -> const float* {
     const int k0 = 32 * c;
     const int s = tg_find_seg(a, k0);
     const NlGemmSeg& sg = a.seg[s];
@@ -118,7 +133,10 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       ok = ok && i >= 0 && i < a.Li;
       row = q * a.Li + i;
     }
-    const float* p = (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + 8 * hh;
+    return (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + 8 * hh;
+  };
+  auto load_act = [&](int c, float4 (&raw)[4]) __attribute__((always_inline)) {
+    const float* p = act_ptr(c);
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) raw[pc] = *(const float4*)(p + 16 * (pc >> 1) + 4 * (pc & 1));
   };
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
   // one chunk: 2 k-steps x NRT row tiles x (3 | 1) MFMAs; A fragments are read two (k-step, tile) pairs ahead
-  auto compute = [&](int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
+  auto compute = [&](int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2], auto&& filler) __attribute__((always_inline)) {
     const tg_bf16x8* L = ring[slot];
     constexpr int nt = 2 * NRT;
     auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
@@ -158,6 +176,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
         acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], acc[rt], 0, 0, 0);
       }
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+      filler(tt);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -175,11 +194,30 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
   store_w(0, wreg);
   __syncthreads();
   for (int g = 0; g < NC; ++g) {   // one straight-line body, no control flow around the MFMAs (accumulators stay put)
+    TG_T(g < 40 ? g : 40);
     tg_bf16x8 bh[2], bl[2];
     convert(raw, bh, bl);
-    load_act(clampc(g + 1), raw);
-    load_w(clampc(g + 1), wreg);
-    compute(g & 1, bh, bl);
+    // The next chunk's 4 activation loads (lane = row: ~64 cycles each in the CU's address unit) and NPW weight loads go out one at a
+    // time between the MFMA groups instead of as a burst in front of them: a burst makes every wave of the workgroup wait at issue
+    // (first half of the chunk only: the weights are stored to LDS right after it; chunks of fewer row tiles are too short for this and
+    // keep the loads in front)
+    if constexpr (NRT == 8) {
+      const float* ap = act_ptr(clampc(g + 1));
+      const tg_bf16x8* wp = w_ptr(clampc(g + 1));
+      compute(g & 1, bh, bl, [&](int tt) __attribute__((always_inline)) {
+        constexpr int NLD = 4 + NPW, nh = NRT;   // slots 0 .. NRT-1
+#pragma unroll
+        for (int l = 0; l < NLD; ++l)
+          if (l * nh / NLD == tt) {
+            if (l < 4) raw[l] = *(const float4*)(ap + 16 * (l >> 1) + 4 * (l & 1));
+            else wreg[l - 4] = wp[NW * (l - 4) * 64];
+          }
+      });
+    } else {
+      load_act(clampc(g + 1), raw);
+      load_w(clampc(g + 1), wreg);
+      compute(g & 1, bh, bl, [](int) __attribute__((always_inline)) {});
+    }
     store_w((g + 1) & 1, wreg);
     __syncthreads();
   }
@@ -190,6 +228,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     // waves per ray, or two rays per wave for So = 16): LayerNorm over each ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional
     // MaxPool(2) along the ray.  A trailing workgroup may hold rays past M: their statistics are computed on zero rows and
     // nothing of them is stored.
+    TG_T(48);
     float* red = sbias + NRT * 32;   // [2][NW] partial sums
     const int wpr = a.So >= 32 ? a.So >> 5 : 1, gb = (wave / wpr) * wpr;
     float s1 = 0.f;
@@ -240,6 +279,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       for (int w = 0; w < NW; ++w) tot2 += w < wpr ? red[NW + gb + (w < wpr ? w : 0)] : 0.f;
     }
     const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
+    TG_T(49);
     // the affine tables come in accumulator-lane order (abi.hip ln_lane_major_kernel): [wave of the ray][rt][gq][lane][4] — one contiguous
     // KB per load instruction; a row tile's eight loads are issued one row tile ahead of their use
     const float* grow = a.ep_gamma + ((size_t)(wave % wpr) * NRT * 4 * 64 + lane) * 4;
@@ -272,13 +312,14 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
           }
           if (p_c && mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;   // p_c == null: only the density head's output is wanted
           if (a.ep_sig_w) {
-            const float4 w4 = *(const float4*)(a.ep_sig_w + n);
+            const float4 w4 = *(const float4*)(sbias + NRT * 32 + 32 + n);
             sg = fmaf(v.x, w4.x, sg); sg = fmaf(v.y, w4.y, sg); sg = fmaf(v.z, w4.z, sg); sg = fmaf(v.w, w4.w, sg);
           }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the gamma/beta loads of later tiles from being hoisted (register budget)
       }
     }
+    TG_T(50);
     if (a.ep_sig_w) {   // the density head rides along: the other half of the row is in lane ^ 32
       sg += __shfl_xor(sg, 32, 64);
       if (hh == 0 && mok) a.ep_sig_out[m] = nl_softplus(sg + a.ep_sig_b[0]);
@@ -779,6 +820,11 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
 
+#ifdef TG_TRACE
+extern "C" __attribute__((visibility("default"))) int nl_debug_tg_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef CHAIN_TRACE
 extern "C" __attribute__((visibility("default"))) int nl_debug_chain_trace(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(chain_trace), sizeof(unsigned long long) * 2 * 4 * 96) == hipSuccess ? 0 : -1;
