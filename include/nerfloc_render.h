@@ -40,7 +40,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NL_ABI_VERSION 1
+#define NL_ABI_VERSION 2   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres) */
 #define NL_MAX_VIEWS 16
 #define NL_KNN_MAX_K 8
 

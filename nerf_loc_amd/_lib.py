@@ -115,7 +115,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nl_abi_version() != 1:
+    if lib.nl_abi_version() != 2:
         raise RuntimeError("libnerfloc_render.so ABI version mismatch")
     _lib = lib
     return lib

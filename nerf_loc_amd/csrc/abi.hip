@@ -789,6 +789,7 @@ Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
 // =====================================================================================================
 extern "C" {
 
+static_assert(sizeof(nl_render_opts) == 32, "nl_render_opts is part of the C-ABI: 32 bytes");
 int nl_abi_version(void) { return NL_ABI_VERSION; }
 
 int nl_profile_begin(void) { g_prof.on = true; g_prof.used = 0; return NL_OK; }

@@ -54,3 +54,13 @@ def test_product_path_fails_loudly_without_gpu():
     from nerf_loc_amd.renderer import HipRenderer
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         HipRenderer(64, 192, 32)
+
+
+def test_render_opts_struct_matches_the_header():
+    """nl_render_opts is passed by pointer across the C-ABI: 32 bytes, the per-ray centre pointer at offset 8 (include/nerfloc_render.h)."""
+    import ctypes
+    from nerf_loc_amd import _lib as L
+    assert ctypes.sizeof(L.NlRenderOpts) == 32
+    assert L.NlRenderOpts.early_term_eps.offset == 0 and L.NlRenderOpts.ray_centers.offset == 8
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "nerfloc_render.h")).read()
+    assert "#define NL_ABI_VERSION 2" in hdr and "const float* ray_centers;" in hdr
