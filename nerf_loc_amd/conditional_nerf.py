@@ -409,8 +409,6 @@ class ConditionalNeRF(nn.Module):
         Both are checked against the reference's autograd in tests/test_diff_render.py."""
         fnear, ffar = [float(x) for x in data["depth_range"][0]]
         if train:
-            if self.args.use_depth_supervision and self.args.render.N_importance > 0:
-                raise NotImplementedError("depth_coarse carries no graph on this path: depth supervision of the hierarchical branch is not available")
             p = {**dict(self.named_buffers()), **dict(self.named_parameters())}
             if self.support_neural_points is None:
                 self.build_support_neural_points(data)   # both levels on the HIP library (no graph): the coarse level for the other callers
@@ -432,7 +430,17 @@ class ConditionalNeRF(nn.Module):
         R, N = o.shape[0], self.args.render.N_samples
         z = self.sample_depths(N, near, far).expand(R, N).contiguous()
         depth_coarse = None
-        if self.args.render.N_importance > 0:   # the resampled depths carry no gradient in the reference either (model.py:495 detaches)
+        if self.args.render.N_importance > 0 and train:
+            # training: the coarse weights keep their graph (depth_coarse is supervised, losses.py:83-88); the resampled depths do not
+            # (model.py:495 detaches the weights)
+            if u is None:
+                u = torch.rand(R, self.args.render.N_importance, device=o.device)
+            zc = self.sample_depths(64, near, far).expand(R, 64).contiguous()
+            wc = diff_render.coarse_weights_diff(p, fr, rays["pixel_coordinates"].to(o.dtype), rays["K"], rays["pose"], zc)
+            depth_coarse = (wc * zc).sum(1)
+            zf = diff_render.sample_pdf_diff(0.5 * (zc[:, :-1] + zc[:, 1:]), wc[:, 1:-1].detach(), u)
+            z = torch.sort(torch.cat([z, zf], -1), -1)[0]
+        elif self.args.render.N_importance > 0:   # the resampled depths carry no gradient in the reference either (model.py:495 detaches)
             with torch.no_grad():
                 if u is None:
                     u = torch.rand(R, self.args.render.N_importance, device=o.device)

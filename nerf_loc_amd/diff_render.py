@@ -216,6 +216,83 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     return out
 
 
+# ----------------------------------------------------------------------------- hierarchical branch with its graph (a20)
+def coarse_weights_diff(p: Dict[str, Tensor], fr: Dict, pix: Tensor, K: Tensor, pose: Tensor, zc: Tensor) -> Tensor:
+    """multiview_aggregator.py:95-154 (+ depth_fusion.py:9-58, visibility_decoder.py:6-51,150-181): hit-probability weights (R, dn) of the
+    coarse depths `zc` along the query rays through pixels `pix`, predicted from the support views' visibility features."""
+    Ks, poses = fr["topk_Ks"], fr["topk_poses"]
+    V = Ks.shape[0]
+    H, W = fr["topk_images"].shape[-2:]
+    near, far = fr["near"], fr["far"]
+    ni, fi = -1.0 / near, -1.0 / far
+    dev, dt = zc.device, zc.dtype
+    rn, dn = zc.shape
+    # query rays: centre + un-normalised K^-1 [u, v, 1] directions in the world frame (depth_fusion.py:9-45)
+    q_w2c = torch.inverse(pose)[:3]
+    rot = q_w2c[:, :3].t()
+    cen = -rot @ q_w2c[:, 3]
+    cam = torch.inverse(K) @ torch.cat([pix, torch.ones(rn, 1, device=dev, dtype=dt)], 1).t()      # (3, rn)
+    dirs = (rot @ cam).t()
+    pts = (cen[None, None, :] + dirs[:, None, :] * zc[..., None]).reshape(-1, 3)
+    # interval lengths in normalised inverse depth, last = 1e6 (depth_fusion.py:47-58)
+    di = (-1.0 / zc - ni) / (fi - ni)
+    dist = torch.cat([di[:, 1:] - di[:, :-1], torch.full((rn, 1), 1e6, device=dev, dtype=dt)], -1)
+    # projection into the support views + visibility features (as in _mv_aggregate)
+    w2c = torch.inverse(poses)
+    xyz_h = torch.cat([pts, torch.ones_like(pts[:, :1])], -1)
+    camv = torch.einsum("vij,nj->vni", Ks.bmm(w2c[:, :3]), xyz_h)
+    depth = camv[..., 2:]
+    bad = depth.abs() < 1e-4
+    depth = torch.where(bad, torch.full_like(depth, 1e-3), depth)
+    pv = camv[..., :2] / depth
+    outside = (pv[..., 0] < -0.5) | (pv[..., 0] >= W - 0.5) | (pv[..., 1] < -0.5) | (pv[..., 1] >= H - 0.5)
+    mask = ((~bad[..., 0]) & (~outside)).to(dt).unsqueeze(-1)
+    vf = fr["vis_featmaps"]
+    g2 = torch.stack([pv[..., 0] / (W - 1) * 2 - 1, pv[..., 1] / (H - 1) * 2 - 1], -1).unsqueeze(1)
+    rf = F.grid_sample(vf, g2, mode="bilinear", padding_mode="border", align_corners=(vf.shape[-2] == H and vf.shape[-1] == W))
+    rf = rf.squeeze(2).permute(0, 2, 1) * mask
+    pre = "multiview_aggregator.dist_decoder"
+    mean = F.softplus(_mlp3(p, f"{pre}.mean_decoder", rf)).view(V, rn, dn, -1)
+    var = (F.softplus(_mlp3(p, f"{pre}.var_decoder", rf)) + 0.05).view(V, rn, dn, -1)
+    aw = torch.sigmoid(_mlp3(p, f"{pre}.aw_decoder", rf)).view(V, rn, dn, -1)
+    vis0 = torch.sigmoid(_mlp3(p, f"{pre}.vis_decoder", rf)).view(V, rn, dn, -1)
+    # probability of a hit inside [d - half interval, d + half interval] (visibility_decoder.py:6-51, 150-181; is_ref = True)
+    d = ((-1.0 / torch.clamp(depth.view(V, rn, dn), min=1e-5) - ni) / (fi - ni))
+    half = dist[None] / 2
+    ext = torch.cat([half[..., 0:1], half], -1)
+    lo, hi = (d - ext[..., :-1]).unsqueeze(-1), (d + ext[..., 1:]).unsqueeze(-1)
+    mix = torch.cat([aw, 1 - aw], -1)
+    c0 = (0.5 + 0.5 * torch.tanh((lo - mean) * var)) * vis0
+    c1 = (0.5 + 0.5 * torch.tanh((hi - mean) * var)) * vis0
+    visib = torch.sum((1 - c0) * mix, -1)
+    hit = torch.sum((c1 - c0) * mix, -1)
+    alpha = torch.log(hit / (visib - hit + 1e-5) + 1e-5)
+    ground = -15.0
+    m = mask.view(V, rn, dn)
+    a = alpha * m + (1 - m) * ground
+    vs = visib * m
+    a = (a * vs).sum(0) / torch.clip(vs.sum(0), min=1e-8)
+    none = (m.sum(0) == 0).to(dt)
+    a = torch.sigmoid(a * (1 - none) + none * ground)
+    T = torch.cumprod(torch.cat([torch.ones_like(a[:, :1]), 1 - a], -1)[:, :-1], -1)
+    return a * T
+
+
+def sample_pdf_diff(bins: Tensor, weights: Tensor, u: Tensor, eps: float = 1e-5) -> Tensor:
+    """conditional_nerf/utils.py:73-112: inverse-CDF samples of the piecewise-constant pdf `weights` over `bins` at the uniform draws u."""
+    n_bins = weights.shape[1]
+    w = weights + eps
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    lo, hi = torch.clamp_min(inds - 1, 0), torch.clamp_max(inds, n_bins)
+    c_lo, c_hi = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b_lo, b_hi = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+    den = c_hi - c_lo
+    den = torch.where(den < eps, torch.ones_like(den), den)
+    return b_lo + (u - c_lo) / den * (b_hi - b_lo)
+
+
 # ----------------------------------------------------------------------------- training step (model.py:641-685)
 def backproject_support_diff(imgs: Tensor, feats: Tensor, depths: Tensor, Ks: Tensor, c2ws: Tensor, stride: int):
     """conditional_nerf/model.py:203-265 in autograd ops: every valid-depth pixel of every (nearest-resized) support view becomes a

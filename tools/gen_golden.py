@@ -246,29 +246,54 @@ def train_targets(cfg, seed):
     return rng.random((3, cfg.H, cfg.Wimg)).astype(np.float32), rng.standard_normal((1, cfg.C, cfg.H // 2, cfg.Wimg // 2)).astype(np.float32)
 
 
-def run_train_case(model_mod, name="train_setup"):
+def train_depth_target(cfg, seed):
+    """Seeded stand-in for the query frame's depth map (depth supervision): inside the depth range, ~15 % invalid (0)."""
+    rng = np.random.default_rng(seed)
+    d = (cfg.near + (cfg.far - cfg.near) * rng.random((cfg.H, cfg.Wimg))).astype(np.float32)
+    d[rng.random(d.shape) < 0.15] = 0.0
+    return d
+
+
+def run_train_case(model_mod, name="train_setup", hier=False):
     """One training step of the reference's render loss (model.py:641-685, losses.py:23-93) in train() mode: per-frame caches rebuilt
     with their graphs (support table, DepthFusionNet maps), beta head on; loss, psnr and the gradient of EVERY parameter the step
     reaches + of the fine feature maps (the 2D backbone's share)."""
     from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_weights
+    from nerf_loc_amd.synth import make_u
     cfg = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
+    if hier:   # hierarchical branch + depth supervision: depth_coarse carries a graph (losses.py:83-88), the resampled depths do not
+        cfg = cfg.replace(N_importance=16)
     frame = add_setup_inputs(cfg, make_frame(cfg))
     rays = make_rays(cfg, frame)
     weights = dict(make_weights(cfg))
     weights.update(make_depth_fusion_weights(cfg.seed))
-    net = model_mod.ConditionalNeRF(ref_args(cfg)).train()
+    args = ref_args(cfg)
+    args.use_depth_supervision = bool(hier)
+    net = model_mod.ConditionalNeRF(args).train()
     net.load_state_dict({k: t(v) for k, v in weights.items()}, strict=True)
     data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
     data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
     img, pyr = train_targets(cfg, cfg.seed + 2000)
     data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8, "scene": "s", "filename": "f",
                  "sample_coords": t(rays["pixel_coordinates"]), "img": t(img), "feat_pyramid": {"layer1": t(pyr)}})
+    orig_rand = torch.rand
+    if hier:
+        data["depth"] = t(train_depth_target(cfg, cfg.seed + 3000))
+        u = make_u(cfg)
+
+        def rand_fixed(*shape, **kw):
+            assert tuple(shape) == tuple(u.shape), (shape, u.shape)
+            return t(u).clone()
+        torch.rand = rand_fixed
     net.support_neural_points = None
     net.multiview_aggregator.vis_featmaps = None
     net.zero_grad()
-    with torch.enable_grad():
-        loss, psnr = net.compute_render_loss(data)
-        loss.backward()
+    try:
+        with torch.enable_grad():
+            loss, psnr = net.compute_render_loss(data)
+            loss.backward()
+    finally:
+        torch.rand = orig_rand
     save = {"loss": np.float64(loss.item()), "psnr": np.float64(psnr.item()), "grad_feat_fine_src": data["feat_fine_src"].grad.numpy()}
     reached = []
     for k, v in net.named_parameters():
@@ -376,7 +401,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "grad":
         for g in GRAD_CASES:
             run_grad_case(model_mod, ku, g)
-        return run_train_case(model_mod)
+        run_train_case(model_mod)
+        return run_train_case(model_mod, "train_hier", hier=True)
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
@@ -386,6 +412,7 @@ def main():
         for g in GRAD_CASES:
             run_grad_case(model_mod, ku, g)
         run_train_case(model_mod)
+        run_train_case(model_mod, "train_hier", hier=True)
 
 
 if __name__ == "__main__":
