@@ -22,6 +22,7 @@ NL_ERR_BAD_ARG, NL_ERR_UNSUPPORTED, NL_ERR_WORKSPACE, NL_ERR_HIP, NL_ERR_NO_DEVI
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 MAX_VIEWS = 16
+ABI_VERSION = 2   # include/nerfloc_render.h: NL_ABI_VERSION
 
 
 class NlConfig(C.Structure):
@@ -115,7 +116,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.nl_abi_version() != 2:
+    if lib.nl_abi_version() != ABI_VERSION:
         raise RuntimeError("libnerfloc_render.so ABI version mismatch")
     _lib = lib
     return lib

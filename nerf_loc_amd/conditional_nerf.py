@@ -173,6 +173,7 @@ class ConditionalNeRF(nn.Module):
     def support_neural_points(self, v):
         self.__dict__["_support_neural_points"] = v
         self.__dict__["_sp_gen"] = self.__dict__.get("_sp_gen", 0) + 1
+        self.__dict__["_sp_from_hip"] = False   # set by _build_support_hip: tables this module built itself, without a graph
 
     def __init__(self, args, activation_func=None, precision: str = "bf16x3", device: Optional[str] = None):
         super().__init__()
@@ -255,17 +256,67 @@ class ConditionalNeRF(nn.Module):
         token = (self._sp_gen, self.multiview_aggregator._vis_gen, data["topk_images"].data_ptr(), feat.data_ptr(),
                  data["topk_Ks"].data_ptr(), data["topk_poses"].data_ptr(), near, far, id(sp), id(vis))
         if self._frame_token.get(level) != token:
-            r.set_frame(data["topk_images"], feat, vis, data["topk_Ks"], data["topk_poses"], near, far, sp)
+            r.set_frame(data["topk_images"], feat.detach(), vis.detach(), data["topk_Ks"], data["topk_poses"], near, far,
+                        {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")})
             self._frame_token[level] = token
         return r
 
-    def _vis_featmaps(self, data):
+    def _vis_featmaps(self, data, graph: bool = False):
+        """The DepthFusionNet maps cache (multiview_aggregator.py:29,178).  graph=True (training): the maps must carry their graph to the
+        CNN's parameters / the feature maps like the reference's do — recomputed once per frame when the cached tensor has none and
+        something upstream can actually receive a gradient."""
         agg = self.multiview_aggregator
+        if graph and agg.vis_featmaps is not None and not agg.vis_featmaps.requires_grad and \
+                (data["feat_fine_src"].requires_grad or any(q.requires_grad for q in agg.depth_fusion.parameters())):
+            agg.vis_featmaps = None
         if agg.vis_featmaps is None:
-            with torch.no_grad():
+            with torch.set_grad_enabled(graph and torch.is_grad_enabled()):
                 agg.vis_featmaps = agg.depth_fusion(data["topk_images"], data["feat_fine_src"].permute(0, 3, 1, 2), data["topk_depths"],
                                                     data["topk_Ks"], data["topk_poses"], data["depth_range"][0])
         return agg.vis_featmaps
+
+    # ------------------------------------------------------------------ gradient-path plumbing (nerf_loc_amd/diff_render.py)
+    def _graph_params(self, weights_graph: bool):
+        """Parameter dict of the gradient path: the live parameters (their graph is kept) or detached constants."""
+        if weights_graph:
+            return {**dict(self.named_buffers()), **dict(self.named_parameters())}
+        return {k: v.detach() for k, v in self.state_dict().items()}
+
+    def _frame_dict(self, data, level: str, graph: bool):
+        """`fr` of diff_render's functions for one level.  graph: per-frame caches with their graphs (training)."""
+        fnear, ffar = [float(x) for x in data["depth_range"][0]]
+        sp = self.support_neural_points[level]
+        if not graph:
+            sp = {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")}
+        vis = self._vis_featmaps(data, graph)
+        return {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"],
+                "feat_fine_src": data["feat_fine_src"] if level == "fine" else data["feat_coarse_src"],
+                "vis_featmaps": vis if graph else vis.detach(), "near": fnear, "far": ffar, "support": sp}
+
+    def _ensure_support(self, data):
+        """The `support_neural_points is None` guard of every reference entry point (model.py:278,313,473), plus: tables cached by an
+        earlier no_grad call are rebuilt with their graphs when a training step needs them."""
+        if self.support_neural_points is None:
+            return self.build_support_neural_points(data)
+        if self.training and torch.is_grad_enabled() and self.__dict__.get("_sp_from_hip", False):
+            self._build_support_graph(data)   # (tables the CALLER injected are never replaced)
+
+    def _build_support_graph(self, data):
+        """build_support_neural_points as the reference runs it in a training step (model.py:144-201 outside no_grad): both tables carry
+        their graph — features gathered from the backbone's maps, fine confidence = confidence_mlp(aggregate at the points), coarse
+        keypoint scores — and are cached for the whole frame, so query_coarse, query_fine and compute_render_loss of one step share one
+        graph (and one DepthFusionNet pass) like the reference's module caches do."""
+        p = self._graph_params(True)
+        fnear, ffar = [float(x) for x in data["depth_range"][0]]
+        fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"],
+              "feat_fine_src": data["feat_fine_src"], "vis_featmaps": self._vis_featmaps(data, True), "near": fnear, "far": ffar}
+        fine = diff_render.support_tables_diff(p, fr, data["topk_depths"], int(data["stride_fine"]))
+        coarse = diff_render.coarse_support_diff(p, data["topk_images"], data["feat_coarse_src"], data["topk_depths"], data["topk_Ks"],
+                                                 data["topk_poses"], int(data["stride_coarse"]))
+        self.support_neural_points = {"coarse": coarse, "fine": fine}
+        self._frame_token.clear()
+        if len(coarse["xyz"]) == 0:
+            print(f"Error: zero support_neural_points {data.get('scene')} : {data.get('filename')}")
 
     # ------------------------------------------------------------------ per-frame setup (a21)
     def backproject_support_frame(self, imgs, feats, depths, Ks, c2ws, stride=1):
@@ -279,9 +330,15 @@ class ConditionalNeRF(nn.Module):
         mv, _, _, _ = r.mv_aggregate(points, data["pose"][:3, 3] if "pose" in data else torch.zeros(3), want_raw=False)
         return self.confidence_mlp(mv)
 
-    @torch.no_grad()
     def build_support_neural_points(self, data):
-        """model.py:144-201."""
+        """model.py:144-201.  Inference: HIP back-projection under no_grad.  In train() mode with autograd on the tables are built
+        WITH their graphs (the reference builds them inside the training step's graph): `_build_support_graph`."""
+        if self.training and torch.is_grad_enabled():
+            return self._build_support_graph(data)
+        with torch.no_grad():
+            return self._build_support_hip(data)
+
+    def _build_support_hip(self, data):
         d = data
         desc_c, pts_c, ndc_c, dir_c = self.backproject_support_frame(d["topk_images"], d["feat_coarse_src"], d["topk_depths"], d["topk_Ks"],
                                                                      d["topk_poses"], stride=d["stride_coarse"])
@@ -299,6 +356,7 @@ class ConditionalNeRF(nn.Module):
             "fine": fine,
         }
         self._frame_token.clear()   # (the assignment above bumped the generation too) every level rebuilds its tables on next use
+        self.__dict__["_sp_from_hip"] = True
         if len(pts_c) == 0:
             print(f"Error: zero support_neural_points {d.get('scene')} : {d.get('filename')}")
 
@@ -313,10 +371,37 @@ class ConditionalNeRF(nn.Module):
     def query(self, data, xyz, support_featmaps=None, support_neural_points=None, direction=None, K=8, embed_a=None, target_proj_mat=None):
         """model.py:344-436.  `support_featmaps` / `support_neural_points` select the level exactly like the reference's
         call sites do (fine: model.py:325-331,509-517; coarse: :296-302)."""
-        self._refuse_autograd("query", xyz, direction, data.get("pose"))
-        if self.support_neural_points is None:
-            self.build_support_neural_points(data)
+        self._ensure_support(data)
         level = "coarse" if (support_neural_points is not None and support_neural_points is self.support_neural_points.get("coarse")) else "fine"
+        if self._query_wants_graph(data, level, xyz, direction):
+            return self._query_grad(data, xyz, level, direction, K)
+        with torch.no_grad():
+            return self._query_hip(data, xyz, level, direction, K)
+
+    def _query_wants_graph(self, data, level, xyz, direction) -> bool:
+        """A descriptor query needs the gradient path whenever autograd could reach anything through it: train() mode (the matcher loss
+        trains base_mlp / the attention / the aggregator / the 2-D backbone through 'feature_agg', nerf_pose_estimator.py:316-320,
+        445-448, 465-468), trainable weights under enable_grad, or an input / feature map / support table that requires grad.  The HIP
+        path returns detached tensors and is only taken when nothing can."""
+        if not torch.is_grad_enabled():
+            return False
+        if self.training or any(q.requires_grad for q in self.parameters()):
+            return True
+        sp = self.support_neural_points[level]
+        maps = data["feat_fine_src"] if level == "fine" else data["feat_coarse_src"]
+        return self._wants_grad(xyz, direction, maps, data.get("feat_fine_src"), self.multiview_aggregator.vis_featmaps, sp["feature"], sp["confidence"])
+
+    def _query_grad(self, data, xyz, level, direction, K):
+        """model.py:344-436 on the gradient path (diff_render.query_diff: fp32 autograd on the GPU, exact KNN indices from the HIP
+        library).  Weights keep their graph in train() mode or when they require grad; the per-frame caches keep theirs when they were
+        built in a training step (`_build_support_graph`)."""
+        weights_graph = self.training or any(q.requires_grad for q in self.parameters())
+        fr = self._frame_dict(data, level, graph=True)
+        r = self._ensure_frame(data, level)
+        idx = r.knn(xyz.detach(), K)[1].long()
+        return diff_render.query_diff(self._graph_params(weights_graph), fr, xyz, direction, idx)
+
+    def _query_hip(self, data, xyz, level, direction, K):
         r = self._ensure_frame(data, level)
         mv, rgb_feat, vis_ang, _ = r.mv_aggregate(xyz, data["pose"][:3, 3] if "pose" in data else torch.zeros(3))
         dirs = None if direction is None else direction[:, :3].contiguous()
@@ -333,12 +418,11 @@ class ConditionalNeRF(nn.Module):
 
     def _nearest_feature(self, level, points, data):
         r = self._ensure_frame(data, level)
-        _, idx = r.knn(points, 1)
+        _, idx = r.knn(points.detach(), 1)
         return self.support_neural_points[level]["feature"][idx[:, 0].long()]
 
     def query_coarse(self, data, points=None, embed_a=None):
-        if self.support_neural_points is None:
-            self.build_support_neural_points(data)
+        self._ensure_support(data)
         if points is None:
             pts3d, pts3d_ndc, sidx = self.sample_points_3d()
             feat2d = self.support_neural_points["coarse"]["feature"][sidx]
@@ -354,8 +438,7 @@ class ConditionalNeRF(nn.Module):
         return desc, pts3d, pts3d_ndc
 
     def query_fine(self, data, points, embed_a=None):
-        if self.support_neural_points is None:
-            self.build_support_neural_points(data)
+        self._ensure_support(data)
         feat2d = self._nearest_feature("fine", points, data)
         q = self.query(data, points, support_neural_points=self.support_neural_points["fine"], K=1, embed_a=embed_a)
         desc = self.proj_layer_3d_fine(torch.cat([q["feature_agg"], feat2d], 1))
@@ -407,24 +490,12 @@ class ConditionalNeRF(nn.Module):
           the reference's (fine support table: features gathered from the feature maps, confidence_mlp on the aggregate;
           DepthFusionNet maps), `beta` is returned.
         Both are checked against the reference's autograd in tests/test_diff_render.py."""
-        fnear, ffar = [float(x) for x in data["depth_range"][0]]
         if train:
-            p = {**dict(self.named_buffers()), **dict(self.named_parameters())}
-            if self.support_neural_points is None:
-                self.build_support_neural_points(data)   # both levels on the HIP library (no graph): the coarse level for the other callers
-            agg = self.multiview_aggregator
-            if agg.vis_featmaps is None or not agg.vis_featmaps.requires_grad:
-                agg.vis_featmaps = agg.depth_fusion(data["topk_images"], data["feat_fine_src"].permute(0, 3, 1, 2), data["topk_depths"],
-                                                    data["topk_Ks"], data["topk_poses"], data["depth_range"][0])
-            fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"],
-                  "feat_fine_src": data["feat_fine_src"], "vis_featmaps": agg.vis_featmaps, "near": fnear, "far": ffar}
-            fr["support"] = diff_render.support_tables_diff(p, fr, data["topk_depths"], int(data["stride_fine"]))
-            r = self._renderer("fine")   # the KNN grid over exactly these points
-            r.set_frame(data["topk_images"], data["feat_fine_src"].detach(), agg.vis_featmaps.detach(), data["topk_Ks"], data["topk_poses"], fnear, ffar,
-                        {k: v.detach() for k, v in fr["support"].items()})
-            self._frame_token.pop("fine", None)
-        else:
-            r = self._ensure_frame(data, "fine")
+            # the per-frame caches with their graphs, built once per frame and shared with the descriptor queries of the same step
+            self._ensure_support(data)
+            p = self._graph_params(True)
+            fr = self._frame_dict(data, "fine", graph=True)
+        r = self._ensure_frame(data, "fine")   # the KNN grid over exactly these points (keyed on the caches' generation counters)
         near, far = rays["depth_range"]
         o, d = rays["rays_o"], rays["rays_d"]
         R, N = o.shape[0], self.args.render.N_samples
@@ -446,12 +517,9 @@ class ConditionalNeRF(nn.Module):
                     u = torch.rand(R, self.args.render.N_importance, device=o.device)
                 z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"].detach(), z, u,
                                                            near=float(near), far=float(far))
-        if not train:
-            sp = self.support_neural_points["fine"]
-            fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"], "feat_fine_src": data["feat_fine_src"],
-                  "vis_featmaps": self._vis_featmaps(data), "near": fnear, "far": ffar,
-                  "support": {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")}}
-            p = {k: v.detach() for k, v in self.state_dict().items()}
+        if not train:   # eval mode: the weights and the per-frame caches are constants (PoseOptimizer optimises the pose only)
+            fr = self._frame_dict(data, "fine", graph=False)
+            p = self._graph_params(False)
         out = diff_render.render_rays_diff(p, fr, o, d, z.to(o.dtype), data["pose"], lambda q: r.knn(q, 8)[1],
                                            white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
                                            beta=train and bool(self.args.render.use_render_uncertainty))

@@ -113,16 +113,25 @@ def _mv_aggregate(p, fr, xyz: Tensor):
     return G, rgb_feat, vis, mask1
 
 
-def _point_branch(p, fr, xyz: Tensor, dirs: Tensor, G: Tensor, idx: Tensor):
-    """conditional_nerf/model.py:344-436 + ibrnet.py:89-119: K = 8 neural points per sample (indices given), relative-position /
-    ray-difference encoding, 3-layer MLP, 4-head attention with the multi-view feature as query, distance x confidence x learnt weights."""
+def _point_branch(p, fr, xyz: Tensor, dirs: Optional[Tensor], G: Tensor, idx: Tensor, full: bool = False):
+    """conditional_nerf/model.py:344-436 + ibrnet.py:89-119: K nearest neural points per sample (indices given), relative-position /
+    ray-difference encoding, 3-layer MLP, 4-head attention with the multi-view feature as query, distance x confidence x learnt weights.
+    dirs None: the nearest neighbour's viewing direction (model.py:391-392, the descriptor queries).  Fewer support points than K: the
+    missing neighbours are zero rows at squared distance 0 (knn_utils.py:48-53, 211-220) — they take part in the attention and get
+    weight 0 through their zero confidence.  full: also return the per-neighbour features (N, K, W) and weights (N, K)."""
     sp = fr["support"]
-    K = idx.shape[1]
-    if sp["xyz"].shape[0] < K:
-        raise NotImplementedError("gradient path: fewer support points than K (the reference zero-fills the missing neighbours)")
-    nb_xyz, nb_feat, nb_conf, nb_dir = sp["xyz"][idx], sp["feature"][idx], sp["confidence"][idx], sp["direction"][idx]
+    K, M = idx.shape[1], sp["xyz"].shape[0]
+    keep = None if M >= K else (torch.arange(K, device=idx.device) < M)
+
+    def take(t):
+        g = t[idx]
+        return g if keep is None else g * keep.view(1, K, 1).to(g.dtype)
+    nb_xyz, nb_feat, nb_conf, nb_dir = take(sp["xyz"]), take(sp["feature"]), take(sp["confidence"]), take(sp["direction"])
+    if dirs is None:
+        dirs = nb_dir[:, 0, :3]
     off = xyz[:, None, :] - nb_xyz
     d2 = (off * off).sum(-1)     # = the KNN op's squared distances; its backward (knn_cpu.cpp:68-117) is 2 (p1 - p2) grad, as autograd gives here
+    dist = d2.sqrt() if keep is None else torch.where(keep.view(1, K), d2.clamp_min(1e-30).sqrt(), torch.zeros_like(d2))
     rd = dirs[:, None, :] - nb_dir[..., :3]
     rd = rd / (torch.norm(rd, dim=-1, keepdim=True) + 1e-8)
     rd = torch.cat([rd, torch.sum(dirs[:, None, :] * nb_dir[..., :3], dim=-1, keepdim=True)], -1)
@@ -141,9 +150,21 @@ def _point_branch(p, fr, xyz: Tensor, dirs: Tensor, G: Tensor, idx: Tensor):
     o = _lin(p, f"{pre}.fc", o, False) + q
     feat = F.layer_norm(o, (o.shape[-1],), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], eps=1e-6)
     lg = _lin(p, "base_mlp_agg_weight.2", _lrelu(_lin(p, "base_mlp_agg_weight.0", feat))).squeeze(-1)
-    w = 1.0 / torch.clamp(d2.sqrt(), min=1e-8) * F.softmax(lg, dim=1) * nb_conf.squeeze(-1)
+    w = 1.0 / torch.clamp(dist, min=1e-8) * F.softmax(lg, dim=1) * nb_conf.squeeze(-1)
     w = w / torch.clamp(w.sum(dim=1, keepdim=True), min=1e-8)
-    return (feat * w.unsqueeze(-1)).sum(dim=1)
+    agg = (feat * w.unsqueeze(-1)).sum(dim=1)
+    return (agg, feat, w) if full else agg
+
+
+def query_diff(p: Dict[str, Tensor], fr: Dict, xyz: Tensor, direction: Optional[Tensor], idx: Tensor) -> Dict[str, Tensor]:
+    """ConditionalNeRF.query (conditional_nerf/model.py:344-436) with autograd: the descriptor queries' core.  `fr['feat_fine_src']`
+    holds the feature maps of the queried level (the reference passes `feat_coarse_src` for query_coarse, model.py:296-302) and
+    `fr['support']` that level's support table; idx (N, K) int64 = the exact KNN of xyz in it (no gradient: indices).  The matcher's
+    training signal reaches base_mlp / the attention / the aggregator / the feature maps through 'feature_agg'
+    (nerf_pose_estimator.py:316-320, 445-448, 465-468)."""
+    G, mvf, mvv, _ = _mv_aggregate(p, fr, xyz)
+    agg, feat, w = _point_branch(p, fr, xyz, None if direction is None else direction[:, :3], G, idx, full=True)
+    return {"feature_agg": agg, "feature": feat, "weights": w, "multiview_feature": mvf, "multiview_visibility": mvv}
 
 
 def _ray_unet(p, x: Tensor) -> Tensor:
@@ -321,10 +342,18 @@ def backproject_support_diff(imgs: Tensor, feats: Tensor, depths: Tensor, Ks: Te
 def support_tables_diff(p: Dict[str, Tensor], fr: Dict, depths: Tensor, stride: int) -> Dict[str, Tensor]:
     """The fine-level support table with its graph (model.py:144-201, 137-142): features gathered from the feature maps, confidence =
     confidence_mlp(multi-view aggregate at the points).  fr as for render_rays_diff, without 'support'."""
-    desc, xyz, _, dirs = backproject_support_diff(fr["topk_images"], fr["feat_fine_src"], depths, fr["topk_Ks"], fr["topk_poses"], stride)
+    desc, xyz, ref, dirs = backproject_support_diff(fr["topk_images"], fr["feat_fine_src"], depths, fr["topk_Ks"], fr["topk_poses"], stride)
     G = _mv_aggregate(p, fr, xyz)[0]
     conf = torch.sigmoid(_lin(p, "confidence_mlp.2", _lrelu(_lin(p, "confidence_mlp.0", G))))
-    return {"xyz": xyz, "feature": desc, "confidence": conf, "direction": dirs}
+    return {"xyz": xyz, "xyz_ndc": ref, "feature": desc, "confidence": conf, "direction": dirs}
+
+
+def coarse_support_diff(p: Dict[str, Tensor], imgs: Tensor, feats_coarse: Tensor, depths: Tensor, Ks: Tensor, c2ws: Tensor, stride: int) -> Dict[str, Tensor]:
+    """The coarse-level support table with its graph (model.py:144-201): features gathered from the coarse feature maps, confidence 1,
+    keypoint_score = keypoint_head(feature) (what `sample_points_3d` draws from)."""
+    desc, xyz, ref, dirs = backproject_support_diff(imgs, feats_coarse, depths, Ks, c2ws, stride)
+    return {"xyz": xyz, "xyz_ndc": ref, "feature": desc, "confidence": torch.ones_like(xyz[:, :1]), "direction": dirs,
+            "keypoint_score": torch.sigmoid(_lin(p, "keypoint_head.0", desc[:, 3:]))}
 
 
 def to_inverse_normalized_depth(depth: Tensor, near, far) -> Tensor:

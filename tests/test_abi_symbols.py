@@ -64,3 +64,9 @@ def test_render_opts_struct_matches_the_header():
     assert L.NlRenderOpts.early_term_eps.offset == 0 and L.NlRenderOpts.ray_centers.offset == 8
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "nerfloc_render.h")).read()
     assert "#define NL_ABI_VERSION 2" in hdr and "const float* ray_centers;" in hdr
+
+
+def test_build_post_check_agrees_with_the_header():
+    """__graft_entry__.build() ends with this check (round 2 shipped a stale hard-coded version there)."""
+    import __graft_entry__ as g
+    g.post_build_check()

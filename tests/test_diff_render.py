@@ -261,3 +261,113 @@ def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier,
     net.multiview_aggregator.vis_featmaps = None
     loss2, _ = net.compute_render_loss(data)
     assert float(loss2.detach()) < float(loss.detach())
+
+
+# ----------------------------------------------------------------------------- matcher-side training signal (query_coarse / query_fine)
+def _query_case(device):
+    from tests.golden_cases import build_setup_case
+    case = build_setup_case("setup")
+    cfg, frame = case["cfg"], case["frame"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
+    data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
+    data["feat_coarse_src"] = data["feat_coarse_src"].clone().requires_grad_(True)
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8})
+    rng = np.random.default_rng(cfg.seed + 4000)   # = tools/gen_golden.py query_train_inputs
+    base = frame["support_fine"]["xyz"][::7][:48]
+    pts = (base + 0.004 * rng.standard_normal((len(base), 3)).astype(np.float32)).astype(np.float32)
+    tc, tf = rng.standard_normal((len(pts), 192)).astype(np.float32), rng.standard_normal((len(pts), 192)).astype(np.float32)
+    return case, cfg, data, t(pts), t(tc), t(tf)
+
+
+def _check_query_train(loss, desc_c, desc_f, ndc, named, data, tol):
+    g = np.load(os.path.join(GOLD, "train_query.npz"))
+    assert abs(float(loss.detach()) - float(g["loss"])) < tol * abs(float(g["loss"]))
+    errs = {"desc_coarse": rel_err(desc_c.detach().cpu().numpy(), g["desc_coarse"]), "desc_fine": rel_err(desc_f.detach().cpu().numpy(), g["desc_fine"]),
+            "pts3d_ndc": rel_err(ndc.detach().cpu().numpy(), g["pts3d_ndc"]),
+            "feat_fine_src": rel_err(data["feat_fine_src"].grad.cpu().numpy(), g["grad_feat_fine_src"]),
+            "feat_coarse_src": rel_err(data["feat_coarse_src"].grad.cpu().numpy(), g["grad_feat_coarse_src"])}
+    gmax = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith(("grad:", "gsub:")))
+    for key in g.files:
+        if key.startswith("grad:"):
+            ours = named[key[5:]].grad
+            assert ours is not None, key
+            errs[key[5:]] = float(np.abs(ours.cpu().numpy() - g[key]).max() / max(np.abs(g[key]).max(), 1e-5 * gmax))
+        elif key.startswith("gsub:"):
+            full = named[key[5:]].grad.cpu().numpy()
+            errs[key[5:]] = float(np.abs(full.reshape(-1)[::7] - g[key]).max() / max(np.abs(g[key]).max(), 1e-5 * gmax))
+    want = {k.split(":", 1)[1] for k in g.files if k.startswith(("grad:", "gsub:")) and float(np.abs(g[k]).max()) > 1e-5 * gmax}
+    reached = {k for k, v in named.items() if v.grad is not None and float(v.grad.abs().max()) > 1e-5 * gmax}
+    assert reached == want, (sorted(reached ^ want))
+    # the point of the case: the matcher's gradient reaches the neural-point MLP, the attention, the aggregator and its per-frame CNN
+    for k in ("base_mlp.0.weight", "base_mlp_attn.w_vs.weight", "multiview_aggregator.out_fc.0.weight",
+              "multiview_aggregator.depth_fusion.conv_out.weight", "proj_layer_3d_coarse.weight", "proj_layer_3d_fine.weight"):
+        assert k in want and float(named[k].grad.abs().max()) > 0, k
+    # tensors whose gradient is mathematically zero here (confidence_mlp: with K = 1 the normalised weight is conf / conf) hold rounding
+    # noise below 1e-5 of the step's largest gradient in the reference: they only have to stay noise
+    bad = {k: e for k, e in errs.items() if not e < (tol if (k in want or k not in named) else 0.1)}
+    assert not bad, bad
+    return {k: e for k, e in errs.items() if k in want or k not in named}
+
+
+def test_query_training_gradients_through_the_dropin_match_reference_autograd_cpu(monkeypatch):
+    """Train-mode query_coarse / query_fine on the drop-in module (round 2 returned detached descriptors here): the per-frame tables
+    are built inside the graph and the gradient of a functional of desc_3d / desc_3d_fine reaches the 128 parameter tensors the
+    reference's autograd reaches + both feature maps (tests/golden/train_query.npz).  CPU: the two library calls of this path — the
+    exact KNN and DepthFusionNet's hand-made input — are served by the brute-force KNN and the setup oracle."""
+    from oracle import setup_oracle as sorc
+    from tests.test_dropin_module import _args
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    case, cfg, data, pts, tc, tf = _query_case("cpu")
+    net = ConditionalNeRF(_args(cfg)).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+
+    class _Knn:
+        def __init__(self, xyz): self.f = {K: knn_bruteforce(xyz.detach(), K) for K in (1, 8)}
+        def knn(self, q, K): return None, self.f[K](q)
+    monkeypatch.setattr(net, "_ensure_frame", lambda d, level: _Knn(net.support_neural_points[level]["xyz"]))
+    df = net.multiview_aggregator.depth_fusion
+    monkeypatch.setattr(df, "forward", lambda imgs, feats, depths, Ks, poses, dr_: df.encode(
+        sorc.cnn_input(imgs, depths, Ks, poses, float(dr_[0]), float(dr_[1]))))
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    desc_c, p3, ndc = net.query_coarse(data, pts)
+    desc_f, _, _ = net.query_fine(data, pts)
+    assert desc_c.requires_grad and desc_f.requires_grad
+    loss = (desc_c * tc).sum() / len(pts) + (desc_f * tf).sum() / len(pts)
+    loss.backward()
+    # (5e-4: two small DepthFusionNet tensors sit at 2.7e-4 under a different fp32 summation order; the heads are at 1e-7, the CNN tensors around 5e-5)
+    errs = _check_query_train(loss, desc_c, desc_f, ndc, dict(net.named_parameters()), data, 5e-4)
+    assert float(np.median(list(errs.values()))) < 1e-4
+    print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    # eval mode under no_grad still takes the (HIP) inference path: without a GPU that raises instead of silently computing on the CPU
+    net.eval()
+    monkeypatch.undo()
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        net.query_fine(data, pts)
+
+
+@pytest.mark.gpu
+def test_query_training_gradients_through_the_dropin_match_reference_autograd_gpu():
+    """The same on the GPU: HIP KNN + HIP cross-view features, matcher-side gradients reach base_mlp.0.weight (and 127 more)."""
+    from tests.test_dropin_module import _args
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    dev = torch.device("cuda:0")
+    case, cfg, data, pts, tc, tf = _query_case(dev)
+    net = ConditionalNeRF(_args(cfg), precision="fp32").to(dev).train()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    desc_c, p3, ndc = net.query_coarse(data, pts)
+    desc_f, _, _ = net.query_fine(data, pts)
+    loss = (desc_c * tc).sum() / len(pts) + (desc_f * tf).sum() / len(pts)
+    loss.backward()
+    errs = _check_query_train(loss, desc_c, desc_f, ndc, dict(net.named_parameters()), data, 3e-3)
+    assert float(np.median(list(errs.values()))) < 1e-4
+    print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    # the graph path's forward equals the HIP inference path's descriptors
+    net.eval()
+    with torch.no_grad():
+        hc, _, _ = net.query_coarse(data, pts)
+        hf, _, _ = net.query_fine(data, pts)
+    assert rel_err(hc.cpu().numpy(), desc_c.detach().cpu().numpy()) < 1e-4 and rel_err(hf.cpu().numpy(), desc_f.detach().cpu().numpy()) < 1e-4

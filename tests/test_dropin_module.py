@@ -93,6 +93,12 @@ def test_dropin_end_to_end_matches_reference(case_name, precision, tol):
     err_a = {k: rel_err(out_a[k].cpu().numpy(), g[k]) for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat")}
     assert max(err_a.values()) < 1e-4, ("library alone (reference vis_featmaps injected)", precision, err_a)
     assert np.array_equal(out_a["mask"].cpu().numpy(), g["mask"])
+    pts = torch.from_numpy(g["query_pts"]).to(dev)
+    with torch.no_grad():   # the HIP descriptor queries (row f3) at 1e-4 as well, the CNN again taken out of the comparison
+        qa_f, _, _ = net.query_fine(data, pts)
+        qa_c, _, _ = net.query_coarse(data, pts)
+    err_q = {"desc_fine": rel_err(qa_f.cpu().numpy(), g["desc_fine"]), "desc_coarse": rel_err(qa_c.cpu().numpy(), g["desc_coarse"])}
+    assert max(err_q.values()) < 1e-4, ("descriptor queries, library alone", precision, err_q)
     # Stage B — end to end, CNN included: `tol` covers MIOpen-vs-CPU convolution differences in vis_featmaps (measured below) on top
     net.support_neural_points = None
     net.multiview_aggregator.vis_featmaps = None
@@ -108,9 +114,10 @@ def test_dropin_end_to_end_matches_reference(case_name, precision, tol):
     err_b = {k: rel_err(out[k].cpu().numpy(), g[k]) for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat")}
     assert max(err_b.values()) < tol, ("end to end", precision, err_b, "library alone", err_a, "vis_featmaps (per-frame CNN on MIOpen)", err_cnn)
     assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
-    pts = torch.from_numpy(g["query_pts"]).to(dev)
-    desc_f, _, _ = net.query_fine(data, pts)
-    desc_c, _, _ = net.query_coarse(data, pts)
+    with torch.no_grad():   # (under enable_grad with trainable weights the queries take the gradient path: tests/test_diff_render.py)
+        desc_f, _, _ = net.query_fine(data, pts)
+        desc_c, _, _ = net.query_coarse(data, pts)
+    assert not desc_f.requires_grad
     assert rel_err(desc_f.detach().cpu().numpy(), g["desc_fine"]) < tol
     assert rel_err(desc_c.detach().cpu().numpy(), g["desc_coarse"]) < tol
     # render_image (model.py:602-639): all pixels in one library call; a pixel's result does not depend on the batch it is in
@@ -145,6 +152,7 @@ def _module_and_data(case, dev, precision="bf16x3"):
 
 
 @pytest.mark.gpu
+@torch.no_grad()   # the inference path (HIP queries); under enable_grad the queries take the gradient path
 def test_frame_tables_follow_the_callers_cache_reset():
     """nerf_pose_estimator.py:289-290 resets `support_neural_points` and `vis_featmaps` by plain assignment for every query frame.
     Frame B below has the SAME tensor shapes as frame A and is written into the SAME device buffers (worst case for keys made of
@@ -194,12 +202,11 @@ def test_cache_attributes_count_generations():
 
 def test_entry_points_without_a_gradient_path_refuse_autograd():
     """The detached HIP outputs must not silently swallow a gradient: entry points that have no gradient path say so (CPU: no renderer
-    involved).  render_rays / points_2d_to_rays do have one (next test)."""
+    involved).  render_rays / points_2d_to_rays and — since round 3 — query / query_coarse / query_fine do have one
+    (tests/test_diff_render.py)."""
     from nerf_loc_amd.conditional_nerf import ConditionalNeRF
     net = ConditionalNeRF(_args(CFG)).eval()
     with torch.enable_grad():
-        with pytest.raises(NotImplementedError, match="requires grad"):
-            net.query({"pose": torch.eye(4, requires_grad=True)}, torch.zeros(3, 3))
         with pytest.raises(NotImplementedError, match="requires grad"):
             net.render_image({"pose": torch.eye(4, requires_grad=True), "K": torch.eye(3)})
 

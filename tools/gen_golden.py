@@ -310,6 +310,57 @@ def run_train_case(model_mod, name="train_setup", hier=False):
     print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) loss={loss.item():.6f} psnr={psnr.item():.4f} parameters with gradient: {len(reached)}")
 
 
+def query_train_inputs(cfg, frame, seed):
+    """Seeded inputs of the `train_query` case: query points near the fine support points (as the matcher's 3-D keypoints are) and the
+    two cotangents that stand in for the matcher losses' gradients at desc_3d / desc_3d_fine."""
+    rng = np.random.default_rng(seed)
+    pts = frame["support_fine"]["xyz"][::7][:48] + 0.004 * rng.standard_normal((len(frame["support_fine"]["xyz"][::7][:48]), 3)).astype(np.float32)
+    return pts.astype(np.float32), rng.standard_normal((len(pts), 192)).astype(np.float32), rng.standard_normal((len(pts), 192)).astype(np.float32)
+
+
+def run_query_train_case(model_mod, name="train_query"):
+    """The matcher-side training signal (nerf_pose_estimator.py:289-320, 445-468): in train() mode, caches reset, query_coarse(points)
+    then query_fine(points) — the per-frame tables are built inside the graph — and a linear functional of the two descriptor sets
+    back-propagated to EVERY parameter it reaches and to both feature maps."""
+    from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_weights
+    cfg = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
+    frame = add_setup_inputs(cfg, make_frame(cfg))
+    weights = dict(make_weights(cfg))
+    weights.update(make_depth_fusion_weights(cfg.seed))
+    net = model_mod.ConditionalNeRF(ref_args(cfg)).train()
+    net.load_state_dict({k: t(v) for k, v in weights.items()}, strict=True)
+    data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
+    data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
+    data["feat_coarse_src"] = data["feat_coarse_src"].clone().requires_grad_(True)
+    data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8, "scene": "s", "filename": "f"})
+    pts, tc, tf = query_train_inputs(cfg, frame, cfg.seed + 4000)
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    net.zero_grad()
+    with torch.enable_grad():
+        desc_c, p3, p3n = net.query_coarse(data, t(pts))
+        desc_f, _, _ = net.query_fine(data, t(pts))
+        loss = (desc_c * t(tc)).sum() / len(pts) + (desc_f * t(tf)).sum() / len(pts)
+        loss.backward()
+    save = {"loss": np.float64(loss.item()), "desc_coarse": desc_c.detach().numpy(), "desc_fine": desc_f.detach().numpy(),
+            "pts3d_ndc": p3n.detach().numpy(), "grad_feat_fine_src": data["feat_fine_src"].grad.numpy(),
+            "grad_feat_coarse_src": data["feat_coarse_src"].grad.numpy()}
+    reached = []
+    for k, v in net.named_parameters():
+        if v.grad is not None and float(v.grad.abs().max()) > 0:
+            gnp = v.grad.numpy()
+            if gnp.size > 8192:
+                save["gsub:" + k] = gnp.reshape(-1)[::7].copy()
+                save["gnorm:" + k] = np.float64(np.linalg.norm(gnp.astype(np.float64)))
+            else:
+                save["grad:" + k] = gnp
+            reached.append(k)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **save)
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB) loss={loss.item():.6f} parameters with gradient: {len(reached)}; "
+          f"base_mlp.0.weight |g|max={float(dict(net.named_parameters())['base_mlp.0.weight'].grad.abs().max()):.3e}")
+
+
 def punch_holes(frame, seed):
     """Ragged support depth for the `setup_holes` case: ~35 % of the pixels invalid (0), a few negative, one view with no valid
     depth at all — nonzero()'s order and the empty-view path of backproject_support_frame (model.py:231)."""
@@ -402,7 +453,10 @@ def main():
         for g in GRAD_CASES:
             run_grad_case(model_mod, ku, g)
         run_train_case(model_mod)
-        return run_train_case(model_mod, "train_hier", hier=True)
+        run_train_case(model_mod, "train_hier", hier=True)
+        return run_query_train_case(model_mod)
+    if len(sys.argv) > 1 and sys.argv[1] == "query":
+        return run_query_train_case(model_mod)
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
@@ -413,6 +467,7 @@ def main():
             run_grad_case(model_mod, ku, g)
         run_train_case(model_mod)
         run_train_case(model_mod, "train_hier", hier=True)
+        run_query_train_case(model_mod)
 
 
 if __name__ == "__main__":
