@@ -63,10 +63,21 @@ def main():
                     help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: strong for c3/c4)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the launcher's own
+        # form of this command line is what the driver uses; both end in the same code below)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
@@ -88,7 +99,12 @@ def main():
         elif one_gpu:
             dist.init_process_group("gloo")
         else:
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} HIP devices are visible (NERFLOC_BENCH_ONE_GPU=1 runs the "
+                                 "control flow on one device over gloo: a functional check, never a reported number)")
             dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from nerf_loc_amd.renderer import HipRenderer
     from nerf_loc_amd.sharding import gather_ray_outputs_async, shard_range
@@ -212,7 +228,9 @@ def main():
                    "rays_per_gpu": R_local, "precision": args.precision,
                    "early_term_eps": et_eps,   # random-init weights give a thin medium: nothing terminates early, the option only costs its two tiny kernels
                    "parallelism": f"ray-shard x{dist.get_world_size() if dist is not None else 1} ({scaling})"
-                                  + (f" + {dist.get_backend()} all-gather" if gather else "")},
+                                  + (f" + {dist.get_backend()} all-gather" if gather else ""),
+                   "collective_world_size": dist.get_world_size() if dist is not None else 1,
+                   "collective_backend": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None)},
         "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                      "traffic": hbm_traffic(args.config, args.precision), "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
                      "flops_per_step": flops_step, "device_ms_per_step": dev_ms / args.steps},

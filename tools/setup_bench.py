@@ -17,6 +17,7 @@ args = NS(multires=10, multires_views=4, i_embed=0, backbone2d_fpn_dim=cfg.C, mo
 frame = add_setup_inputs(cfg, make_frame(cfg))
 rays = make_rays(cfg, frame)
 dev = torch.device("cuda:0")
+torch.set_grad_enabled(False)   # inference path (under enable_grad the descriptor queries take the gradient path)
 net = ConditionalNeRF(args, precision="bf16x3").to(dev).eval()
 w = dict(make_weights(cfg)); w.update(make_depth_fusion_weights(cfg.seed))
 net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
