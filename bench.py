@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--also", default="bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
     ap.add_argument("--early-term-eps", type=float, default=-1.0,
                     help="early-termination compositing threshold (nl_render_opts); default: 1e-5 for c5 (BASELINE names it there), 0 = off otherwise")
+    ap.add_argument("--no-side-stream", action="store_true", help="NL_RENDER_NO_SIDE_STREAM: every kernel on one stream (profiling kernels one at a time)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: strong for c3/c4)")
     args = ap.parse_args()
@@ -156,7 +157,7 @@ def main():
         zz = z
         if hier:
             zz, depth_coarse, _ = rnd.hierarchical_depths(pix, Kq, pose_q, z, u_dev, near=cfg.near, far=cfg.far)
-        out = rnd.render_rays(o, d, qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps)
+        out = rnd.render_rays(o, d, qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps, side_stream=not args.no_side_stream)
         if hier:
             out["depth_coarse"] = depth_coarse
         if gather:

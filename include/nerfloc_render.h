@@ -40,7 +40,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NL_ABI_VERSION 2   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres) */
+#define NL_ABI_VERSION 3   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
+                            * reserved fields validated, side stream owned by the nl_frame */
 #define NL_MAX_VIEWS 16
 #define NL_KNN_MAX_K 8
 
@@ -154,7 +155,11 @@ int nl_get_rays(const float* K, const float* c2w, const float* uv, int H, int W,
 /* A frame keeps the DEVICE pointers of the descriptor (images, feature maps, support points: they must stay alive and unchanged
  * while the frame is used — call nl_frame_create again when the data changes) plus tables derived from them in frame_mem
  * (visibility maps repacked, KNN grid, and — built lazily on the first render with a given packed-weights blob and rebuilt when
- * that blob is re-packed — the per-point table T and the blend-projected feature maps). */
+ * that blob is re-packed — the per-point table T and the blend-projected feature maps).  A frame also owns the side stream (+ two
+ * events) on which nl_render_rays runs the exact KNN beside the multi-view gather: created here, destroyed by nl_frame_destroy —
+ * render calls never create streams or events (safe inside hipGraph capture from the first call on).  One frame must not be rendered
+ * from two host threads / caller streams at the same time (like the reference module, a frame is not re-entrant); different frames are
+ * independent. */
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* desc);
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* desc, void* frame_mem, size_t frame_bytes,
                     void* stream, nl_frame** out);
@@ -215,15 +220,20 @@ size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V);         
  * samples and do not change at all).  0 = off = nl_render_rays.  The density itself cannot be skipped: the ray U-Net
  * (ray_unet.py:55-69) runs along the whole ray. */
 typedef struct nl_render_opts {
-  float early_term_eps;      /* 0 (off) or in (0, 1): e.g. 1e-5 keeps BASELINE's 1e-4 with a wide margin */
-  int32_t reserved0;         /* must be 0 */
+  float early_term_eps;      /* 0 (off) or in (0, 1): e.g. 1e-5 keeps BASELINE's 1e-4 with a wide margin; anything else (NaN too) is NL_ERR_BAD_ARG */
+  uint32_t flags;            /* NL_RENDER_* bits below; unknown bits are NL_ERR_BAD_ARG */
   /* Several query frames per launch: device pointer to (R, 3) per-ray query camera centres, or NULL.  When set
    * it replaces `query_center` (which may then be NULL): rays of different query poses against the SAME support frame go down in one
    * call — the query centre is the only per-query-frame quantity the ray path reads (ibrnet.py:144-167, the view-angle features) —
    * which amortises the launch chain for small per-frame batches (PoseOptimizer-sized: 512 rays). */
   const float* ray_centers;
-  int32_t reserved[4];       /* must be 0 */
+  int32_t reserved[4];       /* must be 0 (checked: NL_ERR_BAD_ARG otherwise) */
 } nl_render_opts;
+/* nl_render_opts.flags */
+#define NL_RENDER_NO_SIDE_STREAM 1u   /* keep every kernel on the caller's stream: no fork of the exact KNN onto the frame's side stream
+                                       * (results are bit-identical either way; for profiling one kernel at a time and for callers that
+                                       * must not see a second stream) */
+#define NL_RENDER_FLAGS_ALL 1u
 
 /* rays_o, rays_d (R,3); z_vals (R,S) or NULL to generate linspace(near,far,S) (model.py:451-458,483-484). */
 int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,

@@ -22,7 +22,8 @@ NL_ERR_BAD_ARG, NL_ERR_UNSUPPORTED, NL_ERR_WORKSPACE, NL_ERR_HIP, NL_ERR_NO_DEVI
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 MAX_VIEWS = 16
-ABI_VERSION = 2   # include/nerfloc_render.h: NL_ABI_VERSION
+RENDER_NO_SIDE_STREAM = 1   # nl_render_opts.flags
+ABI_VERSION = 3   # include/nerfloc_render.h: NL_ABI_VERSION
 
 
 class NlConfig(C.Structure):
@@ -48,7 +49,7 @@ class NlRenderOut(C.Structure):
 
 
 class NlRenderOpts(C.Structure):
-    _fields_ = [("early_term_eps", C.c_float), ("reserved0", C.c_int32), ("ray_centers", C.c_void_p), ("reserved", C.c_int32 * 4)]
+    _fields_ = [("early_term_eps", C.c_float), ("flags", C.c_uint32), ("ray_centers", C.c_void_p), ("reserved", C.c_int32 * 4)]
 
 
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)

@@ -515,8 +515,8 @@ class ConditionalNeRF(nn.Module):
             with torch.no_grad():
                 if u is None:
                     u = torch.rand(R, self.args.render.N_importance, device=o.device)
-                z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"].detach(), z, u,
-                                                           near=float(near), far=float(far))
+                z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"].detach(), z, u, near=near, far=far,
+                                                           lindisp=bool(self.args.render.lindisp))
         if not train:   # eval mode: the weights and the per-frame caches are constants (PoseOptimizer optimises the pose only)
             fr = self._frame_dict(data, "fine", graph=False)
             p = self._graph_params(False)
@@ -541,7 +541,8 @@ class ConditionalNeRF(nn.Module):
             if u is None:
                 u = torch.rand(R, self.args.render.N_importance, device=o.device)
             # the coarse depths use the RAYS' range like the base samples (model.py:489), not the frame's
-            z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=float(near), far=float(far))
+            z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=near, far=far,
+                                                       lindisp=bool(self.args.render.lindisp))
         out = r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
                             want_feat=bool(self.args.render.render_feature))
         if depth_coarse is not None:
@@ -569,7 +570,8 @@ class ConditionalNeRF(nn.Module):
             z = self.sample_depths(N, near, far).expand(R, N).contiguous()
             if self.args.render.N_importance > 0:
                 u = us[i] if us is not None else torch.rand(R, self.args.render.N_importance, device=o.device)
-                z, dc, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=float(near), far=float(far))
+                z, dc, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=near, far=far,
+                                                 lindisp=bool(self.args.render.lindisp))
                 dcs.append(dc)
             os_.append(o); ds_.append(d); zs.append(z); counts.append(R)
             cs.append(rays["pose"][:3, 3].detach().to(o.device).expand(R, 3))

@@ -1,5 +1,6 @@
 // C-ABI of libnerfloc_render.so: weight packing, per-frame state, stage entry points and the chunked
 // render_rays orchestrator (include/nerfloc_render.h documents which reference code each replaces).
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -35,9 +36,9 @@ int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const fl
 int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st,
                     const int* n_alive = nullptr, int S = 1);
 int nl_launch_termination(const float* z_vals, const float* sigma, int64_t R, int S, float eps, int* n_alive, int* tile_list, int* tile_count, hipStream_t st);
-int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const float* pix,
-                             const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask, float* weights,
-                             float* depth_coarse, hipStream_t st);
+int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const void* dpack,
+                             int precision, const float* pix, const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask,
+                             float* weights, float* depth_coarse, hipStream_t st);
 int nl_launch_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R,
                          float* z_out, hipStream_t st);
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
@@ -61,6 +62,14 @@ int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, co
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 
 namespace {
+
+// A/B switches used while developing the kernels (NERFLOC_POINT_V1, NERFLOC_NO_TMERGE, NERFLOC_NO_CHAIN) exist only in a build
+// with -DNERFLOC_DEBUG_SWITCHES; the shipped library reads no environment variable on the render path.
+#ifdef NERFLOC_DEBUG_SWITCHES
+inline bool dbg_switch(const char* name) { return getenv(name) != nullptr; }
+#else
+inline bool dbg_switch(const char*) { return false; }
+#endif
 
 // ------------------------------------------------------------------------------------------ weight table
 const char* kWeightNames[] = {
@@ -347,6 +356,10 @@ struct nl_frame {
   const void* pfeat_for; uint64_t pfeat_gen;   // packed weights (address + pack generation) pfeat was computed with (lazily, first render of the frame)
   float* views_dev;         // device copy of the per-view matrices: [16][12] proj_ibr rows, then [16][3] camera centres
   float views_host[16 * 15];
+  // side stream of the fused render path (exact KNN beside the multi-view gather): owned by the frame, created in nl_frame_create —
+  // never lazily inside a render call (stream / event creation is illegal during graph capture) and never shared between frames, so two
+  // renderers on two caller streams do not record into each other's events.  side_ok == false: everything runs on the caller's stream.
+  hipStream_t side; hipEvent_t ev_fork, ev_join; bool side_ok;
 };
 
 namespace {
@@ -529,31 +542,22 @@ int ensure_ptt(const Ctx& x, const nl_frame* fc) {
   return NL_OK;
 }
 
-// ---- side streams of the fused render path ------------------------------------------------------------------------
-// nl_render_rays forks two independent branches off the caller's stream and joins them again (events, graph-capturable):
-//   * the exact KNN (VALU-issue bound) runs beside the multi-view gather kernels (waiting on bilinear taps), both only need xyz;
-//   * the colour / feature heads' GEMMs + the blend tail (need feature_agg only) run beside the ray U-Net's chain of small,
-//     latency-bound launches.
-// Streams and events are created lazily, once per device, and live for the process (the only library-global state besides
-// the pack-generation registry; like the reference module the library is not re-entrant).  NERFLOC_SERIAL=1 keeps everything on
-// the caller's stream (debugging / A-B timing).
-struct SideStreams { hipStream_t s[2]; hipEvent_t e[4]; bool ok = false, tried = false; };
-SideStreams g_side[16];
-SideStreams* side_streams() {
-  static const bool serial = getenv("NERFLOC_SERIAL") != nullptr;
-  if (serial) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SideStreams& S = g_side[dev];
-  if (!S.tried) {
-    S.tried = true;
-    bool ok = true;
-    for (int i = 0; i < 2; ++i) ok = ok && hipStreamCreateWithFlags(&S.s[i], hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&S.e[i], hipEventDisableTiming) == hipSuccess;
-    S.ok = ok;
+// ---- fork / join of the fused render path's side stream ------------------------------------------------------------------
+// The exact KNN (+ the aggregation scale) only needs the sample positions, like the multi-view gather kernels: nl_render_rays forks it
+// onto the frame's side stream and joins before the neural-point kernel (events: graph-capturable).  SideJoin makes the join
+// unconditional: whatever path leaves the scope after the fork — including an error return — the caller's stream waits for the
+// side stream first, so no kernel is left writing the caller's workspace behind its back and an active capture stays well-formed.
+struct SideJoin {
+  hipStream_t main = nullptr, side = nullptr; hipEvent_t ev = nullptr; bool armed = false;
+  void arm(hipStream_t m, hipStream_t s_, hipEvent_t e) { main = m; side = s_; ev = e; armed = true; }
+  int join() {
+    if (!armed) return NL_OK;
+    armed = false;
+    if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(main, ev, 0) != hipSuccess) return NL_ERR_HIP;
+    return NL_OK;
   }
-  return S.ok ? &S : nullptr;
-}
+  ~SideJoin() { (void)join(); }
+};
 
 // ---- measurement hook: HIP events around the dominant kernel (nl_profile_begin / nl_profile_end) -----------------
 struct ProfState { bool on = false; std::vector<hipEvent_t> ev; int used = 0; };
@@ -592,7 +596,7 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
 // the multiview feature rows G from out_fc's hidden rows t64 (G is then not read here and need not exist); *chain->done reports it
 struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; };
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
-             float* FA, const PtBufs& p, hipEvent_t knn_done = nullptr, const ChainOut* chain = nullptr) {
+             float* FA, const PtBufs& p, SideJoin* knn_done = nullptr, const ChainOut* chain = nullptr) {
   const int W = x.c->W, F = f->C + 3;
   const bool fused_path = K == 8 && nl_point_fused_supported(W, x.c->precision);
   if (!knn_done) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
@@ -603,7 +607,7 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     SegSpec sg{G, W, W, 0, 1};
     NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
   }
-  if (knn_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, knn_done, 0));
+  if (knn_done) NL_TRY(knn_done->join());
   if (fused_path) {
     NL_TRY(ensure_ptt(x, f));
     if (!knn_done) NL_TRY(nl_launch_wscale(p.idx, p.d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
@@ -615,7 +619,7 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
-    const bool use_v1 = getenv("NERFLOC_POINT_V1") != nullptr;   // A/B switch for profiling / debugging
+    const bool use_v1 = dbg_switch("NERFLOC_POINT_V1");
     int rc2 = NL_ERR_UNSUPPORTED;
     if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st);
     if (rc2 == NL_ERR_UNSUPPORTED) rc2 = nl_launch_point_fused(a, W, x.c->precision, x.st);   // (e.g. more rows than 32-bit buffer offsets reach)
@@ -659,7 +663,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
             bool need_geo = true) {
   const int W = x.c->W, S = x.c->S;
   // the two phases of every transposed convolution as one launch (bf16 modes; the fp32 kernels keep the separate phases)
-  static const bool no_merge = getenv("NERFLOC_NO_TMERGE") != nullptr;
+  static const bool no_merge = dbg_switch("NERFLOC_NO_TMERGE");
   const bool merged = x.c->precision != NL_PREC_F32 && !no_merge;
   auto g = [&](int i) { return x.p<float>(x.L.un_g[i]); };
   auto b = [&](int i) { return x.p<float>(x.L.un_b[i]); };
@@ -790,6 +794,7 @@ Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
 extern "C" {
 
 static_assert(sizeof(nl_render_opts) == 32, "nl_render_opts is part of the C-ABI: 32 bytes");
+static_assert(offsetof(nl_render_opts, flags) == 4 && offsetof(nl_render_opts, ray_centers) == 8, "nl_render_opts layout");
 int nl_abi_version(void) { return NL_ABI_VERSION; }
 
 int nl_profile_begin(void) { g_prof.on = true; g_prof.used = 0; return NL_OK; }
@@ -966,11 +971,21 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
     if (rc == NL_OK && hipMemcpyAsync(f->views_dev, f->views_host, sizeof(f->views_host), hipMemcpyHostToDevice, st) != hipSuccess) rc = NL_ERR_HIP;
   }
   if (rc != NL_OK) { delete f; return rc; }
+  // the side stream and its two events (see nl_frame): failure to create them only disables the fork
+  f->side = nullptr; f->ev_fork = f->ev_join = nullptr;
+  f->side_ok = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
+  if (!f->side_ok) (void)hipGetLastError();
   *out = f;
   return NL_OK;
 }
 
 int nl_frame_destroy(nl_frame* f) {
+  if (!f) return NL_OK;
+  if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
+  if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
+  if (f->ev_join) (void)hipEventDestroy(f->ev_join);
   delete f;
   return NL_OK;
 }
@@ -1080,7 +1095,12 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
                       size_t ws_bytes, void* stream, const nl_render_opts* opts) {
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   const float term_eps = opts ? opts->early_term_eps : 0.f;
-  if (term_eps < 0.f || term_eps >= 1.f) return NL_ERR_BAD_ARG;
+  if (!(term_eps >= 0.f && term_eps < 1.f)) return NL_ERR_BAD_ARG;   // (written so that NaN is rejected)
+  if (opts) {   // fields without a meaning in this ABI version must be zero, so that a later version can give them one
+    if (opts->flags & ~(uint32_t)NL_RENDER_FLAGS_ALL) return NL_ERR_BAD_ARG;
+    for (int i = 0; i < 4; ++i) if (opts->reserved[i] != 0) return NL_ERR_BAD_ARG;
+  }
+  const uint32_t flags = opts ? opts->flags : 0u;
   const float* ray_centers = opts ? opts->ray_centers : nullptr;
   if (!cfg_ok(cfg) || !packed || !f || (!qc && !ray_centers) || !rays_o || !rays_d || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, S = cfg->S, W = cfg->W;
@@ -1099,30 +1119,26 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
   }
   Bump b{(char*)ws, 0}; RenderBufs rb; carve_render(b, cfg, V, RC, rb);
   Ctx x = make_ctx(cfg, packed, stream);
-  SideStreams* side = side_streams();
-  // bit 0 = KNN fork (default), bit 1 = heads fork.  The heads fork is OFF by default: it measured < 0.5 % (every kernel of that
-  // phase fills the chip on its own) and the blend tail (a scratch-using VALU kernel) gave run-to-run different colours when it
-  // ran beside the U-Net's kernels on another queue — not worth chasing for that gain.
-  static const int side_mask = getenv("NERFLOC_SIDE") ? atoi(getenv("NERFLOC_SIDE")) : 1;
+  const bool fork = f->side_ok && !(flags & NL_RENDER_NO_SIDE_STREAM) && nl_point_fused_supported(W, cfg->precision);
   for (int64_t r0 = 0; r0 < R; r0 += RC) {
     const int64_t rc = (R - r0 < RC) ? R - r0 : RC;
     const int64_t N = rc * S;
     NL_TRY(nl_launch_sample_points(rays_o + 3 * r0, rays_d + 3 * r0, rc, S, f->views.near_, f->views.far_,
                                    z_vals ? z_vals + r0 * S : nullptr, rb.z, rb.xyz, x.st));
-    // ---- fork 1: exact KNN + aggregation scale on a side stream, beside the multi-view gather kernels (both need xyz only)
-    hipEvent_t knn_done = nullptr;
-    if (side && (side_mask & 1) && nl_point_fused_supported(W, cfg->precision)) {
-      NL_CHECK_HIP(hipEventRecord(side->e[0], x.st));
-      NL_CHECK_HIP(hipStreamWaitEvent(side->s[0], side->e[0], 0));
-      NL_TRY(nl_knn_search(&f->grid, rb.xyz, N, 8, rb.pt.idx, rb.pt.d2, side->s[0]));
-      NL_TRY(nl_launch_wscale(rb.pt.idx, rb.pt.d2, f->sp_conf, N, 8, f->M, rb.pt.wscale, side->s[0]));
-      NL_CHECK_HIP(hipEventRecord(side->e[1], side->s[0]));
-      knn_done = side->e[1];
+    // ---- fork: exact KNN + aggregation scale on the frame's side stream, beside the multi-view gather kernels (both need xyz only).
+    // `knn` joins in do_point before the neural-point kernel — or in its destructor on any earlier exit from this iteration.
+    SideJoin knn;
+    if (fork) {
+      NL_CHECK_HIP(hipEventRecord(f->ev_fork, x.st));
+      NL_CHECK_HIP(hipStreamWaitEvent(f->side, f->ev_fork, 0));
+      knn.arm(x.st, f->side, f->ev_join);
+      NL_TRY(nl_knn_search(&f->grid, rb.xyz, N, 8, rb.pt.idx, rb.pt.d2, f->side));
+      NL_TRY(nl_launch_wscale(rb.pt.idx, rb.pt.d2, f->sp_conf, N, 8, f->M, rb.pt.wscale, f->side));
     }
     // the chain kernels recompute the multiview feature rows G (N x W) from out_fc's 64-wide hidden rows: G is only materialised for
-    // the stage output or when the separate launches run instead (NERFLOC_NO_CHAIN: A/B switch)
-    static const bool no_chain = getenv("NERFLOC_NO_CHAIN") != nullptr;
-    const bool use_chain = !no_chain && W == 256 && cfg->precision != NL_PREC_F32 && N * 1024 <= 0x7fffffffll && nl_point_fused_supported(W, cfg->precision);
+    // the stage output or when the separate launches run instead
+    const bool use_chain = !dbg_switch("NERFLOC_NO_CHAIN") && W == 256 && cfg->precision != NL_PREC_F32 && N * 1024 <= 0x7fffffffll &&
+                           nl_point_fused_supported(W, cfg->precision);
     NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg,
                  ray_centers ? ray_centers + 3 * r0 : nullptr, S));
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
@@ -1130,27 +1146,11 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     bool chain_done = false;
     const bool want_feat = out->feat != nullptr;
     const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr};
-    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, knn_done, &chain));
+    NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
-    // ---- fork 2: heads that need feature_agg only, beside the ray U-Net
-    bool pre_done = false;
-    int pre_parts = 0;
-    if (side && (side_mask & 2) && term_eps == 0.f && !chain_done) {
-      NL_CHECK_HIP(hipEventRecord(side->e[2], x.st));
-      NL_CHECK_HIP(hipStreamWaitEvent(side->s[1], side->e[2], 0));
-      Ctx xs = x;
-      xs.st = side->s[1];
-      static const int parts = getenv("NERFLOC_PARTS") ? atoi(getenv("NERFLOC_PARTS")) : 7;
-      NL_TRY(do_heads_pre(xs, V, rb.FA, rb.bl1, rb.rgbv, N, out->feat != nullptr, rb.hd, parts));
-      NL_CHECK_HIP(hipEventRecord(side->e[3], side->s[1]));
-      pre_parts = parts;
-      pre_done = true;
-    }
     bool have_sigma = false;
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
-    if (pre_done) NL_CHECK_HIP(hipStreamWaitEvent(x.st, side->e[3], 0));
-    if (pre_done && pre_parts != 7) NL_TRY(do_heads_pre(x, V, rb.FA, rb.bl1, rb.rgbv, N, out->feat != nullptr, rb.hd, 7 & ~pre_parts));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, pre_done, term_eps, chain_parts));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
@@ -1172,8 +1172,8 @@ int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* 
   const size_t part = nl_align_up((size_t)f->views.V * R * Sc * 4, 256);
   float* wa = (float*)ws; float* wv = (float*)((char*)ws + part); float* wm = (float*)((char*)ws + 2 * part);
   const Layout L = make_layout(cfg);
-  return nl_launch_coarse_weights(f->views, w2c_kinv, f->visf_hwc, (const float*)((const char*)packed + L.dec_w), pix, zc, R, Sc, wa, wv, wm,
-                                  weights, depth_coarse, (hipStream_t)stream);
+  return nl_launch_coarse_weights(f->views, w2c_kinv, f->visf_hwc, (const float*)((const char*)packed + L.dec_w), (const char*)packed + L.dec_mfma,
+                                  cfg->precision, pix, zc, R, Sc, wa, wv, wm, weights, depth_coarse, (hipStream_t)stream);
 }
 
 int nl_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R, float* z_out,

@@ -66,6 +66,69 @@ __global__ __launch_bounds__(256) void coarse_view_kernel(const NlViews vw, cons
   mask_out[(size_t)v * R * Sc + i] = valid ? 1.f : 0.f;
 }
 
+// MFMA version (bf16x3 / bf16 modes): rows = (view, ray, coarse sample), 32 rows per wave, decoders = mvd_decode_tile (mvdec.h) like
+// mv_vis_mfma_kernel — the per-lane fp32 decoders above cost ~4 400 FMAs per row (2.2 ms of BASELINE config 5's step).
+template <bool X3>
+__global__ __launch_bounds__(256) void coarse_view_mfma_kernel(const NlViews vw, const QueryCam qc, const float* __restrict__ visf,
+                                                               const uint4* __restrict__ dpack, const float* __restrict__ pix /*(R,2)*/,
+                                                               const float* __restrict__ zc /*(R,Sc)*/, int R, int Sc, int tiles_per_view,
+                                                               int total_tiles, float* __restrict__ alpha_out /*(V,R*Sc)*/,
+                                                               float* __restrict__ vis_out, float* __restrict__ mask_out) {
+  __shared__ uint4 sw[MVD_LDS_UINT4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, j = lane & 31;
+  mvd_load_lds<X3>(sw, dpack, tid, 256);
+  __syncthreads();
+  const int NR = R * Sc;
+  // coords2rays: rot = w2c[:, :3]^T, centre = -rot @ t (depth_fusion.py:9-45)
+  const float* Wm = qc.w2c;
+  const float* K = qc.kinv;
+  float cen[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) cen[a] = -(Wm[a] * Wm[3] + Wm[4 + a] * Wm[7] + Wm[8 + a] * Wm[11]);
+  const float ni = -1.f / vw.near_, fi = -1.f / vw.far_;
+  auto dinv = [&](float zz) { return (-1.f / zz - ni) / (fi - ni); };
+  for (int tile = blockIdx.x * 4 + wave; tile < total_tiles; tile += gridDim.x * 4) {
+    const int v = __builtin_amdgcn_readfirstlane(tile / tiles_per_view);
+    const int i = (tile - v * tiles_per_view) * 32 + j;
+    const bool live = i < NR;
+    const int ii = live ? i : NR - 1;
+    const int r = ii / Sc, s = ii - r * Sc;
+    const float u = pix[2 * r], vv = pix[2 * r + 1];
+    const float c0 = K[0] * u + K[1] * vv + K[2], c1 = K[3] * u + K[4] * vv + K[5], c2 = K[6] * u + K[7] * vv + K[8];
+    float dir[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dir[a] = (Wm[a] * c0 + Wm[4 + a] * c1 + Wm[8 + a] * c2 + cen[a]) - cen[a];   // not normalised; same rounding as the reference's pts - centre
+    const float z = zc[ii];
+    const float X = cen[0] + dir[0] * z, Y = cen[1] + dir[1] * z, Z = cen[2] + dir[2] * z;
+    float px, py, depth;
+    const bool valid = project_neuray(vw.P2[v], X, Y, Z, vw.Wimg, vw.H, px, py, depth);
+    const size_t o = (size_t)v * NR + i;
+    if (__ballot(valid && live) == 0ull) {   // no row of the tile projects into the view: masked out downstream (coarse_ray_kernel multiplies by the mask)
+      if (live && hh == 0) { alpha_out[o] = 0.f; vis_out[o] = 0.f; mask_out[o] = 0.f; }
+      continue;
+    }
+    float x0[8], x1[8];
+    mvd_tap16(visf + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh, vw.vh, vw.vw, vw.Wimg, vw.H, px, py, valid, x0, x1);
+    float m0, m1, v0, v1, aw, vs;
+    mvd_decode_tile<X3>(sw, lane, x0, x1, m0, m1, v0, v1, vs, aw);
+    // query-side interval lengths in normalised inverse depth (depth2inv_dists); last = 1e6
+    const float d_s = dinv(z);
+    const float int_s = (s + 1 < Sc) ? dinv(zc[ii + 1]) - d_s : 1e6f;
+    const int sp = s > 0 ? s - 1 : 0;
+    const float int_p = (sp + 1 < Sc) ? dinv(zc[(size_t)r * Sc + sp + 1]) - dinv(zc[(size_t)r * Sc + sp]) : 1e6f;
+    const float dn = (-1.f / fmaxf(depth, 1e-5f) - ni) / (fi - ni);
+    const float nearp = dn - int_p / 2.f, farp = dn + int_s / 2.f;
+    const float a0 = (0.5f + 0.5f * tanhf((nearp - m0) * v0)) * vs, a1 = (0.5f + 0.5f * tanhf((nearp - m1) * v1)) * vs;
+    const float b0 = (0.5f + 0.5f * tanhf((farp - m0) * v0)) * vs, b1 = (0.5f + 0.5f * tanhf((farp - m1) * v1)) * vs;
+    const float visib = (1.f - a0) * aw + (1.f - a1) * (1.f - aw);
+    const float hit = (b0 - a0) * aw + (b1 - a1) * (1.f - aw);
+    const float eps = 1e-5f;
+    const float alpha = logf(hit / (visib - hit + eps) + eps);
+    if (live && hh == 0) { alpha_out[o] = alpha; vis_out[o] = visib; mask_out[o] = valid ? 1.f : 0.f; }
+  }
+}
+
 __global__ __launch_bounds__(256) void coarse_ray_kernel(const float* __restrict__ alpha_in, const float* __restrict__ vis_in,
                                                          const float* __restrict__ mask_in, const float* __restrict__ zc, int V, int R,
                                                          int Sc, float* __restrict__ weights, float* __restrict__ depth_coarse) {
@@ -168,16 +231,25 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
 
 }  // namespace
 
-int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const float* pix,
-                             const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask, float* weights,
-                             float* depth_coarse, hipStream_t st) {
+int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const void* dpack,
+                             int precision, const float* pix, const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask,
+                             float* weights, float* depth_coarse, hipStream_t st) {
   if (R <= 0) return NL_OK;
   if (Sc < 3 || Sc > 64) return NL_ERR_UNSUPPORTED;
   QueryCam qc;
   for (int i = 0; i < 12; ++i) qc.w2c[i] = w2c_kinv_host[i];
   for (int i = 0; i < 9; ++i) qc.kinv[i] = w2c_kinv_host[12 + i];
-  dim3 grid((unsigned)nl_cdiv(R * Sc, 256), (unsigned)vw.V);
-  hipLaunchKernelGGL(coarse_view_kernel, grid, dim3(256), 0, st, vw, qc, visf_hwc, dec_w, pix, zc, (int)R, Sc, ws_alpha, ws_vis, ws_mask);
+  if (precision == NL_PREC_F32 || R * Sc > 0x7fffffffll / 32) {
+    dim3 grid((unsigned)nl_cdiv(R * Sc, 256), (unsigned)vw.V);
+    hipLaunchKernelGGL(coarse_view_kernel, grid, dim3(256), 0, st, vw, qc, visf_hwc, dec_w, pix, zc, (int)R, Sc, ws_alpha, ws_vis, ws_mask);
+  } else {
+    const int tpv = (int)nl_cdiv(R * Sc, 32), total = tpv * vw.V;
+    const int blocks = (int)(nl_cdiv(total, 4) < 2048 ? nl_cdiv(total, 4) : 2048);
+    // always the split-fp16 decoders, in the throughput mode too: the coarse weights only place the resampled depths, and depths that
+    // move make every per-sample output incomparable — single-bf16 decoders here cost the bf16 mode 3e-2 on `weights` for 0.3 ms
+    hipLaunchKernelGGL(coarse_view_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, vw, qc, visf_hwc, (const uint4*)dpack, pix, zc, (int)R, Sc, tpv,
+                       total, ws_alpha, ws_vis, ws_mask);
+  }
   hipLaunchKernelGGL(coarse_ray_kernel, dim3((unsigned)nl_cdiv(R, 4)), dim3(256), 0, st, ws_alpha, ws_vis, ws_mask, zc, vw.V, (int)R, Sc,
                      weights, depth_coarse);
   NL_LAUNCH_CHECK();

@@ -54,42 +54,18 @@ __global__ __launch_bounds__(256) void mv_vis_kernel(const NlViews vw, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MFMA version of mv_vis (bf16x3 / bf16 modes): rows = (view, sample) pairs, 32 rows per wave, transposed MFMA like
-// point_fused_kernel: the four decoders' first layers are one 32->128 product (weights = A operand, 4 row tiles = 4
-// decoders), the second layers four 32->32 products whose K order is permuted to the accumulator's register order, so the
-// hidden activations go C/D registers -> ELU -> bf16 split -> B fragments without leaving the lane.  The 6 output units
-// are VALU dot products over the lane's 16 hidden values + one cross-half shuffle.  Weights live in LDS in fragment order
-// (copied once per persistent workgroup).
-typedef __bf16 mv_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float mv_f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int MVD_W1 = 0;                       // uint4 index: [part][q 2][d 4][lane 64]  -> 2*512
-constexpr int MVD_W2 = 1024;                    // [part][d 4][s 2][lane 64]              -> 2*512
-constexpr int MVD_F32 = 2048;                   // then floats: b1[128] b2[128] w4p[4][2][2][16] b4[8]
-constexpr int MVD_UINT4 = 2048 + (128 + 128 + 256 + 8) / 4;
-
-template <bool X3>
-__device__ __forceinline__ void mv_split8(const float (&v)[8], mv_bf16x8& hi, mv_bf16x8& lo) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    __bf16 h = (__bf16)v[t];
-    hi[t] = h;
-    if (X3) lo[t] = (__bf16)(v[t] - (float)h);
-  }
-}
-
+// MFMA version of mv_vis (bf16x3 / bf16 modes): rows = (view, sample) pairs, 32 rows per wave; the decoders are mvd_decode_tile
+// (mvdec.h: three-term split-fp16 in the parity mode).  Weights live in LDS in fragment order (copied once per persistent workgroup).
 template <bool X3>
 __global__ __launch_bounds__(256) void mv_vis_mfma_kernel(const NlViews vw, const float* __restrict__ visf /*(V,vh,vw,32)*/,
                                                           const uint4* __restrict__ dpack, const float* __restrict__ xyz, int N,
                                                           int tiles_per_view, int total_tiles, float* __restrict__ vis_out,
                                                           float* __restrict__ dd_out) {
-  __shared__ uint4 sw[MVD_UINT4];
+  __shared__ uint4 sw[MVD_LDS_UINT4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, j = lane & 31;
-  for (int i = tid; i < MVD_UINT4; i += 256) sw[i] = dpack[i];
+  mvd_load_lds<X3>(sw, dpack, tid, 256);
   __syncthreads();
-  const float* sf = reinterpret_cast<const float*>(sw + MVD_F32);
-  const float* b1 = sf, *b2 = sf + 128, *w4p = sf + 256, *b4 = sf + 512;
 
   for (int tile = blockIdx.x * 4 + wave; tile < total_tiles; tile += gridDim.x * 4) {
     const int v = __builtin_amdgcn_readfirstlane(tile / tiles_per_view);
@@ -108,108 +84,10 @@ __global__ __launch_bounds__(256) void mv_vis_mfma_kernel(const NlViews vw, cons
       }
       continue;
     }
-    // bilinear (border, align_corners=False) tap of this lane's 16 channels: {8hh..8hh+7} and {16+8hh..16+8hh+7}
     float x0[8], x1[8];
-    {
-      const float xn = px / (float)(vw.Wimg - 1) * 2.f - 1.f;
-      const float yn = py / (float)(vw.H - 1) * 2.f - 1.f;
-      const Taps t = make_taps<false, true>(xn, yn, vw.vw, vw.vh);
-      const float* base = visf + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh;
-      const size_t o00 = ((size_t)(t.mn ? t.y0 : 0) * vw.vw + (t.mw ? t.x0 : 0)) * 32;
-      const size_t o01 = ((size_t)(t.mn ? t.y0 : 0) * vw.vw + (t.me ? t.x0 + 1 : 0)) * 32;
-      const size_t o10 = ((size_t)(t.ms ? t.y0 + 1 : 0) * vw.vw + (t.mw ? t.x0 : 0)) * 32;
-      const size_t o11 = ((size_t)(t.ms ? t.y0 + 1 : 0) * vw.vw + (t.me ? t.x0 + 1 : 0)) * 32;
-      const float w00 = (valid && t.mn && t.mw) ? t.nw : 0.f, w01 = (valid && t.mn && t.me) ? t.ne : 0.f;
-      const float w10 = (valid && t.ms && t.mw) ? t.sw : 0.f, w11 = (valid && t.ms && t.me) ? t.se : 0.f;
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-#pragma unroll
-        for (int c4 = 0; c4 < 2; ++c4) {
-          const int co = 16 * g + 4 * c4;
-          const float4 a = *(const float4*)(base + o00 + co), b = *(const float4*)(base + o01 + co);
-          const float4 c = *(const float4*)(base + o10 + co), d = *(const float4*)(base + o11 + co);
-          float* dst = g ? x1 : x0;
-          dst[4 * c4 + 0] = a.x * w00 + b.x * w01 + c.x * w10 + d.x * w11;
-          dst[4 * c4 + 1] = a.y * w00 + b.y * w01 + c.y * w10 + d.y * w11;
-          dst[4 * c4 + 2] = a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11;
-          dst[4 * c4 + 3] = a.w * w00 + b.w * w01 + c.w * w10 + d.w * w11;
-        }
-      }
-    }
-    mv_bf16x8 xh[2], xl[2];
-    mv_split8<X3>(x0, xh[0], xl[0]);
-    mv_split8<X3>(x1, xh[1], xl[1]);
-    // ---- the four decoders one after the other (32 -> 32 -> 32 -> 1 | 2): only one decoder's 2 x 16 accumulators are live at a
-    // time, which is what lets four waves share a SIMD (all four at once: 128 accumulators, two waves)
-    float o[4][2];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      // layer 1
-      mv_f32x16 acc;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b = *(const float4*)(b1 + 32 * d + 8 * g + 4 * hh);
-        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const mv_bf16x8 ah = __builtin_bit_cast(mv_bf16x8, sw[MVD_W1 + (q * 4 + d) * 64 + lane]);
-        if (X3) {
-          const mv_bf16x8 al = __builtin_bit_cast(mv_bf16x8, sw[MVD_W1 + 512 + (q * 4 + d) * 64 + lane]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[q], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[q], acc, 0, 0, 0);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[q], acc, 0, 0, 0);
-      }
-      // ELU -> layer 2 (32 -> 32), K order = accumulator register order
-      mv_bf16x8 gh[2], gl[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        float vv[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) vv[t] = nl_elu_fast(acc[8 * s + t]);
-        mv_split8<X3>(vv, gh[s], gl[s]);
-      }
-      mv_f32x16 acc2;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b = *(const float4*)(b2 + 32 * d + 8 * g + 4 * hh);
-        acc2[4 * g] = b.x; acc2[4 * g + 1] = b.y; acc2[4 * g + 2] = b.z; acc2[4 * g + 3] = b.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const mv_bf16x8 ah = __builtin_bit_cast(mv_bf16x8, sw[MVD_W2 + (d * 2 + s) * 64 + lane]);
-        if (X3) {
-          const mv_bf16x8 al = __builtin_bit_cast(mv_bf16x8, sw[MVD_W2 + 512 + (d * 2 + s) * 64 + lane]);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, gh[s], acc2, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gl[s], acc2, 0, 0, 0);
-        }
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gh[s], acc2, 0, 0, 0);
-      }
-      // ELU -> output units (VALU dot over this lane's 16 hidden values + the other half's via shuffle)
-      float h2[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h2[r] = nl_elu_fast(acc2[r]);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float p = 0.f;
-        if (u == 0 || d < 2) {
-          const float* w = w4p + ((d * 2 + u) * 2 + hh) * 16;
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 ww = *(const float4*)(w + 4 * r4);
-            p = fmaf(ww.x, h2[4 * r4], p); p = fmaf(ww.y, h2[4 * r4 + 1], p);
-            p = fmaf(ww.z, h2[4 * r4 + 2], p); p = fmaf(ww.w, h2[4 * r4 + 3], p);
-          }
-          p += __shfl_xor(p, 32, 64);
-          p += b4[d * 2 + u];
-        }
-        o[d][u] = p;
-      }
-    }
-    float m0 = nl_softplus(o[0][0]), m1 = nl_softplus(o[0][1]);
-    float v0 = nl_softplus(o[1][0]) + 0.05f, v1 = nl_softplus(o[1][1]) + 0.05f;
-    const float aw = nl_sigmoid(o[2][0]), vs = nl_sigmoid(o[3][0]);
+    mvd_tap16(visf + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh, vw.vh, vw.vw, vw.Wimg, vw.H, px, py, valid, x0, x1);
+    float m0, m1, v0, v1, aw, vs;
+    mvd_decode_tile<X3>(sw, lane, x0, x1, m0, m1, v0, v1, vs, aw);
     const float ni = -1.f / vw.near_, fi = -1.f / vw.far_;
     float refd = -1.f / (m0 * (fi - ni) + ni);
     refd = fminf(fmaxf(refd, vw.near_), vw.far_);
@@ -226,18 +104,24 @@ __global__ __launch_bounds__(256) void mv_vis_mfma_kernel(const NlViews vw, cons
   }
 }
 
-// dpack layout (see MVD_*): fragment-ordered bf16 hi/lo weights of decoder layers 1-2, fp32 biases, lane-ordered layer-3 rows
+// dpack layout (mvdec.h, MVD_*): fragment-ordered bf16 AND fp16 hi / lo weights of decoder layers 1-2, fp32 biases, lane-ordered layer-3 rows
 __global__ void pack_mv_decoder_kernel(const float* __restrict__ dec /* packed VALU layout, 4 x DEC_STRIDE */, uint4* __restrict__ out) {
   unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
+  unsigned short* h16 = reinterpret_cast<unsigned short*>(out + MVD_F16);
   float* of = reinterpret_cast<float*>(out + MVD_F32);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   auto f2bf = [](float x) { unsigned int u = __float_as_uint(x); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
+  auto f2h = [](float x) { const _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h); };
+  auto h2f = [](unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); };
   if (i < 4096) {          // layer 1: element (q, d, lane, t)
     const int t = i & 7, lane = (i >> 3) & 63, d = (i >> 9) & 3, q = i >> 11;
     const float v = dec[d * DEC_STRIDE + (lane & 31) * 32 + 16 * q + 8 * (lane >> 5) + t];
     const unsigned short h = f2bf(v);
     o16[(size_t)MVD_W1 * 8 + i] = h;
     o16[(size_t)(MVD_W1 + 512) * 8 + i] = f2bf(v - __uint_as_float(((unsigned)h) << 16));
+    const unsigned short g = f2h(v);
+    h16[(size_t)MVD_W1 * 8 + i] = g;
+    h16[(size_t)(MVD_W1 + 512) * 8 + i] = f2h(v - h2f(g));
   } else if (i < 8192) {   // layer 2: element (d, s, lane, t), K permuted to accumulator order
     const int e = i - 4096;
     const int t = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1, d = e >> 10;
@@ -246,6 +130,9 @@ __global__ void pack_mv_decoder_kernel(const float* __restrict__ dec /* packed V
     const unsigned short h = f2bf(v);
     o16[(size_t)MVD_W2 * 8 + e] = h;
     o16[(size_t)(MVD_W2 + 512) * 8 + e] = f2bf(v - __uint_as_float(((unsigned)h) << 16));
+    const unsigned short g = f2h(v);
+    h16[(size_t)MVD_W2 * 8 + e] = g;
+    h16[(size_t)(MVD_W2 + 512) * 8 + e] = f2h(v - h2f(g));
   } else if (i < 8192 + 128) { const int e = i - 8192; of[e] = dec[(e >> 5) * DEC_STRIDE + 1024 + (e & 31)]; }            // b1
   else if (i < 8192 + 256) { const int e = i - 8192 - 128; of[128 + e] = dec[(e >> 5) * DEC_STRIDE + 2080 + (e & 31)]; }   // b2
   else if (i < 8192 + 512) {                                                                                               // w4p[d][u][hh][r]
@@ -766,7 +653,7 @@ int nl_launch_mv_vis(const NlViews& vw, const float* visf_hwc, const float* dec_
   return NL_OK;
 }
 
-size_t nl_mv_decoder_pack_bytes() { return (size_t)MVD_UINT4 * 16; }
+size_t nl_mv_decoder_pack_bytes() { return (size_t)MVD_PACK_UINT4 * 16; }
 
 int nl_pack_mv_decoder(const float* dec_valu_layout, void* out, hipStream_t st) {
   hipLaunchKernelGGL(pack_mv_decoder_kernel, dim3((8192 + 520 + 255) / 256), dim3(256), 0, st, dec_valu_layout, (uint4*)out);
@@ -791,7 +678,11 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   const bool v4 = (C % 4 == 0) && ((((size_t)feat) & 15) == 0);   // 16-B channel groups
-  static const bool force_wave = getenv("NERFLOC_MVSTATS_WAVE") != nullptr;   // debugging / A-B switch: one sample per wave everywhere
+#ifdef NERFLOC_DEBUG_SWITCHES
+  static const bool force_wave = getenv("NERFLOC_MVSTATS_WAVE") != nullptr;   // A/B switch (debug builds only): one sample per wave everywhere
+#else
+  const bool force_wave = false;
+#endif
   if (v4 && !rgb_feat && !vis_ang && !force_wave) {   // everything but the stage API: eight samples per wave
     dim3 grid8(nl_xcd_grid(nl_cdiv(N, 32)));
 #define NL_MS8(VT) hipLaunchKernelGGL((mv_stats8_kernel<VT>), grid8, dim3(256), sizeof(float) * 4 * 8 * VT * MS8_SLOT, st, vw, viewsdev, images, feat, C, \

@@ -122,4 +122,166 @@ __device__ __forceinline__ void decode_all(const float* __restrict__ dw, const f
   aw = nl_sigmoid(aw); vs = nl_sigmoid(vs);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA evaluation of the four decoders for a tile of 32 rows (row = one (view, point) pair): used by mv_vis_mfma_kernel (mvagg.hip)
+// and coarse_view_mfma_kernel (hier.hip).  Transposed MFMA: weights = A operand (LDS, fragment order), the rows' activations = B
+// operand in registers; lane (j = lane & 31, hh = lane >> 5) holds channels {8hh..8hh+7} and {16+8hh..16+8hh+7} of row j.  The four
+// decoders' first layers are 32 -> 32 products (2 k-steps), the second layers 32 -> 32 with K in the accumulator's register order, so
+// the hidden activations go C/D registers -> ELU -> 16-bit split -> B fragments without leaving the lane; the 6 output units are VALU
+// dots over the lane's 16 hidden values + one cross-half add.
+// Arithmetic: X3 = THREE-TERM SPLIT-FP16 (hi.hi + lo.hi + hi.lo, fp32 accumulate): fp16 carries 11 significant bits per part, so the
+// products are good to ~2^-22 — the decoders feed exp / tanh / a division by the summed visibility and are the one place of the
+// path where split-bf16's 2^-17 showed (a sample whose views are all almost invisible turned 7e-6 of visibility error into 2e-4 of
+// compositing weight, tools/precision_budget.py); the visibility features are O(1) outputs of the per-frame CNN, far inside fp16's
+// range.  !X3 = one bf16 MFMA per product (throughput mode).
+typedef __bf16 mvd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mvd_f16x8 __attribute__((ext_vector_type(8)));
+typedef float mvd_f32x16 __attribute__((ext_vector_type(16)));
+
+// dpack (uint4 units): [0, 2048) bf16 fragments: W1 hi [q 2][d 4][lane 64] at 0, lo at +512; W2 hi [d 4][s 2][lane 64] at 1024, lo at
+// +512.  [2048, 2048 + 130) floats: b1[128] b2[128] w4p[4][2][2][16] b4[8].  [2178, 2178 + 2048) the same fragments in fp16 hi / lo.
+constexpr int MVD_W1 = 0;
+constexpr int MVD_W2 = 1024;
+constexpr int MVD_F32 = 2048;
+constexpr int MVD_NF32 = (128 + 128 + 256 + 8) / 4;
+constexpr int MVD_F16 = MVD_F32 + MVD_NF32;
+constexpr int MVD_PACK_UINT4 = MVD_F16 + 2048;   // global image
+constexpr int MVD_LDS_UINT4 = 2048 + MVD_NF32;   // what a kernel keeps in LDS: ONE set of fragments + the floats
+
+// copies the fragments the kernel's mode needs + the float block into LDS (all threads of the block; caller syncs)
+template <bool X3>
+__device__ __forceinline__ void mvd_load_lds(uint4* sw, const uint4* __restrict__ dpack, int tid, int nthreads) {
+  for (int i = tid; i < 2048; i += nthreads) sw[i] = dpack[(X3 ? MVD_F16 : 0) + i];
+  for (int i = tid; i < MVD_NF32; i += nthreads) sw[2048 + i] = dpack[MVD_F32 + i];
+}
+
+template <bool X3> struct MvdOps;
+template <> struct MvdOps<true> {
+  typedef mvd_f16x8 v8;
+  static __device__ __forceinline__ void split(const float (&v)[8], v8& hi, v8& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { const _Float16 h = (_Float16)v[t]; hi[t] = h; lo[t] = (_Float16)(v[t] - (float)h); }
+  }
+  static __device__ __forceinline__ mvd_f32x16 mfma(v8 a, v8 b, mvd_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct MvdOps<false> {
+  typedef mvd_bf16x8 v8;
+  static __device__ __forceinline__ void split(const float (&v)[8], v8& hi, v8& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) hi[t] = (__bf16)v[t];
+    lo = hi;
+  }
+  static __device__ __forceinline__ mvd_f32x16 mfma(v8 a, v8 b, mvd_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+// this lane's 16 channels of the bilinear (border, align_corners = False) tap of the channels-last 32-channel visibility map at
+// pixel (px, py) of view `base`; zero when !valid (depth_fusion.py:60-76, neuray_ops.py:14-36)
+__device__ __forceinline__ void mvd_tap16(const float* __restrict__ base /* view's map + 8 * hh */, int vh, int vw_, int Wimg, int H, float px, float py,
+                                          bool valid, float (&x0)[8], float (&x1)[8]) {
+  const float xn = px / (float)(Wimg - 1) * 2.f - 1.f;
+  const float yn = py / (float)(H - 1) * 2.f - 1.f;
+  const Taps t = make_taps<false, true>(xn, yn, vw_, vh);
+  const size_t o00 = ((size_t)(t.mn ? t.y0 : 0) * vw_ + (t.mw ? t.x0 : 0)) * 32;
+  const size_t o01 = ((size_t)(t.mn ? t.y0 : 0) * vw_ + (t.me ? t.x0 + 1 : 0)) * 32;
+  const size_t o10 = ((size_t)(t.ms ? t.y0 + 1 : 0) * vw_ + (t.mw ? t.x0 : 0)) * 32;
+  const size_t o11 = ((size_t)(t.ms ? t.y0 + 1 : 0) * vw_ + (t.me ? t.x0 + 1 : 0)) * 32;
+  const float w00 = (valid && t.mn && t.mw) ? t.nw : 0.f, w01 = (valid && t.mn && t.me) ? t.ne : 0.f;
+  const float w10 = (valid && t.ms && t.mw) ? t.sw : 0.f, w11 = (valid && t.ms && t.me) ? t.se : 0.f;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int c4 = 0; c4 < 2; ++c4) {
+      const int co = 16 * g + 4 * c4;
+      const float4 a = *(const float4*)(base + o00 + co), b = *(const float4*)(base + o01 + co);
+      const float4 c = *(const float4*)(base + o10 + co), d = *(const float4*)(base + o11 + co);
+      float* dst = g ? x1 : x0;
+      dst[4 * c4 + 0] = a.x * w00 + b.x * w01 + c.x * w10 + d.x * w11;
+      dst[4 * c4 + 1] = a.y * w00 + b.y * w01 + c.y * w10 + d.y * w11;
+      dst[4 * c4 + 2] = a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11;
+      dst[4 * c4 + 3] = a.w * w00 + b.w * w01 + c.w * w10 + d.w * w11;
+    }
+  }
+}
+
+// the four decoders of a 32-row tile, one after the other (only one decoder's 2 x 16 accumulators are live at a time: that is what
+// lets four waves share a SIMD) -> mean(2), var(2) + 0.05, vis, aw of this lane's row (both halves of the wave hold the result)
+template <bool X3>
+__device__ __forceinline__ void mvd_decode_tile(const uint4* sw, int lane, const float (&x0)[8], const float (&x1)[8], float& m0, float& m1,
+                                                float& v0, float& v1, float& vs, float& aw) {
+  typedef MvdOps<X3> OP;
+  typedef typename OP::v8 v8;
+  const int hh = lane >> 5;
+  const float* sf = reinterpret_cast<const float*>(sw + 2048);
+  const float* b1 = sf, *b2 = sf + 128, *w4p = sf + 256, *b4 = sf + 512;
+  v8 xh[2], xl[2];
+  OP::split(x0, xh[0], xl[0]);
+  OP::split(x1, xh[1], xl[1]);
+  float o[4][2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    mvd_f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *(const float4*)(b1 + 32 * d + 8 * g + 4 * hh);
+      acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const v8 ah = __builtin_bit_cast(v8, sw[MVD_W1 + (q * 4 + d) * 64 + lane]);
+      if (X3) {
+        const v8 al = __builtin_bit_cast(v8, sw[MVD_W1 + 512 + (q * 4 + d) * 64 + lane]);
+        acc = OP::mfma(al, xh[q], acc);
+        acc = OP::mfma(ah, xl[q], acc);
+      }
+      acc = OP::mfma(ah, xh[q], acc);
+    }
+    v8 gh[2], gl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float vv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) vv[t] = nl_elu_fast(acc[8 * s + t]);
+      OP::split(vv, gh[s], gl[s]);
+    }
+    mvd_f32x16 acc2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *(const float4*)(b2 + 32 * d + 8 * g + 4 * hh);
+      acc2[4 * g] = b.x; acc2[4 * g + 1] = b.y; acc2[4 * g + 2] = b.z; acc2[4 * g + 3] = b.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const v8 ah = __builtin_bit_cast(v8, sw[MVD_W2 + (d * 2 + s) * 64 + lane]);
+      if (X3) {
+        const v8 al = __builtin_bit_cast(v8, sw[MVD_W2 + 512 + (d * 2 + s) * 64 + lane]);
+        acc2 = OP::mfma(al, gh[s], acc2);
+        acc2 = OP::mfma(ah, gl[s], acc2);
+      }
+      acc2 = OP::mfma(ah, gh[s], acc2);
+    }
+    float h2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h2[r] = nl_elu_fast(acc2[r]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float p = 0.f;
+      if (u == 0 || d < 2) {
+        const float* w = w4p + ((d * 2 + u) * 2 + hh) * 16;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float4 ww = *(const float4*)(w + 4 * r4);
+          p = fmaf(ww.x, h2[4 * r4], p); p = fmaf(ww.y, h2[4 * r4 + 1], p);
+          p = fmaf(ww.z, h2[4 * r4 + 2], p); p = fmaf(ww.w, h2[4 * r4 + 3], p);
+        }
+        p += __shfl_xor(p, 32, 64);
+        p += b4[d * 2 + u];
+      }
+      o[d][u] = p;
+    }
+  }
+  m0 = nl_softplus(o[0][0]); m1 = nl_softplus(o[0][1]);
+  v0 = nl_softplus(o[1][0]) + 0.05f; v1 = nl_softplus(o[1][1]) + 0.05f;
+  aw = nl_sigmoid(o[2][0]); vs = nl_sigmoid(o[3][0]);
+}
+
 }  // namespace nlmv

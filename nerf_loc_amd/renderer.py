@@ -44,6 +44,7 @@ class HipRenderer:
         self._ws = None
         self._ws_request = workspace_bytes
         self.V = 0
+        self._zc_rows = {}
 
     # ------------------------------------------------------------------ weights
     def load_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
@@ -115,6 +116,7 @@ class HipRenderer:
             self.lib.nl_frame_destroy(self._frame)
         self._frame = ct.c_void_p(None)
         self._frame_keep = None
+        self._zc_rows = {}
 
     def __del__(self):
         try:
@@ -140,8 +142,11 @@ class HipRenderer:
 
     # ------------------------------------------------------------------ fused path
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
-                    intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0) -> Dict[str, torch.Tensor]:
-        """early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
+                    intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0,
+                    side_stream: bool = True) -> Dict[str, torch.Tensor]:
+        """side_stream=False (nl_render_opts.flags = NL_RENDER_NO_SIDE_STREAM): every kernel on the current stream (bit-identical results;
+        for profiling kernels one at a time).
+        early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
         ray's transmittance falls below eps are not evaluated (rgb / feat move by < eps * max|value|; everything else is unchanged).
         query_center: (3,) for the whole batch, or (R, 3) per ray — rays of several query frames (poses) against this support frame in
         one launch (nl_render_opts.ray_centers)."""
@@ -175,9 +180,11 @@ class HipRenderer:
         opts.early_term_eps = float(early_term_eps)
         if per_ray:
             opts.ray_centers = qc.data_ptr()
+        if not side_stream:
+            opts.flags = L.RENDER_NO_SIDE_STREAM
         L.check(self.lib.nl_render_rays_ex(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, None if per_ray else qc.data_ptr(), o.data_ptr(),
                                            d.data_ptr(), _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream(),
-                                           ct.byref(opts) if (early_term_eps > 0 or per_ray) else None), "nl_render_rays")
+                                           ct.byref(opts) if (early_term_eps > 0 or per_ray or not side_stream) else None), "nl_render_rays")
         out["mask"] = out["mask"].bool()
         if intermediates:
             out["sigma"] = out["sigma"].view(R, S)
@@ -237,9 +244,12 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
-    def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64, near: Optional[float] = None, far: Optional[float] = None):
+    def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64, near=None, far=None, lindisp: bool = False):
         """a20: coarse NeuRay weights along the pixel rays -> inverse-CDF samples (uniforms `u` (R,Ni)) merged with
-        z_base (R,Sb) and sorted.  Returns (z_vals (R,Sb+Ni), depth_coarse (R,), weights_coarse (R,n_coarse))."""
+        z_base (R,Sb) and sorted.  Returns (z_vals (R,Sb+Ni), depth_coarse (R,), weights_coarse (R,n_coarse)).
+        near / far: the RAYS' depth range (model.py:489 samples the coarse depths from rays['depth_range']) as python floats or as
+        tensors on any device — tensors are used where they live, without a device-to-host copy; default: the frame's range.
+        lindisp: the coarse row is sampled like ConditionalNeRF.sample_depths (model.py:451-458), linearly in depth or in disparity."""
         self._ready()
         dev = self.device
         pix = _dev_f32(pixel_coordinates, dev)
@@ -249,18 +259,26 @@ class HipRenderer:
         Kc = torch.as_tensor(K).detach().float().cpu()
         Pc = torch.as_tensor(pose).detach().float().cpu()
         cam = torch.cat([Pc[None].inverse()[0, :3].reshape(-1), torch.inverse(Kc).reshape(-1)]).contiguous()  # depth_fusion.py:19-26
-        # model.py:489 samples the coarse depths from rays['depth_range'] (the caller passes it); the frame's range is only the default.
-        # The 64 values are formed once on the host exactly like the reference forms them and kept on the device: no per-call
-        # host arithmetic or host-to-device copy on the render path.
-        zn, zf = self.near if near is None else float(near), self.far if far is None else float(far)
-        key = (n_coarse, zn, zf)
-        zrow = getattr(self, "_zc_rows", {}).get(key)
-        if zrow is None:
-            t_lin = torch.linspace(0, 1, n_coarse)
-            zrow = (torch.tensor(zn) * (1 - t_lin) + torch.tensor(zf) * t_lin).to(dev)
-            if not hasattr(self, "_zc_rows"):
-                self._zc_rows = {}
-            self._zc_rows[key] = zrow
+        near = self.near if near is None else near
+        far = self.far if far is None else far
+
+        def row(zn, zf, t_lin):   # the reference's own expression (model.py:451-458), evaluated where the operands live
+            return zn * (1 - t_lin) + zf * t_lin if not lindisp else 1 / (1 / zn * (1 - t_lin) + 1 / zf * t_lin)
+        if isinstance(near, torch.Tensor) or isinstance(far, torch.Tensor):
+            zn = torch.as_tensor(near, dtype=torch.float32).detach().to(dev)
+            zf = torch.as_tensor(far, dtype=torch.float32).detach().to(dev)
+            t_dev = self._zc_rows.get(("t", n_coarse))
+            if t_dev is None:   # linspace evaluated on the host (the goldens' arithmetic), uploaded once
+                t_dev = self._zc_rows[("t", n_coarse)] = torch.linspace(0, 1, n_coarse).to(dev)
+            zrow = row(zn, zf, t_dev)
+        else:   # python floats: the row is formed once on the host like the reference forms it and kept on the device (a few entries, reset per frame)
+            key = (n_coarse, float(near), float(far), bool(lindisp))
+            zrow = self._zc_rows.get(key)
+            if zrow is None:
+                if len(self._zc_rows) >= 8:
+                    self._zc_rows.clear()
+                zrow = row(torch.tensor(float(near)), torch.tensor(float(far)), torch.linspace(0, 1, n_coarse)).to(dev)
+                self._zc_rows[key] = zrow
         zc = zrow.expand(R, n_coarse).contiguous()
         wc = torch.empty(R, n_coarse, device=dev)
         dc = torch.empty(R, device=dev)

@@ -63,7 +63,30 @@ def test_render_opts_struct_matches_the_header():
     assert ctypes.sizeof(L.NlRenderOpts) == 32
     assert L.NlRenderOpts.early_term_eps.offset == 0 and L.NlRenderOpts.ray_centers.offset == 8
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "nerfloc_render.h")).read()
-    assert "#define NL_ABI_VERSION 2" in hdr and "const float* ray_centers;" in hdr
+    assert L.NlRenderOpts.flags.offset == 4
+    assert f"#define NL_ABI_VERSION {L.ABI_VERSION}" in hdr and "const float* ray_centers;" in hdr and "uint32_t flags;" in hdr
+
+
+def test_render_opts_validation_rejects_what_a_later_abi_could_define():
+    """nl_render_opts: unknown flag bits, non-zero reserved words and an early_term_eps outside [0, 1) (NaN included) are refused before
+    anything else is looked at — callers with uninitialised fields fail today instead of changing behaviour under a later ABI."""
+    import ctypes as ct
+    lib = _lib.load()
+    cfg = _lib.NlConfig(256, 192, 128, 1)
+    out = _lib.NlRenderOut()
+
+    def call(o):   # (no GPU here: the other arguments are null, which is refused too — the GPU suite repeats this with a live frame,
+        # tests/test_gpu_configs.py::test_render_opts_are_validated_and_streams_do_not_interfere)
+        return lib.nl_render_rays_ex(ct.byref(cfg), None, None, None, None, None, None, 4, 0, ct.byref(out), None, 0, None, ct.byref(o))
+    for bad in (dict(flags=2), dict(flags=0x80000000), dict(early_term_eps=float("nan")), dict(early_term_eps=1.0), dict(early_term_eps=-0.1)):
+        o = _lib.NlRenderOpts()
+        for k, v in bad.items():
+            setattr(o, k, v)
+        assert call(o) == _lib.NL_ERR_BAD_ARG, bad
+    o = _lib.NlRenderOpts()
+    o.reserved[2] = 7
+    assert call(o) == _lib.NL_ERR_BAD_ARG
+    assert lib.nl_frame_destroy(None) == _lib.NL_OK
 
 
 def test_build_post_check_agrees_with_the_header():

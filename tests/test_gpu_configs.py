@@ -138,3 +138,59 @@ def test_early_termination_keeps_parity_and_skips_work(name):
     skipped = float((T < eps).float().mean())
     print(f"\n{name}: early termination eps={eps}: {100 * skipped:.1f} % of the samples skipped, |d rgb| {e_rgb:.2e}, rel |d feat| {e_feat:.2e}")
     assert skipped > 0.02
+
+
+def test_render_opts_are_validated_and_streams_do_not_interfere():
+    """(1) nl_render_opts with unknown flag bits / non-zero reserved words / a bad eps is refused on an otherwise valid call.  (2) The side
+    stream belongs to the frame: two renderers (two frames) driven concurrently from two caller streams give results bit-identical to the
+    same renders done one after the other, and identical with the fork switched off (NL_RENDER_NO_SIDE_STREAM)."""
+    import ctypes as ct
+    from nerf_loc_amd import _lib as L
+    from nerf_loc_amd.synth import CONFIGS
+    sc = _scene("c2")
+    cfg = sc["cfg"].replace(R=1024)
+    sc = dict(sc, cfg=cfg)
+    ra, rb_ = _renderer(sc, "bf16x3"), _renderer(sc, "bf16x3")
+    dev = ra.device
+    o = torch.from_numpy(sc["rays"]["rays_o"][:1024]).to(dev)
+    d = torch.from_numpy(sc["rays"]["rays_d"][:1024]).to(dev)
+    d2 = torch.from_numpy(sc["rays"]["rays_d"][1024:2048]).to(dev)
+    qc = sc["frame"]["pose"][:3, 3]
+    z = _zbase(cfg, 1024).to(dev)
+    # (1) validation with a live frame and valid pointers
+    ws = torch.empty(ra.lib.nl_render_rays_workspace_bytes(ct.byref(ra.cfg), ra.V, 16), dtype=torch.uint8, device=dev)
+    outbuf = {k: torch.empty(16, n, device=dev) for k, n in (("rgb", 3), ("depth", 1), ("weights", cfg.S), ("depth_uncertainty", 1))}
+    ro = L.NlRenderOut()
+    for k, t in outbuf.items():
+        setattr(ro, k, t.data_ptr())
+    qch = torch.as_tensor(qc).float().contiguous()
+
+    def call(opts):
+        return ra.lib.nl_render_rays_ex(ct.byref(ra.cfg), ra.packed.data_ptr(), ra._frame, qch.data_ptr(), o.data_ptr(), d.data_ptr(), None, 16, 0,
+                                        ct.byref(ro), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream, ct.byref(opts))
+    assert call(L.NlRenderOpts()) == L.NL_OK
+    for bad in (dict(flags=2), dict(flags=0x80000000), dict(early_term_eps=float("nan")), dict(early_term_eps=1.0), dict(early_term_eps=-0.5)):
+        op = L.NlRenderOpts()
+        for k, v in bad.items():
+            setattr(op, k, v)
+        assert call(op) == L.NL_ERR_BAD_ARG, bad
+    op = L.NlRenderOpts()
+    op.reserved[3] = 1
+    assert call(op) == L.NL_ERR_BAD_ARG
+    torch.cuda.synchronize()
+    # (2) serial reference, then both renderers at once on two streams
+    ref_a = ra.render_rays(o, d, qc, z_vals=z)
+    ref_b = rb_.render_rays(o, d2, qc, z_vals=z)
+    nofork = ra.render_rays(o, d, qc, z_vals=z, side_stream=False)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert torch.equal(ref_a[k], nofork[k]), k
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            ca = ra.render_rays(o, d, qc, z_vals=z)
+        with torch.cuda.stream(s2):
+            cb = rb_.render_rays(o, d2, qc, z_vals=z)
+        torch.cuda.synchronize()
+        for k in KEYS:
+            assert torch.equal(ca[k], ref_a[k]) and torch.equal(cb[k], ref_b[k]), k
