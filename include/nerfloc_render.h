@@ -15,6 +15,8 @@
  *   nl_coarse_weights    MultiviewFeatureAggregator.predict_weights_from_neuray, multiview_aggregator.py:95-154
  *   nl_sample_pdf        sample_pdf + sort/merge, conditional_nerf/utils.py:73-112 and model.py:492-495
  *   nl_render_rays       ConditionalNeRF.render_rays, conditional_nerf/model.py:472-600 (eval mode), rows a2-a18 fused
+ *   nl_composite_backward  autograd of model.py:544-560,597 (compositing) — first slice of the backward pass
+ *   nl_knn_backward      ops/knn/src/knn.cu:449-490 (KNearestNeighborBackwardKernel), knn_cpu.cpp:68-117
  *   nl_pack_weights      (no reference counterpart: state_dict fp32 tensors -> kernel layouts; names = SURVEY App. C)
  *   nl_frame_*           per-frame caches the reference keeps on the module: `support_neural_points['fine']`
  *                        (model.py:79,180-197) and `multiview_aggregator.vis_featmaps` (multiview_aggregator.py:29,178)
@@ -244,6 +246,21 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* fra
 int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,
                       const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd,
                       const nl_render_out* out, void* ws, size_t ws_bytes, void* stream, const nl_render_opts* opts);
+
+/* ---- backward kernels, first slice ---------------------------------------------------- */
+/* Gradient of the alpha compositing of nl_render_rays / nl_heads_composite (conditional_nerf/model.py:544-560, 597; what autograd
+ * does for torch.cumprod & co. in the reference) w.r.t. its per-sample inputs.  The forward pass saves nothing: the transmittance is
+ * recomputed from z_vals and sigma.  Inputs as in the forward: z_vals (R,S), sigma (R,S), rgb_s (R,S,3) per-sample colours, ft (R,S,C) the
+ * per-sample rows that are composited into `feat` (or NULL).  Incoming gradients (each may be NULL = zero): g_rgb (R,3), g_depth (R),
+ * g_unc (R) [depth_uncertainty], g_feat (R,C), g_weights (R,S).  Outputs: g_sigma (R,S); g_rgb_s (R,S,3) and g_ft (R,S,C) may be NULL. */
+int nl_composite_backward(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, int64_t R, int S, int C, int white_bkgd,
+                          const float* g_rgb, const float* g_depth, const float* g_unc, const float* g_feat, const float* g_weights, float* g_sigma,
+                          float* g_rgb_s, float* g_ft, void* stream);
+/* Backward of nl_knn's squared distances — replaces KNearestNeighborBackwardKernel, ops/knn/src/knn.cu:449-490 (CPU: knn_cpu.cpp:68-117):
+ * g_xyz (N,3) = sum_k 2 g_d2[n,k] (xyz[n] - sp_xyz[idx[n,k]]); g_sp_xyz (M,3) or NULL receives the opposite sign by atomic adds and must be
+ * zero-initialised by the caller (like the reference's at::zeros).  Padded neighbour slots (k >= M) are skipped. */
+int nl_knn_backward(const float* xyz, const float* sp_xyz, const int32_t* idx, const float* g_d2, int64_t N, int K, int64_t M, float* g_xyz,
+                    float* g_sp_xyz, void* stream);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

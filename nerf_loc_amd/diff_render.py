@@ -22,6 +22,81 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
+# ----------------------------------------------------------------------------- HIP backward kernels (first slice)
+def _hip_ok(*tensors) -> bool:
+    return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def composite_eager(sigma: Tensor, rgb_s: Tensor, ft: Tensor, z_vals: Tensor, white_bkgd: bool):
+    """conditional_nerf/model.py:544-560, 597 in plain torch ops: -> (rgb, depth, depth_uncertainty, feat, weights); last interval 1e2."""
+    deltas = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], 1e2 * torch.ones_like(z_vals[:, :1])], -1)
+    alphas = 1 - torch.exp(-deltas * sigma)
+    T = torch.cumprod(torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas], -1)[:, :-1], -1)
+    wts = alphas * T
+    rgb = (wts[..., None] * rgb_s).sum(1)
+    if white_bkgd:
+        rgb = rgb + (1 - wts.sum(1)[:, None])
+    depth = (wts * z_vals).sum(1)
+    feat = (wts[..., None] * ft).sum(1)
+    unc = (wts * (z_vals - depth[:, None]) ** 2).sum(1)
+    return rgb, depth, unc, feat, wts
+
+
+class CompositeFn(torch.autograd.Function):
+    """Alpha compositing with the HIP backward kernel `nl_composite_backward` (the forward is the plain torch expression above; nothing but
+    the inputs is saved — the kernel recomputes the transmittance).  Inputs: sigma (R,S), rgb_s (R,S,3), ft (R,S,C), z_vals (R,S) [constant]."""
+
+    @staticmethod
+    def forward(ctx, sigma, rgb_s, ft, z_vals, white_bkgd):
+        ctx.white = bool(white_bkgd)
+        sigma, rgb_s, ft, z_vals = sigma.contiguous(), rgb_s.contiguous(), ft.contiguous(), z_vals.contiguous()
+        ctx.save_for_backward(sigma, rgb_s, ft, z_vals)
+        return composite_eager(sigma, rgb_s, ft, z_vals, ctx.white)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts):
+        from . import _lib as L
+        sigma, rgb_s, ft, z = ctx.saved_tensors
+        R, S = sigma.shape
+        C = ft.shape[-1]
+        gs, grs, gft = torch.empty_like(sigma), torch.empty_like(rgb_s), torch.empty_like(ft)
+        ptr = lambda t: None if t is None else t.contiguous().data_ptr()   # noqa: E731
+        keep = [None if g is None else g.contiguous() for g in (g_rgb, g_depth, g_unc, g_feat, g_wts)]
+        st = torch.cuda.current_stream(sigma.device).cuda_stream
+        with torch.cuda.device(sigma.device):
+            L.check(L.load().nl_composite_backward(z.data_ptr(), sigma.data_ptr(), rgb_s.data_ptr(), ft.data_ptr(), R, S, C, int(ctx.white),
+                                                   *[ptr(g) for g in keep], gs.data_ptr(), grs.data_ptr(), gft.data_ptr(), st), "nl_composite_backward")
+        return gs, grs, gft, None, None
+
+
+class KnnDist2Fn(torch.autograd.Function):
+    """Squared distances to the given neighbours with the HIP backward kernel `nl_knn_backward` (= the reference's
+    KNearestNeighborBackwardKernel, ops/knn/src/knn.cu:449-490)."""
+
+    @staticmethod
+    def forward(ctx, xyz, sp_xyz, idx):
+        xyz, sp_xyz = xyz.contiguous(), sp_xyz.contiguous()
+        idx32 = idx.to(torch.int32).contiguous()
+        ctx.save_for_backward(xyz, sp_xyz, idx32)
+        off = xyz[:, None, :] - sp_xyz[idx.long()]
+        return (off * off).sum(-1)
+
+    @staticmethod
+    def backward(ctx, g_d2):
+        from . import _lib as L
+        xyz, sp, idx32 = ctx.saved_tensors
+        N, K = idx32.shape
+        M = sp.shape[0]
+        g = g_d2.contiguous()
+        gx = torch.empty_like(xyz)
+        gsp = torch.zeros_like(sp) if ctx.needs_input_grad[1] else None
+        st = torch.cuda.current_stream(xyz.device).cuda_stream
+        with torch.cuda.device(xyz.device):
+            L.check(L.load().nl_knn_backward(xyz.data_ptr(), sp.data_ptr(), idx32.data_ptr(), g.data_ptr(), N, K, M, gx.data_ptr(),
+                                             None if gsp is None else gsp.data_ptr(), st), "nl_knn_backward")
+        return gx, gsp, None
+
+
 def rays_from_pose(uv: Tensor, K: Tensor, pose: Tensor):
     """conditional_nerf/utils.py:56-70 + model.py:687-700 for the selected pixels only (integer-truncated pixel coordinates):
     unit directions rotated by the camera-to-world pose, origin = its translation.  Differentiable w.r.t. `pose`."""
@@ -130,7 +205,12 @@ def _point_branch(p, fr, xyz: Tensor, dirs: Optional[Tensor], G: Tensor, idx: Te
     if dirs is None:
         dirs = nb_dir[:, 0, :3]
     off = xyz[:, None, :] - nb_xyz
-    d2 = (off * off).sum(-1)     # = the KNN op's squared distances; its backward (knn_cpu.cpp:68-117) is 2 (p1 - p2) grad, as autograd gives here
+    # = the KNN op's squared distances; its backward (knn.cu:449-490 / knn_cpu.cpp:68-117) is 2 (p1 - p2) grad: the HIP kernel on the GPU,
+    # plain autograd of the same expression elsewhere (CPU tests, fp64 checks)
+    if keep is None and _hip_ok(xyz, sp["xyz"]):
+        d2 = KnnDist2Fn.apply(xyz, sp["xyz"], idx)
+    else:
+        d2 = (off * off).sum(-1)
     dist = d2.sqrt() if keep is None else torch.where(keep.view(1, K), d2.clamp_min(1e-30).sqrt(), torch.zeros_like(d2))
     rd = dirs[:, None, :] - nb_dir[..., :3]
     rd = rd / (torch.norm(rd, dim=-1, keepdim=True) + 1e-8)
@@ -218,20 +298,14 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
         xb = _lrelu(_lin(p, f"rgb_blending_mlp.{i}", xb))
     bw = F.softmax(_lin(p, "rgb_blending_mlp.4", xb).masked_fill(mvv == 0, -1e9), dim=1)
     rgb_s = torch.sum(mvf[:, :, :3] * bw, dim=1).view(R, S, 3)
-    # front-to-back compositing (model.py:544-553): last interval 1e2
-    deltas = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], 1e2 * torch.ones_like(z_vals[:, :1])], -1)
-    alphas = 1 - torch.exp(-deltas * sigma)
-    T = torch.cumprod(torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas], -1)[:, :-1], -1)
-    wts = alphas * T
-    rgb = (wts[..., None] * rgb_s).sum(1)
-    if white_bkgd:
-        rgb = rgb + (1 - wts.sum(1)[:, None])
-    depth = (wts * z_vals).sum(1)
-    ft = _lin(p, "feat_mlp.2", _lrelu(_lin(p, "feat_mlp.0", agg)))
-    feat = (wts[..., None] * ft.view(R, S, -1)).sum(1)
+    # front-to-back compositing (model.py:544-560, 597): its backward is the HIP kernel nl_composite_backward on the GPU
+    ft = _lin(p, "feat_mlp.2", _lrelu(_lin(p, "feat_mlp.0", agg))).view(R, S, -1)
+    if _hip_ok(sigma, rgb_s, ft, z_vals) and not z_vals.requires_grad and S <= 256:
+        rgb, depth, unc, feat, wts = CompositeFn.apply(sigma, rgb_s, ft, z_vals, white_bkgd)
+    else:
+        rgb, depth, unc, feat, wts = composite_eager(sigma, rgb_s, ft, z_vals, white_bkgd)
     valid = (mask1.view(R, S, V).sum(2) > 1).float().sum(1) > 8
-    out = {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid,
-           "depth_uncertainty": (wts * (z_vals - depth[:, None]) ** 2).sum(1)}
+    out = {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": unc}
     if beta:
         out["beta"] = (wts * F.softplus(_lin(p, "beta_mlp.0", geo)).view(R, S)).sum(1) + 0.1   # beta_min, model.py:98
     return out
