@@ -16,6 +16,7 @@
  *   nl_sample_pdf        sample_pdf + sort/merge, conditional_nerf/utils.py:73-112 and model.py:492-495
  *   nl_render_rays       ConditionalNeRF.render_rays, conditional_nerf/model.py:472-600 (eval mode), rows a2-a18 fused
  *   nl_composite_backward  autograd of model.py:544-560,597 (compositing) — first slice of the backward pass
+ *   nl_point_mlp_backward  autograd of model.py:372-427 w.r.t. the sample positions / directions / query features (frozen weights)
  *   nl_knn_backward      ops/knn/src/knn.cu:449-490 (KNearestNeighborBackwardKernel), knn_cpu.cpp:68-117
  *   nl_pack_weights      (no reference counterpart: state_dict fp32 tensors -> kernel layouts; names = SURVEY App. C)
  *   nl_frame_*           per-frame caches the reference keeps on the module: `support_neural_points['fine']`
@@ -261,6 +262,18 @@ int nl_composite_backward(const float* z_vals, const float* sigma, const float* 
  * zero-initialised by the caller (like the reference's at::zeros).  Padded neighbour slots (k >= M) are skipped. */
 int nl_knn_backward(const float* xyz, const float* sp_xyz, const int32_t* idx, const float* g_d2, int64_t N, int K, int64_t M, float* g_xyz,
                     float* g_sp_xyz, void* stream);
+/* Input gradient of nl_point_mlp (rows a8-a12; conditional_nerf/model.py:372-427, ibrnet.py:89-119) with FROZEN weights and a frozen support
+ * table — the part of the backward pass PoseOptimizer needs (pose_optimizer.py:131-168 optimises the pose only) and the input-gradient half
+ * of a training step: g_feature_agg (N,W) -> g_xyz (N,3) [through the positional encoding of the neighbour offsets], g_dir (N,3) [through
+ * ray_diff_fc; NULL when dir is NULL] and g_mv_feat (N,W) [attention query + residual; may be NULL].  Nothing is saved by the forward call:
+ * the staged forward is re-run into the workspace (KNN, neighbour encoding, base_mlp, k / v / q projections, attention), then transposed-
+ * weight GEMMs and the reductions' derivatives walk back.  Arguments as nl_point_mlp (dir: one row per sample, row stride dir_stride).
+ * The neighbour weights' dependence on the distances is exactly zero for this network (the normalised weights multiply K identical rows)
+ * and is not propagated.  Samples are processed in chunks that fit the workspace. */
+size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N);
+int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, const float* dir, int64_t dir_stride,
+                          const float* mv_feat, int64_t N, int K, const float* g_feature_agg, float* g_xyz, float* g_dir, float* g_mv_feat, void* ws,
+                          size_t ws_bytes, void* stream);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

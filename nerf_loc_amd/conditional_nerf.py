@@ -522,7 +522,8 @@ class ConditionalNeRF(nn.Module):
             p = self._graph_params(False)
         out = diff_render.render_rays_diff(p, fr, o, d, z.to(o.dtype), data["pose"], lambda q: r.knn(q, 8)[1],
                                            white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
-                                           beta=train and bool(self.args.render.use_render_uncertainty))
+                                           beta=train and bool(self.args.render.use_render_uncertainty),
+                                           frozen_renderer=None if train else r)   # eval: weights + support table are constants -> HIP backward of the point branch
         if not self.args.render.render_feature:
             out.pop("feat")
         if depth_coarse is not None:

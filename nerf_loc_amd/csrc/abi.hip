@@ -60,6 +60,15 @@ int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
+// backward.hip: glue kernels of the neural-point branch's input gradient
+int nl_launch_ln_agg_backward(const float* FC, const float* G, const float* gy, int64_t N, int W, const float* gamma, float eps, const float* wscale, float* gx,
+                              hipStream_t st);
+int nl_launch_attn_backward(const float* Q, const float* KV, const float* gO, int64_t N, int K, float* gQ, float* gKV, hipStream_t st);
+int nl_launch_lrelu_mask(float* g, const float* h, size_t n, hipStream_t st);
+int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t st);
+int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
+                                    const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
+                                    float* g_dir, hipStream_t st);
 
 namespace {
 
@@ -105,7 +114,9 @@ static_assert(kNumWeights == 84, "weight table");
 // ------------------------------------------------------------------------------------------ GEMM layer table
 enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
-  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_QP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT, G_COUNT
+  G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_QP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT,
+  G_FC_T, G_Q_T, G_KV_T, G_BASE4_T, G_BASE2_T, G_BASE0_T,   // transposed weights: input gradients of the neural-point branch (do_point_backward)
+  G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
 
@@ -170,6 +181,14 @@ Layout make_layout(const nl_config* c) {
   set(G_BLENDP, C, 32, false);
   // per-frame neural-point table T = sp_feature . base_mlp.0.weight[:, :F]^T + bias, columns in accumulator order (point_fused.hip)
   set(G_PTT, F, W, true);
+  // dX = dY . W for y = x W^T: K = the layer's outputs, N = its inputs; base_mlp.0 only towards its posenc + ray_diff_fc columns
+  // (the feature columns multiply rows of the frozen support table)
+  set(G_FC_T, W, 128, false);
+  set(G_Q_T, 128, W, false);
+  set(G_KV_T, 256, W, false);
+  set(G_BASE4_T, W, W, false);
+  set(G_BASE2_T, W, W, false);
+  set(G_BASE0_T, W, 96, false);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
   for (int i = 0; i < G_COUNT; ++i) {
@@ -655,6 +674,63 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   return NL_OK;
 }
 
+// ---- input gradient of the neural-point branch (frozen weights) ---------------------------------------------------------------------
+struct PtBwdBufs { int* idx; float *d2, *X, *H1, *H2, *H3, *KV, *Q, *O, *FCo, *wscale, *gpre, *gO, *gQ, *gKV, *gA, *gB, *gX; };
+void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p) {
+  const int W = c->W;
+  const size_t NK = (size_t)N * K;
+  p.idx = b.take<int>(NK); p.d2 = b.take<float>(NK);
+  p.X = b.take<float>(NK * ldx_of(c->C));
+  p.H1 = b.take<float>(NK * W); p.H2 = b.take<float>(NK * W); p.H3 = b.take<float>(NK * W);
+  p.KV = b.take<float>(NK * 256);
+  p.Q = b.take<float>((size_t)N * 128); p.O = b.take<float>((size_t)N * 128); p.FCo = b.take<float>((size_t)N * W); p.wscale = b.take<float>((size_t)N);
+  p.gpre = b.take<float>((size_t)N * W); p.gO = b.take<float>((size_t)N * 128); p.gQ = b.take<float>((size_t)N * 128);
+  p.gKV = b.take<float>(NK * 256); p.gA = b.take<float>(NK * W); p.gB = b.take<float>(NK * W); p.gX = b.take<float>(NK * 96);
+}
+
+// Re-runs the staged forward (point.hip kernels + segment GEMMs in the configured precision) into the workspace, then walks back:
+// g_FA -> LayerNorm/scale -> {residual -> g_G ; fc^T -> attention -> {w_qs^T -> g_G ; [w_ks; w_vs]^T -> base_mlp^T x 3 with LeakyReLU masks ->
+// posenc / ray_diff_fc -> g_xyz, g_dir}}.  The aggregation scale sum_k w_k is a constant of the backward pass: it is identically 1 (or 0)
+// whatever the distances are (model.py:419-427 normalises the weights; the K rows they multiply are identical, see point.hip).
+int do_point_backward(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
+                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p) {
+  const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
+  const int64_t NK = N * K;
+  const float inv_span = 1.f / (f->views.far_ - f->views.near_);
+  const int64_t M = f->M;
+  // ---- forward, staged
+  NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
+  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, 1, N, K, M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
+                                inv_span, p.X, ldx, p.wscale, x.st));
+  SegSpec sx{p.X, ldx, F + 90, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
+  NL_TRY(run_gemm(x, G_BASE0, &sx, 1, NK, p.H1, W, NL_ACT_LRELU));
+  NL_TRY(run_gemm(x, G_BASE2, &s1, 1, NK, p.H2, W, NL_ACT_LRELU));
+  NL_TRY(run_gemm(x, G_BASE4, &s2, 1, NK, p.H3, W, NL_ACT_LRELU));
+  NL_TRY(run_gemm(x, G_KV, &s3, 1, NK, p.KV, 256, NL_ACT_NONE));
+  NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
+  NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
+  NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE));
+  // ---- backward
+  NL_TRY(nl_launch_ln_agg_backward(p.FCo, G, gFA, N, W, x.p<float>(x.L.ln_g), 1e-6f, p.wscale, p.gpre, x.st));
+  SegSpec sp{p.gpre, W, W, 0, 1}, sgq{p.gQ, 128, 128, 0, 1}, skv{p.gKV, 256, 256, 0, 1}, sa{p.gA, W, W, 0, 1}, sb{p.gB, W, W, 0, 1};
+  NL_TRY(run_gemm(x, G_FC_T, &sp, 1, N, p.gO, 128, NL_ACT_NONE));
+  NL_TRY(nl_launch_attn_backward(p.Q, p.KV, p.gO, N, K, p.gQ, p.gKV, x.st));
+  if (g_G) {   // residual path + query projection
+    NL_TRY(run_gemm(x, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
+    NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
+  }
+  NL_TRY(run_gemm(x, G_KV_T, &skv, 1, NK, p.gA, W, NL_ACT_NONE));
+  NL_TRY(nl_launch_lrelu_mask(p.gA, p.H3, (size_t)NK * W, x.st));
+  NL_TRY(run_gemm(x, G_BASE4_T, &sa, 1, NK, p.gB, W, NL_ACT_NONE));
+  NL_TRY(nl_launch_lrelu_mask(p.gB, p.H2, (size_t)NK * W, x.st));
+  NL_TRY(run_gemm(x, G_BASE2_T, &sb, 1, NK, p.gA, W, NL_ACT_NONE));
+  NL_TRY(nl_launch_lrelu_mask(p.gA, p.H1, (size_t)NK * W, x.st));
+  NL_TRY(run_gemm(x, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
+  NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, 1, N, K, M, p.idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
+                                         g_dir, x.st));
+  return NL_OK;
+}
+
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and
 // *sigma_done is set; otherwise the caller runs sigma_kernel on geo
 // need_geo == false: the caller only wants the density (model.py:525 is the sole consumer of the U-Net's output); when the density
@@ -859,6 +935,24 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   }
   P.linear(G_Q, t[T_WQ], nullptr);
   P.linear(G_FC, t[T_FC], nullptr);
+  // transposed copies (element [k = output o][n = input i] = w[o][i]): source strides swapped
+  P.block(G_FC_T, 0, t[T_FC], 0, 1, 128, W);
+  P.block(G_Q_T, 0, t[T_WQ], 0, 1, W, 128);
+  {
+    const GemmDim& d = L.g[G_KV_T];   // K = [k-projection outputs 128 | v-projection outputs 128]
+    for (int half = 0; half < 2; ++half)
+      hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(128 * W, 256)), dim3(256), 0, st, t[half ? T_WV : T_WK], 0, 1, W, 128, W, half * 128,
+                         (float*)((char*)packed + L.b32[G_KV_T]), (unsigned short*)((char*)packed + L.bhi[G_KV_T]),
+                         (unsigned short*)((char*)packed + L.blo[G_KV_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_KV_T]), nl_tgemm_nrt(d.N), 0);
+  }
+  P.block(G_BASE4_T, 0, t[T_B4W], 0, 1, W, W);
+  P.block(G_BASE2_T, 0, t[T_B2W], 0, 1, W, W);
+  {
+    const GemmDim& d = L.g[G_BASE0_T];   // columns F .. F+89 of base_mlp.0.weight (W, F + 90); the 6 pad columns stay zero
+    hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(W * 90, 256)), dim3(256), 0, st, t[T_B0W], F, 1, F + 90, W, 90, 0,
+                       (float*)((char*)packed + L.b32[G_BASE0_T]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_T]),
+                       (unsigned short*)((char*)packed + L.blo[G_BASE0_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_T]), nl_tgemm_nrt(d.N), 0);
+  }
   const float* const* un = t + T_UNET;
   { const int w1[1] = {W}, w2[1] = {64}, w3[1] = {128};
     P.conv3(G_CONV1, un[0], un[1], W, w1, 1);
@@ -1036,6 +1130,43 @@ int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, co
   NL_TRY(do_point(x, f, xyz, dir, (int)dir_stride, 1, mv_feat, N, K, feature_agg, p));
   if (knn_idx) NL_CHECK_HIP(hipMemcpyAsync(knn_idx, p.idx, sizeof(int) * N * K, hipMemcpyDeviceToDevice, x.st));
   if (knn_d2) NL_CHECK_HIP(hipMemcpyAsync(knn_d2, p.d2, sizeof(float) * N * K, hipMemcpyDeviceToDevice, x.st));
+  return NL_OK;
+}
+
+static size_t point_bwd_bytes(const nl_config* cfg, int64_t n) { Bump b{nullptr, 0}; PtBwdBufs p; carve_ptb(b, cfg, n, 8, p); return b.off; }
+
+size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N) {
+  if (!cfg_ok(cfg)) return 0;
+  const int64_t n = N < 1 ? 1 : (N > (1 << 14) ? (1 << 14) : N);   // recommended: chunks of <= 16 384 samples (131 072 neighbour rows, ~1.1 GB at W = 256)
+  return point_bwd_bytes(cfg, n);
+}
+
+int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
+                          const float* mv_feat, int64_t N, int K, const float* g_feature_agg, float* g_xyz, float* g_dir, float* g_mv_feat, void* ws,
+                          size_t ws_bytes, void* stream) {
+  if (N == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
+  if (f->M < 1) return NL_ERR_UNSUPPORTED;
+  if (ws_bytes < point_bwd_bytes(cfg, 1)) return NL_ERR_WORKSPACE;
+  // The backward pass always multiplies in exact fp32 (v_mfma_f32_32x32x2_f32), whatever the forward's mode: the gradient w.r.t. the sample
+  // positions sums positional-encoding terms of alternating sign scaled by up to 2^9 — a conditioning of ~1e3 that turns split-bf16's 1e-5
+  // into 2e-2 (measured) and plain fp32 autograd's 1e-6 into 4e-3; batches that are differentiated are small (PoseOptimizer: 512 rays).
+  nl_config c32 = *cfg;
+  c32.precision = NL_PREC_F32;
+  int64_t lo = 1, hi = N;
+  while (lo < hi) {   // largest sample chunk whose buffers fit the workspace
+    const int64_t mid = (lo + hi + 1) / 2;
+    if (point_bwd_bytes(cfg, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
+  }
+  const int64_t NC = lo < (1 << 17) ? lo : (1 << 17);
+  Ctx x = make_ctx(&c32, packed, stream);
+  const int W = cfg->W;
+  for (int64_t n0 = 0; n0 < N; n0 += NC) {
+    const int64_t nc = N - n0 < NC ? N - n0 : NC;
+    Bump b{(char*)ws, 0}; PtBwdBufs p; carve_ptb(b, cfg, nc, 8, p);
+    NL_TRY(do_point_backward(x, f, xyz + 3 * n0, dir ? dir + dir_stride * n0 : nullptr, (int)dir_stride, mv_feat + n0 * W, nc, K, g_feature_agg + n0 * W,
+                             g_xyz + 3 * n0, g_dir ? g_dir + 3 * n0 : nullptr, g_mv_feat ? g_mv_feat + n0 * W : nullptr, p));
+  }
   return NL_OK;
 }
 

@@ -97,6 +97,29 @@ class KnnDist2Fn(torch.autograd.Function):
         return gx, gsp, None
 
 
+class PointBranchFn(torch.autograd.Function):
+    """The neural-point branch (model.py:372-427) with FROZEN weights as one autograd node on the HIP library: forward = the fused kernels
+    of `nl_point_mlp`, backward = `nl_point_mlp_backward` (staged recompute + transposed-weight GEMMs; nothing is saved but the inputs).
+    Used by the pose-refinement gradient path (eval mode: the weights and the support table are constants, pose_optimizer.py:131-168);
+    training keeps the eager graph, which also reaches the weights.  `renderer`: a HipRenderer holding the same weights and frame."""
+
+    @staticmethod
+    def forward(ctx, xyz, dirs, G, renderer, K):
+        xyz, G = xyz.contiguous(), G.contiguous()
+        dirs = None if dirs is None else dirs.contiguous()
+        ctx.r, ctx.K, ctx.has_dir = renderer, int(K), dirs is not None
+        ctx.save_for_backward(xyz, G, *([dirs] if dirs is not None else []))
+        fa, _, _ = renderer.point_mlp(xyz, dirs, G, K=int(K))
+        return fa
+
+    @staticmethod
+    def backward(ctx, g_fa):
+        xyz, G = ctx.saved_tensors[:2]
+        dirs = ctx.saved_tensors[2] if ctx.has_dir else None
+        gx, gd, gg = ctx.r.point_mlp_backward(xyz, dirs, G, g_fa.contiguous(), K=ctx.K)
+        return gx, gd, gg, None, None
+
+
 def rays_from_pose(uv: Tensor, K: Tensor, pose: Tensor):
     """conditional_nerf/utils.py:56-70 + model.py:687-700 for the selected pixels only (integer-truncated pixel coordinates):
     unit directions rotated by the camera-to-world pose, origin = its translation.  Differentiable w.r.t. `pose`."""
@@ -275,19 +298,24 @@ def _view_angles(xyz: Tensor, query_center: Tensor, view_centers: Tensor) -> Ten
 
 
 def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, query_pose: Tensor,
-                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False, beta: bool = False) -> Dict[str, Tensor]:
+                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False, beta: bool = False, frozen_renderer=None) -> Dict[str, Tensor]:
     """conditional_nerf/model.py:472-600 with autograd.  `z_vals` (R, S) are constants (the hierarchical resampling detaches its
     weights, model.py:495); `knn_idx(xyz) -> (N, 8) int64` is the exact KNN (no gradient: indices); beta: the training-mode
     uncertainty output (model.py:587-592).  Gradients reach whatever requires grad among rays_o / rays_d / query_pose, the
-    parameters `p` and the frame tensors.
+    parameters `p` and the frame tensors.  frozen_renderer: a HipRenderer holding exactly `p` and `fr['support']` — states that both are
+    constants of this call, so the neural-point branch may run as PointBranchFn (HIP forward + HIP backward) instead of eager ops.
     fr: topk_Ks, topk_poses, topk_images, feat_fine_src, vis_featmaps, near, far (python floats), support {xyz, feature, confidence, direction}."""
     R, S = z_vals.shape
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3)
     G, mvf, mvv, mask1 = _mv_aggregate(p, fr, xyz)
-    with torch.no_grad():
-        idx = knn_idx(xyz.detach()).long()
-    agg = _point_branch(p, fr, xyz, dirs, G, idx)
+    if frozen_renderer is not None and _hip_ok(xyz, dirs, G):
+        # frozen weights + frozen support table (pose refinement): the whole branch is one node whose backward is nl_point_mlp_backward
+        agg = PointBranchFn.apply(xyz, dirs.contiguous(), G, frozen_renderer, 8)
+    else:
+        with torch.no_grad():
+            idx = knn_idx(xyz.detach()).long()
+        agg = _point_branch(p, fr, xyz, dirs, G, idx)
     W = agg.shape[1]
     geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
     sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)

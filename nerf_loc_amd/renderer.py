@@ -244,6 +244,22 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
+    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8):
+        """Input gradient of `point_mlp` with frozen weights (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W))."""
+        self._ready()
+        dev = self.device
+        x, g, gy = _dev_f32(xyz, dev), _dev_f32(mv_feat, dev), _dev_f32(g_feature_agg, dev)
+        N = x.shape[0]
+        dr = None if direction is None else _dev_f32(direction, dev)
+        gx = torch.empty(N, 3, device=dev)
+        gd = None if dr is None else torch.empty(N, 3, device=dev)
+        gg = torch.empty(N, self.W, device=dev)
+        ws = self._workspace(self.lib.nl_point_mlp_backward_workspace_bytes(ct.byref(self.cfg), N))
+        L.check(self.lib.nl_point_mlp_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
+                                               g.data_ptr(), N, K, gy.data_ptr(), gx.data_ptr(), _ptr(gd), gg.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               self._stream()), "nl_point_mlp_backward")
+        return gx, gd, gg
+
     def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64, near=None, far=None, lindisp: bool = False):
         """a20: coarse NeuRay weights along the pixel rays -> inverse-CDF samples (uniforms `u` (R,Ni)) merged with
         z_base (R,Sb) and sorted.  Returns (z_vals (R,Sb+Ni), depth_coarse (R,), weights_coarse (R,n_coarse)).

@@ -85,3 +85,50 @@ def test_knn_backward_matches_autograd(N, K, M):
     a3 = xyz.clone().requires_grad_(True)
     g3 = torch.autograd.grad((dr.KnnDist2Fn.apply(a3, sp, idx) * cot).sum(), a3)[0]
     assert torch.equal(g3, ga)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,precision,tol", [("tiny_full", "fp32", 2e-4), ("c1", "fp32", 2e-4), ("w256s128", "fp32", 2e-4), ("w256s128", "bf16x3", 2e-4),
+                                                ("fewpts", "fp32", 2e-4)])
+def test_point_branch_backward_matches_autograd(case, precision, tol):
+    """nl_point_mlp_backward (frozen weights) against autograd of the eager restatement of the branch (diff_render._point_branch, itself
+    checked against the reference's autograd): gradients w.r.t. the sample positions, the viewing directions and the query features."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case(case)
+    cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    # (fewpts: fewer support points than K — zero rows at distance 0 in the padded neighbour slots, knn_utils.py:211-220.  bf16x3: the
+    # FORWARD mode; the backward pass multiplies in exact fp32 in every mode)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = {k: t(v) for k, v in c["weights"].items()}
+    fr = {"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}}
+    R = min(cfg.R, 12)
+    o, d = t(rays["rays_o"][:R]), t(rays["rays_d"][:R])
+    lin = torch.linspace(0, 1, cfg.S, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, cfg.S)
+    xyz = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
+    dirs = d[:, None, :].expand(R, cfg.S, 3).reshape(-1, 3).contiguous()
+    g = torch.Generator().manual_seed(3)
+    G = torch.randn(xyz.shape[0], cfg.W, generator=g).to(dev)
+    cot = torch.randn(xyz.shape[0], cfg.W, generator=g).to(dev)
+    idx = r.knn(xyz, 8)[1].long()
+
+    def grads(fn, dt):
+        a, b, cc = (v.detach().to(dt).requires_grad_(True) for v in (xyz, dirs, G))
+        out = fn(a, b, cc, dt)
+        return out.detach(), torch.autograd.grad((out * cot.to(dt)).sum(), [a, b, cc])
+    cast = lambda tree, dt: {k: (cast(v, dt) if isinstance(v, dict) else (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v)) for k, v in tree.items()}
+    eager = lambda a, b, cc, dt: dr._point_branch(cast(p, dt), cast(fr, dt), a, b, cc, idx)
+    hip = lambda a, b, cc, dt: dr.PointBranchFn.apply(a, b, cc, r, 8)
+    o_hip, g_hip = grads(hip, torch.float32)
+    o_ref, g_ref = grads(eager, torch.float32)
+    _, g_64 = grads(eager, torch.float64)
+    assert rel_err(o_hip.cpu().numpy(), o_ref.cpu().numpy()) < (1e-4 if precision == "bf16x3" else 5e-5)
+    for name, a, b, c64 in zip(("xyz", "dirs", "G"), g_hip, g_ref, g_64):
+        e_hip, e_ref = rel_err(a.cpu().numpy(), c64.cpu().numpy()), rel_err(b.cpu().numpy(), c64.cpu().numpy())
+        print(case, precision, name, "hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
+        assert e_hip < max(tol, 3 * e_ref), (name, e_hip, e_ref)

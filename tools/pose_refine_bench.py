@@ -27,22 +27,29 @@ pose = t(frame["pose"]).clone().requires_grad_(True)
 tf = torch.randn(R, cfg.C, device=dev)
 knn = lambda q: r.knn(q, 8)[1]
 
-def step():
+def step(frozen):
     o, d = dr.rays_from_pose(uv, K, pose)
-    out = dr.render_rays_diff(p, fr, o, d, z, pose, knn)
+    out = dr.render_rays_diff(p, fr, o, d, z, pose, knn, frozen_renderer=r if frozen else None)
     loss = torch.mean(((out["feat"] - tf) * out["mask"].unsqueeze(1)) ** 2)
     g, = torch.autograd.grad(loss, pose)
     return g
 
-for _ in range(2): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps): g = step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+res = {}
+for frozen in (False, True):   # False: everything eager (round 2); True: the neural-point branch as one HIP node (forward + nl_point_mlp_backward)
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(2): step(frozen)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): g = step(frozen)
+    torch.cuda.synchronize()
+    res[frozen] = ((time.perf_counter() - t0) / steps, torch.cuda.max_memory_allocated() / 2**30, g.clone())
+dt = res[False][0]
+print(f"{R} rays x {cfg.S} samples: gradient step with the HIP point-branch backward {res[True][0]*1e3:.1f} ms, peak memory {res[True][1]:.1f} GiB; "
+      f"relative difference of dL/dpose to the eager graph {float((res[True][2] - res[False][2]).abs().max() / res[False][2].abs().max()):.2e}")
 with torch.no_grad():
     o, d = dr.rays_from_pose(uv, K, pose)
     for _ in range(3): r.render_rays(o, d, pose[:3, 3])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): r.render_rays(o, d, pose[:3, 3])
     torch.cuda.synchronize(); df = (time.perf_counter() - t0) / steps
-print(f"{R} rays x {cfg.S} samples: gradient step (eager fp32 autograd + HIP KNN) {dt*1e3:.1f} ms, peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB; "
+print(f"{R} rays x {cfg.S} samples: gradient step (eager fp32 autograd + HIP KNN) {dt*1e3:.1f} ms, peak memory {res[False][1]:.1f} GiB; "
       f"HIP forward alone {df*1e3:.2f} ms; |dL/dpose| max {float(g.abs().max()):.3e}")
