@@ -321,9 +321,12 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)
     V = mvf.shape[1]
     ang = _view_angles(xyz, query_pose[:3, 3], fr["topk_poses"][:, :3, 3])
-    xb = torch.cat([agg.unsqueeze(1).expand(-1, V, -1), mvf, mvv, ang], -1)
-    for i in (0, 2):
-        xb = _lrelu(_lin(p, f"rgb_blending_mlp.{i}", xb))
+    # rgb_blending_mlp.0 on cat[feature_agg (repeated over the views), multi-view feature, visibility, view angles] (model.py:532-535), evaluated
+    # by linearity as four partial products: the (N, V, W + C + 8) concatenation (1.2 GB per 512-ray batch) is never materialised
+    w0, b0 = p["rgb_blending_mlp.0.weight"], p["rgb_blending_mlp.0.bias"]
+    Fd = mvf.shape[-1]
+    xb = (F.linear(agg, w0[:, :W]) + b0).unsqueeze(1) + F.linear(mvf, w0[:, W:W + Fd]) + mvv * w0[:, W + Fd] + F.linear(ang, w0[:, W + Fd + 1:])
+    xb = _lrelu(_lin(p, "rgb_blending_mlp.2", _lrelu(xb)))
     bw = F.softmax(_lin(p, "rgb_blending_mlp.4", xb).masked_fill(mvv == 0, -1e9), dim=1)
     rgb_s = torch.sum(mvf[:, :, :3] * bw, dim=1).view(R, S, 3)
     # front-to-back compositing (model.py:544-560, 597): its backward is the HIP kernel nl_composite_backward on the GPU
