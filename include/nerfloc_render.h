@@ -275,6 +275,24 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
                           const float* mv_feat, int64_t N, int K, const float* g_feature_agg, float* g_xyz, float* g_dir, float* g_mv_feat, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* Input gradient of nl_mv_aggregate's feature rows (rows a4-a7; multiview_aggregator.py:156-222, ibrnet.py:169-231, visibility_decoder.py:64-148)
+ * with frozen weights and frozen support maps: g_mv_feat (N,W) -> g_xyz (N,3).  The forward is recomputed in exact fp32; the way back goes through
+ * out_fc (transposed-weight products, ELU), the visibility-weighted statistics, the bilinear taps' spatial derivative (zeros padding,
+ * align_corners = True), the projection, and — for the visibility weights and the depth difference — the NeuRay decoders, the border-mode tap of
+ * the visibility map and the NeuRay projection. */
+size_t nl_mv_aggregate_backward_workspace_bytes(const nl_config* cfg, int V, int64_t N);
+int nl_mv_aggregate_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, int64_t N, const float* g_mv_feat,
+                             float* g_xyz, void* ws, size_t ws_bytes, void* stream);
+/* a15 as a stage (model.py:528-538): per-sample colours rgb_s (N,3) = softmax-over-views blend of the tapped colours, from the sample positions and
+ * feature_agg (N,W) (query_center HOST, 3 floats) — what nl_render_rays computes between the neural-point branch and the compositing — and its
+ * input gradient: g_rgb_s (N,3) -> g_xyz (N,3), g_feature_agg (N,W) or NULL, g_query_center (N,3: per-sample contributions, the caller sums
+ * them) or NULL.  One workspace size serves both. */
+size_t nl_blend_workspace_bytes(const nl_config* cfg, int V, int64_t N);
+int nl_blend(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center, const float* xyz, const float* feature_agg, int64_t N,
+             float* rgb_s, void* ws, size_t ws_bytes, void* stream);
+int nl_blend_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center, const float* xyz, const float* feature_agg,
+                      int64_t N, const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center, void* ws, size_t ws_bytes, void* stream);
+
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop
 #endif

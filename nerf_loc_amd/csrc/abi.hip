@@ -66,6 +66,14 @@ int nl_launch_ln_agg_backward(const float* FC, const float* G, const float* gy, 
 int nl_launch_attn_backward(const float* Q, const float* KV, const float* gO, int64_t N, int K, float* gQ, float* gKV, hipStream_t st);
 int nl_launch_lrelu_mask(float* g, const float* h, size_t n, hipStream_t st);
 int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t st);
+int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
+                               int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
+                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, hipStream_t st);
+int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, const float* g_vis, const float* g_dd,
+                           float* g_xyz, hipStream_t st);
+int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
+                             const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st);
+int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
                                     float* g_dir, hipStream_t st);
@@ -116,6 +124,7 @@ enum {
   G_OUTFC0 = 0, G_OUTFC2, G_BASE0, G_BASE2, G_BASE4, G_KV, G_Q, G_FC, G_CONV1, G_CONV2, G_CONV3,
   G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_QP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT,
   G_FC_T, G_Q_T, G_KV_T, G_BASE4_T, G_BASE2_T, G_BASE0_T,   // transposed weights: input gradients of the neural-point branch (do_point_backward)
+  G_OUTFC2_T, G_OUTFC0_T, G_BLENDA_T,                         // ... of the multi-view aggregation's out_fc and of the blend's per-sample projection
   G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
@@ -189,6 +198,9 @@ Layout make_layout(const nl_config* c) {
   set(G_BASE4_T, W, W, false);
   set(G_BASE2_T, W, W, false);
   set(G_BASE0_T, W, 96, false);
+  set(G_OUTFC2_T, W, 64, false);
+  set(G_OUTFC0_T, 64, (int)nl_align_up(2 * F + 3, 32), false);   // = ldg_of(C): the statistics row incl. its zero padding (416 columns: generic kernels)
+  set(G_BLENDA_T, 32, W, false);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
   for (int i = 0; i < G_COUNT; ++i) {
@@ -196,7 +208,7 @@ Layout make_layout(const nl_config* c) {
     L.b32[i] = take(n * 4);
     L.bhi[i] = take(n * 2);
     L.blo[i] = take(n * 2);
-    L.bst[i] = take(nl_tgemm_stream_bytes(L.g[i].Kpad, L.g[i].N));
+    L.bst[i] = take(L.g[i].N <= 256 ? nl_tgemm_stream_bytes(L.g[i].Kpad, L.g[i].N) : 0);
     L.bias[i] = take((size_t)L.g[i].Npad * 4);
   }
   L.rd_w = take(4 * (64 + 16 + 27 * 16 + 27));
@@ -254,6 +266,7 @@ __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld
   const unsigned short l = pk_f2bf(v - hf);
   blo[(size_t)n * Kpad + k0 + k] = l;
   // weight stream of tgemm.hip: chunk (32 k) = [part hi/lo][k-step][row tile][lane = (n&31) + 32*((k>>3)&1)][k&7]
+  if (!bst) return;   // (matrices wider than 256 columns have no streaming layout: generic kernels only)
   const int kk = k0 + k, ng = n0 + n;
   const size_t e = (size_t)(kk >> 5) * (4 * nrts * 512) + ((size_t)(((kk >> 4) & 1) * nrts + (ng >> 5)) * 64 + (ng & 31) + 32 * ((kk >> 3) & 1)) * 8 + (kk & 7);
   bst[e] = h;
@@ -692,7 +705,7 @@ void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p) {
 // g_FA -> LayerNorm/scale -> {residual -> g_G ; fc^T -> attention -> {w_qs^T -> g_G ; [w_ks; w_vs]^T -> base_mlp^T x 3 with LeakyReLU masks ->
 // posenc / ray_diff_fc -> g_xyz, g_dir}}.  The aggregation scale sum_k w_k is a constant of the backward pass: it is identically 1 (or 0)
 // whatever the distances are (model.py:419-427 normalises the weights; the K rows they multiply are identical, see point.hip).
-int do_point_backward(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
+int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
                       const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p) {
   const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
   const int64_t NK = N * K;
@@ -713,22 +726,96 @@ int do_point_backward(const Ctx& x, const nl_frame* f, const float* xyz, const f
   // ---- backward
   NL_TRY(nl_launch_ln_agg_backward(p.FCo, G, gFA, N, W, x.p<float>(x.L.ln_g), 1e-6f, p.wscale, p.gpre, x.st));
   SegSpec sp{p.gpre, W, W, 0, 1}, sgq{p.gQ, 128, 128, 0, 1}, skv{p.gKV, 256, 256, 0, 1}, sa{p.gA, W, W, 0, 1}, sb{p.gB, W, W, 0, 1};
-  NL_TRY(run_gemm(x, G_FC_T, &sp, 1, N, p.gO, 128, NL_ACT_NONE));
+  NL_TRY(run_gemm(xb, G_FC_T, &sp, 1, N, p.gO, 128, NL_ACT_NONE));
   NL_TRY(nl_launch_attn_backward(p.Q, p.KV, p.gO, N, K, p.gQ, p.gKV, x.st));
   if (g_G) {   // residual path + query projection
-    NL_TRY(run_gemm(x, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
+    NL_TRY(run_gemm(xb, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
     NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
   }
-  NL_TRY(run_gemm(x, G_KV_T, &skv, 1, NK, p.gA, W, NL_ACT_NONE));
+  NL_TRY(run_gemm(xb, G_KV_T, &skv, 1, NK, p.gA, W, NL_ACT_NONE));
   NL_TRY(nl_launch_lrelu_mask(p.gA, p.H3, (size_t)NK * W, x.st));
-  NL_TRY(run_gemm(x, G_BASE4_T, &sa, 1, NK, p.gB, W, NL_ACT_NONE));
+  NL_TRY(run_gemm(xb, G_BASE4_T, &sa, 1, NK, p.gB, W, NL_ACT_NONE));
   NL_TRY(nl_launch_lrelu_mask(p.gB, p.H2, (size_t)NK * W, x.st));
-  NL_TRY(run_gemm(x, G_BASE2_T, &sb, 1, NK, p.gA, W, NL_ACT_NONE));
+  NL_TRY(run_gemm(xb, G_BASE2_T, &sb, 1, NK, p.gA, W, NL_ACT_NONE));
   NL_TRY(nl_launch_lrelu_mask(p.gA, p.H1, (size_t)NK * W, x.st));
-  NL_TRY(run_gemm(x, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
+  NL_TRY(run_gemm(xb, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
   NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, 1, N, K, M, p.idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
                                          g_dir, x.st));
   return NL_OK;
+}
+
+// ---- input gradients of the multi-view aggregation and of the colour blend (frozen weights) ------------------------------------------
+struct MvBwdBufs { float *vis, *dd, *g393, *t64, *G, *gA, *gt64, *gg393, *gvis, *gdd, *bl1, *rgbv, *blA, *ghA, *gpf, *grgbv, *gang; int* valid_s; };
+void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdBufs& m) {
+  const int W = c->W, ldg = ldg_of(c->C);
+  m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N); m.gvis = b.take<float>((size_t)V * N); m.gdd = b.take<float>((size_t)V * N);
+  m.g393 = b.take<float>((size_t)N * ldg); m.valid_s = b.take<int>((size_t)N);
+  if (!blend) {
+    m.t64 = b.take<float>((size_t)N * 64); m.G = b.take<float>((size_t)N * W); m.gA = b.take<float>((size_t)N * W);
+    m.gt64 = b.take<float>((size_t)N * 64); m.gg393 = b.take<float>((size_t)N * ldg);
+    m.bl1 = m.rgbv = m.blA = m.ghA = m.gpf = m.grgbv = m.gang = nullptr;
+  } else {
+    m.bl1 = b.take<float>((size_t)N * V * 32); m.rgbv = b.take<float>((size_t)N * V * 4); m.blA = b.take<float>((size_t)N * 32);
+    m.ghA = b.take<float>((size_t)N * 32); m.gpf = b.take<float>((size_t)N * V * 32); m.grgbv = b.take<float>((size_t)N * V * 4);
+    m.gang = b.take<float>((size_t)N * V * 4);
+    m.t64 = m.G = m.gA = m.gt64 = m.gg393 = nullptr;
+  }
+}
+
+// the recomputed forward both need: visibility / depth difference (exact fp32 decoders: the backward kernel differentiates those) and the
+// statistics rows (+ the blend's per-(sample, view) layer-1 part when bl1 != null)
+int mv_recompute(const Ctx& x32, const nl_frame* f, const NlViews& vw, const float* xyz, int64_t N, const MvBwdBufs& m) {
+  if (m.bl1) NL_TRY(ensure_pfeat(x32, f));
+  NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.vis, m.dd, x32.st));
+  return nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, ldg_of(f->C), nullptr, nullptr, m.valid_s, f->pfeat,
+                            x32.p<float>(x32.L.blw), m.bl1, m.rgbv, x32.st);
+}
+
+// g_G (N, W) -> g_xyz (N, 3): out_fc backwards (two transposed-weight products, ELU masks), the visibility-weighted statistics, the bilinear taps'
+// spatial derivative, the IBRNet projection; visibility / depth difference through the NeuRay decoders and the NeuRay projection.
+int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* xyz, int64_t N, const float* gG, float* g_xyz, const MvBwdBufs& m) {
+  const int W = x32.c->W, ldg = ldg_of(f->C);
+  const NlViews vw = with_query(f, nullptr);
+  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
+  SegSpec s0{m.g393, ldg, ldg, 0, 1}, s1{m.t64, 64, 64, 0, 1};
+  NL_TRY(run_gemm(x32, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
+  NL_TRY(run_gemm(x32, G_OUTFC2, &s1, 1, N, m.G, W, NL_ACT_ELU));
+  NL_CHECK_HIP(hipMemcpyAsync(m.gA, gG, sizeof(float) * (size_t)N * W, hipMemcpyDeviceToDevice, x32.st));
+  NL_TRY(nl_launch_elu_mask(m.gA, m.G, (size_t)N * W, x32.st));
+  SegSpec sa{m.gA, W, W, 0, 1}, st{m.gt64, 64, 64, 0, 1};
+  NL_TRY(run_gemm(xb, G_OUTFC2_T, &sa, 1, N, m.gt64, 64, NL_ACT_NONE));
+  NL_TRY(nl_launch_elu_mask(m.gt64, m.t64, (size_t)N * 64, x32.st));
+  NL_TRY(run_gemm(xb, G_OUTFC0_T, &st, 1, N, m.gg393, ldg, NL_ACT_NONE));
+  NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, nullptr, xyz, N, m.vis, m.dd, m.gg393, ldg, nullptr, nullptr, nullptr, g_xyz,
+                                    nullptr, m.gvis, m.gdd, x32.st));
+  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, g_xyz, x32.st);
+}
+
+// rgb_s = blend(feature_agg, per-view taps) forward (staged) and its input gradient
+int do_blend_forward(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, const float* FA, int64_t N, float* rgb_s, const MvBwdBufs& m) {
+  const int W = x.c->W;
+  const NlViews vw = with_query(f, qc);
+  nl_config c32 = *x.c; c32.precision = NL_PREC_F32;
+  Ctx x32 = x; x32.c = &c32;
+  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
+  SegSpec sa{FA, W, W, 0, 1};
+  NL_TRY(run_gemm(x32, G_BLENDA, &sa, 1, N, m.blA, 32, NL_ACT_NONE));
+  return nl_launch_blend(m.blA, m.bl1, m.rgbv, N, vw.V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w), x.p<float>(x.L.bl4_b), rgb_s, x.st);
+}
+
+int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* xyz, const float* FA, int64_t N, const float* g_rgb_s,
+                      float* g_xyz, float* g_FA, float* g_qc, const MvBwdBufs& m) {
+  const int W = x32.c->W;
+  const NlViews vw = with_query(f, qc);
+  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
+  SegSpec sa{FA, W, W, 0, 1}, sg{m.ghA, 32, 32, 0, 1};
+  NL_TRY(run_gemm(x32, G_BLENDA, &sa, 1, N, m.blA, 32, NL_ACT_NONE));
+  NL_TRY(nl_launch_blend_backward(m.blA, m.bl1, m.rgbv, N, vw.V, x32.p<float>(x32.L.bl2_w), x32.p<float>(x32.L.bl2_b), x32.p<float>(x32.L.bl4_w),
+                                  x32.p<float>(x32.L.bl4_b), x32.p<float>(x32.L.blw), g_rgb_s, m.ghA, m.gpf, m.grgbv, m.gang, x32.st));
+  if (g_FA) NL_TRY(run_gemm(xb, G_BLENDA_T, &sg, 1, N, g_FA, W, NL_ACT_NONE));
+  NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, f->pfeat, xyz, N, m.vis, m.dd, nullptr, ldg_of(f->C), m.gpf, m.grgbv, m.gang, g_xyz,
+                                    g_qc, m.gvis, m.gdd, x32.st));
+  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, g_xyz, x32.st);
 }
 
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and
@@ -953,6 +1040,19 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
                        (float*)((char*)packed + L.b32[G_BASE0_T]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_T]),
                        (unsigned short*)((char*)packed + L.blo[G_BASE0_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_T]), nl_tgemm_nrt(d.N), 0);
   }
+  P.block(G_OUTFC2_T, 0, t[T_OUT2W], 0, 1, 64, W);
+  {
+    const GemmDim& d = L.g[G_OUTFC0_T];   // out_fc.0.weight (64, 2F + 3): element [k = o][n = i]; no streaming layout (N > 256)
+    hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(64 * (2 * F + 3), 256)), dim3(256), 0, st, t[T_OUT0W], 0, 1, 2 * F + 3, 64, 2 * F + 3, 0,
+                       (float*)((char*)packed + L.b32[G_OUTFC0_T]), (unsigned short*)((char*)packed + L.bhi[G_OUTFC0_T]),
+                       (unsigned short*)((char*)packed + L.blo[G_OUTFC0_T]), d.Kpad, d.Npad, (unsigned short*)nullptr, 8, 0);
+  }
+  {
+    const GemmDim& d = L.g[G_BLENDA_T];   // the feature_agg columns of rgb_blending_mlp.0.weight (32, W + F + 5)
+    hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(32 * W, 256)), dim3(256), 0, st, t[T_BL0W], 0, 1, W + F + 5, 32, W, 0,
+                       (float*)((char*)packed + L.b32[G_BLENDA_T]), (unsigned short*)((char*)packed + L.bhi[G_BLENDA_T]),
+                       (unsigned short*)((char*)packed + L.blo[G_BLENDA_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BLENDA_T]), nl_tgemm_nrt(d.N), 0);
+  }
   const float* const* un = t + T_UNET;
   { const int w1[1] = {W}, w2[1] = {64}, w3[1] = {128};
     P.conv3(G_CONV1, un[0], un[1], W, w1, 1);
@@ -1148,24 +1248,97 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
   if (ws_bytes < point_bwd_bytes(cfg, 1)) return NL_ERR_WORKSPACE;
-  // The backward pass always multiplies in exact fp32 (v_mfma_f32_32x32x2_f32), whatever the forward's mode: the gradient w.r.t. the sample
-  // positions sums positional-encoding terms of alternating sign scaled by up to 2^9 — a conditioning of ~1e3 that turns split-bf16's 1e-5
-  // into 2e-2 (measured) and plain fp32 autograd's 1e-6 into 4e-3; batches that are differentiated are small (PoseOptimizer: 512 rays).
-  nl_config c32 = *cfg;
+  // Precision of the two halves (measured, tools/r3 experiment in DESIGN.md §5.12):
+  //  * the RECOMPUTED FORWARD multiplies in exact fp32 (v_mfma_f32_32x32x2_f32) whatever the render mode: the derivative of a LeakyReLU
+  //    network is piecewise constant, and a forward that is 1e-5 off (split-bf16) flips the sign of a few pre-activations near zero — every
+  //    flip changes that neighbour row's gradient by a few percent (2e-2 in the max-norm of g_xyz, against 4e-6 with the fp32 forward; plain
+  //    fp32 autograd is 4e-3 from the fp64 gradient for the same reason);
+  //  * the transposed-weight products of the way back are linear in the incoming gradient and run in split-bf16 (1e-5, no discontinuity).
+  nl_config c32 = *cfg, cbw = *cfg;
   c32.precision = NL_PREC_F32;
+  if (cbw.precision == NL_PREC_BF16) cbw.precision = NL_PREC_BF16X3;
   int64_t lo = 1, hi = N;
   while (lo < hi) {   // largest sample chunk whose buffers fit the workspace
     const int64_t mid = (lo + hi + 1) / 2;
     if (point_bwd_bytes(cfg, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
   }
   const int64_t NC = lo < (1 << 17) ? lo : (1 << 17);
-  Ctx x = make_ctx(&c32, packed, stream);
+  const Ctx xf = make_ctx(&c32, packed, stream), xb = make_ctx(&cbw, packed, stream);   // recomputed forward / way back
   const int W = cfg->W;
   for (int64_t n0 = 0; n0 < N; n0 += NC) {
     const int64_t nc = N - n0 < NC ? N - n0 : NC;
     Bump b{(char*)ws, 0}; PtBwdBufs p; carve_ptb(b, cfg, nc, 8, p);
-    NL_TRY(do_point_backward(x, f, xyz + 3 * n0, dir ? dir + dir_stride * n0 : nullptr, (int)dir_stride, mv_feat + n0 * W, nc, K, g_feature_agg + n0 * W,
+    NL_TRY(do_point_backward(xb, xf, f, xyz + 3 * n0, dir ? dir + dir_stride * n0 : nullptr, (int)dir_stride, mv_feat + n0 * W, nc, K, g_feature_agg + n0 * W,
                              g_xyz + 3 * n0, g_dir ? g_dir + 3 * n0 : nullptr, g_mv_feat ? g_mv_feat + n0 * W : nullptr, p));
+  }
+  return NL_OK;
+}
+
+static size_t mv_bwd_bytes(const nl_config* cfg, int V, int64_t n, bool blend) { Bump b{nullptr, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, n, blend, m); return b.off; }
+static int64_t mv_bwd_chunk(const nl_config* cfg, int V, int64_t N, bool blend, size_t ws_bytes) {
+  if (ws_bytes < mv_bwd_bytes(cfg, V, 1, blend)) return 0;
+  int64_t lo = 1, hi = N;
+  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (mv_bwd_bytes(cfg, V, mid, blend) <= ws_bytes) lo = mid; else hi = mid - 1; }
+  return lo < (1 << 18) ? lo : (1 << 18);
+}
+struct BwdCtx { nl_config c32, cbw; Ctx x32, xb; };
+static void make_bwd_ctx(BwdCtx& B, const nl_config* cfg, const void* packed, void* stream) {
+  B.c32 = *cfg; B.cbw = *cfg;
+  B.c32.precision = NL_PREC_F32;
+  if (B.cbw.precision == NL_PREC_BF16) B.cbw.precision = NL_PREC_BF16X3;
+  B.x32 = make_ctx(&B.c32, packed, stream); B.xb = make_ctx(&B.cbw, packed, stream);
+}
+
+size_t nl_mv_aggregate_backward_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 16) ? (1 << 16) : N), false) : 0;
+}
+int nl_mv_aggregate_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, int64_t N, const float* g_mv_feat, float* g_xyz,
+                             void* ws, size_t ws_bytes, void* stream) {
+  if (N == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !xyz || !g_mv_feat || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
+  const int V = f->views.V, W = cfg->W;
+  const int64_t NC = mv_bwd_chunk(cfg, V, N, false, ws_bytes);
+  if (NC == 0) return NL_ERR_WORKSPACE;
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  for (int64_t n0 = 0; n0 < N; n0 += NC) {
+    const int64_t nc = N - n0 < NC ? N - n0 : NC;
+    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, false, m);
+    NL_TRY(do_mv_backward(B.xb, B.x32, f, xyz + 3 * n0, nc, g_mv_feat + n0 * W, g_xyz + 3 * n0, m));
+  }
+  return NL_OK;
+}
+
+size_t nl_blend_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 16) ? (1 << 16) : N), true) : 0;
+}
+int nl_blend(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N, float* rgb_s,
+             void* ws, size_t ws_bytes, void* stream) {
+  if (N == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !qc || !xyz || !feature_agg || !rgb_s || !ws || N < 0) return NL_ERR_BAD_ARG;
+  const int V = f->views.V, W = cfg->W;
+  const int64_t NC = mv_bwd_chunk(cfg, V, N, true, ws_bytes);
+  if (NC == 0) return NL_ERR_WORKSPACE;
+  Ctx x = make_ctx(cfg, packed, stream);
+  for (int64_t n0 = 0; n0 < N; n0 += NC) {
+    const int64_t nc = N - n0 < NC ? N - n0 : NC;
+    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, true, m);
+    NL_TRY(do_blend_forward(x, f, qc, xyz + 3 * n0, feature_agg + n0 * W, nc, rgb_s + 3 * n0, m));
+  }
+  return NL_OK;
+}
+int nl_blend_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N,
+                      const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center, void* ws, size_t ws_bytes, void* stream) {
+  if (N == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !qc || !xyz || !feature_agg || !g_rgb_s || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
+  const int V = f->views.V, W = cfg->W;
+  const int64_t NC = mv_bwd_chunk(cfg, V, N, true, ws_bytes);
+  if (NC == 0) return NL_ERR_WORKSPACE;
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  for (int64_t n0 = 0; n0 < N; n0 += NC) {
+    const int64_t nc = N - n0 < NC ? N - n0 : NC;
+    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, true, m);
+    NL_TRY(do_blend_backward(B.xb, B.x32, f, qc, xyz + 3 * n0, feature_agg + n0 * W, nc, g_rgb_s + 3 * n0, g_xyz + 3 * n0,
+                             g_feature_agg ? g_feature_agg + n0 * W : nullptr, g_query_center ? g_query_center + 3 * n0 : nullptr, m));
   }
   return NL_OK;
 }

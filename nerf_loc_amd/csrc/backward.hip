@@ -407,3 +407,511 @@ int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
+
+// =====================================================================================================================
+// Multi-view aggregation (rows a4-a7) and colour blend (a15): gradient w.r.t. the sample positions (and, for the blend, feature_agg and
+// the query camera centre) with frozen weights / frozen support maps.  Three kernels share the work:
+//   blend_backward_kernel    (lane = sample)  d rgb_s -> gradient of the per-(sample, view) inputs of rgb_blending_mlp: the 32 blend-projected
+//                            feature taps, the tapped colour, the visibility, the 4 view-angle features; and of the per-sample projection
+//   mv_geom_backward_kernel  (wave = sample)  gradients w.r.t. tapped values (from the statistics and / or from the blend) -> re-gathers the
+//                            bilinear taps, contracts with their spatial derivative -> pixel -> camera -> world; view angles; the visibility
+//                            weights' normalisation; emits d/d visibility and d/d depth-difference per (view, sample)
+//   dec_backward_kernel      (lane = (view, sample))  the NeuRay decoders + visibility formula (visibility_decoder.py:64-148) backwards, through the
+//                            border-mode tap of the visibility map and the NeuRay projection
+#include "mvdec.h"
+
+namespace {
+using namespace nlmv;
+
+__device__ __forceinline__ float bk_rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int bk_rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+struct TapD { int o[4]; float m[4]; float e, w, s, n; };   // clamped texel offsets, validity (0/1), fractional weights: value = s e t0 + s w t1 + n e t2 + n w t3
+__device__ __forceinline__ TapD make_tapd(const Taps& t, int Wm, int Hm) {
+  TapD d;
+  const int x0 = min(max(t.x0, 0), Wm - 1), x1 = min(max(t.x0 + 1, 0), Wm - 1), y0 = min(max(t.y0, 0), Hm - 1), y1 = min(max(t.y0 + 1, 0), Hm - 1);
+  d.o[0] = y0 * Wm + x0; d.o[1] = y0 * Wm + x1; d.o[2] = y1 * Wm + x0; d.o[3] = y1 * Wm + x1;
+  d.m[0] = (t.mn && t.mw) ? 1.f : 0.f; d.m[1] = (t.mn && t.me) ? 1.f : 0.f; d.m[2] = (t.ms && t.mw) ? 1.f : 0.f; d.m[3] = (t.ms && t.me) ? 1.f : 0.f;
+  // make_taps: nw = s e, ne = s w, sw = n e, se = n w with w = frac(ix), e = 1 - w, n = frac(iy), s = 1 - n
+  d.s = t.nw + t.ne; d.n = t.sw + t.se; d.e = t.nw + t.sw; d.w = t.ne + t.se;
+  return d;
+}
+
+// One wave per sample.  Inputs (each may be null = zero): g393 (N, ldg) gradient of the statistics row [mean F | var F | mean_dd, var_dd, mean_w];
+// g_pf (N*V, 32) gradient of the blend-projected feature taps; g_rgbv (N*V, 4) gradient of [tapped r, g, b | visibility]; g_ang (N*V, 4).
+// Outputs: g_xyz (N,3) (written), g_qc (N,3) or null, g_vis / g_dd (V,N) (written).
+template <int VT>
+__global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
+                                                               const float* __restrict__ feat, int C, const float* __restrict__ pfeat,
+                                                               const float* __restrict__ xyz, int N, const float* __restrict__ vis_in,
+                                                               const float* __restrict__ dd_in, const float* __restrict__ g393, int ldg,
+                                                               const float* __restrict__ g_pf, const float* __restrict__ g_rgbv,
+                                                               const float* __restrict__ g_ang, float* __restrict__ g_xyz, float* __restrict__ g_qc,
+                                                               float* __restrict__ g_vis, float* __restrict__ g_dd) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int V = vw.V, F = C + 3;
+  const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
+  // ---------------------------------------------------------------- per-view scalars (lane = view)
+  const int vl = lane < V ? lane : 0;
+  const bool vact = lane < V;
+  const float4 p0 = *(const float4*)(viewsdev + 12 * vl), p1 = *(const float4*)(viewsdev + 12 * vl + 4), p2 = *(const float4*)(viewsdev + 12 * vl + 8);
+  const float cx = fmaf(p0.z, Z, fmaf(p0.y, Y, p0.x * X)) + p0.w, cy = fmaf(p1.z, Z, fmaf(p1.y, Y, p1.x * X)) + p1.w;
+  const float cz = fmaf(p2.z, Z, fmaf(p2.y, Y, p2.x * X)) + p2.w;
+  const float zc = fmaxf(cz, 1e-8f);
+  const float pxr = cx / zc, pyr = cy / zc;
+  const float px = fminf(fmaxf(pxr, -1e6f), 1e6f), py = fminf(fmaxf(pyr, -1e6f), 1e6f);
+  const bool clx = !(pxr > -1e6f && pxr < 1e6f), cly = !(pyr > -1e6f && pyr < 1e6f);
+  const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f, yn = 2.f * py / (float)(vw.H - 1) - 1.f;
+  const TapD tf = make_tapd(make_taps<true, false>(xn, yn, vw.w, vw.h), vw.w, vw.h);
+  const TapD ti = make_tapd(make_taps<true, false>(xn, yn, vw.Wimg, vw.H), vw.Wimg, vw.H);
+  const float a_vis = vact ? vis_in[(size_t)vl * N + n] : 0.f, a_dd = vact ? dd_in[(size_t)vl * N + n] : 0.f;
+  float vsum = 0.f;
+#pragma unroll
+  for (int v = 0; v < VT; ++v) vsum += v < V ? bk_rl(a_vis, v) : 0.f;
+  const float a_wgt = a_vis / (vsum + 1e-8f);
+  float Wt = 0.f;   // sum of the weights (< 1 by the 1e-8)
+#pragma unroll
+  for (int v = 0; v < VT; ++v) Wt += v < V ? bk_rl(a_wgt, v) : 0.f;
+  const float omW = 1.f - Wt;
+
+  // ---------------------------------------------------------------- statistics part: pass 1 = weighted means, pass 2 = gradients
+  // channel slots of this lane: feature channels lane, lane + 64, lane + 128 (slots 0..2) and colour plane `lane` (slot 3, lanes 0..2)
+  auto tapval = [&](const float* base, size_t stride, const int (&o)[4], const float (&m)[4], float (&t)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = base[(size_t)o[k] * stride] * m[k];
+  };
+  float gix = 0.f, giy = 0.f, gixI = 0.f, giyI = 0.f, gw = 0.f;   // lane v accumulates view v's totals at the end (wave-reduced per view below)
+  float acc_ix[VT], acc_iy[VT], acc_ixI[VT], acc_iyI[VT], acc_w[VT];
+#pragma unroll
+  for (int v = 0; v < VT; ++v) acc_ix[v] = acc_iy[v] = acc_ixI[v] = acc_iyI[v] = acc_w[v] = 0.f;
+  const size_t fmap = (size_t)vw.h * vw.w, imap = (size_t)vw.H * vw.Wimg;
+  if (g393) {
+    const float* g = g393 + (size_t)n * ldg;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        int o[4]; float m[4]; float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = bk_rli(tf.o[k], v); m[k] = bk_rl(tf.m[k], v); }
+        const float e = bk_rl(tf.e, v), w = bk_rl(tf.w, v), s = bk_rl(tf.s, v), nn = bk_rl(tf.n, v), wg = bk_rl(a_wgt, v);
+        const float* fb = feat + (size_t)v * fmap * C;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int ch = lane + 64 * j;
+          if (ch < C) { tapval(fb + ch, (size_t)C, o, m, t); mean[j] = fmaf((s * e * t[0] + s * w * t[1]) + (nn * e * t[2] + nn * w * t[3]), wg, mean[j]); }
+        }
+        if (lane < 3) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o[k] = bk_rli(ti.o[k], v); m[k] = bk_rl(ti.m[k], v); }
+          const float ei = bk_rl(ti.e, v), wi = bk_rl(ti.w, v), si = bk_rl(ti.s, v), ni = bk_rl(ti.n, v);
+          tapval(images + (size_t)v * 3 * imap + (size_t)lane * imap, 1, o, m, t);
+          mean[3] = fmaf((si * ei * t[0] + si * wi * t[1]) + (ni * ei * t[2] + ni * wi * t[3]), wg, mean[3]);
+        }
+      }
+    }
+    float gm[4], gv[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const int ch = lane + 64 * j; gm[j] = ch < C ? g[3 + ch] : 0.f; gv[j] = ch < C ? g[F + 3 + ch] : 0.f; }
+    gm[3] = lane < 3 ? g[lane] : 0.f; gv[3] = lane < 3 ? g[F + lane] : 0.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        int o[4]; float m[4]; float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = bk_rli(tf.o[k], v); m[k] = bk_rl(tf.m[k], v); }
+        const float e = bk_rl(tf.e, v), w = bk_rl(tf.w, v), s = bk_rl(tf.s, v), nn = bk_rl(tf.n, v), wg = bk_rl(a_wgt, v);
+        const float* fb = feat + (size_t)v * fmap * C;
+        float six = 0.f, siy = 0.f, sw = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int ch = lane + 64 * j;
+          if (ch < C) {
+            tapval(fb + ch, (size_t)C, o, m, t);
+            const float x = (s * e * t[0] + s * w * t[1]) + (nn * e * t[2] + nn * w * t[3]);
+            const float d = x - mean[j];
+            const float gx = wg * (gm[j] + 2.f * gv[j] * (d - mean[j] * omW));
+            six = fmaf(gx, s * (t[1] - t[0]) + nn * (t[3] - t[2]), six);
+            siy = fmaf(gx, e * (t[2] - t[0]) + w * (t[3] - t[1]), siy);
+            sw += gm[j] * x + gv[j] * (d * d - 2.f * x * mean[j] * omW);
+          }
+        }
+        float sixI = 0.f, siyI = 0.f;
+        if (lane < 3) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o[k] = bk_rli(ti.o[k], v); m[k] = bk_rl(ti.m[k], v); }
+          const float ei = bk_rl(ti.e, v), wi = bk_rl(ti.w, v), si = bk_rl(ti.s, v), ni = bk_rl(ti.n, v);
+          tapval(images + (size_t)v * 3 * imap + (size_t)lane * imap, 1, o, m, t);
+          const float x = (si * ei * t[0] + si * wi * t[1]) + (ni * ei * t[2] + ni * wi * t[3]);
+          const float d = x - mean[3];
+          const float gx = wg * (gm[3] + 2.f * gv[3] * (d - mean[3] * omW));
+          sixI = gx * (si * (t[1] - t[0]) + ni * (t[3] - t[2]));
+          siyI = gx * (ei * (t[2] - t[0]) + wi * (t[3] - t[1]));
+          sw += gm[3] * x + gv[3] * (d * d - 2.f * x * mean[3] * omW);
+        }
+        acc_ix[v] = wave_sum(six); acc_iy[v] = wave_sum(siy); acc_ixI[v] = wave_sum(sixI); acc_iyI[v] = wave_sum(siyI); acc_w[v] = wave_sum(sw);
+      }
+    }
+  }
+  // ---------------------------------------------------------------- blend part: blend-projected feature taps (32 channels) and tapped colours
+  if (g_pf) {
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        int o[4]; float m[4]; float t[4];
+        float six = 0.f, siy = 0.f, sixI = 0.f, siyI = 0.f;
+        if (lane < 32) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o[k] = bk_rli(tf.o[k], v); m[k] = bk_rl(tf.m[k], v); }
+          const float e = bk_rl(tf.e, v), w = bk_rl(tf.w, v), s = bk_rl(tf.s, v), nn = bk_rl(tf.n, v);
+          tapval(pfeat + (size_t)v * fmap * 32 + lane, 32, o, m, t);
+          const float gx = g_pf[((size_t)n * V + v) * 32 + lane];
+          six = gx * (s * (t[1] - t[0]) + nn * (t[3] - t[2]));
+          siy = gx * (e * (t[2] - t[0]) + w * (t[3] - t[1]));
+        }
+        if (lane < 3 && g_rgbv) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o[k] = bk_rli(ti.o[k], v); m[k] = bk_rl(ti.m[k], v); }
+          const float ei = bk_rl(ti.e, v), wi = bk_rl(ti.w, v), si = bk_rl(ti.s, v), ni = bk_rl(ti.n, v);
+          tapval(images + (size_t)v * 3 * imap + (size_t)lane * imap, 1, o, m, t);
+          const float gx = g_rgbv[((size_t)n * V + v) * 4 + lane];
+          sixI = gx * (si * (t[1] - t[0]) + ni * (t[3] - t[2]));
+          siyI = gx * (ei * (t[2] - t[0]) + wi * (t[3] - t[1]));
+        }
+        acc_ix[v] += wave_sum(six); acc_iy[v] += wave_sum(siy); acc_ixI[v] += wave_sum(sixI); acc_iyI[v] += wave_sum(siyI);
+      }
+    }
+  }
+  // hand view v's totals to lane v
+#pragma unroll
+  for (int v = 0; v < VT; ++v)
+    if (lane == v) { gix = acc_ix[v]; giy = acc_iy[v]; gixI = acc_ixI[v]; giyI = acc_iyI[v]; gw = acc_w[v]; }
+
+  float mdd = 0.f;   // weighted mean of the depth differences (all lanes: cross-lane reads stay outside divergent code)
+#pragma unroll
+  for (int v = 0; v < VT; ++v) mdd += v < V ? bk_rl(a_dd, v) * bk_rl(a_wgt, v) : 0.f;
+  // ---------------------------------------------------------------- per-view scalar backward (lane = view)
+  float gX = 0.f, gY = 0.f, gZ = 0.f, gq0 = 0.f, gq1 = 0.f, gq2 = 0.f, gvis_out = 0.f, gdd_out = 0.f;
+  if (vact) {
+    // pixel -> camera -> world (ibrnet.py:183-188).  ix = px (w - 1) / (Wimg - 1) for the feature map, = px for the image.
+    float gpx = gix * ((float)(vw.w - 1) / (float)(vw.Wimg - 1)) + gixI, gpy = giy * ((float)(vw.h - 1) / (float)(vw.H - 1)) + giyI;
+    if (clx) gpx = 0.f;
+    if (cly) gpy = 0.f;
+    const float gcx = gpx / zc, gcy = gpy / zc, gcz = cz > 1e-8f ? -(gpx * pxr + gpy * pyr) / zc : 0.f;
+    gX = p0.x * gcx + p1.x * gcy + p2.x * gcz; gY = p0.y * gcx + p1.y * gcy + p2.y * gcz; gZ = p0.z * gcx + p1.z * gcy + p2.z * gcz;
+    // view angles (ibrnet.py:144-167)
+    if (g_ang) {
+      const float4 ga = *(const float4*)(g_ang + ((size_t)n * V + vl) * 4);
+      float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+      if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(n / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+      const float rq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
+      const float nq = sqrtf(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2]), dq = nq + 1e-6f;
+      const float tq[3] = {rq[0] / dq, rq[1] / dq, rq[2] / dq};
+      const float rt[3] = {viewsdev[192 + 3 * vl] - X, viewsdev[192 + 3 * vl + 1] - Y, viewsdev[192 + 3 * vl + 2] - Z};
+      const float nt = sqrtf(rt[0] * rt[0] + rt[1] * rt[1] + rt[2] * rt[2]), dt = nt + 1e-6f;
+      const float tt[3] = {rt[0] / dt, rt[1] / dt, rt[2] / dt};
+      const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+      const float ndf = sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), nd = fmaxf(ndf, 1e-6f);
+      float gdf[3] = {ga.x / nd, ga.y / nd, ga.z / nd};
+      if (ndf > 1e-6f) {   // u = df / |df|
+        const float dotg = (ga.x * df[0] + ga.y * df[1] + ga.z * df[2]) / (nd * nd * nd);
+        gdf[0] -= df[0] * dotg; gdf[1] -= df[1] * dotg; gdf[2] -= df[2] * dotg;
+      }
+      const float gtq[3] = {gdf[0] + ga.w * tt[0], gdf[1] + ga.w * tt[1], gdf[2] + ga.w * tt[2]};
+      const float gtt[3] = {-gdf[0] + ga.w * tq[0], -gdf[1] + ga.w * tq[1], -gdf[2] + ga.w * tq[2]};
+      // t = r / (|r| + 1e-6): dt_i/dr_j = delta_ij / d - r_i r_j / (|r| d^2)
+      const float cq = nq > 0.f ? (gtq[0] * rq[0] + gtq[1] * rq[1] + gtq[2] * rq[2]) / (nq * dq * dq) : 0.f;
+      const float grq[3] = {gtq[0] / dq - rq[0] * cq, gtq[1] / dq - rq[1] * cq, gtq[2] / dq - rq[2] * cq};
+      const float ct = nt > 0.f ? (gtt[0] * rt[0] + gtt[1] * rt[1] + gtt[2] * rt[2]) / (nt * dt * dt) : 0.f;
+      const float grt[3] = {gtt[0] / dt - rt[0] * ct, gtt[1] / dt - rt[1] * ct, gtt[2] / dt - rt[2] * ct};
+      gX -= grq[0] + grt[0]; gY -= grq[1] + grt[1]; gZ -= grq[2] + grt[2];
+      gq0 = grq[0]; gq1 = grq[1]; gq2 = grq[2];
+    }
+    // depth-difference statistics + mean weight (multiview_aggregator.py:202-216) -> d/d weight, d/d depth difference
+    if (g393) {
+      const float* g = g393 + (size_t)n * ldg;
+      const float gmd = g[2 * F], gvd = g[2 * F + 1], gmw = g[2 * F + 2];
+      const float d = a_dd - mdd;
+      gw += gmd * a_dd + gvd * (d * d - 2.f * a_dd * mdd * omW) + gmw / (float)V;
+      gdd_out = a_wgt * (gmd + 2.f * gvd * (d - mdd * omW));
+    }
+  }
+  // weights = vis / (sum vis + 1e-8): d/d vis_v = gw_v / (S + eps) - sum_u gw_u vis_u / (S + eps)^2
+  const float den = vsum + 1e-8f;
+  const float cross = wave_sum(vact ? gw * a_vis : 0.f) / (den * den);
+  if (vact) {
+    gvis_out = gw / den - cross;
+    if (g_rgbv) gvis_out += g_rgbv[((size_t)n * V + vl) * 4 + 3];
+    g_vis[(size_t)vl * N + n] = gvis_out;
+    g_dd[(size_t)vl * N + n] = gdd_out;
+  }
+  gX = wave_sum(vact ? gX : 0.f); gY = wave_sum(vact ? gY : 0.f); gZ = wave_sum(vact ? gZ : 0.f);
+  if (g_qc) { gq0 = wave_sum(vact ? gq0 : 0.f); gq1 = wave_sum(vact ? gq1 : 0.f); gq2 = wave_sum(vact ? gq2 : 0.f); }
+  if (lane == 0) {
+    g_xyz[3 * (size_t)n] = gX; g_xyz[3 * (size_t)n + 1] = gY; g_xyz[3 * (size_t)n + 2] = gZ;
+    if (g_qc) { g_qc[3 * (size_t)n] = gq0; g_qc[3 * (size_t)n + 1] = gq1; g_qc[3 * (size_t)n + 2] = gq2; }
+  }
+}
+
+}  // namespace
+
+namespace {
+using namespace nlmv;
+
+// backward of one 32-32-32-{1,2} decoder (visibility_decoder.py:64-97; ELU between the layers): recomputes the hidden layers, adds W0^T g_h1 to gx
+__device__ __forceinline__ void decoder_backward(const float* __restrict__ w, const float (&x)[32], float go0, float go1, float (&gx)[32]) {
+  float h1[32], h2[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float a = w[1024 + j];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a = fmaf(w[j * 32 + i], x[i], a);
+    h1[j] = nl_elu(a);
+  }
+  const float* w2 = w + 1024 + 32;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float a = w2[1024 + j];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a = fmaf(w2[j * 32 + i], h1[i], a);
+    h2[j] = nl_elu(a);
+  }
+  const float* w4 = w2 + 1024 + 32;
+  float g1[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) g1[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    // d ELU(a)/da = a > 0 ? 1 : exp(a) = ELU(a) + 1
+    const float gh2 = (go0 * w4[j] + go1 * w4[32 + j]) * (h2[j] > 0.f ? 1.f : h2[j] + 1.f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g1[i] = fmaf(w2[j * 32 + i], gh2, g1[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float gh1 = g1[j] * (h1[j] > 0.f ? 1.f : h1[j] + 1.f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gx[i] = fmaf(w[j * 32 + i], gh1, gx[i]);
+  }
+}
+
+// One lane per (view, sample): backward of mv_vis_kernel (mvagg.hip).  g_xyz is accumulated with atomics (V lanes per sample).
+__global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, const float* __restrict__ visf, const float* __restrict__ dw,
+                                                           const float* __restrict__ xyz, int N, const float* __restrict__ g_vis,
+                                                           const float* __restrict__ g_dd, float* __restrict__ g_xyz) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (n >= N) return;
+  const float gv = g_vis[(size_t)v * N + n], gd = g_dd[(size_t)v * N + n];
+  if (gv == 0.f && gd == 0.f) return;
+  const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
+  const float* P = vw.P2[v];
+  const float cx = fmaf(P[2], Z, fmaf(P[1], Y, P[0] * X)) + P[3], cy = fmaf(P[6], Z, fmaf(P[5], Y, P[4] * X)) + P[7];
+  float depth = fmaf(P[10], Z, fmaf(P[9], Y, P[8] * X)) + P[11];
+  const bool bad = fabsf(depth) < 1e-4f;
+  if (bad) depth = 1e-3f;
+  const float px = cx / depth, py = cy / depth;
+  const bool outside = (px < -0.5f) | (px >= (float)vw.Wimg - 0.5f) | (py < -0.5f) | (py >= (float)vw.H - 0.5f);
+  const bool valid = !bad && !outside;
+  // visibility-map tap (border, align_corners = False) and its spatial derivative
+  float x[32], dxv[32], dyv[32];
+  const float xn = px / (float)(vw.Wimg - 1) * 2.f - 1.f, yn = py / (float)(vw.H - 1) * 2.f - 1.f;
+  const float ixr = (xn + 1.f) * ((float)vw.vw / 2.f) - 0.5f, iyr = (yn + 1.f) * ((float)vw.vh / 2.f) - 0.5f;
+  const bool cxl = !(ixr > 0.f && ixr < (float)(vw.vw - 1)), cyl = !(iyr > 0.f && iyr < (float)(vw.vh - 1));   // clamped by the border mode: no gradient
+  {
+    const Taps t = make_taps<false, true>(xn, yn, vw.vw, vw.vh);
+    const TapD d = make_tapd(t, vw.vw, vw.vh);
+    const float* base = visf + (size_t)v * vw.vh * vw.vw * 32;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const float t0 = base[(size_t)d.o[0] * 32 + c] * d.m[0], t1 = base[(size_t)d.o[1] * 32 + c] * d.m[1];
+      const float t2 = base[(size_t)d.o[2] * 32 + c] * d.m[2], t3 = base[(size_t)d.o[3] * 32 + c] * d.m[3];
+      x[c] = valid ? (d.s * d.e * t0 + d.s * d.w * t1) + (d.n * d.e * t2 + d.n * d.w * t3) : 0.f;
+      dxv[c] = d.s * (t1 - t0) + d.n * (t3 - t2);
+      dyv[c] = d.e * (t2 - t0) + d.w * (t3 - t1);
+    }
+  }
+  float m0, m1, v0, v1, aw, vs;
+  float o[4][2];
+  { float dummy; decoder(dw + 0 * DEC_STRIDE, x, o[0][0], o[0][1]); decoder(dw + 1 * DEC_STRIDE, x, o[1][0], o[1][1]);
+    decoder(dw + 2 * DEC_STRIDE, x, o[2][0], dummy); decoder(dw + 3 * DEC_STRIDE, x, o[3][0], dummy); o[2][1] = o[3][1] = 0.f; }
+  m0 = nl_softplus(o[0][0]); m1 = nl_softplus(o[0][1]); v0 = nl_softplus(o[1][0]) + 0.05f; v1 = nl_softplus(o[1][1]) + 0.05f;
+  aw = nl_sigmoid(o[2][0]); vs = nl_sigmoid(o[3][0]);
+  const float ni = -1.f / vw.near_, fi = -1.f / vw.far_, span = vw.far_ - vw.near_;
+  const float tref = m0 * (fi - ni) + ni;
+  const float refd_raw = -1.f / tref;
+  const float refd = fminf(fmaxf(refd_raw, vw.near_), vw.far_);
+  const float dn = (-1.f / fmaxf(depth, 1e-5f) - ni) / (fi - ni);
+  const float u0 = (dn - m0) * v0, u1 = (dn - m1) * v1;
+  const float th0 = tanhf(u0), th1 = tanhf(u1);
+  const float c0 = (0.5f + 0.5f * th0) * vs, c1 = (0.5f + 0.5f * th1) * vs;
+  // ---- backward of vis = valid * ((1 - c0) aw + (1 - c1) (1 - aw)) and dd = |depth - refd| / span
+  const float gvv = valid ? gv : 0.f;
+  const float gc0 = -gvv * aw, gc1 = -gvv * (1.f - aw);
+  float g_aw = gvv * (c1 - c0);
+  float g_vs = gc0 * (0.5f + 0.5f * th0) + gc1 * (0.5f + 0.5f * th1);
+  const float gu0 = gc0 * vs * 0.5f * (1.f - th0 * th0), gu1 = gc1 * vs * 0.5f * (1.f - th1 * th1);
+  float g_dn = gu0 * v0 + gu1 * v1;
+  float g_m0 = -gu0 * v0, g_m1 = -gu1 * v1, g_v0 = gu0 * (dn - m0), g_v1 = gu1 * (dn - m1);
+  const float sgn = depth > refd ? 1.f : (depth < refd ? -1.f : 0.f);
+  float g_depth = gd * sgn / span;
+  if (refd_raw > vw.near_ && refd_raw < vw.far_) g_m0 += (-gd * sgn / span) * ((fi - ni) / (tref * tref));   // d(-1/t)/dm0 = (fi - ni) / t^2
+  if (depth > 1e-5f) g_depth += g_dn / (depth * depth * (fi - ni));
+  // activations: softplus' = sigmoid, sigmoid' = y (1 - y)
+  const float go00 = g_m0 * nl_sigmoid(o[0][0]), go01 = g_m1 * nl_sigmoid(o[0][1]);
+  const float go10 = g_v0 * nl_sigmoid(o[1][0]), go11 = g_v1 * nl_sigmoid(o[1][1]);
+  const float go2 = g_aw * aw * (1.f - aw), go3 = g_vs * vs * (1.f - vs);
+  float gx[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) gx[c] = 0.f;
+  decoder_backward(dw + 0 * DEC_STRIDE, x, go00, go01, gx);
+  decoder_backward(dw + 1 * DEC_STRIDE, x, go10, go11, gx);
+  decoder_backward(dw + 2 * DEC_STRIDE, x, go2, 0.f, gx);
+  decoder_backward(dw + 3 * DEC_STRIDE, x, go3, 0.f, gx);
+  float gix = 0.f, giy = 0.f;
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { gix = fmaf(gx[c], dxv[c], gix); giy = fmaf(gx[c], dyv[c], giy); }
+  }
+  // ix = (2 px / (Wimg - 1)) vw / 2 - 0.5
+  const float gpx = cxl ? 0.f : gix * (float)vw.vw / (float)(vw.Wimg - 1), gpy = cyl ? 0.f : giy * (float)vw.vh / (float)(vw.H - 1);
+  float gcx = gpx / depth, gcy = gpy / depth;
+  float gde = g_depth - (gpx * px + gpy * py) / depth;
+  if (bad) { gde = 0.f; }   // the depth was replaced by a constant
+  const float gX = P[0] * gcx + P[4] * gcy + P[8] * gde, gY = P[1] * gcx + P[5] * gcy + P[9] * gde, gZ = P[2] * gcx + P[6] * gcy + P[10] * gde;
+  atomicAdd(g_xyz + 3 * (size_t)n, gX); atomicAdd(g_xyz + 3 * (size_t)n + 1, gY); atomicAdd(g_xyz + 3 * (size_t)n + 2, gZ);
+}
+
+// One lane per sample: backward of blend_kernel (heads.hip; model.py:532-538).  hA (N,32) per-sample part of layer 1, h1 (N*V,32) per-(sample, view)
+// part, rgbv (N*V,4) = [r,g,b,vis]; blw [32][8] = layer-1 columns of [rgb 3 | vis 1 | angle 4].
+// -> g_hA (N,32), g_pf (N*V,32) [= d/d(layer-1 pre-activation) = d/d(blend-projected feature tap)], g_rgbv (N*V,4), g_ang (N*V,4)
+__global__ __launch_bounds__(256) void blend_backward_kernel(const float* __restrict__ hA, const float* __restrict__ h1, const float* __restrict__ rgbv, int N, int V,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w4,
+                                                             const float* __restrict__ b4, const float* __restrict__ blw, const float* __restrict__ g_rgb_s,
+                                                             float* __restrict__ g_hA, float* __restrict__ g_pf, float* __restrict__ g_rgbv,
+                                                             float* __restrict__ g_ang) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float xa[32];
+#pragma unroll
+  for (int i4 = 0; i4 < 8; ++i4) { const float4 t = *(const float4*)(hA + (size_t)n * 32 + 4 * i4); xa[4 * i4] = t.x; xa[4 * i4 + 1] = t.y; xa[4 * i4 + 2] = t.z; xa[4 * i4 + 3] = t.w; }
+  auto logit = [&](int v, float (&pre1)[32], float (&a2)[16]) __attribute__((always_inline)) {
+    const float* h = h1 + ((size_t)n * V + v) * 32;
+    float x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { pre1[i] = xa[i] + h[i]; x[i] = nl_lrelu(pre1[i]); }
+    float o = b4[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float a = b2[j];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) a = fmaf(w2[j * 32 + i], x[i], a);
+      a2[j] = a;
+      o = fmaf(w4[j], nl_lrelu(a), o);
+    }
+    return o;
+  };
+  float lg[NL_MAX_VIEWS];
+  float mx = -3.4e38f;
+  for (int v = 0; v < V; ++v) {
+    float pre1[32], a2[16];
+    float o = logit(v, pre1, a2);
+    if (rgbv[((size_t)n * V + v) * 4 + 3] == 0.f) o = -1e9f;
+    lg[v] = o; mx = fmaxf(mx, o);
+  }
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) { lg[v] = expf(lg[v] - mx); den += lg[v]; }
+  const float gr = g_rgb_s[3 * (size_t)n], gg = g_rgb_s[3 * (size_t)n + 1], gb = g_rgb_s[3 * (size_t)n + 2];
+  float dot = 0.f;
+  for (int v = 0; v < V; ++v) {
+    lg[v] /= den;
+    const float* c = rgbv + ((size_t)n * V + v) * 4;
+    dot += lg[v] * (gr * c[0] + gg * c[1] + gb * c[2]);
+  }
+  float gA[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) gA[i] = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float* c = rgbv + ((size_t)n * V + v) * 4;
+    const float bw = lg[v];
+    const float glog = (c[3] == 0.f) ? 0.f : bw * ((gr * c[0] + gg * c[1] + gb * c[2]) - dot);   // masked logits are constants
+    float pre1[32], a2[16];
+    (void)logit(v, pre1, a2);
+    float g1[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g1[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float ga = glog * w4[j] * (a2[j] > 0.f ? 1.f : 0.01f);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) g1[i] = fmaf(w2[j * 32 + i], ga, g1[i]);
+    }
+    float go[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* pf = g_pf + ((size_t)n * V + v) * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float g = g1[i] * (pre1[i] > 0.f ? 1.f : 0.01f);
+      pf[i] = g;
+      gA[i] += g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) go[k] = fmaf(blw[i * 8 + k], g, go[k]);
+    }
+    *(float4*)(g_rgbv + ((size_t)n * V + v) * 4) = make_float4(go[0] + bw * gr, go[1] + bw * gg, go[2] + bw * gb, go[3]);
+    *(float4*)(g_ang + ((size_t)n * V + v) * 4) = make_float4(go[4], go[5], go[6], go[7]);
+  }
+#pragma unroll
+  for (int i4 = 0; i4 < 8; ++i4) *(float4*)(g_hA + (size_t)n * 32 + 4 * i4) = make_float4(gA[4 * i4], gA[4 * i4 + 1], gA[4 * i4 + 2], gA[4 * i4 + 3]);
+}
+
+// g *= ELU'(pre-activation), from the layer's OUTPUT e: e > 0 ? 1 : e + 1
+__global__ void elu_mask_kernel(float4* __restrict__ g, const float4* __restrict__ e, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = g[i];
+  const float4 b = e[i];
+  a.x *= b.x > 0.f ? 1.f : b.x + 1.f; a.y *= b.y > 0.f ? 1.f : b.y + 1.f; a.z *= b.z > 0.f ? 1.f : b.z + 1.f; a.w *= b.w > 0.f ? 1.f : b.w + 1.f;
+  g[i] = a;
+}
+
+}  // namespace
+
+int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
+                               int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
+                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  if (C > 192) return NL_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)nl_cdiv(N, 4));
+#define NL_MGB(VT) hipLaunchKernelGGL((mv_geom_backward_kernel<VT>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, \
+                                      g393, ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd)
+  if (vw.V <= 4) NL_MGB(4); else if (vw.V <= 8) NL_MGB(8); else if (vw.V <= 10) NL_MGB(10); else NL_MGB(16);
+#undef NL_MGB
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, const float* g_vis, const float* g_dd,
+                           float* g_xyz, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  dim3 grid((unsigned)nl_cdiv(N, 256), (unsigned)vw.V);
+  hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, g_xyz);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
+                             const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(blend_backward_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgbv, (int)N, V, w2, b2, w4, b4, blw, g_rgb_s, g_hA, g_pf,
+                     g_rgbv, g_ang);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st) {
+  if (n == 0) return NL_OK;
+  hipLaunchKernelGGL(elu_mask_kernel, dim3((unsigned)nl_cdiv((int64_t)(n / 4), 256)), dim3(256), 0, st, (float4*)g, (const float4*)e, n / 4);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}

@@ -120,6 +120,43 @@ class PointBranchFn(torch.autograd.Function):
         return gx, gd, gg, None, None
 
 
+class MvAggFn(torch.autograd.Function):
+    """Multi-view aggregation (multiview_aggregator.py:156-222) with frozen weights / support maps as one autograd node on the HIP library:
+    xyz (N,3) -> (G (N,W), valid_s (N) int32 [non-differentiable: #views that see the sample > 1]); backward = nl_mv_aggregate_backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, renderer):
+        xyz = xyz.contiguous()
+        ctx.r = renderer
+        ctx.save_for_backward(xyz)
+        mv, _, _, valid = renderer.mv_aggregate(xyz, torch.zeros(3), want_raw=False)
+        ctx.mark_non_differentiable(valid)
+        return mv, valid
+
+    @staticmethod
+    def backward(ctx, g_mv, _g_valid):
+        xyz, = ctx.saved_tensors
+        return ctx.r.mv_aggregate_backward(xyz, g_mv.contiguous()), None
+
+
+class BlendFn(torch.autograd.Function):
+    """Per-sample colours (model.py:528-538) with frozen weights / maps: (xyz (N,3), feature_agg (N,W), query camera centre (3,)) -> rgb_s (N,3);
+    forward = nl_blend, backward = nl_blend_backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, fa, qc, renderer):
+        xyz, fa = xyz.contiguous(), fa.contiguous()
+        ctx.r = renderer
+        ctx.save_for_backward(xyz, fa, qc)
+        return renderer.blend(xyz, qc, fa)
+
+    @staticmethod
+    def backward(ctx, g_rgb_s):
+        xyz, fa, qc = ctx.saved_tensors
+        gx, gfa, gq = ctx.r.blend_backward(xyz, qc, fa, g_rgb_s.contiguous(), want_g_query_center=ctx.needs_input_grad[2])
+        return gx, gfa, (None if gq is None else gq.to(qc.dtype)), None
+
+
 def rays_from_pose(uv: Tensor, K: Tensor, pose: Tensor):
     """conditional_nerf/utils.py:56-70 + model.py:687-700 for the selected pixels only (integer-truncated pixel coordinates):
     unit directions rotated by the camera-to-world pose, origin = its translation.  Differentiable w.r.t. `pose`."""
@@ -270,11 +307,32 @@ def query_diff(p: Dict[str, Tensor], fr: Dict, xyz: Tensor, direction: Optional[
     return {"feature_agg": agg, "feature": feat, "weights": w, "multiview_feature": mvf, "multiview_visibility": mvv}
 
 
+def _conv3(t: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """Conv1d(k = 3, stride 1, padding 1) as ONE matrix product over the three taps: t (R, Ci, L), w (Co, Ci, 3) -> (R, Co, L).  (The
+    framework's convolution kernels are slow for these short rays: 6 ms of a 512-ray gradient step; a GEMM is 10x faster and its autograd
+    is two more GEMMs.)"""
+    R, Ci, L = t.shape
+    cols = F.pad(t, (1, 1)).unfold(2, 3, 1)                                    # (R, Ci, L, 3)
+    y = cols.permute(0, 2, 1, 3).reshape(R * L, Ci * 3) @ w.reshape(w.shape[0], -1).t()
+    return y.view(R, L, -1).permute(0, 2, 1) + b[None, :, None]
+
+
+def _convT3(t: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """ConvTranspose1d(k = 3, stride 2, padding 1, output_padding 1) by its two output phases: y[2m] = W[:, :, 1]^T x[m],
+    y[2m + 1] = W[:, :, 2]^T x[m] + W[:, :, 0]^T x[m + 1];  t (R, Ci, L), w (Ci, Co, 3) -> (R, Co, 2L)."""
+    R, Ci, L = t.shape
+    xt = t.permute(0, 2, 1)
+    xn = F.pad(xt, (0, 0, 0, 1))[:, 1:]
+    even = xt.reshape(R * L, Ci) @ w[:, :, 1]
+    odd = torch.cat([xt, xn], -1).reshape(R * L, 2 * Ci) @ torch.cat([w[:, :, 2], w[:, :, 0]], 0)
+    return torch.stack([even, odd], 1).view(R, L, 2, -1).reshape(R, 2 * L, -1).permute(0, 2, 1) + b[None, :, None]
+
+
 def _ray_unet(p, x: Tensor) -> Tensor:
     """conditional_nerf/ray_unet.py:5-69 — x (R, W, S) -> (R, W, S)."""
     def block(name, t, transposed=False):
         w, b = p[f"ray_unet.{name}.0.weight"], p[f"ray_unet.{name}.0.bias"]
-        t = F.conv_transpose1d(t, w, b, stride=2, padding=1, output_padding=1) if transposed else F.conv1d(t, w, b, stride=1, padding=1)
+        t = _convT3(t, w, b) if transposed else _conv3(t, w, b)
         g, be = p[f"ray_unet.{name}.1.weight"], p[f"ray_unet.{name}.1.bias"]
         return F.elu(F.layer_norm(t, tuple(g.shape), g, be, eps=1e-5))
 
@@ -308,34 +366,40 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     R, S = z_vals.shape
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3)
-    G, mvf, mvv, mask1 = _mv_aggregate(p, fr, xyz)
-    if frozen_renderer is not None and _hip_ok(xyz, dirs, G):
-        # frozen weights + frozen support table (pose refinement): the whole branch is one node whose backward is nl_point_mlp_backward
+    frozen = frozen_renderer is not None and _hip_ok(xyz, dirs)
+    if frozen:
+        # frozen weights + frozen per-frame tables (pose refinement): aggregation, neural-point branch and blend are three autograd nodes whose
+        # forward AND backward run in the HIP library; nothing of them is kept on the tape but their inputs
+        G, valid_s = MvAggFn.apply(xyz, frozen_renderer)
         agg = PointBranchFn.apply(xyz, dirs.contiguous(), G, frozen_renderer, 8)
     else:
+        G, mvf, mvv, mask1 = _mv_aggregate(p, fr, xyz)
         with torch.no_grad():
             idx = knn_idx(xyz.detach()).long()
         agg = _point_branch(p, fr, xyz, dirs, G, idx)
     W = agg.shape[1]
     geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
     sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)
-    V = mvf.shape[1]
-    ang = _view_angles(xyz, query_pose[:3, 3], fr["topk_poses"][:, :3, 3])
-    # rgb_blending_mlp.0 on cat[feature_agg (repeated over the views), multi-view feature, visibility, view angles] (model.py:532-535), evaluated
-    # by linearity as four partial products: the (N, V, W + C + 8) concatenation (1.2 GB per 512-ray batch) is never materialised
-    w0, b0 = p["rgb_blending_mlp.0.weight"], p["rgb_blending_mlp.0.bias"]
-    Fd = mvf.shape[-1]
-    xb = (F.linear(agg, w0[:, :W]) + b0).unsqueeze(1) + F.linear(mvf, w0[:, W:W + Fd]) + mvv * w0[:, W + Fd] + F.linear(ang, w0[:, W + Fd + 1:])
-    xb = _lrelu(_lin(p, "rgb_blending_mlp.2", _lrelu(xb)))
-    bw = F.softmax(_lin(p, "rgb_blending_mlp.4", xb).masked_fill(mvv == 0, -1e9), dim=1)
-    rgb_s = torch.sum(mvf[:, :, :3] * bw, dim=1).view(R, S, 3)
+    if frozen:
+        rgb_s = BlendFn.apply(xyz, agg, query_pose[:3, 3], frozen_renderer).view(R, S, 3)
+    else:
+        V = mvf.shape[1]
+        ang = _view_angles(xyz, query_pose[:3, 3], fr["topk_poses"][:, :3, 3])
+        # rgb_blending_mlp.0 on cat[feature_agg (repeated over the views), multi-view feature, visibility, view angles] (model.py:532-535), evaluated
+        # by linearity as four partial products: the (N, V, W + C + 8) concatenation (1.2 GB per 512-ray batch) is never materialised
+        w0, b0 = p["rgb_blending_mlp.0.weight"], p["rgb_blending_mlp.0.bias"]
+        Fd = mvf.shape[-1]
+        xb = (F.linear(agg, w0[:, :W]) + b0).unsqueeze(1) + F.linear(mvf, w0[:, W:W + Fd]) + mvv * w0[:, W + Fd] + F.linear(ang, w0[:, W + Fd + 1:])
+        xb = _lrelu(_lin(p, "rgb_blending_mlp.2", _lrelu(xb)))
+        bw = F.softmax(_lin(p, "rgb_blending_mlp.4", xb).masked_fill(mvv == 0, -1e9), dim=1)
+        rgb_s = torch.sum(mvf[:, :, :3] * bw, dim=1).view(R, S, 3)
     # front-to-back compositing (model.py:544-560, 597): its backward is the HIP kernel nl_composite_backward on the GPU
     ft = _lin(p, "feat_mlp.2", _lrelu(_lin(p, "feat_mlp.0", agg))).view(R, S, -1)
     if _hip_ok(sigma, rgb_s, ft, z_vals) and not z_vals.requires_grad and S <= 256:
         rgb, depth, unc, feat, wts = CompositeFn.apply(sigma, rgb_s, ft, z_vals, white_bkgd)
     else:
         rgb, depth, unc, feat, wts = composite_eager(sigma, rgb_s, ft, z_vals, white_bkgd)
-    valid = (mask1.view(R, S, V).sum(2) > 1).float().sum(1) > 8
+    valid = (valid_s.view(R, S) > 0).float().sum(1) > 8 if frozen else (mask1.view(R, S, -1).sum(2) > 1).float().sum(1) > 8
     out = {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": unc}
     if beta:
         out["beta"] = (wts * F.softplus(_lin(p, "beta_mlp.0", geo)).view(R, S)).sum(1) + 0.1   # beta_min, model.py:98

@@ -244,6 +244,43 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
+    def mv_aggregate_backward(self, xyz, g_mv_feat):
+        """Input gradient of `mv_aggregate`'s feature rows with frozen weights / maps (nl_mv_aggregate_backward): -> g_xyz (N,3)."""
+        self._ready()
+        x, g = _dev_f32(xyz, self.device), _dev_f32(g_mv_feat, self.device)
+        N = x.shape[0]
+        gx = torch.empty(N, 3, device=self.device)
+        ws = self._workspace(self.lib.nl_mv_aggregate_backward_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        L.check(self.lib.nl_mv_aggregate_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), N, g.data_ptr(), gx.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate_backward")
+        return gx
+
+    def blend(self, xyz, query_center, feature_agg):
+        """Row a15 as a stage (nl_blend): per-sample colours (N,3) from the sample positions and feature_agg."""
+        self._ready()
+        x, fa = _dev_f32(xyz, self.device), _dev_f32(feature_agg, self.device)
+        N = x.shape[0]
+        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        out = torch.empty(N, 3, device=self.device)
+        ws = self._workspace(self.lib.nl_blend_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        L.check(self.lib.nl_blend(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), fa.data_ptr(), N, out.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), self._stream()), "nl_blend")
+        return out
+
+    def blend_backward(self, xyz, query_center, feature_agg, g_rgb_s, want_g_query_center: bool = True):
+        """nl_blend_backward: -> (g_xyz (N,3), g_feature_agg (N,W), g_query_center (3,) or None)."""
+        self._ready()
+        x, fa, g = _dev_f32(xyz, self.device), _dev_f32(feature_agg, self.device), _dev_f32(g_rgb_s, self.device)
+        N = x.shape[0]
+        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        gx = torch.empty(N, 3, device=self.device)
+        gfa = torch.empty(N, self.W, device=self.device)
+        gq = torch.empty(N, 3, device=self.device) if want_g_query_center else None
+        ws = self._workspace(self.lib.nl_blend_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        L.check(self.lib.nl_blend_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), fa.data_ptr(), N, g.data_ptr(),
+                                           gx.data_ptr(), gfa.data_ptr(), _ptr(gq), ws.data_ptr(), ws.numel(), self._stream()), "nl_blend_backward")
+        return gx, gfa, (None if gq is None else gq.sum(0))
+
     def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8):
         """Input gradient of `point_mlp` with frozen weights (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W))."""
         self._ready()

@@ -132,3 +132,87 @@ def test_point_branch_backward_matches_autograd(case, precision, tol):
         e_hip, e_ref = rel_err(a.cpu().numpy(), c64.cpu().numpy()), rel_err(b.cpu().numpy(), c64.cpu().numpy())
         print(case, precision, name, "hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
         assert e_hip < max(tol, 3 * e_ref), (name, e_hip, e_ref)
+
+
+def _mv_setup(case, precision="fp32", R_max=10):
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case(case)
+    cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = {k: t(v) for k, v in c["weights"].items()}
+    fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
+    fr.update({"near": float(cfg.near), "far": float(cfg.far)})
+    R = min(cfg.R, R_max)
+    o, d = t(rays["rays_o"][:R]), t(rays["rays_d"][:R])
+    lin = torch.linspace(0, 1, cfg.S, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, cfg.S)
+    xyz = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
+    return cfg, r, p, fr, xyz, t(frame["pose"])
+
+
+def _cast(tree, dt):
+    return {k: (_cast(v, dt) if isinstance(v, dict) else (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v)) for k, v in tree.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tiny_full", "offview", "c1", "w256s128"])
+def test_mv_aggregate_backward_matches_autograd(case):
+    """nl_mv_aggregate_backward against autograd of diff_render._mv_aggregate (frozen weights): d(sum G . cotangent) / d xyz."""
+    cfg, r, p, fr, xyz, _ = _mv_setup(case)
+    g = torch.Generator().manual_seed(5)
+    cot = torch.randn(xyz.shape[0], cfg.W, generator=g).to(xyz.device)
+
+    def grads(fn, dt):
+        a = xyz.detach().to(dt).requires_grad_(True)
+        out = fn(a, dt)
+        return out.detach(), torch.autograd.grad((out * cot.to(dt)).sum(), a)[0]
+    o_hip, g_hip = grads(lambda a, dt: dr.MvAggFn.apply(a, r)[0], torch.float32)
+    o_ref, g_ref = grads(lambda a, dt: dr._mv_aggregate(_cast(p, dt), _cast(fr, dt), a)[0], torch.float32)
+    _, g_64 = grads(lambda a, dt: dr._mv_aggregate(_cast(p, dt), _cast(fr, dt), a)[0], torch.float64)
+    assert rel_err(o_hip.cpu().numpy(), o_ref.cpu().numpy()) < 5e-5
+    e_hip, e_ref = rel_err(g_hip.cpu().numpy(), g_64.cpu().numpy()), rel_err(g_ref.cpu().numpy(), g_64.cpu().numpy())
+    print(case, "g_xyz hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
+    assert e_hip < max(2e-4, 3 * e_ref), (e_hip, e_ref)
+
+
+def _blend_eager(p, fr, xyz, agg, qc):
+    """The colour blend of diff_render.render_rays_diff's eager branch as a function of (xyz, feature_agg, query centre)."""
+    import torch.nn.functional as F
+    _, mvf, mvv, _ = dr._mv_aggregate(p, fr, xyz)
+    W = agg.shape[1]
+    ang = dr._view_angles(xyz, qc, fr["topk_poses"][:, :3, 3])
+    w0, b0 = p["rgb_blending_mlp.0.weight"], p["rgb_blending_mlp.0.bias"]
+    Fd = mvf.shape[-1]
+    xb = (F.linear(agg, w0[:, :W]) + b0).unsqueeze(1) + F.linear(mvf, w0[:, W:W + Fd]) + mvv * w0[:, W + Fd] + F.linear(ang, w0[:, W + Fd + 1:])
+    xb = dr._lrelu(dr._lin(p, "rgb_blending_mlp.2", dr._lrelu(xb)))
+    bw = F.softmax(dr._lin(p, "rgb_blending_mlp.4", xb).masked_fill(mvv == 0, -1e9), dim=1)
+    return torch.sum(mvf[:, :, :3] * bw, dim=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tiny_full", "offview", "c1", "w256s128"])
+def test_blend_backward_matches_autograd(case):
+    """nl_blend / nl_blend_backward against autograd of the eager blend: gradients w.r.t. the sample positions, feature_agg and the query centre."""
+    cfg, r, p, fr, xyz, pose = _mv_setup(case)
+    g = torch.Generator().manual_seed(6)
+    fa = torch.randn(xyz.shape[0], cfg.W, generator=g).to(xyz.device)
+    cot = torch.randn(xyz.shape[0], 3, generator=g).to(xyz.device)
+    qc0 = pose[:3, 3].clone()
+
+    def grads(fn, dt):
+        a, b, q = (v.detach().to(dt).requires_grad_(True) for v in (xyz, fa, qc0))
+        out = fn(a, b, q, dt)
+        return out.detach(), torch.autograd.grad((out * cot.to(dt)).sum(), [a, b, q])
+    o_hip, g_hip = grads(lambda a, b, q, dt: dr.BlendFn.apply(a, b, q, r), torch.float32)
+    o_ref, g_ref = grads(lambda a, b, q, dt: _blend_eager(_cast(p, dt), _cast(fr, dt), a, b, q), torch.float32)
+    _, g_64 = grads(lambda a, b, q, dt: _blend_eager(_cast(p, dt), _cast(fr, dt), a, b, q), torch.float64)
+    assert rel_err(o_hip.cpu().numpy(), o_ref.cpu().numpy()) < 5e-5
+    for name, a, b, c64 in zip(("xyz", "feature_agg", "query_center"), g_hip, g_ref, g_64):
+        e_hip, e_ref = rel_err(a.cpu().numpy(), c64.cpu().numpy()), rel_err(b.cpu().numpy(), c64.cpu().numpy())
+        print(case, name, "hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
+        assert e_hip < max(2e-4, 3 * e_ref), (name, e_hip, e_ref)
