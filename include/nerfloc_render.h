@@ -283,6 +283,12 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
 size_t nl_mv_aggregate_backward_workspace_bytes(const nl_config* cfg, int V, int64_t N);
 int nl_mv_aggregate_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, int64_t N, const float* g_mv_feat,
                              float* g_xyz, void* ws, size_t ws_bytes, void* stream);
+/* Input gradient of nl_ray_unet (row a13; ray_unet.py:55-69) with frozen weights: g_geo (R*S,W) -> g_x (R*S,W).  The unfused forward is re-run in exact
+ * fp32 (every layer's pre-LayerNorm output stays in the workspace); then, layer by layer, the LayerNorm([C,L]) / ELU / MaxPool1d derivative and the
+ * transposed-weight convolution, with the skip connections' gradients added where the concatenations were. */
+size_t nl_ray_unet_backward_workspace_bytes(const nl_config* cfg, int64_t R);
+int nl_ray_unet_backward(const nl_config* cfg, const void* packed, const float* x, int64_t R, const float* g_geo, float* g_x, void* ws, size_t ws_bytes,
+                         void* stream);
 /* a15 as a stage (model.py:528-538): per-sample colours rgb_s (N,3) = softmax-over-views blend of the tapped colours, from the sample positions and
  * feature_agg (N,W) (query_center HOST, 3 floats) — what nl_render_rays computes between the neural-point branch and the compositing — and its
  * input gradient: g_rgb_s (N,3) -> g_xyz (N,3), g_feature_agg (N,W) or NULL, g_query_center (N,3: per-sample contributions, the caller sums

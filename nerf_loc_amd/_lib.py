@@ -95,6 +95,8 @@ SYMBOLS = [
     ("nl_blend_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_blend", _I, [_CFG, _P, _P, _P, _P, _P, _L, _P, _P, _Z, _P]),
     ("nl_blend_backward", _I, [_CFG, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _Z, _P]),
+    ("nl_ray_unet_backward_workspace_bytes", _Z, [_CFG, _L]),
+    ("nl_ray_unet_backward", _I, [_CFG, _P, _P, _L, _P, _P, _P, _Z, _P]),
     ("nl_knn_backward", _I, [_P, _P, _P, _P, _L, _I, _L, _P, _P, _P]),
     ("nl_backproject_support", _I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, C.POINTER(_L), _P, _Z, _P]),
 ]

@@ -74,6 +74,9 @@ int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float
 int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
                              const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st);
 int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
+int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
+                                   float* g_x, hipStream_t st);
+int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, int ldo, int64_t rows, int cols, hipStream_t st);
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
                                     float* g_dir, hipStream_t st);
@@ -125,6 +128,7 @@ enum {
   G_T3E, G_T3O, G_T2E, G_T2O, G_T1E, G_T1O, G_T3M, G_T2M, G_T1M, G_FEAT0P, G_BLENDAP, G_QP, G_CONVOUT, G_FEAT0, G_FEAT2, G_BLENDA, G_BLENDP, G_PTT,
   G_FC_T, G_Q_T, G_KV_T, G_BASE4_T, G_BASE2_T, G_BASE0_T,   // transposed weights: input gradients of the neural-point branch (do_point_backward)
   G_OUTFC2_T, G_OUTFC0_T, G_BLENDA_T,                         // ... of the multi-view aggregation's out_fc and of the blend's per-sample projection
+  G_UB_OUTA, G_UB_OUTB, G_UB_T1, G_UB_T2, G_UB_T3, G_UB_C3, G_UB_C2, G_UB_C1,   // ... of the ray U-Net's seven convolutions (do_unet_backward)
   G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
@@ -201,6 +205,15 @@ Layout make_layout(const nl_config* c) {
   set(G_OUTFC2_T, W, 64, false);
   set(G_OUTFC0_T, 64, (int)nl_align_up(2 * F + 3, 32), false);   // = ldg_of(C): the statistics row incl. its zero padding (416 columns: generic kernels)
   set(G_BLENDA_T, 32, W, false);
+  // convolution input gradients: K = the layer's output channels x 3 taps (transposed convolutions: [even | odd | odd of the previous position])
+  set(G_UB_OUTA, 3 * W, W, false);   // conv_out -> its feature_agg input channels
+  set(G_UB_OUTB, 3 * W, 32, false);  // conv_out -> its x2 input channels
+  set(G_UB_T1, 96, 128, false);
+  set(G_UB_T2, 192, 256, false);
+  set(G_UB_T3, 384, 128, false);
+  set(G_UB_C3, 384, 128, false);
+  set(G_UB_C2, 384, 64, false);
+  set(G_UB_C1, 192, W, false);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += nl_align_up(bytes, 256); return o; };
   for (int i = 0; i < G_COUNT; ++i) {
@@ -362,6 +375,29 @@ struct Packer {
     win(ci, 0, co);
     copy(b, L->bias[g], co);
     copy(b, L->bias[g] + 4 * (size_t)co, co);
+  }
+  // input-gradient weights of Conv1d(k = 3, padding 1), weight (co, ci, 3), for the input channels [n0, n0 + nn): K order [32-co block][tap slot
+  // tau][32] like conv3 (NlGemmSeg::ntap), slot tau reads the output-gradient row t + tau - 1 and therefore carries tap 2 - tau
+  void conv3_dgrad(int g, const float* w, int co, int ci, int n0, int nn) {
+    const GemmDim& d = L->g[g];
+    int k0 = 0;
+    for (int cb = 0; cb < co / 32; ++cb)
+      for (int tau = 0; tau < 3; ++tau) {
+        hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(32 * nn, 256)), dim3(256), 0, st, w, 32 * cb * ci * 3 + n0 * 3 + (2 - tau), 3, ci * 3, 32, nn, k0,
+                           (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad,
+                           (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0);
+        k0 += 32;
+      }
+  }
+  // input-gradient weights of ConvTranspose1d(k = 3, stride 2), weight (ci, co, 3), against the merged-phase gradient rows [even | odd]:
+  // K = [even: tap 1 | odd: tap 2 | odd of the previous position: tap 0]
+  void convT_dgrad(int g, const float* w, int ci, int co) {
+    const GemmDim& d = L->g[g];
+    const int taps[3] = {1, 2, 0};
+    for (int part = 0; part < 3; ++part)
+      hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(co * ci, 256)), dim3(256), 0, st, w, taps[part], co * 3, 3, co, ci, part * co,
+                         (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad,
+                         (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0);
   }
   void convT(int ge, int go, const float* w, const float* b, int ci, int co) {
     block(ge, 0, w, 1, 3, co * 3, ci);
@@ -908,6 +944,67 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   return NL_OK;
 }
 
+// ---- input gradient of the ray U-Net (frozen weights) -------------------------------------------------------------------------------
+struct UnBwdBufs { UnBufs u; float *geo, *gout, *gx2, *gx2r, *gcat1, *gx1r, *gcat2, *gx0r, *gc3, *gr3, *gc2, *gr2, *gc1, *gr1, *tmp; };
+void carve_unb(Bump& b, const nl_config* c, int64_t R, UnBwdBufs& q) {
+  const size_t N = (size_t)R * c->S;
+  const int W = c->W;
+  carve_un(b, c, R, q.u);
+  q.geo = b.take<float>(N * W); q.gout = b.take<float>(N * W);
+  q.gx2 = b.take<float>(N * 32); q.gx2r = b.take<float>(N * 32);
+  q.gcat1 = b.take<float>(N / 2 * 128); q.gx1r = b.take<float>(N / 2 * 64);
+  q.gcat2 = b.take<float>(N / 4 * 256); q.gx0r = b.take<float>(N / 4 * 128);
+  q.gc3 = b.take<float>(N / 8 * 128); q.gr3 = b.take<float>(N / 4 * 128);
+  q.gc2 = b.take<float>(N / 4 * 128); q.gr2 = b.take<float>(N / 2 * 128);
+  q.gc1 = b.take<float>(N / 2 * 64); q.gr1 = b.take<float>(N * 64);
+  q.tmp = b.take<float>(N * W);
+}
+
+// Unfused forward in exact fp32 (every layer's pre-LayerNorm output stays in the workspace), then layer by layer backwards: LayerNorm / ELU /
+// MaxPool derivative (one block per ray) -> transposed-weight convolution (segment GEMM over the gradient rows' taps), the skip connections'
+// gradients added where the concatenations were.
+int do_unet_backward(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, const float* g_geo, float* g_in, const UnBwdBufs& q) {
+  const int W = x32.c->W, S = x32.c->S;
+  const UnBufs& u = q.u;
+  NL_TRY(do_unet(x32, in, R, q.geo, u));   // fp32: separate GEMM + ln_slab_elu launches
+  auto g = [&](int i) { return x32.p<float>(x32.L.un_g[i]); };
+  auto b = [&](int i) { return x32.p<float>(x32.L.un_b[i]); };
+  const float eps = 1e-5f;
+  hipStream_t st = x32.st;
+  // conv_out
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, g_geo, W, 0, q.gout, st));
+  { SegSpec s[1] = {{q.gout, W, W, 0, 1, 3}};
+    NL_TRY(run_gemm(xb, G_UB_OUTA, s, 1, R * S, g_in, W, NL_ACT_NONE, S, S, S, 1, 0));
+    NL_TRY(run_gemm(xb, G_UB_OUTB, s, 1, R * S, q.gx2, 32, NL_ACT_NONE, S, S, S, 1, 0)); }
+  // trans_conv1: slab (S x 32) = merged rows (S/2 x 64)
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.x2r, R, S, 32, g(U_T1), b(U_T1), eps, q.gx2, 32, 0, q.gx2r, st));
+  { SegSpec s[2] = {{q.gx2r, 64, 64, 0, 1}, {q.gx2r + 32, 64, 32, -1, 1}};
+    NL_TRY(run_gemm(xb, G_UB_T1, s, 2, R * (S / 2), q.gcat1, 128, NL_ACT_NONE, S / 2, S / 2, S / 2, 1, 0)); }
+  // trans_conv2: output x1 = columns 64..127 of cat[c1, x1]'s gradient
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.x1r, R, S / 2, 64, g(U_T2), b(U_T2), eps, q.gcat1 + 64, 128, 0, q.gx1r, st));
+  { SegSpec s[2] = {{q.gx1r, 128, 128, 0, 1}, {q.gx1r + 64, 128, 64, -1, 1}};
+    NL_TRY(run_gemm(xb, G_UB_T2, s, 2, R * (S / 4), q.gcat2, 256, NL_ACT_NONE, S / 4, S / 4, S / 4, 1, 0)); }
+  // trans_conv3: output x0 = columns 128..255 of cat[c2, x0]'s gradient
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.x0r, R, S / 4, 128, g(U_T3), b(U_T3), eps, q.gcat2 + 128, 256, 0, q.gx0r, st));
+  { SegSpec s[2] = {{q.gx0r, 256, 256, 0, 1}, {q.gx0r + 128, 256, 128, -1, 1}};
+    NL_TRY(run_gemm(xb, G_UB_T3, s, 2, R * (S / 8), q.gc3, 128, NL_ACT_NONE, S / 8, S / 8, S / 8, 1, 0)); }
+  // conv3 (+ MaxPool): gradient of its pooled output c3
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, q.gc3, 128, 1, q.gr3, st));
+  { SegSpec s[1] = {{q.gr3, 128, 128, 0, 1, 3}};
+    NL_TRY(run_gemm(xb, G_UB_C3, s, 1, R * (S / 4), q.tmp, 128, NL_ACT_NONE, S / 4, S / 4, S / 4, 1, 0)); }
+  NL_TRY(nl_launch_add2d(q.gcat2, 256, q.tmp, 128, q.gc2, 128, R * (S / 4), 128, st));
+  // conv2 (+ MaxPool)
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, q.gc2, 128, 1, q.gr2, st));
+  { SegSpec s[1] = {{q.gr2, 128, 128, 0, 1, 3}};
+    NL_TRY(run_gemm(xb, G_UB_C2, s, 1, R * (S / 2), q.tmp, 64, NL_ACT_NONE, S / 2, S / 2, S / 2, 1, 0)); }
+  NL_TRY(nl_launch_add2d(q.gcat1, 128, q.tmp, 64, q.gc1, 64, R * (S / 2), 64, st));
+  // conv1 (+ MaxPool)
+  NL_TRY(nl_launch_ln_slab_elu_backward(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, q.gc1, 64, 1, q.gr1, st));
+  { SegSpec s[1] = {{q.gr1, 64, 64, 0, 1, 3}};
+    NL_TRY(run_gemm(xb, G_UB_C1, s, 1, R * S, q.tmp, W, NL_ACT_NONE, S, S, S, 1, 0)); }
+  return nl_launch_add2d(g_in, W, q.tmp, W, g_in, W, R * S, W, st);
+}
+
 // the part of the heads that needs feature_agg only (not the density): feat_mlp.0, the per-sample blend projection, the blend tail
 // term == true: n_alive / tile_list of `h` are valid (nl_launch_termination ran): dead samples are skipped
 int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const float* rgbv, int64_t N, bool want_feat, const HdBufs& h, int parts = 7,
@@ -1065,6 +1162,14 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.convT_merged(G_T2M, un[16], un[17], 256, 64);
   P.convT_merged(G_T1M, un[20], un[21], 128, 32);
   { const int wo[2] = {W, 32}; P.conv3(G_CONVOUT, un[24], un[25], W + 32, wo, 2); }
+  P.conv3_dgrad(G_UB_OUTA, un[24], W, W + 32, 0, W);
+  P.conv3_dgrad(G_UB_OUTB, un[24], W, W + 32, W, 32);
+  P.convT_dgrad(G_UB_T1, un[20], 128, 32);
+  P.convT_dgrad(G_UB_T2, un[16], 256, 64);
+  P.convT_dgrad(G_UB_T3, un[12], 128, 128);
+  P.conv3_dgrad(G_UB_C3, un[8], 128, 128, 0, 128);
+  P.conv3_dgrad(G_UB_C2, un[4], 128, 64, 0, 64);
+  P.conv3_dgrad(G_UB_C1, un[0], 64, W, 0, W);
   for (int u = 0; u < U_COUNT; ++u) {
     P.transpose(un[4 * u + 2], L.un_g[u], L.un_c[u], L.un_l[u]);   // (C, L) -> (L, C)
     P.transpose(un[4 * u + 3], L.un_b[u], L.un_c[u], L.un_l[u]);
@@ -1339,6 +1444,28 @@ int nl_blend_backward(const nl_config* cfg, const void* packed, const nl_frame* 
     Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, true, m);
     NL_TRY(do_blend_backward(B.xb, B.x32, f, qc, xyz + 3 * n0, feature_agg + n0 * W, nc, g_rgb_s + 3 * n0, g_xyz + 3 * n0,
                              g_feature_agg ? g_feature_agg + n0 * W : nullptr, g_query_center ? g_query_center + 3 * n0 : nullptr, m));
+  }
+  return NL_OK;
+}
+
+static size_t unet_bwd_bytes(const nl_config* cfg, int64_t r) { Bump b{nullptr, 0}; UnBwdBufs q; carve_unb(b, cfg, r, q); return b.off; }
+size_t nl_ray_unet_backward_workspace_bytes(const nl_config* cfg, int64_t R) {
+  return cfg_ok(cfg) ? unet_bwd_bytes(cfg, R < 1 ? 1 : (R > 1024 ? 1024 : R)) : 0;   // recommended: chunks of <= 1024 rays
+}
+int nl_ray_unet_backward(const nl_config* cfg, const void* packed, const float* xin, int64_t R, const float* g_geo, float* g_x, void* ws, size_t ws_bytes,
+                         void* stream) {
+  if (R == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !xin || !g_geo || !g_x || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (ws_bytes < unet_bwd_bytes(cfg, 1)) return NL_ERR_WORKSPACE;
+  int64_t lo = 1, hi = R;
+  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (unet_bwd_bytes(cfg, mid) <= ws_bytes) lo = mid; else hi = mid - 1; }
+  const int64_t RC = lo;
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  const size_t row = (size_t)cfg->S * cfg->W;
+  for (int64_t r0 = 0; r0 < R; r0 += RC) {
+    const int64_t rc = R - r0 < RC ? R - r0 : RC;
+    Bump b{(char*)ws, 0}; UnBwdBufs q; carve_unb(b, cfg, rc, q);
+    NL_TRY(do_unet_backward(B.xb, B.x32, xin + r0 * row, rc, g_geo + r0 * row, g_x + r0 * row, q));
   }
   return NL_OK;
 }

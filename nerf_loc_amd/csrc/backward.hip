@@ -915,3 +915,102 @@ int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st) {
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
+
+// =====================================================================================================================
+// Ray U-Net (row a13; ray_unet.py:5-69), gradient w.r.t. its input with frozen weights: between the transposed-weight convolutions (segment
+// GEMMs, abi.hip: do_unet_backward) sits the backward of [LayerNorm over the ray's whole (L x C) slab, per-(position, channel) affine] -> ELU ->
+// optional MaxPool1d(2).
+namespace {
+
+// one block per ray.  x (L, Cc) the layer's pre-LayerNorm output (recomputed by the unfused forward); g_out: gradient w.r.t. the block's output —
+// (L/2, Cc) rows when pooled, (L, Cc) otherwise — with row stride ldgo (a column window of a wider gradient matrix is fine); g_x (L, Cc) contiguous.
+__global__ __launch_bounds__(256) void ln_slab_elu_backward_kernel(const float* __restrict__ xin, int L, int Cc, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps, const float* __restrict__ g_out, int ldgo,
+                                                                   int pool, float* __restrict__ g_x) {
+  __shared__ float red[8];
+  const int r = blockIdx.x;
+  const int n = L * Cc;
+  const float* x = xin + (size_t)r * n;
+  float* gx = g_x + (size_t)r * n;
+  const float* go = g_out + (size_t)r * (pool ? L / 2 : L) * ldgo;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float x0 = x[0];
+  float s = 0.f, q = 0.f;
+  for (int i = tid; i < n; i += 256) { const float d = x[i] - x0; s += d; q += d * d; }
+  s = wave_sum(s); q = wave_sum(q);
+  if (lane == 0) { red[wave] = s; red[4 + wave] = q; }
+  __syncthreads();
+  const float ms = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+  const float mean = x0 + ms;
+  const float var = fmaxf((red[4] + red[5] + red[6] + red[7]) / (float)n - ms * ms, 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  __syncthreads();
+  // pass B: g_xhat = g_y * gamma into g_x (scratch), and the two slab sums of the LayerNorm backward
+  float s1 = 0.f, s2 = 0.f;
+  auto one = [&](int i, float ge) __attribute__((always_inline)) {
+    const float xh = (x[i] - mean) * rstd;
+    const float y = xh * gamma[i] + beta[i];
+    const float gy = ge * (y > 0.f ? 1.f : expf(y));     // ELU'
+    const float gh = gy * gamma[i];
+    gx[i] = gh;
+    s1 += gh; s2 += gh * xh;
+  };
+  if (pool) {
+    const int half = (L / 2) * Cc;
+    for (int i = tid; i < half; i += 256) {
+      const int p = i / Cc, c = i - p * Cc;
+      const int i0 = 2 * p * Cc + c, i1 = i0 + Cc;
+      const float a = nl_elu((x[i0] - mean) * rstd * gamma[i0] + beta[i0]);
+      const float b = nl_elu((x[i1] - mean) * rstd * gamma[i1] + beta[i1]);
+      const float g = go[(size_t)p * ldgo + c];
+      const bool first = a >= b;     // max_pool1d keeps the first of two equal values
+      one(i0, first ? g : 0.f);
+      one(i1, first ? 0.f : g);
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) { const int t = i / Cc, c = i - t * Cc; one(i, go[(size_t)t * ldgo + c]); }
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+  __syncthreads();
+  const float m1 = (red[0] + red[1] + red[2] + red[3]) / (float)n, m2 = (red[4] + red[5] + red[6] + red[7]) / (float)n;
+  // pass C (every element was written by this same thread in pass B: same index striding)
+  if (pool) {
+    const int half = (L / 2) * Cc;
+    for (int i = tid; i < half; i += 256) {
+      const int p = i / Cc, c = i - p * Cc;
+      const int i0 = 2 * p * Cc + c, i1 = i0 + Cc;
+      gx[i0] = rstd * (gx[i0] - m1 - (x[i0] - mean) * rstd * m2);
+      gx[i1] = rstd * (gx[i1] - m1 - (x[i1] - mean) * rstd * m2);
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) gx[i] = rstd * (gx[i] - m1 - (x[i] - mean) * rstd * m2);
+  }
+}
+
+// out[r][c] = a[r][c] + b[r][c] over (rows, cols) windows with row strides (cols % 4 == 0, 16-byte aligned rows)
+__global__ void add2d_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ o, int ldo, int rows, int cols4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols4) return;
+  const int r = (int)(i / cols4), c = (int)(i - (size_t)r * cols4) * 4;
+  const float4 x = *(const float4*)(a + (size_t)r * lda + c), y = *(const float4*)(b + (size_t)r * ldb + c);
+  *(float4*)(o + (size_t)r * ldo + c) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+}  // namespace
+
+int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
+                                   float* g_x, hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  hipLaunchKernelGGL(ln_slab_elu_backward_kernel, dim3((unsigned)R), dim3(256), 0, st, x, L, Cc, gamma, beta, eps, g_out, ldgo, pool, g_x);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, int ldo, int64_t rows, int cols, hipStream_t st) {
+  if (rows <= 0) return NL_OK;
+  const int64_t n = rows * (cols / 4);
+  hipLaunchKernelGGL(add2d_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, a, lda, b, ldb, o, ldo, (int)rows, cols / 4);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}

@@ -139,6 +139,22 @@ class MvAggFn(torch.autograd.Function):
         return ctx.r.mv_aggregate_backward(xyz, g_mv.contiguous()), None
 
 
+class UnetFn(torch.autograd.Function):
+    """The ray U-Net (ray_unet.py:55-69) with frozen weights on the HIP library: x (R*S, W) sample-major -> geo (R*S, W); backward = nl_ray_unet_backward."""
+
+    @staticmethod
+    def forward(ctx, x, renderer):
+        x = x.contiguous()
+        ctx.r = renderer
+        ctx.save_for_backward(x)
+        return renderer.ray_unet(x)
+
+    @staticmethod
+    def backward(ctx, g_geo):
+        x, = ctx.saved_tensors
+        return ctx.r.ray_unet_backward(x, g_geo.contiguous()), None
+
+
 class BlendFn(torch.autograd.Function):
     """Per-sample colours (model.py:528-538) with frozen weights / maps: (xyz (N,3), feature_agg (N,W), query camera centre (3,)) -> rgb_s (N,3);
     forward = nl_blend, backward = nl_blend_backward."""
@@ -378,7 +394,10 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
             idx = knn_idx(xyz.detach()).long()
         agg = _point_branch(p, fr, xyz, dirs, G, idx)
     W = agg.shape[1]
-    geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
+    if frozen and S == frozen_renderer.S:
+        geo = UnetFn.apply(agg, frozen_renderer)
+    else:
+        geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
     sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)
     if frozen:
         rgb_s = BlendFn.apply(xyz, agg, query_pose[:3, 3], frozen_renderer).view(R, S, 3)

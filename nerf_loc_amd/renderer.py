@@ -244,6 +244,18 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
+    def ray_unet_backward(self, x, g_geo):
+        """Input gradient of `ray_unet` with frozen weights (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W)."""
+        if not self._weights_loaded:
+            raise RuntimeError("load_weights() first")
+        xin, g = _dev_f32(x, self.device), _dev_f32(g_geo, self.device)
+        R = xin.shape[0] // self.S
+        gx = torch.empty_like(xin)
+        ws = self._workspace(self.lib.nl_ray_unet_backward_workspace_bytes(ct.byref(self.cfg), R))
+        L.check(self.lib.nl_ray_unet_backward(ct.byref(self.cfg), self.packed.data_ptr(), xin.data_ptr(), R, g.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              self._stream()), "nl_ray_unet_backward")
+        return gx
+
     def mv_aggregate_backward(self, xyz, g_mv_feat):
         """Input gradient of `mv_aggregate`'s feature rows with frozen weights / maps (nl_mv_aggregate_backward): -> g_xyz (N,3)."""
         self._ready()

@@ -216,3 +216,35 @@ def test_blend_backward_matches_autograd(case):
         e_hip, e_ref = rel_err(a.cpu().numpy(), c64.cpu().numpy()), rel_err(b.cpu().numpy(), c64.cpu().numpy())
         print(case, name, "hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
         assert e_hip < max(2e-4, 3 * e_ref), (name, e_hip, e_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,precision", [("tiny_full", "fp32"), ("c1", "fp32"), ("w128s64", "bf16x3"), ("w256s128", "bf16x3"), ("s192out", "bf16x3")])
+def test_ray_unet_backward_matches_autograd(case, precision):
+    """nl_ray_unet_backward (frozen weights) against autograd of the eager U-Net (diff_render._ray_unet), for every slab height the configs use
+    (S = 16 ... 192; fused and unfused forward paths)."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case(case)
+    cfg = c["cfg"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    p = {k: torch.from_numpy(v).to(dev) for k, v in c["weights"].items()}
+    R, S, W = 6, cfg.S_total, cfg.W
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(R * S, W, generator=g).to(dev)
+    cot = torch.randn(R * S, W, generator=g).to(dev)
+
+    def grads(fn, dt):
+        a = x.detach().to(dt).requires_grad_(True)
+        out = fn(a, dt)
+        return out.detach(), torch.autograd.grad((out * cot.to(dt)).sum(), a)[0]
+    eager = lambda a, dt: dr._ray_unet(_cast(p, dt), a.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
+    o_hip, g_hip = grads(lambda a, dt: dr.UnetFn.apply(a, r), torch.float32)
+    o_ref, g_ref = grads(eager, torch.float32)
+    _, g_64 = grads(eager, torch.float64)
+    assert rel_err(o_hip.cpu().numpy(), o_ref.cpu().numpy()) < (1e-4 if precision == "bf16x3" else 2e-5)
+    e_hip, e_ref = rel_err(g_hip.cpu().numpy(), g_64.cpu().numpy()), rel_err(g_ref.cpu().numpy(), g_64.cpu().numpy())
+    print(case, precision, "g_x hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
+    assert e_hip < max(1e-4, 3 * e_ref), (e_hip, e_ref)
