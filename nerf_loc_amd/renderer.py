@@ -185,7 +185,7 @@ class HipRenderer:
         L.check(self.lib.nl_render_rays_ex(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, None if per_ray else qc.data_ptr(), o.data_ptr(),
                                            d.data_ptr(), _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream(),
                                            ct.byref(opts) if (early_term_eps > 0 or per_ray or not side_stream) else None), "nl_render_rays")
-        out["mask"] = out["mask"].bool()
+        out["mask"] = out["mask"].view(torch.bool)   # 0 / 1 bytes reinterpreted: no conversion kernel
         if intermediates:
             out["sigma"] = out["sigma"].view(R, S)
         return out
