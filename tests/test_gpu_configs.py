@@ -185,6 +185,11 @@ def test_render_opts_are_validated_and_streams_do_not_interfere():
     torch.cuda.synchronize()
     for k in KEYS:
         assert torch.equal(ref_a[k], nofork[k]), k
+    from nerf_loc_amd.renderer import render_rays_concurrent
+    both = render_rays_concurrent([(ra, o, d, qc, {"z_vals": z}), (rb_, o, d2, qc, {"z_vals": z})])
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert torch.equal(both[0][k], ref_a[k]) and torch.equal(both[1][k], ref_b[k]), k
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     for _ in range(5):
         with torch.cuda.stream(s1):

@@ -25,3 +25,26 @@ def timed(fn, n=10):
 one = timed(lambda: r.render_rays(o, d, per_ray))
 sep = timed(lambda: [r.render_rays(o[i * R:(i + 1) * R], d[i * R:(i + 1) * R], centres[i]) for i in range(F)])
 print(f"{F} query frames x {R} rays x {cfg.S} samples: one launch {one:.2f} ms ({one / F:.2f} per frame), {F} launches {sep:.2f} ms ({sep / F:.2f} per frame)")
+
+# ---- frames with DIFFERENT support sets: one renderer (frame tables, workspace, side stream) per support frame; the launch chains of
+# the frames are independent, so they may run on separate caller streams and fill the chip together
+def other_frame(i):
+    c = cfg.replace(seed=cfg.seed + 100 + i)
+    fr = make_frame(c)
+    rr = HipRenderer(cfg.W, cfg.C, cfg.S_total, "bf16x3", workspace_bytes=None)
+    rr.packed = r.packed; rr._weights_loaded = True          # the same packed weights
+    rr.set_frame(fr["topk_images"], fr["feat_fine_src"], fr["vis_featmaps"], fr["topk_Ks"], fr["topk_poses"], c.near, c.far, fr["support_fine"])
+    ry = make_rays(c, fr)
+    return rr, torch.from_numpy(ry["rays_o"][:R]).to(dev), torch.from_numpy(ry["rays_d"][:R]).to(dev), fr["pose"][:3, 3]
+frames = [other_frame(i) for i in range(F)]
+from nerf_loc_amd.renderer import render_rays_concurrent
+streams = [torch.cuda.Stream() for _ in range(F)]
+def serial():
+    return [rr.render_rays(oo, dd, qc) for rr, oo, dd, qc in frames]
+def concurrent():
+    return render_rays_concurrent(frames, streams)
+ts, tc = timed(serial), timed(concurrent)
+a, b = serial(), concurrent()
+torch.cuda.synchronize()
+assert all(torch.equal(x[k], y[k]) for x, y in zip(a, b) for k in x), "concurrent rendering must be bit-identical to serial"
+print(f"{F} DIFFERENT support frames x {R} rays: one stream {ts:.2f} ms ({ts / F:.2f} per frame), {F} streams {tc:.2f} ms ({tc / F:.2f} per frame)")
