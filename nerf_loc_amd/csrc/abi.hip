@@ -137,7 +137,7 @@ struct GemmDim { int K, N, Kpad, Npad; bool bias; };
 
 struct Layout {
   GemmDim g[G_COUNT];
-  size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bias[G_COUNT];
+  size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bsh[G_COUNT], bias[G_COUNT];   // bsh: the weight stream in fp16 hi / lo (split-FP16 arithmetic)
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
   size_t pt_stream, pt_stream2, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
@@ -222,6 +222,7 @@ Layout make_layout(const nl_config* c) {
     L.bhi[i] = take(n * 2);
     L.blo[i] = take(n * 2);
     L.bst[i] = take(L.g[i].N <= 256 ? nl_tgemm_stream_bytes(L.g[i].Kpad, L.g[i].N) : 0);
+    L.bsh[i] = take(L.g[i].N <= 256 ? nl_tgemm_stream_bytes(L.g[i].Kpad, L.g[i].N) : 0);
     L.bias[i] = take((size_t)L.g[i].Npad * 4);
   }
   L.rd_w = take(4 * (64 + 16 + 27 * 16 + 27));
@@ -263,7 +264,8 @@ __device__ __forceinline__ unsigned short pk_f2bf(float x) {
 // dst[k0+k][n] (f32 [Kpad][Npad]) and bf16 hi/lo [n][Kpad] <- src[off + n*ld_n + k*ld_k], k < kc, n < N
 __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld_n, int ld_k, int kc, int N, int k0,
                                   float* __restrict__ b32, unsigned short* __restrict__ bhi, unsigned short* __restrict__ blo,
-                                  int Kpad, int Npad, unsigned short* __restrict__ bst, int nrts, int n0, int perm = 0) {
+                                  int Kpad, int Npad, unsigned short* __restrict__ bst, int nrts, int n0, int perm = 0,
+                                  unsigned short* __restrict__ bsh = nullptr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kc * N) return;
   int k = i / N, n = i - k * N;
@@ -284,6 +286,11 @@ __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld
   const size_t e = (size_t)(kk >> 5) * (4 * nrts * 512) + ((size_t)(((kk >> 4) & 1) * nrts + (ng >> 5)) * 64 + (ng & 31) + 32 * ((kk >> 3) & 1)) * 8 + (kk & 7);
   bst[e] = h;
   bst[e + (size_t)2 * nrts * 512] = l;
+  if (bsh) {   // the same stream in fp16: hi = round(v), lo = round(v - hi)
+    const _Float16 g = (_Float16)v;
+    bsh[e] = __builtin_bit_cast(unsigned short, g);
+    bsh[e + (size_t)2 * nrts * 512] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)g));
+  }
 }
 
 // [32][8] = rgb(3) | vis(1) | angle(4) columns of rgb_blending_mlp.0.weight (32, W+F+5), then its bias[32]
@@ -331,7 +338,7 @@ struct Packer {
     int n = kc * d.N;
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, off, ld_n, ld_k, kc, d.N, k0,
                        (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad,
-                       (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0, perm);
+                       (unsigned short*)(base + L->bst[g]), nl_tgemm_nrt(d.N), 0, perm, d.N <= 256 ? (unsigned short*)(base + L->bsh[g]) : nullptr);
   }
   void copy(const float* src, size_t dst_off, int n) {
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, (float*)(base + dst_off), n);
@@ -368,7 +375,7 @@ struct Packer {
       hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, w, tap, 3, co * 3, ci, co, k0,
                          (float*)(base + L->b32[g]) + n0, (unsigned short*)(base + L->bhi[g]) + (size_t)n0 * d.Kpad,
                          (unsigned short*)(base + L->blo[g]) + (size_t)n0 * d.Kpad, d.Kpad, d.Npad, (unsigned short*)(base + L->bst[g]),
-                         nl_tgemm_nrt(d.N), n0);
+                         nl_tgemm_nrt(d.N), n0, 0, (unsigned short*)(base + L->bsh[g]));
     };
     win(0, 1, 0);
     win(0, 2, co);
@@ -532,8 +539,15 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   const GemmDim& d = x.L.g[g];
   if (ksum != ((d.K + 31) & ~31)) return NL_ERR_BAD_ARG;
   a.nseg = nseg; a.M = (int)M; a.K = d.K; a.N = d.N; a.Kpad = d.Kpad; a.Npad = d.Npad;
-  if (x.c->precision == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
-  else { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; a.Bst = x.pk + x.L.bst[g]; }
+  int prec = x.c->precision;
+  if (prec == NL_PREC_F16X3_INTERNAL) {   // split-FP16 where the streaming kernel applies (its only implementation), exact fp32 elsewhere
+    a.Bst = x.pk + x.L.bsh[g];
+    a.zeros = x.p<float>(x.L.zeros); a.C = C; a.ldc = ldc; a.N = d.N; a.M = (int)M;
+    a.epi = NL_EPI_NONE;
+    if (tiles || d.N > 256 || !nl_tgemm_supported(a, prec)) { prec = NL_PREC_F32; a.Bst = nullptr; }   // (a requested fused epilogue is simply not fused)
+  }
+  if (prec == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
+  else if (prec != NL_PREC_F16X3_INTERNAL) { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; a.Bst = x.pk + x.L.bst[g]; }
   a.zeros = x.p<float>(x.L.zeros);
   a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
   a.C = C; a.ldc = ldc; a.act = act;
@@ -543,11 +557,11 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.epi = epi->kind; a.ep_pool = epi->pool; a.ep_res = epi->res; a.ep_ldres = epi->ldres; a.ep_gamma = epi->gamma; a.ep_beta = epi->beta;
     a.ep_scale = epi->scale; a.ep_eps = epi->eps;
     a.ep_sig_w = epi->sig_w; a.ep_sig_b = epi->sig_b; a.ep_sig_out = epi->sig_out;
-    if (nl_tgemm_supported(a, x.c->precision)) { a.C = epi->out; if (fused) *fused = true; }
+    if (nl_tgemm_supported(a, prec)) { a.C = epi->out; if (fused) *fused = true; }
     else a.epi = NL_EPI_NONE;
   }
-  if (tiles && !nl_tgemm_supported(a, x.c->precision)) { a.tile_map = nullptr; a.tile_count = nullptr; }   // generic kernels compute every row
-  return nl_gemm_launch(a, x.c->precision, x.st);
+  if (tiles && !nl_tgemm_supported(a, prec)) { a.tile_map = nullptr; a.tile_count = nullptr; }   // generic kernels compute every row
+  return nl_gemm_launch(a, prec, x.st);
 }
 
 #define NL_TRY(e) do { int _rc = (e); if (_rc != NL_OK) return _rc; } while (0)
@@ -751,7 +765,8 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
   NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
   NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, 1, N, K, M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
                                 inv_span, p.X, ldx, p.wscale, x.st));
-  SegSpec sx{p.X, ldx, F + 90, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
+  // (the encoded rows' pad columns are zero and so are the weights' pad rows: taking all ldx columns keeps the streaming kernel applicable)
+  SegSpec sx{p.X, ldx, ldx, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
   NL_TRY(run_gemm(x, G_BASE0, &sx, 1, NK, p.H1, W, NL_ACT_LRELU));
   NL_TRY(run_gemm(x, G_BASE2, &s1, 1, NK, p.H2, W, NL_ACT_LRELU));
   NL_TRY(run_gemm(x, G_BASE4, &s2, 1, NK, p.H3, W, NL_ACT_LRELU));
@@ -1114,7 +1129,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
                          (float*)((char*)packed + L.b32[G_KV]) + half * 128,
                          (unsigned short*)((char*)packed + L.bhi[G_KV]) + (size_t)half * 128 * d.Kpad,
                          (unsigned short*)((char*)packed + L.blo[G_KV]) + (size_t)half * 128 * d.Kpad, d.Kpad, d.Npad,
-                         (unsigned short*)((char*)packed + L.bst[G_KV]), nl_tgemm_nrt(d.N), half * 128);
+                         (unsigned short*)((char*)packed + L.bst[G_KV]), nl_tgemm_nrt(d.N), half * 128, 0, (unsigned short*)((char*)packed + L.bsh[G_KV]));
     }
   }
   P.linear(G_Q, t[T_WQ], nullptr);
@@ -1338,6 +1353,16 @@ int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, co
   return NL_OK;
 }
 
+struct BwdCtx { nl_config c32, cbw; Ctx x32, xb; };
+static void make_bwd_ctx(BwdCtx& B, const nl_config* cfg, const void* packed, void* stream) {
+  B.c32 = *cfg; B.cbw = *cfg;
+  // recomputed forward: exact fp32 in the fp32 mode, three-term split-FP16 (products good to ~2^-22, the speed of split-bf16) otherwise — see
+  // nl_point_mlp_backward for why split-bf16 is not enough there; the way back: split-bf16
+  B.c32.precision = cfg->precision == NL_PREC_F32 ? NL_PREC_F32 : NL_PREC_F16X3_INTERNAL;
+  if (B.cbw.precision == NL_PREC_BF16) B.cbw.precision = NL_PREC_BF16X3;
+  B.x32 = make_ctx(&B.c32, packed, stream); B.xb = make_ctx(&B.cbw, packed, stream);
+}
+
 static size_t point_bwd_bytes(const nl_config* cfg, int64_t n) { Bump b{nullptr, 0}; PtBwdBufs p; carve_ptb(b, cfg, n, 8, p); return b.off; }
 
 size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N) {
@@ -1353,22 +1378,20 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
   if (ws_bytes < point_bwd_bytes(cfg, 1)) return NL_ERR_WORKSPACE;
-  // Precision of the two halves (measured, tools/r3 experiment in DESIGN.md §5.12):
-  //  * the RECOMPUTED FORWARD multiplies in exact fp32 (v_mfma_f32_32x32x2_f32) whatever the render mode: the derivative of a LeakyReLU
-  //    network is piecewise constant, and a forward that is 1e-5 off (split-bf16) flips the sign of a few pre-activations near zero — every
-  //    flip changes that neighbour row's gradient by a few percent (2e-2 in the max-norm of g_xyz, against 4e-6 with the fp32 forward; plain
-  //    fp32 autograd is 4e-3 from the fp64 gradient for the same reason);
+  // Precision of the two halves (measured):
+  //  * the RECOMPUTED FORWARD must be much better than split-bf16: the derivative of a LeakyReLU network is piecewise constant, and a forward that
+  //    is 1e-5 off flips the sign of a few pre-activations near zero — every flip changes that neighbour row's gradient by a few percent (2e-2 in
+  //    the max-norm of g_xyz with a split-bf16 recompute against 4e-6 with exact fp32; plain fp32 autograd is 4e-3 from the fp64 gradient for the
+  //    same reason).  Exact fp32 in the fp32 mode; three-term split-FP16 (~2^-22) otherwise: 40x fewer flips than split-bf16 at the same speed;
   //  * the transposed-weight products of the way back are linear in the incoming gradient and run in split-bf16 (1e-5, no discontinuity).
-  nl_config c32 = *cfg, cbw = *cfg;
-  c32.precision = NL_PREC_F32;
-  if (cbw.precision == NL_PREC_BF16) cbw.precision = NL_PREC_BF16X3;
   int64_t lo = 1, hi = N;
   while (lo < hi) {   // largest sample chunk whose buffers fit the workspace
     const int64_t mid = (lo + hi + 1) / 2;
     if (point_bwd_bytes(cfg, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
   }
   const int64_t NC = lo < (1 << 17) ? lo : (1 << 17);
-  const Ctx xf = make_ctx(&c32, packed, stream), xb = make_ctx(&cbw, packed, stream);   // recomputed forward / way back
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  const Ctx &xf = B.x32, &xb = B.xb;   // recomputed forward / way back
   const int W = cfg->W;
   for (int64_t n0 = 0; n0 < N; n0 += NC) {
     const int64_t nc = N - n0 < NC ? N - n0 : NC;
@@ -1386,14 +1409,6 @@ static int64_t mv_bwd_chunk(const nl_config* cfg, int V, int64_t N, bool blend, 
   while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (mv_bwd_bytes(cfg, V, mid, blend) <= ws_bytes) lo = mid; else hi = mid - 1; }
   return lo < (1 << 18) ? lo : (1 << 18);
 }
-struct BwdCtx { nl_config c32, cbw; Ctx x32, xb; };
-static void make_bwd_ctx(BwdCtx& B, const nl_config* cfg, const void* packed, void* stream) {
-  B.c32 = *cfg; B.cbw = *cfg;
-  B.c32.precision = NL_PREC_F32;
-  if (B.cbw.precision == NL_PREC_BF16) B.cbw.precision = NL_PREC_BF16X3;
-  B.x32 = make_ctx(&B.c32, packed, stream); B.xb = make_ctx(&B.cbw, packed, stream);
-}
-
 size_t nl_mv_aggregate_backward_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
   return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 16) ? (1 << 16) : N), false) : 0;
 }

@@ -46,6 +46,22 @@ __device__ __forceinline__ void tg_split8(const float (&v)[8], tg_bf16x8& hi, tg
   }
 }
 
+// three-term split-FP16 variant (internal precision NL_PREC_F16X3_INTERNAL: the backward passes' recomputed forward): the same storage type (16-bit
+// lanes), fp16 bit patterns; products good to ~2^-22 at the speed of split-bf16
+typedef _Float16 tg_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void tg_split8_f16(const float (&v)[8], tg_bf16x8& hi, tg_bf16x8& lo) {
+  tg_f16x8 h, l;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { const _Float16 x = (_Float16)v[t]; h[t] = x; l[t] = (_Float16)(v[t] - (float)x); }
+  hi = __builtin_bit_cast(tg_bf16x8, h);
+  lo = __builtin_bit_cast(tg_bf16x8, l);
+}
+template <bool F16>
+__device__ __forceinline__ tg_f32x16 tg_mfma(const tg_bf16x8& a, const tg_bf16x8& b, const tg_f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, a), __builtin_bit_cast(tg_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // chunk c (k-space [32c, 32c+32)) lies in exactly one segment (every segment is a multiple of 32 wide here);
 // kstart[] are the segments' first k (INT_MAX for unused slots) -> branch-free, wave-uniform lookup
 __device__ __forceinline__ int tg_find_seg(const NlGemmArgs& a, int k0) {
@@ -68,7 +84,7 @@ __device__ unsigned long long tg_trace[64];
 #define TG_T(i)
 #endif
 
-template <int NRT, int NW, bool X3, int EPI>
+template <int NRT, int NW, bool X3, int EPI, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
                                                             const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
   constexpr int PARTS = X3 ? 2 : 1;
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
     for (int ks = 0; ks < 2; ++ks) {
       const float v[8] = {raw[2 * ks].x, raw[2 * ks].y, raw[2 * ks].z, raw[2 * ks].w,
                           raw[2 * ks + 1].x, raw[2 * ks + 1].y, raw[2 * ks + 1].z, raw[2 * ks + 1].w};
-      tg_split8<X3>(v, bh[ks], bl[ks]);
+      if constexpr (F16) tg_split8_f16(v, bh[ks], bl[ks]); else tg_split8<X3>(v, bh[ks], bl[ks]);
     }
   };
 
@@ -172,10 +188,10 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       if (tt + 2 < nt) ldA(tt + 2, ah[(tt + 2) % 3], al[(tt + 2) % 3]);
       const int ks = tt / NRT, rt = tt - ks * NRT;
       if (X3) {
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt % 3], bh[ks], acc[rt], 0, 0, 0);
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], acc[rt], 0, 0, 0);
+        acc[rt] = tg_mfma<F16>(al[tt % 3], bh[ks], acc[rt]);
+        acc[rt] = tg_mfma<F16>(ah[tt % 3], bl[ks], acc[rt]);
       }
-      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], acc[rt], 0, 0, 0);
+      acc[rt] = tg_mfma<F16>(ah[tt % 3], bh[ks], acc[rt]);
       filler(tt);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -789,6 +805,7 @@ int nl_tgemm_nrt(int N) { return N <= 64 ? 2 : (N <= 128 ? 4 : 8); }
 size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 * nl_tgemm_nrt(N) * 1024; }
 
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
+  if (precision == NL_PREC_F16X3_INTERNAL && (a.epi != NL_EPI_NONE || a.tile_map)) return false;   // plain products only
   if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
@@ -813,6 +830,13 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
     else                                                                                                     \
       hipLaunchKernelGGL((tgemm_kernel<NRT, NW, X3, NL_EPI_NONE>), grid, dim3(64 * NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);  \
   } while (0)
+  if (precision == NL_PREC_F16X3_INTERNAL) {
+    dim3 grid((unsigned)nl_cdiv(a.M, 32 * 4));
+    if (nrt == 8) hipLaunchKernelGGL((tgemm_kernel<8, 4, true, NL_EPI_NONE, true>), grid, dim3(256), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    else if (nrt == 4) hipLaunchKernelGGL((tgemm_kernel<4, 4, true, NL_EPI_NONE, true>), grid, dim3(256), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    else hipLaunchKernelGGL((tgemm_kernel<2, 4, true, NL_EPI_NONE, true>), grid, dim3(256), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+  }
   if (nrt == 8) { if (x3) NL_TG(8, 4, true); else NL_TG(8, 4, false); }
   else if (nrt == 4) { if (x3) NL_TG(4, 4, true); else NL_TG(4, 4, false); }
   else { if (x3) NL_TG(2, 4, true); else NL_TG(2, 4, false); }
