@@ -269,11 +269,12 @@ int nl_knn_backward(const float* xyz, const float* sp_xyz, const int32_t* idx, c
  * the staged forward is re-run into the workspace (KNN, neighbour encoding, base_mlp, k / v / q projections, attention), then transposed-
  * weight GEMMs and the reductions' derivatives walk back.  Arguments as nl_point_mlp (dir: one row per sample, row stride dir_stride).
  * The neighbour weights' dependence on the distances is exactly zero for this network (the normalised weights multiply K identical rows)
- * and is not propagated.  Samples are processed in chunks that fit the workspace. */
+ * and is not propagated.  knn_idx / knn_d2 (N,K): the neighbours nl_point_mlp returned for the same xyz (both or neither; NULL: the search runs again).
+ * Samples are processed in chunks that fit the workspace. */
 size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N);
 int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, const float* dir, int64_t dir_stride,
-                          const float* mv_feat, int64_t N, int K, const float* g_feature_agg, float* g_xyz, float* g_dir, float* g_mv_feat, void* ws,
-                          size_t ws_bytes, void* stream);
+                          const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
+                          float* g_dir, float* g_mv_feat, void* ws, size_t ws_bytes, void* stream);
 
 /* Input gradient of nl_mv_aggregate's feature rows (rows a4-a7; multiview_aggregator.py:156-222, ibrnet.py:169-231, visibility_decoder.py:64-148)
  * with frozen weights and frozen support maps: g_mv_feat (N,W) -> g_xyz (N,3).  The forward is recomputed in exact fp32; the way back goes through

@@ -89,7 +89,7 @@ SYMBOLS = [
     ("nl_get_rays", _I, [_P, _P, _P, _I, _I, _L, _P, _P, _P]),
     ("nl_composite_backward", _I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
-    ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_mv_aggregate_backward_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_mv_aggregate_backward", _I, [_CFG, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
     ("nl_blend_workspace_bytes", _Z, [_CFG, _I, _L]),

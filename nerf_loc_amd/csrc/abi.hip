@@ -751,19 +751,31 @@ void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p) {
   p.gKV = b.take<float>(NK * 256); p.gA = b.take<float>(NK * W); p.gB = b.take<float>(NK * W); p.gX = b.take<float>(NK * 96);
 }
 
+// dX = (dY . W) * LeakyReLU'(h): the mask inside the streaming GEMM's epilogue where that kernel runs, a separate pass otherwise (fp32 mode)
+int gemm_lrelu_masked(const Ctx& x, int g, const SegSpec& s, int64_t M, float* out, int ld, const float* h) {
+  if (x.c->precision != NL_PREC_F32 && (s.k & 31) == 0 && (((size_t)s.ptr) & 15) == 0 && (s.ld & 3) == 0 && (ld & 3) == 0 && (((size_t)h) & 15) == 0 && x.L.g[g].N <= 256) {
+    const RowEpi ep{h, ld, nullptr, nullptr, nullptr, 0.f, out, NL_EPI_NONE};
+    return run_gemm(x, g, &s, 1, M, out, ld, NL_ACT_LRELU_MASK, 0, 0, 0, 1, 0, &ep);
+  }
+  NL_TRY(run_gemm(x, g, &s, 1, M, out, ld, NL_ACT_NONE));
+  return nl_launch_lrelu_mask(out, h, (size_t)M * ld, x.st);
+}
+
 // Re-runs the staged forward (point.hip kernels + segment GEMMs in the configured precision) into the workspace, then walks back:
 // g_FA -> LayerNorm/scale -> {residual -> g_G ; fc^T -> attention -> {w_qs^T -> g_G ; [w_ks; w_vs]^T -> base_mlp^T x 3 with LeakyReLU masks ->
 // posenc / ray_diff_fc -> g_xyz, g_dir}}.  The aggregation scale sum_k w_k is a constant of the backward pass: it is identically 1 (or 0)
 // whatever the distances are (model.py:419-427 normalises the weights; the K rows they multiply are identical, see point.hip).
 int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
-                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p) {
+                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in = nullptr, const float* d2_in = nullptr) {
   const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
   const int64_t NK = N * K;
   const float inv_span = 1.f / (f->views.far_ - f->views.near_);
   const int64_t M = f->M;
   // ---- forward, staged
-  NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
-  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, 1, N, K, M, p.idx, p.d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
+  const int* idx = idx_in && d2_in ? idx_in : p.idx;
+  const float* d2 = idx_in && d2_in ? d2_in : p.d2;
+  if (idx == p.idx) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));   // (the caller may hand over the forward call's neighbours)
+  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, 1, N, K, M, idx, d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
                                 inv_span, p.X, ldx, p.wscale, x.st));
   // (the encoded rows' pad columns are zero and so are the weights' pad rows: taking all ldx columns keeps the streaming kernel applicable)
   SegSpec sx{p.X, ldx, ldx, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
@@ -783,14 +795,11 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
     NL_TRY(run_gemm(xb, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
     NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
   }
-  NL_TRY(run_gemm(xb, G_KV_T, &skv, 1, NK, p.gA, W, NL_ACT_NONE));
-  NL_TRY(nl_launch_lrelu_mask(p.gA, p.H3, (size_t)NK * W, x.st));
-  NL_TRY(run_gemm(xb, G_BASE4_T, &sa, 1, NK, p.gB, W, NL_ACT_NONE));
-  NL_TRY(nl_launch_lrelu_mask(p.gB, p.H2, (size_t)NK * W, x.st));
-  NL_TRY(run_gemm(xb, G_BASE2_T, &sb, 1, NK, p.gA, W, NL_ACT_NONE));
-  NL_TRY(nl_launch_lrelu_mask(p.gA, p.H1, (size_t)NK * W, x.st));
+  NL_TRY(gemm_lrelu_masked(xb, G_KV_T, skv, NK, p.gA, W, p.H3));
+  NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2));
+  NL_TRY(gemm_lrelu_masked(xb, G_BASE2_T, sb, NK, p.gA, W, p.H1));
   NL_TRY(run_gemm(xb, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
-  NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, 1, N, K, M, p.idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
+  NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, 1, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
                                          g_dir, x.st));
   return NL_OK;
 }
@@ -817,7 +826,8 @@ void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdB
 // statistics rows (+ the blend's per-(sample, view) layer-1 part when bl1 != null)
 int mv_recompute(const Ctx& x32, const nl_frame* f, const NlViews& vw, const float* xyz, int64_t N, const MvBwdBufs& m) {
   if (m.bl1) NL_TRY(ensure_pfeat(x32, f));
-  NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.vis, m.dd, x32.st));
+  if (x32.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.vis, m.dd, x32.st));
+  else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x32.p<char>(x32.L.dec_mfma), xyz, N, m.vis, m.dd, true, x32.st));   // split-FP16 decoders (§2)
   return nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, ldg_of(f->C), nullptr, nullptr, m.valid_s, f->pfeat,
                             x32.p<float>(x32.L.blw), m.bl1, m.rgbv, x32.st);
 }
@@ -846,7 +856,8 @@ int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float
 int do_blend_forward(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, const float* FA, int64_t N, float* rgb_s, const MvBwdBufs& m) {
   const int W = x.c->W;
   const NlViews vw = with_query(f, qc);
-  nl_config c32 = *x.c; c32.precision = NL_PREC_F32;
+  nl_config c32 = *x.c;   // the same arithmetic as the backward call's recomputed forward
+  c32.precision = x.c->precision == NL_PREC_F32 ? NL_PREC_F32 : NL_PREC_F16X3_INTERNAL;
   Ctx x32 = x; x32.c = &c32;
   NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
   SegSpec sa{FA, W, W, 0, 1};
@@ -1372,8 +1383,8 @@ size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N) {
 }
 
 int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
-                          const float* mv_feat, int64_t N, int K, const float* g_feature_agg, float* g_xyz, float* g_dir, float* g_mv_feat, void* ws,
-                          size_t ws_bytes, void* stream) {
+                          const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
+                          float* g_dir, float* g_mv_feat, void* ws, size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
@@ -1397,7 +1408,8 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
     const int64_t nc = N - n0 < NC ? N - n0 : NC;
     Bump b{(char*)ws, 0}; PtBwdBufs p; carve_ptb(b, cfg, nc, 8, p);
     NL_TRY(do_point_backward(xb, xf, f, xyz + 3 * n0, dir ? dir + dir_stride * n0 : nullptr, (int)dir_stride, mv_feat + n0 * W, nc, K, g_feature_agg + n0 * W,
-                             g_xyz + 3 * n0, g_dir ? g_dir + 3 * n0 : nullptr, g_mv_feat ? g_mv_feat + n0 * W : nullptr, p));
+                             g_xyz + 3 * n0, g_dir ? g_dir + 3 * n0 : nullptr, g_mv_feat ? g_mv_feat + n0 * W : nullptr, p,
+                             knn_idx ? knn_idx + n0 * K : nullptr, knn_d2 ? knn_d2 + n0 * K : nullptr));
   }
   return NL_OK;
 }

@@ -10,6 +10,9 @@
 
 namespace {
 
+__device__ __forceinline__ float bk_rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int bk_rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
 // w_s = a_s T_s, a_s = 1 - exp(-delta_s sigma_s), T_s = prod_{j<s} (1 - a_j).  With q_s = dL/dw_s:
 //   dL/dsigma_s = delta_s ( q_s T_{s+1} - B_s ),  B_s = sum_{j>s} q_j w_j          (no division: exp(-delta sigma) may underflow to 0)
 // q_s = g_rgb . rgb_s - [white] sum_c g_rgb_c + g_depth z_s + g_unc ((z_s - D)^2 - 2 D (1 - W) z_s) + g_feat . ft_s + g_w_s
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
     const int i0 = idx[(size_t)n * K];
     dx = sp_dir[4 * (size_t)i0]; dy = sp_dir[4 * (size_t)i0 + 1]; dz = sp_dir[4 * (size_t)i0 + 2];
   }
-  float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;
+  float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gd0 = 0.f, gd1 = 0.f, gd2 = 0.f;   // per-lane partial sums over the neighbours; reduced once at the end
+  const float* w2 = rd_w + 80;
   for (int k = 0; k < K; ++k) {
     const bool have = k < M;
     const int i = idx[(size_t)n * K + k];
@@ -303,7 +307,6 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
     const float nx = have ? sp_xyz[3 * (size_t)i] : 0.f, ny = have ? sp_xyz[3 * (size_t)i + 1] : 0.f, nz = have ? sp_xyz[3 * (size_t)i + 2] : 0.f;
     const float off[3] = {(qx - nx) * inv_span, (qy - ny) * inv_span, (qz - nz) * inv_span};
     // ---- positional encoding: column j of lane j < 63
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (lane < 63) {
       const float g = grow[lane];
       int ax;
@@ -317,46 +320,37 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
         dv = r < 3 ? cosf(arg) * sc2 : -sinf(arg) * sc2;
       }
       const float t = g * dv;
-      c0 = ax == 0 ? t : 0.f; c1 = ax == 1 ? t : 0.f; c2 = ax == 2 ? t : 0.f;
+      gx0 += ax == 0 ? t : 0.f; gx1 += ax == 1 ? t : 0.f; gx2 += ax == 2 ? t : 0.f;
     }
-    gx0 += wave_sum(c0); gx1 += wave_sum(c1); gx2 += wave_sum(c2);
-    // ---- ray_diff_fc (4 -> 16 -> 27, LeakyReLU after both): forward values recomputed
+    // ---- ray_diff_fc (4 -> 16 -> 27, LeakyReLU after both): lane j < 16 owns hidden unit j, lane l < 27 output l; values cross lanes by readlane
     if (dir) {   // (wave-uniform)
       const float ndx = have ? sp_dir[4 * (size_t)i] : 0.f, ndy = have ? sp_dir[4 * (size_t)i + 1] : 0.f, ndz = have ? sp_dir[4 * (size_t)i + 2] : 0.f;
       const float rr0 = dx - ndx, rr1 = dy - ndy, rr2 = dz - ndz;
       const float nrm = sqrtf(rr0 * rr0 + rr1 * rr1 + rr2 * rr2), nr = nrm + 1e-8f;
       const float r0 = rr0 / nr, r1 = rr1 / nr, r2 = rr2 / nr, r3 = dx * ndx + dy * ndy + dz * ndz;
-      float a1[16], h[16];
+      const int ju = lane < 16 ? lane : 0, lu = lane < 27 ? lane : 0;
+      float a1 = rd_w[64 + ju];
+      a1 = fmaf(rd_w[ju * 4 + 0], r0, a1); a1 = fmaf(rd_w[ju * 4 + 1], r1, a1); a1 = fmaf(rd_w[ju * 4 + 2], r2, a1); a1 = fmaf(rd_w[ju * 4 + 3], r3, a1);
+      const float hj = nl_lrelu(a1);
+      float a2 = w2[27 * 16 + lu];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float a = rd_w[64 + j];
-        a = fmaf(rd_w[j * 4 + 0], r0, a); a = fmaf(rd_w[j * 4 + 1], r1, a); a = fmaf(rd_w[j * 4 + 2], r2, a); a = fmaf(rd_w[j * 4 + 3], r3, a);
-        a1[j] = a; h[j] = nl_lrelu(a);
-      }
-      const float* w2 = rd_w + 80;
-      float ga2 = 0.f;
-      if (lane < 27) {
-        float a = w2[27 * 16 + lane];
+      for (int j = 0; j < 16; ++j) a2 = fmaf(w2[lu * 16 + j], bk_rl(hj, j), a2);
+      const float ga2 = lane < 27 ? grow[63 + lane] * (a2 > 0.f ? 1.f : 0.01f) : 0.f;
+      float gh = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a = fmaf(w2[lane * 16 + j], h[j], a);
-        ga2 = grow[63 + lane] * (a > 0.f ? 1.f : 0.01f);
-      }
-      float gr[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float gh = wave_sum(lane < 27 ? w2[lane * 16 + j] * ga2 : 0.f);
-        const float ga1 = gh * (a1[j] > 0.f ? 1.f : 0.01f);
-        gr[0] = fmaf(rd_w[j * 4 + 0], ga1, gr[0]); gr[1] = fmaf(rd_w[j * 4 + 1], ga1, gr[1]);
-        gr[2] = fmaf(rd_w[j * 4 + 2], ga1, gr[2]); gr[3] = fmaf(rd_w[j * 4 + 3], ga1, gr[3]);
-      }
+      for (int l = 0; l < 27; ++l) gh = fmaf(w2[l * 16 + ju], bk_rl(ga2, l), gh);
+      const float ga1 = lane < 16 ? gh * (a1 > 0.f ? 1.f : 0.01f) : 0.f;
+      const float gr0 = wave_sum(rd_w[ju * 4 + 0] * ga1), gr1 = wave_sum(rd_w[ju * 4 + 1] * ga1), gr2 = wave_sum(rd_w[ju * 4 + 2] * ga1),
+                  gr3 = wave_sum(rd_w[ju * 4 + 3] * ga1);
       // u = rr / (|rr| + 1e-8): du_i/drr_j = delta_ij / nr - rr_i rr_j / (|rr| nr^2)  (0 at rr = 0, like torch.norm's subgradient)
-      const float gdot = gr[0] * rr0 + gr[1] * rr1 + gr[2] * rr2;
+      const float gdot = gr0 * rr0 + gr1 * rr1 + gr2 * rr2;
       const float cc = nrm > 0.f ? gdot / (nrm * nr * nr) : 0.f;
-      gd0 += gr[0] / nr - rr0 * cc + gr[3] * ndx;
-      gd1 += gr[1] / nr - rr1 * cc + gr[3] * ndy;
-      gd2 += gr[2] / nr - rr2 * cc + gr[3] * ndz;
+      gd0 += gr0 / nr - rr0 * cc + gr3 * ndx;   // (the same value in every lane: not reduced)
+      gd1 += gr1 / nr - rr1 * cc + gr3 * ndy;
+      gd2 += gr2 / nr - rr2 * cc + gr3 * ndz;
     }
   }
+  gx0 = wave_sum(gx0); gx1 = wave_sum(gx1); gx2 = wave_sum(gx2);
   if (lane == 0) {
     g_xyz[3 * (size_t)n] = gx0 * inv_span; g_xyz[3 * (size_t)n + 1] = gx1 * inv_span; g_xyz[3 * (size_t)n + 2] = gx2 * inv_span;
     if (g_dir) { g_dir[3 * (size_t)n] = gd0; g_dir[3 * (size_t)n + 1] = gd1; g_dir[3 * (size_t)n + 2] = gd2; }
@@ -423,8 +417,6 @@ int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_
 namespace {
 using namespace nlmv;
 
-__device__ __forceinline__ float bk_rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-__device__ __forceinline__ int bk_rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 struct TapD { int o[4]; float m[4]; float e, w, s, n; };   // clamped texel offsets, validity (0/1), fractional weights: value = s e t0 + s w t1 + n e t2 + n w t3
 __device__ __forceinline__ TapD make_tapd(const Taps& t, int Wm, int Hm) {

@@ -23,7 +23,8 @@ static inline size_t nl_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 static inline int64_t nl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------ activations (match torch fp32 CPU ops)
-enum { NL_ACT_NONE = 0, NL_ACT_LRELU = 1, NL_ACT_ELU = 2 };
+enum { NL_ACT_NONE = 0, NL_ACT_LRELU = 1, NL_ACT_ELU = 2,
+       NL_ACT_LRELU_MASK = 3 };   // backward passes (streaming GEMM only): out = acc * LeakyReLU'(.) taken from the sign of ep_res[m][n] (the layer's forward output)
 
 __device__ __forceinline__ float nl_lrelu(float x) { return x > 0.f ? x : x * 0.01f; }
 __device__ __forceinline__ float nl_elu(float x) { return x > 0.f ? x : expm1f(x); }

@@ -396,10 +396,16 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       if (n < a.N) {   // N % 4 == 0 and ldc % 4 == 0 are launch preconditions
         const float4 b4 = *(const float4*)(sbias + n);
         float4 v;
-        v.x = nl_act(acc[rt][4 * gq + 0] + b4.x, a.act);
-        v.y = nl_act(acc[rt][4 * gq + 1] + b4.y, a.act);
-        v.z = nl_act(acc[rt][4 * gq + 2] + b4.z, a.act);
-        v.w = nl_act(acc[rt][4 * gq + 3] + b4.w, a.act);
+        if (a.act == NL_ACT_LRELU_MASK) {   // input gradient through a LeakyReLU: the mask comes from the forward output's sign
+          const float4 h4 = *(const float4*)(a.ep_res + (size_t)m * a.ep_ldres + n);
+          v.x = acc[rt][4 * gq + 0] * (h4.x > 0.f ? 1.f : 0.01f); v.y = acc[rt][4 * gq + 1] * (h4.y > 0.f ? 1.f : 0.01f);
+          v.z = acc[rt][4 * gq + 2] * (h4.z > 0.f ? 1.f : 0.01f); v.w = acc[rt][4 * gq + 3] * (h4.w > 0.f ? 1.f : 0.01f);
+        } else {
+          v.x = nl_act(acc[rt][4 * gq + 0] + b4.x, a.act);
+          v.y = nl_act(acc[rt][4 * gq + 1] + b4.y, a.act);
+          v.z = nl_act(acc[rt][4 * gq + 2] + b4.z, a.act);
+          v.w = nl_act(acc[rt][4 * gq + 3] + b4.w, a.act);
+        }
         *(float4*)(crow + n) = v;
       }
     }
@@ -806,6 +812,7 @@ size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 *
 
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (precision == NL_PREC_F16X3_INTERNAL && (a.epi != NL_EPI_NONE || a.tile_map)) return false;   // plain products only
+  if (a.act == NL_ACT_LRELU_MASK && (a.epi != NL_EPI_NONE || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
   if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;

@@ -108,15 +108,15 @@ class PointBranchFn(torch.autograd.Function):
         xyz, G = xyz.contiguous(), G.contiguous()
         dirs = None if dirs is None else dirs.contiguous()
         ctx.r, ctx.K, ctx.has_dir = renderer, int(K), dirs is not None
-        ctx.save_for_backward(xyz, G, *([dirs] if dirs is not None else []))
-        fa, _, _ = renderer.point_mlp(xyz, dirs, G, K=int(K))
+        fa, d2, idx = renderer.point_mlp(xyz, dirs, G, K=int(K))
+        ctx.save_for_backward(xyz, G, d2, idx, *([dirs] if dirs is not None else []))
         return fa
 
     @staticmethod
     def backward(ctx, g_fa):
-        xyz, G = ctx.saved_tensors[:2]
-        dirs = ctx.saved_tensors[2] if ctx.has_dir else None
-        gx, gd, gg = ctx.r.point_mlp_backward(xyz, dirs, G, g_fa.contiguous(), K=ctx.K)
+        xyz, G, d2, idx = ctx.saved_tensors[:4]
+        dirs = ctx.saved_tensors[4] if ctx.has_dir else None
+        gx, gd, gg = ctx.r.point_mlp_backward(xyz, dirs, G, g_fa.contiguous(), K=ctx.K, knn=(d2, idx))
         return gx, gd, gg, None, None
 
 

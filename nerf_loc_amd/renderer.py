@@ -293,8 +293,9 @@ class HipRenderer:
                                            gx.data_ptr(), gfa.data_ptr(), _ptr(gq), ws.data_ptr(), ws.numel(), self._stream()), "nl_blend_backward")
         return gx, gfa, (None if gq is None else gq.sum(0))
 
-    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8):
-        """Input gradient of `point_mlp` with frozen weights (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W))."""
+    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None):
+        """Input gradient of `point_mlp` with frozen weights (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W)).
+        knn = (d2, idx) as `point_mlp` returned them for the same points: saves the second neighbour search."""
         self._ready()
         dev = self.device
         x, g, gy = _dev_f32(xyz, dev), _dev_f32(mv_feat, dev), _dev_f32(g_feature_agg, dev)
@@ -304,9 +305,10 @@ class HipRenderer:
         gd = None if dr is None else torch.empty(N, 3, device=dev)
         gg = torch.empty(N, self.W, device=dev)
         ws = self._workspace(self.lib.nl_point_mlp_backward_workspace_bytes(ct.byref(self.cfg), N))
+        d2, idx = (None, None) if knn is None else (knn[0].contiguous(), knn[1].to(torch.int32).contiguous())
         L.check(self.lib.nl_point_mlp_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
-                                               g.data_ptr(), N, K, gy.data_ptr(), gx.data_ptr(), _ptr(gd), gg.data_ptr(), ws.data_ptr(), ws.numel(),
-                                               self._stream()), "nl_point_mlp_backward")
+                                               g.data_ptr(), N, K, _ptr(idx), _ptr(d2), gy.data_ptr(), gx.data_ptr(), _ptr(gd), gg.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), self._stream()), "nl_point_mlp_backward")
         return gx, gd, gg
 
     def hierarchical_depths(self, pixel_coordinates, K, pose, z_base, u, n_coarse: int = 64, near=None, far=None, lindisp: bool = False):
