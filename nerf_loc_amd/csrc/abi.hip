@@ -70,7 +70,7 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
                                int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
                                const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, hipStream_t st);
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, const float* g_vis, const float* g_dd,
-                           float* g_xyz, hipStream_t st);
+                           float* part, float* g_xyz, hipStream_t st);
 int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
                              const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st);
 int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
@@ -805,10 +805,11 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
 }
 
 // ---- input gradients of the multi-view aggregation and of the colour blend (frozen weights) ------------------------------------------
-struct MvBwdBufs { float *vis, *dd, *g393, *t64, *G, *gA, *gt64, *gg393, *gvis, *gdd, *bl1, *rgbv, *blA, *ghA, *gpf, *grgbv, *gang; int* valid_s; };
+struct MvBwdBufs { float *vis, *dd, *g393, *t64, *G, *gA, *gt64, *gg393, *gvis, *gdd, *gpart, *bl1, *rgbv, *blA, *ghA, *gpf, *grgbv, *gang; int* valid_s; };
 void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdBufs& m) {
   const int W = c->W, ldg = ldg_of(c->C);
   m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N); m.gvis = b.take<float>((size_t)V * N); m.gdd = b.take<float>((size_t)V * N);
+  m.gpart = b.take<float>((size_t)V * N * 3);
   m.g393 = b.take<float>((size_t)N * ldg); m.valid_s = b.take<int>((size_t)N);
   if (!blend) {
     m.t64 = b.take<float>((size_t)N * 64); m.G = b.take<float>((size_t)N * W); m.gA = b.take<float>((size_t)N * W);
@@ -849,7 +850,7 @@ int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float
   NL_TRY(run_gemm(xb, G_OUTFC0_T, &st, 1, N, m.gg393, ldg, NL_ACT_NONE));
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, nullptr, xyz, N, m.vis, m.dd, m.gg393, ldg, nullptr, nullptr, nullptr, g_xyz,
                                     nullptr, m.gvis, m.gdd, x32.st));
-  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, g_xyz, x32.st);
+  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
 }
 
 // rgb_s = blend(feature_agg, per-view taps) forward (staged) and its input gradient
@@ -877,7 +878,7 @@ int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const fl
   if (g_FA) NL_TRY(run_gemm(xb, G_BLENDA_T, &sg, 1, N, g_FA, W, NL_ACT_NONE));
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, f->pfeat, xyz, N, m.vis, m.dd, nullptr, ldg_of(f->C), m.gpf, m.grgbv, m.gang, g_xyz,
                                     g_qc, m.gvis, m.gdd, x32.st));
-  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, g_xyz, x32.st);
+  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
 }
 
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and

@@ -689,15 +689,17 @@ __device__ __forceinline__ void decoder_backward(const float* __restrict__ w, co
   }
 }
 
-// One lane per (view, sample): backward of mv_vis_kernel (mvagg.hip).  g_xyz is accumulated with atomics (V lanes per sample).
+// One lane per (view, sample): backward of mv_vis_kernel (mvagg.hip).  Writes the view's contribution to d/d xyz into part (V, N, 3); a second
+// kernel adds the views in a fixed order (no atomics: the gradient is bit-reproducible like the forward).
 __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, const float* __restrict__ visf, const float* __restrict__ dw,
                                                            const float* __restrict__ xyz, int N, const float* __restrict__ g_vis,
-                                                           const float* __restrict__ g_dd, float* __restrict__ g_xyz) {
+                                                           const float* __restrict__ g_dd, float* __restrict__ part) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.y;
   if (n >= N) return;
+  float* po = part + ((size_t)v * N + n) * 3;
   const float gv = g_vis[(size_t)v * N + n], gd = g_dd[(size_t)v * N + n];
-  if (gv == 0.f && gd == 0.f) return;
+  if (gv == 0.f && gd == 0.f) { po[0] = 0.f; po[1] = 0.f; po[2] = 0.f; return; }
   const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
   const float* P = vw.P2[v];
   const float cx = fmaf(P[2], Z, fmaf(P[1], Y, P[0] * X)) + P[3], cy = fmaf(P[6], Z, fmaf(P[5], Y, P[4] * X)) + P[7];
@@ -773,7 +775,15 @@ __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, con
   float gde = g_depth - (gpx * px + gpy * py) / depth;
   if (bad) { gde = 0.f; }   // the depth was replaced by a constant
   const float gX = P[0] * gcx + P[4] * gcy + P[8] * gde, gY = P[1] * gcx + P[5] * gcy + P[9] * gde, gZ = P[2] * gcx + P[6] * gcy + P[10] * gde;
-  atomicAdd(g_xyz + 3 * (size_t)n, gX); atomicAdd(g_xyz + 3 * (size_t)n + 1, gY); atomicAdd(g_xyz + 3 * (size_t)n + 2, gZ);
+  po[0] = gX; po[1] = gY; po[2] = gZ;
+}
+
+__global__ void view_sum_kernel(const float* __restrict__ part, int V, size_t n3, float* __restrict__ g_xyz) {   // g_xyz += sum_v part[v], v ascending
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n3) return;
+  float a = g_xyz[i];
+  for (int v = 0; v < V; ++v) a += part[(size_t)v * n3 + i];
+  g_xyz[i] = a;
 }
 
 // One lane per sample: backward of blend_kernel (heads.hip; model.py:532-538).  hA (N,32) per-sample part of layer 1, h1 (N*V,32) per-(sample, view)
@@ -884,10 +894,11 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
 }
 
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, const float* g_vis, const float* g_dd,
-                           float* g_xyz, hipStream_t st) {
+                           float* part /*(V,N,3) scratch*/, float* g_xyz, hipStream_t st) {
   if (N <= 0) return NL_OK;
   dim3 grid((unsigned)nl_cdiv(N, 256), (unsigned)vw.V);
-  hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, g_xyz);
+  hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, part);
+  hipLaunchKernelGGL(view_sum_kernel, dim3((unsigned)nl_cdiv(3 * N, 256)), dim3(256), 0, st, part, vw.V, (size_t)3 * N, g_xyz);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -244,7 +244,7 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
-    def ray_unet_backward(self, x, g_geo):
+    def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None):
         """Input gradient of `ray_unet` with frozen weights (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W)."""
         if not self._weights_loaded:
             raise RuntimeError("load_weights() first")
@@ -252,17 +252,21 @@ class HipRenderer:
         R = xin.shape[0] // self.S
         gx = torch.empty_like(xin)
         ws = self._workspace(self.lib.nl_ray_unet_backward_workspace_bytes(ct.byref(self.cfg), R))
+        if workspace_rays is not None:
+            ws = ws[: self.lib.nl_ray_unet_backward_workspace_bytes(ct.byref(self.cfg), int(workspace_rays))]
         L.check(self.lib.nl_ray_unet_backward(ct.byref(self.cfg), self.packed.data_ptr(), xin.data_ptr(), R, g.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(),
                                               self._stream()), "nl_ray_unet_backward")
         return gx
 
-    def mv_aggregate_backward(self, xyz, g_mv_feat):
+    def mv_aggregate_backward(self, xyz, g_mv_feat, workspace_samples: Optional[int] = None):
         """Input gradient of `mv_aggregate`'s feature rows with frozen weights / maps (nl_mv_aggregate_backward): -> g_xyz (N,3)."""
         self._ready()
         x, g = _dev_f32(xyz, self.device), _dev_f32(g_mv_feat, self.device)
         N = x.shape[0]
         gx = torch.empty(N, 3, device=self.device)
         ws = self._workspace(self.lib.nl_mv_aggregate_backward_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        if workspace_samples is not None:
+            ws = ws[: self.lib.nl_mv_aggregate_backward_workspace_bytes(ct.byref(self.cfg), self.V, int(workspace_samples))]
         L.check(self.lib.nl_mv_aggregate_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), N, g.data_ptr(), gx.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate_backward")
         return gx
@@ -279,7 +283,7 @@ class HipRenderer:
                                   ws.data_ptr(), ws.numel(), self._stream()), "nl_blend")
         return out
 
-    def blend_backward(self, xyz, query_center, feature_agg, g_rgb_s, want_g_query_center: bool = True):
+    def blend_backward(self, xyz, query_center, feature_agg, g_rgb_s, want_g_query_center: bool = True, workspace_samples: Optional[int] = None):
         """nl_blend_backward: -> (g_xyz (N,3), g_feature_agg (N,W), g_query_center (3,) or None)."""
         self._ready()
         x, fa, g = _dev_f32(xyz, self.device), _dev_f32(feature_agg, self.device), _dev_f32(g_rgb_s, self.device)
@@ -289,11 +293,13 @@ class HipRenderer:
         gfa = torch.empty(N, self.W, device=self.device)
         gq = torch.empty(N, 3, device=self.device) if want_g_query_center else None
         ws = self._workspace(self.lib.nl_blend_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        if workspace_samples is not None:
+            ws = ws[: self.lib.nl_blend_workspace_bytes(ct.byref(self.cfg), self.V, int(workspace_samples))]
         L.check(self.lib.nl_blend_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), fa.data_ptr(), N, g.data_ptr(),
                                            gx.data_ptr(), gfa.data_ptr(), _ptr(gq), ws.data_ptr(), ws.numel(), self._stream()), "nl_blend_backward")
         return gx, gfa, (None if gq is None else gq.sum(0))
 
-    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None):
+    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None, workspace_samples: Optional[int] = None):
         """Input gradient of `point_mlp` with frozen weights (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W)).
         knn = (d2, idx) as `point_mlp` returned them for the same points: saves the second neighbour search."""
         self._ready()
@@ -305,6 +311,8 @@ class HipRenderer:
         gd = None if dr is None else torch.empty(N, 3, device=dev)
         gg = torch.empty(N, self.W, device=dev)
         ws = self._workspace(self.lib.nl_point_mlp_backward_workspace_bytes(ct.byref(self.cfg), N))
+        if workspace_samples is not None:   # (tests: a workspace for fewer samples than N makes the entry point walk N in chunks)
+            ws = ws[: self.lib.nl_point_mlp_backward_workspace_bytes(ct.byref(self.cfg), int(workspace_samples))]
         d2, idx = (None, None) if knn is None else (knn[0].contiguous(), knn[1].to(torch.int32).contiguous())
         L.check(self.lib.nl_point_mlp_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
                                                g.data_ptr(), N, K, _ptr(idx), _ptr(d2), gy.data_ptr(), gx.data_ptr(), _ptr(gd), gg.data_ptr(), ws.data_ptr(),

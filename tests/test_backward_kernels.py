@@ -258,3 +258,25 @@ def test_ray_unet_backward_matches_autograd(case, precision):
     e_hip, e_ref = rel_err(g_hip.cpu().numpy(), g_64.cpu().numpy()), rel_err(g_ref.cpu().numpy(), g_64.cpu().numpy())
     print(case, precision, "g_x hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref)
     assert e_hip < max(1e-4, 3 * e_ref), (e_hip, e_ref)
+
+
+@pytest.mark.gpu
+def test_backward_entry_points_walk_large_batches_in_chunks():
+    """Every backward entry point processes N samples (R rays) in pieces that fit the caller's workspace: a workspace sized for a third of the batch
+    must give the same gradients as one that holds it all (per-sample stages: bit-identical; the support-side atomics are not involved)."""
+    cfg, r, p, fr, xyz, pose = _mv_setup("c1", "bf16x3", R_max=12)
+    N, W, S = xyz.shape[0], cfg.W, cfg.S_total
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(xyz.device)
+    G, cotW, cot3, dirs = rnd(N, W), rnd(N, W), rnd(N, 3), torch.nn.functional.normalize(rnd(N, 3), dim=1)
+    third = N // 3 + 1
+    a = r.point_mlp_backward(xyz, dirs, G, cotW)
+    b = r.point_mlp_backward(xyz, dirs, G, cotW, workspace_samples=third)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(r.mv_aggregate_backward(xyz, cotW), r.mv_aggregate_backward(xyz, cotW, workspace_samples=third))
+    a = r.blend_backward(xyz, pose[:3, 3], G, cot3)
+    b = r.blend_backward(xyz, pose[:3, 3], G, cot3, workspace_samples=third)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and rel_err(b[2].cpu().numpy(), a[2].cpu().numpy()) < 1e-5
+    x = rnd(12 * S, W)
+    assert torch.equal(r.ray_unet_backward(x, cotW[: 12 * S]), r.ray_unet_backward(x, cotW[: 12 * S], workspace_rays=5))
