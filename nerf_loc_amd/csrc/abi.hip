@@ -69,8 +69,8 @@ int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_
 int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
                                int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
                                const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, hipStream_t st);
-int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, const float* g_vis, const float* g_dd,
-                           float* part, float* g_xyz, hipStream_t st);
+int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
+                           const float* g_dd, float* part, float* g_xyz, hipStream_t st);
 int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
                              const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st);
 int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
@@ -850,7 +850,8 @@ int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float
   NL_TRY(run_gemm(xb, G_OUTFC0_T, &st, 1, N, m.gg393, ldg, NL_ACT_NONE));
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, nullptr, xyz, N, m.vis, m.dd, m.gg393, ldg, nullptr, nullptr, nullptr, g_xyz,
                                     nullptr, m.gvis, m.gdd, x32.st));
-  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
+  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
+                                m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
 }
 
 // rgb_s = blend(feature_agg, per-view taps) forward (staged) and its input gradient
@@ -878,7 +879,8 @@ int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const fl
   if (g_FA) NL_TRY(run_gemm(xb, G_BLENDA_T, &sg, 1, N, g_FA, W, NL_ACT_NONE));
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, f->pfeat, xyz, N, m.vis, m.dd, nullptr, ldg_of(f->C), m.gpf, m.grgbv, m.gang, g_xyz,
                                     g_qc, m.gvis, m.gdd, x32.st));
-  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), xyz, N, m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
+  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
+                                m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
 }
 
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and

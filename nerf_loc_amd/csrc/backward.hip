@@ -778,6 +778,189 @@ __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, con
   po[0] = gX; po[1] = gY; po[2] = gZ;
 }
 
+// MFMA version of dec_backward_kernel (non-fp32 modes): rows = (view, sample), 32 rows per wave like mv_vis_mfma_kernel.  Phase 1 decodes the tile
+// (mvd_decode_tile, split-FP16) to get the six outputs the visibility formula's derivative needs; phase 2 walks the four decoders again, keeping each
+// one's two hidden layers in registers (16 + 16 per lane), and multiplies back through the TRANSPOSED weights (bf16 hi / lo fragments packed with K in
+// accumulator order, mvdec.h MVD_T; split-bf16: the incoming gradient's scale is arbitrary, fp16's range is not) into ONE accumulator whose register r
+// holds d/d(channel this lane tapped into register r).  48 + 4 x 24 MFMAs per 32 rows instead of ~40 k FMAs per row.
+__global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw, const float* __restrict__ visf, const uint4* __restrict__ dpack,
+                                                                const float* __restrict__ xyz, int N, int tiles_per_view, int total_tiles,
+                                                                const float* __restrict__ g_vis, const float* __restrict__ g_dd,
+                                                                float* __restrict__ part) {
+  __shared__ uint4 sw[MVD_LDS_UINT4 + 2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, j = lane & 31;
+  mvd_load_lds<true>(sw, dpack, tid, 256);
+  for (int i = tid; i < 2048; i += 256) sw[MVD_LDS_UINT4 + i] = dpack[MVD_T + i];
+  __syncthreads();
+  const uint4* swt = sw + MVD_LDS_UINT4;
+  const float* sf = reinterpret_cast<const float*>(sw + 2048);
+  const float* b1 = sf, *b2 = sf + 128, *w4p = sf + 256;
+  typedef MvdOps<true> OP;
+  const float ni = -1.f / vw.near_, fi = -1.f / vw.far_, span = vw.far_ - vw.near_;
+  for (int tile = blockIdx.x * 4 + wave; tile < total_tiles; tile += gridDim.x * 4) {
+    const int v = __builtin_amdgcn_readfirstlane(tile / tiles_per_view);
+    const int n = (tile - v * tiles_per_view) * 32 + j;
+    const bool live = n < N;
+    const int nn = live ? n : N - 1;
+    float* po = part + ((size_t)v * N + nn) * 3;
+    const float gv = live ? g_vis[(size_t)v * N + nn] : 0.f, gd = live ? g_dd[(size_t)v * N + nn] : 0.f;
+    if (__ballot(gv != 0.f || gd != 0.f) == 0ull) {
+      if (live && hh == 0) { po[0] = 0.f; po[1] = 0.f; po[2] = 0.f; }
+      continue;
+    }
+    const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
+    const float* P = vw.P2[v];
+    const float cx = fmaf(P[2], Z, fmaf(P[1], Y, P[0] * X)) + P[3], cy = fmaf(P[6], Z, fmaf(P[5], Y, P[4] * X)) + P[7];
+    float depth = fmaf(P[10], Z, fmaf(P[9], Y, P[8] * X)) + P[11];
+    const bool bad = fabsf(depth) < 1e-4f;
+    if (bad) depth = 1e-3f;
+    const float px = cx / depth, py = cy / depth;
+    const bool outside = (px < -0.5f) | (px >= (float)vw.Wimg - 0.5f) | (py < -0.5f) | (py >= (float)vw.H - 0.5f);
+    const bool valid = !bad && !outside;
+    // this lane's 16 channels (8 hh .. + 7 and 16 + 8 hh .. + 7) of the tap and of its spatial derivative
+    float x0[8], x1[8], dx[16], dy[16];
+    const float xn = px / (float)(vw.Wimg - 1) * 2.f - 1.f, yn = py / (float)(vw.H - 1) * 2.f - 1.f;
+    const float ixr = (xn + 1.f) * ((float)vw.vw / 2.f) - 0.5f, iyr = (yn + 1.f) * ((float)vw.vh / 2.f) - 0.5f;
+    const bool cxl = !(ixr > 0.f && ixr < (float)(vw.vw - 1)), cyl = !(iyr > 0.f && iyr < (float)(vw.vh - 1));
+    {
+      const TapD d = make_tapd(make_taps<false, true>(xn, yn, vw.vw, vw.vh), vw.vw, vw.vh);
+      const float* base = visf + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+          const int co = 16 * g + 4 * c4;
+          float4 t[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            t[k] = *(const float4*)(base + (size_t)d.o[k] * 32 + co);
+            t[k].x *= d.m[k]; t[k].y *= d.m[k]; t[k].z *= d.m[k]; t[k].w *= d.m[k];
+          }
+          float* xd = g ? x1 : x0;
+          const float w00 = d.s * d.e, w01 = d.s * d.w, w10 = d.n * d.e, w11 = d.n * d.w;
+#define NL_TAPC(C, I)                                                                                  \
+          xd[4 * c4 + I] = valid ? (w00 * t[0].C + w01 * t[1].C) + (w10 * t[2].C + w11 * t[3].C) : 0.f; \
+          dx[8 * g + 4 * c4 + I] = d.s * (t[1].C - t[0].C) + d.n * (t[3].C - t[2].C);                   \
+          dy[8 * g + 4 * c4 + I] = d.e * (t[2].C - t[0].C) + d.w * (t[3].C - t[1].C);
+          NL_TAPC(x, 0) NL_TAPC(y, 1) NL_TAPC(z, 2) NL_TAPC(w, 3)
+#undef NL_TAPC
+        }
+    }
+    float m0, m1, v0, v1, aw, vs;
+    mvd_decode_tile<true>(sw, lane, x0, x1, m0, m1, v0, v1, vs, aw);
+    // ---- derivative of the visibility formula and of the depth difference (as dec_backward_kernel)
+    const float tref = m0 * (fi - ni) + ni;
+    const float refd_raw = -1.f / tref;
+    const float refd = fminf(fmaxf(refd_raw, vw.near_), vw.far_);
+    const float dn = (-1.f / fmaxf(depth, 1e-5f) - ni) / (fi - ni);
+    const float u0 = (dn - m0) * v0, u1 = (dn - m1) * v1;
+    const float th0 = tanhf(u0), th1 = tanhf(u1);
+    const float c0 = (0.5f + 0.5f * th0) * vs, c1 = (0.5f + 0.5f * th1) * vs;
+    const float gvv = valid ? gv : 0.f;
+    const float gc0 = -gvv * aw, gc1 = -gvv * (1.f - aw);
+    const float g_aw = gvv * (c1 - c0);
+    const float g_vs = gc0 * (0.5f + 0.5f * th0) + gc1 * (0.5f + 0.5f * th1);
+    const float gu0 = gc0 * vs * 0.5f * (1.f - th0 * th0), gu1 = gc1 * vs * 0.5f * (1.f - th1 * th1);
+    const float g_dn = gu0 * v0 + gu1 * v1;
+    float g_m0 = -gu0 * v0;
+    const float g_m1 = -gu1 * v1, g_v0 = gu0 * (dn - m0), g_v1 = gu1 * (dn - m1);
+    const float sgn = depth > refd ? 1.f : (depth < refd ? -1.f : 0.f);
+    float g_depth = gd * sgn / span;
+    if (refd_raw > vw.near_ && refd_raw < vw.far_) g_m0 += (-gd * sgn / span) * ((fi - ni) / (tref * tref));
+    if (depth > 1e-5f) g_depth += g_dn / (depth * depth * (fi - ni));
+    // output activations' derivatives from the outputs themselves: softplus' = 1 - exp(-softplus), sigmoid' = y (1 - y)
+    float go[4][2];
+    go[0][0] = g_m0 * (1.f - expf(-m0)); go[0][1] = g_m1 * (1.f - expf(-m1));
+    go[1][0] = g_v0 * (1.f - expf(-(v0 - 0.05f))); go[1][1] = g_v1 * (1.f - expf(-(v1 - 0.05f)));
+    go[2][0] = g_aw * aw * (1.f - aw); go[2][1] = 0.f;
+    go[3][0] = g_vs * vs * (1.f - vs); go[3][1] = 0.f;
+    // ---- phase 2: one decoder at a time, hidden layers kept, transposed products accumulate d/dx
+    OP::v8 xh[2], xl[2];
+    OP::split(x0, xh[0], xl[0]);
+    OP::split(x1, xh[1], xl[1]);
+    mvd_f32x16 gxa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gxa[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      mvd_f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const float4 b = *(const float4*)(b1 + 32 * d + 8 * g + 4 * hh); acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const OP::v8 ah = __builtin_bit_cast(OP::v8, sw[MVD_W1 + (q * 4 + d) * 64 + lane]), al = __builtin_bit_cast(OP::v8, sw[MVD_W1 + 512 + (q * 4 + d) * 64 + lane]);
+        acc = OP::mfma(al, xh[q], acc); acc = OP::mfma(ah, xl[q], acc); acc = OP::mfma(ah, xh[q], acc);
+      }
+      float h1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[r] = nl_elu_fast(acc[r]);
+      OP::v8 gh[2], gl[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) vv[t] = h1[8 * s2 + t];
+        OP::split(vv, gh[s2], gl[s2]); }
+      mvd_f32x16 acc2;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const float4 b = *(const float4*)(b2 + 32 * d + 8 * g + 4 * hh); acc2[4 * g] = b.x; acc2[4 * g + 1] = b.y; acc2[4 * g + 2] = b.z; acc2[4 * g + 3] = b.w; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const OP::v8 ah = __builtin_bit_cast(OP::v8, sw[MVD_W2 + (d * 2 + s2) * 64 + lane]), al = __builtin_bit_cast(OP::v8, sw[MVD_W2 + 512 + (d * 2 + s2) * 64 + lane]);
+        acc2 = OP::mfma(al, gh[s2], acc2); acc2 = OP::mfma(ah, gl[s2], acc2); acc2 = OP::mfma(ah, gh[s2], acc2);
+      }
+      // d/d(hidden 2 pre-activation): output weights (this half's 16 units) x ELU'
+      float ga[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float h2 = nl_elu_fast(acc2[r]);
+        const float g2 = go[d][0] * w4p[((d * 2 + 0) * 2 + hh) * 16 + r] + go[d][1] * w4p[((d * 2 + 1) * 2 + hh) * 16 + r];
+        ga[r] = g2 * (h2 > 0.f ? 1.f : h2 + 1.f);
+      }
+      mvd_bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) vv[t] = ga[8 * s2 + t];
+        mvd_split_bf16(vv, bh[s2], bl[s2]); }
+      mvd_f32x16 accb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const mvd_bf16x8 ah = __builtin_bit_cast(mvd_bf16x8, swt[(d * 2 + s2) * 64 + lane]), al = __builtin_bit_cast(mvd_bf16x8, swt[512 + (d * 2 + s2) * 64 + lane]);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s2], accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s2], accb, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s2], accb, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int r = 8 * s2 + t; vv[t] = accb[r] * (h1[r] > 0.f ? 1.f : h1[r] + 1.f); }
+        mvd_split_bf16(vv, bh[s2], bl[s2]); }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const mvd_bf16x8 ah = __builtin_bit_cast(mvd_bf16x8, swt[1024 + (d * 2 + s2) * 64 + lane]), al = __builtin_bit_cast(mvd_bf16x8, swt[1024 + 512 + (d * 2 + s2) * 64 + lane]);
+        gxa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s2], gxa, 0, 0, 0);
+        gxa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s2], gxa, 0, 0, 0);
+        gxa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s2], gxa, 0, 0, 0);
+      }
+    }
+    float gix = 0.f, giy = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gix = fmaf(gxa[r], dx[r], gix); giy = fmaf(gxa[r], dy[r], giy); }
+    gix += __shfl_xor(gix, 32, 64); giy += __shfl_xor(giy, 32, 64);
+    if (!valid) { gix = 0.f; giy = 0.f; }
+    const float gpx = cxl ? 0.f : gix * (float)vw.vw / (float)(vw.Wimg - 1), gpy = cyl ? 0.f : giy * (float)vw.vh / (float)(vw.H - 1);
+    const float gcx = gpx / depth, gcy = gpy / depth;
+    float gde = g_depth - (gpx * px + gpy * py) / depth;
+    if (bad) gde = 0.f;
+    if (live && hh == 0) {
+      po[0] = P[0] * gcx + P[4] * gcy + P[8] * gde; po[1] = P[1] * gcx + P[5] * gcy + P[9] * gde; po[2] = P[2] * gcx + P[6] * gcy + P[10] * gde;
+    }
+  }
+}
+
 __global__ void view_sum_kernel(const float* __restrict__ part, int V, size_t n3, float* __restrict__ g_xyz) {   // g_xyz += sum_v part[v], v ascending
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n3) return;
@@ -893,11 +1076,17 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
   return NL_OK;
 }
 
-int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const float* xyz, int64_t N, const float* g_vis, const float* g_dd,
-                           float* part /*(V,N,3) scratch*/, float* g_xyz, hipStream_t st) {
+int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
+                           const float* g_dd, float* part /*(V,N,3) scratch*/, float* g_xyz, hipStream_t st) {
   if (N <= 0) return NL_OK;
-  dim3 grid((unsigned)nl_cdiv(N, 256), (unsigned)vw.V);
-  hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, part);
+  if (dpack) {   // non-fp32 modes: the decoders on the matrix pipe
+    const int tpv = (int)nl_cdiv(N, 32), total = tpv * vw.V;
+    const int blocks = (int)(nl_cdiv(total, 4) < 2048 ? nl_cdiv(total, 4) : 2048);
+    hipLaunchKernelGGL(dec_backward_mfma_kernel, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, g_vis, g_dd, part);
+  } else {
+    dim3 grid((unsigned)nl_cdiv(N, 256), (unsigned)vw.V);
+    hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, part);
+  }
   hipLaunchKernelGGL(view_sum_kernel, dim3((unsigned)nl_cdiv(3 * N, 256)), dim3(256), 0, st, part, vw.V, (size_t)3 * N, g_xyz);
   NL_LAUNCH_CHECK();
   return NL_OK;

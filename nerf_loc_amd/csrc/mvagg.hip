@@ -141,6 +141,24 @@ __global__ void pack_mv_decoder_kernel(const float* __restrict__ dec /* packed V
     const int idx = (r & 3) + 8 * (r >> 2) + 4 * hh;
     of[256 + e] = dec[d * DEC_STRIDE + 2112 + u * 32 + idx];
   } else if (i < 8192 + 520) { const int e = i - 8192 - 512; of[512 + e] = dec[(e >> 1) * DEC_STRIDE + 2176 + (e & 1)]; }   // b4
+  // transposed fragments for the input gradient (bf16 hi / lo): element (which, d, s, lane, t), which 0 = W2T, 1 = W1T
+  if (i < 8192) {
+    unsigned short* t16 = reinterpret_cast<unsigned short*>(out + MVD_T);
+    const int which = i >> 12, e = i & 4095;
+    const int t = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1, d = e >> 10;
+    const int u = 16 * s + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);   // K slot -> unit of the layer's OUTPUT side (accumulator order)
+    const int row = lane & 31;
+    float v;
+    if (which == 0) v = dec[d * DEC_STRIDE + 1056 + u * 32 + row];     // W2[u][row]
+    else {
+      const int hh = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);   // the register / half whose accumulator row is `row`
+      const int chan = r < 8 ? 8 * hh + r : 16 + 8 * hh + (r - 8);
+      v = dec[d * DEC_STRIDE + u * 32 + chan];                          // W1[u][chan]
+    }
+    const unsigned short h = f2bf(v);
+    t16[(size_t)which * 1024 * 8 + e] = h;
+    t16[(size_t)which * 1024 * 8 + 512 * 8 + e] = f2bf(v - __uint_as_float(((unsigned)h) << 16));
+  }
 }
 
 // The four tap offsets of one bilinear sample in one register: offset of the (clamped) north-west texel in bits 0-29, whether the

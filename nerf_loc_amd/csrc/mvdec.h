@@ -145,7 +145,12 @@ constexpr int MVD_W2 = 1024;
 constexpr int MVD_F32 = 2048;
 constexpr int MVD_NF32 = (128 + 128 + 256 + 8) / 4;
 constexpr int MVD_F16 = MVD_F32 + MVD_NF32;
-constexpr int MVD_PACK_UINT4 = MVD_F16 + 2048;   // global image
+// [MVD_T, MVD_T + 2048): TRANSPOSED layer-2 / layer-1 fragments in bf16 hi / lo for the decoders' input gradient (backward.hip):
+//   W2T [part 2][d 4][s 2][lane 64] at +0 (1024 uint4): A row = hidden-1 unit, K = hidden-2 units in accumulator order
+//   W1T [part 2][d 4][s 2][lane 64] at +1024: A row i = the INPUT CHANNEL that the tap code keeps in register r of half hh with m(r, hh) = i
+//       (channels 8 hh + r for r < 8, 16 + 8 hh + r - 8 otherwise), K = hidden-1 units in accumulator order
+constexpr int MVD_T = MVD_F16 + 2048;
+constexpr int MVD_PACK_UINT4 = MVD_T + 2048;   // global image
 constexpr int MVD_LDS_UINT4 = 2048 + MVD_NF32;   // what a kernel keeps in LDS: ONE set of fragments + the floats
 
 // copies the fragments the kernel's mode needs + the float block into LDS (all threads of the block; caller syncs)
@@ -173,6 +178,11 @@ template <> struct MvdOps<false> {
   }
   static __device__ __forceinline__ mvd_f32x16 mfma(v8 a, v8 b, mvd_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
+
+__device__ __forceinline__ void mvd_split_bf16(const float (&v)[8], mvd_bf16x8& hi, mvd_bf16x8& lo) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { const __bf16 h = (__bf16)v[t]; hi[t] = h; lo[t] = (__bf16)(v[t] - (float)h); }
+}
 
 // this lane's 16 channels of the bilinear (border, align_corners = False) tap of the channels-last 32-channel visibility map at
 // pixel (px, py) of view `base`; zero when !valid (depth_fusion.py:60-76, neuray_ops.py:14-36)

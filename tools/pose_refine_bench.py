@@ -24,7 +24,7 @@ uv, K = t(rays["pixel_coordinates"][sel]), t(rays["K"])
 lin = torch.linspace(0, 1, cfg.S, device=dev)
 z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, cfg.S).contiguous()
 pose = t(frame["pose"]).clone().requires_grad_(True)
-tf = torch.randn(R, cfg.C, device=dev)
+tf = torch.randn(R, cfg.C, generator=torch.Generator().manual_seed(0)).to(dev)
 knn = lambda q: r.knn(q, 8)[1]
 
 def step(frozen):
