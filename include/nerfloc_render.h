@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NL_ABI_VERSION 3   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
+#define NL_ABI_VERSION 4   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
                             * reserved fields validated, side stream owned by the nl_frame */
 #define NL_MAX_VIEWS 16
 #define NL_KNN_MAX_K 8
@@ -275,6 +275,29 @@ size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N);
 int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, const float* dir, int64_t dir_stride,
                           const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
                           float* g_dir, float* g_mv_feat, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- training: weight gradients (compute_render_loss, conditional_nerf/model.py:641-685) ----------------------------
+ * The *_train variants of the backward entry points do everything their frozen-weight counterparts do and, in the same pass over the
+ * recomputed activations, ADD the gradients of the stage's parameters (and of the per-frame tables the stage reads) into caller-owned
+ * buffers: the caller zero-fills them once per step, every call — and every workspace chunk inside a call — accumulates.  Weight
+ * gradients are reduced in a fixed order (split-K partial tiles, no atomics); the table gradients are scatter-adds (atomics, like
+ * index_add / grid_sample's backward in the reference's autograd).  `packed` must hold the CURRENT weights (nl_pack_weights after every
+ * optimizer step: ~0.5 ms). */
+typedef struct nl_train_grads {
+  float* const* weights;     /* HOST array of nl_num_weights() DEVICE pointers, tensor i laid out like state_dict[nl_weight_name(i)];
+                              * NULL entries (and a NULL array) = that gradient is not wanted */
+  float* support_feature;    /* (M, C+3) gradient of the support table's features (knn_gather's backward), or NULL */
+  void* scratch;             /* split-K partial tiles: nl_train_scratch_bytes(cfg) */
+  size_t scratch_bytes;
+  int32_t reserved[8];       /* must be 0 */
+} nl_train_grads;
+size_t nl_train_scratch_bytes(const nl_config* cfg);
+/* nl_point_mlp_backward + gradients of ray_diff_fc.*, base_mlp.*, base_mlp_attn.{w_qs, w_ks, w_vs, fc, layer_norm}.* and of the support
+ * features.  (base_mlp_agg_weight's gradient is identically zero: its softmax runs over K identical rows, model.py:415-427.) */
+size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t N);
+int nl_point_mlp_backward_train(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, const float* dir, int64_t dir_stride,
+                                const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg,
+                                float* g_xyz, float* g_dir, float* g_mv_feat, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* Input gradient of nl_mv_aggregate's feature rows (rows a4-a7; multiview_aggregator.py:156-222, ibrnet.py:169-231, visibility_decoder.py:64-148)
  * with frozen weights and frozen support maps: g_mv_feat (N,W) -> g_xyz (N,3).  The forward is recomputed in exact fp32; the way back goes through

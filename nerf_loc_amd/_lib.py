@@ -23,7 +23,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 MAX_VIEWS = 16
 RENDER_NO_SIDE_STREAM = 1   # nl_render_opts.flags
-ABI_VERSION = 3   # include/nerfloc_render.h: NL_ABI_VERSION
+ABI_VERSION = 4   # include/nerfloc_render.h: NL_ABI_VERSION
 
 
 class NlConfig(C.Structure):
@@ -50,6 +50,11 @@ class NlRenderOut(C.Structure):
 
 class NlRenderOpts(C.Structure):
     _fields_ = [("early_term_eps", C.c_float), ("flags", C.c_uint32), ("ray_centers", C.c_void_p), ("reserved", C.c_int32 * 4)]
+
+
+class NlTrainGrads(C.Structure):
+    _fields_ = [("weights", C.POINTER(C.c_void_p)), ("support_feature", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+                ("reserved", C.c_int32 * 8)]
 
 
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)
@@ -90,6 +95,9 @@ SYMBOLS = [
     ("nl_composite_backward", _I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    ("nl_train_scratch_bytes", _Z, [_CFG]),
+    ("nl_point_mlp_backward_train_workspace_bytes", _Z, [_CFG, _L]),
+    ("nl_point_mlp_backward_train", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_mv_aggregate_backward_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_mv_aggregate_backward", _I, [_CFG, _P, _P, _P, _L, _P, _P, _P, _Z, _P]),
     ("nl_blend_workspace_bytes", _Z, [_CFG, _I, _L]),

@@ -215,6 +215,9 @@ class ConditionalNeRF(nn.Module):
         self._renderers: Dict[str, HipRenderer] = {}
         self._frame_token: Dict[str, object] = {}
         self._weights_version = -1
+        # training steps (compute_render_loss): the stages whose weight gradients the library computes run as HIP autograd nodes
+        # (diff_render.*TrainFn); False = the all-eager fp32 graph
+        self.hip_training = True
 
     # ------------------------------------------------------------------ HIP plumbing
     def _renderer(self, level: str) -> HipRenderer:
@@ -523,7 +526,8 @@ class ConditionalNeRF(nn.Module):
         out = diff_render.render_rays_diff(p, fr, o, d, z.to(o.dtype), data["pose"], lambda q: r.knn(q, 8)[1],
                                            white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
                                            beta=train and bool(self.args.render.use_render_uncertainty),
-                                           frozen_renderer=None if train else r)   # eval: weights + support table are constants -> HIP backward of the point branch
+                                           frozen_renderer=None if train else r,   # eval: weights + support table are constants -> HIP backward of the point branch
+                                           train_renderer=r if train and self.hip_training else None)
         if not self.args.render.render_feature:
             out.pop("feat")
         if depth_coarse is not None:

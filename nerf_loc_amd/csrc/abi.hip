@@ -61,8 +61,13 @@ int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, co
                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 // backward.hip: glue kernels of the neural-point branch's input gradient
+int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
+                    float* gb, float* scratch, size_t scratch_floats, hipStream_t st);
+size_t nl_wgrad_scratch_floats(int64_t rows, int M, int N);
+int nl_launch_colsum(const float* Y, int ldy, int64_t rows, int M, float* out, float* scratch, hipStream_t st);
+int nl_launch_sp_feat_scatter(const float* gXF, int ld, int F, const int* idx, int64_t N, int K, int64_t M, float* g_sp_feat, hipStream_t st);
 int nl_launch_ln_agg_backward(const float* FC, const float* G, const float* gy, int64_t N, int W, const float* gamma, float eps, const float* wscale, float* gx,
-                              hipStream_t st);
+                              float* aff, hipStream_t st);
 int nl_launch_attn_backward(const float* Q, const float* KV, const float* gO, int64_t N, int K, float* gQ, float* gKV, hipStream_t st);
 int nl_launch_lrelu_mask(float* g, const float* h, size_t n, hipStream_t st);
 int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t st);
@@ -79,7 +84,7 @@ int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, con
 int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, int ldo, int64_t rows, int cols, hipStream_t st);
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
-                                    float* g_dir, hipStream_t st);
+                                    float* g_dir, float* tr, hipStream_t st);
 
 namespace {
 
@@ -129,6 +134,7 @@ enum {
   G_FC_T, G_Q_T, G_KV_T, G_BASE4_T, G_BASE2_T, G_BASE0_T,   // transposed weights: input gradients of the neural-point branch (do_point_backward)
   G_OUTFC2_T, G_OUTFC0_T, G_BLENDA_T,                         // ... of the multi-view aggregation's out_fc and of the blend's per-sample projection
   G_UB_OUTA, G_UB_OUTB, G_UB_T1, G_UB_T2, G_UB_T3, G_UB_C3, G_UB_C2, G_UB_C1,   // ... of the ray U-Net's seven convolutions (do_unet_backward)
+  G_BASE0_TF,                                                                    // training: base_mlp.0 towards its support-feature columns
   G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
@@ -202,6 +208,7 @@ Layout make_layout(const nl_config* c) {
   set(G_BASE4_T, W, W, false);
   set(G_BASE2_T, W, W, false);
   set(G_BASE0_T, W, 96, false);
+  set(G_BASE0_TF, W, F, false);
   set(G_OUTFC2_T, W, 64, false);
   set(G_OUTFC0_T, 64, (int)nl_align_up(2 * F + 3, 32), false);   // = ldg_of(C): the statistics row incl. its zero padding (416 columns: generic kernels)
   set(G_BLENDA_T, 32, W, false);
@@ -738,8 +745,15 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
 }
 
 // ---- input gradient of the neural-point branch (frozen weights) ---------------------------------------------------------------------
-struct PtBwdBufs { int* idx; float *d2, *X, *H1, *H2, *H3, *KV, *Q, *O, *FCo, *wscale, *gpre, *gO, *gQ, *gKV, *gA, *gB, *gX; };
-void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p) {
+// Where a training step's backward calls ADD the gradients of the weights and of the per-frame tables (nl_train_grads, resolved)
+struct TrainOut {
+  float* w[kNumWeights];
+  float* sp_feat;
+  float* scratch; size_t scratch_floats;
+};
+inline int ldf_of(int C) { return (int)nl_align_up(C + 3, 32); }
+struct PtBwdBufs { int* idx; float *d2, *X, *H1, *H2, *H3, *KV, *Q, *O, *FCo, *wscale, *gpre, *gO, *gQ, *gKV, *gA, *gB, *gX, *aff, *tr, *gXF; };
+void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p, bool train = false) {
   const int W = c->W;
   const size_t NK = (size_t)N * K;
   p.idx = b.take<int>(NK); p.d2 = b.take<float>(NK);
@@ -749,6 +763,8 @@ void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p) {
   p.Q = b.take<float>((size_t)N * 128); p.O = b.take<float>((size_t)N * 128); p.FCo = b.take<float>((size_t)N * W); p.wscale = b.take<float>((size_t)N);
   p.gpre = b.take<float>((size_t)N * W); p.gO = b.take<float>((size_t)N * 128); p.gQ = b.take<float>((size_t)N * 128);
   p.gKV = b.take<float>(NK * 256); p.gA = b.take<float>(NK * W); p.gB = b.take<float>(NK * W); p.gX = b.take<float>(NK * 96);
+  p.aff = p.tr = p.gXF = nullptr;
+  if (train) { p.aff = b.take<float>((size_t)N * 2 * W); p.tr = b.take<float>(NK * 68); p.gXF = b.take<float>(NK * ldf_of(c->C)); }
 }
 
 // dX = (dY . W) * LeakyReLU'(h): the mask inside the streaming GEMM's epilogue where that kernel runs, a separate pass otherwise (fp32 mode)
@@ -766,8 +782,15 @@ int gemm_lrelu_masked(const Ctx& x, int g, const SegSpec& s, int64_t M, float* o
 // posenc / ray_diff_fc -> g_xyz, g_dir}}.  The aggregation scale sum_k w_k is a constant of the backward pass: it is identically 1 (or 0)
 // whatever the distances are (model.py:419-427 normalises the weights; the K rows they multiply are identical, see point.hip).
 int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
-                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in = nullptr, const float* d2_in = nullptr) {
+                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in = nullptr, const float* d2_in = nullptr,
+                      const TrainOut* tg = nullptr) {
   const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
+  // training: gW += dY^T X right after each dY exists (its buffer is reused by the next layer's)
+  auto wg = [&](int tw, int tb, const float* dY, int ldy, int Mo, const float* X, int ldxx, int Ni, int64_t rows) -> int {
+    if (!tg || (!tg->w[tw] && (tb < 0 || !tg->w[tb]))) return NL_OK;
+    if (!tg->w[tw]) return nl_launch_colsum(dY, ldy, rows, Mo, tg->w[tb], tg->scratch, x.st);
+    return nl_launch_wgrad(dY, ldy, Mo, X, ldxx, Ni, rows, 0, 0, tg->w[tw], Ni, 1, 0, tb >= 0 ? tg->w[tb] : nullptr, tg->scratch, tg->scratch_floats, x.st);
+  };
   const int64_t NK = N * K;
   const float inv_span = 1.f / (f->views.far_ - f->views.near_);
   const int64_t M = f->M;
@@ -787,20 +810,42 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
   NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
   NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE));
   // ---- backward
-  NL_TRY(nl_launch_ln_agg_backward(p.FCo, G, gFA, N, W, x.p<float>(x.L.ln_g), 1e-6f, p.wscale, p.gpre, x.st));
+  const bool aff = tg && (tg->w[T_LNW] || tg->w[T_LNB]);
+  NL_TRY(nl_launch_ln_agg_backward(p.FCo, G, gFA, N, W, x.p<float>(x.L.ln_g), 1e-6f, p.wscale, p.gpre, aff ? p.aff : nullptr, x.st));
+  if (aff) {
+    if (tg->w[T_LNW]) NL_TRY(nl_launch_colsum(p.aff, 2 * W, N, W, tg->w[T_LNW], tg->scratch, x.st));
+    if (tg->w[T_LNB]) NL_TRY(nl_launch_colsum(p.aff + W, 2 * W, N, W, tg->w[T_LNB], tg->scratch, x.st));
+  }
+  NL_TRY(wg(T_FC, -1, p.gpre, W, W, p.O, 128, 128, N));
   SegSpec sp{p.gpre, W, W, 0, 1}, sgq{p.gQ, 128, 128, 0, 1}, skv{p.gKV, 256, 256, 0, 1}, sa{p.gA, W, W, 0, 1}, sb{p.gB, W, W, 0, 1};
   NL_TRY(run_gemm(xb, G_FC_T, &sp, 1, N, p.gO, 128, NL_ACT_NONE));
   NL_TRY(nl_launch_attn_backward(p.Q, p.KV, p.gO, N, K, p.gQ, p.gKV, x.st));
+  NL_TRY(wg(T_WQ, -1, p.gQ, 128, 128, G, W, W, N));
+  NL_TRY(wg(T_WK, -1, p.gKV, 256, 128, p.H3, W, W, NK));
+  NL_TRY(wg(T_WV, -1, p.gKV + 128, 256, 128, p.H3, W, W, NK));
   if (g_G) {   // residual path + query projection
     NL_TRY(run_gemm(xb, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
     NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
   }
   NL_TRY(gemm_lrelu_masked(xb, G_KV_T, skv, NK, p.gA, W, p.H3));
+  NL_TRY(wg(T_B4W, T_B4B, p.gA, W, W, p.H2, W, W, NK));
   NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2));
+  NL_TRY(wg(T_B2W, T_B2B, p.gB, W, W, p.H1, W, W, NK));
   NL_TRY(gemm_lrelu_masked(xb, G_BASE2_T, sb, NK, p.gA, W, p.H1));
+  NL_TRY(wg(T_B0W, T_B0B, p.gA, W, W, p.X, ldx, F + 90, NK));
   NL_TRY(run_gemm(xb, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
+  const bool rdw = tg && (tg->w[T_RD0W] || tg->w[T_RD0B] || tg->w[T_RD2W] || tg->w[T_RD2B]);
   NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, 1, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
-                                         g_dir, x.st));
+                                         g_dir, rdw ? p.tr : nullptr, x.st));
+  if (rdw) {   // ray_diff_fc (model.py:36-39): rows [input 4 | hidden 16 | d hidden 16 | d output 32]
+    NL_TRY(wg(T_RD2W, T_RD2B, p.tr + 36, 68, 27, p.tr + 4, 68, 16, NK));
+    NL_TRY(wg(T_RD0W, T_RD0B, p.tr + 20, 68, 16, p.tr, 68, 4, NK));
+  }
+  if (tg && tg->sp_feat) {   // the gathered support features (columns 0 .. F-1 of the encoded rows)
+    const int ldf = ldf_of(f->C);
+    NL_TRY(run_gemm(xb, G_BASE0_TF, &sa, 1, NK, p.gXF, ldf, NL_ACT_NONE));
+    NL_TRY(nl_launch_sp_feat_scatter(p.gXF, ldf, F, idx, N, K, M, tg->sp_feat, x.st));
+  }
   return NL_OK;
 }
 
@@ -1166,6 +1211,12 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
                        (float*)((char*)packed + L.b32[G_BASE0_T]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_T]),
                        (unsigned short*)((char*)packed + L.blo[G_BASE0_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_T]), nl_tgemm_nrt(d.N), 0);
   }
+  {
+    const GemmDim& d = L.g[G_BASE0_TF];   // columns 0 .. F-1 of base_mlp.0.weight
+    hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(W * F, 256)), dim3(256), 0, st, t[T_B0W], 0, 1, F + 90, W, F, 0,
+                       (float*)((char*)packed + L.b32[G_BASE0_TF]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_TF]),
+                       (unsigned short*)((char*)packed + L.blo[G_BASE0_TF]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_TF]), nl_tgemm_nrt(d.N), 0);
+  }
   P.block(G_OUTFC2_T, 0, t[T_OUT2W], 0, 1, 64, W);
   {
     const GemmDim& d = L.g[G_OUTFC0_T];   // out_fc.0.weight (64, 2F + 3): element [k = o][n = i]; no streaming layout (N > 256)
@@ -1377,7 +1428,18 @@ static void make_bwd_ctx(BwdCtx& B, const nl_config* cfg, const void* packed, vo
   B.x32 = make_ctx(&B.c32, packed, stream); B.xb = make_ctx(&B.cbw, packed, stream);
 }
 
-static size_t point_bwd_bytes(const nl_config* cfg, int64_t n) { Bump b{nullptr, 0}; PtBwdBufs p; carve_ptb(b, cfg, n, 8, p); return b.off; }
+static size_t point_bwd_bytes(const nl_config* cfg, int64_t n, bool train = false) { Bump b{nullptr, 0}; PtBwdBufs p; carve_ptb(b, cfg, n, 8, p, train); return b.off; }
+// nl_train_grads -> TrainOut (validated)
+static int resolve_train(const nl_config* cfg, const nl_train_grads* g, TrainOut& t) {
+  memset(&t, 0, sizeof(t));
+  if (!g) return NL_OK;
+  for (int i = 0; i < 8; ++i) if (g->reserved[i] != 0) return NL_ERR_BAD_ARG;
+  if (g->weights) for (int i = 0; i < kNumWeights; ++i) t.w[i] = g->weights[i];
+  t.sp_feat = g->support_feature;
+  if (!g->scratch || g->scratch_bytes < nl_train_scratch_bytes(cfg) || ((uintptr_t)g->scratch & 15)) return NL_ERR_WORKSPACE;
+  t.scratch = (float*)g->scratch; t.scratch_floats = g->scratch_bytes / sizeof(float);
+  return NL_OK;
+}
 
 size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N) {
   if (!cfg_ok(cfg)) return 0;
@@ -1385,13 +1447,35 @@ size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N) {
   return point_bwd_bytes(cfg, n);
 }
 
+size_t nl_train_scratch_bytes(const nl_config* cfg) {
+  if (!cfg_ok(cfg)) return 0;
+  const int F = cfg->C + 3;
+  // the largest weight the split-K kernel is asked for: conv_out (W, 3 (W + 32)) is done one tap at a time -> W x (W + 32); out_fc.0 64 x (2F + 3); base_mlp.0 W x (F + 90)
+  size_t mx = (size_t)cfg->W * (F + 90);
+  if ((size_t)64 * (2 * F + 3) > mx) mx = (size_t)64 * (2 * F + 3);
+  return sizeof(float) * nl_wgrad_scratch_floats(0, 1, (int)(mx + 256));
+}
+size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t N) {
+  if (!cfg_ok(cfg)) return 0;
+  const int64_t n = N < 1 ? 1 : (N > (1 << 15) ? (1 << 15) : N);
+  return point_bwd_bytes(cfg, n, true);
+}
 int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
                           const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
                           float* g_dir, float* g_mv_feat, void* ws, size_t ws_bytes, void* stream) {
+  return nl_point_mlp_backward_train(cfg, packed, f, xyz, dir, dir_stride, mv_feat, N, K, knn_idx, knn_d2, g_feature_agg, g_xyz, g_dir, g_mv_feat, nullptr, ws,
+                                     ws_bytes, stream);
+}
+int nl_point_mlp_backward_train(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
+                                const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
+                                float* g_dir, float* g_mv_feat, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
-  if (ws_bytes < point_bwd_bytes(cfg, 1)) return NL_ERR_WORKSPACE;
+  const bool train = grads != nullptr;
+  TrainOut T;
+  NL_TRY(resolve_train(cfg, grads, T));
+  if (ws_bytes < point_bwd_bytes(cfg, 1, train)) return NL_ERR_WORKSPACE;
   // Precision of the two halves (measured):
   //  * the RECOMPUTED FORWARD must be much better than split-bf16: the derivative of a LeakyReLU network is piecewise constant, and a forward that
   //    is 1e-5 off flips the sign of a few pre-activations near zero — every flip changes that neighbour row's gradient by a few percent (2e-2 in
@@ -1401,7 +1485,7 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
   int64_t lo = 1, hi = N;
   while (lo < hi) {   // largest sample chunk whose buffers fit the workspace
     const int64_t mid = (lo + hi + 1) / 2;
-    if (point_bwd_bytes(cfg, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
+    if (point_bwd_bytes(cfg, mid, train) <= ws_bytes) lo = mid; else hi = mid - 1;
   }
   const int64_t NC = lo < (1 << 17) ? lo : (1 << 17);
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
@@ -1409,10 +1493,10 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
   const int W = cfg->W;
   for (int64_t n0 = 0; n0 < N; n0 += NC) {
     const int64_t nc = N - n0 < NC ? N - n0 : NC;
-    Bump b{(char*)ws, 0}; PtBwdBufs p; carve_ptb(b, cfg, nc, 8, p);
+    Bump b{(char*)ws, 0}; PtBwdBufs p; carve_ptb(b, cfg, nc, 8, p, train);
     NL_TRY(do_point_backward(xb, xf, f, xyz + 3 * n0, dir ? dir + dir_stride * n0 : nullptr, (int)dir_stride, mv_feat + n0 * W, nc, K, g_feature_agg + n0 * W,
                              g_xyz + 3 * n0, g_dir ? g_dir + 3 * n0 : nullptr, g_mv_feat ? g_mv_feat + n0 * W : nullptr, p,
-                             knn_idx ? knn_idx + n0 * K : nullptr, knn_d2 ? knn_d2 + n0 * K : nullptr));
+                             knn_idx ? knn_idx + n0 * K : nullptr, knn_d2 ? knn_d2 + n0 * K : nullptr, train ? &T : nullptr));
   }
   return NL_OK;
 }

@@ -184,7 +184,7 @@ namespace {
 template <int WPL>
 __global__ __launch_bounds__(256) void ln_agg_backward_kernel(const float* __restrict__ FC, const float* __restrict__ G, const float* __restrict__ gy, int N, int W,
                                                               const float* __restrict__ gamma, float eps, const float* __restrict__ wscale,
-                                                              float* __restrict__ gx) {
+                                                              float* __restrict__ gx, float* __restrict__ aff /* (N, 2W) [gy sc xhat | gy sc] or null */) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -211,6 +211,13 @@ __global__ __launch_bounds__(256) void ln_agg_backward_kernel(const float* __res
   for (int j = 0; j < WPL; ++j) {
     const int c = lane + 64 * j;
     if (c < W) gx[(size_t)n * W + c] = rstd * (g[j] - m1 - x[j] * m2);
+  }
+  if (aff) {   // training: the rows whose column sums are d/d gamma and d/d beta
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < W) { const float gs = gy[(size_t)n * W + c] * sc; aff[(size_t)n * 2 * W + c] = gs * x[j]; aff[(size_t)n * 2 * W + W + c] = gs; }
+    }
   }
 }
 
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
                                                                     int N, int K, int M, const int* __restrict__ idx, const float* __restrict__ sp_xyz,
                                                                     const float* __restrict__ sp_dir, const float* __restrict__ rd_w, float inv_span,
                                                                     const float* __restrict__ gX, int ldg, float* __restrict__ g_xyz,
-                                                                    float* __restrict__ g_dir) {
+                                                                    float* __restrict__ g_dir, float* __restrict__ tr /* training: (N*K, 68) or null */) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
       gx0 += ax == 0 ? t : 0.f; gx1 += ax == 1 ? t : 0.f; gx2 += ax == 2 ? t : 0.f;
     }
     // ---- ray_diff_fc (4 -> 16 -> 27, LeakyReLU after both): lane j < 16 owns hidden unit j, lane l < 27 output l; values cross lanes by readlane
-    if (dir) {   // (wave-uniform)
+    if (dir || tr) {   // (wave-uniform)
       const float ndx = have ? sp_dir[4 * (size_t)i] : 0.f, ndy = have ? sp_dir[4 * (size_t)i + 1] : 0.f, ndz = have ? sp_dir[4 * (size_t)i + 2] : 0.f;
       const float rr0 = dx - ndx, rr1 = dy - ndy, rr2 = dz - ndz;
       const float nrm = sqrtf(rr0 * rr0 + rr1 * rr1 + rr2 * rr2), nr = nrm + 1e-8f;
@@ -348,6 +355,12 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
       gd0 += gr0 / nr - rr0 * cc + gr3 * ndx;   // (the same value in every lane: not reduced)
       gd1 += gr1 / nr - rr1 * cc + gr3 * ndy;
       gd2 += gr2 / nr - rr2 * cc + gr3 * ndz;
+      if (tr) {   // rows for ray_diff_fc's weight gradients: [input 4 | hidden 16 | d hidden 16 | d output 32 (27 used)]
+        float* t = tr + ((size_t)n * K + k) * 68;
+        if (lane < 4) t[lane] = lane == 0 ? r0 : lane == 1 ? r1 : lane == 2 ? r2 : r3;
+        if (lane < 16) { t[4 + lane] = hj; t[20 + lane] = ga1; }
+        if (lane < 32) t[36 + lane] = ga2;
+      }
     }
   }
   gx0 = wave_sum(gx0); gx1 = wave_sum(gx1); gx2 = wave_sum(gx2);
@@ -357,15 +370,67 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
   }
 }
 
+// training: gradient of the gathered support features (knn_gather's backward, knn_utils.py:211-233 = index_add): one wave per (sample, neighbour) row
+__global__ __launch_bounds__(256) void sp_feat_scatter_kernel(const float* __restrict__ gXF, int ld, int F, const int* __restrict__ idx, long long NK, int K, int M,
+                                                              float* __restrict__ g_sp_feat) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= NK) return;
+  if ((int)(row % K) >= M) return;   // zero-filled neighbour
+  const int i = idx[row];
+  for (int c = lane; c < F; c += 64) atomicAdd(g_sp_feat + (size_t)i * F + c, gXF[(size_t)row * ld + c]);
+}
+
+// column sums of a (rows, M) matrix, coalesced: block = 64 columns x 4 row phases over one slab of rows; part[slab][M]
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ Y, int ldy, long long rows, int M, long long slab, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * slab, r1 = min(rows, r0 + slab);
+  float s = 0.f;
+  if (c < M)
+    for (long long r = r0 + ph; r < r1; r += 4) s += Y[(size_t)r * ldy + c];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < M) part[(size_t)blockIdx.y * M + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nslab, int M, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= M) return;
+  float s = 0.f;
+  for (int z = 0; z < nslab; ++z) s += part[(size_t)z * M + c];
+  out[c] += s;
+}
+
 }  // namespace
 
+// out (M) += column sums of Y (rows, M; ld ldy); scratch: 256 * M floats
+int nl_launch_colsum(const float* Y, int ldy, int64_t rows, int M, float* out, float* scratch, hipStream_t st) {
+  if (rows <= 0 || M <= 0) return NL_OK;
+  int nslab = (int)(nl_cdiv(rows, 64) < 256 ? nl_cdiv(rows, 64) : 256);
+  const long long slab = nl_cdiv(rows, nslab);
+  nslab = (int)nl_cdiv(rows, slab);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)nl_cdiv(M, 64), (unsigned)nslab), dim3(256), 0, st, Y, ldy, (long long)rows, M, slab, scratch);
+  NL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nl_cdiv(M, 256)), dim3(256), 0, st, scratch, nslab, M, out);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_sp_feat_scatter(const float* gXF, int ld, int F, const int* idx, int64_t N, int K, int64_t M, float* g_sp_feat, hipStream_t st) {
+  if (N <= 0 || M <= 0) return NL_OK;
+  hipLaunchKernelGGL(sp_feat_scatter_kernel, dim3((unsigned)nl_cdiv(N * K, 4)), dim3(256), 0, st, gXF, ld, F, idx, (long long)(N * K), K,
+                     (int)(M > 0x7fffffff ? 0x7fffffff : M), g_sp_feat);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
 int nl_launch_ln_agg_backward(const float* FC, const float* G, const float* gy, int64_t N, int W, const float* gamma, float eps, const float* wscale, float* gx,
-                              hipStream_t st) {
+                              float* aff, hipStream_t st) {
   if (N <= 0) return NL_OK;
   dim3 grid((unsigned)nl_cdiv(N, 4));
-  if (W <= 64) hipLaunchKernelGGL(ln_agg_backward_kernel<1>, grid, dim3(256), 0, st, FC, G, gy, (int)N, W, gamma, eps, wscale, gx);
-  else if (W <= 128) hipLaunchKernelGGL(ln_agg_backward_kernel<2>, grid, dim3(256), 0, st, FC, G, gy, (int)N, W, gamma, eps, wscale, gx);
-  else if (W <= 256) hipLaunchKernelGGL(ln_agg_backward_kernel<4>, grid, dim3(256), 0, st, FC, G, gy, (int)N, W, gamma, eps, wscale, gx);
+  if (W <= 64) hipLaunchKernelGGL(ln_agg_backward_kernel<1>, grid, dim3(256), 0, st, FC, G, gy, (int)N, W, gamma, eps, wscale, gx, aff);
+  else if (W <= 128) hipLaunchKernelGGL(ln_agg_backward_kernel<2>, grid, dim3(256), 0, st, FC, G, gy, (int)N, W, gamma, eps, wscale, gx, aff);
+  else if (W <= 256) hipLaunchKernelGGL(ln_agg_backward_kernel<4>, grid, dim3(256), 0, st, FC, G, gy, (int)N, W, gamma, eps, wscale, gx, aff);
   else return NL_ERR_UNSUPPORTED;
   NL_LAUNCH_CHECK();
   return NL_OK;
@@ -394,10 +459,10 @@ int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_
 
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
-                                    float* g_dir, hipStream_t st) {
+                                    float* g_dir, float* tr, hipStream_t st) {
   if (N <= 0) return NL_OK;
   hipLaunchKernelGGL(point_encode_backward_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, xyz, dir, dir_stride, dir_div > 0 ? dir_div : 1, (int)N, K,
-                     (int)(M > 0x7fffffff ? 0x7fffffff : M), idx, sp_xyz, sp_dir, rd_w, inv_span, gX, ldg, g_xyz, dir ? g_dir : nullptr);
+                     (int)(M > 0x7fffffff ? 0x7fffffff : M), idx, sp_xyz, sp_dir, rd_w, inv_span, gX, ldg, g_xyz, dir ? g_dir : nullptr, tr);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -120,6 +120,39 @@ class PointBranchFn(torch.autograd.Function):
         return gx, gd, gg, None, None
 
 
+POINT_PARAMS = ("ray_diff_fc.0.weight", "ray_diff_fc.0.bias", "ray_diff_fc.2.weight", "ray_diff_fc.2.bias",
+                "base_mlp.0.weight", "base_mlp.0.bias", "base_mlp.2.weight", "base_mlp.2.bias", "base_mlp.4.weight", "base_mlp.4.bias",
+                "base_mlp_attn.w_qs.weight", "base_mlp_attn.w_ks.weight", "base_mlp_attn.w_vs.weight", "base_mlp_attn.fc.weight",
+                "base_mlp_attn.layer_norm.weight", "base_mlp_attn.layer_norm.bias")
+
+
+class PointBranchTrainFn(torch.autograd.Function):
+    """PointBranchFn for a TRAINING step (compute_render_loss, model.py:641-685): the same HIP forward, and a backward that also delivers the
+    gradients of the branch's 16 parameter tensors and of the support table's features (nl_point_mlp_backward_train: weight gradients as
+    split-K products over the recomputed activations, in the same pass as the input gradients).  `renderer` holds the CURRENT values of
+    `params` (POINT_PARAMS order) and of the support table; the tensors are passed so that autograd knows where the gradients go.
+    base_mlp_agg_weight and the neighbours' confidences get no gradient: it is identically zero (the softmax / the normalisation run over K
+    identical rows, model.py:415-427)."""
+
+    @staticmethod
+    def forward(ctx, xyz, dirs, G, sp_feature, renderer, K, *params):
+        xyz, G = xyz.contiguous(), G.contiguous()
+        dirs = None if dirs is None else dirs.contiguous()
+        ctx.r, ctx.K, ctx.has_dir = renderer, int(K), dirs is not None
+        fa, d2, idx = renderer.point_mlp(xyz, dirs, G, K=int(K))
+        ctx.save_for_backward(xyz, G, d2, idx, *([dirs] if dirs is not None else []))
+        return fa
+
+    @staticmethod
+    def backward(ctx, g_fa):
+        xyz, G, d2, idx = ctx.saved_tensors[:4]
+        dirs = ctx.saved_tensors[4] if ctx.has_dir else None
+        names = [n for n, need in zip(POINT_PARAMS, ctx.needs_input_grad[6:]) if need]
+        tg = ctx.r.train_grads(names, support_feature=ctx.needs_input_grad[3])
+        gx, gd, gg = ctx.r.point_mlp_backward(xyz, dirs, G, g_fa.contiguous(), K=ctx.K, knn=(d2, idx), train=tg)
+        return (gx, gd, gg, tg.support_feature, None, None) + tuple(tg.weights.get(n) for n in POINT_PARAMS)
+
+
 class MvAggFn(torch.autograd.Function):
     """Multi-view aggregation (multiview_aggregator.py:156-222) with frozen weights / support maps as one autograd node on the HIP library:
     xyz (N,3) -> (G (N,W), valid_s (N) int32 [non-differentiable: #views that see the sample > 1]); backward = nl_mv_aggregate_backward."""
@@ -372,12 +405,15 @@ def _view_angles(xyz: Tensor, query_center: Tensor, view_centers: Tensor) -> Ten
 
 
 def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, query_pose: Tensor,
-                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False, beta: bool = False, frozen_renderer=None) -> Dict[str, Tensor]:
+                     knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False, beta: bool = False, frozen_renderer=None,
+                     train_renderer=None) -> Dict[str, Tensor]:
     """conditional_nerf/model.py:472-600 with autograd.  `z_vals` (R, S) are constants (the hierarchical resampling detaches its
     weights, model.py:495); `knn_idx(xyz) -> (N, 8) int64` is the exact KNN (no gradient: indices); beta: the training-mode
     uncertainty output (model.py:587-592).  Gradients reach whatever requires grad among rays_o / rays_d / query_pose, the
     parameters `p` and the frame tensors.  frozen_renderer: a HipRenderer holding exactly `p` and `fr['support']` — states that both are
     constants of this call, so the neural-point branch may run as PointBranchFn (HIP forward + HIP backward) instead of eager ops.
+    train_renderer: a HipRenderer holding the CURRENT VALUES of `p` and of the frame tensors (a training step): the stages whose weight
+    gradients the library computes (`*TrainFn`) run as HIP nodes that also return d/d parameters and d/d frame tensors; the others stay eager.
     fr: topk_Ks, topk_poses, topk_images, feat_fine_src, vis_featmaps, near, far (python floats), support {xyz, feature, confidence, direction}."""
     R, S = z_vals.shape
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
@@ -390,9 +426,12 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
         agg = PointBranchFn.apply(xyz, dirs.contiguous(), G, frozen_renderer, 8)
     else:
         G, mvf, mvv, mask1 = _mv_aggregate(p, fr, xyz)
-        with torch.no_grad():
-            idx = knn_idx(xyz.detach()).long()
-        agg = _point_branch(p, fr, xyz, dirs, G, idx)
+        if train_renderer is not None and _hip_ok(xyz, dirs, G) and fr["support"]["xyz"].shape[0] >= 1:
+            agg = PointBranchTrainFn.apply(xyz, dirs.contiguous(), G, fr["support"]["feature"], train_renderer, 8, *[p[n] for n in POINT_PARAMS])
+        else:
+            with torch.no_grad():
+                idx = knn_idx(xyz.detach()).long()
+            agg = _point_branch(p, fr, xyz, dirs, G, idx)
     W = agg.shape[1]
     if frozen and S == frozen_renderer.S:
         geo = UnetFn.apply(agg, frozen_renderer)

@@ -7,7 +7,7 @@ packed weights <- state_dict, frame <- (`data`, `support_neural_points['fine']`,
 from __future__ import annotations
 
 import ctypes as ct
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import torch
 
@@ -21,6 +21,31 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def _dev_f32(t, device) -> torch.Tensor:
     t = torch.as_tensor(t)
     return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class TrainGrads:
+    """Gradient buffers of one training step (nl_train_grads): `.weights[name]` fp32 tensors shaped like the state_dict entries,
+    `.support_feature` (M, C+3) or None; the library ADDS into them, so one object serves all backward calls (and chunks) of a step."""
+
+    def __init__(self, renderer: "HipRenderer", names: Sequence[str], support_feature: bool):
+        all_names = L.weight_names()
+        shapes = renderer.weight_shapes()
+        unknown = [n for n in names if n not in shapes]
+        if unknown:
+            raise KeyError(f"not a weight of the ray path: {unknown}")
+        dev = renderer.device
+        self.weights = {n: torch.zeros(shapes[n], device=dev) for n in names}
+        self._arr = (ct.c_void_p * len(all_names))()
+        for i, n in enumerate(all_names):
+            self._arr[i] = self.weights[n].data_ptr() if n in self.weights else None
+        self.support_feature = torch.zeros(renderer.M, renderer.C + 3, device=dev) if support_feature else None
+        nb = renderer.lib.nl_train_scratch_bytes(ct.byref(renderer.cfg))
+        self._scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        self.c = L.NlTrainGrads()
+        self.c.weights = ct.cast(self._arr, ct.POINTER(ct.c_void_p))
+        self.c.support_feature = _ptr(self.support_feature)
+        self.c.scratch = self._scratch.data_ptr()
+        self.c.scratch_bytes = nb
 
 
 class HipRenderer:
@@ -57,10 +82,17 @@ class HipRenderer:
             t = _dev_f32(state_dict[n].detach() if isinstance(state_dict[n], torch.Tensor) else state_dict[n], self.device)
             keep.append(t)
             arr[i] = t.data_ptr()
+        self._weight_shapes = {n: tuple(t.shape) for n, t in zip(names, keep)}
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.nl_pack_weights(ct.byref(self.cfg), arr, len(names), self.packed.data_ptr(), self.packed.numel(), st), "nl_pack_weights")
         torch.cuda.current_stream(self.device).synchronize()  # sources may be freed after this
         self._weights_loaded = True
+
+    def weight_shapes(self) -> Dict[str, tuple]:
+        """Shapes of the state_dict tensors the ray path consumes (as last loaded)."""
+        if not self._weights_loaded:
+            raise RuntimeError("load_weights first")
+        return dict(self._weight_shapes)
 
     def set_precision(self, precision: str) -> None:
         """All three weight layouts are packed at once, so switching is free."""
@@ -299,9 +331,17 @@ class HipRenderer:
                                            gx.data_ptr(), gfa.data_ptr(), _ptr(gq), ws.data_ptr(), ws.numel(), self._stream()), "nl_blend_backward")
         return gx, gfa, (None if gq is None else gq.sum(0))
 
-    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None, workspace_samples: Optional[int] = None):
-        """Input gradient of `point_mlp` with frozen weights (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W)).
-        knn = (d2, idx) as `point_mlp` returned them for the same points: saves the second neighbour search."""
+    # ------------------------------------------------------------------ training: weight gradients
+    def train_grads(self, names: Sequence[str], support_feature: bool = False) -> "TrainGrads":
+        """Zero-filled gradient buffers for the listed state_dict tensors (and the support table's features): hand the object to the
+        `*_backward(..., train=...)` calls of one step, then read `.weights[name]` / `.support_feature`."""
+        self._ready()
+        return TrainGrads(self, names, support_feature)
+
+    def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None, workspace_samples: Optional[int] = None, train: "TrainGrads" = None):
+        """Input gradient of `point_mlp` (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W)).
+        knn = (d2, idx) as `point_mlp` returned them for the same points: saves the second neighbour search.
+        train: a TrainGrads — the call also ADDS the gradients of the stage's weights / the support features into it (nl_point_mlp_backward_train)."""
         self._ready()
         dev = self.device
         x, g, gy = _dev_f32(xyz, dev), _dev_f32(mv_feat, dev), _dev_f32(g_feature_agg, dev)
@@ -310,10 +350,16 @@ class HipRenderer:
         gx = torch.empty(N, 3, device=dev)
         gd = None if dr is None else torch.empty(N, 3, device=dev)
         gg = torch.empty(N, self.W, device=dev)
-        ws = self._workspace(self.lib.nl_point_mlp_backward_workspace_bytes(ct.byref(self.cfg), N))
+        wsb = self.lib.nl_point_mlp_backward_workspace_bytes if train is None else self.lib.nl_point_mlp_backward_train_workspace_bytes
+        ws = self._workspace(wsb(ct.byref(self.cfg), N))
         if workspace_samples is not None:   # (tests: a workspace for fewer samples than N makes the entry point walk N in chunks)
-            ws = ws[: self.lib.nl_point_mlp_backward_workspace_bytes(ct.byref(self.cfg), int(workspace_samples))]
+            ws = ws[: wsb(ct.byref(self.cfg), int(workspace_samples))]
         d2, idx = (None, None) if knn is None else (knn[0].contiguous(), knn[1].to(torch.int32).contiguous())
+        if train is not None:
+            L.check(self.lib.nl_point_mlp_backward_train(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
+                                                         g.data_ptr(), N, K, _ptr(idx), _ptr(d2), gy.data_ptr(), gx.data_ptr(), _ptr(gd), gg.data_ptr(),
+                                                         ct.byref(train.c), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp_backward_train")
+            return gx, gd, gg
         L.check(self.lib.nl_point_mlp_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
                                                g.data_ptr(), N, K, _ptr(idx), _ptr(d2), gy.data_ptr(), gx.data_ptr(), _ptr(gd), gg.data_ptr(), ws.data_ptr(),
                                                ws.numel(), self._stream()), "nl_point_mlp_backward")

@@ -280,3 +280,75 @@ def test_backward_entry_points_walk_large_batches_in_chunks():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and rel_err(b[2].cpu().numpy(), a[2].cpu().numpy()) < 1e-5
     x = rnd(12 * S, W)
     assert torch.equal(r.ray_unet_backward(x, cotW[: 12 * S]), r.ray_unet_backward(x, cotW[: 12 * S], workspace_rays=5))
+
+
+# --------------------------------------------------------------------------------------------- training: weight gradients (nl_*_backward_train)
+POINT_PARAMS = ["ray_diff_fc.0.weight", "ray_diff_fc.0.bias", "ray_diff_fc.2.weight", "ray_diff_fc.2.bias",
+                "base_mlp.0.weight", "base_mlp.0.bias", "base_mlp.2.weight", "base_mlp.2.bias", "base_mlp.4.weight", "base_mlp.4.bias",
+                "base_mlp_attn.w_qs.weight", "base_mlp_attn.w_ks.weight", "base_mlp_attn.w_vs.weight", "base_mlp_attn.fc.weight",
+                "base_mlp_attn.layer_norm.weight", "base_mlp_attn.layer_norm.bias"]
+
+
+def _assert_param_grads(got, ref32, ref64, tol, what, exact_forward):
+    """Every tensor against the fp64 autograd gradient, relative to that tensor's largest entry.  exact_forward (fp32 mode on a small network): to `tol`,
+    or 5x what fp32 autograd manages.  Otherwise the comparison has to live with the piecewise-constant derivative of a LeakyReLU network: the
+    rounding of the forward pass decides the sign of the few pre-activations within ~1e-7 of zero (for fp32 autograd as well: e_ref), and one
+    flipped unit changes that sample's whole contribution to its layer's weight gradient and to everything upstream (percents of single entries
+    at test sizes, where a gradient sums ~10^4 rows) — so: every tensor in the L2 norm, and no entry off by more than a few percent."""
+    for n in got:
+        a, c64 = got[n].double().cpu(), ref64[n].double().cpu()
+        e_hip, e_ref = rel_err(a.numpy(), c64.numpy()), rel_err(ref32[n].cpu().numpy(), c64.numpy())
+        rows = (a - c64).abs().reshape(a.shape[0], -1).max(1)[0] / c64.abs().max()
+        bad, l2 = int((rows > tol).sum()), float((a - c64).norm() / c64.norm())
+        print(what, n, tuple(a.shape), "hip vs fp64", e_hip, "| fp32 autograd vs fp64", e_ref, "| rows beyond tol", bad, "of", rows.numel(), "| L2-rel", l2)
+        if exact_forward:
+            assert e_hip < max(tol, 5 * e_ref), (n, e_hip, e_ref)
+        else:
+            assert l2 < 1e-2 and e_hip < 5e-2, (n, bad, l2, e_hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("c1", "fp32", None), ("c1", "bf16x3", 100), ("w256s128", "bf16x3", None)])
+def test_point_branch_weight_gradients_match_autograd(case, precision, chunk):
+    """nl_point_mlp_backward_train: the gradients of the branch's 16 parameter tensors and of the support table's features, against autograd of the
+    eager restatement (fp64).  chunk: a workspace for fewer samples than N — the weight gradients accumulate over the chunks."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case(case)
+    cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = {k: t(v) for k, v in c["weights"].items()}
+    fr = {"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}}
+    R = min(cfg.R, 12)
+    o, d = t(rays["rays_o"][:R]), t(rays["rays_d"][:R])
+    lin = torch.linspace(0, 1, cfg.S, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, cfg.S)
+    xyz = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
+    dirs = d[:, None, :].expand(R, cfg.S, 3).reshape(-1, 3).contiguous()
+    g = torch.Generator().manual_seed(5)
+    G = torch.randn(xyz.shape[0], cfg.W, generator=g).to(dev)
+    cot = torch.randn(xyz.shape[0], cfg.W, generator=g).to(dev)
+    d2, idx = r.knn(xyz, 8)
+
+    def eager(dt):
+        pp = {k: v.detach().to(dt).requires_grad_(k in POINT_PARAMS) for k, v in p.items()}
+        sp = {k: v.to(dt) for k, v in fr["support"].items()}
+        sp["feature"] = sp["feature"].detach().requires_grad_(True)
+        out = dr._point_branch(pp, {"near": fr["near"], "far": fr["far"], "support": sp}, xyz.to(dt), dirs.to(dt), G.to(dt), idx.long())
+        gs = torch.autograd.grad((out * cot.to(dt)).sum(), [pp[n] for n in POINT_PARAMS] + [sp["feature"]])
+        return dict(zip(POINT_PARAMS + ["support.feature"], gs))
+    ref32, ref64 = eager(torch.float32), eager(torch.float64)
+    tg = r.train_grads(POINT_PARAMS, support_feature=True)
+    gx, gd, gg = r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), train=tg, workspace_samples=chunk)
+    gx0, gd0, gg0 = r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), workspace_samples=chunk)
+    assert torch.equal(gx, gx0) and torch.equal(gd, gd0) and torch.equal(gg, gg0), "the input gradients do not depend on the training outputs"
+    got = {k: v.clone() for k, v in tg.weights.items()}
+    got["support.feature"] = tg.support_feature.clone()
+    _assert_param_grads(got, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=case != "w256s128")
+    # a second call ADDS
+    r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), train=tg, workspace_samples=chunk)
+    assert rel_err(tg.weights["base_mlp.2.weight"].cpu().numpy(), 2 * got["base_mlp.2.weight"].cpu().numpy()) < 1e-6
