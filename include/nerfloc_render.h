@@ -287,9 +287,14 @@ typedef struct nl_train_grads {
   float* const* weights;     /* HOST array of nl_num_weights() DEVICE pointers, tensor i laid out like state_dict[nl_weight_name(i)];
                               * NULL entries (and a NULL array) = that gradient is not wanted */
   float* support_feature;    /* (M, C+3) gradient of the support table's features (knn_gather's backward), or NULL */
+  float* feat_maps;          /* (V, h, w, C) gradient of the support feature maps (nl_frame_desc.featmaps, channels-last), or NULL */
+  float* vis_featmaps;       /* (V, vh, vw, 32) CHANNELS-LAST gradient of the DepthFusionNet maps (nl_frame_desc.vis_featmaps is (V,32,vh,vw)), or NULL */
+  float* blend_feat_maps;    /* (V, h, w, 32) gradient of the blend-projected feature maps P = featmaps . rgb_blending_mlp.0.weight[:, W+3 : W+3+C]^T
+                              * (the blend taps P instead of projecting every tap, model.py:532-535 by linearity): the caller continues with
+                              * d weight[:, W+3 : W+3+C] += sum P_grad^T featmaps and d featmaps += P_grad . weight[:, W+3 : W+3+C].  Or NULL */
   void* scratch;             /* split-K partial tiles: nl_train_scratch_bytes(cfg) */
   size_t scratch_bytes;
-  int32_t reserved[8];       /* must be 0 */
+  int32_t reserved[4];       /* must be 0 */
 } nl_train_grads;
 size_t nl_train_scratch_bytes(const nl_config* cfg);
 /* nl_point_mlp_backward + gradients of ray_diff_fc.*, base_mlp.*, base_mlp_attn.{w_qs, w_ks, w_vs, fc, layer_norm}.* and of the support
@@ -298,6 +303,18 @@ size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t
 int nl_point_mlp_backward_train(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, const float* dir, int64_t dir_stride,
                                 const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg,
                                 float* g_xyz, float* g_dir, float* g_mv_feat, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* nl_mv_aggregate_backward + gradients of multiview_aggregator.out_fc.*, the four dist_decoder MLPs (24 tensors), the support feature maps
+ * (grid_sample's backward: scatter-add of the taps) and the DepthFusionNet maps. */
+size_t nl_mv_aggregate_backward_train_workspace_bytes(const nl_config* cfg, int V, int64_t N);
+int nl_mv_aggregate_backward_train(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* xyz, int64_t N, const float* g_mv_feat,
+                                   float* g_xyz, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
+/* nl_blend_backward + gradients of rgb_blending_mlp.* (layer 1: every column except the feature columns, see blend_feat_maps), the decoders,
+ * the DepthFusionNet maps and the blend-projected feature maps. */
+size_t nl_blend_backward_train_workspace_bytes(const nl_config* cfg, int V, int64_t N);
+int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center, const float* xyz,
+                            const float* feature_agg, int64_t N, const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center,
+                            const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* Input gradient of nl_mv_aggregate's feature rows (rows a4-a7; multiview_aggregator.py:156-222, ibrnet.py:169-231, visibility_decoder.py:64-148)
  * with frozen weights and frozen support maps: g_mv_feat (N,W) -> g_xyz (N,3).  The forward is recomputed in exact fp32; the way back goes through

@@ -53,8 +53,8 @@ class NlRenderOpts(C.Structure):
 
 
 class NlTrainGrads(C.Structure):
-    _fields_ = [("weights", C.POINTER(C.c_void_p)), ("support_feature", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
-                ("reserved", C.c_int32 * 8)]
+    _fields_ = [("weights", C.POINTER(C.c_void_p)), ("support_feature", C.c_void_p), ("feat_maps", C.c_void_p), ("vis_featmaps", C.c_void_p),
+                ("blend_feat_maps", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("reserved", C.c_int32 * 4)]
 
 
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)
@@ -96,6 +96,10 @@ SYMBOLS = [
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
+    ("nl_mv_aggregate_backward_train_workspace_bytes", _Z, [_CFG, _I, _L]),
+    ("nl_mv_aggregate_backward_train", _I, [_CFG, _P, _P, _P, _L, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
+    ("nl_blend_backward_train_workspace_bytes", _Z, [_CFG, _I, _L]),
+    ("nl_blend_backward_train", _I, [_CFG, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_point_mlp_backward_train_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward_train", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_mv_aggregate_backward_workspace_bytes", _Z, [_CFG, _I, _L]),

@@ -73,11 +73,15 @@ int nl_launch_lrelu_mask(float* g, const float* h, size_t n, hipStream_t st);
 int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t st);
 int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
                                int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
-                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, hipStream_t st);
+                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, hipStream_t st);
+int nl_dec_train_row(void);
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
-                           const float* g_dd, float* part, float* g_xyz, hipStream_t st);
+                           const float* g_dd, float* part, float* g_xyz, float* tr, float* sc_vis, hipStream_t st);
 int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
-                             const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st);
+                             const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, float* tr,
+                             hipStream_t st);
+int nl_launch_blend_inputs8(const NlViews& vw, const float* viewsdev, const float* xyz, int64_t N, const float* rgbv, float* x8, hipStream_t st);
+int nl_launch_blw_unpack(const float* t, float* g, int W, int F, hipStream_t st);
 int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
 int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
                                    float* g_x, hipStream_t st);
@@ -749,8 +753,16 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
 struct TrainOut {
   float* w[kNumWeights];
   float* sp_feat;
+  float *feat_maps, *pfeat_maps, *vis_maps;   // (V,h,w,C), (V,h,w,32), (V,vh,vw,32)
   float* scratch; size_t scratch_floats;
+  bool any(int a, int b) const { for (int i = a; i < b; ++i) if (w[i]) return true; return false; }
 };
+// gW[tw] += dY^T X (and gb[tb] += column sums of dY) for whichever of the two the caller asked for
+int wgrad_to(const TrainOut* tg, hipStream_t st, int tw, int tb, const float* dY, int ldy, int Mo, const float* X, int ldxx, int Ni, int64_t rows) {
+  if (!tg || (!tg->w[tw] && (tb < 0 || !tg->w[tb]))) return NL_OK;
+  if (!tg->w[tw]) return nl_launch_colsum(dY, ldy, rows, Mo, tg->w[tb], tg->scratch, st);
+  return nl_launch_wgrad(dY, ldy, Mo, X, ldxx, Ni, rows, 0, 0, tg->w[tw], Ni, 1, 0, tb >= 0 ? tg->w[tb] : nullptr, tg->scratch, tg->scratch_floats, st);
+}
 inline int ldf_of(int C) { return (int)nl_align_up(C + 3, 32); }
 struct PtBwdBufs { int* idx; float *d2, *X, *H1, *H2, *H3, *KV, *Q, *O, *FCo, *wscale, *gpre, *gO, *gQ, *gKV, *gA, *gB, *gX, *aff, *tr, *gXF; };
 void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p, bool train = false) {
@@ -787,9 +799,7 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
   const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
   // training: gW += dY^T X right after each dY exists (its buffer is reused by the next layer's)
   auto wg = [&](int tw, int tb, const float* dY, int ldy, int Mo, const float* X, int ldxx, int Ni, int64_t rows) -> int {
-    if (!tg || (!tg->w[tw] && (tb < 0 || !tg->w[tb]))) return NL_OK;
-    if (!tg->w[tw]) return nl_launch_colsum(dY, ldy, rows, Mo, tg->w[tb], tg->scratch, x.st);
-    return nl_launch_wgrad(dY, ldy, Mo, X, ldxx, Ni, rows, 0, 0, tg->w[tw], Ni, 1, 0, tb >= 0 ? tg->w[tb] : nullptr, tg->scratch, tg->scratch_floats, x.st);
+    return wgrad_to(tg, x.st, tw, tb, dY, ldy, Mo, X, ldxx, Ni, rows);
   };
   const int64_t NK = N * K;
   const float inv_span = 1.f / (f->views.far_ - f->views.near_);
@@ -850,8 +860,8 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
 }
 
 // ---- input gradients of the multi-view aggregation and of the colour blend (frozen weights) ------------------------------------------
-struct MvBwdBufs { float *vis, *dd, *g393, *t64, *G, *gA, *gt64, *gg393, *gvis, *gdd, *gpart, *bl1, *rgbv, *blA, *ghA, *gpf, *grgbv, *gang; int* valid_s; };
-void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdBufs& m) {
+struct MvBwdBufs { float *vis, *dd, *g393, *t64, *G, *gA, *gt64, *gg393, *gvis, *gdd, *gpart, *bl1, *rgbv, *blA, *ghA, *gpf, *grgbv, *gang, *dtr, *btr, *ang; int* valid_s; };
+void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdBufs& m, bool train = false) {
   const int W = c->W, ldg = ldg_of(c->C);
   m.vis = b.take<float>((size_t)V * N); m.dd = b.take<float>((size_t)V * N); m.gvis = b.take<float>((size_t)V * N); m.gdd = b.take<float>((size_t)V * N);
   m.gpart = b.take<float>((size_t)V * N * 3);
@@ -866,6 +876,11 @@ void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdB
     m.gang = b.take<float>((size_t)N * V * 4);
     m.t64 = m.G = m.gA = m.gt64 = m.gg393 = nullptr;
   }
+  m.dtr = m.btr = m.ang = nullptr;
+  if (train) {
+    m.dtr = b.take<float>((size_t)V * N * nl_dec_train_row());
+    if (blend) { m.btr = b.take<float>((size_t)V * N * 68); m.ang = b.take<float>((size_t)V * N * 8 + 256); }
+  }
 }
 
 // the recomputed forward both need: visibility / depth difference (exact fp32 decoders: the backward kernel differentiates those) and the
@@ -878,9 +893,23 @@ int mv_recompute(const Ctx& x32, const nl_frame* f, const NlViews& vw, const flo
                             x32.p<float>(x32.L.blw), m.bl1, m.rgbv, x32.st);
 }
 
+// the 24 decoder tensors from the rows the decoder backward kernels emit (backward.hip: [x 32 | per decoder: h1 32, h2 32, d a1 32, d a2 32, d out 2, pad 2])
+int dec_wgrads(const TrainOut* tg, hipStream_t st, const float* tr, int64_t rows) {
+  const int ld = nl_dec_train_row();
+  for (int d = 0; d < 4; ++d) {
+    const float* q = tr + 32 + 132 * d;
+    const int t0 = T_DEC + 6 * d;
+    NL_TRY(wgrad_to(tg, st, t0, t0 + 1, q + 64, ld, 32, tr, ld, 32, rows));
+    NL_TRY(wgrad_to(tg, st, t0 + 2, t0 + 3, q + 96, ld, 32, q, ld, 32, rows));
+    NL_TRY(wgrad_to(tg, st, t0 + 4, t0 + 5, q + 128, ld, d < 2 ? 2 : 1, q + 32, ld, 32, rows));
+  }
+  return NL_OK;
+}
+
 // g_G (N, W) -> g_xyz (N, 3): out_fc backwards (two transposed-weight products, ELU masks), the visibility-weighted statistics, the bilinear taps'
 // spatial derivative, the IBRNet projection; visibility / depth difference through the NeuRay decoders and the NeuRay projection.
-int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* xyz, int64_t N, const float* gG, float* g_xyz, const MvBwdBufs& m) {
+int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* xyz, int64_t N, const float* gG, float* g_xyz, const MvBwdBufs& m,
+                   const TrainOut* tg = nullptr) {
   const int W = x32.c->W, ldg = ldg_of(f->C);
   const NlViews vw = with_query(f, nullptr);
   NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
@@ -889,14 +918,18 @@ int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float
   NL_TRY(run_gemm(x32, G_OUTFC2, &s1, 1, N, m.G, W, NL_ACT_ELU));
   NL_CHECK_HIP(hipMemcpyAsync(m.gA, gG, sizeof(float) * (size_t)N * W, hipMemcpyDeviceToDevice, x32.st));
   NL_TRY(nl_launch_elu_mask(m.gA, m.G, (size_t)N * W, x32.st));
+  NL_TRY(wgrad_to(tg, x32.st, T_OUT2W, T_OUT2B, m.gA, W, W, m.t64, 64, 64, N));
   SegSpec sa{m.gA, W, W, 0, 1}, st{m.gt64, 64, 64, 0, 1};
   NL_TRY(run_gemm(xb, G_OUTFC2_T, &sa, 1, N, m.gt64, 64, NL_ACT_NONE));
   NL_TRY(nl_launch_elu_mask(m.gt64, m.t64, (size_t)N * 64, x32.st));
+  NL_TRY(wgrad_to(tg, x32.st, T_OUT0W, T_OUT0B, m.gt64, 64, 64, m.g393, ldg, 2 * (f->C + 3) + 3, N));
   NL_TRY(run_gemm(xb, G_OUTFC0_T, &st, 1, N, m.gg393, ldg, NL_ACT_NONE));
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, nullptr, xyz, N, m.vis, m.dd, m.gg393, ldg, nullptr, nullptr, nullptr, g_xyz,
-                                    nullptr, m.gvis, m.gdd, x32.st));
-  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
-                                m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
+                                    nullptr, m.gvis, m.gdd, tg ? tg->feat_maps : nullptr, nullptr, x32.st));
+  const bool decw = tg && tg->any(T_DEC, T_DEC + 24);
+  NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
+                                m.gvis, m.gdd, m.gpart, g_xyz, decw ? m.dtr : nullptr, tg ? tg->vis_maps : nullptr, x32.st));
+  return decw ? dec_wgrads(tg, x32.st, m.dtr, (int64_t)vw.V * N) : NL_OK;
 }
 
 // rgb_s = blend(feature_agg, per-view taps) forward (staged) and its input gradient
@@ -913,19 +946,39 @@ int do_blend_forward(const Ctx& x, const nl_frame* f, const float* qc, const flo
 }
 
 int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* xyz, const float* FA, int64_t N, const float* g_rgb_s,
-                      float* g_xyz, float* g_FA, float* g_qc, const MvBwdBufs& m) {
+                      float* g_xyz, float* g_FA, float* g_qc, const MvBwdBufs& m, const TrainOut* tg = nullptr) {
   const int W = x32.c->W;
   const NlViews vw = with_query(f, qc);
   NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
   SegSpec sa{FA, W, W, 0, 1}, sg{m.ghA, 32, 32, 0, 1};
   NL_TRY(run_gemm(x32, G_BLENDA, &sa, 1, N, m.blA, 32, NL_ACT_NONE));
+  const bool blw = tg && (tg->any(T_BL0W, T_BL4B + 1));
   NL_TRY(nl_launch_blend_backward(m.blA, m.bl1, m.rgbv, N, vw.V, x32.p<float>(x32.L.bl2_w), x32.p<float>(x32.L.bl2_b), x32.p<float>(x32.L.bl4_w),
-                                  x32.p<float>(x32.L.bl4_b), x32.p<float>(x32.L.blw), g_rgb_s, m.ghA, m.gpf, m.grgbv, m.gang, x32.st));
+                                  x32.p<float>(x32.L.bl4_b), x32.p<float>(x32.L.blw), g_rgb_s, m.ghA, m.gpf, m.grgbv, m.gang, blw ? m.btr : nullptr, x32.st));
+  if (blw) {   // rgb_blending_mlp (model.py:84-93, 532-535)
+    const int64_t NV = N * vw.V;
+    const int F = f->C + 3;
+    NL_TRY(wgrad_to(tg, x32.st, T_BL2W, T_BL2B, m.btr + 32, 68, 16, m.btr, 68, 32, NV));
+    NL_TRY(wgrad_to(tg, x32.st, T_BL4W, T_BL4B, m.btr + 64, 68, 1, m.btr + 48, 68, 16, NV));
+    if (tg->w[T_BL0W]) {
+      // layer 1 by linearity: the feature_agg columns (per sample), the [rgb | visibility | view angles] columns (per sample and view); the feature
+      // columns multiply the per-frame projected maps, whose gradient goes back as a map (nl_train_grads.blend_feat_maps)
+      NL_TRY(nl_launch_wgrad(m.ghA, 32, 32, FA, W, W, N, 0, 0, tg->w[T_BL0W], W + F + 5, 1, 0, nullptr, tg->scratch, tg->scratch_floats, x32.st));
+      float* t8 = m.ang + (size_t)NV * 8;
+      NL_CHECK_HIP(hipMemsetAsync(t8, 0, sizeof(float) * 256, x32.st));
+      NL_TRY(nl_launch_blend_inputs8(vw, f->views_dev, xyz, N, m.rgbv, m.ang, x32.st));
+      NL_TRY(nl_launch_wgrad(m.gpf, 32, 32, m.ang, 8, 8, NV, 0, 0, t8, 8, 1, 0, nullptr, tg->scratch, tg->scratch_floats, x32.st));
+      NL_TRY(nl_launch_blw_unpack(t8, tg->w[T_BL0W], W, F, x32.st));
+    }
+    if (tg->w[T_BL0B]) NL_TRY(nl_launch_colsum(m.gpf, 32, NV, 32, tg->w[T_BL0B], tg->scratch, x32.st));
+  }
   if (g_FA) NL_TRY(run_gemm(xb, G_BLENDA_T, &sg, 1, N, g_FA, W, NL_ACT_NONE));
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, f->pfeat, xyz, N, m.vis, m.dd, nullptr, ldg_of(f->C), m.gpf, m.grgbv, m.gang, g_xyz,
-                                    g_qc, m.gvis, m.gdd, x32.st));
-  return nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
-                                m.gvis, m.gdd, m.gpart, g_xyz, x32.st);
+                                    g_qc, m.gvis, m.gdd, tg ? tg->feat_maps : nullptr, tg ? tg->pfeat_maps : nullptr, x32.st));
+  const bool decw = tg && tg->any(T_DEC, T_DEC + 24);
+  NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
+                                m.gvis, m.gdd, m.gpart, g_xyz, decw ? m.dtr : nullptr, tg ? tg->vis_maps : nullptr, x32.st));
+  return decw ? dec_wgrads(tg, x32.st, m.dtr, (int64_t)vw.V * N) : NL_OK;
 }
 
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and
@@ -1433,9 +1486,10 @@ static size_t point_bwd_bytes(const nl_config* cfg, int64_t n, bool train = fals
 static int resolve_train(const nl_config* cfg, const nl_train_grads* g, TrainOut& t) {
   memset(&t, 0, sizeof(t));
   if (!g) return NL_OK;
-  for (int i = 0; i < 8; ++i) if (g->reserved[i] != 0) return NL_ERR_BAD_ARG;
+  for (int i = 0; i < 4; ++i) if (g->reserved[i] != 0) return NL_ERR_BAD_ARG;
   if (g->weights) for (int i = 0; i < kNumWeights; ++i) t.w[i] = g->weights[i];
   t.sp_feat = g->support_feature;
+  t.feat_maps = g->feat_maps; t.pfeat_maps = g->blend_feat_maps; t.vis_maps = g->vis_featmaps;
   if (!g->scratch || g->scratch_bytes < nl_train_scratch_bytes(cfg) || ((uintptr_t)g->scratch & 15)) return NL_ERR_WORKSPACE;
   t.scratch = (float*)g->scratch; t.scratch_floats = g->scratch_bytes / sizeof(float);
   return NL_OK;
@@ -1501,28 +1555,43 @@ int nl_point_mlp_backward_train(const nl_config* cfg, const void* packed, const 
   return NL_OK;
 }
 
-static size_t mv_bwd_bytes(const nl_config* cfg, int V, int64_t n, bool blend) { Bump b{nullptr, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, n, blend, m); return b.off; }
-static int64_t mv_bwd_chunk(const nl_config* cfg, int V, int64_t N, bool blend, size_t ws_bytes) {
-  if (ws_bytes < mv_bwd_bytes(cfg, V, 1, blend)) return 0;
+static size_t mv_bwd_bytes(const nl_config* cfg, int V, int64_t n, bool blend, bool train = false) {
+  Bump b{nullptr, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, n, blend, m, train); return b.off;
+}
+static int64_t mv_bwd_chunk(const nl_config* cfg, int V, int64_t N, bool blend, size_t ws_bytes, bool train = false) {
+  if (ws_bytes < mv_bwd_bytes(cfg, V, 1, blend, train)) return 0;
   int64_t lo = 1, hi = N;
-  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (mv_bwd_bytes(cfg, V, mid, blend) <= ws_bytes) lo = mid; else hi = mid - 1; }
+  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (mv_bwd_bytes(cfg, V, mid, blend, train) <= ws_bytes) lo = mid; else hi = mid - 1; }
   return lo < (1 << 18) ? lo : (1 << 18);
+}
+size_t nl_mv_aggregate_backward_train_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 15) ? (1 << 15) : N), false, true) : 0;
+}
+size_t nl_blend_backward_train_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 15) ? (1 << 15) : N), true, true) : 0;
 }
 size_t nl_mv_aggregate_backward_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
   return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 16) ? (1 << 16) : N), false) : 0;
 }
 int nl_mv_aggregate_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, int64_t N, const float* g_mv_feat, float* g_xyz,
                              void* ws, size_t ws_bytes, void* stream) {
+  return nl_mv_aggregate_backward_train(cfg, packed, f, xyz, N, g_mv_feat, g_xyz, nullptr, ws, ws_bytes, stream);
+}
+int nl_mv_aggregate_backward_train(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, int64_t N, const float* g_mv_feat, float* g_xyz,
+                                   const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !g_mv_feat || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, W = cfg->W;
-  const int64_t NC = mv_bwd_chunk(cfg, V, N, false, ws_bytes);
+  const bool train = grads != nullptr;
+  TrainOut T;
+  NL_TRY(resolve_train(cfg, grads, T));
+  const int64_t NC = mv_bwd_chunk(cfg, V, N, false, ws_bytes, train);
   if (NC == 0) return NL_ERR_WORKSPACE;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   for (int64_t n0 = 0; n0 < N; n0 += NC) {
     const int64_t nc = N - n0 < NC ? N - n0 : NC;
-    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, false, m);
-    NL_TRY(do_mv_backward(B.xb, B.x32, f, xyz + 3 * n0, nc, g_mv_feat + n0 * W, g_xyz + 3 * n0, m));
+    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, false, m, train);
+    NL_TRY(do_mv_backward(B.xb, B.x32, f, xyz + 3 * n0, nc, g_mv_feat + n0 * W, g_xyz + 3 * n0, m, train ? &T : nullptr));
   }
   return NL_OK;
 }
@@ -1547,17 +1616,25 @@ int nl_blend(const nl_config* cfg, const void* packed, const nl_frame* f, const 
 }
 int nl_blend_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N,
                       const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center, void* ws, size_t ws_bytes, void* stream) {
+  return nl_blend_backward_train(cfg, packed, f, qc, xyz, feature_agg, N, g_rgb_s, g_xyz, g_feature_agg, g_query_center, nullptr, ws, ws_bytes, stream);
+}
+int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N,
+                            const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center, const nl_train_grads* grads, void* ws,
+                            size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !qc || !xyz || !feature_agg || !g_rgb_s || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, W = cfg->W;
-  const int64_t NC = mv_bwd_chunk(cfg, V, N, true, ws_bytes);
+  const bool train = grads != nullptr;
+  TrainOut T;
+  NL_TRY(resolve_train(cfg, grads, T));
+  const int64_t NC = mv_bwd_chunk(cfg, V, N, true, ws_bytes, train);
   if (NC == 0) return NL_ERR_WORKSPACE;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   for (int64_t n0 = 0; n0 < N; n0 += NC) {
     const int64_t nc = N - n0 < NC ? N - n0 : NC;
-    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, true, m);
+    Bump b{(char*)ws, 0}; MvBwdBufs m; carve_mvb(b, cfg, V, nc, true, m, train);
     NL_TRY(do_blend_backward(B.xb, B.x32, f, qc, xyz + 3 * n0, feature_agg + n0 * W, nc, g_rgb_s + 3 * n0, g_xyz + 3 * n0,
-                             g_feature_agg ? g_feature_agg + n0 * W : nullptr, g_query_center ? g_query_center + 3 * n0 : nullptr, m));
+                             g_feature_agg ? g_feature_agg + n0 * W : nullptr, g_query_center ? g_query_center + 3 * n0 : nullptr, m, train ? &T : nullptr));
   }
   return NL_OK;
 }

@@ -504,7 +504,9 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
                                                                const float* __restrict__ dd_in, const float* __restrict__ g393, int ldg,
                                                                const float* __restrict__ g_pf, const float* __restrict__ g_rgbv,
                                                                const float* __restrict__ g_ang, float* __restrict__ g_xyz, float* __restrict__ g_qc,
-                                                               float* __restrict__ g_vis, float* __restrict__ g_dd) {
+                                                               float* __restrict__ g_vis, float* __restrict__ g_dd,
+                                                               float* __restrict__ sc_feat /* training: (V,h,w,C) += , or null */,
+                                                               float* __restrict__ sc_pfeat /* training: (V,h,w,32) +=, or null */) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -593,6 +595,13 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
             six = fmaf(gx, s * (t[1] - t[0]) + nn * (t[3] - t[2]), six);
             siy = fmaf(gx, e * (t[2] - t[0]) + w * (t[3] - t[1]), siy);
             sw += gm[j] * x + gv[j] * (d * d - 2.f * x * mean[j] * omW);
+            if (sc_feat && gx != 0.f) {   // grid_sample's backward towards the map (zeros padding: masked taps receive nothing)
+              float* sb = sc_feat + (size_t)v * fmap * C + ch;
+              if (m[0] != 0.f) atomicAdd(sb + (size_t)o[0] * C, gx * s * e);
+              if (m[1] != 0.f) atomicAdd(sb + (size_t)o[1] * C, gx * s * w);
+              if (m[2] != 0.f) atomicAdd(sb + (size_t)o[2] * C, gx * nn * e);
+              if (m[3] != 0.f) atomicAdd(sb + (size_t)o[3] * C, gx * nn * w);
+            }
           }
         }
         float sixI = 0.f, siyI = 0.f;
@@ -627,6 +636,13 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
           const float gx = g_pf[((size_t)n * V + v) * 32 + lane];
           six = gx * (s * (t[1] - t[0]) + nn * (t[3] - t[2]));
           siy = gx * (e * (t[2] - t[0]) + w * (t[3] - t[1]));
+          if (sc_pfeat && gx != 0.f) {
+            float* sb = sc_pfeat + (size_t)v * fmap * 32 + lane;
+            if (m[0] != 0.f) atomicAdd(sb + (size_t)o[0] * 32, gx * s * e);
+            if (m[1] != 0.f) atomicAdd(sb + (size_t)o[1] * 32, gx * s * w);
+            if (m[2] != 0.f) atomicAdd(sb + (size_t)o[2] * 32, gx * nn * e);
+            if (m[3] != 0.f) atomicAdd(sb + (size_t)o[3] * 32, gx * nn * w);
+          }
         }
         if (lane < 3 && g_rgbv) {
 #pragma unroll
@@ -718,7 +734,9 @@ namespace {
 using namespace nlmv;
 
 // backward of one 32-32-32-{1,2} decoder (visibility_decoder.py:64-97; ELU between the layers): recomputes the hidden layers, adds W0^T g_h1 to gx
-__device__ __forceinline__ void decoder_backward(const float* __restrict__ w, const float (&x)[32], float go0, float go1, float (&gx)[32]) {
+// trd (training): this decoder's 132 floats of the row [h1 32 | h2 32 | d pre-activation 1 32 | d pre-activation 2 32 | d outputs 2 | pad 2]
+constexpr int DEC_TR_D = 132, DEC_TR_ROW = 32 + 4 * DEC_TR_D;
+__device__ __forceinline__ void decoder_backward(const float* __restrict__ w, const float (&x)[32], float go0, float go1, float (&gx)[32], float* __restrict__ trd = nullptr) {
   float h1[32], h2[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
@@ -743,22 +761,27 @@ __device__ __forceinline__ void decoder_backward(const float* __restrict__ w, co
   for (int j = 0; j < 32; ++j) {
     // d ELU(a)/da = a > 0 ? 1 : exp(a) = ELU(a) + 1
     const float gh2 = (go0 * w4[j] + go1 * w4[32 + j]) * (h2[j] > 0.f ? 1.f : h2[j] + 1.f);
+    if (trd) { trd[j] = h1[j]; trd[32 + j] = h2[j]; trd[96 + j] = gh2; }
 #pragma unroll
     for (int i = 0; i < 32; ++i) g1[i] = fmaf(w2[j * 32 + i], gh2, g1[i]);
   }
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     const float gh1 = g1[j] * (h1[j] > 0.f ? 1.f : h1[j] + 1.f);
+    if (trd) trd[64 + j] = gh1;
 #pragma unroll
     for (int i = 0; i < 32; ++i) gx[i] = fmaf(w[j * 32 + i], gh1, gx[i]);
   }
+  if (trd) { trd[128] = go0; trd[129] = go1; }
 }
 
 // One lane per (view, sample): backward of mv_vis_kernel (mvagg.hip).  Writes the view's contribution to d/d xyz into part (V, N, 3); a second
 // kernel adds the views in a fixed order (no atomics: the gradient is bit-reproducible like the forward).
 __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, const float* __restrict__ visf, const float* __restrict__ dw,
                                                            const float* __restrict__ xyz, int N, const float* __restrict__ g_vis,
-                                                           const float* __restrict__ g_dd, float* __restrict__ part) {
+                                                           const float* __restrict__ g_dd, float* __restrict__ part,
+                                                           float* __restrict__ tr /* training: (V*N, DEC_TR_ROW) rows, pre-zeroed, or null */,
+                                                           float* __restrict__ sc_vis /* training: (V,vh,vw,32) +=, or null */) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.y;
   if (n >= N) return;
@@ -825,14 +848,30 @@ __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, con
   float gx[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) gx[c] = 0.f;
-  decoder_backward(dw + 0 * DEC_STRIDE, x, go00, go01, gx);
-  decoder_backward(dw + 1 * DEC_STRIDE, x, go10, go11, gx);
-  decoder_backward(dw + 2 * DEC_STRIDE, x, go2, 0.f, gx);
-  decoder_backward(dw + 3 * DEC_STRIDE, x, go3, 0.f, gx);
+  float* trr = tr ? tr + ((size_t)v * N + n) * DEC_TR_ROW : nullptr;
+  if (trr) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) trr[c] = x[c];
+  }
+  decoder_backward(dw + 0 * DEC_STRIDE, x, go00, go01, gx, trr ? trr + 32 : nullptr);
+  decoder_backward(dw + 1 * DEC_STRIDE, x, go10, go11, gx, trr ? trr + 32 + DEC_TR_D : nullptr);
+  decoder_backward(dw + 2 * DEC_STRIDE, x, go2, 0.f, gx, trr ? trr + 32 + 2 * DEC_TR_D : nullptr);
+  decoder_backward(dw + 3 * DEC_STRIDE, x, go3, 0.f, gx, trr ? trr + 32 + 3 * DEC_TR_D : nullptr);
   float gix = 0.f, giy = 0.f;
   if (valid) {
 #pragma unroll
     for (int c = 0; c < 32; ++c) { gix = fmaf(gx[c], dxv[c], gix); giy = fmaf(gx[c], dyv[c], giy); }
+    if (sc_vis) {   // interpolate_feats' backward towards the DepthFusionNet map (border mode: clamped texels receive the weight of every tap that maps to them)
+      const Taps t = make_taps<false, true>(xn, yn, vw.vw, vw.vh);
+      const TapD d = make_tapd(t, vw.vw, vw.vh);
+      float* sb = sc_vis + (size_t)v * vw.vh * vw.vw * 32;
+      const float wk[4] = {d.s * d.e * d.m[0], d.s * d.w * d.m[1], d.n * d.e * d.m[2], d.n * d.w * d.m[3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (wk[k] != 0.f)
+#pragma unroll
+          for (int c = 0; c < 32; ++c) atomicAdd(sb + (size_t)d.o[k] * 32 + c, gx[c] * wk[k]);
+    }
   }
   // ix = (2 px / (Wimg - 1)) vw / 2 - 0.5
   const float gpx = cxl ? 0.f : gix * (float)vw.vw / (float)(vw.Wimg - 1), gpy = cyl ? 0.f : giy * (float)vw.vh / (float)(vw.H - 1);
@@ -851,7 +890,7 @@ __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, con
 __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw, const float* __restrict__ visf, const uint4* __restrict__ dpack,
                                                                 const float* __restrict__ xyz, int N, int tiles_per_view, int total_tiles,
                                                                 const float* __restrict__ g_vis, const float* __restrict__ g_dd,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part, float* __restrict__ tr, float* __restrict__ sc_vis) {
   __shared__ uint4 sw[MVD_LDS_UINT4 + 2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, j = lane & 31;
@@ -888,8 +927,8 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     const float xn = px / (float)(vw.Wimg - 1) * 2.f - 1.f, yn = py / (float)(vw.H - 1) * 2.f - 1.f;
     const float ixr = (xn + 1.f) * ((float)vw.vw / 2.f) - 0.5f, iyr = (yn + 1.f) * ((float)vw.vh / 2.f) - 0.5f;
     const bool cxl = !(ixr > 0.f && ixr < (float)(vw.vw - 1)), cyl = !(iyr > 0.f && iyr < (float)(vw.vh - 1));
+    const TapD d = make_tapd(make_taps<false, true>(xn, yn, vw.vw, vw.vh), vw.vw, vw.vh);
     {
-      const TapD d = make_tapd(make_taps<false, true>(xn, yn, vw.vw, vw.vh), vw.vw, vw.vh);
       const float* base = visf + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh;
 #pragma unroll
       for (int g = 0; g < 2; ++g)
@@ -944,6 +983,12 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     OP::v8 xh[2], xl[2];
     OP::split(x0, xh[0], xl[0]);
     OP::split(x1, xh[1], xl[1]);
+    // training rows: register r of half hh = unit / channel (r & 3) + 8 (r >> 2) + 4 hh (accumulators), 8 hh + t | 16 + 8 hh + t (the tap)
+    float* trr = tr && live ? tr + ((size_t)v * N + nn) * DEC_TR_ROW : nullptr;
+    if (trr) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { trr[8 * hh + t] = x0[t]; trr[16 + 8 * hh + t] = x1[t]; }
+    }
     mvd_f32x16 gxa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gxa[r] = 0.f;
@@ -981,7 +1026,9 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
         const float h2 = nl_elu_fast(acc2[r]);
         const float g2 = go[d][0] * w4p[((d * 2 + 0) * 2 + hh) * 16 + r] + go[d][1] * w4p[((d * 2 + 1) * 2 + hh) * 16 + r];
         ga[r] = g2 * (h2 > 0.f ? 1.f : h2 + 1.f);
+        if (trr) { float* q = trr + 32 + d * DEC_TR_D + (r & 3) + 8 * (r >> 2) + 4 * hh; q[0] = h1[r]; q[32] = h2; q[96] = ga[r]; }
       }
+      if (trr && hh == 0) { trr[32 + d * DEC_TR_D + 128] = go[d][0]; trr[32 + d * DEC_TR_D + 129] = go[d][1]; }
       mvd_bf16x8 bh[2], bl[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
@@ -1001,7 +1048,10 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const int r = 8 * s2 + t; vv[t] = accb[r] * (h1[r] > 0.f ? 1.f : h1[r] + 1.f); }
+        for (int t = 0; t < 8; ++t) {
+          const int r = 8 * s2 + t; vv[t] = accb[r] * (h1[r] > 0.f ? 1.f : h1[r] + 1.f);
+          if (trr) trr[32 + d * DEC_TR_D + 64 + (r & 3) + 8 * (r >> 2) + 4 * hh] = vv[t];
+        }
         mvd_split_bf16(vv, bh[s2], bl[s2]); }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -1016,6 +1066,15 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     for (int r = 0; r < 16; ++r) { gix = fmaf(gxa[r], dx[r], gix); giy = fmaf(gxa[r], dy[r], giy); }
     gix += __shfl_xor(gix, 32, 64); giy += __shfl_xor(giy, 32, 64);
     if (!valid) { gix = 0.f; giy = 0.f; }
+    if (sc_vis && valid && live) {   // this lane's 16 channels of the map gradient
+      float* sb = sc_vis + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh;
+      const float wk[4] = {d.s * d.e * d.m[0], d.s * d.w * d.m[1], d.n * d.e * d.m[2], d.n * d.w * d.m[3]};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (wk[k] != 0.f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(sb + (size_t)d.o[k] * 32 + (r < 8 ? r : 8 + r), gxa[r] * wk[k]);
+    }
     const float gpx = cxl ? 0.f : gix * (float)vw.vw / (float)(vw.Wimg - 1), gpy = cyl ? 0.f : giy * (float)vw.vh / (float)(vw.H - 1);
     const float gcx = gpx / depth, gcy = gpy / depth;
     float gde = g_depth - (gpx * px + gpy * py) / depth;
@@ -1041,7 +1100,8 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(const float* __rest
                                                              const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w4,
                                                              const float* __restrict__ b4, const float* __restrict__ blw, const float* __restrict__ g_rgb_s,
                                                              float* __restrict__ g_hA, float* __restrict__ g_pf, float* __restrict__ g_rgbv,
-                                                             float* __restrict__ g_ang) {
+                                                             float* __restrict__ g_ang,
+                                                             float* __restrict__ tr /* training: (N*V, 68) [layer-1 output 32 | d a2 16 | layer-2 output 16 | d logit | pad 3] or null */) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float xa[32];
@@ -1092,11 +1152,18 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(const float* __rest
     float g1[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) g1[i] = 0.f;
+    float* trr = tr ? tr + ((size_t)n * V + v) * 68 : nullptr;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const float ga = glog * w4[j] * (a2[j] > 0.f ? 1.f : 0.01f);
+      if (trr) { trr[32 + j] = ga; trr[48 + j] = nl_lrelu(a2[j]); }
 #pragma unroll
       for (int i = 0; i < 32; ++i) g1[i] = fmaf(w2[j * 32 + i], ga, g1[i]);
+    }
+    if (trr) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) trr[i] = nl_lrelu(pre1[i]);
+      trr[64] = glog; trr[65] = 0.f; trr[66] = 0.f; trr[67] = 0.f;
     }
     float go[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float* pf = g_pf + ((size_t)n * V + v) * 32;
@@ -1115,6 +1182,36 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(const float* __rest
   for (int i4 = 0; i4 < 8; ++i4) *(float4*)(g_hA + (size_t)n * 32 + 4 * i4) = make_float4(gA[4 * i4], gA[4 * i4 + 1], gA[4 * i4 + 2], gA[4 * i4 + 3]);
 }
 
+// training: the 8 per-(sample, view) inputs of rgb_blending_mlp.0 next to the projected features: [r, g, b, visibility | view-angle features 4]
+// (ibrnet.py:144-167 as mv_stats8_kernel evaluates them) -> x8 (N*V, 8)
+__global__ void blend_inputs8_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ xyz, int N, const float* __restrict__ rgbv,
+                                     float* __restrict__ x8) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * vw.V) return;
+  const int n = i / vw.V, v = i - n * vw.V;
+  const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
+  float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+  if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(n / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+  float tq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
+  const float rq = 1.f / (sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f);
+  tq[0] *= rq; tq[1] *= rq; tq[2] *= rq;
+  float tt[3] = {viewsdev[192 + 3 * v] - X, viewsdev[192 + 3 * v + 1] - Y, viewsdev[192 + 3 * v + 2] - Z};
+  const float rt = 1.f / (sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f);
+  tt[0] *= rt; tt[1] *= rt; tt[2] *= rt;
+  const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+  const float rd = 1.f / fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
+  const float4 c = *(const float4*)(rgbv + (size_t)i * 4);
+  *(float4*)(x8 + (size_t)i * 8) = c;
+  *(float4*)(x8 + (size_t)i * 8 + 4) = make_float4(df[0] * rd, df[1] * rd, df[2] * rd, tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2]);
+}
+// g (32, W + F + 5) columns [W, W+3) | W+F | [W+F+1, W+F+5) += t (32, 8)
+__global__ void blw_unpack_kernel(const float* __restrict__ t, float* __restrict__ g, int W, int F) {
+  const int i = threadIdx.x;   // 256 = 32 x 8
+  const int m = i >> 3, k = i & 7;
+  const int col = k < 3 ? W + k : W + F + (k - 3);
+  g[(size_t)m * (W + F + 5) + col] += t[i];
+}
+
 // g *= ELU'(pre-activation), from the layer's OUTPUT e: e > 0 ? 1 : e + 1
 __global__ void elu_mask_kernel(float4* __restrict__ g, const float4* __restrict__ e, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1129,28 +1226,30 @@ __global__ void elu_mask_kernel(float4* __restrict__ g, const float4* __restrict
 
 int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
                                int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
-                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, hipStream_t st) {
+                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(N, 4));
 #define NL_MGB(VT) hipLaunchKernelGGL((mv_geom_backward_kernel<VT>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, \
-                                      g393, ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd)
+                                      g393, ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, sc_feat, sc_pfeat)
   if (vw.V <= 4) NL_MGB(4); else if (vw.V <= 8) NL_MGB(8); else if (vw.V <= 10) NL_MGB(10); else NL_MGB(16);
 #undef NL_MGB
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
 
+int nl_dec_train_row(void) { return DEC_TR_ROW; }
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
-                           const float* g_dd, float* part /*(V,N,3) scratch*/, float* g_xyz, hipStream_t st) {
+                           const float* g_dd, float* part /*(V,N,3) scratch*/, float* g_xyz, float* tr, float* sc_vis, hipStream_t st) {
   if (N <= 0) return NL_OK;
+  if (tr) NL_CHECK_HIP(hipMemsetAsync(tr, 0, sizeof(float) * (size_t)vw.V * N * DEC_TR_ROW, st));   // rows without a gradient are skipped by the kernels
   if (dpack) {   // non-fp32 modes: the decoders on the matrix pipe
     const int tpv = (int)nl_cdiv(N, 32), total = tpv * vw.V;
     const int blocks = (int)(nl_cdiv(total, 4) < 2048 ? nl_cdiv(total, 4) : 2048);
-    hipLaunchKernelGGL(dec_backward_mfma_kernel, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, g_vis, g_dd, part);
+    hipLaunchKernelGGL(dec_backward_mfma_kernel, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, g_vis, g_dd, part, tr, sc_vis);
   } else {
     dim3 grid((unsigned)nl_cdiv(N, 256), (unsigned)vw.V);
-    hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, part);
+    hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, part, tr, sc_vis);
   }
   hipLaunchKernelGGL(view_sum_kernel, dim3((unsigned)nl_cdiv(3 * N, 256)), dim3(256), 0, st, part, vw.V, (size_t)3 * N, g_xyz);
   NL_LAUNCH_CHECK();
@@ -1158,10 +1257,23 @@ int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float
 }
 
 int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
-                             const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, hipStream_t st) {
+                             const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, float* tr,
+                             hipStream_t st) {
   if (N <= 0) return NL_OK;
   hipLaunchKernelGGL(blend_backward_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgbv, (int)N, V, w2, b2, w4, b4, blw, g_rgb_s, g_hA, g_pf,
-                     g_rgbv, g_ang);
+                     g_rgbv, g_ang, tr);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_blend_inputs8(const NlViews& vw, const float* viewsdev, const float* xyz, int64_t N, const float* rgbv, float* x8, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(blend_inputs8_kernel, dim3((unsigned)nl_cdiv(N * vw.V, 256)), dim3(256), 0, st, vw, viewsdev, xyz, (int)N, rgbv, x8);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+int nl_launch_blw_unpack(const float* t, float* g, int W, int F, hipStream_t st) {
+  hipLaunchKernelGGL(blw_unpack_kernel, dim3(1), dim3(256), 0, st, t, g, W, F);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -153,6 +153,55 @@ class PointBranchTrainFn(torch.autograd.Function):
         return (gx, gd, gg, tg.support_feature, None, None) + tuple(tg.weights.get(n) for n in POINT_PARAMS)
 
 
+_DEC = [f"multiview_aggregator.dist_decoder.{d}_decoder.{i}.{t}" for d in ("mean", "var", "aw", "vis") for i in (0, 2, 4) for t in ("weight", "bias")]
+MV_PARAMS = tuple(f"multiview_aggregator.out_fc.{i}.{t}" for i in (0, 2) for t in ("weight", "bias")) + tuple(_DEC)
+BLEND_PARAMS = tuple(f"rgb_blending_mlp.{i}.{t}" for i in (0, 2, 4) for t in ("weight", "bias")) + tuple(_DEC)
+
+
+class MvAggTrainFn(torch.autograd.Function):
+    """MvAggFn for a training step: (xyz, feature maps (V,h,w,C), DepthFusionNet maps (V,32,vh,vw), renderer, *MV_PARAMS tensors) -> (G, valid_s);
+    backward = nl_mv_aggregate_backward_train: also d/d out_fc, d/d the four decoders, d/d both maps."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat_maps, vis_maps, renderer, *params):
+        xyz = xyz.contiguous()
+        ctx.r = renderer
+        ctx.save_for_backward(xyz)
+        mv, _, _, valid = renderer.mv_aggregate(xyz, torch.zeros(3), want_raw=False)
+        ctx.mark_non_differentiable(valid)
+        return mv, valid
+
+    @staticmethod
+    def backward(ctx, g_mv, _g_valid):
+        xyz, = ctx.saved_tensors
+        names = [n for n, need in zip(MV_PARAMS, ctx.needs_input_grad[4:]) if need]
+        tg = ctx.r.train_grads(names, feat_maps=ctx.needs_input_grad[1], vis_featmaps=ctx.needs_input_grad[2])
+        gx = ctx.r.mv_aggregate_backward(xyz, g_mv.contiguous(), train=tg)
+        return (gx if ctx.needs_input_grad[0] else None, tg.feat_maps, tg.vis_featmaps, None) + tuple(tg.weights.get(n) for n in MV_PARAMS)
+
+
+class BlendTrainFn(torch.autograd.Function):
+    """BlendFn for a training step: (xyz, feature_agg, query centre, blend-projected maps P (V,h,w,32) = feature maps . the feature columns of
+    rgb_blending_mlp.0 [its graph carries those columns' and the maps' gradient], DepthFusionNet maps, renderer, *BLEND_PARAMS) -> rgb_s (N,3);
+    backward = nl_blend_backward_train."""
+
+    @staticmethod
+    def forward(ctx, xyz, fa, qc, pmaps, vis_maps, renderer, *params):
+        xyz, fa = xyz.contiguous(), fa.contiguous()
+        ctx.r = renderer
+        ctx.save_for_backward(xyz, fa, qc)
+        return renderer.blend(xyz, qc, fa)
+
+    @staticmethod
+    def backward(ctx, g_rgb_s):
+        xyz, fa, qc = ctx.saved_tensors
+        names = [n for n, need in zip(BLEND_PARAMS, ctx.needs_input_grad[6:]) if need]
+        tg = ctx.r.train_grads(names, vis_featmaps=ctx.needs_input_grad[4], blend_feat_maps=ctx.needs_input_grad[3])
+        gx, gfa, gq = ctx.r.blend_backward(xyz, qc, fa, g_rgb_s.contiguous(), want_g_query_center=ctx.needs_input_grad[2], train=tg)
+        return (gx if ctx.needs_input_grad[0] else None, gfa, None if gq is None else gq.to(qc.dtype), tg.blend_feat_maps, tg.vis_featmaps, None) + \
+            tuple(tg.weights.get(n) for n in BLEND_PARAMS)
+
+
 class MvAggFn(torch.autograd.Function):
     """Multi-view aggregation (multiview_aggregator.py:156-222) with frozen weights / support maps as one autograd node on the HIP library:
     xyz (N,3) -> (G (N,W), valid_s (N) int32 [non-differentiable: #views that see the sample > 1]); backward = nl_mv_aggregate_backward."""
@@ -419,27 +468,36 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3)
     frozen = frozen_renderer is not None and _hip_ok(xyz, dirs)
+    hip_train = not frozen and train_renderer is not None and _hip_ok(xyz, dirs) and fr["support"]["xyz"].shape[0] >= 1
+    r = frozen_renderer if frozen else train_renderer
     if frozen:
         # frozen weights + frozen per-frame tables (pose refinement): aggregation, neural-point branch and blend are three autograd nodes whose
         # forward AND backward run in the HIP library; nothing of them is kept on the tape but their inputs
-        G, valid_s = MvAggFn.apply(xyz, frozen_renderer)
-        agg = PointBranchFn.apply(xyz, dirs.contiguous(), G, frozen_renderer, 8)
+        G, valid_s = MvAggFn.apply(xyz, r)
+        agg = PointBranchFn.apply(xyz, dirs.contiguous(), G, r, 8)
+    elif hip_train:
+        # a training step: the same three nodes, whose backward also returns the gradients of their parameters and of the per-frame tensors
+        G, valid_s = MvAggTrainFn.apply(xyz, fr["feat_fine_src"], fr["vis_featmaps"], r, *[p[n] for n in MV_PARAMS])
+        agg = PointBranchTrainFn.apply(xyz, dirs.contiguous(), G, fr["support"]["feature"], r, 8, *[p[n] for n in POINT_PARAMS])
     else:
         G, mvf, mvv, mask1 = _mv_aggregate(p, fr, xyz)
-        if train_renderer is not None and _hip_ok(xyz, dirs, G) and fr["support"]["xyz"].shape[0] >= 1:
-            agg = PointBranchTrainFn.apply(xyz, dirs.contiguous(), G, fr["support"]["feature"], train_renderer, 8, *[p[n] for n in POINT_PARAMS])
-        else:
-            with torch.no_grad():
-                idx = knn_idx(xyz.detach()).long()
-            agg = _point_branch(p, fr, xyz, dirs, G, idx)
+        with torch.no_grad():
+            idx = knn_idx(xyz.detach()).long()
+        agg = _point_branch(p, fr, xyz, dirs, G, idx)
     W = agg.shape[1]
-    if frozen and S == frozen_renderer.S:
-        geo = UnetFn.apply(agg, frozen_renderer)
+    if frozen and S == r.S:
+        geo = UnetFn.apply(agg, r)
     else:
         geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
     sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)
     if frozen:
-        rgb_s = BlendFn.apply(xyz, agg, query_pose[:3, 3], frozen_renderer).view(R, S, 3)
+        rgb_s = BlendFn.apply(xyz, agg, query_pose[:3, 3], r).view(R, S, 3)
+    elif hip_train:
+        # the feature columns of rgb_blending_mlp.0 act on bilinear taps of the feature maps = taps of the projected maps (linearity): the
+        # projection is one small product per frame here, its graph carries those columns' and the maps' share of the gradient
+        Cf = fr["feat_fine_src"].shape[-1]
+        pmaps = F.linear(fr["feat_fine_src"], p["rgb_blending_mlp.0.weight"][:, W + 3:W + 3 + Cf])
+        rgb_s = BlendTrainFn.apply(xyz, agg, query_pose[:3, 3], pmaps, fr["vis_featmaps"], r, *[p[n] for n in BLEND_PARAMS]).view(R, S, 3)
     else:
         V = mvf.shape[1]
         ang = _view_angles(xyz, query_pose[:3, 3], fr["topk_poses"][:, :3, 3])
@@ -457,7 +515,7 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
         rgb, depth, unc, feat, wts = CompositeFn.apply(sigma, rgb_s, ft, z_vals, white_bkgd)
     else:
         rgb, depth, unc, feat, wts = composite_eager(sigma, rgb_s, ft, z_vals, white_bkgd)
-    valid = (valid_s.view(R, S) > 0).float().sum(1) > 8 if frozen else (mask1.view(R, S, -1).sum(2) > 1).float().sum(1) > 8
+    valid = (valid_s.view(R, S) > 0).float().sum(1) > 8 if (frozen or hip_train) else (mask1.view(R, S, -1).sum(2) > 1).float().sum(1) > 8
     out = {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": unc}
     if beta:
         out["beta"] = (wts * F.softplus(_lin(p, "beta_mlp.0", geo)).view(R, S)).sum(1) + 0.1   # beta_min, model.py:98

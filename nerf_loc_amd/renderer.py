@@ -27,7 +27,8 @@ class TrainGrads:
     """Gradient buffers of one training step (nl_train_grads): `.weights[name]` fp32 tensors shaped like the state_dict entries,
     `.support_feature` (M, C+3) or None; the library ADDS into them, so one object serves all backward calls (and chunks) of a step."""
 
-    def __init__(self, renderer: "HipRenderer", names: Sequence[str], support_feature: bool):
+    def __init__(self, renderer: "HipRenderer", names: Sequence[str], support_feature: bool, feat_maps: bool = False, vis_featmaps: bool = False,
+                 blend_feat_maps: bool = False):
         all_names = L.weight_names()
         shapes = renderer.weight_shapes()
         unknown = [n for n in names if n not in shapes]
@@ -39,13 +40,23 @@ class TrainGrads:
         for i, n in enumerate(all_names):
             self._arr[i] = self.weights[n].data_ptr() if n in self.weights else None
         self.support_feature = torch.zeros(renderer.M, renderer.C + 3, device=dev) if support_feature else None
+        shp = renderer._map_shapes
+        self.feat_maps = torch.zeros(shp[0], device=dev) if feat_maps else None
+        self._vis_hwc = torch.zeros(shp[1], device=dev) if vis_featmaps else None
+        self.blend_feat_maps = torch.zeros(shp[2], device=dev) if blend_feat_maps else None
         nb = renderer.lib.nl_train_scratch_bytes(ct.byref(renderer.cfg))
         self._scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         self.c = L.NlTrainGrads()
         self.c.weights = ct.cast(self._arr, ct.POINTER(ct.c_void_p))
         self.c.support_feature = _ptr(self.support_feature)
+        self.c.feat_maps, self.c.vis_featmaps, self.c.blend_feat_maps = _ptr(self.feat_maps), _ptr(self._vis_hwc), _ptr(self.blend_feat_maps)
         self.c.scratch = self._scratch.data_ptr()
         self.c.scratch_bytes = nb
+
+    @property
+    def vis_featmaps(self):
+        """(V, 32, vh, vw) like data's DepthFusionNet maps (the library accumulates channels-last)."""
+        return None if self._vis_hwc is None else self._vis_hwc.permute(0, 3, 1, 2)
 
 
 class HipRenderer:
@@ -142,6 +153,7 @@ class HipRenderer:
         self._frame = fr
         self._frame_keep = (images, feat, visf, sp, mem, proj_ibr, proj_neuray, cams)
         self.V, self.near, self.far, self.M = V, float(near), float(far), M
+        self._map_shapes = ((V, h, w, feat.shape[3]), (V, visf.shape[2], visf.shape[3], 32), (V, h, w, 32))
 
     def clear_frame(self) -> None:
         if self._frame:
@@ -290,15 +302,21 @@ class HipRenderer:
                                               self._stream()), "nl_ray_unet_backward")
         return gx
 
-    def mv_aggregate_backward(self, xyz, g_mv_feat, workspace_samples: Optional[int] = None):
-        """Input gradient of `mv_aggregate`'s feature rows with frozen weights / maps (nl_mv_aggregate_backward): -> g_xyz (N,3)."""
+    def mv_aggregate_backward(self, xyz, g_mv_feat, workspace_samples: Optional[int] = None, train: "TrainGrads" = None):
+        """Input gradient of `mv_aggregate`'s feature rows (nl_mv_aggregate_backward): -> g_xyz (N,3).  train: also ADD the gradients of out_fc, the
+        decoders, the feature maps and the DepthFusionNet maps into that TrainGrads (nl_mv_aggregate_backward_train)."""
         self._ready()
         x, g = _dev_f32(xyz, self.device), _dev_f32(g_mv_feat, self.device)
         N = x.shape[0]
         gx = torch.empty(N, 3, device=self.device)
-        ws = self._workspace(self.lib.nl_mv_aggregate_backward_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        wsb = self.lib.nl_mv_aggregate_backward_workspace_bytes if train is None else self.lib.nl_mv_aggregate_backward_train_workspace_bytes
+        ws = self._workspace(wsb(ct.byref(self.cfg), self.V, N))
         if workspace_samples is not None:
-            ws = ws[: self.lib.nl_mv_aggregate_backward_workspace_bytes(ct.byref(self.cfg), self.V, int(workspace_samples))]
+            ws = ws[: wsb(ct.byref(self.cfg), self.V, int(workspace_samples))]
+        if train is not None:
+            L.check(self.lib.nl_mv_aggregate_backward_train(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), N, g.data_ptr(), gx.data_ptr(),
+                                                            ct.byref(train.c), ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate_backward_train")
+            return gx
         L.check(self.lib.nl_mv_aggregate_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), N, g.data_ptr(), gx.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), self._stream()), "nl_mv_aggregate_backward")
         return gx
@@ -315,8 +333,10 @@ class HipRenderer:
                                   ws.data_ptr(), ws.numel(), self._stream()), "nl_blend")
         return out
 
-    def blend_backward(self, xyz, query_center, feature_agg, g_rgb_s, want_g_query_center: bool = True, workspace_samples: Optional[int] = None):
-        """nl_blend_backward: -> (g_xyz (N,3), g_feature_agg (N,W), g_query_center (3,) or None)."""
+    def blend_backward(self, xyz, query_center, feature_agg, g_rgb_s, want_g_query_center: bool = True, workspace_samples: Optional[int] = None,
+                       train: "TrainGrads" = None):
+        """nl_blend_backward: -> (g_xyz (N,3), g_feature_agg (N,W), g_query_center (3,) or None).  train: also ADD the gradients of rgb_blending_mlp, the
+        decoders, the DepthFusionNet maps and the blend-projected feature maps into that TrainGrads (nl_blend_backward_train)."""
         self._ready()
         x, fa, g = _dev_f32(xyz, self.device), _dev_f32(feature_agg, self.device), _dev_f32(g_rgb_s, self.device)
         N = x.shape[0]
@@ -324,19 +344,27 @@ class HipRenderer:
         gx = torch.empty(N, 3, device=self.device)
         gfa = torch.empty(N, self.W, device=self.device)
         gq = torch.empty(N, 3, device=self.device) if want_g_query_center else None
-        ws = self._workspace(self.lib.nl_blend_workspace_bytes(ct.byref(self.cfg), self.V, N))
+        wsb = self.lib.nl_blend_workspace_bytes if train is None else self.lib.nl_blend_backward_train_workspace_bytes
+        ws = self._workspace(wsb(ct.byref(self.cfg), self.V, N))
         if workspace_samples is not None:
-            ws = ws[: self.lib.nl_blend_workspace_bytes(ct.byref(self.cfg), self.V, int(workspace_samples))]
+            ws = ws[: wsb(ct.byref(self.cfg), self.V, int(workspace_samples))]
+        if train is not None:
+            L.check(self.lib.nl_blend_backward_train(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), fa.data_ptr(), N,
+                                                     g.data_ptr(), gx.data_ptr(), gfa.data_ptr(), _ptr(gq), ct.byref(train.c), ws.data_ptr(), ws.numel(),
+                                                     self._stream()), "nl_blend_backward_train")
+            return gx, gfa, (None if gq is None else gq.sum(0))
         L.check(self.lib.nl_blend_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), x.data_ptr(), fa.data_ptr(), N, g.data_ptr(),
                                            gx.data_ptr(), gfa.data_ptr(), _ptr(gq), ws.data_ptr(), ws.numel(), self._stream()), "nl_blend_backward")
         return gx, gfa, (None if gq is None else gq.sum(0))
 
     # ------------------------------------------------------------------ training: weight gradients
-    def train_grads(self, names: Sequence[str], support_feature: bool = False) -> "TrainGrads":
-        """Zero-filled gradient buffers for the listed state_dict tensors (and the support table's features): hand the object to the
-        `*_backward(..., train=...)` calls of one step, then read `.weights[name]` / `.support_feature`."""
+    def train_grads(self, names: Sequence[str], support_feature: bool = False, feat_maps: bool = False, vis_featmaps: bool = False,
+                    blend_feat_maps: bool = False) -> "TrainGrads":
+        """Zero-filled gradient buffers for the listed state_dict tensors (and the per-frame tensors asked for): hand the object to the
+        `*_backward(..., train=...)` calls of one step, then read `.weights[name]` / `.support_feature` / `.feat_maps` (V,h,w,C) /
+        `.vis_featmaps` (V,32,vh,vw) / `.blend_feat_maps` (V,h,w,32)."""
         self._ready()
-        return TrainGrads(self, names, support_feature)
+        return TrainGrads(self, names, support_feature, feat_maps, vis_featmaps, blend_feat_maps)
 
     def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None, workspace_samples: Optional[int] = None, train: "TrainGrads" = None):
         """Input gradient of `point_mlp` (nl_point_mlp_backward): -> (g_xyz (N,3), g_direction (N,3) or None, g_mv_feat (N,W)).
