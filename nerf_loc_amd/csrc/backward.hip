@@ -6,6 +6,7 @@
 // Both are called from nerf_loc_amd/diff_render.py (autograd.Function) when the gradient path runs on the GPU, and are checked against
 // PyTorch autograd of the same expressions and, end to end, against the reference's autograd goldens (tests/test_backward_kernels.py,
 // tests/test_diff_render.py).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -734,6 +735,31 @@ namespace {
 using namespace nlmv;
 
 // backward of one 32-32-32-{1,2} decoder (visibility_decoder.py:64-97; ELU between the layers): recomputes the hidden layers, adds W0^T g_h1 to gx
+// Scatter-add of per-lane values into a map where NEIGHBOURING LANES MOSTLY HIT THE SAME TEXEL (consecutive samples of a ray in one view): plain
+// atomics serialise on that texel (7 ms per training step measured).  Segmented inclusive scan over the lanes of a group (runs of equal keys are
+// contiguous along a ray), then only the last lane of every run issues the atomic: 5-8x fewer, and no two of them back to back on one address.
+// key < 0: lane takes no part.  All lanes of the group must call.
+template <int WIDTH, int NS>
+struct SegMerge {
+  bool mg[NS], last;
+  __device__ __forceinline__ SegMerge(int key, int j) {
+    // first lane of the CONTIGUOUS run this lane belongs to (equal keys further away, behind another texel, are a run of their own)
+    // (every cross-lane read is its own statement: behind a short-circuit || the source lanes would be switched off)
+    const int kprev = __shfl_up(key, 1, WIDTH), knext = __shfl_down(key, 1, WIDTH);
+    int start = (j == 0 || kprev != key) ? j : 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { const int o = __shfl_up(start, 1 << s, WIDTH); if (j >= (1 << s)) start = max(start, o); }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mg[s] = j - (1 << s) >= start;
+    last = (j == WIDTH - 1) || knext != key;
+  }
+  __device__ __forceinline__ float sum(float v) const {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { const float o = __shfl_up(v, 1 << s, WIDTH); if (mg[s]) v += o; }
+    return v;
+  }
+};
+
 // trd (training): this decoder's 132 floats of the row [h1 32 | h2 32 | d pre-activation 1 32 | d pre-activation 2 32 | d outputs 2 | pad 2]
 constexpr int DEC_TR_D = 132, DEC_TR_ROW = 32 + 4 * DEC_TR_D;
 __device__ __forceinline__ void decoder_backward(const float* __restrict__ w, const float (&x)[32], float go0, float go1, float (&gx)[32], float* __restrict__ trd = nullptr) {
@@ -861,7 +887,8 @@ __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, con
   if (valid) {
 #pragma unroll
     for (int c = 0; c < 32; ++c) { gix = fmaf(gx[c], dxv[c], gix); giy = fmaf(gx[c], dyv[c], giy); }
-    if (sc_vis) {   // interpolate_feats' backward towards the DepthFusionNet map (border mode: clamped texels receive the weight of every tap that maps to them)
+    if (sc_vis) {   // interpolate_feats' backward towards the DepthFusionNet map (border mode: a clamped texel receives the weight of every tap that maps to it).
+      // Plain atomics: this is the exact-fp32 path (lanes leave early, so no cross-lane merging here; the MFMA kernel merges runs of equal texels)
       const Taps t = make_taps<false, true>(xn, yn, vw.vw, vw.vh);
       const TapD d = make_tapd(t, vw.vw, vw.vh);
       float* sb = sc_vis + (size_t)v * vw.vh * vw.vw * 32;
@@ -1066,14 +1093,20 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     for (int r = 0; r < 16; ++r) { gix = fmaf(gxa[r], dx[r], gix); giy = fmaf(gxa[r], dy[r], giy); }
     gix += __shfl_xor(gix, 32, 64); giy += __shfl_xor(giy, 32, 64);
     if (!valid) { gix = 0.f; giy = 0.f; }
-    if (sc_vis && valid && live) {   // this lane's 16 channels of the map gradient
+    if (sc_vis) {   // this lane's 16 channels of the map gradient; the 32 rows of the tile are consecutive samples: runs of equal texels are merged first
       float* sb = sc_vis + (size_t)v * vw.vh * vw.vw * 32 + 8 * hh;
       const float wk[4] = {d.s * d.e * d.m[0], d.s * d.w * d.m[1], d.n * d.e * d.m[2], d.n * d.w * d.m[3]};
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (wk[k] != 0.f)
+      for (int k = 0; k < 4; ++k) {
+        const bool on = valid && live && wk[k] != 0.f;
+        const int key = on ? d.o[k] : -1 - j;
+        const SegMerge<32, 5> sm(key, j);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) atomicAdd(sb + (size_t)d.o[k] * 32 + (r < 8 ? r : 8 + r), gxa[r] * wk[k]);
+        for (int r = 0; r < 16; ++r) {
+          const float t = sm.sum(on ? gxa[r] * wk[k] : 0.f);
+          if (sm.last && on) atomicAdd(sb + (size_t)key * 32 + (r < 8 ? r : 8 + r), t);
+        }
+      }
     }
     const float gpx = cxl ? 0.f : gix * (float)vw.vw / (float)(vw.Wimg - 1), gpy = cyl ? 0.f : giy * (float)vw.vh / (float)(vw.H - 1);
     const float gcx = gpx / depth, gcy = gpy / depth;

@@ -154,20 +154,125 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   }
 }
 
-// gW[m * ldc + n * cs + co] += sum_z part[z][m][n]  (fixed order);  gb[m] += sum_z bpart[z][m]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int nsplit, int M, int N, float* __restrict__ gW, int ldc, int cs,
-                                    int co, float* __restrict__ gb) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < M * N) {
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * M * N + e];
-    const int m = e / N, n = e - m * N;
-    gW[(size_t)m * ldc + (size_t)n * cs + co] += s;
+// The same product for the SMALL layers (M, N <= 32: the NeuRay decoders, the blend MLP's tail, ray_diff_fc): one 32 x 32 tile per workgroup, so the
+// four waves split the ROWS instead — a step is 128 rows, wave w multiplies rows 32 w .. 32 w + 31 of it — and add their accumulators through LDS at
+// the end.  16x fewer MFMAs than padding the tile to 128 x 128.
+constexpr int WS_S = 16 * 16 + 32, WS_KG = 4 * WS_S, WS_PLANE = 16 * WS_KG, WS_LDS = 2 * WS_PLANE;
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const WgArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[WS_LDS];
+  __shared__ float bsum[16][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = tid & 15, kg = tid >> 4;          // loader role: columns 4 cg .. + 3 of the 64 (32 of dY | 32 of X), rows 8 kg .. + 7 of the 128
+  const bool isA = cg < 8;
+  const int col0 = isA ? 4 * cg : 4 * (cg - 8);
+  const float* src = isA ? a.dY : a.X;
+  const int ld = isA ? a.ldy : a.ldx;
+  const bool colok = col0 < (isA ? a.M : a.N);
+  const int shift = isA ? 0 : a.shift;
+  const long long r_begin = (long long)blockIdx.z * a.rows_per_split;
+  const long long r_end = min(a.rows, r_begin + a.rows_per_split);
+  const bool want_bias = a.bpart && isA;
+  float4 ld_[8];
+  auto fetch = [&](long long r0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const long long r = r0 + 8 * kg + t;
+      bool ok = colok && r < r_end;
+      long long rr = r;
+      if (shift != 0) {
+        const int s = (int)((unsigned)r % (unsigned)a.period) + shift;
+        ok = ok && s >= 0 && s < a.period;
+        rr = r + shift;
+      }
+      ld_[t] = ok ? *(const float4*)(src + (size_t)rr * ld + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto stage = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = c == 0 ? ld_[t].x : c == 1 ? ld_[t].y : c == 2 ? ld_[t].z : ld_[t].w;
+      if (want_bias) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bs[c] += v[t];
+      }
+      uint4 hi, lo;
+      wg_split(v, hi, lo);
+      char* p = lds + kg * WS_KG + c * WS_S + cg * 16;
+      *(uint4*)p = hi;
+      *(uint4*)(p + WS_PLANE) = lo;
+    }
+  };
+  auto frag = [&](int col, int kgi, int plane) {
+    return __builtin_bit_cast(wg_bf16x8, *(const uint4*)(lds + plane * WS_PLANE + kgi * WS_KG + (col & 3) * WS_S + (col >> 2) * 16));
+  };
+  const int hh = lane >> 5, i = lane & 31;
+  wg_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (r_begin < r_end) fetch(r_begin);
+  for (long long r0 = r_begin; r0 < r_end; r0 += 128) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (r0 + 128 < r_end) fetch(r0 + 128);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kgi = 4 * wave + 2 * s + hh;
+      const wg_bf16x8 ah = frag(i, kgi, 0), al = frag(i, kgi, 1), bh = frag(32 + i, kgi, 0), bl = frag(32 + i, kgi, 1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
   }
-  if (gb && bpart && e < M) {
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += bpart[(size_t)z * M + e];
-    gb[e] += s;
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);   // [wave][r 16][lane 64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  if (want_bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bsum[kg][4 * cg + c] = bs[c];
+  }
+  __syncthreads();
+  float* part = a.part + (size_t)blockIdx.z * a.M * a.N;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // 1024 outputs, 256 threads
+    const int e = q * 256 + tid, r = e >> 6, l = e & 63;
+    const float v = (red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l]) + (red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l]);
+    const int m = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3), n = l & 31;
+    if (m < a.M && n < a.N) part[(size_t)m * a.N + n] = v;
+  }
+  if (a.bpart && tid < 32 && tid < a.M) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += bsum[g][tid];
+    a.bpart[(size_t)blockIdx.z * a.M + tid] = v;
+  }
+}
+
+// gW[m * ldc + n * cs + co] += sum_z part[z][m][n]  (fixed order);  gb[m] += sum_z bpart[z][m]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int nsplit, int M, int N,
+                                                           float* __restrict__ gW, int ldc, int cs, int co, float* __restrict__ gb) {
+  // 32 elements per block, 8 threads each over interleaved row ranges, combined in a fixed order
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, zz = threadIdx.x >> 5;
+  const int tot = M * N + (gb && bpart ? M : 0);
+  const int e = blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (e < tot) {
+    const bool isb = e >= M * N;
+    const float* src = isb ? bpart + (e - M * N) : part + e;
+    const size_t stride = isb ? (size_t)M : (size_t)M * N;
+    for (int z = zz; z < nsplit; z += 8) s += src[(size_t)z * stride];
+  }
+  red[zz][el] = s;
+  __syncthreads();
+  if (zz == 0 && e < tot) {
+    const float v = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+    if (e < M * N) { const int m = e / N, n = e - m * N; gW[(size_t)m * ldc + (size_t)n * cs + co] += v; }
+    else gb[e - M * N] += v;
   }
 }
 
@@ -186,23 +291,25 @@ int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, in
   if (rows <= 0 || M <= 0 || N <= 0) return NL_OK;
   if ((ldy & 3) || (ldx & 3) || ((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return NL_ERR_UNSUPPORTED;
   if ((shift != 0 && period <= 0) || rows >= (1ll << 31)) return NL_ERR_BAD_ARG;
-  const int nbm = (int)nl_cdiv(M, 128), nbn = (int)nl_cdiv(N, 128);
-  int nsplit = 1024 / (nbm * nbn);
-  const int64_t maxsplit = nl_cdiv(rows, 256);
+  const bool small = M <= 32 && N <= 32;
+  const int nbm = small ? 1 : (int)nl_cdiv(M, 128), nbn = small ? 1 : (int)nl_cdiv(N, 128);
+  int nsplit = small ? 256 : 1024 / (nbm * nbn);
+  const int64_t maxsplit = nl_cdiv(rows, small ? 1024 : 256);
   if (nsplit > maxsplit) nsplit = (int)maxsplit;
   if (nsplit > 256) nsplit = 256;
   if (nsplit < 1) nsplit = 1;
   if ((size_t)nsplit * ((size_t)M * N + M) > scratch_floats) return NL_ERR_WORKSPACE;
   WgArgs a;
   a.dY = dY; a.ldy = ldy; a.M = M; a.X = X; a.ldx = ldx; a.N = N; a.rows = rows;
-  a.rows_per_split = nl_align_up((size_t)nl_cdiv(rows, nsplit), 32);
+  a.rows_per_split = nl_align_up((size_t)nl_cdiv(rows, nsplit), 128);
   nsplit = (int)nl_cdiv(rows, a.rows_per_split);
   a.shift = shift; a.period = period > 0 ? period : 1;
   a.part = scratch; a.bpart = gb ? scratch + (size_t)nsplit * M * N : nullptr;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nbm, nbn, nsplit), dim3(256), 0, st, a);
+  if (small) hipLaunchKernelGGL(wgrad_small_kernel, dim3(1, 1, nsplit), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel, dim3(nbm, nbn, nsplit), dim3(256), 0, st, a);
   NL_LAUNCH_CHECK();
-  const int tot = M * N;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nl_cdiv(tot, 256)), dim3(256), 0, st, a.part, a.bpart, nsplit, M, N, gW, ldc, cs, co, gb);
+  const int tot = M * N + (gb ? M : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nl_cdiv(tot, 32)), dim3(256), 0, st, a.part, a.bpart, nsplit, M, N, gW, ldc, cs, co, gb);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -64,3 +64,11 @@ for n, a, b in zip(names, res[True][3], res[False][3]):
 print(f"{R} rays x {S} samples, W = {W}: training step (render forward + backward to all parameters) eager fp32 graph {res[False][0]*1e3:.1f} ms / "
       f"{res[False][1]:.1f} GiB; with the library's training nodes {res[True][0]*1e3:.1f} ms / {res[True][1]:.1f} GiB; "
       f"loss {float(res[False][2]):.6f} vs {float(res[True][2]):.6f}; largest per-tensor gradient difference {worst[1]:.2e} ({worst[0]})")
+if os.environ.get("PROFILE"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(3): step(True)
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.self_device_time_total)[:28]
+    for e in rows:
+        print(f"{e.self_device_time_total / 3e3:8.3f} ms/step  {e.count // 3:4d} calls  {e.key[:110]}")
