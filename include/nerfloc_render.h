@@ -316,6 +316,11 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
                             const float* feature_agg, int64_t N, const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center,
                             const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
 
+/* nl_ray_unet_backward + gradients of the seven blocks' convolution weights / biases and LayerNorm([C, L]) tables (28 tensors). */
+size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R);
+int nl_ray_unet_backward_train(const nl_config* cfg, const void* packed, const float* x, int64_t R, const float* g_geo, float* g_x,
+                               const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
+
 /* Input gradient of nl_mv_aggregate's feature rows (rows a4-a7; multiview_aggregator.py:156-222, ibrnet.py:169-231, visibility_decoder.py:64-148)
  * with frozen weights and frozen support maps: g_mv_feat (N,W) -> g_xyz (N,3).  The forward is recomputed in exact fp32; the way back goes through
  * out_fc (transposed-weight products, ELU), the visibility-weighted statistics, the bilinear taps' spatial derivative (zeros padding,

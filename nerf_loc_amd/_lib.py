@@ -96,6 +96,8 @@ SYMBOLS = [
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
+    ("nl_ray_unet_backward_train_workspace_bytes", _Z, [_CFG, _L]),
+    ("nl_ray_unet_backward_train", _I, [_CFG, _P, _P, _L, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_mv_aggregate_backward_train_workspace_bytes", _Z, [_CFG, _I, _L]),
     ("nl_mv_aggregate_backward_train", _I, [_CFG, _P, _P, _P, _L, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_blend_backward_train_workspace_bytes", _Z, [_CFG, _I, _L]),

@@ -84,7 +84,8 @@ int nl_launch_blend_inputs8(const NlViews& vw, const float* viewsdev, const floa
 int nl_launch_blw_unpack(const float* t, float* g, int W, int F, hipStream_t st);
 int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
 int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
-                                   float* g_x, hipStream_t st);
+                                   float* g_x, float* aff, hipStream_t st);
+int nl_launch_table_add_t(const float* t, float* g, int L, int Cc, hipStream_t st);
 int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, int ldo, int64_t rows, int cols, hipStream_t st);
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
@@ -1072,8 +1073,8 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
 }
 
 // ---- input gradient of the ray U-Net (frozen weights) -------------------------------------------------------------------------------
-struct UnBwdBufs { UnBufs u; float *geo, *gout, *gx2, *gx2r, *gcat1, *gx1r, *gcat2, *gx0r, *gc3, *gr3, *gc2, *gr2, *gc1, *gr1, *tmp; };
-void carve_unb(Bump& b, const nl_config* c, int64_t R, UnBwdBufs& q) {
+struct UnBwdBufs { UnBufs u; float *geo, *gout, *gx2, *gx2r, *gcat1, *gx1r, *gcat2, *gx0r, *gc3, *gr3, *gc2, *gr2, *gc1, *gr1, *tmp, *aff; };
+void carve_unb(Bump& b, const nl_config* c, int64_t R, UnBwdBufs& q, bool train = false) {
   const size_t N = (size_t)R * c->S;
   const int W = c->W;
   carve_un(b, c, R, q.u);
@@ -1085,12 +1086,13 @@ void carve_unb(Bump& b, const nl_config* c, int64_t R, UnBwdBufs& q) {
   q.gc2 = b.take<float>(N / 4 * 128); q.gr2 = b.take<float>(N / 2 * 128);
   q.gc1 = b.take<float>(N / 2 * 64); q.gr1 = b.take<float>(N * 64);
   q.tmp = b.take<float>(N * W);
+  q.aff = train ? b.take<float>(2 * N * W) : nullptr;   // the largest slab (conv_out: S x W per ray), [d y * xhat | d y]
 }
 
 // Unfused forward in exact fp32 (every layer's pre-LayerNorm output stays in the workspace), then layer by layer backwards: LayerNorm / ELU /
 // MaxPool derivative (one block per ray) -> transposed-weight convolution (segment GEMM over the gradient rows' taps), the skip connections'
 // gradients added where the concatenations were.
-int do_unet_backward(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, const float* g_geo, float* g_in, const UnBwdBufs& q) {
+int do_unet_backward(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, const float* g_geo, float* g_in, const UnBwdBufs& q, const TrainOut* tg = nullptr) {
   const int W = x32.c->W, S = x32.c->S;
   const UnBufs& u = q.u;
   NL_TRY(do_unet(x32, in, R, q.geo, u));   // fp32: separate GEMM + ln_slab_elu launches
@@ -1098,35 +1100,88 @@ int do_unet_backward(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, 
   auto b = [&](int i) { return x32.p<float>(x32.L.un_b[i]); };
   const float eps = 1e-5f;
   hipStream_t st = x32.st;
+  // LayerNorm / ELU / MaxPool backward of block `li`; training: + its affine tables' gradients (column sums over the rays, transposed into the
+  // state_dict's (C, L) layout)
+  auto ln_bwd = [&](int li, const float* x, int L, int Cc, const float* go, int ldgo, int pool, float* gx) -> int {
+    float* gw = tg ? tg->w[T_UNET + 4 * li + 2] : nullptr;
+    float* gb = tg ? tg->w[T_UNET + 4 * li + 3] : nullptr;
+    const bool aff = gw || gb;
+    NL_TRY(nl_launch_ln_slab_elu_backward(x, R, L, Cc, g(li), b(li), eps, go, ldgo, pool, gx, aff ? q.aff : nullptr, st));
+    if (!aff) return NL_OK;
+    const int n = L * Cc;
+    float* sums = tg->scratch;                       // (2 n) sums, then the partials of nl_launch_colsum
+    NL_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * n, st));
+    NL_TRY(nl_launch_colsum(q.aff, 2 * n, R, 2 * n, sums, sums + 2 * n, st));
+    if (gw) NL_TRY(nl_launch_table_add_t(sums, gw, L, Cc, st));
+    if (gb) NL_TRY(nl_launch_table_add_t(sums + n, gb, L, Cc, st));
+    return NL_OK;
+  };
+  // Conv1d(k = 3, padding 1) weight (co, ci_total, 3): one product per tap, the input rows shifted by tap - 1 inside each ray
+  auto conv_wg = [&](int li, const float* dY, int co, const float* X, int ci, int ci_total, int ci0, int L, bool bias) -> int {
+    float* gw = tg ? tg->w[T_UNET + 4 * li] : nullptr;
+    float* gb = tg && bias ? tg->w[T_UNET + 4 * li + 1] : nullptr;
+    if (!gw && gb) return nl_launch_colsum(dY, co, R * L, co, gb, tg->scratch, st);
+    if (!gw) return NL_OK;
+    for (int k = 0; k < 3; ++k)
+      NL_TRY(nl_launch_wgrad(dY, co, co, X, ci, ci, R * L, k - 1, L, gw, ci_total * 3, 3, ci0 * 3 + k, k == 1 ? gb : nullptr, tg->scratch, tg->scratch_floats, st));
+    return NL_OK;
+  };
+  // ConvTranspose1d(k = 3, stride 2, padding 1, output_padding 1) weight (ci_total, co, 3): y[2m] = x[m] w1, y[2m+1] = x[m] w2 + x[m+1] w0;
+  // gy = the merged rows (R Li, 2 co) [even | odd]
+  auto convT_wg = [&](int li, const float* X, int ci, int ci0, const float* gy, int co, int Li) -> int {
+    float* gw = tg ? tg->w[T_UNET + 4 * li] : nullptr;
+    if (!gw) return NL_OK;
+    float* base = gw + (size_t)ci0 * co * 3;
+    NL_TRY(nl_launch_wgrad(X, ci, ci, gy, 2 * co, co, R * Li, 0, 0, base, co * 3, 3, 1, nullptr, tg->scratch, tg->scratch_floats, st));
+    NL_TRY(nl_launch_wgrad(X, ci, ci, gy + co, 2 * co, co, R * Li, 0, 0, base, co * 3, 3, 2, nullptr, tg->scratch, tg->scratch_floats, st));
+    return nl_launch_wgrad(X, ci, ci, gy + co, 2 * co, co, R * Li, -1, Li, base, co * 3, 3, 0, nullptr, tg->scratch, tg->scratch_floats, st);
+  };
+  auto convT_bias = [&](int li, const float* gy, int co, int Lo) -> int {
+    float* gb = tg ? tg->w[T_UNET + 4 * li + 1] : nullptr;
+    return gb ? nl_launch_colsum(gy, co, R * Lo, co, gb, tg->scratch, st) : NL_OK;
+  };
   // conv_out
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, g_geo, W, 0, q.gout, st));
+  NL_TRY(ln_bwd(U_OUT, u.outr, S, W, g_geo, W, 0, q.gout));
+  NL_TRY(conv_wg(U_OUT, q.gout, W, in, W, W + 32, 0, S, true));
+  NL_TRY(conv_wg(U_OUT, q.gout, W, u.x2, 32, W + 32, W, S, false));
   { SegSpec s[1] = {{q.gout, W, W, 0, 1, 3}};
     NL_TRY(run_gemm(xb, G_UB_OUTA, s, 1, R * S, g_in, W, NL_ACT_NONE, S, S, S, 1, 0));
     NL_TRY(run_gemm(xb, G_UB_OUTB, s, 1, R * S, q.gx2, 32, NL_ACT_NONE, S, S, S, 1, 0)); }
   // trans_conv1: slab (S x 32) = merged rows (S/2 x 64)
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.x2r, R, S, 32, g(U_T1), b(U_T1), eps, q.gx2, 32, 0, q.gx2r, st));
+  NL_TRY(ln_bwd(U_T1, u.x2r, S, 32, q.gx2, 32, 0, q.gx2r));
+  NL_TRY(convT_wg(U_T1, u.c1, 64, 0, q.gx2r, 32, S / 2));
+  NL_TRY(convT_wg(U_T1, u.x1, 64, 64, q.gx2r, 32, S / 2));
+  NL_TRY(convT_bias(U_T1, q.gx2r, 32, S));
   { SegSpec s[2] = {{q.gx2r, 64, 64, 0, 1}, {q.gx2r + 32, 64, 32, -1, 1}};
     NL_TRY(run_gemm(xb, G_UB_T1, s, 2, R * (S / 2), q.gcat1, 128, NL_ACT_NONE, S / 2, S / 2, S / 2, 1, 0)); }
   // trans_conv2: output x1 = columns 64..127 of cat[c1, x1]'s gradient
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.x1r, R, S / 2, 64, g(U_T2), b(U_T2), eps, q.gcat1 + 64, 128, 0, q.gx1r, st));
+  NL_TRY(ln_bwd(U_T2, u.x1r, S / 2, 64, q.gcat1 + 64, 128, 0, q.gx1r));
+  NL_TRY(convT_wg(U_T2, u.c2, 128, 0, q.gx1r, 64, S / 4));
+  NL_TRY(convT_wg(U_T2, u.x0, 128, 128, q.gx1r, 64, S / 4));
+  NL_TRY(convT_bias(U_T2, q.gx1r, 64, S / 2));
   { SegSpec s[2] = {{q.gx1r, 128, 128, 0, 1}, {q.gx1r + 64, 128, 64, -1, 1}};
     NL_TRY(run_gemm(xb, G_UB_T2, s, 2, R * (S / 4), q.gcat2, 256, NL_ACT_NONE, S / 4, S / 4, S / 4, 1, 0)); }
   // trans_conv3: output x0 = columns 128..255 of cat[c2, x0]'s gradient
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.x0r, R, S / 4, 128, g(U_T3), b(U_T3), eps, q.gcat2 + 128, 256, 0, q.gx0r, st));
+  NL_TRY(ln_bwd(U_T3, u.x0r, S / 4, 128, q.gcat2 + 128, 256, 0, q.gx0r));
+  NL_TRY(convT_wg(U_T3, u.c3, 128, 0, q.gx0r, 128, S / 8));
+  NL_TRY(convT_bias(U_T3, q.gx0r, 128, S / 4));
   { SegSpec s[2] = {{q.gx0r, 256, 256, 0, 1}, {q.gx0r + 128, 256, 128, -1, 1}};
     NL_TRY(run_gemm(xb, G_UB_T3, s, 2, R * (S / 8), q.gc3, 128, NL_ACT_NONE, S / 8, S / 8, S / 8, 1, 0)); }
   // conv3 (+ MaxPool): gradient of its pooled output c3
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.r3, R, S / 4, 128, g(U_CONV3), b(U_CONV3), eps, q.gc3, 128, 1, q.gr3, st));
+  NL_TRY(ln_bwd(U_CONV3, u.r3, S / 4, 128, q.gc3, 128, 1, q.gr3));
+  NL_TRY(conv_wg(U_CONV3, q.gr3, 128, u.c2, 128, 128, 0, S / 4, true));
   { SegSpec s[1] = {{q.gr3, 128, 128, 0, 1, 3}};
     NL_TRY(run_gemm(xb, G_UB_C3, s, 1, R * (S / 4), q.tmp, 128, NL_ACT_NONE, S / 4, S / 4, S / 4, 1, 0)); }
   NL_TRY(nl_launch_add2d(q.gcat2, 256, q.tmp, 128, q.gc2, 128, R * (S / 4), 128, st));
   // conv2 (+ MaxPool)
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.r2, R, S / 2, 128, g(U_CONV2), b(U_CONV2), eps, q.gc2, 128, 1, q.gr2, st));
+  NL_TRY(ln_bwd(U_CONV2, u.r2, S / 2, 128, q.gc2, 128, 1, q.gr2));
+  NL_TRY(conv_wg(U_CONV2, q.gr2, 128, u.c1, 64, 64, 0, S / 2, true));
   { SegSpec s[1] = {{q.gr2, 128, 128, 0, 1, 3}};
     NL_TRY(run_gemm(xb, G_UB_C2, s, 1, R * (S / 2), q.tmp, 64, NL_ACT_NONE, S / 2, S / 2, S / 2, 1, 0)); }
   NL_TRY(nl_launch_add2d(q.gcat1, 128, q.tmp, 64, q.gc1, 64, R * (S / 2), 64, st));
   // conv1 (+ MaxPool)
-  NL_TRY(nl_launch_ln_slab_elu_backward(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, q.gc1, 64, 1, q.gr1, st));
+  NL_TRY(ln_bwd(U_CONV1, u.r1, S, 64, q.gc1, 64, 1, q.gr1));
+  NL_TRY(conv_wg(U_CONV1, q.gr1, 64, in, W, W, 0, S, true));
   { SegSpec s[1] = {{q.gr1, 64, 64, 0, 1, 3}};
     NL_TRY(run_gemm(xb, G_UB_C1, s, 1, R * S, q.tmp, W, NL_ACT_NONE, S, S, S, 1, 0)); }
   return nl_launch_add2d(g_in, W, q.tmp, W, g_in, W, R * S, W, st);
@@ -1507,7 +1562,10 @@ size_t nl_train_scratch_bytes(const nl_config* cfg) {
   // the largest weight the split-K kernel is asked for: conv_out (W, 3 (W + 32)) is done one tap at a time -> W x (W + 32); out_fc.0 64 x (2F + 3); base_mlp.0 W x (F + 90)
   size_t mx = (size_t)cfg->W * (F + 90);
   if ((size_t)64 * (2 * F + 3) > mx) mx = (size_t)64 * (2 * F + 3);
-  return sizeof(float) * nl_wgrad_scratch_floats(0, 1, (int)(mx + 256));
+  size_t fl = nl_wgrad_scratch_floats(0, 1, (int)(mx + 256));
+  const size_t ln = (size_t)258 * 2 * cfg->S * cfg->W;   // the U-Net's LayerNorm tables: 2 S W sums + up to 256 partial rows of them
+  if (ln > fl) fl = ln;
+  return sizeof(float) * fl;
 }
 size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t N) {
   if (!cfg_ok(cfg)) return 0;
@@ -1639,24 +1697,34 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
   return NL_OK;
 }
 
-static size_t unet_bwd_bytes(const nl_config* cfg, int64_t r) { Bump b{nullptr, 0}; UnBwdBufs q; carve_unb(b, cfg, r, q); return b.off; }
+static size_t unet_bwd_bytes(const nl_config* cfg, int64_t r, bool train = false) { Bump b{nullptr, 0}; UnBwdBufs q; carve_unb(b, cfg, r, q, train); return b.off; }
+size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R) {
+  return cfg_ok(cfg) ? unet_bwd_bytes(cfg, R < 1 ? 1 : (R > 1024 ? 1024 : R), true) : 0;
+}
 size_t nl_ray_unet_backward_workspace_bytes(const nl_config* cfg, int64_t R) {
   return cfg_ok(cfg) ? unet_bwd_bytes(cfg, R < 1 ? 1 : (R > 1024 ? 1024 : R)) : 0;   // recommended: chunks of <= 1024 rays
 }
 int nl_ray_unet_backward(const nl_config* cfg, const void* packed, const float* xin, int64_t R, const float* g_geo, float* g_x, void* ws, size_t ws_bytes,
                          void* stream) {
+  return nl_ray_unet_backward_train(cfg, packed, xin, R, g_geo, g_x, nullptr, ws, ws_bytes, stream);
+}
+int nl_ray_unet_backward_train(const nl_config* cfg, const void* packed, const float* xin, int64_t R, const float* g_geo, float* g_x, const nl_train_grads* grads,
+                               void* ws, size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !xin || !g_geo || !g_x || !ws || R < 0) return NL_ERR_BAD_ARG;
-  if (ws_bytes < unet_bwd_bytes(cfg, 1)) return NL_ERR_WORKSPACE;
+  const bool train = grads != nullptr;
+  TrainOut T;
+  NL_TRY(resolve_train(cfg, grads, T));
+  if (ws_bytes < unet_bwd_bytes(cfg, 1, train)) return NL_ERR_WORKSPACE;
   int64_t lo = 1, hi = R;
-  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (unet_bwd_bytes(cfg, mid) <= ws_bytes) lo = mid; else hi = mid - 1; }
+  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (unet_bwd_bytes(cfg, mid, train) <= ws_bytes) lo = mid; else hi = mid - 1; }
   const int64_t RC = lo;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   const size_t row = (size_t)cfg->S * cfg->W;
   for (int64_t r0 = 0; r0 < R; r0 += RC) {
     const int64_t rc = R - r0 < RC ? R - r0 : RC;
-    Bump b{(char*)ws, 0}; UnBwdBufs q; carve_unb(b, cfg, rc, q);
-    NL_TRY(do_unet_backward(B.xb, B.x32, xin + r0 * row, rc, g_geo + r0 * row, g_x + r0 * row, q));
+    Bump b{(char*)ws, 0}; UnBwdBufs q; carve_unb(b, cfg, rc, q, train);
+    NL_TRY(do_unet_backward(B.xb, B.x32, xin + r0 * row, rc, g_geo + r0 * row, g_x + r0 * row, q, train ? &T : nullptr));
   }
   return NL_OK;
 }

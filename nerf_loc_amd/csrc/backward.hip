@@ -1328,7 +1328,8 @@ namespace {
 // (L/2, Cc) rows when pooled, (L, Cc) otherwise — with row stride ldgo (a column window of a wider gradient matrix is fine); g_x (L, Cc) contiguous.
 __global__ __launch_bounds__(256) void ln_slab_elu_backward_kernel(const float* __restrict__ xin, int L, int Cc, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, const float* __restrict__ g_out, int ldgo,
-                                                                   int pool, float* __restrict__ g_x) {
+                                                                   int pool, float* __restrict__ g_x,
+                                                                   float* __restrict__ aff /* training: (R, 2 L Cc) [d y * xhat | d y] per element, or null */) {
   __shared__ float red[8];
   const int r = blockIdx.x;
   const int n = L * Cc;
@@ -1356,6 +1357,7 @@ __global__ __launch_bounds__(256) void ln_slab_elu_backward_kernel(const float* 
     const float gh = gy * gamma[i];
     gx[i] = gh;
     s1 += gh; s2 += gh * xh;
+    if (aff) { aff[(size_t)r * 2 * n + i] = gy * xh; aff[(size_t)r * 2 * n + n + i] = gy; }
   };
   if (pool) {
     const int half = (L / 2) * Cc;
@@ -1402,9 +1404,21 @@ __global__ void add2d_kernel(const float* __restrict__ a, int lda, const float* 
 }  // namespace
 
 int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
-                                   float* g_x, hipStream_t st) {
+                                   float* g_x, float* aff, hipStream_t st) {
   if (R <= 0) return NL_OK;
-  hipLaunchKernelGGL(ln_slab_elu_backward_kernel, dim3((unsigned)R), dim3(256), 0, st, x, L, Cc, gamma, beta, eps, g_out, ldgo, pool, g_x);
+  hipLaunchKernelGGL(ln_slab_elu_backward_kernel, dim3((unsigned)R), dim3(256), 0, st, x, L, Cc, gamma, beta, eps, g_out, ldgo, pool, g_x, aff);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+// g (Cc, L) += t (L, Cc)^T   (the library keeps the U-Net's LayerNorm tables position-major; the state_dict is channel-major)
+__global__ void table_add_t_kernel(const float* __restrict__ t, float* __restrict__ g, int L, int Cc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * Cc) return;
+  const int c = i / L, l = i - c * L;
+  g[i] += t[(size_t)l * Cc + c];
+}
+int nl_launch_table_add_t(const float* t, float* g, int L, int Cc, hipStream_t st) {
+  hipLaunchKernelGGL(table_add_t_kernel, dim3((unsigned)nl_cdiv((int64_t)L * Cc, 256)), dim3(256), 0, st, t, g, L, Cc);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -158,6 +158,30 @@ MV_PARAMS = tuple(f"multiview_aggregator.out_fc.{i}.{t}" for i in (0, 2) for t i
 BLEND_PARAMS = tuple(f"rgb_blending_mlp.{i}.{t}" for i in (0, 2, 4) for t in ("weight", "bias")) + tuple(_DEC)
 
 
+UNET_PARAMS = tuple(f"ray_unet.{blk}.{i}.{t}" for blk in ("conv1", "conv2", "conv3", "trans_conv3", "trans_conv2", "trans_conv1", "conv_out")
+                    for i in (0, 1) for t in ("weight", "bias"))
+
+
+class UnetTrainFn(torch.autograd.Function):
+    """UnetFn for a training step: (x (R*S, W), renderer, *UNET_PARAMS) -> geo; backward = nl_ray_unet_backward_train: also the gradients of the seven
+    blocks' convolutions (one split-K product per tap) and LayerNorm([C, L]) tables (sums over the rays)."""
+
+    @staticmethod
+    def forward(ctx, x, renderer, *params):
+        x = x.contiguous()
+        ctx.r = renderer
+        ctx.save_for_backward(x)
+        return renderer.ray_unet(x)
+
+    @staticmethod
+    def backward(ctx, g_geo):
+        x, = ctx.saved_tensors
+        names = [n for n, need in zip(UNET_PARAMS, ctx.needs_input_grad[2:]) if need]
+        tg = ctx.r.train_grads(names)
+        gx = ctx.r.ray_unet_backward(x, g_geo.contiguous(), train=tg)
+        return (gx, None) + tuple(tg.weights.get(n) for n in UNET_PARAMS)
+
+
 class MvAggTrainFn(torch.autograd.Function):
     """MvAggFn for a training step: (xyz, feature maps (V,h,w,C), DepthFusionNet maps (V,32,vh,vw), renderer, *MV_PARAMS tensors) -> (G, valid_s);
     backward = nl_mv_aggregate_backward_train: also d/d out_fc, d/d the four decoders, d/d both maps."""
@@ -487,6 +511,8 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     W = agg.shape[1]
     if frozen and S == r.S:
         geo = UnetFn.apply(agg, r)
+    elif hip_train and S == r.S:
+        geo = UnetTrainFn.apply(agg, r, *[p[n] for n in UNET_PARAMS])
     else:
         geo = _ray_unet(p, agg.view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
     sigma = F.softplus(_lin(p, "sigma_mlp.0", geo)).view(R, S)

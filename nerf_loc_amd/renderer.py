@@ -40,7 +40,7 @@ class TrainGrads:
         for i, n in enumerate(all_names):
             self._arr[i] = self.weights[n].data_ptr() if n in self.weights else None
         self.support_feature = torch.zeros(renderer.M, renderer.C + 3, device=dev) if support_feature else None
-        shp = renderer._map_shapes
+        shp = renderer._map_shapes if (feat_maps or vis_featmaps or blend_feat_maps) else (None, None, None)
         self.feat_maps = torch.zeros(shp[0], device=dev) if feat_maps else None
         self._vis_hwc = torch.zeros(shp[1], device=dev) if vis_featmaps else None
         self.blend_feat_maps = torch.zeros(shp[2], device=dev) if blend_feat_maps else None
@@ -288,16 +288,22 @@ class HipRenderer:
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
 
-    def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None):
-        """Input gradient of `ray_unet` with frozen weights (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W)."""
+    def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None, train: "TrainGrads" = None):
+        """Input gradient of `ray_unet` (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W).  train: also ADD the gradients of the 28 U-Net tensors
+        into that TrainGrads (nl_ray_unet_backward_train)."""
         if not self._weights_loaded:
             raise RuntimeError("load_weights() first")
         xin, g = _dev_f32(x, self.device), _dev_f32(g_geo, self.device)
         R = xin.shape[0] // self.S
         gx = torch.empty_like(xin)
-        ws = self._workspace(self.lib.nl_ray_unet_backward_workspace_bytes(ct.byref(self.cfg), R))
+        wsb = self.lib.nl_ray_unet_backward_workspace_bytes if train is None else self.lib.nl_ray_unet_backward_train_workspace_bytes
+        ws = self._workspace(wsb(ct.byref(self.cfg), R))
         if workspace_rays is not None:
-            ws = ws[: self.lib.nl_ray_unet_backward_workspace_bytes(ct.byref(self.cfg), int(workspace_rays))]
+            ws = ws[: wsb(ct.byref(self.cfg), int(workspace_rays))]
+        if train is not None:
+            L.check(self.lib.nl_ray_unet_backward_train(ct.byref(self.cfg), self.packed.data_ptr(), xin.data_ptr(), R, g.data_ptr(), gx.data_ptr(), ct.byref(train.c),
+                                                        ws.data_ptr(), ws.numel(), self._stream()), "nl_ray_unet_backward_train")
+            return gx
         L.check(self.lib.nl_ray_unet_backward(ct.byref(self.cfg), self.packed.data_ptr(), xin.data_ptr(), R, g.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(),
                                               self._stream()), "nl_ray_unet_backward")
         return gx
@@ -363,7 +369,10 @@ class HipRenderer:
         """Zero-filled gradient buffers for the listed state_dict tensors (and the per-frame tensors asked for): hand the object to the
         `*_backward(..., train=...)` calls of one step, then read `.weights[name]` / `.support_feature` / `.feat_maps` (V,h,w,C) /
         `.vis_featmaps` (V,32,vh,vw) / `.blend_feat_maps` (V,h,w,32)."""
-        self._ready()
+        if support_feature or feat_maps or vis_featmaps or blend_feat_maps:
+            self._ready()
+        elif not self._weights_loaded:
+            raise RuntimeError("load_weights() first")
         return TrainGrads(self, names, support_feature, feat_maps, vis_featmaps, blend_feat_maps)
 
     def point_mlp_backward(self, xyz, direction, mv_feat, g_feature_agg, K: int = 8, knn=None, workspace_samples: Optional[int] = None, train: "TrainGrads" = None):

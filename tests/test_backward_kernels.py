@@ -416,3 +416,33 @@ def test_blend_weight_gradients_match_autograd(case, precision, chunk):
     gs = torch.autograd.grad((out * cot).sum(), [pp[n] for n in names] + [feat, vis])
     got = dict(zip(names + ["feat_fine_src", "vis_featmaps"], gs))
     _assert_param_grads(got, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("c1", "fp32", 2), ("w128s64", "bf16x3", None), ("s192out", "bf16x3", None)])
+def test_ray_unet_weight_gradients_match_autograd(case, precision, chunk):
+    """nl_ray_unet_backward_train: the 28 U-Net tensors (convolutions: one split-K product per tap with the input rows shifted inside each ray; transposed
+    convolutions: the three taps from the even / odd output phases; LayerNorm([C, L]) tables: sums over the rays) against autograd of the eager U-Net in fp64."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case(case)
+    cfg = c["cfg"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    p = {k: torch.from_numpy(v).to(dev) for k, v in c["weights"].items()}
+    R, S, W = 6, cfg.S_total, cfg.W
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(R * S, W, generator=g).to(dev)
+    cot = torch.randn(R * S, W, generator=g).to(dev)
+    names = list(dr.UNET_PARAMS)
+
+    def eager(dt):
+        pp = {k: v.detach().to(dt).requires_grad_(k in names) for k, v in p.items()}
+        out = dr._ray_unet(pp, x.to(dt).view(R, S, W).permute(0, 2, 1)).permute(0, 2, 1).reshape(R * S, W)
+        return dict(zip(names, torch.autograd.grad((out * cot.to(dt)).sum(), [pp[n] for n in names])))
+    ref32, ref64 = eager(torch.float32), eager(torch.float64)
+    tg = r.train_grads(names)
+    gx = r.ray_unet_backward(x, cot, train=tg, workspace_rays=chunk)
+    assert torch.equal(gx, r.ray_unet_backward(x, cot, workspace_rays=chunk))
+    _assert_param_grads({k: v.clone() for k, v in tg.weights.items()}, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=True)
