@@ -401,8 +401,30 @@ class ConditionalNeRF(nn.Module):
         weights_graph = self.training or any(q.requires_grad for q in self.parameters())
         fr = self._frame_dict(data, level, graph=True)
         r = self._ensure_frame(data, level)
+        p = self._graph_params(weights_graph)
+        sp = fr["support"]
+        if self.hip_training and weights_graph and xyz.is_cuda and not xyz.requires_grad and (direction is None or not direction.requires_grad) \
+                and len(sp["xyz"]) >= 1:
+            # a training step: the aggregation and the neural-point branch as the library's training nodes (HIP forward; backward with the
+            # gradients of their parameters, of the level's feature maps, of the DepthFusionNet maps and of the support features).  What the
+            # matcher loss differentiates is 'feature_agg' (nerf_pose_estimator.py:316-320, 445-448, 465-468); 'weights' keeps its graph to the
+            # confidences; the two raw multi-view entries are returned without one.
+            xyz = xyz.detach().float().contiguous()
+            dirs = None if direction is None else direction[:, :3].detach().float().contiguous()
+            G, _ = diff_render.MvAggTrainFn.apply(xyz, fr["feat_fine_src"], fr["vis_featmaps"], r, *[p[n] for n in diff_render.MV_PARAMS])
+            fa = diff_render.PointBranchTrainFn.apply(xyz, dirs, G, sp["feature"], r, int(K), *[p[n] for n in diff_render.POINT_PARAMS])
+            with torch.no_grad():
+                _, rgb_feat, vis_ang, _ = r.mv_aggregate(xyz, data["pose"][:3, 3] if "pose" in data else torch.zeros(3))
+                d2, idx = r.knn(xyz, K)
+            dist = d2.sqrt()
+            conf = sp["confidence"].squeeze(-1)[idx.long()] if len(sp["xyz"]) >= K else torch.zeros_like(dist)
+            w = (1.0 / torch.clamp(dist, min=1e-8)) * (1.0 / K) * conf
+            w = w / torch.clamp(w.sum(1, keepdim=True), min=1e-8)
+            feature = (fa / torch.clamp(w.sum(1, keepdim=True).detach(), min=1e-20)).unsqueeze(1).expand(-1, K, -1)
+            return {"feature_agg": fa, "feature": feature, "weights": w, "multiview_feature": rgb_feat[:, :, :self.C + 3],
+                    "multiview_visibility": vis_ang[:, :, :1]}
         idx = r.knn(xyz.detach(), K)[1].long()
-        return diff_render.query_diff(self._graph_params(weights_graph), fr, xyz, direction, idx)
+        return diff_render.query_diff(p, fr, xyz, direction, idx)
 
     def _query_hip(self, data, xyz, level, direction, K):
         r = self._ensure_frame(data, level)

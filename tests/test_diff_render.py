@@ -301,7 +301,9 @@ def _check_query_train(loss, desc_c, desc_f, ndc, named, data, tol):
     for key in g.files:
         if key.startswith("grad:"):
             ours = named[key[5:]].grad
-            assert ours is not None, key
+            if ours is None:   # the library's training nodes do not propagate identically-zero gradients: the reference holds noise there
+                assert float(np.abs(g[key]).max()) <= 1e-5 * gmax, key
+                ours = torch.zeros_like(named[key[5:]])
             errs[key[5:]] = float(np.abs(ours.cpu().numpy() - g[key]).max() / max(np.abs(g[key]).max(), 1e-5 * gmax))
         elif key.startswith("gsub:"):
             full = named[key[5:]].grad.cpu().numpy()
@@ -358,13 +360,16 @@ def test_query_training_gradients_through_the_dropin_match_reference_autograd_cp
 
 
 @pytest.mark.gpu
-def test_query_training_gradients_through_the_dropin_match_reference_autograd_gpu():
-    """The same on the GPU: HIP KNN + HIP cross-view features, matcher-side gradients reach base_mlp.0.weight (and 127 more)."""
+@pytest.mark.parametrize("hip_nodes", [True, False])
+def test_query_training_gradients_through_the_dropin_match_reference_autograd_gpu(hip_nodes):
+    """The same on the GPU: HIP KNN + HIP cross-view features, matcher-side gradients reach base_mlp.0.weight (and 127 more).
+    hip_nodes: aggregation + neural-point branch as the library's training nodes (default) / the all-eager fp32 graph."""
     from tests.test_dropin_module import _args
     from nerf_loc_amd.conditional_nerf import ConditionalNeRF
     dev = torch.device("cuda:0")
     case, cfg, data, pts, tc, tf = _query_case(dev)
     net = ConditionalNeRF(_args(cfg), precision="fp32").to(dev).train()
+    net.hip_training = hip_nodes
     net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
     net.support_neural_points = None
     net.multiview_aggregator.vis_featmaps = None
