@@ -794,22 +794,17 @@ int gemm_lrelu_masked(const Ctx& x, int g, const SegSpec& s, int64_t M, float* o
 // g_FA -> LayerNorm/scale -> {residual -> g_G ; fc^T -> attention -> {w_qs^T -> g_G ; [w_ks; w_vs]^T -> base_mlp^T x 3 with LeakyReLU masks ->
 // posenc / ray_diff_fc -> g_xyz, g_dir}}.  The aggregation scale sum_k w_k is a constant of the backward pass: it is identically 1 (or 0)
 // whatever the distances are (model.py:419-427 normalises the weights; the K rows they multiply are identical, see point.hip).
-int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
-                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in = nullptr, const float* d2_in = nullptr,
-                      const TrainOut* tg = nullptr) {
+// the staged forward of the branch into the workspace (everything the way back reads); dir: one row per dir_div samples
+int pt_forward_staged(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
+                      const PtBwdBufs& p, const int* idx_in, const float* d2_in) {
   const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
-  // training: gW += dY^T X right after each dY exists (its buffer is reused by the next layer's)
-  auto wg = [&](int tw, int tb, const float* dY, int ldy, int Mo, const float* X, int ldxx, int Ni, int64_t rows) -> int {
-    return wgrad_to(tg, x.st, tw, tb, dY, ldy, Mo, X, ldxx, Ni, rows);
-  };
   const int64_t NK = N * K;
   const float inv_span = 1.f / (f->views.far_ - f->views.near_);
   const int64_t M = f->M;
-  // ---- forward, staged
   const int* idx = idx_in && d2_in ? idx_in : p.idx;
   const float* d2 = idx_in && d2_in ? d2_in : p.d2;
   if (idx == p.idx) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));   // (the caller may hand over the forward call's neighbours)
-  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, 1, N, K, M, idx, d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
+  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, M, idx, d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
                                 inv_span, p.X, ldx, p.wscale, x.st));
   // (the encoded rows' pad columns are zero and so are the weights' pad rows: taking all ldx columns keeps the streaming kernel applicable)
   SegSpec sx{p.X, ldx, ldx, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
@@ -819,8 +814,20 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
   NL_TRY(run_gemm(x, G_KV, &s3, 1, NK, p.KV, 256, NL_ACT_NONE));
   NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
   NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
-  NL_TRY(run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE));
-  // ---- backward
+  return run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE);
+}
+int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N,
+                     int K, const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in, const float* d2_in,
+                     const TrainOut* tg) {
+  const int W = x.c->W, F = f->C + 3, ldx = ldx_of(f->C);
+  // training: gW += dY^T X right after each dY exists (its buffer is reused by the next layer's)
+  auto wg = [&](int tw, int tb, const float* dY, int ldy, int Mo, const float* X, int ldxx, int Ni, int64_t rows) -> int {
+    return wgrad_to(tg, x.st, tw, tb, dY, ldy, Mo, X, ldxx, Ni, rows);
+  };
+  const int64_t NK = N * K;
+  const float inv_span = 1.f / (f->views.far_ - f->views.near_);
+  const int64_t M = f->M;
+  const int* idx = idx_in && d2_in ? idx_in : p.idx;
   const bool aff = tg && (tg->w[T_LNW] || tg->w[T_LNB]);
   NL_TRY(nl_launch_ln_agg_backward(p.FCo, G, gFA, N, W, x.p<float>(x.L.ln_g), 1e-6f, p.wscale, p.gpre, aff ? p.aff : nullptr, x.st));
   if (aff) {
@@ -846,7 +853,7 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
   NL_TRY(wg(T_B0W, T_B0B, p.gA, W, W, p.X, ldx, F + 90, NK));
   NL_TRY(run_gemm(xb, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
   const bool rdw = tg && (tg->w[T_RD0W] || tg->w[T_RD0B] || tg->w[T_RD2W] || tg->w[T_RD2B]);
-  NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, 1, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
+  NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, dir_div, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
                                          g_dir, rdw ? p.tr : nullptr, x.st));
   if (rdw) {   // ray_diff_fc (model.py:36-39): rows [input 4 | hidden 16 | d hidden 16 | d output 32]
     NL_TRY(wg(T_RD2W, T_RD2B, p.tr + 36, 68, 27, p.tr + 4, 68, 16, NK));
@@ -858,6 +865,12 @@ int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const floa
     NL_TRY(nl_launch_sp_feat_scatter(p.gXF, ldf, F, idx, N, K, M, tg->sp_feat, x.st));
   }
   return NL_OK;
+}
+int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
+                      const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in = nullptr, const float* d2_in = nullptr,
+                      const TrainOut* tg = nullptr) {
+  NL_TRY(pt_forward_staged(x, f, xyz, dir, dir_stride, 1, G, N, K, p, idx_in, d2_in));
+  return pt_backward_only(xb, x, f, xyz, dir, dir_stride, 1, G, N, K, gFA, g_xyz, g_dir, g_G, p, idx_in, d2_in, tg);
 }
 
 // ---- input gradients of the multi-view aggregation and of the colour blend (frozen weights) ------------------------------------------
@@ -909,14 +922,16 @@ int dec_wgrads(const TrainOut* tg, hipStream_t st, const float* tr, int64_t rows
 
 // g_G (N, W) -> g_xyz (N, 3): out_fc backwards (two transposed-weight products, ELU masks), the visibility-weighted statistics, the bilinear taps'
 // spatial derivative, the IBRNet projection; visibility / depth difference through the NeuRay decoders and the NeuRay projection.
-int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* xyz, int64_t N, const float* gG, float* g_xyz, const MvBwdBufs& m,
-                   const TrainOut* tg = nullptr) {
+// out_fc on the recomputed statistics rows -> m.t64, m.G
+int mv_outfc_forward(const Ctx& x32, const nl_frame* f, int64_t N, const MvBwdBufs& m) {
   const int W = x32.c->W, ldg = ldg_of(f->C);
-  const NlViews vw = with_query(f, nullptr);
-  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
   SegSpec s0{m.g393, ldg, ldg, 0, 1}, s1{m.t64, 64, 64, 0, 1};
   NL_TRY(run_gemm(x32, G_OUTFC0, &s0, 1, N, m.t64, 64, NL_ACT_ELU));
-  NL_TRY(run_gemm(x32, G_OUTFC2, &s1, 1, N, m.G, W, NL_ACT_ELU));
+  return run_gemm(x32, G_OUTFC2, &s1, 1, N, m.G, W, NL_ACT_ELU);
+}
+// gG (N, W) -> m.gg393 (the statistics rows' gradient) + out_fc's weight gradients
+int mv_outfc_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, int64_t N, const float* gG, const MvBwdBufs& m, const TrainOut* tg) {
+  const int W = x32.c->W, ldg = ldg_of(f->C);
   NL_CHECK_HIP(hipMemcpyAsync(m.gA, gG, sizeof(float) * (size_t)N * W, hipMemcpyDeviceToDevice, x32.st));
   NL_TRY(nl_launch_elu_mask(m.gA, m.G, (size_t)N * W, x32.st));
   NL_TRY(wgrad_to(tg, x32.st, T_OUT2W, T_OUT2B, m.gA, W, W, m.t64, 64, 64, N));
@@ -924,13 +939,27 @@ int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float
   NL_TRY(run_gemm(xb, G_OUTFC2_T, &sa, 1, N, m.gt64, 64, NL_ACT_NONE));
   NL_TRY(nl_launch_elu_mask(m.gt64, m.t64, (size_t)N * 64, x32.st));
   NL_TRY(wgrad_to(tg, x32.st, T_OUT0W, T_OUT0B, m.gt64, 64, 64, m.g393, ldg, 2 * (f->C + 3) + 3, N));
-  NL_TRY(run_gemm(xb, G_OUTFC0_T, &st, 1, N, m.gg393, ldg, NL_ACT_NONE));
-  NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, nullptr, xyz, N, m.vis, m.dd, m.gg393, ldg, nullptr, nullptr, nullptr, g_xyz,
-                                    nullptr, m.gvis, m.gdd, tg ? tg->feat_maps : nullptr, nullptr, x32.st));
+  return run_gemm(xb, G_OUTFC0_T, &st, 1, N, m.gg393, ldg, NL_ACT_NONE);
+}
+// gradients of the tapped values (statistics rows: gg393; blend: g_pf / g_rgbv / g_ang; either may be null) -> g_xyz (written), g_qc, the maps' scatter-adds;
+// then visibility / depth difference back through the decoders (ONE pass for whatever consumers contributed) -> += g_xyz, the decoders' gradients
+int mv_geom_dec_backward(const Ctx& x32, const nl_frame* f, const NlViews& vw, const float* xyz, int64_t N, const float* gg393, bool blend, float* g_xyz,
+                         float* g_qc, const MvBwdBufs& m, const TrainOut* tg) {
+  NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, blend ? f->pfeat : nullptr, xyz, N, m.vis, m.dd, gg393, ldg_of(f->C),
+                                    blend ? m.gpf : nullptr, blend ? m.grgbv : nullptr, blend ? m.gang : nullptr, g_xyz, g_qc, m.gvis, m.gdd,
+                                    tg ? tg->feat_maps : nullptr, tg && blend ? tg->pfeat_maps : nullptr, x32.st));
   const bool decw = tg && tg->any(T_DEC, T_DEC + 24);
   NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
                                 m.gvis, m.gdd, m.gpart, g_xyz, decw ? m.dtr : nullptr, tg ? tg->vis_maps : nullptr, x32.st));
   return decw ? dec_wgrads(tg, x32.st, m.dtr, (int64_t)vw.V * N) : NL_OK;
+}
+int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* xyz, int64_t N, const float* gG, float* g_xyz, const MvBwdBufs& m,
+                   const TrainOut* tg = nullptr) {
+  const NlViews vw = with_query(f, nullptr);
+  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
+  NL_TRY(mv_outfc_forward(x32, f, N, m));
+  NL_TRY(mv_outfc_backward(xb, x32, f, N, gG, m, tg));
+  return mv_geom_dec_backward(x32, f, vw, xyz, N, m.gg393, false, g_xyz, nullptr, m, tg);
 }
 
 // rgb_s = blend(feature_agg, per-view taps) forward (staged) and its input gradient
@@ -946,13 +975,11 @@ int do_blend_forward(const Ctx& x, const nl_frame* f, const float* qc, const flo
   return nl_launch_blend(m.blA, m.bl1, m.rgbv, N, vw.V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w), x.p<float>(x.L.bl4_b), rgb_s, x.st);
 }
 
-int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* xyz, const float* FA, int64_t N, const float* g_rgb_s,
-                      float* g_xyz, float* g_FA, float* g_qc, const MvBwdBufs& m, const TrainOut* tg = nullptr) {
+// g_rgb_s -> m.ghA / m.gpf / m.grgbv / m.gang (+ rgb_blending_mlp's weight gradients) and g_FA (may be null); needs m.blA, m.bl1, m.rgbv of the forward
+int blend_tail_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const NlViews& vw, const float* xyz, const float* FA, int64_t N, const float* g_rgb_s,
+                        float* g_FA, const MvBwdBufs& m, const TrainOut* tg) {
   const int W = x32.c->W;
-  const NlViews vw = with_query(f, qc);
-  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
-  SegSpec sa{FA, W, W, 0, 1}, sg{m.ghA, 32, 32, 0, 1};
-  NL_TRY(run_gemm(x32, G_BLENDA, &sa, 1, N, m.blA, 32, NL_ACT_NONE));
+  SegSpec sg{m.ghA, 32, 32, 0, 1};
   const bool blw = tg && (tg->any(T_BL0W, T_BL4B + 1));
   NL_TRY(nl_launch_blend_backward(m.blA, m.bl1, m.rgbv, N, vw.V, x32.p<float>(x32.L.bl2_w), x32.p<float>(x32.L.bl2_b), x32.p<float>(x32.L.bl4_w),
                                   x32.p<float>(x32.L.bl4_b), x32.p<float>(x32.L.blw), g_rgb_s, m.ghA, m.gpf, m.grgbv, m.gang, blw ? m.btr : nullptr, x32.st));
@@ -974,12 +1001,17 @@ int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const fl
     if (tg->w[T_BL0B]) NL_TRY(nl_launch_colsum(m.gpf, 32, NV, 32, tg->w[T_BL0B], tg->scratch, x32.st));
   }
   if (g_FA) NL_TRY(run_gemm(xb, G_BLENDA_T, &sg, 1, N, g_FA, W, NL_ACT_NONE));
-  NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, f->pfeat, xyz, N, m.vis, m.dd, nullptr, ldg_of(f->C), m.gpf, m.grgbv, m.gang, g_xyz,
-                                    g_qc, m.gvis, m.gdd, tg ? tg->feat_maps : nullptr, tg ? tg->pfeat_maps : nullptr, x32.st));
-  const bool decw = tg && tg->any(T_DEC, T_DEC + 24);
-  NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
-                                m.gvis, m.gdd, m.gpart, g_xyz, decw ? m.dtr : nullptr, tg ? tg->vis_maps : nullptr, x32.st));
-  return decw ? dec_wgrads(tg, x32.st, m.dtr, (int64_t)vw.V * N) : NL_OK;
+  return NL_OK;
+}
+int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* xyz, const float* FA, int64_t N, const float* g_rgb_s,
+                      float* g_xyz, float* g_FA, float* g_qc, const MvBwdBufs& m, const TrainOut* tg = nullptr) {
+  const int W = x32.c->W;
+  const NlViews vw = with_query(f, qc);
+  NL_TRY(mv_recompute(x32, f, vw, xyz, N, m));
+  SegSpec sa{FA, W, W, 0, 1};
+  NL_TRY(run_gemm(x32, G_BLENDA, &sa, 1, N, m.blA, 32, NL_ACT_NONE));
+  NL_TRY(blend_tail_backward(xb, x32, f, vw, xyz, FA, N, g_rgb_s, g_FA, m, tg));
+  return mv_geom_dec_backward(x32, f, vw, xyz, N, nullptr, true, g_xyz, g_qc, m, tg);
 }
 
 // sigma_out (optional): when conv_out's LayerNorm runs inside the GEMM, the density head is evaluated there too and
@@ -1092,10 +1124,15 @@ void carve_unb(Bump& b, const nl_config* c, int64_t R, UnBwdBufs& q, bool train 
 // Unfused forward in exact fp32 (every layer's pre-LayerNorm output stays in the workspace), then layer by layer backwards: LayerNorm / ELU /
 // MaxPool derivative (one block per ray) -> transposed-weight convolution (segment GEMM over the gradient rows' taps), the skip connections'
 // gradients added where the concatenations were.
+int unet_backward_only(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, const float* g_geo, float* g_in, const UnBwdBufs& q, const TrainOut* tg);
 int do_unet_backward(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, const float* g_geo, float* g_in, const UnBwdBufs& q, const TrainOut* tg = nullptr) {
+  NL_TRY(do_unet(x32, in, R, q.geo, q.u));   // fp32: separate GEMM + ln_slab_elu launches
+  return unet_backward_only(xb, x32, in, R, g_geo, g_in, q, tg);
+}
+// (the forward's pre-LayerNorm outputs and block outputs are in q.u)
+int unet_backward_only(const Ctx& xb, const Ctx& x32, const float* in, int64_t R, const float* g_geo, float* g_in, const UnBwdBufs& q, const TrainOut* tg) {
   const int W = x32.c->W, S = x32.c->S;
   const UnBufs& u = q.u;
-  NL_TRY(do_unet(x32, in, R, q.geo, u));   // fp32: separate GEMM + ln_slab_elu launches
   auto g = [&](int i) { return x32.p<float>(x32.L.un_g[i]); };
   auto b = [&](int i) { return x32.p<float>(x32.L.un_b[i]); };
   const float eps = 1e-5f;

@@ -143,7 +143,128 @@ __global__ void knn_backward_kernel(const float* __restrict__ xyz, const float* 
   if (g_xyz) { g_xyz[3 * (size_t)n] = ax; g_xyz[3 * (size_t)n + 1] = ay; g_xyz[3 * (size_t)n + 2] = az; }
 }
 
+// ---- glue of the whole-path backward (abi.hip: do_render_backward) -----------------------------------------------------------------------
+// hc[r][c] = sum_s w_s ft[r][s][c], wsum4[r] = (sum_s w_s, 0, 0, 0): the composited hidden rows feat_mlp.2's weight gradient multiplies
+template <int CH>
+__global__ __launch_bounds__(256) void ray_feat_sum_kernel(const float* __restrict__ z_vals, const float* __restrict__ sigma, const float* __restrict__ ft, int R,
+                                                           int S, int C, float* __restrict__ hc, float* __restrict__ wsum4) {
+  __shared__ float wsh[4][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wv;
+  if (r >= R) return;
+  const float* z = z_vals + (size_t)r * S;
+  float al[CH];
+  float prod = 1.f;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) {
+      const float dl = (s + 1 < S) ? z[s + 1] - z[s] : 1e2f;
+      al[j] = 1.f - expf(-dl * sigma[(size_t)r * S + s]);
+      prod *= (1.f - al[j]);
+    } else al[j] = 0.f;
+  }
+  float inc = prod;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o, 64); if (lane >= o) inc *= t; }
+  float T = __shfl_up(inc, 1, 64);
+  if (lane == 0) T = 1.f;
+  float ws = 0.f;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int s = lane * CH + j;
+    if (s < S) { const float w = al[j] * T; T *= (1.f - al[j]); ws += w; wsh[wv][s] = w; }
+  }
+  ws = wave_sum(ws);
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < C; c += 64) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a = fmaf(wsh[wv][s], ft[((size_t)r * S + s) * C + c], a);
+    hc[(size_t)r * C + c] = a;
+  }
+  if (lane == 0) *(float4*)(wsum4 + 4 * (size_t)r) = make_float4(ws, 0.f, 0.f, 0.f);
+}
+// sigma = softplus(geo . w + b) backwards: g_geo (N, W) = g_pre w, gpre4 (N, 4) = (g_pre, 0, 0, 0), g_pre = g_sigma * sigmoid(pre); one wave per sample
+__global__ __launch_bounds__(256) void sigma_backward_kernel(const float* __restrict__ geo, int N, int W, const float* __restrict__ w, const float* __restrict__ b,
+                                                             const float* __restrict__ g_sigma, float* __restrict__ g_geo, float* __restrict__ gpre4) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float a = 0.f;
+  for (int c = lane; c < W; c += 64) a = fmaf(geo[(size_t)n * W + c], w[c], a);
+  const float pre = wave_sum(a) + b[0];
+  const float gp = g_sigma[n] * (pre > 20.f ? 1.f : nl_sigmoid(pre));
+  for (int c = lane; c < W; c += 64) g_geo[(size_t)n * W + c] = gp * w[c];
+  if (lane == 0) *(float4*)(gpre4 + 4 * (size_t)n) = make_float4(gp, 0.f, 0.f, 0.f);
+}
+// the weights' total cotangent: gw[r][s] = g_wts[r][s] + g_feat[r] . b2   (feat = W2 . sum_s w_s hidden_s + b2 sum_s w_s); one wave per ray
+__global__ __launch_bounds__(256) void gw_total_kernel(const float* __restrict__ g_wts, const float* __restrict__ g_feat, const float* __restrict__ b2, int R, int S,
+                                                       int C, float* __restrict__ gw) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float a = 0.f;
+  if (g_feat) for (int c = lane; c < C; c += 64) a = fmaf(g_feat[(size_t)r * C + c], b2[c], a);
+  a = wave_sum(a);
+  for (int s = lane; s < S; s += 64) gw[(size_t)r * S + s] = a + (g_wts ? g_wts[(size_t)r * S + s] : 0.f);
+}
+// xyz = o + z d: g_o[r] = sum_s g_xyz, g_d[r] = sum_s (z_s g_xyz + g_dir), g_qc[r] = sum_s g_qcN; g_xyz = ga + gb (+ gc); one wave per ray
+__global__ __launch_bounds__(256) void ray_reduce_kernel(const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc,
+                                                         const float* __restrict__ g_dir, const float* __restrict__ g_qcN, const float* __restrict__ z, int R, int S,
+                                                         float* __restrict__ g_o, float* __restrict__ g_d, float* __restrict__ g_qc) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f};
+  for (int s = lane; s < S; s += 64) {
+    const size_t n = (size_t)r * S + s;
+    const float zz = z[n];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float g = ga[3 * n + k] + (gb ? gb[3 * n + k] : 0.f) + (gc ? gc[3 * n + k] : 0.f);
+      o[k] += g;
+      d[k] += zz * g + (g_dir ? g_dir[3 * n + k] : 0.f);
+      if (g_qcN) q[k] += g_qcN[3 * n + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = wave_sum(o[k]); d[k] = wave_sum(d[k]); q[k] = wave_sum(q[k]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { g_o[3 * (size_t)r + k] = o[k]; g_d[3 * (size_t)r + k] = d[k]; if (g_qc) g_qc[3 * (size_t)r + k] = q[k]; }
+  }
+}
+
 }  // namespace
+
+int nl_launch_ray_feat_sum(const float* z, const float* sigma, const float* ft, int64_t R, int S, int C, float* hc, float* wsum4, hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  dim3 grid((unsigned)nl_cdiv(R, 4));
+#define NL_RF(CH) hipLaunchKernelGGL(ray_feat_sum_kernel<CH>, grid, dim3(256), 0, st, z, sigma, ft, (int)R, S, C, hc, wsum4)
+  if (S <= 64) NL_RF(1); else if (S <= 128) NL_RF(2); else if (S <= 192) NL_RF(3); else NL_RF(4);
+#undef NL_RF
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+int nl_launch_sigma_backward(const float* geo, int64_t N, int W, const float* w, const float* b, const float* g_sigma, float* g_geo, float* gpre4, hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(sigma_backward_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, geo, (int)N, W, w, b, g_sigma, g_geo, gpre4);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  hipLaunchKernelGGL(gw_total_kernel, dim3((unsigned)nl_cdiv(R, 4)), dim3(256), 0, st, g_wts, g_feat, b2, (int)R, S, C, gw);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+int nl_launch_ray_reduce(const float* ga, const float* gb, const float* gc, const float* g_dir, const float* g_qcN, const float* z, int64_t R, int S, float* g_o,
+                         float* g_d, float* g_qc, hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  hipLaunchKernelGGL(ray_reduce_kernel, dim3((unsigned)nl_cdiv(R, 4)), dim3(256), 0, st, ga, gb, gc, g_dir, g_qcN, z, (int)R, S, g_o, g_d, g_qc);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
 
 extern "C" {
 
