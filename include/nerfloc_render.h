@@ -316,6 +316,27 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
                             const float* feature_agg, int64_t N, const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center,
                             const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
 
+/* The whole ray path backwards in ONE call (ConditionalNeRF.render_rays, model.py:472-600, as PoseOptimizer — pose_optimizer.py:131-168 — and a training
+ * step — model.py:641-685 — differentiate it): cotangents of the per-ray outputs -> gradients of the rays (and, with `grads`, of all 84 parameter tensors,
+ * the maps and the support features).  Equivalent to chaining the stage entry points above through compositing and the three heads, but every
+ * per-frame / per-sample quantity is recomputed ONCE per call: one pass of the visibility decoders forward and one backward for the aggregation's and
+ * the blend's uses of them, one geometry kernel for both sets of taps, one neighbour search.  z_vals (R,S): the sample depths the forward call used
+ * (the hierarchical branch's resampled depths are constants: model.py:495 detaches them).  g_query_center_rows (R,3) or NULL: per-ray partial sums of
+ * d/d(query camera centre) — the caller adds them up.  Rays are processed in chunks that fit the workspace. */
+typedef struct nl_render_cotangents {
+  const float* g_rgb;                 /* (R,3) or NULL (= zero) */
+  const float* g_depth;               /* (R) */
+  const float* g_depth_uncertainty;   /* (R) */
+  const float* g_feat;                /* (R,C) */
+  const float* g_weights;             /* (R,S) */
+  const void* reserved[3];            /* must be NULL */
+} nl_render_cotangents;
+size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train);
+int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST, 3 floats */,
+                            const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_cotangents* g,
+                            float* g_rays_o, float* g_rays_d, float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* nl_ray_unet_backward + gradients of the seven blocks' convolution weights / biases and LayerNorm([C, L]) tables (28 tensors). */
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R);
 int nl_ray_unet_backward_train(const nl_config* cfg, const void* packed, const float* x, int64_t R, const float* g_geo, float* g_x,

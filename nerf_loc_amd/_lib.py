@@ -57,6 +57,11 @@ class NlTrainGrads(C.Structure):
                 ("blend_feat_maps", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("reserved", C.c_int32 * 4)]
 
 
+class NlRenderCotangents(C.Structure):
+    _fields_ = [("g_rgb", C.c_void_p), ("g_depth", C.c_void_p), ("g_depth_uncertainty", C.c_void_p), ("g_feat", C.c_void_p), ("g_weights", C.c_void_p),
+                ("reserved", C.c_void_p * 3)]
+
+
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)
 _P, _I, _L, _Z, _F = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _CFG, _DESC, _OUT = C.POINTER(NlConfig), C.POINTER(NlFrameDesc), C.POINTER(NlRenderOut)
@@ -96,6 +101,8 @@ SYMBOLS = [
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
+    ("nl_render_rays_backward_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
+    ("nl_render_rays_backward", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_ray_unet_backward_train_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_ray_unet_backward_train", _I, [_CFG, _P, _P, _L, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_mv_aggregate_backward_train_workspace_bytes", _Z, [_CFG, _I, _L]),

@@ -86,6 +86,11 @@ int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
 int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
                                    float* g_x, float* aff, hipStream_t st);
 int nl_launch_table_add_t(const float* t, float* g, int L, int Cc, hipStream_t st);
+int nl_launch_ray_feat_sum(const float* z, const float* sigma, const float* ft, int64_t R, int S, int C, float* hc, float* wsum4, hipStream_t st);
+int nl_launch_sigma_backward(const float* geo, int64_t N, int W, const float* w, const float* b, const float* g_sigma, float* g_geo, float* gpre4, hipStream_t st);
+int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, hipStream_t st);
+int nl_launch_ray_reduce(const float* ga, const float* gb, const float* gc, const float* g_dir, const float* g_qcN, const float* z, int64_t R, int S, float* g_o,
+                         float* g_d, float* g_qc, hipStream_t st);
 int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, int ldo, int64_t rows, int cols, hipStream_t st);
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
@@ -140,6 +145,7 @@ enum {
   G_OUTFC2_T, G_OUTFC0_T, G_BLENDA_T,                         // ... of the multi-view aggregation's out_fc and of the blend's per-sample projection
   G_UB_OUTA, G_UB_OUTB, G_UB_T1, G_UB_T2, G_UB_T3, G_UB_C3, G_UB_C2, G_UB_C1,   // ... of the ray U-Net's seven convolutions (do_unet_backward)
   G_BASE0_TF,                                                                    // training: base_mlp.0 towards its support-feature columns
+  G_FEAT0_T, G_FEAT2_T,                                                          // whole-path backward: feat_mlp's two layers towards their inputs
   G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
@@ -214,6 +220,8 @@ Layout make_layout(const nl_config* c) {
   set(G_BASE2_T, W, W, false);
   set(G_BASE0_T, W, 96, false);
   set(G_BASE0_TF, W, F, false);
+  set(G_FEAT0_T, W, W, false);
+  set(G_FEAT2_T, C, W, false);
   set(G_OUTFC2_T, W, 64, false);
   set(G_OUTFC0_T, 64, (int)nl_align_up(2 * F + 3, 32), false);   // = ldg_of(C): the statistics row incl. its zero padding (416 columns: generic kernels)
   set(G_BLENDA_T, 32, W, false);
@@ -1261,6 +1269,91 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
   return NL_OK;
 }
 
+// ---- the whole ray path backwards in one call (nl_render_rays_backward) ----------------------------------------------------------------
+// = the four stage backwards above + the heads + compositing, sharing what the separate autograd nodes each recompute: ONE pass of the visibility
+// decoders forward and ONE backward for the aggregation's and the blend's uses of visibility / depth difference, one geometry kernel for
+// both sets of taps, one neighbour search.
+struct RbBufs {
+  MvBwdBufs m; PtBwdBufs p; UnBwdBufs q;
+  float *xyz, *zc, *FA, *sigma, *Hf, *rgb_s, *hc, *wsum4, *ghc, *gw, *g_sigma, *g_rgb_s, *gFA, *gtmp, *gpre4, *gxyz_m, *gxyz_p, *gdir, *gG, *gqcN;
+};
+void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool train) {
+  const int W = c->W, S = c->S;
+  const size_t N = (size_t)R * S;
+  // multi-view buffers: the union of the aggregation's and the blend's sets
+  carve_mvb(b, c, V, (int64_t)N, true, a.m, train);
+  a.m.t64 = b.take<float>(N * 64); a.m.G = b.take<float>(N * W); a.m.gA = b.take<float>(N * W);
+  a.m.gt64 = b.take<float>(N * 64); a.m.gg393 = b.take<float>(N * ldg_of(c->C));
+  carve_ptb(b, c, (int64_t)N, 8, a.p, train);
+  carve_unb(b, c, R, a.q, train);
+  a.xyz = b.take<float>(N * 3); a.zc = b.take<float>(N); a.FA = b.take<float>(N * W); a.sigma = b.take<float>(N); a.Hf = b.take<float>(N * W);
+  a.rgb_s = b.take<float>(N * 3); a.hc = b.take<float>((size_t)R * W); a.wsum4 = b.take<float>((size_t)R * 4); a.ghc = b.take<float>((size_t)R * W);
+  a.gw = b.take<float>(N); a.g_sigma = b.take<float>(N); a.g_rgb_s = b.take<float>(N * 3); a.gFA = b.take<float>(N * W); a.gtmp = b.take<float>(N * W);
+  a.gpre4 = b.take<float>(N * 4); a.gxyz_m = b.take<float>(N * 3); a.gxyz_p = b.take<float>(N * 3); a.gdir = b.take<float>(N * 3);
+  a.gG = b.take<float>(N * W); a.gqcN = b.take<float>(N * 3);
+}
+struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; };
+int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R,
+                       int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
+  const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
+  const int64_t N = R * S;
+  hipStream_t st = x32.st;
+  const NlViews vw = with_query(f, qc);
+  const float eps_ln = 1e-6f;
+  // ---------------------------------------------------------------- forward, staged, everything kept in the workspace
+  NL_TRY(nl_launch_sample_points(rays_o, rays_d, R, S, f->views.near_, f->views.far_, z, a.zc, a.xyz, st));
+  NL_TRY(mv_recompute(x32, f, vw, a.xyz, N, a.m));                       // visibility / depth difference, statistics rows, the blend's per-view part
+  NL_TRY(mv_outfc_forward(x32, f, N, a.m));                              // -> G
+  NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, nullptr, nullptr));
+  NL_TRY(nl_launch_ln_agg(a.p.FCo, a.m.G, N, W, x32.p<float>(x32.L.ln_g), x32.p<float>(x32.L.ln_b), eps_ln, a.p.wscale, a.FA, st));
+  NL_TRY(do_unet(x32, a.FA, R, a.q.geo, a.q.u));
+  NL_TRY(nl_launch_sigma(a.q.geo, N, W, x32.p<float>(x32.L.sig_w), x32.p<float>(x32.L.sig_b), a.sigma, st));
+  SegSpec sfa{a.FA, W, W, 0, 1};
+  const bool want_feat = ct.g_feat != nullptr;
+  if (want_feat) NL_TRY(run_gemm(x32, G_FEAT0, &sfa, 1, N, a.Hf, W, NL_ACT_LRELU));
+  NL_TRY(run_gemm(x32, G_BLENDA, &sfa, 1, N, a.m.blA, 32, NL_ACT_NONE));
+  NL_TRY(nl_launch_blend(a.m.blA, a.m.bl1, a.m.rgbv, N, vw.V, x32.p<float>(x32.L.bl2_w), x32.p<float>(x32.L.bl2_b), x32.p<float>(x32.L.bl4_w),
+                         x32.p<float>(x32.L.bl4_b), a.rgb_s, st));
+  // ---------------------------------------------------------------- compositing backwards (feat = W2 . sum_s w_s hidden_s + b2 sum_s w_s)
+  const float* b2 = x32.p<float>(x32.L.b32[G_FEAT2]) + (size_t)W * x32.L.g[G_FEAT2].Npad;   // the bias row of G_FEAT2's fp32 weights (K row W)
+  if (want_feat) {
+    SegSpec sgf{ct.g_feat, C, C, 0, 1};
+    NL_TRY(run_gemm(xb, G_FEAT2_T, &sgf, 1, R, a.ghc, W, NL_ACT_NONE));
+  }
+  NL_TRY(nl_launch_gw_total(ct.g_wts, ct.g_feat, b2, R, S, C, a.gw, st));
+  NL_TRY(nl_composite_backward(a.zc, a.sigma, a.rgb_s, want_feat ? a.Hf : nullptr, R, S, want_feat ? W : 0, white, ct.g_rgb, ct.g_depth, ct.g_unc,
+                               want_feat ? a.ghc : nullptr, a.gw, a.g_sigma, a.g_rgb_s, want_feat ? a.gtmp : nullptr, st));
+  // ---------------------------------------------------------------- heads
+  bool have_gfa = false;
+  if (want_feat) {   // feat_mlp: gtmp = d/d hidden -> LeakyReLU mask -> feat_mlp.0^T
+    NL_TRY(nl_launch_lrelu_mask(a.gtmp, a.Hf, (size_t)N * W, st));
+    NL_TRY(wgrad_to(tg, st, T_F0W, T_F0B, a.gtmp, W, W, a.FA, W, W, N));
+    SegSpec sg{a.gtmp, W, W, 0, 1};
+    NL_TRY(run_gemm(xb, G_FEAT0_T, &sg, 1, N, a.gFA, W, NL_ACT_NONE));
+    have_gfa = true;
+    if (tg && (tg->w[T_F2W] || tg->w[T_F2B])) {
+      NL_TRY(nl_launch_ray_feat_sum(a.zc, a.sigma, a.Hf, R, S, W, a.hc, a.wsum4, st));
+      if (tg->w[T_F2W]) NL_TRY(nl_launch_wgrad(ct.g_feat, C, C, a.hc, W, W, R, 0, 0, tg->w[T_F2W], W, 1, 0, nullptr, tg->scratch, tg->scratch_floats, st));
+      if (tg->w[T_F2B]) NL_TRY(nl_launch_wgrad(ct.g_feat, C, C, a.wsum4, 4, 1, R, 0, 0, tg->w[T_F2B], 1, 1, 0, nullptr, tg->scratch, tg->scratch_floats, st));
+    }
+  }
+  // density head -> g_geo (in q.gout's neighbour: reuse a.gG as scratch is not possible yet; g_geo lives in a.Hf, free from here on)
+  float* g_geo = a.Hf;
+  NL_TRY(nl_launch_sigma_backward(a.q.geo, N, W, x32.p<float>(x32.L.sig_w), x32.p<float>(x32.L.sig_b), a.g_sigma, g_geo, a.gpre4, st));
+  NL_TRY(wgrad_to(tg, st, T_SIGW, T_SIGB, a.gpre4, 4, 1, a.q.geo, W, W, N));
+  // ---------------------------------------------------------------- ray U-Net, colour blend: their shares of d/d feature_agg
+  NL_TRY(unet_backward_only(xb, x32, a.FA, R, g_geo, a.gtmp, a.q, tg));
+  if (have_gfa) NL_TRY(nl_launch_add(a.gFA, a.gtmp, a.gFA, (size_t)N * W, st));
+  else NL_CHECK_HIP(hipMemcpyAsync(a.gFA, a.gtmp, sizeof(float) * (size_t)N * W, hipMemcpyDeviceToDevice, st));
+  NL_TRY(blend_tail_backward(xb, x32, f, vw, a.xyz, a.FA, N, a.g_rgb_s, a.gtmp, a.m, tg));
+  NL_TRY(nl_launch_add(a.gFA, a.gtmp, a.gFA, (size_t)N * W, st));
+  // ---------------------------------------------------------------- neural-point branch, aggregation, geometry + decoders
+  NL_TRY(pt_backward_only(xb, x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.gFA, a.gxyz_p, a.gdir, a.gG, a.p, nullptr, nullptr, tg));
+  NL_TRY(mv_outfc_backward(xb, x32, f, N, a.gG, a.m, tg));
+  NL_TRY(mv_geom_dec_backward(x32, f, vw, a.xyz, N, a.m.gg393, true, a.gxyz_m, g_qc_rows ? a.gqcN : nullptr, a.m, tg));
+  return nl_launch_ray_reduce(a.gxyz_m, a.gxyz_p, nullptr, a.gdir, g_qc_rows ? a.gqcN : nullptr, a.zc, R, S, g_o, g_d, g_qc_rows, st);
+}
+
 Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
   Ctx x;
   x.c = c; x.L = make_layout(c); x.pk = (const char*)packed; x.st = (hipStream_t)stream;
@@ -1363,6 +1456,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
                        (unsigned short*)((char*)packed + L.blo[G_BASE0_TF]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_TF]), nl_tgemm_nrt(d.N), 0);
   }
   P.block(G_OUTFC2_T, 0, t[T_OUT2W], 0, 1, 64, W);
+  P.block(G_FEAT0_T, 0, t[T_F0W], 0, 1, W, W);
+  P.block(G_FEAT2_T, 0, t[T_F2W], 0, 1, W, C);
   {
     const GemmDim& d = L.g[G_OUTFC0_T];   // out_fc.0.weight (64, 2F + 3): element [k = o][n = i]; no streaming layout (N > 256)
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(64 * (2 * F + 3), 256)), dim3(256), 0, st, t[T_OUT0W], 0, 1, 2 * F + 3, 64, 2 * F + 3, 0,
@@ -1735,6 +1830,39 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
 }
 
 static size_t unet_bwd_bytes(const nl_config* cfg, int64_t r, bool train = false) { Bump b{nullptr, 0}; UnBwdBufs q; carve_unb(b, cfg, r, q, train); return b.off; }
+static size_t render_bwd_bytes(const nl_config* cfg, int V, int64_t r, bool train) { Bump b{nullptr, 0}; RbBufs a; carve_rb(b, cfg, V, r, a, train); return b.off; }
+size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train) {
+  if (!cfg_ok(cfg) || V < 1 || V > NL_MAX_VIEWS) return 0;
+  const int64_t cap = (1 << 16) / cfg->S > 1 ? (1 << 16) / cfg->S : 1;   // recommended chunk: ~64 k samples (~70 KB of workspace per sample at W = 256)
+  return render_bwd_bytes(cfg, V, R < 1 ? 1 : (R > cap ? cap : R), train != 0);
+}
+int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_o, const float* rays_d,
+                            const float* z_vals, int64_t R, int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d,
+                            float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
+  for (int i = 0; i < 3; ++i) if (g->reserved[i] != nullptr) return NL_ERR_BAD_ARG;
+  if (f->M < 1) return NL_ERR_UNSUPPORTED;
+  const int V = f->views.V, S = cfg->S, C = cfg->C;
+  const bool train = grads != nullptr;
+  TrainOut T;
+  NL_TRY(resolve_train(cfg, grads, T));
+  if (ws_bytes < render_bwd_bytes(cfg, V, 1, train)) return NL_ERR_WORKSPACE;
+  int64_t lo = 1, hi = R;
+  while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (render_bwd_bytes(cfg, V, mid, train) <= ws_bytes) lo = mid; else hi = mid - 1; }
+  const int64_t RC = lo;
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  for (int64_t r0 = 0; r0 < R; r0 += RC) {
+    const int64_t rc = R - r0 < RC ? R - r0 : RC;
+    Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, rc, a, train);
+    RbCot ct{g->g_rgb ? g->g_rgb + 3 * r0 : nullptr, g->g_depth ? g->g_depth + r0 : nullptr, g->g_depth_uncertainty ? g->g_depth_uncertainty + r0 : nullptr,
+             g->g_feat ? g->g_feat + r0 * C : nullptr, g->g_weights ? g->g_weights + r0 * S : nullptr};
+    NL_TRY(do_render_backward(B.xb, B.x32, f, query_center, rays_o + 3 * r0, rays_d + 3 * r0, z_vals + r0 * S, rc, white_bkgd, ct, g_rays_o + 3 * r0,
+                              g_rays_d + 3 * r0, g_query_center_rows ? g_query_center_rows + 3 * r0 : nullptr, a, train ? &T : nullptr));
+  }
+  return NL_OK;
+}
+
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R) {
   return cfg_ok(cfg) ? unet_bwd_bytes(cfg, R < 1 ? 1 : (R > 1024 ? 1024 : R), true) : 0;
 }

@@ -120,6 +120,51 @@ class PointBranchFn(torch.autograd.Function):
         return gx, gd, gg, None, None
 
 
+class RenderFn(torch.autograd.Function):
+    """ConditionalNeRF.render_rays (model.py:472-600) as ONE autograd node on the HIP library: forward = the fused inference path
+    (`nl_render_rays`), backward = `nl_render_rays_backward` — the whole path backwards in one call, every per-sample quantity recomputed once
+    (DESIGN.md §5.15).  Inputs: rays_o, rays_d (R,3), query centre (3,), z_vals (R,S) constants, renderer, white_bkgd, then — a training step —
+    the frame tensors (feature maps, DepthFusionNet maps, support features) and the RENDER_PARAMS tensors whose gradients the call also
+    produces (the renderer must hold their current values).  Returns (rgb, depth, depth_uncertainty, feat, weights, mask)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, qc, z_vals, renderer, white_bkgd, feat_maps=None, vis_maps=None, sp_feature=None, *params):
+        o, d, z = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
+        out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd))
+        ctx.r, ctx.white = renderer, bool(white_bkgd)
+        ctx.save_for_backward(o, d, qc, z)
+        ctx.mark_non_differentiable(out["mask"])
+        return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts, _g_mask):
+        o, d, qc, z = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        names = [n for n, nd in zip(RENDER_PARAMS, need[9:]) if nd]
+        train = bool(names) or any(need[6:9])
+        tg = None
+        if train:
+            # rgb_blending_mlp.0's feature columns act on taps of the projected maps: their gradient and the maps' share of it come back as a map
+            tg = ctx.r.train_grads(names, support_feature=need[8], feat_maps=need[6], vis_featmaps=need[7],
+                                   blend_feat_maps=need[6] or "rgb_blending_mlp.0.weight" in names)
+        go, gd, gq = ctx.r.render_rays_backward(o, d, z, qc, g_rgb, g_depth, g_unc, g_feat, g_wts, white_bkgd=ctx.white, want_g_query_center=need[2], train=tg)
+        gmaps = gvis = gsp = None
+        gw = {}
+        if tg is not None:
+            gw = dict(tg.weights)
+            gmaps, gvis, gsp = tg.feat_maps, tg.vis_featmaps, tg.support_feature
+            if tg.blend_feat_maps is not None:   # P = maps . W0f^T  ->  d W0f = P_grad^T maps, d maps += P_grad . W0f
+                fm, w0 = ctx.r._frame_keep[1], ctx.r.weight_tensor("rgb_blending_mlp.0.weight")
+                W, Cf = ctx.r.W, fm.shape[-1]
+                pg = tg.blend_feat_maps.reshape(-1, 32)
+                if "rgb_blending_mlp.0.weight" in gw:
+                    gw["rgb_blending_mlp.0.weight"][:, W + 3:W + 3 + Cf] += pg.t() @ fm.reshape(-1, Cf)
+                if gmaps is not None:
+                    gmaps += (pg @ w0[:, W + 3:W + 3 + Cf]).view_as(gmaps)
+        return (go if need[0] else None, gd if need[1] else None, None if gq is None else gq.to(qc.dtype), None, None, None, gmaps, gvis, gsp) + \
+            tuple(gw.get(n) for n in RENDER_PARAMS)
+
+
 POINT_PARAMS = ("ray_diff_fc.0.weight", "ray_diff_fc.0.bias", "ray_diff_fc.2.weight", "ray_diff_fc.2.bias",
                 "base_mlp.0.weight", "base_mlp.0.bias", "base_mlp.2.weight", "base_mlp.2.bias", "base_mlp.4.weight", "base_mlp.4.bias",
                 "base_mlp_attn.w_qs.weight", "base_mlp_attn.w_ks.weight", "base_mlp_attn.w_vs.weight", "base_mlp_attn.fc.weight",
@@ -156,6 +201,7 @@ class PointBranchTrainFn(torch.autograd.Function):
 _DEC = [f"multiview_aggregator.dist_decoder.{d}_decoder.{i}.{t}" for d in ("mean", "var", "aw", "vis") for i in (0, 2, 4) for t in ("weight", "bias")]
 MV_PARAMS = tuple(f"multiview_aggregator.out_fc.{i}.{t}" for i in (0, 2) for t in ("weight", "bias")) + tuple(_DEC)
 BLEND_PARAMS = tuple(f"rgb_blending_mlp.{i}.{t}" for i in (0, 2, 4) for t in ("weight", "bias")) + tuple(_DEC)
+HEAD_PARAMS = ("sigma_mlp.0.weight", "sigma_mlp.0.bias", "feat_mlp.0.weight", "feat_mlp.0.bias", "feat_mlp.2.weight", "feat_mlp.2.bias")
 
 
 UNET_PARAMS = tuple(f"ray_unet.{blk}.{i}.{t}" for blk in ("conv1", "conv2", "conv3", "trans_conv3", "trans_conv2", "trans_conv1", "conv_out")
@@ -224,6 +270,9 @@ class BlendTrainFn(torch.autograd.Function):
         gx, gfa, gq = ctx.r.blend_backward(xyz, qc, fa, g_rgb_s.contiguous(), want_g_query_center=ctx.needs_input_grad[2], train=tg)
         return (gx if ctx.needs_input_grad[0] else None, gfa, None if gq is None else gq.to(qc.dtype), tg.blend_feat_maps, tg.vis_featmaps, None) + \
             tuple(tg.weights.get(n) for n in BLEND_PARAMS)
+
+
+RENDER_PARAMS = POINT_PARAMS + MV_PARAMS + BLEND_PARAMS[:6] + UNET_PARAMS + HEAD_PARAMS   # the 84 tensors of the ray path
 
 
 class MvAggFn(torch.autograd.Function):
@@ -479,7 +528,7 @@ def _view_angles(xyz: Tensor, query_center: Tensor, view_centers: Tensor) -> Ten
 
 def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Tensor, z_vals: Tensor, query_pose: Tensor,
                      knn_idx: Callable[[Tensor], Tensor], white_bkgd: bool = False, beta: bool = False, frozen_renderer=None,
-                     train_renderer=None) -> Dict[str, Tensor]:
+                     train_renderer=None, whole_path: bool = True) -> Dict[str, Tensor]:
     """conditional_nerf/model.py:472-600 with autograd.  `z_vals` (R, S) are constants (the hierarchical resampling detaches its
     weights, model.py:495); `knn_idx(xyz) -> (N, 8) int64` is the exact KNN (no gradient: indices); beta: the training-mode
     uncertainty output (model.py:587-592).  Gradients reach whatever requires grad among rays_o / rays_d / query_pose, the
@@ -487,6 +536,8 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     constants of this call, so the neural-point branch may run as PointBranchFn (HIP forward + HIP backward) instead of eager ops.
     train_renderer: a HipRenderer holding the CURRENT VALUES of `p` and of the frame tensors (a training step): the stages whose weight
     gradients the library computes (`*TrainFn`) run as HIP nodes that also return d/d parameters and d/d frame tensors; the others stay eager.
+    whole_path (with either renderer; no `beta`): the whole function is ONE node (`RenderFn`: fused forward, `nl_render_rays_backward`) instead of one
+    node per stage.
     fr: topk_Ks, topk_poses, topk_images, feat_fine_src, vis_featmaps, near, far (python floats), support {xyz, feature, confidence, direction}."""
     R, S = z_vals.shape
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
@@ -494,6 +545,12 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     frozen = frozen_renderer is not None and _hip_ok(xyz, dirs)
     hip_train = not frozen and train_renderer is not None and _hip_ok(xyz, dirs) and fr["support"]["xyz"].shape[0] >= 1
     r = frozen_renderer if frozen else train_renderer
+    if (frozen or hip_train) and whole_path and not beta and S == r.S and not z_vals.requires_grad and fr["support"]["xyz"].shape[0] >= 1 \
+            and all(n in p for n in HEAD_PARAMS):
+        # ONE autograd node for the whole path: the fused inference kernels forward, nl_render_rays_backward backward
+        extra = () if frozen else (fr["feat_fine_src"], fr["vis_featmaps"], fr["support"]["feature"]) + tuple(p[n] for n in RENDER_PARAMS)
+        rgb, depth, unc, feat, wts, valid = RenderFn.apply(rays_o, rays_d, query_pose[:3, 3], z_vals, r, white_bkgd, *extra)
+        return {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": unc}
     if frozen:
         # frozen weights + frozen per-frame tables (pose refinement): aggregation, neural-point branch and blend are three autograd nodes whose
         # forward AND backward run in the HIP library; nothing of them is kept on the tape but their inputs

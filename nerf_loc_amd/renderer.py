@@ -94,6 +94,7 @@ class HipRenderer:
             keep.append(t)
             arr[i] = t.data_ptr()
         self._weight_shapes = {n: tuple(t.shape) for n, t in zip(names, keep)}
+        self._weight_tensors = dict(zip(names, keep))   # fp32 device copies as packed (a few MB): the training nodes read some of them back
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.nl_pack_weights(ct.byref(self.cfg), arr, len(names), self.packed.data_ptr(), self.packed.numel(), st), "nl_pack_weights")
         torch.cuda.current_stream(self.device).synchronize()  # sources may be freed after this
@@ -104,6 +105,12 @@ class HipRenderer:
         if not self._weights_loaded:
             raise RuntimeError("load_weights first")
         return dict(self._weight_shapes)
+
+    def weight_tensor(self, name: str) -> torch.Tensor:
+        """The fp32 device copy of a state_dict tensor as it was last packed."""
+        if not self._weights_loaded:
+            raise RuntimeError("load_weights first")
+        return self._weight_tensors[name]
 
     def set_precision(self, precision: str) -> None:
         """All three weight layouts are packed at once, so switching is free."""
@@ -287,6 +294,33 @@ class HipRenderer:
         L.check(self.lib.nl_point_mlp(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, x.data_ptr(), _ptr(dr), 0 if dr is None else dr.shape[1],
                                       g.data_ptr(), N, K, fa.data_ptr(), idx.data_ptr(), d2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "nl_point_mlp")
         return fa, d2, idx
+
+    def render_rays_backward(self, rays_o, rays_d, z_vals, query_center, g_rgb=None, g_depth=None, g_depth_uncertainty=None, g_feat=None, g_weights=None,
+                             white_bkgd: bool = False, want_g_query_center: bool = False, train: "TrainGrads" = None, workspace_rays: Optional[int] = None):
+        """The whole ray path backwards in one library call (nl_render_rays_backward): cotangents of render_rays' per-ray outputs ->
+        (g_rays_o (R,3), g_rays_d (R,3), g_query_center (3,) or None); train: also ADD every parameter / map / table gradient into that TrainGrads.
+        z_vals (R,S): the sample depths of the forward call."""
+        self._ready()
+        dev = self.device
+        o, d, z = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev), _dev_f32(z_vals, dev)
+        R = o.shape[0]
+        if z.shape != (R, self.S):
+            raise ValueError(f"z_vals must be ({R}, {self.S})")
+        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        cots = [None if t is None else _dev_f32(t, dev) for t in (g_rgb, g_depth, g_depth_uncertainty, g_feat, g_weights)]
+        c = L.NlRenderCotangents()
+        c.g_rgb, c.g_depth, c.g_depth_uncertainty, c.g_feat, c.g_weights = [_ptr(t) for t in cots]
+        go, gd = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
+        gq = torch.empty(R, 3, device=dev) if want_g_query_center else None
+        if workspace_rays is None:
+            workspace_rays = getattr(self, "backward_rays_per_chunk", None)   # None: the library's default (~64 k samples per chunk, ~90 KB each at W = 256)
+        ws = self._workspace(self.lib.nl_render_rays_backward_workspace_bytes(ct.byref(self.cfg), self.V, R if workspace_rays is None else int(workspace_rays),
+                                                                              0 if train is None else 1))
+        L.check(self.lib.nl_render_rays_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
+                                                 1 if white_bkgd else 0, ct.byref(c), go.data_ptr(), gd.data_ptr(), _ptr(gq),
+                                                 None if train is None else ct.byref(train.c), ws.data_ptr(), ws.numel(), self._stream()),
+                "nl_render_rays_backward")
+        return go, gd, (None if gq is None else gq.sum(0))
 
     def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None, train: "TrainGrads" = None):
         """Input gradient of `ray_unet` (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W).  train: also ADD the gradients of the 28 U-Net tensors
