@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"])
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gradient-step", action="store_true", help="skip the (untimed for the headline) PoseOptimizer-step measurement")
     ap.add_argument("--force-gather", action="store_true", help="run the N>1 collective path on one GPU (single-rank RCCL group): a functional check")
     ap.add_argument("--also", default="bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
     ap.add_argument("--early-term-eps", type=float, default=-1.0,
@@ -262,6 +263,8 @@ def main():
         rnd.set_precision(args.precision)
         result["other_precisions"] = extra
 
+    if rank == 0 and world == 1 and not args.no_gradient_step and not hier and args.precision != "fp32":
+        result["gradient_step"] = gradient_step(rnd, cfg, frame, rays, weights, torch.device(f"cuda:{local_rank}"))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights, u_all)
     # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which a pipe flushes only at exit: every rank pushes it out
@@ -277,6 +280,39 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def gradient_step(rnd, cfg, frame, rays, weights, dev):
+    """Not the headline: one PoseOptimizer step (pose_optimizer.py:131-160: 512 rays, feature loss, forward + backward to the 4x4 pose) of the same
+    scene through the library's gradient path (fused forward, nl_render_rays_backward), after the timed region of the headline."""
+    from nerf_loc_amd import diff_render as dr
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Rg = min(512, cfg.R)
+    p = {k: t(v) for k, v in weights.items()}
+    fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
+    fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}})
+    sel = np.random.default_rng(0).choice(len(rays["pixel_coordinates"]), Rg, replace=False)
+    uv, K = t(rays["pixel_coordinates"][sel]), t(rays["K"])
+    lin = torch.linspace(0, 1, cfg.S, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(Rg, cfg.S).contiguous()
+    pose = t(frame["pose"]).clone().requires_grad_(True)
+    tf = torch.randn(Rg, cfg.C, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def one():
+        o, d = dr.rays_from_pose(uv, K, pose)
+        out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: rnd.knn(q, 8)[1], frozen_renderer=rnd)
+        loss = torch.mean(((out["feat"] - tf) * out["mask"].unsqueeze(1)) ** 2)
+        return torch.autograd.grad(loss, pose)[0]
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        g = one()
+    torch.cuda.synchronize(dev)
+    return {"what": f"PoseOptimizer step: {Rg} rays x {cfg.S} samples, forward + backward to the pose, frozen weights", "ms_per_step": (time.perf_counter() - t0) / n * 1e3,
+            "grad_finite": bool(torch.isfinite(g).all()), "path": "nl_render_rays (fused forward) + nl_render_rays_backward"}
 
 
 def baseline_metric() -> str:

@@ -8,9 +8,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > $OUT/bench_1gpu.json 2> $OUT/bench_1gpu.err
 for c in c1 c3 c4 c5; do python bench.py --config $c --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT/other_configs.jsonl; done
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --also ''"
 kt() {  # name, extra args
-  rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt_$1 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --also "" $2 > $OUT/kt_$1.log 2>&1
+  rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt_$1 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gradient-step --also "" $2 > $OUT/kt_$1.log 2>&1
   DB=$(find $OUT/kt_$1 -name "*.db" | head -1)
   python tools/prof_summary.py $DB $OUT/${1}_kernel_stats.csv > /dev/null
   [ "$1" = "c2" ] && python tools/prof_timeline.py $DB $OUT/c2_timeline.txt > /dev/null
@@ -21,7 +20,7 @@ kt c2_serial "--no-side-stream"
 kt c5 "--config c5"
 kt c4 "--config c4"
 pmc() {  # name, counters
-  rocprofv3 --kernel-trace --pmc $2 --output-format rocpd -d $OUT/pmc_$1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --also "" > $OUT/pmc_$1.log 2>&1
+  rocprofv3 --kernel-trace --pmc $2 --output-format rocpd -d $OUT/pmc_$1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gradient-step --also "" > $OUT/pmc_$1.log 2>&1
 }
 pmc sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 pmc sq2 "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
@@ -31,4 +30,7 @@ for n in sq sq2 f w; do DB=$(find $OUT/pmc_$n -name "*.db" | head -1); python to
 python tools/hbm_traffic.py $(find $OUT/pmc_f -name "*.db" | head -1) $(find $OUT/pmc_w -name "*.db" | head -1) 7 $OUT/hbm_traffic.json > /dev/null
 rm -rf $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_f $OUT/pmc_w
 python tools/pose_refine_bench.py 2>&1 | grep "rays x" > $OUT/pose_refine.txt
+ROWS=40 python tools/pose_step_profile.py 2>&1 | grep "ms/step" > $OUT/pose_step_profile.txt
+python tools/train_step_bench.py 2>&1 | grep "training step" > $OUT/train_step.txt
+PROFILE=1 python tools/train_step_bench.py 2>&1 | grep "ms/step" > $OUT/train_step_profile.txt
 python tools/setup_bench.py c2 > $OUT/setup_bench.txt 2>&1
