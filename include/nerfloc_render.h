@@ -329,7 +329,10 @@ typedef struct nl_render_cotangents {
   const float* g_depth_uncertainty;   /* (R) */
   const float* g_feat;                /* (R,C) */
   const float* g_weights;             /* (R,S) */
-  const void* reserved[3];            /* must be NULL */
+  const int32_t* knn_idx;             /* (R*S,8) and */
+  const float* knn_d2;                /* (R*S,8): the neighbours the forward call returned for the same rays (nl_render_out.knn_idx / knn_d2), both or neither;
+                                       * NULL: the search runs again */
+  const void* reserved[1];            /* must be NULL */
 } nl_render_cotangents;
 size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train);
 int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST, 3 floats */,

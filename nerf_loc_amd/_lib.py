@@ -59,7 +59,7 @@ class NlTrainGrads(C.Structure):
 
 class NlRenderCotangents(C.Structure):
     _fields_ = [("g_rgb", C.c_void_p), ("g_depth", C.c_void_p), ("g_depth_uncertainty", C.c_void_p), ("g_feat", C.c_void_p), ("g_weights", C.c_void_p),
-                ("reserved", C.c_void_p * 3)]
+                ("knn_idx", C.c_void_p), ("knn_d2", C.c_void_p), ("reserved", C.c_void_p * 1)]
 
 
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)

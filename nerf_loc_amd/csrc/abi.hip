@@ -1292,7 +1292,7 @@ void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool tra
   a.gpre4 = b.take<float>(N * 4); a.gxyz_m = b.take<float>(N * 3); a.gxyz_p = b.take<float>(N * 3); a.gdir = b.take<float>(N * 3);
   a.gG = b.take<float>(N * W); a.gqcN = b.take<float>(N * 3);
 }
-struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; };
+struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; const int* idx; const float* d2; };
 int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R,
                        int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
   const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
@@ -1304,7 +1304,7 @@ int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const f
   NL_TRY(nl_launch_sample_points(rays_o, rays_d, R, S, f->views.near_, f->views.far_, z, a.zc, a.xyz, st));
   NL_TRY(mv_recompute(x32, f, vw, a.xyz, N, a.m));                       // visibility / depth difference, statistics rows, the blend's per-view part
   NL_TRY(mv_outfc_forward(x32, f, N, a.m));                              // -> G
-  NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, nullptr, nullptr));
+  NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, ct.idx, ct.d2));
   NL_TRY(nl_launch_ln_agg(a.p.FCo, a.m.G, N, W, x32.p<float>(x32.L.ln_g), x32.p<float>(x32.L.ln_b), eps_ln, a.p.wscale, a.FA, st));
   NL_TRY(do_unet(x32, a.FA, R, a.q.geo, a.q.u));
   NL_TRY(nl_launch_sigma(a.q.geo, N, W, x32.p<float>(x32.L.sig_w), x32.p<float>(x32.L.sig_b), a.sigma, st));
@@ -1348,7 +1348,7 @@ int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const f
   NL_TRY(blend_tail_backward(xb, x32, f, vw, a.xyz, a.FA, N, a.g_rgb_s, a.gtmp, a.m, tg));
   NL_TRY(nl_launch_add(a.gFA, a.gtmp, a.gFA, (size_t)N * W, st));
   // ---------------------------------------------------------------- neural-point branch, aggregation, geometry + decoders
-  NL_TRY(pt_backward_only(xb, x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.gFA, a.gxyz_p, a.gdir, a.gG, a.p, nullptr, nullptr, tg));
+  NL_TRY(pt_backward_only(xb, x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.gFA, a.gxyz_p, a.gdir, a.gG, a.p, ct.idx, ct.d2, tg));
   NL_TRY(mv_outfc_backward(xb, x32, f, N, a.gG, a.m, tg));
   NL_TRY(mv_geom_dec_backward(x32, f, vw, a.xyz, N, a.m.gg393, true, a.gxyz_m, g_qc_rows ? a.gqcN : nullptr, a.m, tg));
   return nl_launch_ray_reduce(a.gxyz_m, a.gxyz_p, nullptr, a.gdir, g_qc_rows ? a.gqcN : nullptr, a.zc, R, S, g_o, g_d, g_qc_rows, st);
@@ -1841,7 +1841,7 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
                             float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
-  for (int i = 0; i < 3; ++i) if (g->reserved[i] != nullptr) return NL_ERR_BAD_ARG;
+  if (g->reserved[0] != nullptr || (g->knn_idx == nullptr) != (g->knn_d2 == nullptr)) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
   const int V = f->views.V, S = cfg->S, C = cfg->C;
   const bool train = grads != nullptr;
@@ -1856,7 +1856,8 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
     const int64_t rc = R - r0 < RC ? R - r0 : RC;
     Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, rc, a, train);
     RbCot ct{g->g_rgb ? g->g_rgb + 3 * r0 : nullptr, g->g_depth ? g->g_depth + r0 : nullptr, g->g_depth_uncertainty ? g->g_depth_uncertainty + r0 : nullptr,
-             g->g_feat ? g->g_feat + r0 * C : nullptr, g->g_weights ? g->g_weights + r0 * S : nullptr};
+             g->g_feat ? g->g_feat + r0 * C : nullptr, g->g_weights ? g->g_weights + r0 * S : nullptr,
+             g->knn_idx ? g->knn_idx + r0 * S * 8 : nullptr, g->knn_d2 ? g->knn_d2 + r0 * S * 8 : nullptr};
     NL_TRY(do_render_backward(B.xb, B.x32, f, query_center, rays_o + 3 * r0, rays_d + 3 * r0, z_vals + r0 * S, rc, white_bkgd, ct, g_rays_o + 3 * r0,
                               g_rays_d + 3 * r0, g_query_center_rows ? g_query_center_rows + 3 * r0 : nullptr, a, train ? &T : nullptr));
   }

@@ -130,15 +130,15 @@ class RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, qc, z_vals, renderer, white_bkgd, feat_maps=None, vis_maps=None, sp_feature=None, *params):
         o, d, z = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
-        out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd))
+        out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd), want_knn=True)
         ctx.r, ctx.white = renderer, bool(white_bkgd)
-        ctx.save_for_backward(o, d, qc, z)
+        ctx.save_for_backward(o, d, qc, z, out["knn_d2"], out["knn_idx"])
         ctx.mark_non_differentiable(out["mask"])
         return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts, _g_mask):
-        o, d, qc, z = ctx.saved_tensors
+        o, d, qc, z, kd2, kidx = ctx.saved_tensors
         need = ctx.needs_input_grad
         names = [n for n, nd in zip(RENDER_PARAMS, need[9:]) if nd]
         train = bool(names) or any(need[6:9])
@@ -147,7 +147,8 @@ class RenderFn(torch.autograd.Function):
             # rgb_blending_mlp.0's feature columns act on taps of the projected maps: their gradient and the maps' share of it come back as a map
             tg = ctx.r.train_grads(names, support_feature=need[8], feat_maps=need[6], vis_featmaps=need[7],
                                    blend_feat_maps=need[6] or "rgb_blending_mlp.0.weight" in names)
-        go, gd, gq = ctx.r.render_rays_backward(o, d, z, qc, g_rgb, g_depth, g_unc, g_feat, g_wts, white_bkgd=ctx.white, want_g_query_center=need[2], train=tg)
+        go, gd, gq = ctx.r.render_rays_backward(o, d, z, qc, g_rgb, g_depth, g_unc, g_feat, g_wts, white_bkgd=ctx.white, want_g_query_center=need[2], train=tg,
+                                                knn=(kd2, kidx))
         gmaps = gvis = gsp = None
         gw = {}
         if tg is not None:

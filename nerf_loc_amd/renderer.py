@@ -194,7 +194,7 @@ class HipRenderer:
     # ------------------------------------------------------------------ fused path
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
                     intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0,
-                    side_stream: bool = True) -> Dict[str, torch.Tensor]:
+                    side_stream: bool = True, want_knn: bool = False) -> Dict[str, torch.Tensor]:
         """side_stream=False (nl_render_opts.flags = NL_RENDER_NO_SIDE_STREAM): every kernel on the current stream (bit-identical results;
         for profiling kernels one at a time).
         early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
@@ -217,6 +217,8 @@ class HipRenderer:
         }
         if want_feat:
             out["feat"] = torch.empty(R, self.C, device=dev)
+        if want_knn and not intermediates:   # the neighbours alone (the gradient path hands them to nl_render_rays_backward)
+            out.update({"knn_idx": torch.empty(R * S, 8, dtype=torch.int32, device=dev), "knn_d2": torch.empty(R * S, 8, device=dev)})
         if intermediates:
             N = R * S
             out.update({"sigma": torch.empty(N, device=dev), "feature_agg": torch.empty(N, W, device=dev),
@@ -296,7 +298,8 @@ class HipRenderer:
         return fa, d2, idx
 
     def render_rays_backward(self, rays_o, rays_d, z_vals, query_center, g_rgb=None, g_depth=None, g_depth_uncertainty=None, g_feat=None, g_weights=None,
-                             white_bkgd: bool = False, want_g_query_center: bool = False, train: "TrainGrads" = None, workspace_rays: Optional[int] = None):
+                             white_bkgd: bool = False, want_g_query_center: bool = False, train: "TrainGrads" = None, workspace_rays: Optional[int] = None,
+                             knn=None):
         """The whole ray path backwards in one library call (nl_render_rays_backward): cotangents of render_rays' per-ray outputs ->
         (g_rays_o (R,3), g_rays_d (R,3), g_query_center (3,) or None); train: also ADD every parameter / map / table gradient into that TrainGrads.
         z_vals (R,S): the sample depths of the forward call."""
@@ -310,6 +313,9 @@ class HipRenderer:
         cots = [None if t is None else _dev_f32(t, dev) for t in (g_rgb, g_depth, g_depth_uncertainty, g_feat, g_weights)]
         c = L.NlRenderCotangents()
         c.g_rgb, c.g_depth, c.g_depth_uncertainty, c.g_feat, c.g_weights = [_ptr(t) for t in cots]
+        if knn is not None:   # (d2, idx) of the forward call: saves the second neighbour search
+            kd2, kidx = knn[0].contiguous(), knn[1].to(torch.int32).contiguous()
+            c.knn_d2, c.knn_idx = kd2.data_ptr(), kidx.data_ptr()
         go, gd = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
         gq = torch.empty(R, 3, device=dev) if want_g_query_center else None
         if workspace_rays is None:
