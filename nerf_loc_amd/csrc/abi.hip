@@ -1366,6 +1366,7 @@ Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
 extern "C" {
 
 static_assert(sizeof(nl_render_opts) == 32, "nl_render_opts is part of the C-ABI: 32 bytes");
+static_assert(sizeof(nl_train_grads) == 72 && sizeof(nl_render_cotangents) == 64, "training / cotangent blocks are part of the C-ABI");
 static_assert(offsetof(nl_render_opts, flags) == 4 && offsetof(nl_render_opts, ray_centers) == 8, "nl_render_opts layout");
 int nl_abi_version(void) { return NL_ABI_VERSION; }
 
@@ -1715,10 +1716,10 @@ int nl_point_mlp_backward_train(const nl_config* cfg, const void* packed, const 
                                 float* g_dir, float* g_mv_feat, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
-  if (f->M < 1) return NL_ERR_UNSUPPORTED;
   const bool train = grads != nullptr;
   TrainOut T;
-  NL_TRY(resolve_train(cfg, grads, T));
+  NL_TRY(resolve_train(cfg, grads, T));   // (validated before anything is dereferenced)
+  if (f->M < 1) return NL_ERR_UNSUPPORTED;
   if (ws_bytes < point_bwd_bytes(cfg, 1, train)) return NL_ERR_WORKSPACE;
   // Precision of the two halves (measured):
   //  * the RECOMPUTED FORWARD must be much better than split-bf16: the derivative of a LeakyReLU network is piecewise constant, and a forward that
@@ -1771,10 +1772,10 @@ int nl_mv_aggregate_backward_train(const nl_config* cfg, const void* packed, con
                                    const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !g_mv_feat || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
-  const int V = f->views.V, W = cfg->W;
   const bool train = grads != nullptr;
   TrainOut T;
   NL_TRY(resolve_train(cfg, grads, T));
+  const int V = f->views.V, W = cfg->W;
   const int64_t NC = mv_bwd_chunk(cfg, V, N, false, ws_bytes, train);
   if (NC == 0) return NL_ERR_WORKSPACE;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
@@ -1813,10 +1814,10 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
                             size_t ws_bytes, void* stream) {
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !qc || !xyz || !feature_agg || !g_rgb_s || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
-  const int V = f->views.V, W = cfg->W;
   const bool train = grads != nullptr;
   TrainOut T;
   NL_TRY(resolve_train(cfg, grads, T));
+  const int V = f->views.V, W = cfg->W;
   const int64_t NC = mv_bwd_chunk(cfg, V, N, true, ws_bytes, train);
   if (NC == 0) return NL_ERR_WORKSPACE;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
@@ -1842,11 +1843,11 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (g->reserved[0] != nullptr || (g->knn_idx == nullptr) != (g->knn_d2 == nullptr)) return NL_ERR_BAD_ARG;
-  if (f->M < 1) return NL_ERR_UNSUPPORTED;
-  const int V = f->views.V, S = cfg->S, C = cfg->C;
   const bool train = grads != nullptr;
   TrainOut T;
   NL_TRY(resolve_train(cfg, grads, T));
+  if (f->M < 1) return NL_ERR_UNSUPPORTED;
+  const int V = f->views.V, S = cfg->S, C = cfg->C;
   if (ws_bytes < render_bwd_bytes(cfg, V, 1, train)) return NL_ERR_WORKSPACE;
   int64_t lo = 1, hi = R;
   while (lo < hi) { const int64_t mid = (lo + hi + 1) / 2; if (render_bwd_bytes(cfg, V, mid, train) <= ws_bytes) lo = mid; else hi = mid - 1; }

@@ -93,3 +93,37 @@ def test_build_post_check_agrees_with_the_header():
     """__graft_entry__.build() ends with this check (round 2 shipped a stale hard-coded version there)."""
     import __graft_entry__ as g
     g.post_build_check()
+
+
+def test_train_grads_are_validated_before_anything_is_dereferenced():
+    """nl_train_grads (training entry points): non-zero reserved words are NL_ERR_BAD_ARG, a missing / short / misaligned split-K scratch is
+    NL_ERR_WORKSPACE — checked before the frame or any device pointer is touched (no GPU needed: the pointers below are host buffers that are never read)."""
+    import ctypes as ct
+    lib = _lib.load()
+    cfg = _lib.NlConfig(64, 192, 32, 1)
+    buf = (ct.c_char * 4096)()
+    p = ct.cast(buf, ct.c_void_p)
+    need = lib.nl_train_scratch_bytes(ct.byref(cfg))
+    assert need > 0 and lib.nl_train_scratch_bytes(None) == 0
+
+    def unet(g):
+        return lib.nl_ray_unet_backward_train(ct.byref(cfg), p, p, 4, p, p, ct.byref(g), p, 4096, None)
+    g = _lib.NlTrainGrads()
+    g.scratch, g.scratch_bytes = p, need
+    g.reserved[1] = 5
+    assert unet(g) == _lib.NL_ERR_BAD_ARG
+    g = _lib.NlTrainGrads()
+    assert unet(g) == _lib.NL_ERR_WORKSPACE                       # no scratch
+    g.scratch, g.scratch_bytes = p, need - 1
+    assert unet(g) == _lib.NL_ERR_WORKSPACE                       # short
+    g.scratch, g.scratch_bytes = ct.c_void_p(p.value + 4), need
+    assert unet(g) == _lib.NL_ERR_WORKSPACE                       # misaligned
+    # the cotangent block of the whole-path backward: its reserved word and a half-given neighbour pair
+    c = _lib.NlRenderCotangents()
+    c.reserved[0] = p
+    call = lambda cc: lib.nl_render_rays_backward(ct.byref(cfg), p, p, p, p, p, p, 4, 0, ct.byref(cc), p, p, None, None, p, 4096, None)
+    assert call(c) == _lib.NL_ERR_BAD_ARG
+    c = _lib.NlRenderCotangents()
+    c.knn_idx = p
+    assert call(c) == _lib.NL_ERR_BAD_ARG
+    assert ct.sizeof(_lib.NlTrainGrads) == 72 and ct.sizeof(_lib.NlRenderCotangents) == 64
