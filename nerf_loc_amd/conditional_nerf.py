@@ -228,15 +228,15 @@ class ConditionalNeRF(nn.Module):
         if r is None:
             r = HipRenderer(self.W, self.C, self.S, self._precision, device=dev)
             self._renderers[level] = r
-            self._weights_version = -1
         ver = sum(p._version for p in self.parameters())
-        if ver != self._weights_version or not r._weights_loaded:
+        stale = [rr for rr in self._renderers.values() if ver != self._weights_version or not rr._weights_loaded]
+        if stale:   # (a renderer created later in a step packs for itself: the others' state — and the autograd nodes that hold them — stay untouched)
             sd = dict(self.state_dict())
             if "feat_mlp.0.weight" not in sd:   # render.render_feature=False (model.py:84-89): the head does not exist and is never evaluated
                 z = next(self.parameters()).new_zeros
                 sd.update({"feat_mlp.0.weight": z(self.W, self.W), "feat_mlp.0.bias": z(self.W), "feat_mlp.2.weight": z(self.C, self.W),
                            "feat_mlp.2.bias": z(self.C)})
-            for rr in self._renderers.values():
+            for rr in stale:
                 rr.load_weights(sd)
             self._weights_version = ver
         return r

@@ -107,17 +107,25 @@ class PointBranchFn(torch.autograd.Function):
     def forward(ctx, xyz, dirs, G, renderer, K):
         xyz, G = xyz.contiguous(), G.contiguous()
         dirs = None if dirs is None else dirs.contiguous()
-        ctx.r, ctx.K, ctx.has_dir = renderer, int(K), dirs is not None
+        ctx.r, ctx.K, ctx.has_dir, ctx.gen = renderer, int(K), dirs is not None, renderer.state_gen
         fa, d2, idx = renderer.point_mlp(xyz, dirs, G, K=int(K))
         ctx.save_for_backward(xyz, G, d2, idx, *([dirs] if dirs is not None else []))
         return fa
 
     @staticmethod
     def backward(ctx, g_fa):
+        _same_state(ctx)
         xyz, G, d2, idx = ctx.saved_tensors[:4]
         dirs = ctx.saved_tensors[4] if ctx.has_dir else None
         gx, gd, gg = ctx.r.point_mlp_backward(xyz, dirs, G, g_fa.contiguous(), K=ctx.K, knn=(d2, idx))
         return gx, gd, gg, None, None
+
+
+def _same_state(ctx):
+    """The library nodes keep no activations: their backward recomputes from the renderer's CURRENT weights and frame tables, which therefore must be
+    the forward call's (one training / refinement step = forward and backward against one frame)."""
+    if ctx.r.state_gen != ctx.gen:
+        raise RuntimeError("the HipRenderer's weights or frame were replaced between the forward and the backward pass of this autograd node")
 
 
 class RenderFn(torch.autograd.Function):
@@ -131,13 +139,14 @@ class RenderFn(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, qc, z_vals, renderer, white_bkgd, feat_maps=None, vis_maps=None, sp_feature=None, *params):
         o, d, z = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
         out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd), want_knn=True)
-        ctx.r, ctx.white = renderer, bool(white_bkgd)
+        ctx.r, ctx.white, ctx.gen = renderer, bool(white_bkgd), renderer.state_gen
         ctx.save_for_backward(o, d, qc, z, out["knn_d2"], out["knn_idx"])
         ctx.mark_non_differentiable(out["mask"])
         return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts, _g_mask):
+        _same_state(ctx)
         o, d, qc, z, kd2, kidx = ctx.saved_tensors
         need = ctx.needs_input_grad
         names = [n for n, nd in zip(RENDER_PARAMS, need[9:]) if nd]
@@ -184,13 +193,14 @@ class PointBranchTrainFn(torch.autograd.Function):
     def forward(ctx, xyz, dirs, G, sp_feature, renderer, K, *params):
         xyz, G = xyz.contiguous(), G.contiguous()
         dirs = None if dirs is None else dirs.contiguous()
-        ctx.r, ctx.K, ctx.has_dir = renderer, int(K), dirs is not None
+        ctx.r, ctx.K, ctx.has_dir, ctx.gen = renderer, int(K), dirs is not None, renderer.state_gen
         fa, d2, idx = renderer.point_mlp(xyz, dirs, G, K=int(K))
         ctx.save_for_backward(xyz, G, d2, idx, *([dirs] if dirs is not None else []))
         return fa
 
     @staticmethod
     def backward(ctx, g_fa):
+        _same_state(ctx)
         xyz, G, d2, idx = ctx.saved_tensors[:4]
         dirs = ctx.saved_tensors[4] if ctx.has_dir else None
         names = [n for n, need in zip(POINT_PARAMS, ctx.needs_input_grad[6:]) if need]
@@ -216,12 +226,13 @@ class UnetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, renderer, *params):
         x = x.contiguous()
-        ctx.r = renderer
+        ctx.r, ctx.gen = renderer, renderer.state_gen
         ctx.save_for_backward(x)
         return renderer.ray_unet(x)
 
     @staticmethod
     def backward(ctx, g_geo):
+        _same_state(ctx)
         x, = ctx.saved_tensors
         names = [n for n, need in zip(UNET_PARAMS, ctx.needs_input_grad[2:]) if need]
         tg = ctx.r.train_grads(names)
@@ -236,7 +247,7 @@ class MvAggTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, feat_maps, vis_maps, renderer, *params):
         xyz = xyz.contiguous()
-        ctx.r = renderer
+        ctx.r, ctx.gen = renderer, renderer.state_gen
         ctx.save_for_backward(xyz)
         mv, _, _, valid = renderer.mv_aggregate(xyz, torch.zeros(3), want_raw=False)
         ctx.mark_non_differentiable(valid)
@@ -244,6 +255,7 @@ class MvAggTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_mv, _g_valid):
+        _same_state(ctx)
         xyz, = ctx.saved_tensors
         names = [n for n, need in zip(MV_PARAMS, ctx.needs_input_grad[4:]) if need]
         tg = ctx.r.train_grads(names, feat_maps=ctx.needs_input_grad[1], vis_featmaps=ctx.needs_input_grad[2])
@@ -259,12 +271,13 @@ class BlendTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, fa, qc, pmaps, vis_maps, renderer, *params):
         xyz, fa = xyz.contiguous(), fa.contiguous()
-        ctx.r = renderer
+        ctx.r, ctx.gen = renderer, renderer.state_gen
         ctx.save_for_backward(xyz, fa, qc)
         return renderer.blend(xyz, qc, fa)
 
     @staticmethod
     def backward(ctx, g_rgb_s):
+        _same_state(ctx)
         xyz, fa, qc = ctx.saved_tensors
         names = [n for n, need in zip(BLEND_PARAMS, ctx.needs_input_grad[6:]) if need]
         tg = ctx.r.train_grads(names, vis_featmaps=ctx.needs_input_grad[4], blend_feat_maps=ctx.needs_input_grad[3])
@@ -283,7 +296,7 @@ class MvAggFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, renderer):
         xyz = xyz.contiguous()
-        ctx.r = renderer
+        ctx.r, ctx.gen = renderer, renderer.state_gen
         ctx.save_for_backward(xyz)
         mv, _, _, valid = renderer.mv_aggregate(xyz, torch.zeros(3), want_raw=False)
         ctx.mark_non_differentiable(valid)
@@ -291,6 +304,7 @@ class MvAggFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_mv, _g_valid):
+        _same_state(ctx)
         xyz, = ctx.saved_tensors
         return ctx.r.mv_aggregate_backward(xyz, g_mv.contiguous()), None
 
@@ -301,12 +315,13 @@ class UnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, renderer):
         x = x.contiguous()
-        ctx.r = renderer
+        ctx.r, ctx.gen = renderer, renderer.state_gen
         ctx.save_for_backward(x)
         return renderer.ray_unet(x)
 
     @staticmethod
     def backward(ctx, g_geo):
+        _same_state(ctx)
         x, = ctx.saved_tensors
         return ctx.r.ray_unet_backward(x, g_geo.contiguous()), None
 
@@ -318,12 +333,13 @@ class BlendFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, fa, qc, renderer):
         xyz, fa = xyz.contiguous(), fa.contiguous()
-        ctx.r = renderer
+        ctx.r, ctx.gen = renderer, renderer.state_gen
         ctx.save_for_backward(xyz, fa, qc)
         return renderer.blend(xyz, qc, fa)
 
     @staticmethod
     def backward(ctx, g_rgb_s):
+        _same_state(ctx)
         xyz, fa, qc = ctx.saved_tensors
         gx, gfa, gq = ctx.r.blend_backward(xyz, qc, fa, g_rgb_s.contiguous(), want_g_query_center=ctx.needs_input_grad[2])
         return gx, gfa, (None if gq is None else gq.to(qc.dtype)), None

@@ -95,6 +95,7 @@ class HipRenderer:
             arr[i] = t.data_ptr()
         self._weight_shapes = {n: tuple(t.shape) for n, t in zip(names, keep)}
         self._weight_tensors = dict(zip(names, keep))   # fp32 device copies as packed (a few MB): the training nodes read some of them back
+        self.state_gen = getattr(self, "state_gen", 0) + 1   # autograd nodes check that weights / frame did not change between their forward and backward
         st = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.nl_pack_weights(ct.byref(self.cfg), arr, len(names), self.packed.data_ptr(), self.packed.numel(), st), "nl_pack_weights")
         torch.cuda.current_stream(self.device).synchronize()  # sources may be freed after this
@@ -161,6 +162,7 @@ class HipRenderer:
         self._frame_keep = (images, feat, visf, sp, mem, proj_ibr, proj_neuray, cams)
         self.V, self.near, self.far, self.M = V, float(near), float(far), M
         self._map_shapes = ((V, h, w, feat.shape[3]), (V, visf.shape[2], visf.shape[3], 32), (V, h, w, 32))
+        self.state_gen = getattr(self, "state_gen", 0) + 1
 
     def clear_frame(self) -> None:
         if self._frame:

@@ -512,3 +512,17 @@ def test_whole_path_backward_matches_the_stage_nodes(case, precision, train, chu
     assert worst[1] < (2e-3 if precision == "fp32" else 3e-2), worst
     assert float(np.median(list(errs.values()))) < (1e-5 if precision == "fp32" else 2e-3)
     print(case, precision, "train" if train else "frozen", "worst", worst, "median", float(np.median(list(errs.values()))))
+
+
+@pytest.mark.gpu
+def test_nodes_refuse_a_backward_pass_against_replaced_state():
+    """The library nodes recompute from the renderer's current weights / frame: replacing either between forward and backward raises instead of
+    silently differentiating another function."""
+    cfg, r, p, fr, xyz, pose = _mv_setup("tiny_full")
+    from tests.golden_cases import build_case
+    frame = build_case("tiny_full")["frame"]
+    a = xyz.clone().requires_grad_(True)
+    out = dr.MvAggFn.apply(a, r)[0]
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    with pytest.raises(RuntimeError, match="replaced between the forward and the backward"):
+        out.sum().backward()

@@ -386,3 +386,44 @@ def test_query_training_gradients_through_the_dropin_match_reference_autograd_gp
         hc, _, _ = net.query_coarse(data, pts)
         hf, _, _ = net.query_fine(data, pts)
     assert rel_err(hc.cpu().numpy(), desc_c.detach().cpu().numpy()) < 1e-4 and rel_err(hf.cpu().numpy(), desc_f.detach().cpu().numpy()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_one_training_step_with_both_losses_shares_the_frame_state():
+    """The reference's training step (nerf_pose_estimator.py:316-365): query_coarse, query_fine and compute_render_loss against ONE frame, then one
+    backward pass.  The library nodes of all three recompute from the renderers' frame tables at backward time, so nothing may replace those
+    between the calls (the nodes check it): the combined step's gradients equal the sum of the gradients of the two losses taken separately."""
+    from tests.test_dropin_module import _args
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    dev = torch.device("cuda:0")
+
+    def step(which):
+        case, cfg, data, rays = _train_case(dev, False)
+        _, _, _, pts, tc, tf = _query_case(dev)
+        data["feat_coarse_src"] = data["feat_coarse_src"].clone().requires_grad_(True)
+        net = ConditionalNeRF(_args(cfg), precision="fp32").to(dev).train()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+        net.support_neural_points = None
+        net.multiview_aggregator.vis_featmaps = None
+        loss = 0.0
+        if "q" in which:
+            desc_c, _, _ = net.query_coarse(data, pts)
+            desc_f, _, _ = net.query_fine(data, pts)
+            loss = loss + (desc_c * tc).sum() / len(pts) + (desc_f * tf).sum() / len(pts)
+        if "r" in which:
+            loss = loss + net.compute_render_loss(data)[0]
+        loss.backward()
+        g = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+        g["feat_fine_src"], g["feat_coarse_src"] = data["feat_fine_src"].grad, data["feat_coarse_src"].grad
+        return g
+    both, q, r = step("qr"), step("q"), step("r")
+    gmax = max(float(v.abs().max()) for v in both.values() if v is not None)
+    worst = ("", 0.0)
+    for k, v in both.items():
+        if v is None:
+            continue
+        ref = sum(x[k] for x in (q, r) if x.get(k) is not None)
+        e = float((v - ref).abs().max() / max(float(ref.abs().max()) if torch.is_tensor(ref) else 0.0, 1e-5 * gmax))
+        if e > worst[1]: worst = (k, e)
+    print("worst:", worst)
+    assert worst[1] < 2e-3, worst    # (summation order of the accumulated .grad and of the map scatter-adds)
