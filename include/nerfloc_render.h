@@ -340,6 +340,20 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
                             float* g_rays_o, float* g_rays_d, float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* The gradient path's forward and backward as a PAIR sharing one workspace: nl_render_rays_forward_keep runs the STAGED forward (the arithmetic of the
+ * backward pass's recompute: exact fp32 / split-FP16), writes the per-ray outputs and leaves every intermediate in `ws`; nl_render_rays_backward_kept walks
+ * back from them — no recompute, no second neighbour search.  The caller keeps `ws` untouched in between and passes the same rays / query centre / `train`
+ * flag to both.  The whole batch is one chunk: NL_ERR_WORKSPACE when it does not fit (then: nl_render_rays + nl_render_rays_backward, which chunk).
+ * `out`: rgb, depth, weights, mask, depth_uncertainty required, feat optional (without it feat_mlp is not evaluated and g_feat must be NULL), the
+ * optional intermediates are ignored. */
+size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train);
+int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST */, const float* rays_o,
+                                const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, int train, void* ws,
+                                size_t ws_bytes, void* stream);
+int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST */, const float* rays_d,
+                                 int64_t R, int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d, float* g_query_center_rows,
+                                 const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
+
 /* nl_ray_unet_backward + gradients of the seven blocks' convolution weights / biases and LayerNorm([C, L]) tables (28 tensors). */
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R);
 int nl_ray_unet_backward_train(const nl_config* cfg, const void* packed, const float* x, int64_t R, const float* g_geo, float* g_x,

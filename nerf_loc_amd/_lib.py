@@ -101,6 +101,9 @@ SYMBOLS = [
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
+    ("nl_render_rays_keep_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
+    ("nl_render_rays_forward_keep", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _I, _P, _Z, _P]),
+    ("nl_render_rays_backward_kept", _I, [_CFG, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_render_rays_backward_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
     ("nl_render_rays_backward", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_ray_unet_backward_train_workspace_bytes", _Z, [_CFG, _L]),

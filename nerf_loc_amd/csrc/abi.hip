@@ -1293,27 +1293,35 @@ void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool tra
   a.gG = b.take<float>(N * W); a.gqcN = b.take<float>(N * 3);
 }
 struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; const int* idx; const float* d2; };
-int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R,
-                       int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
-  const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
+// the staged forward of the whole path into the workspace (everything the way back reads).  want_feat: feat_mlp.0's hidden rows too
+int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R, bool want_feat,
+                          const int* knn_idx, const float* knn_d2, const RbBufs& a) {
+  const int W = x32.c->W, S = x32.c->S;
   const int64_t N = R * S;
   hipStream_t st = x32.st;
   const NlViews vw = with_query(f, qc);
   const float eps_ln = 1e-6f;
-  // ---------------------------------------------------------------- forward, staged, everything kept in the workspace
   NL_TRY(nl_launch_sample_points(rays_o, rays_d, R, S, f->views.near_, f->views.far_, z, a.zc, a.xyz, st));
   NL_TRY(mv_recompute(x32, f, vw, a.xyz, N, a.m));                       // visibility / depth difference, statistics rows, the blend's per-view part
   NL_TRY(mv_outfc_forward(x32, f, N, a.m));                              // -> G
-  NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, ct.idx, ct.d2));
+  NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, knn_idx, knn_d2));
   NL_TRY(nl_launch_ln_agg(a.p.FCo, a.m.G, N, W, x32.p<float>(x32.L.ln_g), x32.p<float>(x32.L.ln_b), eps_ln, a.p.wscale, a.FA, st));
   NL_TRY(do_unet(x32, a.FA, R, a.q.geo, a.q.u));
   NL_TRY(nl_launch_sigma(a.q.geo, N, W, x32.p<float>(x32.L.sig_w), x32.p<float>(x32.L.sig_b), a.sigma, st));
   SegSpec sfa{a.FA, W, W, 0, 1};
-  const bool want_feat = ct.g_feat != nullptr;
   if (want_feat) NL_TRY(run_gemm(x32, G_FEAT0, &sfa, 1, N, a.Hf, W, NL_ACT_LRELU));
   NL_TRY(run_gemm(x32, G_BLENDA, &sfa, 1, N, a.m.blA, 32, NL_ACT_NONE));
-  NL_TRY(nl_launch_blend(a.m.blA, a.m.bl1, a.m.rgbv, N, vw.V, x32.p<float>(x32.L.bl2_w), x32.p<float>(x32.L.bl2_b), x32.p<float>(x32.L.bl4_w),
-                         x32.p<float>(x32.L.bl4_b), a.rgb_s, st));
+  return nl_launch_blend(a.m.blA, a.m.bl1, a.m.rgbv, N, vw.V, x32.p<float>(x32.L.bl2_w), x32.p<float>(x32.L.bl2_b), x32.p<float>(x32.L.bl4_w),
+                         x32.p<float>(x32.L.bl4_b), a.rgb_s, st);
+}
+// the way back from the staged forward's workspace
+int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_d, int64_t R, int white, const RbCot& ct,
+                           float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
+  const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
+  const int64_t N = R * S;
+  hipStream_t st = x32.st;
+  const NlViews vw = with_query(f, qc);
+  const bool want_feat = ct.g_feat != nullptr;
   // ---------------------------------------------------------------- compositing backwards (feat = W2 . sum_s w_s hidden_s + b2 sum_s w_s)
   const float* b2 = x32.p<float>(x32.L.b32[G_FEAT2]) + (size_t)W * x32.L.g[G_FEAT2].Npad;   // the bias row of G_FEAT2's fp32 weights (K row W)
   if (want_feat) {
@@ -1352,6 +1360,23 @@ int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const f
   NL_TRY(mv_outfc_backward(xb, x32, f, N, a.gG, a.m, tg));
   NL_TRY(mv_geom_dec_backward(x32, f, vw, a.xyz, N, a.m.gg393, true, a.gxyz_m, g_qc_rows ? a.gqcN : nullptr, a.m, tg));
   return nl_launch_ray_reduce(a.gxyz_m, a.gxyz_p, nullptr, a.gdir, g_qc_rows ? a.gqcN : nullptr, a.zc, R, S, g_o, g_d, g_qc_rows, st);
+}
+int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R,
+                       int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
+  NL_TRY(render_forward_staged(x32, f, qc, rays_o, rays_d, z, R, ct.g_feat != nullptr, ct.idx, ct.d2, a));
+  return render_backward_staged(xb, x32, f, qc, rays_d, R, white, ct, g_o, g_d, g_qc_rows, a, tg);
+}
+// the per-ray outputs from the staged forward's workspace (the gradient path's forward values: split-FP16 arithmetic in the bf16 modes)
+int render_outputs_staged(const Ctx& x32, const nl_frame* f, int64_t R, int white, const nl_render_out* out, const RbBufs& a) {
+  const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
+  const bool want_feat = out->feat != nullptr;
+  NL_TRY(nl_launch_composite(a.zc, a.sigma, a.rgb_s, want_feat ? a.Hf : nullptr, a.m.valid_s, R, S, W, white, out, 0, want_feat ? a.hc : nullptr,
+                             want_feat ? a.gw : nullptr, x32.st));   // (a.gw: R floats of scratch for the weight sums; the way back rewrites it)
+  if (want_feat) {
+    SegSpec s1[2] = {{a.hc, W, W, 0, 1}, {a.gw, 1, 1, 0, 1}};
+    NL_TRY(run_gemm(x32, G_FEAT2, s1, 2, R, out->feat, C, NL_ACT_NONE));
+  }
+  return NL_OK;
 }
 
 Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
@@ -1863,6 +1888,44 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
                               g_rays_d + 3 * r0, g_query_center_rows ? g_query_center_rows + 3 * r0 : nullptr, a, train ? &T : nullptr));
   }
   return NL_OK;
+}
+
+// The gradient path's forward and backward as a PAIR that shares one workspace: the forward call leaves the staged activations there, the backward call
+// walks back from them without recomputing.  The whole batch must fit the workspace as one chunk (NL_ERR_WORKSPACE otherwise: use nl_render_rays +
+// nl_render_rays_backward, which chunk).
+size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train) {
+  if (!cfg_ok(cfg) || V < 1 || V > NL_MAX_VIEWS || R < 1) return 0;
+  return render_bwd_bytes(cfg, V, R, train != 0);
+}
+int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_o, const float* rays_d,
+                                const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, int train, void* ws, size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (!out->rgb || !out->depth || !out->weights || !out->mask || !out->depth_uncertainty) return NL_ERR_BAD_ARG;
+  if (f->M < 1) return NL_ERR_UNSUPPORTED;
+  const int V = f->views.V;
+  if (ws_bytes < render_bwd_bytes(cfg, V, R, train != 0)) return NL_ERR_WORKSPACE;
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train != 0);
+  NL_TRY(render_forward_staged(B.x32, f, query_center, rays_o, rays_d, z_vals, R, out->feat != nullptr, nullptr, nullptr, a));
+  return render_outputs_staged(B.x32, f, R, white_bkgd, out, a);
+}
+int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_d, int64_t R,
+                                 int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d, float* g_query_center_rows,
+                                 const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  if (R == 0) return NL_OK;
+  if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_d || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (g->reserved[0] != nullptr || g->knn_idx || g->knn_d2) return NL_ERR_BAD_ARG;   // (the neighbours are in the workspace)
+  const bool train = grads != nullptr;
+  TrainOut T;
+  NL_TRY(resolve_train(cfg, grads, T));
+  if (f->M < 1) return NL_ERR_UNSUPPORTED;
+  const int V = f->views.V;
+  if (ws_bytes < render_bwd_bytes(cfg, V, R, train)) return NL_ERR_WORKSPACE;
+  BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
+  Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train);
+  RbCot ct{g->g_rgb, g->g_depth, g->g_depth_uncertainty, g->g_feat, g->g_weights, nullptr, nullptr};
+  return render_backward_staged(B.xb, B.x32, f, query_center, rays_d, R, white_bkgd, ct, g_rays_o, g_rays_d, g_query_center_rows, a, train ? &T : nullptr);
 }
 
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R) {

@@ -128,6 +128,11 @@ def _same_state(ctx):
         raise RuntimeError("the HipRenderer's weights or frame were replaced between the forward and the backward pass of this autograd node")
 
 
+# RenderFn keeps the staged forward's activations for the backward call when they fit this many bytes (one chunk: ~90 KB per sample at W = 256, i.e. a
+# PoseOptimizer or training batch); 0 = never (fused forward + recompute)
+KEEP_BYTES = 12 << 30
+
+
 class RenderFn(torch.autograd.Function):
     """ConditionalNeRF.render_rays (model.py:472-600) as ONE autograd node on the HIP library: forward = the fused inference path
     (`nl_render_rays`), backward = `nl_render_rays_backward` — the whole path backwards in one call, every per-sample quantity recomputed once
@@ -138,16 +143,24 @@ class RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, qc, z_vals, renderer, white_bkgd, feat_maps=None, vis_maps=None, sp_feature=None, *params):
         o, d, z = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
-        out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd), want_knn=True)
         ctx.r, ctx.white, ctx.gen = renderer, bool(white_bkgd), renderer.state_gen
-        ctx.save_for_backward(o, d, qc, z, out["knn_d2"], out["knn_idx"])
+        ctx.kept = None
+        train = len(params) > 0
+        # small batches (a PoseOptimizer / training step): the staged forward whose activations the backward call reuses, when they fit KEEP_BYTES
+        kept = renderer.render_rays_keep(o, d, z, qc, white_bkgd=bool(white_bkgd), train=train, max_bytes=KEEP_BYTES) if KEEP_BYTES else None
+        if kept is not None:
+            out, ctx.kept = kept
+            ctx.save_for_backward(o, d, qc, z)
+        else:
+            out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd), want_knn=True)
+            ctx.save_for_backward(o, d, qc, z, out["knn_d2"], out["knn_idx"])
         ctx.mark_non_differentiable(out["mask"])
         return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts, _g_mask):
         _same_state(ctx)
-        o, d, qc, z, kd2, kidx = ctx.saved_tensors
+        o, d, qc, z = ctx.saved_tensors[:4]
         need = ctx.needs_input_grad
         names = [n for n, nd in zip(RENDER_PARAMS, need[9:]) if nd]
         train = bool(names) or any(need[6:9])
@@ -156,8 +169,12 @@ class RenderFn(torch.autograd.Function):
             # rgb_blending_mlp.0's feature columns act on taps of the projected maps: their gradient and the maps' share of it come back as a map
             tg = ctx.r.train_grads(names, support_feature=need[8], feat_maps=need[6], vis_featmaps=need[7],
                                    blend_feat_maps=need[6] or "rgb_blending_mlp.0.weight" in names)
-        go, gd, gq = ctx.r.render_rays_backward(o, d, z, qc, g_rgb, g_depth, g_unc, g_feat, g_wts, white_bkgd=ctx.white, want_g_query_center=need[2], train=tg,
-                                                knn=(kd2, kidx))
+        if ctx.kept is not None:
+            go, gd, gq = ctx.r.render_rays_backward_kept(ctx.kept, g_rgb, g_depth, g_unc, g_feat, g_wts, want_g_query_center=need[2], train=tg)
+            ctx.kept = None
+        else:
+            go, gd, gq = ctx.r.render_rays_backward(o, d, z, qc, g_rgb, g_depth, g_unc, g_feat, g_wts, white_bkgd=ctx.white, want_g_query_center=need[2], train=tg,
+                                                    knn=(ctx.saved_tensors[4], ctx.saved_tensors[5]))
         gmaps = gvis = gsp = None
         gw = {}
         if tg is not None:

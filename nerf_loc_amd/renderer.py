@@ -330,6 +330,46 @@ class HipRenderer:
                 "nl_render_rays_backward")
         return go, gd, (None if gq is None else gq.sum(0))
 
+    def render_rays_keep(self, rays_o, rays_d, z_vals, query_center, white_bkgd: bool = False, train: bool = False, max_bytes: Optional[int] = None):
+        """Forward of the gradient path that KEEPS its staged activations (nl_render_rays_forward_keep): -> (outputs dict, state) where `state` goes to
+        `render_rays_backward_kept` — or None when the batch does not fit `max_bytes` of workspace as one chunk (then: render_rays + render_rays_backward)."""
+        self._ready()
+        dev = self.device
+        o, d, z = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev), _dev_f32(z_vals, dev)
+        R, S = o.shape[0], self.S
+        need = self.lib.nl_render_rays_keep_workspace_bytes(ct.byref(self.cfg), self.V, R, 1 if train else 0)
+        if need == 0 or (max_bytes is not None and need > max_bytes):
+            return None
+        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        out = {"rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
+               "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev), "feat": torch.empty(R, self.C, device=dev)}
+        ro = L.NlRenderOut()
+        for k, t in out.items():
+            setattr(ro, k, t.data_ptr())
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)   # owned by the returned state, not the shared workspace: it must survive until the backward call
+        L.check(self.lib.nl_render_rays_forward_keep(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
+                                                     1 if white_bkgd else 0, ct.byref(ro), 1 if train else 0, ws.data_ptr(), ws.numel(), self._stream()),
+                "nl_render_rays_forward_keep")
+        out["mask"] = out["mask"].view(torch.bool)
+        return out, (ws, qc, d, R, bool(white_bkgd), bool(train))
+
+    def render_rays_backward_kept(self, state, g_rgb=None, g_depth=None, g_depth_uncertainty=None, g_feat=None, g_weights=None, want_g_query_center: bool = False,
+                                  train: "TrainGrads" = None):
+        """nl_render_rays_backward_kept: the way back from the activations `render_rays_keep` left in `state` -> (g_rays_o, g_rays_d, g_query_center or None)."""
+        ws, qc, d, R, white, was_train = state
+        if (train is not None) != was_train:
+            raise ValueError("the state was made for " + ("a training" if was_train else "a frozen-weights") + " backward pass")
+        dev = self.device
+        cots = [None if t is None else _dev_f32(t, dev) for t in (g_rgb, g_depth, g_depth_uncertainty, g_feat, g_weights)]
+        c = L.NlRenderCotangents()
+        c.g_rgb, c.g_depth, c.g_depth_uncertainty, c.g_feat, c.g_weights = [_ptr(t) for t in cots]
+        go, gd = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
+        gq = torch.empty(R, 3, device=dev) if want_g_query_center else None
+        L.check(self.lib.nl_render_rays_backward_kept(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), d.data_ptr(), R, 1 if white else 0,
+                                                      ct.byref(c), go.data_ptr(), gd.data_ptr(), _ptr(gq), None if train is None else ct.byref(train.c),
+                                                      ws.data_ptr(), ws.numel(), self._stream()), "nl_render_rays_backward_kept")
+        return go, gd, (None if gq is None else gq.sum(0))
+
     def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None, train: "TrainGrads" = None):
         """Input gradient of `ray_unet` (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W).  train: also ADD the gradients of the 28 U-Net tensors
         into that TrainGrads (nl_ray_unet_backward_train)."""
