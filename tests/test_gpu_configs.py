@@ -215,3 +215,35 @@ def test_ill_conditioned_visibility_sample_stays_inside_the_bar():
     errs = {k: rel_err(out[k].cpu().numpy(), ref[k].numpy()) for k in KEYS}
     print(errs)
     assert max(errs.values()) < 5e-5, errs
+
+
+def test_full_size_backward_properties():
+    """nl_render_rays_backward at BASELINE config 2's full size (4096 rays x 128 samples = 524 288 samples, eight workspace chunks): size-independent
+    properties of a backward pass — linear in the cotangents, bit-reproducible, and a ray's gradient does not depend on the batch / chunk it is
+    differentiated in (what sharding a refinement batch over GPUs relies on)."""
+    sc = _scene("c2")
+    cfg = sc["cfg"]
+    r = _renderer(sc, "bf16x3")
+    dev = torch.device("cuda:0")
+    o, d = torch.from_numpy(sc["rays"]["rays_o"]).to(dev), torch.from_numpy(sc["rays"]["rays_d"]).to(dev)
+    z = _zbase(cfg, cfg.R).to(dev)
+    qc = sc["frame"]["pose"][:3, 3]
+    g = torch.Generator().manual_seed(31)
+    grgb, gfeat, gdep = torch.randn(cfg.R, 3, generator=g).to(dev), torch.randn(cfg.R, cfg.C, generator=g).to(dev), torch.randn(cfg.R, generator=g).to(dev)
+    a = r.render_rays_backward(o, d, z, qc, g_rgb=grgb, g_feat=gfeat, g_depth=gdep, want_g_query_center=True)
+    b = r.render_rays_backward(o, d, z, qc, g_rgb=grgb, g_feat=gfeat, g_depth=gdep, want_g_query_center=True)
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all() and torch.equal(x, y), "determinism"
+    assert float(a[0].abs().max()) > 0 and float(a[1].abs().max()) > 0
+    # linearity: g(2 c1) = 2 g(c1) exactly (powers of two), g(c1 + c2) = g(c1) + g(c2) to rounding
+    two = r.render_rays_backward(o, d, z, qc, g_rgb=2 * grgb, g_feat=2 * gfeat, g_depth=2 * gdep)
+    assert torch.equal(two[0], 2 * a[0]) and torch.equal(two[1], 2 * a[1])
+    p1 = r.render_rays_backward(o, d, z, qc, g_rgb=grgb)
+    p2 = r.render_rays_backward(o, d, z, qc, g_feat=gfeat, g_depth=gdep)
+    for k in (0, 1):
+        assert rel_err((p1[k] + p2[k]).cpu().numpy(), a[k].cpu().numpy()) < 2e-5, k
+    # a sub-batch (other chunk boundaries) gives the same rows
+    sel = torch.arange(cfg.R // 2 - 150, cfg.R // 2 + 150, device=dev)
+    c = r.render_rays_backward(o[sel], d[sel], z[sel], qc, g_rgb=grgb[sel], g_feat=gfeat[sel], g_depth=gdep[sel])
+    for k in (0, 1):
+        assert torch.equal(c[k], a[k][sel]), ("batch invariance", k)
