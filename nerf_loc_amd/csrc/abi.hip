@@ -73,7 +73,8 @@ int nl_launch_lrelu_mask(float* g, const float* h, size_t n, hipStream_t st);
 int nl_launch_add(const float* a, const float* b, float* o, size_t n, hipStream_t st);
 int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
                                int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
-                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, hipStream_t st);
+                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, const float* stats,
+                               hipStream_t st);
 int nl_dec_train_row(void);
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
                            const float* g_dd, float* part, float* g_xyz, float* tr, float* sc_vis, hipStream_t st);
@@ -955,7 +956,7 @@ int mv_geom_dec_backward(const Ctx& x32, const nl_frame* f, const NlViews& vw, c
                          float* g_qc, const MvBwdBufs& m, const TrainOut* tg) {
   NL_TRY(nl_launch_mv_geom_backward(vw, f->views_dev, f->images, f->feat, f->C, blend ? f->pfeat : nullptr, xyz, N, m.vis, m.dd, gg393, ldg_of(f->C),
                                     blend ? m.gpf : nullptr, blend ? m.grgbv : nullptr, blend ? m.gang : nullptr, g_xyz, g_qc, m.gvis, m.gdd,
-                                    tg ? tg->feat_maps : nullptr, tg && blend ? tg->pfeat_maps : nullptr, x32.st));
+                                    tg ? tg->feat_maps : nullptr, tg && blend ? tg->pfeat_maps : nullptr, gg393 ? m.g393 : nullptr, x32.st));
   const bool decw = tg && tg->any(T_DEC, T_DEC + 24);
   NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
                                 m.gvis, m.gdd, m.gpart, g_xyz, decw ? m.dtr : nullptr, tg ? tg->vis_maps : nullptr, x32.st));

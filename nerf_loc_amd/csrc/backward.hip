@@ -628,7 +628,8 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
                                                                const float* __restrict__ g_ang, float* __restrict__ g_xyz, float* __restrict__ g_qc,
                                                                float* __restrict__ g_vis, float* __restrict__ g_dd,
                                                                float* __restrict__ sc_feat /* training: (V,h,w,C) += , or null */,
-                                                               float* __restrict__ sc_pfeat /* training: (V,h,w,32) +=, or null */) {
+                                                               float* __restrict__ sc_pfeat /* training: (V,h,w,32) +=, or null */,
+                                                               const float* __restrict__ stats /* the forward's statistics rows (N, ldg) or null */) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -671,9 +672,15 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
   if (g393) {
     const float* g = g393 + (size_t)n * ldg;
     float mean[4] = {0.f, 0.f, 0.f, 0.f};
+    if (stats) {   // the weighted means are columns [0, F) of the forward's statistics row: no first pass over the taps
+      const float* sr = stats + (size_t)n * ldg;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { const int ch = lane + 64 * j; mean[j] = ch < C ? sr[3 + ch] : 0.f; }
+      mean[3] = lane < 3 ? sr[lane] : 0.f;
+    }
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
-      if (v < V) {
+      if (v < V && !stats) {
         int o[4]; float m[4]; float t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[k] = bk_rli(tf.o[k], v); m[k] = bk_rl(tf.m[k], v); }
@@ -1380,12 +1387,13 @@ __global__ void elu_mask_kernel(float4* __restrict__ g, const float4* __restrict
 
 int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, int C, const float* pfeat, const float* xyz,
                                int64_t N, const float* vis_in, const float* dd_in, const float* g393, int ldg, const float* g_pf, const float* g_rgbv,
-                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, hipStream_t st) {
+                               const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, const float* stats,
+                               hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(N, 4));
 #define NL_MGB(VT) hipLaunchKernelGGL((mv_geom_backward_kernel<VT>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, \
-                                      g393, ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, sc_feat, sc_pfeat)
+                                      g393, ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, sc_feat, sc_pfeat, stats)
   if (vw.V <= 4) NL_MGB(4); else if (vw.V <= 8) NL_MGB(8); else if (vw.V <= 10) NL_MGB(10); else NL_MGB(16);
 #undef NL_MGB
   NL_LAUNCH_CHECK();
