@@ -537,7 +537,8 @@ struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; int ntap =
 
 struct TileMap { const int* map; const int* count; };
 struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0;
-                const float* sig_w = nullptr; const float* sig_b = nullptr; float* sig_out = nullptr; };   // out: destination when fused
+                const float* sig_w = nullptr; const float* sig_b = nullptr; float* sig_out = nullptr;
+                unsigned* maskout = nullptr; const unsigned* maskin = nullptr; };   // out: destination when fused; mask*: sign bits (common.h: ep_maskout / ep_maskin)
 
 // fills the launch descriptor; *fused says whether the optional row epilogue will run inside the GEMM (else the caller runs it)
 int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
@@ -578,8 +579,9 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.epi = epi->kind; a.ep_pool = epi->pool; a.ep_res = epi->res; a.ep_ldres = epi->ldres; a.ep_gamma = epi->gamma; a.ep_beta = epi->beta;
     a.ep_scale = epi->scale; a.ep_eps = epi->eps;
     a.ep_sig_w = epi->sig_w; a.ep_sig_b = epi->sig_b; a.ep_sig_out = epi->sig_out;
+    a.ep_maskout = epi->maskout; a.ep_maskin = epi->maskin;
     if (nl_tgemm_supported(a, prec)) { a.C = epi->out; if (fused) *fused = true; }
-    else a.epi = NL_EPI_NONE;
+    else { a.epi = NL_EPI_NONE; a.ep_maskout = nullptr; a.ep_maskin = nullptr; }
   }
   if (tiles && !nl_tgemm_supported(a, prec)) { a.tile_map = nullptr; a.tile_count = nullptr; }   // generic kernels compute every row
   return nl_gemm_launch(a, prec, x.st);
@@ -774,7 +776,7 @@ int wgrad_to(const TrainOut* tg, hipStream_t st, int tw, int tb, const float* dY
   return nl_launch_wgrad(dY, ldy, Mo, X, ldxx, Ni, rows, 0, 0, tg->w[tw], Ni, 1, 0, tb >= 0 ? tg->w[tb] : nullptr, tg->scratch, tg->scratch_floats, st);
 }
 inline int ldf_of(int C) { return (int)nl_align_up(C + 3, 32); }
-struct PtBwdBufs { int* idx; float *d2, *X, *H1, *H2, *H3, *KV, *Q, *O, *FCo, *wscale, *gpre, *gO, *gQ, *gKV, *gA, *gB, *gX, *aff, *tr, *gXF; };
+struct PtBwdBufs { int* idx; float *d2, *X, *H1, *H2, *H3, *KV, *Q, *O, *FCo, *wscale, *gpre, *gO, *gQ, *gKV, *gA, *gB, *gX, *aff, *tr, *gXF; unsigned* mk[3]; };
 void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p, bool train = false) {
   const int W = c->W;
   const size_t NK = (size_t)N * K;
@@ -785,15 +787,21 @@ void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p, bool
   p.Q = b.take<float>((size_t)N * 128); p.O = b.take<float>((size_t)N * 128); p.FCo = b.take<float>((size_t)N * W); p.wscale = b.take<float>((size_t)N);
   p.gpre = b.take<float>((size_t)N * W); p.gO = b.take<float>((size_t)N * 128); p.gQ = b.take<float>((size_t)N * 128);
   p.gKV = b.take<float>(NK * 256); p.gA = b.take<float>(NK * W); p.gB = b.take<float>(NK * W); p.gX = b.take<float>(NK * 96);
+  for (int i = 0; i < 3; ++i) p.mk[i] = b.take<unsigned>((NK / 32 + 8) * 256);   // LeakyReLU sign bits of the three base_mlp layers: 32 bytes per row
   p.aff = p.tr = p.gXF = nullptr;
   if (train) { p.aff = b.take<float>((size_t)N * 2 * W); p.tr = b.take<float>(NK * 68); p.gXF = b.take<float>(NK * ldf_of(c->C)); }
 }
 
 // dX = (dY . W) * LeakyReLU'(h): the mask inside the streaming GEMM's epilogue where that kernel runs, a separate pass otherwise (fp32 mode)
-int gemm_lrelu_masked(const Ctx& x, int g, const SegSpec& s, int64_t M, float* out, int ld, const float* h) {
+// the layers' sign bits exist when the forward layers ran on the streaming kernel (every mode but fp32: pt_forward_staged checks it)
+inline bool pt_mask_bits(const Ctx& x) { return x.c->precision != NL_PREC_F32; }
+int gemm_lrelu_masked(const Ctx& x, int g, const SegSpec& s, int64_t M, float* out, int ld, const float* h, const unsigned* bits = nullptr) {
   if (x.c->precision != NL_PREC_F32 && (s.k & 31) == 0 && (((size_t)s.ptr) & 15) == 0 && (s.ld & 3) == 0 && (ld & 3) == 0 && (((size_t)h) & 15) == 0 && x.L.g[g].N <= 256) {
-    const RowEpi ep{h, ld, nullptr, nullptr, nullptr, 0.f, out, NL_EPI_NONE};
-    return run_gemm(x, g, &s, 1, M, out, ld, NL_ACT_LRELU_MASK, 0, 0, 0, 1, 0, &ep);
+    RowEpi ep{h, ld, nullptr, nullptr, nullptr, 0.f, out, NL_EPI_NONE};
+    ep.maskin = bits;
+    bool streamed = false;
+    NL_TRY(run_gemm(x, g, &s, 1, M, out, ld, NL_ACT_LRELU_MASK, 0, 0, 0, 1, 0, &ep, &streamed));
+    return streamed ? NL_OK : NL_ERR_UNSUPPORTED;   // (the generic kernels do not know this activation)
   }
   NL_TRY(run_gemm(x, g, &s, 1, M, out, ld, NL_ACT_NONE));
   return nl_launch_lrelu_mask(out, h, (size_t)M * ld, x.st);
@@ -817,9 +825,22 @@ int pt_forward_staged(const Ctx& x, const nl_frame* f, const float* xyz, const f
                                 inv_span, p.X, ldx, p.wscale, x.st));
   // (the encoded rows' pad columns are zero and so are the weights' pad rows: taking all ldx columns keeps the streaming kernel applicable)
   SegSpec sx{p.X, ldx, ldx, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
-  NL_TRY(run_gemm(x, G_BASE0, &sx, 1, NK, p.H1, W, NL_ACT_LRELU));
-  NL_TRY(run_gemm(x, G_BASE2, &s1, 1, NK, p.H2, W, NL_ACT_LRELU));
-  NL_TRY(run_gemm(x, G_BASE4, &s2, 1, NK, p.H3, W, NL_ACT_LRELU));
+  if (pt_mask_bits(x)) {   // the layers also leave their outputs' signs as bits: the way back reads 32 bytes per row instead of the 1 KB activation row
+    const int gs[3] = {G_BASE0, G_BASE2, G_BASE4};
+    const SegSpec* ss[3] = {&sx, &s1, &s2};
+    float* hs[3] = {p.H1, p.H2, p.H3};
+    for (int i = 0; i < 3; ++i) {
+      RowEpi ep{nullptr, 0, nullptr, nullptr, nullptr, 0.f, hs[i], NL_EPI_NONE};
+      ep.maskout = p.mk[i];
+      bool streamed = false;
+      NL_TRY(run_gemm(x, gs[i], ss[i], 1, NK, hs[i], W, NL_ACT_LRELU, 0, 0, 0, 1, 0, &ep, &streamed));
+      if (!streamed) return NL_ERR_UNSUPPORTED;
+    }
+  } else {
+    NL_TRY(run_gemm(x, G_BASE0, &sx, 1, NK, p.H1, W, NL_ACT_LRELU));
+    NL_TRY(run_gemm(x, G_BASE2, &s1, 1, NK, p.H2, W, NL_ACT_LRELU));
+    NL_TRY(run_gemm(x, G_BASE4, &s2, 1, NK, p.H3, W, NL_ACT_LRELU));
+  }
   NL_TRY(run_gemm(x, G_KV, &s3, 1, NK, p.KV, 256, NL_ACT_NONE));
   NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
   NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
@@ -854,11 +875,12 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
     NL_TRY(run_gemm(xb, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
     NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
   }
-  NL_TRY(gemm_lrelu_masked(xb, G_KV_T, skv, NK, p.gA, W, p.H3));
+  const bool bits = pt_mask_bits(x);
+  NL_TRY(gemm_lrelu_masked(xb, G_KV_T, skv, NK, p.gA, W, p.H3, bits ? p.mk[2] : nullptr));
   NL_TRY(wg(T_B4W, T_B4B, p.gA, W, W, p.H2, W, W, NK));
-  NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2));
+  NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2, bits ? p.mk[1] : nullptr));
   NL_TRY(wg(T_B2W, T_B2B, p.gB, W, W, p.H1, W, W, NK));
-  NL_TRY(gemm_lrelu_masked(xb, G_BASE2_T, sb, NK, p.gA, W, p.H1));
+  NL_TRY(gemm_lrelu_masked(xb, G_BASE2_T, sb, NK, p.gA, W, p.H1, bits ? p.mk[0] : nullptr));
   NL_TRY(wg(T_B0W, T_B0B, p.gA, W, W, p.X, ldx, F + 90, NK));
   NL_TRY(run_gemm(xb, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
   const bool rdw = tg && (tg->w[T_RD0W] || tg->w[T_RD0B] || tg->w[T_RD2W] || tg->w[T_RD2B]);

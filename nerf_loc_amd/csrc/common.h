@@ -156,6 +156,10 @@ struct NlGemmArgs {
   // optional (tgemm.hip, plain row mapping, no fused epilogue): only the 32-row tiles listed in tile_map[0 .. *tile_count) are computed
   // (early termination: rows of dead samples are neither read nor written)
   const int* tile_map; const int* tile_count;
+  // optional (tgemm.hip, plain epilogue): the SIGN of every output (post-activation) as bits, 16 bytes per lane of each 32-row tile ([tile][lane][4 dwords],
+  // bit 16 (rt & 1) + 4 gq + e of dword rt >> 1 <-> column 32 rt + 8 gq + 4 hh + e) — written by a forward layer (ep_maskout), read back by the
+  // NL_ACT_LRELU_MASK product of the backward pass (ep_maskin) instead of 1 KB of activations per row
+  unsigned* ep_maskout; const unsigned* ep_maskin;
 };
 enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1, NL_EPI_LNSLAB = 2 };
 // internal arithmetic of the segment GEMMs beyond the public nl_precision values: three-term split-FP16 (tgemm.hip), used by the backward passes for

@@ -388,27 +388,45 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
       }
     return;
   }
+  unsigned mb[(NRT + 1) / 2];   // sign bits of this lane's outputs (ep_maskout) / of the forward layer's (ep_maskin)
+#pragma unroll
+  for (int i = 0; i < (NRT + 1) / 2; ++i) mb[i] = 0u;
+  if (a.ep_maskin) {
+    const uint4 mi = *(const uint4*)(a.ep_maskin + ((size_t)tile * 64 + lane) * 4);
+    mb[0] = mi.x;
+    if (NRT > 2) mb[1] = mi.y;
+    if (NRT > 4) { mb[2] = mi.z; mb[3] = mi.w; }
+  }
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int n = 32 * rt + 8 * gq + 4 * hh;
+      const int sh = 16 * (rt & 1) + 4 * gq;
       if (n < a.N) {   // N % 4 == 0 and ldc % 4 == 0 are launch preconditions
         const float4 b4 = *(const float4*)(sbias + n);
         float4 v;
         if (a.act == NL_ACT_LRELU_MASK) {   // input gradient through a LeakyReLU: the mask comes from the forward output's sign
-          const float4 h4 = *(const float4*)(a.ep_res + (size_t)m * a.ep_ldres + n);
-          v.x = acc[rt][4 * gq + 0] * (h4.x > 0.f ? 1.f : 0.01f); v.y = acc[rt][4 * gq + 1] * (h4.y > 0.f ? 1.f : 0.01f);
-          v.z = acc[rt][4 * gq + 2] * (h4.z > 0.f ? 1.f : 0.01f); v.w = acc[rt][4 * gq + 3] * (h4.w > 0.f ? 1.f : 0.01f);
+          if (a.ep_maskin) {
+            const unsigned w = mb[rt >> 1] >> sh;
+            v.x = acc[rt][4 * gq + 0] * ((w & 1u) ? 1.f : 0.01f); v.y = acc[rt][4 * gq + 1] * ((w & 2u) ? 1.f : 0.01f);
+            v.z = acc[rt][4 * gq + 2] * ((w & 4u) ? 1.f : 0.01f); v.w = acc[rt][4 * gq + 3] * ((w & 8u) ? 1.f : 0.01f);
+          } else {
+            const float4 h4 = *(const float4*)(a.ep_res + (size_t)m * a.ep_ldres + n);
+            v.x = acc[rt][4 * gq + 0] * (h4.x > 0.f ? 1.f : 0.01f); v.y = acc[rt][4 * gq + 1] * (h4.y > 0.f ? 1.f : 0.01f);
+            v.z = acc[rt][4 * gq + 2] * (h4.z > 0.f ? 1.f : 0.01f); v.w = acc[rt][4 * gq + 3] * (h4.w > 0.f ? 1.f : 0.01f);
+          }
         } else {
           v.x = nl_act(acc[rt][4 * gq + 0] + b4.x, a.act);
           v.y = nl_act(acc[rt][4 * gq + 1] + b4.y, a.act);
           v.z = nl_act(acc[rt][4 * gq + 2] + b4.z, a.act);
           v.w = nl_act(acc[rt][4 * gq + 3] + b4.w, a.act);
+          if (a.ep_maskout) mb[rt >> 1] |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << sh;
         }
         *(float4*)(crow + n) = v;
       }
     }
+  if (a.ep_maskout) *(uint4*)(a.ep_maskout + ((size_t)tile * 64 + lane) * 4) = make_uint4(mb[0], NRT > 2 ? mb[1] : 0u, NRT > 4 ? mb[2] : 0u, NRT > 4 ? mb[3] : 0u);
 }
 
 
@@ -812,7 +830,8 @@ size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 *
 
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (precision == NL_PREC_F16X3_INTERNAL && (a.epi != NL_EPI_NONE || a.tile_map)) return false;   // plain products only
-  if (a.act == NL_ACT_LRELU_MASK && (a.epi != NL_EPI_NONE || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
+  if (a.act == NL_ACT_LRELU_MASK && (a.epi != NL_EPI_NONE || a.So > 0 || (!a.ep_maskin && (!a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))))) return false;
+  if ((a.ep_maskout || a.ep_maskin) && (a.epi != NL_EPI_NONE || a.So > 0 || a.tile_map)) return false;
   if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
