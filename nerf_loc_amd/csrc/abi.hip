@@ -1149,7 +1149,7 @@ void carve_unb(Bump& b, const nl_config* c, int64_t R, UnBwdBufs& q, bool train 
   q.gc2 = b.take<float>(N / 4 * 128); q.gr2 = b.take<float>(N / 2 * 128);
   q.gc1 = b.take<float>(N / 2 * 64); q.gr1 = b.take<float>(N * 64);
   q.tmp = b.take<float>(N * W);
-  q.aff = train ? b.take<float>(2 * N * W) : nullptr;   // the largest slab (conv_out: S x W per ray), [d y * xhat | d y]
+  q.aff = train ? b.take<float>(2 * N * (W > 64 ? W : 64)) : nullptr;   // the largest slab per ray (conv_out: S x W; conv1: S x 64; conv2: S/2 x 128), [d y * xhat | d y]
 }
 
 // Unfused forward in exact fp32 (every layer's pre-LayerNorm output stays in the workspace), then layer by layer backwards: LayerNorm / ELU /
@@ -1743,8 +1743,10 @@ size_t nl_train_scratch_bytes(const nl_config* cfg) {
   // the largest weight the split-K kernel is asked for: conv_out (W, 3 (W + 32)) is done one tap at a time -> W x (W + 32); out_fc.0 64 x (2F + 3); base_mlp.0 W x (F + 90)
   size_t mx = (size_t)cfg->W * (F + 90);
   if ((size_t)64 * (2 * F + 3) > mx) mx = (size_t)64 * (2 * F + 3);
+  if ((size_t)128 * 128 > mx) mx = (size_t)128 * 128;                       // the U-Net's fixed-width layers (one tap / one phase at a time)
+  if ((size_t)cfg->C * cfg->W > mx) mx = (size_t)cfg->C * cfg->W;           // feat_mlp.2
   size_t fl = nl_wgrad_scratch_floats(0, 1, (int)(mx + 256));
-  const size_t ln = (size_t)258 * 2 * cfg->S * cfg->W;   // the U-Net's LayerNorm tables: 2 S W sums + up to 256 partial rows of them
+  const size_t ln = (size_t)258 * 2 * cfg->S * (cfg->W > 64 ? cfg->W : 64);   // the U-Net's LayerNorm tables: 2 S max(W, 64) sums + up to 256 partial rows of them
   if (ln > fl) fl = ln;
   return sizeof(float) * fl;
 }
