@@ -182,10 +182,30 @@ class HipRenderer:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
+        if getattr(self, "guard_bytes", 0):
+            return self._guarded(nbytes)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    # test facility: with `guard_bytes` > 0 every workspace handed to the library is EXACTLY the size its *_workspace_bytes query asked for, followed
+    # by a canary region; `check_guards()` verifies that no call wrote past its workspace
+    def _guarded(self, nbytes: int) -> torch.Tensor:
+        buf = torch.empty(int(nbytes) + int(self.guard_bytes), dtype=torch.uint8, device=self.device)
+        buf[nbytes:] = 0xA5
+        self.__dict__.setdefault("_guards", []).append((buf, int(nbytes)))
+        return buf[:nbytes]
+
+    def check_guards(self) -> int:
+        torch.cuda.synchronize(self.device)
+        n = 0
+        for buf, nb in self.__dict__.get("_guards", []):
+            if not bool((buf[nb:] == 0xA5).all()):
+                raise AssertionError(f"a library call wrote past its {nb}-byte workspace")
+            n += 1
+        self._guards = []
+        return n
 
     def _ready(self):
         if not self._weights_loaded:
@@ -346,7 +366,8 @@ class HipRenderer:
         ro = L.NlRenderOut()
         for k, t in out.items():
             setattr(ro, k, t.data_ptr())
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)   # owned by the returned state, not the shared workspace: it must survive until the backward call
+        # owned by the returned state, not the shared workspace: it must survive until the backward call
+        ws = self._guarded(need) if getattr(self, "guard_bytes", 0) else torch.empty(need, dtype=torch.uint8, device=dev)
         L.check(self.lib.nl_render_rays_forward_keep(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
                                                      1 if white_bkgd else 0, ct.byref(ro), 1 if train else 0, ws.data_ptr(), ws.numel(), self._stream()),
                 "nl_render_rays_forward_keep")

@@ -532,3 +532,52 @@ def test_nodes_refuse_a_backward_pass_against_replaced_state():
     r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
     with pytest.raises(RuntimeError, match="replaced between the forward and the backward"):
         out.sum().backward()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,precision", [("tiny_full", "fp32"), ("tiny_full", "bf16x3"), ("fewpts", "bf16x3"), ("c1", "bf16x3"), ("w128s64", "bf16x3"), ("s192out", "bf16x3")])
+def test_no_call_writes_past_its_workspace(case, precision):
+    """Every workspace is carved by the library from a caller buffer of exactly the size its *_workspace_bytes query returned: with a canary region
+    behind each of them, the forward stages, every backward / training entry point and the whole-path pairs leave the canaries intact (the buffer
+    that the U-Net's LayerNorm rows overflowed at W = 32 was the LAST one of its workspace: nothing but a canary notices that)."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case(case)
+    cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.guard_bytes = 1 << 20
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R, S, W = min(cfg.R, 9), cfg.S_total, cfg.W
+    o, d = t(rays["rays_o"][:R]), t(rays["rays_d"][:R])
+    lin = torch.linspace(0, 1, S, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, S).contiguous()
+    xyz = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
+    dirs = d[:, None, :].expand(R, S, 3).reshape(-1, 3).contiguous()
+    N = R * S
+    g = torch.Generator().manual_seed(41)
+    rnd = lambda *shp: torch.randn(*shp, generator=g).to(dev)
+    qc = t(frame["pose"])[:3, 3]
+    names = list(dr.RENDER_PARAMS)
+    calls = 0
+    r.render_rays(o, d, qc, z_vals=z); calls += r.check_guards()
+    mv, _, _, _ = r.mv_aggregate(xyz, qc, want_raw=False); calls += r.check_guards()
+    fa, d2, idx = r.point_mlp(xyz, dirs, mv, K=8); calls += r.check_guards()
+    geo = r.ray_unet(fa); calls += r.check_guards()
+    r.blend(xyz, qc, fa); calls += r.check_guards()
+    for chunk in (None, 3):
+        tg = r.train_grads(names, support_feature=True, feat_maps=True, vis_featmaps=True, blend_feat_maps=True)
+        r.mv_aggregate_backward(xyz, rnd(N, W), train=tg, workspace_samples=None if chunk is None else chunk * S); calls += r.check_guards()
+        r.point_mlp_backward(xyz, dirs, mv, rnd(N, W), K=8, knn=(d2, idx), train=tg, workspace_samples=None if chunk is None else chunk * S); calls += r.check_guards()
+        r.ray_unet_backward(fa, rnd(N, W), train=tg, workspace_rays=chunk); calls += r.check_guards()
+        r.blend_backward(xyz, qc, fa, rnd(N, 3), train=tg, workspace_samples=None if chunk is None else chunk * S); calls += r.check_guards()
+        r.render_rays_backward(o, d, z, qc, g_rgb=rnd(R, 3), g_feat=rnd(R, cfg.C), g_depth=rnd(R), g_weights=rnd(R, S), want_g_query_center=True, train=tg,
+                               workspace_rays=chunk); calls += r.check_guards()
+        r.render_rays_backward(o, d, z, qc, g_rgb=rnd(R, 3), workspace_rays=chunk); calls += r.check_guards()
+    for train in (False, True):
+        out, state = r.render_rays_keep(o, d, z, qc, train=train)
+        tg = r.train_grads(names, support_feature=True, feat_maps=True, vis_featmaps=True, blend_feat_maps=True) if train else None
+        r.render_rays_backward_kept(state, g_rgb=rnd(R, 3), g_feat=rnd(R, cfg.C), train=tg); calls += r.check_guards()
+    assert calls >= 15   # (guarded workspaces checked)
