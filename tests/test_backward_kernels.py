@@ -451,7 +451,8 @@ def test_ray_unet_weight_gradients_match_autograd(case, precision, chunk):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,precision,train,chunk", [("tiny_full", "fp32", False, None), ("tiny_full", "fp32", False, 4), ("fewpts", "fp32", True, None),
                                                         ("tiny_full", "fp32", True, 5), ("offview", "bf16x3", False, 2), ("c1", "fp32", True, 3),
-                                                        ("c1", "fp32", True, None), ("c1", "bf16x3", True, None), ("w128s64", "bf16x3", False, None)])
+                                                        ("c1", "fp32", True, None), ("c1", "bf16x3", True, None), ("w128s64", "bf16x3", False, None), ("w128s64", "fp32", True, None),
+                                                        ("s192out", "fp32", True, 2), ("w256s128", "fp32", True, None)])
 def test_whole_path_backward_matches_the_stage_nodes(case, precision, train, chunk):
     """nl_render_rays_backward (one call for the whole path: RenderFn) against the chain of per-stage autograd nodes + eager heads: the same
     gradients w.r.t. the rays, the query pose and — train — every parameter tensor, the maps and the support features."""
