@@ -345,14 +345,26 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
  * back from them — no recompute, no second neighbour search.  The caller keeps `ws` untouched in between and passes the same rays / query centre / `train`
  * flag to both.  The whole batch is one chunk: NL_ERR_WORKSPACE when it does not fit (then: nl_render_rays + nl_render_rays_backward, which chunk).
  * `out`: rgb, depth, weights, mask, depth_uncertainty required, feat optional (without it feat_mlp is not evaluated and g_feat must be NULL), the
- * optional intermediates are ignored. */
+ * optional intermediates are ignored.
+ * beta (may be NULL): the training-mode uncertainty head (model.py:98,111,587-592; `render.use_render_uncertainty`, the reference configs' default):
+ * beta[r] = sum_s w_s softplus(beta_mlp.0(geo_s)) + beta_min.  beta_mlp is not one of the nl_pack_weights tensors (eval-mode rendering never evaluates it):
+ * its two tensors, the output, its cotangent and its gradients travel in this block; the same block goes to both calls of the pair. */
+typedef struct nl_beta_head {
+  const float* weight;   /* beta_mlp.0.weight (W) */
+  const float* bias;     /* beta_mlp.0.bias (1) */
+  float beta_min;        /* 0.1 (model.py:98) */
+  float* beta;           /* forward call: (R) output */
+  const float* g_beta;   /* backward call: (R) cotangent, or NULL */
+  float* g_weight;       /* backward call: (W) +=, or NULL */
+  float* g_bias;         /* backward call: (1) +=, or NULL */
+} nl_beta_head;
 size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train);
 int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST */, const float* rays_o,
-                                const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, int train, void* ws,
-                                size_t ws_bytes, void* stream);
+                                const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, const nl_beta_head* beta,
+                                int train, void* ws, size_t ws_bytes, void* stream);
 int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST */, const float* rays_d,
-                                 int64_t R, int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d, float* g_query_center_rows,
-                                 const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
+                                 int64_t R, int white_bkgd, const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d,
+                                 float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* nl_ray_unet_backward + gradients of the seven blocks' convolution weights / biases and LayerNorm([C, L]) tables (28 tensors). */
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R);

@@ -62,6 +62,11 @@ class NlRenderCotangents(C.Structure):
                 ("knn_idx", C.c_void_p), ("knn_d2", C.c_void_p), ("reserved", C.c_void_p * 1)]
 
 
+class NlBetaHead(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("beta_min", C.c_float), ("beta", C.c_void_p), ("g_beta", C.c_void_p), ("g_weight", C.c_void_p),
+                ("g_bias", C.c_void_p)]
+
+
 # every symbol include/nerfloc_render.h declares: (name, restype, argtypes)
 _P, _I, _L, _Z, _F = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _CFG, _DESC, _OUT = C.POINTER(NlConfig), C.POINTER(NlFrameDesc), C.POINTER(NlRenderOut)
@@ -102,8 +107,9 @@ SYMBOLS = [
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
     ("nl_render_rays_keep_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
-    ("nl_render_rays_forward_keep", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _I, _P, _Z, _P]),
-    ("nl_render_rays_backward_kept", _I, [_CFG, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
+    ("nl_render_rays_forward_keep", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, C.POINTER(NlBetaHead), _I, _P, _Z, _P]),
+    ("nl_render_rays_backward_kept", _I, [_CFG, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), C.POINTER(NlBetaHead), _P, _P, _P, C.POINTER(NlTrainGrads),
+                                          _P, _Z, _P]),
     ("nl_render_rays_backward_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
     ("nl_render_rays_backward", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_ray_unet_backward_train_workspace_bytes", _Z, [_CFG, _L]),

@@ -89,7 +89,11 @@ int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, con
 int nl_launch_table_add_t(const float* t, float* g, int L, int Cc, hipStream_t st);
 int nl_launch_ray_feat_sum(const float* z, const float* sigma, const float* ft, int64_t R, int S, int C, float* hc, float* wsum4, hipStream_t st);
 int nl_launch_sigma_backward(const float* geo, int64_t N, int W, const float* w, const float* b, const float* g_sigma, float* g_geo, float* gpre4, hipStream_t st);
-int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, hipStream_t st);
+int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, const float* g_beta, const float* bv,
+                       hipStream_t st);
+int nl_launch_beta_forward(const float* wts, const float* bv, int64_t R, int S, float beta_min, float* beta, hipStream_t st);
+int nl_launch_beta_backward(const float* geo, int64_t N, int S, int W, const float* wb, const float* bb, const float* wts, const float* g_beta, float* g_geo, float* gpre4,
+                            hipStream_t st);
 int nl_launch_ray_reduce(const float* ga, const float* gb, const float* gc, const float* g_dir, const float* g_qcN, const float* z, int64_t R, int S, float* g_o,
                          float* g_d, float* g_qc, hipStream_t st);
 int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, int ldo, int64_t rows, int cols, hipStream_t st);
@@ -1298,7 +1302,7 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
 // both sets of taps, one neighbour search.
 struct RbBufs {
   MvBwdBufs m; PtBwdBufs p; UnBwdBufs q;
-  float *xyz, *zc, *FA, *sigma, *Hf, *rgb_s, *hc, *wsum4, *ghc, *gw, *g_sigma, *g_rgb_s, *gFA, *gtmp, *gpre4, *gxyz_m, *gxyz_p, *gdir, *gG, *gqcN;
+  float *xyz, *zc, *FA, *sigma, *Hf, *rgb_s, *hc, *wsum4, *ghc, *gw, *g_sigma, *g_rgb_s, *gFA, *gtmp, *gpre4, *gxyz_m, *gxyz_p, *gdir, *gG, *gqcN, *wts, *bv, *gpre4b;
 };
 void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool train) {
   const int W = c->W, S = c->S;
@@ -1314,6 +1318,7 @@ void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool tra
   a.gw = b.take<float>(N); a.g_sigma = b.take<float>(N); a.g_rgb_s = b.take<float>(N * 3); a.gFA = b.take<float>(N * W); a.gtmp = b.take<float>(N * W);
   a.gpre4 = b.take<float>(N * 4); a.gxyz_m = b.take<float>(N * 3); a.gxyz_p = b.take<float>(N * 3); a.gdir = b.take<float>(N * 3);
   a.gG = b.take<float>(N * W); a.gqcN = b.take<float>(N * 3);
+  a.wts = b.take<float>(N); a.bv = b.take<float>(N); a.gpre4b = b.take<float>(N * 4);   // the uncertainty head (keep / kept pair)
 }
 struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; const int* idx; const float* d2; };
 // the staged forward of the whole path into the workspace (everything the way back reads).  want_feat: feat_mlp.0's hidden rows too
@@ -1339,7 +1344,7 @@ int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, co
 }
 // the way back from the staged forward's workspace
 int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_d, int64_t R, int white, const RbCot& ct,
-                           float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
+                           float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg, const nl_beta_head* bh = nullptr) {
   const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
   const int64_t N = R * S;
   hipStream_t st = x32.st;
@@ -1351,7 +1356,10 @@ int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, con
     SegSpec sgf{ct.g_feat, C, C, 0, 1};
     NL_TRY(run_gemm(xb, G_FEAT2_T, &sgf, 1, R, a.ghc, W, NL_ACT_NONE));
   }
-  NL_TRY(nl_launch_gw_total(ct.g_wts, ct.g_feat, b2, R, S, C, a.gw, st));
+  const bool beta = bh && bh->g_beta;
+  // (the uncertainty head's share of the weights' cotangent has to be in before compositing is differentiated; its share of d/d geo joins the density
+  // head's below)
+  NL_TRY(nl_launch_gw_total(ct.g_wts, ct.g_feat, b2, R, S, C, a.gw, beta ? bh->g_beta : nullptr, a.bv, st));
   NL_TRY(nl_composite_backward(a.zc, a.sigma, a.rgb_s, want_feat ? a.Hf : nullptr, R, S, want_feat ? W : 0, white, ct.g_rgb, ct.g_depth, ct.g_unc,
                                want_feat ? a.ghc : nullptr, a.gw, a.g_sigma, a.g_rgb_s, want_feat ? a.gtmp : nullptr, st));
   // ---------------------------------------------------------------- heads
@@ -1372,6 +1380,11 @@ int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, con
   float* g_geo = a.Hf;
   NL_TRY(nl_launch_sigma_backward(a.q.geo, N, W, x32.p<float>(x32.L.sig_w), x32.p<float>(x32.L.sig_b), a.g_sigma, g_geo, a.gpre4, st));
   NL_TRY(wgrad_to(tg, st, T_SIGW, T_SIGB, a.gpre4, 4, 1, a.q.geo, W, W, N));
+  if (beta) {
+    NL_TRY(nl_launch_beta_backward(a.q.geo, N, S, W, bh->weight, bh->bias, a.wts, bh->g_beta, g_geo, a.gpre4b, st));
+    if (bh->g_weight) NL_TRY(nl_launch_wgrad(a.gpre4b, 4, 1, a.q.geo, W, W, N, 0, 0, bh->g_weight, W, 1, 0, bh->g_bias, tg ? tg->scratch : nullptr,
+                                            tg ? tg->scratch_floats : 0, st));
+  }
   // ---------------------------------------------------------------- ray U-Net, colour blend: their shares of d/d feature_agg
   NL_TRY(unet_backward_only(xb, x32, a.FA, R, g_geo, a.gtmp, a.q, tg));
   if (have_gfa) NL_TRY(nl_launch_add(a.gFA, a.gtmp, a.gFA, (size_t)N * W, st));
@@ -1390,7 +1403,7 @@ int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const f
   return render_backward_staged(xb, x32, f, qc, rays_d, R, white, ct, g_o, g_d, g_qc_rows, a, tg);
 }
 // the per-ray outputs from the staged forward's workspace (the gradient path's forward values: split-FP16 arithmetic in the bf16 modes)
-int render_outputs_staged(const Ctx& x32, const nl_frame* f, int64_t R, int white, const nl_render_out* out, const RbBufs& a) {
+int render_outputs_staged(const Ctx& x32, const nl_frame* f, int64_t R, int white, const nl_render_out* out, const RbBufs& a, const nl_beta_head* bh = nullptr) {
   const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
   const bool want_feat = out->feat != nullptr;
   NL_TRY(nl_launch_composite(a.zc, a.sigma, a.rgb_s, want_feat ? a.Hf : nullptr, a.m.valid_s, R, S, W, white, out, 0, want_feat ? a.hc : nullptr,
@@ -1398,6 +1411,11 @@ int render_outputs_staged(const Ctx& x32, const nl_frame* f, int64_t R, int whit
   if (want_feat) {
     SegSpec s1[2] = {{a.hc, W, W, 0, 1}, {a.gw, 1, 1, 0, 1}};
     NL_TRY(run_gemm(x32, G_FEAT2, s1, 2, R, out->feat, C, NL_ACT_NONE));
+  }
+  if (bh) {   // the uncertainty head: softplus(beta_mlp.0(geo)) per sample (the density head's kernel), composited with the weights; both stay for the way back
+    NL_TRY(nl_launch_sigma(a.q.geo, R * S, W, bh->weight, bh->bias, a.bv, x32.st));
+    NL_CHECK_HIP(hipMemcpyAsync(a.wts, out->weights, sizeof(float) * (size_t)R * S, hipMemcpyDeviceToDevice, x32.st));
+    NL_TRY(nl_launch_beta_forward(a.wts, a.bv, R, S, bh->beta_min, bh->beta, x32.st));
   }
   return NL_OK;
 }
@@ -1923,9 +1941,11 @@ size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t 
   return render_bwd_bytes(cfg, V, R, train != 0);
 }
 int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_o, const float* rays_d,
-                                const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, int train, void* ws, size_t ws_bytes, void* stream) {
+                                const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, const nl_beta_head* beta, int train, void* ws,
+                                size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (beta && (!beta->weight || !beta->bias || !beta->beta)) return NL_ERR_BAD_ARG;
   if (!out->rgb || !out->depth || !out->weights || !out->mask || !out->depth_uncertainty) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
   const int V = f->views.V;
@@ -1933,13 +1953,14 @@ int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const 
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train != 0);
   NL_TRY(render_forward_staged(B.x32, f, query_center, rays_o, rays_d, z_vals, R, out->feat != nullptr, nullptr, nullptr, a));
-  return render_outputs_staged(B.x32, f, R, white_bkgd, out, a);
+  return render_outputs_staged(B.x32, f, R, white_bkgd, out, a, beta);
 }
 int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_d, int64_t R,
-                                 int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d, float* g_query_center_rows,
-                                 const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+                                 int white_bkgd, const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d,
+                                 float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_d || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (beta && (!beta->weight || !beta->bias || (beta->g_weight && !grads))) return NL_ERR_BAD_ARG;   // (the weight gradient's split-K scratch comes with `grads`)
   if (g->reserved[0] != nullptr || g->knn_idx || g->knn_d2) return NL_ERR_BAD_ARG;   // (the neighbours are in the workspace)
   const bool train = grads != nullptr;
   TrainOut T;
@@ -1950,7 +1971,7 @@ int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train);
   RbCot ct{g->g_rgb, g->g_depth, g->g_depth_uncertainty, g->g_feat, g->g_weights, nullptr, nullptr};
-  return render_backward_staged(B.xb, B.x32, f, query_center, rays_d, R, white_bkgd, ct, g_rays_o, g_rays_d, g_query_center_rows, a, train ? &T : nullptr);
+  return render_backward_staged(B.xb, B.x32, f, query_center, rays_d, R, white_bkgd, ct, g_rays_o, g_rays_d, g_query_center_rows, a, train ? &T : nullptr, beta);
 }
 
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R) {

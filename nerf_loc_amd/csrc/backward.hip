@@ -199,15 +199,43 @@ __global__ __launch_bounds__(256) void sigma_backward_kernel(const float* __rest
 }
 // the weights' total cotangent: gw[r][s] = g_wts[r][s] + g_feat[r] . b2   (feat = W2 . sum_s w_s hidden_s + b2 sum_s w_s); one wave per ray
 __global__ __launch_bounds__(256) void gw_total_kernel(const float* __restrict__ g_wts, const float* __restrict__ g_feat, const float* __restrict__ b2, int R, int S,
-                                                       int C, float* __restrict__ gw) {
+                                                       int C, float* __restrict__ gw, const float* __restrict__ g_beta, const float* __restrict__ bv) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   float a = 0.f;
   if (g_feat) for (int c = lane; c < C; c += 64) a = fmaf(g_feat[(size_t)r * C + c], b2[c], a);
   a = wave_sum(a);
-  for (int s = lane; s < S; s += 64) gw[(size_t)r * S + s] = a + (g_wts ? g_wts[(size_t)r * S + s] : 0.f);
+  const float gb = g_beta ? g_beta[r] : 0.f;   // + the uncertainty head: beta = sum_s w_s b_s + beta_min
+  for (int s = lane; s < S; s += 64) gw[(size_t)r * S + s] = a + (g_wts ? g_wts[(size_t)r * S + s] : 0.f) + (g_beta ? gb * bv[(size_t)r * S + s] : 0.f);
 }
+// training-mode uncertainty head (model.py:587-592): beta[r] = sum_s w_s softplus(geo_s . wb + bb) + beta_min.  Forward from the kept weights / head values:
+__global__ __launch_bounds__(256) void beta_forward_kernel(const float* __restrict__ wts, const float* __restrict__ bv, int R, int S, float beta_min, float* __restrict__ beta) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float a = 0.f;
+  for (int s = lane; s < S; s += 64) a = fmaf(wts[(size_t)r * S + s], bv[(size_t)r * S + s], a);
+  a = wave_sum(a);
+  if (lane == 0) beta[r] = a + beta_min;
+}
+// ... and backwards (the weights' cotangent g_beta b_s is added by gw_total_kernel, before compositing is differentiated): the head's pre-activation
+// gradient g_beta w_s sigmoid(pre) goes to g_geo (+=) and to gpre4
+__global__ __launch_bounds__(256) void beta_backward_kernel(const float* __restrict__ geo, int N, int S, int W, const float* __restrict__ wb, const float* __restrict__ bb,
+                                                            const float* __restrict__ wts, const float* __restrict__ g_beta,
+                                                            float* __restrict__ g_geo, float* __restrict__ gpre4) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float gb = g_beta[n / S];
+  float a = 0.f;
+  for (int c = lane; c < W; c += 64) a = fmaf(geo[(size_t)n * W + c], wb[c], a);
+  const float pre = wave_sum(a) + bb[0];
+  const float gp = gb * wts[n] * (pre > 20.f ? 1.f : nl_sigmoid(pre));
+  for (int c = lane; c < W; c += 64) g_geo[(size_t)n * W + c] += gp * wb[c];
+  if (lane == 0) *(float4*)(gpre4 + 4 * (size_t)n) = make_float4(gp, 0.f, 0.f, 0.f);
+}
+
 // xyz = o + z d: g_o[r] = sum_s g_xyz, g_d[r] = sum_s (z_s g_xyz + g_dir), g_qc[r] = sum_s g_qcN; g_xyz = ga + gb (+ gc); one wave per ray
 __global__ __launch_bounds__(256) void ray_reduce_kernel(const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gc,
                                                          const float* __restrict__ g_dir, const float* __restrict__ g_qcN, const float* __restrict__ z, int R, int S,
@@ -252,9 +280,23 @@ int nl_launch_sigma_backward(const float* geo, int64_t N, int W, const float* w,
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
-int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, hipStream_t st) {
+int nl_launch_beta_forward(const float* wts, const float* bv, int64_t R, int S, float beta_min, float* beta, hipStream_t st) {
   if (R <= 0) return NL_OK;
-  hipLaunchKernelGGL(gw_total_kernel, dim3((unsigned)nl_cdiv(R, 4)), dim3(256), 0, st, g_wts, g_feat, b2, (int)R, S, C, gw);
+  hipLaunchKernelGGL(beta_forward_kernel, dim3((unsigned)nl_cdiv(R, 4)), dim3(256), 0, st, wts, bv, (int)R, S, beta_min, beta);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+int nl_launch_beta_backward(const float* geo, int64_t N, int S, int W, const float* wb, const float* bb, const float* wts, const float* g_beta, float* g_geo, float* gpre4,
+                            hipStream_t st) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(beta_backward_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, geo, (int)N, S, W, wb, bb, wts, g_beta, g_geo, gpre4);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, const float* g_beta, const float* bv,
+                       hipStream_t st) {
+  if (R <= 0) return NL_OK;
+  hipLaunchKernelGGL(gw_total_kernel, dim3((unsigned)nl_cdiv(R, 4)), dim3(256), 0, st, g_wts, g_feat, b2, (int)R, S, C, gw, g_beta, bv);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

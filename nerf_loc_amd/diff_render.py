@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
+import ctypes as ct
+
 import torch
 import torch.nn.functional as F
 
@@ -146,6 +148,17 @@ class RenderFn(torch.autograd.Function):
         ctx.r, ctx.white, ctx.gen = renderer, bool(white_bkgd), renderer.state_gen
         ctx.kept = None
         train = len(params) > 0
+        # params = the RENDER_PARAMS tensors [+ beta_mlp.0.weight, beta_mlp.0.bias: the training-mode uncertainty head, keep / kept pair only]
+        ctx.has_beta = len(params) == len(RENDER_PARAMS) + 2
+        if ctx.has_beta:
+            kept = renderer.render_rays_keep(o, d, z, qc, white_bkgd=bool(white_bkgd), train=True, max_bytes=KEEP_BYTES or None,
+                                             beta_head=(params[-2].detach(), params[-1].detach()))
+            if kept is None:
+                raise RuntimeError("RenderFn with the uncertainty head needs the batch to fit one workspace chunk (diff_render.KEEP_BYTES)")
+            out, ctx.kept = kept
+            ctx.save_for_backward(o, d, qc, z)
+            ctx.mark_non_differentiable(out["mask"])
+            return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"], out["beta"]
         # small batches (a PoseOptimizer / training step): the staged forward whose activations the backward call reuses, when they fit KEEP_BYTES
         kept = renderer.render_rays_keep(o, d, z, qc, white_bkgd=bool(white_bkgd), train=train, max_bytes=KEEP_BYTES) if KEEP_BYTES else None
         if kept is not None:
@@ -158,7 +171,7 @@ class RenderFn(torch.autograd.Function):
         return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts, _g_mask):
+    def backward(ctx, g_rgb, g_depth, g_unc, g_feat, g_wts, _g_mask, g_beta=None):
         _same_state(ctx)
         o, d, qc, z = ctx.saved_tensors[:4]
         need = ctx.needs_input_grad
@@ -169,7 +182,12 @@ class RenderFn(torch.autograd.Function):
             # rgb_blending_mlp.0's feature columns act on taps of the projected maps: their gradient and the maps' share of it come back as a map
             tg = ctx.r.train_grads(names, support_feature=need[8], feat_maps=need[6], vis_featmaps=need[7],
                                    blend_feat_maps=need[6] or "rgb_blending_mlp.0.weight" in names)
-        if ctx.kept is not None:
+        gbeta_w = gbeta_b = None
+        if ctx.kept is not None and ctx.has_beta:
+            go, gd, gq, (gbeta_w, gbeta_b) = ctx.r.render_rays_backward_kept(ctx.kept, g_rgb, g_depth, g_unc, g_feat, g_wts, want_g_query_center=need[2], train=tg,
+                                                                            g_beta=g_beta, want_beta_grads=True)
+            ctx.kept = None
+        elif ctx.kept is not None:
             go, gd, gq = ctx.r.render_rays_backward_kept(ctx.kept, g_rgb, g_depth, g_unc, g_feat, g_wts, want_g_query_center=need[2], train=tg)
             ctx.kept = None
         else:
@@ -189,7 +207,7 @@ class RenderFn(torch.autograd.Function):
                 if gmaps is not None:
                     gmaps += (pg @ w0[:, W + 3:W + 3 + Cf]).view_as(gmaps)
         return (go if need[0] else None, gd if need[1] else None, None if gq is None else gq.to(qc.dtype), None, None, None, gmaps, gvis, gsp) + \
-            tuple(gw.get(n) for n in RENDER_PARAMS)
+            tuple(gw.get(n) for n in RENDER_PARAMS) + ((gbeta_w, gbeta_b) if ctx.has_beta else ())
 
 
 POINT_PARAMS = ("ray_diff_fc.0.weight", "ray_diff_fc.0.bias", "ray_diff_fc.2.weight", "ray_diff_fc.2.bias",
@@ -579,12 +597,20 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     frozen = frozen_renderer is not None and _hip_ok(xyz, dirs)
     hip_train = not frozen and train_renderer is not None and _hip_ok(xyz, dirs) and fr["support"]["xyz"].shape[0] >= 1
     r = frozen_renderer if frozen else train_renderer
-    if (frozen or hip_train) and whole_path and not beta and S == r.S and not z_vals.requires_grad and fr["support"]["xyz"].shape[0] >= 1 \
+    beta_ok = not beta or (hip_train and KEEP_BYTES and "beta_mlp.0.weight" in p and
+                           r.lib.nl_render_rays_keep_workspace_bytes(ct.byref(r.cfg), r.V, R, 1) <= KEEP_BYTES)   # (the uncertainty head lives in the keep / kept pair)
+    if (frozen or hip_train) and whole_path and beta_ok and S == r.S and not z_vals.requires_grad and fr["support"]["xyz"].shape[0] >= 1 \
             and all(n in p for n in HEAD_PARAMS):
         # ONE autograd node for the whole path: the fused inference kernels forward, nl_render_rays_backward backward
         extra = () if frozen else (fr["feat_fine_src"], fr["vis_featmaps"], fr["support"]["feature"]) + tuple(p[n] for n in RENDER_PARAMS)
-        rgb, depth, unc, feat, wts, valid = RenderFn.apply(rays_o, rays_d, query_pose[:3, 3], z_vals, r, white_bkgd, *extra)
-        return {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": unc}
+        if beta:
+            extra = extra + (p["beta_mlp.0.weight"], p["beta_mlp.0.bias"])
+        res = RenderFn.apply(rays_o, rays_d, query_pose[:3, 3], z_vals, r, white_bkgd, *extra)
+        rgb, depth, unc, feat, wts, valid = res[:6]
+        out = {"rgb": rgb, "feat": feat, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": unc}
+        if beta:
+            out["beta"] = res[6]
+        return out
     if frozen:
         # frozen weights + frozen per-frame tables (pose refinement): aggregation, neural-point branch and blend are three autograd nodes whose
         # forward AND backward run in the HIP library; nothing of them is kept on the tape but their inputs

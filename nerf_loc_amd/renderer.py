@@ -350,9 +350,11 @@ class HipRenderer:
                 "nl_render_rays_backward")
         return go, gd, (None if gq is None else gq.sum(0))
 
-    def render_rays_keep(self, rays_o, rays_d, z_vals, query_center, white_bkgd: bool = False, train: bool = False, max_bytes: Optional[int] = None):
+    def render_rays_keep(self, rays_o, rays_d, z_vals, query_center, white_bkgd: bool = False, train: bool = False, max_bytes: Optional[int] = None,
+                         beta_head=None, beta_min: float = 0.1):
         """Forward of the gradient path that KEEPS its staged activations (nl_render_rays_forward_keep): -> (outputs dict, state) where `state` goes to
-        `render_rays_backward_kept` — or None when the batch does not fit `max_bytes` of workspace as one chunk (then: render_rays + render_rays_backward)."""
+        `render_rays_backward_kept` — or None when the batch does not fit `max_bytes` of workspace as one chunk (then: render_rays + render_rays_backward).
+        beta_head = (beta_mlp.0.weight, beta_mlp.0.bias): also the training-mode uncertainty output 'beta' (model.py:587-592)."""
         self._ready()
         dev = self.device
         o, d, z = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev), _dev_f32(z_vals, dev)
@@ -368,16 +370,24 @@ class HipRenderer:
             setattr(ro, k, t.data_ptr())
         # owned by the returned state, not the shared workspace: it must survive until the backward call
         ws = self._guarded(need) if getattr(self, "guard_bytes", 0) else torch.empty(need, dtype=torch.uint8, device=dev)
+        bh, bkeep = None, None
+        if beta_head is not None:
+            bw, bb = _dev_f32(beta_head[0], dev).reshape(-1), _dev_f32(beta_head[1], dev).reshape(-1)
+            out["beta"] = torch.empty(R, device=dev)
+            bh = L.NlBetaHead()
+            bh.weight, bh.bias, bh.beta_min, bh.beta = bw.data_ptr(), bb.data_ptr(), float(beta_min), out["beta"].data_ptr()
+            bkeep = (bw, bb, float(beta_min))
         L.check(self.lib.nl_render_rays_forward_keep(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
-                                                     1 if white_bkgd else 0, ct.byref(ro), 1 if train else 0, ws.data_ptr(), ws.numel(), self._stream()),
-                "nl_render_rays_forward_keep")
+                                                     1 if white_bkgd else 0, ct.byref(ro), None if bh is None else ct.byref(bh), 1 if train else 0, ws.data_ptr(),
+                                                     ws.numel(), self._stream()), "nl_render_rays_forward_keep")
         out["mask"] = out["mask"].view(torch.bool)
-        return out, (ws, qc, d, R, bool(white_bkgd), bool(train))
+        return out, (ws, qc, d, R, bool(white_bkgd), bool(train), bkeep)
 
     def render_rays_backward_kept(self, state, g_rgb=None, g_depth=None, g_depth_uncertainty=None, g_feat=None, g_weights=None, want_g_query_center: bool = False,
-                                  train: "TrainGrads" = None):
-        """nl_render_rays_backward_kept: the way back from the activations `render_rays_keep` left in `state` -> (g_rays_o, g_rays_d, g_query_center or None)."""
-        ws, qc, d, R, white, was_train = state
+                                  train: "TrainGrads" = None, g_beta=None, want_beta_grads: bool = False):
+        """nl_render_rays_backward_kept: the way back from the activations `render_rays_keep` left in `state` -> (g_rays_o, g_rays_d, g_query_center or None)
+        [+ (g_beta_weight (1,W), g_beta_bias (1,)) when want_beta_grads]."""
+        ws, qc, d, R, white, was_train, bkeep = state
         if (train is not None) != was_train:
             raise ValueError("the state was made for " + ("a training" if was_train else "a frozen-weights") + " backward pass")
         dev = self.device
@@ -386,10 +396,20 @@ class HipRenderer:
         c.g_rgb, c.g_depth, c.g_depth_uncertainty, c.g_feat, c.g_weights = [_ptr(t) for t in cots]
         go, gd = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
         gq = torch.empty(R, 3, device=dev) if want_g_query_center else None
+        bh, gbw, gbb = None, None, None
+        if bkeep is not None and g_beta is not None:
+            gbt = _dev_f32(g_beta, dev)
+            bh = L.NlBetaHead()
+            bh.weight, bh.bias, bh.beta_min, bh.g_beta = bkeep[0].data_ptr(), bkeep[1].data_ptr(), bkeep[2], gbt.data_ptr()
+            if want_beta_grads and train is not None:
+                gbw, gbb = torch.zeros(1, self.W, device=dev), torch.zeros(1, device=dev)
+                bh.g_weight, bh.g_bias = gbw.data_ptr(), gbb.data_ptr()
         L.check(self.lib.nl_render_rays_backward_kept(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), d.data_ptr(), R, 1 if white else 0,
-                                                      ct.byref(c), go.data_ptr(), gd.data_ptr(), _ptr(gq), None if train is None else ct.byref(train.c),
-                                                      ws.data_ptr(), ws.numel(), self._stream()), "nl_render_rays_backward_kept")
-        return go, gd, (None if gq is None else gq.sum(0))
+                                                      ct.byref(c), None if bh is None else ct.byref(bh), go.data_ptr(), gd.data_ptr(), _ptr(gq),
+                                                      None if train is None else ct.byref(train.c), ws.data_ptr(), ws.numel(), self._stream()),
+                "nl_render_rays_backward_kept")
+        res = (go, gd, (None if gq is None else gq.sum(0)))
+        return res + ((gbw, gbb),) if want_beta_grads else res
 
     def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None, train: "TrainGrads" = None):
         """Input gradient of `ray_unet` (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W).  train: also ADD the gradients of the 28 U-Net tensors

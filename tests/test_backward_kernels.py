@@ -482,11 +482,15 @@ def test_whole_path_backward_matches_the_stage_nodes(case, precision, train, chu
             fr["feat_fine_src"].requires_grad_(True); fr["vis_featmaps"].requires_grad_(True); sp["feature"].requires_grad_(True)
         fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": sp})
         o, d, pose = o0.clone().requires_grad_(True), d0.clone().requires_grad_(True), t(frame["pose"]).clone().requires_grad_(True)
-        out = dr.render_rays_diff(p, fr, o, d, z, pose, knn, frozen_renderer=None if train else r, train_renderer=r if train else None, whole_path=whole)
+        use_beta = train and chunk is None    # (the uncertainty head exists in the keep / kept pair and in the stage nodes' eager tail)
+        out = dr.render_rays_diff(p, fr, o, d, z, pose, knn, frozen_renderer=None if train else r, train_renderer=r if train else None, whole_path=whole,
+                                  beta=use_beta)
         loss = sum((out[k] * cot[k]).sum() for k in cot)
+        if use_beta:
+            loss = loss + (out["beta"] * cot["depth"]).sum()
         leaves = {"rays_o": o, "rays_d": d, "pose": pose}
         if train:
-            leaves.update({n: p[n] for n in dr.RENDER_PARAMS})
+            leaves.update({n: p[n] for n in dr.RENDER_PARAMS + (("beta_mlp.0.weight", "beta_mlp.0.bias") if use_beta else ())})
             leaves.update({"feat_fine_src": fr["feat_fine_src"], "vis_featmaps": fr["vis_featmaps"], "support.feature": sp["feature"]})
         gs = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
         return {k: v.detach() for k, v in out.items()}, dict(zip(leaves.keys(), gs))

@@ -38,9 +38,10 @@ leaves = [v for v in p.values()] + [fr["feat_fine_src"], fr["vis_featmaps"], sp[
 
 
 def step(hip):
-    out = dr.render_rays_diff(p, fr, o, d, z, pose, knn, beta=False, train_renderer=r if hip else None)
+    out = dr.render_rays_diff(p, fr, o, d, z, pose, knn, beta=True, train_renderer=r if hip else None)   # render.use_render_uncertainty: the reference configs' default
     m = out["mask"].unsqueeze(1).float()
-    loss = torch.mean(((out["rgb"] - t_rgb) * m) ** 2) + 0.1 * torch.mean(((out["feat"] - t_feat) * m) ** 2)
+    b = out["beta"].unsqueeze(1)
+    loss = torch.mean(((out["rgb"] - t_rgb) * m) ** 2 / (2 * b ** 2)) + torch.mean(torch.log(b)) + 0.1 * torch.mean(((out["feat"] - t_feat) * m) ** 2)
     gs = torch.autograd.grad(loss, leaves, allow_unused=True)
     return loss.detach(), gs
 
