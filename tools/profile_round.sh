@@ -30,6 +30,12 @@ for n in sq sq2 f w; do DB=$(find $OUT/pmc_$n -name "*.db" | head -1); python to
 python tools/hbm_traffic.py $(find $OUT/pmc_f -name "*.db" | head -1) $(find $OUT/pmc_w -name "*.db" | head -1) 7 $OUT/hbm_traffic.json > /dev/null
 rm -rf $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_f $OUT/pmc_w
 python tools/pose_refine_bench.py 2>&1 | grep "rays x" > $OUT/pose_refine.txt
+# rocprofv3 kernel traces of the two gradient benches (the whole processes: eager reference steps included; the library's kernels are the named ones)
+for t in pose_refine train_step; do
+  rocprofv3 --kernel-trace --output-format rocpd -d $OUT/kt_$t -- python tools/${t}_bench.py > $OUT/kt_$t.log 2>&1
+  python tools/prof_summary.py $(find $OUT/kt_$t -name "*.db" | head -1) $OUT/${t}_kernel_stats.csv > /dev/null
+  rm -rf $OUT/kt_$t
+done
 ROWS=40 python tools/pose_step_profile.py 2>&1 | grep "ms/step" > $OUT/pose_step_profile.txt
 python tools/train_step_bench.py 2>&1 | grep "training step" > $OUT/train_step.txt
 PROFILE=1 python tools/train_step_bench.py 2>&1 | grep "ms/step" > $OUT/train_step_profile.txt
