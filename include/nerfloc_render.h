@@ -121,6 +121,13 @@ const char* nl_weight_name(int i);
 int nl_profile_begin(void);
 int nl_profile_end(float* fused_ms, int* launches);
 
+/* Debug facility for tests (not thread-safe, process-global): with a gap set, every buffer the library carves from a caller workspace is followed by
+ * `bytes` unused bytes (the *_workspace_bytes queries grow accordingly) and the carve records the regions between the buffers; a caller that filled its
+ * workspace with `pattern` before a call learns from nl_debug_check_gaps how many of those regions a kernel wrote into.  0 switches it off. */
+int nl_debug_bump_gap(size_t bytes);
+int nl_debug_check_gaps(int pattern, int32_t* scratch /* device, 4 bytes */, int* bad_regions /* host */, int* checked_regions /* host, may be NULL */,
+                        void* stream);
+
 /* ---- weights ---------------------------------------------------------------------------------- */
 size_t nl_packed_weights_bytes(const nl_config* cfg);
 /* tensors[i] = DEVICE pointer of state_dict[nl_weight_name(i)] (fp32, contiguous, torch layout). */

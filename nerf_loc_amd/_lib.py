@@ -105,6 +105,8 @@ SYMBOLS = [
     ("nl_composite_backward", _I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("nl_point_mlp_backward_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_point_mlp_backward", _I, [_CFG, _P, _P, _P, _P, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    ("nl_debug_bump_gap", _I, [_Z]),
+    ("nl_debug_check_gaps", _I, [_I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
     ("nl_render_rays_keep_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
     ("nl_render_rays_forward_keep", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, C.POINTER(NlBetaHead), _I, _P, _Z, _P]),

@@ -464,11 +464,17 @@ struct nl_frame {
 
 namespace {
 
+// Debug facility (nl_debug_bump_gap / nl_debug_check_gaps, used by the test-suite's guarded workspaces): with a gap size set, every buffer carved from a
+// workspace is followed by that many untouched bytes, and the carve records [exact end of the buffer, start of the next one) — the caller fills the workspace
+// with a pattern before the call and the check finds any byte a kernel wrote outside its buffer, also BETWEEN two buffers of one workspace.
+size_t g_bump_gap = 0;
+std::vector<std::pair<char*, size_t>> g_bump_gaps;
 struct Bump {
   char* base; size_t off;
   template <class T> T* take(size_t count) {
     size_t o = off;
-    off += nl_align_up(count * sizeof(T), 256);
+    off += nl_align_up(count * sizeof(T), 256) + g_bump_gap;
+    if (g_bump_gap && base && g_bump_gaps.size() < (1u << 16)) g_bump_gaps.push_back({base + o + count * sizeof(T), off - o - count * sizeof(T)});
     return base ? (T*)(base + o) : nullptr;
   }
 };
@@ -1420,6 +1426,11 @@ int render_outputs_staged(const Ctx& x32, const nl_frame* f, int64_t R, int whit
   return NL_OK;
 }
 
+__global__ void gap_check_kernel(const unsigned char* __restrict__ p, size_t n, unsigned char pat, int* __restrict__ bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && p[i] != pat) atomicAdd(bad, 1);
+}
+
 Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
   Ctx x;
   x.c = c; x.L = make_layout(c); x.pk = (const char*)packed; x.st = (hipStream_t)stream;
@@ -1435,6 +1446,27 @@ static_assert(sizeof(nl_render_opts) == 32, "nl_render_opts is part of the C-ABI
 static_assert(sizeof(nl_train_grads) == 72 && sizeof(nl_render_cotangents) == 64, "training / cotangent blocks are part of the C-ABI");
 static_assert(offsetof(nl_render_opts, flags) == 4 && offsetof(nl_render_opts, ray_centers) == 8, "nl_render_opts layout");
 int nl_abi_version(void) { return NL_ABI_VERSION; }
+
+int nl_debug_bump_gap(size_t bytes) { g_bump_gap = nl_align_up(bytes, 256); g_bump_gaps.clear(); return NL_OK; }
+// counts the recorded gap regions (since the last nl_debug_bump_gap / nl_debug_check_gaps) that hold anything but `pattern`; scratch: 4 device bytes
+int nl_debug_check_gaps(int pattern, int* scratch, int* bad_regions, int* checked_regions, void* stream) {
+  if (!scratch || !bad_regions) return NL_ERR_BAD_ARG;
+  if (checked_regions) *checked_regions = (int)g_bump_gaps.size();
+  hipStream_t st = (hipStream_t)stream;
+  int bad = 0;
+  for (const auto& g : g_bump_gaps) {
+    NL_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(int), st));
+    hipLaunchKernelGGL(gap_check_kernel, dim3((unsigned)nl_cdiv((int64_t)g.second, 256)), dim3(256), 0, st, (const unsigned char*)g.first, g.second, (unsigned char)pattern,
+                       scratch);
+    int h = 0;
+    NL_CHECK_HIP(hipMemcpyAsync(&h, scratch, sizeof(int), hipMemcpyDeviceToHost, st));
+    NL_CHECK_HIP(hipStreamSynchronize(st));
+    if (h) ++bad;
+  }
+  *bad_regions = bad;
+  g_bump_gaps.clear();
+  return NL_OK;
+}
 
 int nl_profile_begin(void) { g_prof.on = true; g_prof.used = 0; return NL_OK; }
 int nl_profile_end(float* fused_ms, int* launches) {

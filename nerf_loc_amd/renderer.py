@@ -198,9 +198,14 @@ class HipRenderer:
 
     # test facility: with `guard_bytes` > 0 every workspace handed to the library is EXACTLY the size its *_workspace_bytes query asked for, followed
     # by a canary region; `check_guards()` verifies that no call wrote past its workspace
+    def set_guard(self, guard_bytes: int, gap_bytes: int = 0) -> None:
+        """guard_bytes: canary behind every workspace; gap_bytes: also BETWEEN the buffers the library carves from it (nl_debug_bump_gap: process-global,
+        switch it off again with set_guard(0))."""
+        self.guard_bytes = int(guard_bytes)
+        L.check(self.lib.nl_debug_bump_gap(int(gap_bytes)), "nl_debug_bump_gap")
+
     def _guarded(self, nbytes: int) -> torch.Tensor:
-        buf = torch.empty(int(nbytes) + int(self.guard_bytes), dtype=torch.uint8, device=self.device)
-        buf[nbytes:] = 0xA5
+        buf = torch.full((int(nbytes) + int(self.guard_bytes),), 0xA5, dtype=torch.uint8, device=self.device)
         self.__dict__.setdefault("_guards", []).append((buf, int(nbytes)))
         return buf[:nbytes]
 
@@ -211,6 +216,12 @@ class HipRenderer:
             if not bool((buf[nb:] == 0xA5).all()):
                 raise AssertionError(f"a library call wrote past its {nb}-byte workspace")
             n += 1
+        bad, checked = ct.c_int(0), ct.c_int(0)
+        scratch = torch.zeros(1, dtype=torch.int32, device=self.device)
+        L.check(self.lib.nl_debug_check_gaps(0xA5, scratch.data_ptr(), ct.byref(bad), ct.byref(checked), self._stream()), "nl_debug_check_gaps")
+        if bad.value:
+            raise AssertionError(f"a kernel wrote outside its buffer inside a workspace ({bad.value} of {checked.value} gap regions touched)")
+        self.gaps_checked = getattr(self, "gaps_checked", 0) + checked.value
         self._guards = []
         return n
 

@@ -543,15 +543,23 @@ def test_nodes_refuse_a_backward_pass_against_replaced_state():
 @pytest.mark.parametrize("case,precision", [("tiny_full", "fp32"), ("tiny_full", "bf16x3"), ("fewpts", "bf16x3"), ("c1", "bf16x3"), ("w128s64", "bf16x3"), ("s192out", "bf16x3")])
 def test_no_call_writes_past_its_workspace(case, precision):
     """Every workspace is carved by the library from a caller buffer of exactly the size its *_workspace_bytes query returned: with a canary region
-    behind each of them, the forward stages, every backward / training entry point and the whole-path pairs leave the canaries intact (the buffer
-    that the U-Net's LayerNorm rows overflowed at W = 32 was the LAST one of its workspace: nothing but a canary notices that)."""
+    behind each workspace AND between the buffers carved from it (nl_debug_bump_gap), the forward stages, every backward / training entry point and the
+    whole-path pairs leave all of them intact (the buffer that the U-Net's LayerNorm rows overflowed at W = 32 was the last one of its workspace in the
+    stage call and an inner one in the whole-path call)."""
     from nerf_loc_amd.renderer import HipRenderer
     from tests.golden_cases import build_case
     c = build_case(case)
     cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
     dev = torch.device("cuda:0")
     r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
-    r.guard_bytes = 1 << 20
+    r.set_guard(1 << 20, gap_bytes=4096)   # a canary behind every workspace and between the buffers carved from it
+    try:
+        _guarded_calls(r, c, cfg, frame, rays, dev)
+    finally:
+        r.set_guard(0)
+
+
+def _guarded_calls(r, c, cfg, frame, rays, dev):
     r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
     r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -585,4 +593,4 @@ def test_no_call_writes_past_its_workspace(case, precision):
         out, state = r.render_rays_keep(o, d, z, qc, train=train)
         tg = r.train_grads(names, support_feature=True, feat_maps=True, vis_featmaps=True, blend_feat_maps=True) if train else None
         r.render_rays_backward_kept(state, g_rgb=rnd(R, 3), g_feat=rnd(R, cfg.C), train=tg); calls += r.check_guards()
-    assert calls >= 15   # (guarded workspaces checked)
+    assert calls >= 15 and r.gaps_checked > 300   # (guarded workspaces / gap regions between their buffers checked)
