@@ -264,7 +264,10 @@ def main():
         result["other_precisions"] = extra
 
     if rank == 0 and world == 1 and not args.no_gradient_step and not hier and args.precision != "fp32":
-        result["gradient_step"] = gradient_step(rnd, cfg, frame, rays, weights, torch.device(f"cuda:{local_rank}"))
+        try:   # (an extra next to the headline: whatever happens here must not cost the line)
+            result["gradient_step"] = gradient_step(rnd, cfg, frame, rays, weights, torch.device(f"cuda:{local_rank}"))
+        except Exception as e:   # noqa: BLE001
+            result["gradient_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights, u_all)
     # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which a pipe flushes only at exit: every rank pushes it out
