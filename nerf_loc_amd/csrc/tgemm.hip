@@ -85,12 +85,15 @@ __device__ unsigned long long tg_trace[64];
 #endif
 
 template <int NRT, int NW, bool X3, int EPI, bool F16 = false>
-__global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
+__global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
                                                             const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
   constexpr int PARTS = X3 ? 2 : 1;
   constexpr int PIECES = PARTS * 2 * NRT;   // 1-KB pieces of weights per chunk
-  constexpr int NPW = PIECES / NW;          // pieces staged by each wave
-  static_assert(PIECES % NW == 0, "pieces must split evenly over the waves");
+  // waves that stage weights: all of them, or the first four of a six-wave workgroup (S = 192 / 96 slabs: a ray = six / three row tiles; 8 ... 32
+  // pieces do not split over six)
+  constexpr int NWS = PIECES % NW == 0 ? NW : 4;
+  constexpr int NPW = PIECES / NWS;         // pieces staged by each staging wave
+  static_assert(PIECES % NWS == 0 && NWS <= NW, "pieces must split evenly over the staging waves");
   constexpr int CH16 = 4 * NRT * 64;        // 16-B units per chunk in the global stream (hi and lo parts are always stored)
   constexpr int SLOT16 = PIECES * 64;       // 16-B units per LDS slot
   __shared__ uint4 lds_all[2 * SLOT16 + NRT * 8 * (EPI == NL_EPI_LNROW ? 3 : EPI == NL_EPI_LNSLAB ? 2 : 1) + (EPI == NL_EPI_LNSLAB ? 8 : 0)];
@@ -120,14 +123,17 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 
   // weights of chunk c: this wave's NPW pieces, 16 B per lane, fully coalesced
   auto w_ptr = [&](int c) __attribute__((always_inline)) { return reinterpret_cast<const tg_bf16x8*>(p_bst) + (size_t)c * CH16 + wave * 64 + lane; };
+  const bool stager = NWS == NW || wave < NWS;   // (wave-uniform; a compile-time `true` for the four-wave kernels)
   auto load_w = [&](int c, tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
+    if (!stager) return;
     const tg_bf16x8* src = w_ptr(c);
 #pragma unroll
-    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[NW * jj * 64];
+    for (int jj = 0; jj < NPW; ++jj) w[jj] = src[NWS * jj * 64];
   };
   auto store_w = [&](int slot, const tg_bf16x8 (&w)[NPW]) __attribute__((always_inline)) {
+    if (!stager) return;
 #pragma unroll
-    for (int jj = 0; jj < NPW; ++jj) ring[slot][(wave + NW * jj) * 64 + lane] = w[jj];
+    for (int jj = 0; jj < NPW; ++jj) ring[slot][(wave + NWS * jj) * 64 + lane] = w[jj];
   };
   // activation fragments of chunk c: 2 k-steps x 8 floats of this lane's source row, straight into registers.  Conv halo
   // rows and rows >= M read a device zero page instead (no masking arithmetic).
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
         for (int l = 0; l < NLD; ++l)
           if (l * nh / NLD == tt) {
             if (l < 4) raw[l] = *(const float4*)(ap + 16 * (l >> 1) + 4 * (l & 1));
-            else wreg[l - 4] = wp[NW * (l - 4) * 64];
+            else if (stager) wreg[l - 4] = wp[NWS * (l - 4) * 64];
           }
       });
     } else {
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tgemm_kernel(const NlGemmArgs a, c
 
   // epilogue: C/D layout col = lane&31 (= this lane's output row), reg r = 4*gq + e <-> n = 32*rt + 8*gq + 4*hh + e
   if constexpr (EPI == NL_EPI_LNSLAB) {
-    // The workgroup's 32*NW rows are one, two, four or eight whole rays (launch precondition: So in {128, 64, 32, 16}, M % So == 0; `wpr`
+    // The workgroup's 32*NW rows are one, two, four or eight whole rays (launch precondition: So in {128, 64, 32, 16} with four waves, {192, 96} with six, M % So == 0; `wpr`
     // waves per ray, or two rays per wave for So = 16): LayerNorm over each ray's whole (So x N) slab with per-(position, channel) affine, ELU, optional
     // MaxPool(2) along the ray.  A trailing workgroup may hold rays past M: their statistics are computed on zero rows and
     // nothing of them is stored.
@@ -835,7 +841,7 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
-  if (a.epi == NL_EPI_LNSLAB && ((a.So != 128 && a.So != 64 && a.So != 32 && a.So != 16) || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
+  if (a.epi == NL_EPI_LNSLAB && ((a.So != 192 && a.So != 96 && a.So != 128 && a.So != 64 && a.So != 32 && a.So != 16) || a.M % a.So || a.Li != a.So || a.ostride != 1 || a.ooff != 0 || !a.ep_gamma || !a.ep_beta)) return false;
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
     if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k || g.ntap < 1) return false;
@@ -861,6 +867,14 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
     if (nrt == 8) hipLaunchKernelGGL((tgemm_kernel<8, 4, true, NL_EPI_NONE, true>), grid, dim3(256), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
     else if (nrt == 4) hipLaunchKernelGGL((tgemm_kernel<4, 4, true, NL_EPI_NONE, true>), grid, dim3(256), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
     else hipLaunchKernelGGL((tgemm_kernel<2, 4, true, NL_EPI_NONE, true>), grid, dim3(256), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+  }
+  if (a.epi == NL_EPI_LNSLAB && (a.So == 192 || a.So == 96)) {   // six waves = one ray of 192 rows or two of 96
+#define NL_TG6(NRT, X3) hipLaunchKernelGGL((tgemm_kernel<NRT, 6, X3, NL_EPI_LNSLAB>), dim3((unsigned)nl_cdiv(a.M, 192)), dim3(384), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias)
+    if (nrt == 8) { if (x3) NL_TG6(8, true); else NL_TG6(8, false); }
+    else if (nrt == 4) { if (x3) NL_TG6(4, true); else NL_TG6(4, false); }
+    else { if (x3) NL_TG6(2, true); else NL_TG6(2, false); }
+#undef NL_TG6
     return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
   }
   if (nrt == 8) { if (x3) NL_TG(8, 4, true); else NL_TG(8, 4, false); }
