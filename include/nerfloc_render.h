@@ -328,7 +328,9 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
  * the maps and the support features).  Equivalent to chaining the stage entry points above through compositing and the three heads, but every
  * per-frame / per-sample quantity is recomputed ONCE per call: one pass of the visibility decoders forward and one backward for the aggregation's and
  * the blend's uses of them, one geometry kernel for both sets of taps, one neighbour search.  z_vals (R,S): the sample depths the forward call used
- * (the hierarchical branch's resampled depths are constants: model.py:495 detaches them).  g_query_center_rows (R,3) or NULL: per-ray partial sums of
+ * (the hierarchical branch's resampled depths are constants: model.py:495 detaches them).  The query camera centre comes from the host (3 floats) or —
+ * no device-to-host copy of a pose that is being optimised on the device — as per-ray rows in device memory (like nl_render_opts.ray_centers).
+ * g_query_center_rows (R,3) or NULL: per-ray partial sums of
  * d/d(query camera centre) — the caller adds them up.  Rays are processed in chunks that fit the workspace. */
 typedef struct nl_render_cotangents {
   const float* g_rgb;                 /* (R,3) or NULL (= zero) */
@@ -342,7 +344,8 @@ typedef struct nl_render_cotangents {
   const void* reserved[1];            /* must be NULL */
 } nl_render_cotangents;
 size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train);
-int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST, 3 floats */,
+int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST, 3 floats, or NULL */,
+                            const float* ray_centers /* DEVICE (R,3) per-ray query centres, or NULL: one of the two */,
                             const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_cotangents* g,
                             float* g_rays_o, float* g_rays_d, float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes,
                             void* stream);
@@ -366,12 +369,13 @@ typedef struct nl_beta_head {
   float* g_bias;         /* backward call: (1) +=, or NULL */
 } nl_beta_head;
 size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train);
-int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST */, const float* rays_o,
-                                const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, const nl_beta_head* beta,
-                                int train, void* ws, size_t ws_bytes, void* stream);
-int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST */, const float* rays_d,
-                                 int64_t R, int white_bkgd, const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d,
-                                 float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
+int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST or NULL */,
+                                const float* ray_centers /* DEVICE (R,3) or NULL */, const float* rays_o, const float* rays_d, const float* z_vals, int64_t R,
+                                int white_bkgd, const nl_render_out* out, const nl_beta_head* beta, int train, void* ws, size_t ws_bytes, void* stream);
+int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center /* HOST or NULL */,
+                                 const float* ray_centers /* DEVICE (R,3) or NULL */, const float* rays_d, int64_t R, int white_bkgd,
+                                 const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d, float* g_query_center_rows,
+                                 const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* nl_ray_unet_backward + gradients of the seven blocks' convolution weights / biases and LayerNorm([C, L]) tables (28 tensors). */
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R);

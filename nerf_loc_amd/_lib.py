@@ -109,11 +109,11 @@ SYMBOLS = [
     ("nl_debug_check_gaps", _I, [_I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), _P]),
     ("nl_train_scratch_bytes", _Z, [_CFG]),
     ("nl_render_rays_keep_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
-    ("nl_render_rays_forward_keep", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, C.POINTER(NlBetaHead), _I, _P, _Z, _P]),
-    ("nl_render_rays_backward_kept", _I, [_CFG, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), C.POINTER(NlBetaHead), _P, _P, _P, C.POINTER(NlTrainGrads),
-                                          _P, _Z, _P]),
+    ("nl_render_rays_forward_keep", _I, [_CFG, _P, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, C.POINTER(NlBetaHead), _I, _P, _Z, _P]),
+    ("nl_render_rays_backward_kept", _I, [_CFG, _P, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), C.POINTER(NlBetaHead), _P, _P, _P,
+                                          C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_render_rays_backward_workspace_bytes", _Z, [_CFG, _I, _L, _I]),
-    ("nl_render_rays_backward", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
+    ("nl_render_rays_backward", _I, [_CFG, _P, _P, _P, _P, _P, _P, _P, _L, _I, C.POINTER(NlRenderCotangents), _P, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_ray_unet_backward_train_workspace_bytes", _Z, [_CFG, _L]),
     ("nl_ray_unet_backward_train", _I, [_CFG, _P, _P, _L, _P, _P, C.POINTER(NlTrainGrads), _P, _Z, _P]),
     ("nl_mv_aggregate_backward_train_workspace_bytes", _Z, [_CFG, _I, _L]),

@@ -1328,12 +1328,12 @@ void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool tra
 }
 struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; const int* idx; const float* d2; };
 // the staged forward of the whole path into the workspace (everything the way back reads).  want_feat: feat_mlp.0's hidden rows too
-int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R, bool want_feat,
-                          const int* knn_idx, const float* knn_d2, const RbBufs& a) {
+int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, const float* qrows, const float* rays_o, const float* rays_d, const float* z, int64_t R,
+                          bool want_feat, const int* knn_idx, const float* knn_d2, const RbBufs& a) {
   const int W = x32.c->W, S = x32.c->S;
   const int64_t N = R * S;
   hipStream_t st = x32.st;
-  const NlViews vw = with_query(f, qc);
+  const NlViews vw = with_query(f, qc, qrows, S);
   const float eps_ln = 1e-6f;
   NL_TRY(nl_launch_sample_points(rays_o, rays_d, R, S, f->views.near_, f->views.far_, z, a.zc, a.xyz, st));
   NL_TRY(mv_recompute(x32, f, vw, a.xyz, N, a.m));                       // visibility / depth difference, statistics rows, the blend's per-view part
@@ -1349,12 +1349,12 @@ int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, co
                          x32.p<float>(x32.L.bl4_b), a.rgb_s, st);
 }
 // the way back from the staged forward's workspace
-int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_d, int64_t R, int white, const RbCot& ct,
-                           float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg, const nl_beta_head* bh = nullptr) {
+int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* qrows, const float* rays_d, int64_t R, int white,
+                           const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg, const nl_beta_head* bh = nullptr) {
   const int W = x32.c->W, S = x32.c->S, C = x32.c->C;
   const int64_t N = R * S;
   hipStream_t st = x32.st;
-  const NlViews vw = with_query(f, qc);
+  const NlViews vw = with_query(f, qc, qrows, S);
   const bool want_feat = ct.g_feat != nullptr;
   // ---------------------------------------------------------------- compositing backwards (feat = W2 . sum_s w_s hidden_s + b2 sum_s w_s)
   const float* b2 = x32.p<float>(x32.L.b32[G_FEAT2]) + (size_t)W * x32.L.g[G_FEAT2].Npad;   // the bias row of G_FEAT2's fp32 weights (K row W)
@@ -1403,10 +1403,10 @@ int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, con
   NL_TRY(mv_geom_dec_backward(x32, f, vw, a.xyz, N, a.m.gg393, true, a.gxyz_m, g_qc_rows ? a.gqcN : nullptr, a.m, tg));
   return nl_launch_ray_reduce(a.gxyz_m, a.gxyz_p, nullptr, a.gdir, g_qc_rows ? a.gqcN : nullptr, a.zc, R, S, g_o, g_d, g_qc_rows, st);
 }
-int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z, int64_t R,
-                       int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
-  NL_TRY(render_forward_staged(x32, f, qc, rays_o, rays_d, z, R, ct.g_feat != nullptr, ct.idx, ct.d2, a));
-  return render_backward_staged(xb, x32, f, qc, rays_d, R, white, ct, g_o, g_d, g_qc_rows, a, tg);
+int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* qrows, const float* rays_o, const float* rays_d, const float* z,
+                       int64_t R, int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
+  NL_TRY(render_forward_staged(x32, f, qc, qrows, rays_o, rays_d, z, R, ct.g_feat != nullptr, ct.idx, ct.d2, a));
+  return render_backward_staged(xb, x32, f, qc, qrows, rays_d, R, white, ct, g_o, g_d, g_qc_rows, a, tg);
 }
 // the per-ray outputs from the staged forward's workspace (the gradient path's forward values: split-FP16 arithmetic in the bf16 modes)
 int render_outputs_staged(const Ctx& x32, const nl_frame* f, int64_t R, int white, const nl_render_out* out, const RbBufs& a, const nl_beta_head* bh = nullptr) {
@@ -1937,11 +1937,11 @@ size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int6
   const int64_t cap = (1 << 16) / cfg->S > 1 ? (1 << 16) / cfg->S : 1;   // recommended chunk: ~64 k samples (~70 KB of workspace per sample at W = 256)
   return render_bwd_bytes(cfg, V, R < 1 ? 1 : (R > cap ? cap : R), train != 0);
 }
-int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_o, const float* rays_d,
-                            const float* z_vals, int64_t R, int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d,
+int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_o,
+                            const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d,
                             float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
-  if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (!cfg_ok(cfg) || !packed || !f || (!query_center && !ray_centers) || !rays_o || !rays_d || !z_vals || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (g->reserved[0] != nullptr || (g->knn_idx == nullptr) != (g->knn_d2 == nullptr)) return NL_ERR_BAD_ARG;
   const bool train = grads != nullptr;
   TrainOut T;
@@ -1959,7 +1959,8 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
     RbCot ct{g->g_rgb ? g->g_rgb + 3 * r0 : nullptr, g->g_depth ? g->g_depth + r0 : nullptr, g->g_depth_uncertainty ? g->g_depth_uncertainty + r0 : nullptr,
              g->g_feat ? g->g_feat + r0 * C : nullptr, g->g_weights ? g->g_weights + r0 * S : nullptr,
              g->knn_idx ? g->knn_idx + r0 * S * 8 : nullptr, g->knn_d2 ? g->knn_d2 + r0 * S * 8 : nullptr};
-    NL_TRY(do_render_backward(B.xb, B.x32, f, query_center, rays_o + 3 * r0, rays_d + 3 * r0, z_vals + r0 * S, rc, white_bkgd, ct, g_rays_o + 3 * r0,
+    NL_TRY(do_render_backward(B.xb, B.x32, f, query_center, ray_centers ? ray_centers + 3 * r0 : nullptr, rays_o + 3 * r0, rays_d + 3 * r0, z_vals + r0 * S, rc,
+                              white_bkgd, ct, g_rays_o + 3 * r0,
                               g_rays_d + 3 * r0, g_query_center_rows ? g_query_center_rows + 3 * r0 : nullptr, a, train ? &T : nullptr));
   }
   return NL_OK;
@@ -1972,11 +1973,11 @@ size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t 
   if (!cfg_ok(cfg) || V < 1 || V > NL_MAX_VIEWS || R < 1) return 0;
   return render_bwd_bytes(cfg, V, R, train != 0);
 }
-int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_o, const float* rays_d,
-                                const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, const nl_beta_head* beta, int train, void* ws,
-                                size_t ws_bytes, void* stream) {
+int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_o,
+                                const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, const nl_beta_head* beta, int train,
+                                void* ws, size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
-  if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_o || !rays_d || !z_vals || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (!cfg_ok(cfg) || !packed || !f || (!query_center && !ray_centers) || !rays_o || !rays_d || !z_vals || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (beta && (!beta->weight || !beta->bias || !beta->beta)) return NL_ERR_BAD_ARG;
   if (!out->rgb || !out->depth || !out->weights || !out->mask || !out->depth_uncertainty) return NL_ERR_BAD_ARG;
   if (f->M < 1) return NL_ERR_UNSUPPORTED;
@@ -1984,14 +1985,14 @@ int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const 
   if (ws_bytes < render_bwd_bytes(cfg, V, R, train != 0)) return NL_ERR_WORKSPACE;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train != 0);
-  NL_TRY(render_forward_staged(B.x32, f, query_center, rays_o, rays_d, z_vals, R, out->feat != nullptr, nullptr, nullptr, a));
+  NL_TRY(render_forward_staged(B.x32, f, query_center, ray_centers, rays_o, rays_d, z_vals, R, out->feat != nullptr, nullptr, nullptr, a));
   return render_outputs_staged(B.x32, f, R, white_bkgd, out, a, beta);
 }
-int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* rays_d, int64_t R,
-                                 int white_bkgd, const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d,
+int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_d,
+                                 int64_t R, int white_bkgd, const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d,
                                  float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   if (R == 0) return NL_OK;
-  if (!cfg_ok(cfg) || !packed || !f || !query_center || !rays_d || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
+  if (!cfg_ok(cfg) || !packed || !f || (!query_center && !ray_centers) || !rays_d || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (beta && (!beta->weight || !beta->bias || (beta->g_weight && !grads))) return NL_ERR_BAD_ARG;   // (the weight gradient's split-K scratch comes with `grads`)
   if (g->reserved[0] != nullptr || g->knn_idx || g->knn_d2) return NL_ERR_BAD_ARG;   // (the neighbours are in the workspace)
   const bool train = grads != nullptr;
@@ -2003,7 +2004,8 @@ int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train);
   RbCot ct{g->g_rgb, g->g_depth, g->g_depth_uncertainty, g->g_feat, g->g_weights, nullptr, nullptr};
-  return render_backward_staged(B.xb, B.x32, f, query_center, rays_d, R, white_bkgd, ct, g_rays_o, g_rays_d, g_query_center_rows, a, train ? &T : nullptr, beta);
+  return render_backward_staged(B.xb, B.x32, f, query_center, ray_centers, rays_d, R, white_bkgd, ct, g_rays_o, g_rays_d, g_query_center_rows, a, train ? &T : nullptr,
+                                beta);
 }
 
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R) {

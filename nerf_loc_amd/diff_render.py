@@ -165,7 +165,9 @@ class RenderFn(torch.autograd.Function):
             out, ctx.kept = kept
             ctx.save_for_backward(o, d, qc, z)
         else:
-            out = renderer.render_rays(o, d, qc, z_vals=z, white_bkgd=bool(white_bkgd), want_knn=True)
+            # (a query centre on the device goes down as per-ray rows: no device-to-host copy, no synchronisation point in the loop)
+            qarg = qc.detach().float().reshape(1, 3).expand(o.shape[0], 3).contiguous() if qc.is_cuda else qc
+            out = renderer.render_rays(o, d, qarg, z_vals=z, white_bkgd=bool(white_bkgd), want_knn=True)
             ctx.save_for_backward(o, d, qc, z, out["knn_d2"], out["knn_idx"])
         ctx.mark_non_differentiable(out["mask"])
         return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]

@@ -24,6 +24,16 @@ def _dev_f32(t, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+class _Lease:
+    """Marks a renderer's pooled keep-workspace as free again when the state that borrowed it is dropped (after the backward call, or never used)."""
+
+    def __init__(self, pool):
+        self._pool = pool
+
+    def __del__(self):
+        self._pool["busy"] = False
+
+
 class TrainGrads:
     """Gradient buffers of one training step (nl_train_grads): `.weights[name]` fp32 tensors shaped like the state_dict entries,
     `.support_feature` (M, C+3) or None; the library ADDS into them, so one object serves all backward calls (and chunks) of a step."""
@@ -225,6 +235,16 @@ class HipRenderer:
         self._guards = []
         return n
 
+    def _centres(self, query_center, R: int):
+        """(host pointer tensor or None, device (R,3) rows or None): a query centre that lives on the device (a pose being optimised) is handed over as per-ray
+        rows — no device-to-host copy, i.e. no synchronisation point in the middle of a training / refinement loop."""
+        qc = torch.as_tensor(query_center).detach()
+        if qc.is_cuda:
+            rows = qc.float().reshape(-1, 3)
+            rows = rows.expand(R, 3) if rows.shape[0] == 1 else rows
+            return None, rows.contiguous()
+        return qc.float().reshape(3).contiguous(), None
+
     def _ready(self):
         if not self._weights_loaded:
             raise RuntimeError("load_weights() first")
@@ -349,7 +369,7 @@ class HipRenderer:
         R = o.shape[0]
         if z.shape != (R, self.S):
             raise ValueError(f"z_vals must be ({R}, {self.S})")
-        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        qc, qrows = self._centres(query_center, R)
         cots = [None if t is None else _dev_f32(t, dev) for t in (g_rgb, g_depth, g_depth_uncertainty, g_feat, g_weights)]
         c = L.NlRenderCotangents()
         c.g_rgb, c.g_depth, c.g_depth_uncertainty, c.g_feat, c.g_weights = [_ptr(t) for t in cots]
@@ -362,7 +382,7 @@ class HipRenderer:
             workspace_rays = getattr(self, "backward_rays_per_chunk", None)   # None: the library's default (~64 k samples per chunk, ~90 KB each at W = 256)
         ws = self._workspace(self.lib.nl_render_rays_backward_workspace_bytes(ct.byref(self.cfg), self.V, R if workspace_rays is None else int(workspace_rays),
                                                                               0 if train is None else 1))
-        L.check(self.lib.nl_render_rays_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
+        L.check(self.lib.nl_render_rays_backward(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, _ptr(qc), _ptr(qrows), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
                                                  1 if white_bkgd else 0, ct.byref(c), go.data_ptr(), gd.data_ptr(), _ptr(gq),
                                                  None if train is None else ct.byref(train.c), ws.data_ptr(), ws.numel(), self._stream()),
                 "nl_render_rays_backward")
@@ -380,14 +400,28 @@ class HipRenderer:
         need = self.lib.nl_render_rays_keep_workspace_bytes(ct.byref(self.cfg), self.V, R, 1 if train else 0)
         if need == 0 or (max_bytes is not None and need > max_bytes):
             return None
-        qc = torch.as_tensor(query_center).detach().float().cpu().contiguous()
+        qc, qrows = self._centres(query_center, R)
         out = {"rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
                "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev), "feat": torch.empty(R, self.C, device=dev)}
         ro = L.NlRenderOut()
         for k, t in out.items():
             setattr(ro, k, t.data_ptr())
-        # owned by the returned state, not the shared workspace: it must survive until the backward call
-        ws = self._guarded(need) if getattr(self, "guard_bytes", 0) else torch.empty(need, dtype=torch.uint8, device=dev)
+        # owned by the returned state, not the shared workspace: it must survive until the backward call.  One buffer per renderer is pooled (a training /
+        # refinement loop would otherwise allocate and free gigabytes every step: the caching allocator falls back to hipMalloc when it cannot serve
+        # that from its cache, milliseconds each time); a second forward before the first one's backward gets a buffer of its own
+        lease = None
+        if getattr(self, "guard_bytes", 0):
+            ws = self._guarded(need)
+        else:
+            pool = self.__dict__.setdefault("_keep_pool", {"buf": None, "busy": False})
+            if not pool["busy"]:
+                if pool["buf"] is None or pool["buf"].numel() < need:
+                    pool["buf"] = None
+                    pool["buf"] = torch.empty(need, dtype=torch.uint8, device=dev)
+                pool["busy"] = True
+                ws, lease = pool["buf"][:need], _Lease(pool)
+            else:
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
         bh, bkeep = None, None
         if beta_head is not None:
             bw, bb = _dev_f32(beta_head[0], dev).reshape(-1), _dev_f32(beta_head[1], dev).reshape(-1)
@@ -395,17 +429,17 @@ class HipRenderer:
             bh = L.NlBetaHead()
             bh.weight, bh.bias, bh.beta_min, bh.beta = bw.data_ptr(), bb.data_ptr(), float(beta_min), out["beta"].data_ptr()
             bkeep = (bw, bb, float(beta_min))
-        L.check(self.lib.nl_render_rays_forward_keep(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
+        L.check(self.lib.nl_render_rays_forward_keep(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, _ptr(qc), _ptr(qrows), o.data_ptr(), d.data_ptr(), z.data_ptr(), R,
                                                      1 if white_bkgd else 0, ct.byref(ro), None if bh is None else ct.byref(bh), 1 if train else 0, ws.data_ptr(),
                                                      ws.numel(), self._stream()), "nl_render_rays_forward_keep")
         out["mask"] = out["mask"].view(torch.bool)
-        return out, (ws, qc, d, R, bool(white_bkgd), bool(train), bkeep)
+        return out, (ws, (qc, qrows), d, R, bool(white_bkgd), bool(train), bkeep, lease)
 
     def render_rays_backward_kept(self, state, g_rgb=None, g_depth=None, g_depth_uncertainty=None, g_feat=None, g_weights=None, want_g_query_center: bool = False,
                                   train: "TrainGrads" = None, g_beta=None, want_beta_grads: bool = False):
         """nl_render_rays_backward_kept: the way back from the activations `render_rays_keep` left in `state` -> (g_rays_o, g_rays_d, g_query_center or None)
         [+ (g_beta_weight (1,W), g_beta_bias (1,)) when want_beta_grads]."""
-        ws, qc, d, R, white, was_train, bkeep = state
+        ws, (qc, qrows), d, R, white, was_train, bkeep, _lease = state   # (the lease returns the pooled buffer when the state is dropped)
         if (train is not None) != was_train:
             raise ValueError("the state was made for " + ("a training" if was_train else "a frozen-weights") + " backward pass")
         dev = self.device
@@ -422,7 +456,7 @@ class HipRenderer:
             if want_beta_grads and train is not None:
                 gbw, gbb = torch.zeros(1, self.W, device=dev), torch.zeros(1, device=dev)
                 bh.g_weight, bh.g_bias = gbw.data_ptr(), gbb.data_ptr()
-        L.check(self.lib.nl_render_rays_backward_kept(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, qc.data_ptr(), d.data_ptr(), R, 1 if white else 0,
+        L.check(self.lib.nl_render_rays_backward_kept(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, _ptr(qc), _ptr(qrows), d.data_ptr(), R, 1 if white else 0,
                                                       ct.byref(c), None if bh is None else ct.byref(bh), go.data_ptr(), gd.data_ptr(), _ptr(gq),
                                                       None if train is None else ct.byref(train.c), ws.data_ptr(), ws.numel(), self._stream()),
                 "nl_render_rays_backward_kept")

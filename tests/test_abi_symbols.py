@@ -121,7 +121,7 @@ def test_train_grads_are_validated_before_anything_is_dereferenced():
     # the cotangent block of the whole-path backward: its reserved word and a half-given neighbour pair
     c = _lib.NlRenderCotangents()
     c.reserved[0] = p
-    call = lambda cc: lib.nl_render_rays_backward(ct.byref(cfg), p, p, p, p, p, p, 4, 0, ct.byref(cc), p, p, None, None, p, 4096, None)
+    call = lambda cc: lib.nl_render_rays_backward(ct.byref(cfg), p, p, p, None, p, p, p, 4, 0, ct.byref(cc), p, p, None, None, p, 4096, None)
     assert call(c) == _lib.NL_ERR_BAD_ARG
     c = _lib.NlRenderCotangents()
     c.knn_idx = p
