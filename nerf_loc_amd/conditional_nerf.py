@@ -246,6 +246,20 @@ class ConditionalNeRF(nn.Module):
         self._weights_version = -1
         return out
 
+    def _depth_range(self, data):
+        """(near, far) of data['depth_range'] as python floats.  On a device tensor that read is a synchronisation point: it is done once per tensor
+        (identity + version), not once per render call of a refinement / training loop."""
+        t = data["depth_range"]
+        if not isinstance(t, torch.Tensor):
+            return float(t[0][0]), float(t[0][1])
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        c = self.__dict__.get("_dr_cache")
+        if c is None or c[0] != key:
+            v = t[0].detach().cpu().tolist()
+            c = (key, float(v[0]), float(v[1]))
+            self.__dict__["_dr_cache"] = c
+        return c[1], c[2]
+
     def _ensure_frame(self, data, level: str) -> HipRenderer:
         """(Re)build the HIP per-frame tables when the caller reset the caches (nerf_pose_estimator.py:289-290)."""
         if self.support_neural_points is None:
@@ -253,7 +267,7 @@ class ConditionalNeRF(nn.Module):
         r = self._renderer(level)
         sp = self.support_neural_points[level]
         feat = data["feat_fine_src"] if level == "fine" else data["feat_coarse_src"]
-        near, far = [float(x) for x in data["depth_range"][0]]
+        near, far = self._depth_range(data)
         vis = self._vis_featmaps(data)   # (re)computes the cache first, so its generation is final below
         # generation counters of the two caller-reset caches + the identity of everything else the tables are built from
         token = (self._sp_gen, self.multiview_aggregator._vis_gen, data["topk_images"].data_ptr(), feat.data_ptr(),
@@ -287,7 +301,7 @@ class ConditionalNeRF(nn.Module):
 
     def _frame_dict(self, data, level: str, graph: bool):
         """`fr` of diff_render's functions for one level.  graph: per-frame caches with their graphs (training)."""
-        fnear, ffar = [float(x) for x in data["depth_range"][0]]
+        fnear, ffar = self._depth_range(data)
         sp = self.support_neural_points[level]
         if not graph:
             sp = {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")}
@@ -310,7 +324,7 @@ class ConditionalNeRF(nn.Module):
         keypoint scores — and are cached for the whole frame, so query_coarse, query_fine and compute_render_loss of one step share one
         graph (and one DepthFusionNet pass) like the reference's module caches do."""
         p = self._graph_params(True)
-        fnear, ffar = [float(x) for x in data["depth_range"][0]]
+        fnear, ffar = self._depth_range(data)
         fr = {"topk_Ks": data["topk_Ks"], "topk_poses": data["topk_poses"], "topk_images": data["topk_images"],
               "feat_fine_src": data["feat_fine_src"], "vis_featmaps": self._vis_featmaps(data, True), "near": fnear, "far": ffar}
         fine = diff_render.support_tables_diff(p, fr, data["topk_depths"], int(data["stride_fine"]))
@@ -350,7 +364,7 @@ class ConditionalNeRF(nn.Module):
         # the fine-level confidence needs the aggregator -> a frame with provisional confidence is set first
         fine = {"xyz": pts_f, "xyz_ndc": ndc_f, "feature": desc_f, "confidence": torch.ones_like(pts_f[:, :1]), "direction": dir_f}
         r = self._renderer("fine")
-        near, far = [float(x) for x in d["depth_range"][0]]
+        near, far = self._depth_range(d)
         r.set_frame(d["topk_images"], d["feat_fine_src"], self._vis_featmaps(d), d["topk_Ks"], d["topk_poses"], near, far, fine)
         fine["confidence"] = self.estimate_neural_points_confidence(pts_f, d, None)
         self.support_neural_points = {

@@ -270,6 +270,8 @@ class HipRenderer:
         per_ray = qc_t.dim() == 2
         if per_ray and tuple(qc_t.shape) != (R, 3):
             raise ValueError(f"per-ray query centres must have shape ({R}, 3), got {tuple(qc_t.shape)}")
+        if not per_ray and qc_t.is_cuda:   # one centre that lives on the device: R identical rows instead of a device-to-host copy (= a synchronisation
+            qc_t, per_ray = qc_t.reshape(1, 3).expand(R, 3), True   # point per call: 21 of them in a render_image loop)
         qc = qc_t.to(dev).contiguous() if per_ray else qc_t.cpu().contiguous()
         out = {
             "rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
