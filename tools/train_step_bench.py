@@ -52,8 +52,9 @@ for hip in (False, True):
     for _ in range(2): step(hip)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): l, gs = step(hip)
+    t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
-    res[hip] = ((time.perf_counter() - t0) / steps, torch.cuda.max_memory_allocated() / 2**30, l, gs)
+    res[hip] = ((time.perf_counter() - t0) / steps, torch.cuda.max_memory_allocated() / 2**30, l, gs, t_issue / steps)
 names = list(p.keys()) + ["feat_fine_src", "vis_featmaps", "support.feature", "support.confidence"]
 gmax = max(float(g.abs().max()) for g in res[False][3] if g is not None)
 worst = ("", 0.0)
@@ -64,7 +65,7 @@ for n, a, b in zip(names, res[True][3], res[False][3]):
     if e > worst[1]: worst = (n, e)
 print(f"{R} rays x {S} samples, W = {W}: training step (render forward + backward to all parameters) eager fp32 graph {res[False][0]*1e3:.1f} ms / "
       f"{res[False][1]:.1f} GiB; with the library's training nodes {res[True][0]*1e3:.1f} ms / {res[True][1]:.1f} GiB; "
-      f"loss {float(res[False][2]):.6f} vs {float(res[True][2]):.6f}; largest per-tensor gradient difference {worst[1]:.2e} ({worst[0]})")
+      f"(CPU issue time {res[True][4]*1e3:.1f} ms); loss {float(res[False][2]):.6f} vs {float(res[True][2]):.6f}; largest per-tensor gradient difference {worst[1]:.2e} ({worst[0]})")
 if os.environ.get("PROFILE"):
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
