@@ -133,6 +133,8 @@ def _same_state(ctx):
 # RenderFn keeps the staged forward's activations for the backward call when they fit this many bytes (one chunk: ~90 KB per sample at W = 256, i.e. a
 # PoseOptimizer or training batch); 0 = never (fused forward + recompute)
 KEEP_BYTES = 12 << 30
+# ... and replays the pair as HIP graphs from the second step of a shape against one frame on (frozen weights; renderer.GraphedKeep)
+USE_GRAPHS = True
 
 
 class RenderFn(torch.autograd.Function):
@@ -159,6 +161,17 @@ class RenderFn(torch.autograd.Function):
             ctx.save_for_backward(o, d, qc, z)
             ctx.mark_non_differentiable(out["mask"])
             return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"], out["beta"]
+        # frozen weights, a shape this frame has seen before (a refinement loop): the pair replayed as two HIP graphs
+        ctx.graph = None
+        if not train and USE_GRAPHS and KEEP_BYTES and qc.is_cuda:
+            gk = renderer.graphed_keep(o.shape[0], bool(white_bkgd), max_bytes=KEEP_BYTES)
+            lease = gk.acquire() if gk is not None else None
+            if lease is not None:
+                out = gk.forward(o, d, z, qc.detach().float())
+                ctx.graph, ctx.lease = gk, lease
+                ctx.save_for_backward(o, d, qc, z)
+                ctx.mark_non_differentiable(out["mask"])
+                return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
         # small batches (a PoseOptimizer / training step): the staged forward whose activations the backward call reuses, when they fit KEEP_BYTES
         kept = renderer.render_rays_keep(o, d, z, qc, white_bkgd=bool(white_bkgd), train=train, max_bytes=KEEP_BYTES) if KEEP_BYTES else None
         if kept is not None:
@@ -185,6 +198,10 @@ class RenderFn(torch.autograd.Function):
             tg = ctx.r.train_grads(names, support_feature=need[8], feat_maps=need[6], vis_featmaps=need[7],
                                    blend_feat_maps=need[6] or "rgb_blending_mlp.0.weight" in names)
         gbeta_w = gbeta_b = None
+        if getattr(ctx, "graph", None) is not None:   # (between this node's forward and backward the graphs' static buffers were not touched: one step at a time)
+            go, gd, gq = ctx.graph.backward(g_rgb, g_depth, g_unc, g_feat, g_wts)
+            ctx.graph = ctx.lease = None
+            return (go if need[0] else None, gd if need[1] else None, gq.to(qc.dtype) if need[2] else None, None, None, None, None, None, None)
         if ctx.kept is not None and ctx.has_beta:
             go, gd, gq, (gbeta_w, gbeta_b) = ctx.r.render_rays_backward_kept(ctx.kept, g_rgb, g_depth, g_unc, g_feat, g_wts, want_g_query_center=need[2], train=tg,
                                                                             g_beta=g_beta, want_beta_grads=True)

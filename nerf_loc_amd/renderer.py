@@ -24,6 +24,84 @@ def _dev_f32(t, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+class GraphedKeep:
+    """The keep / kept pair of ONE batch shape against ONE frame and weight set as two HIP graphs (torch.cuda.CUDAGraph around the library calls): a pose
+    refinement loop (pose_optimizer.py:131-168: ~50 steps of 512 rays against one frame) otherwise re-issues ~130 launches per step, which is what
+    its wall time follows once the host's cores are busy.  Inputs are copied into static buffers, the graph is replayed, results are cloned out;
+    frozen weights only (a training step meets a new frame — new camera kernel arguments — every time)."""
+
+    def __init__(self, r: "HipRenderer", R: int, white: bool):
+        dev, S, C = r.device, r.S, r.C
+        self.r, self.R, self.white, self.gen = r, int(R), bool(white), r.state_gen
+        e = lambda *shp: torch.zeros(*shp, device=dev)
+        self.o, self.d, self.z, self.q = e(R, 3), e(R, 3), e(R, S), e(R, 3)
+        self.out = {"rgb": e(R, 3), "depth": e(R), "weights": e(R, S), "mask": torch.zeros(R, dtype=torch.uint8, device=dev), "depth_uncertainty": e(R), "feat": e(R, C)}
+        self.cot = {"g_rgb": e(R, 3), "g_depth": e(R), "g_depth_uncertainty": e(R), "g_feat": e(R, C), "g_weights": e(R, S)}
+        self.go, self.gd, self.gq = e(R, 3), e(R, 3), e(R, 3)
+        need = r.lib.nl_render_rays_keep_workspace_bytes(ct.byref(r.cfg), r.V, R, 0)
+        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.ro = L.NlRenderOut()
+        for k, t in self.out.items():
+            setattr(self.ro, k, t.data_ptr())
+        self.c = L.NlRenderCotangents()
+        self.c.g_rgb, self.c.g_depth, self.c.g_depth_uncertainty, self.c.g_feat, self.c.g_weights = [self.cot[k].data_ptr() for k in
+                                                                                                      ("g_rgb", "g_depth", "g_depth_uncertainty", "g_feat", "g_weights")]
+        self.fwd = self.bwd = None
+        self.stream = torch.cuda.Stream(device=dev)
+        self._pool = {"busy": False}   # the static buffers serve ONE forward / backward pair at a time
+
+    def acquire(self):
+        """A lease on the static buffers (released when dropped), or None while another forward's backward is still pending."""
+        if self._pool["busy"]:
+            return None
+        self._pool["busy"] = True
+        return _Lease(self._pool)
+
+    def _fwd_call(self):
+        r = self.r
+        L.check(r.lib.nl_render_rays_forward_keep(ct.byref(r.cfg), r.packed.data_ptr(), r._frame, None, self.q.data_ptr(), self.o.data_ptr(), self.d.data_ptr(),
+                                                  self.z.data_ptr(), self.R, 1 if self.white else 0, ct.byref(self.ro), None, 0, self.ws.data_ptr(), self.ws.numel(),
+                                                  r._stream()), "nl_render_rays_forward_keep")
+
+    def _bwd_call(self):
+        r = self.r
+        L.check(r.lib.nl_render_rays_backward_kept(ct.byref(r.cfg), r.packed.data_ptr(), r._frame, None, self.q.data_ptr(), self.d.data_ptr(), self.R,
+                                                   1 if self.white else 0, ct.byref(self.c), None, self.go.data_ptr(), self.gd.data_ptr(), self.gq.data_ptr(), None,
+                                                   self.ws.data_ptr(), self.ws.numel(), r._stream()), "nl_render_rays_backward_kept")
+
+    def _run(self, which):
+        g = getattr(self, which)
+        if g is None:   # first use: capture on a side stream (the library only enqueues kernels / async copies on the stream it is given)
+            call = self._fwd_call if which == "fwd" else self._bwd_call
+            cur = torch.cuda.current_stream(self.r.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                if which == "fwd":
+                    call()                              # warm (per-frame tables that are built on first use).  NOT for the way back: it consumes the
+                g = torch.cuda.CUDAGraph()              # kept activations (buffers are reused), so it must run exactly once per forward — the replay
+                with torch.cuda.graph(g, stream=self.stream):
+                    call()
+            cur.wait_stream(self.stream)
+            setattr(self, which, g)
+        g.replay()
+
+    def forward(self, o, d, z, q):
+        self.o.copy_(o); self.d.copy_(d); self.z.copy_(z); self.q.copy_(q.reshape(-1, 3).expand(self.R, 3))
+        self._run("fwd")
+        out = {k: v.clone() for k, v in self.out.items()}
+        out["mask"] = out["mask"].view(torch.bool)
+        return out
+
+    def backward(self, g_rgb=None, g_depth=None, g_depth_uncertainty=None, g_feat=None, g_weights=None):
+        for k, v in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_depth_uncertainty", g_depth_uncertainty), ("g_feat", g_feat), ("g_weights", g_weights)):
+            if v is None:
+                self.cot[k].zero_()
+            else:
+                self.cot[k].copy_(v)
+        self._run("bwd")
+        return self.go.clone(), self.gd.clone(), self.gq.sum(0)
+
+
 class _Lease:
     """Marks a renderer's pooled keep-workspace as free again when the state that borrowed it is dropped (after the backward call, or never used)."""
 
@@ -464,6 +542,27 @@ class HipRenderer:
                 "nl_render_rays_backward_kept")
         res = (go, gd, (None if gq is None else gq.sum(0)))
         return res + ((gbw, gbb),) if want_beta_grads else res
+
+    def graphed_keep(self, R: int, white_bkgd: bool = False, max_bytes: Optional[int] = None):
+        """The GraphedKeep of this batch shape for the CURRENT frame / weights: None on the first request of a shape (the caller runs that step
+        ungraphed: it may be the only one), the graphs from the second request on; dropped when the frame or the weights change."""
+        self._ready()
+        if getattr(self, "guard_bytes", 0):
+            return None
+        reg = self.__dict__.setdefault("_graphs", {})
+        if reg.get("gen") != self.state_gen:
+            reg.clear()
+            reg["gen"] = self.state_gen
+        key = (int(R), bool(white_bkgd))
+        ent = reg.get(key)
+        if ent is None:
+            reg[key] = "seen"
+            return None
+        if ent == "seen":
+            if max_bytes is not None and self.lib.nl_render_rays_keep_workspace_bytes(ct.byref(self.cfg), self.V, int(R), 0) > max_bytes:
+                return None
+            ent = reg[key] = GraphedKeep(self, R, white_bkgd)
+        return ent
 
     def ray_unet_backward(self, x, g_geo, workspace_rays: Optional[int] = None, train: "TrainGrads" = None):
         """Input gradient of `ray_unet` (nl_ray_unet_backward): x, g_geo (R*S, W) -> g_x (R*S, W).  train: also ADD the gradients of the 28 U-Net tensors

@@ -594,3 +594,53 @@ def _guarded_calls(r, c, cfg, frame, rays, dev):
         tg = r.train_grads(names, support_feature=True, feat_maps=True, vis_featmaps=True, blend_feat_maps=True) if train else None
         r.render_rays_backward_kept(state, g_rgb=rnd(R, 3), g_feat=rnd(R, cfg.C), train=tg); calls += r.check_guards()
     assert calls >= 15 and r.gaps_checked > 300   # (guarded workspaces / gap regions between their buffers checked)
+
+
+@pytest.mark.gpu
+def test_graphed_refinement_steps_equal_the_ungraphed_ones():
+    """RenderFn replays the keep / kept pair of a repeated batch shape as two HIP graphs (renderer.GraphedKeep) from the second step against one frame on:
+    the same outputs and gradients, bit for bit, as the ungraphed pair — over steps with different rays and cotangents, and dropped when the frame changes."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case("c1")
+    cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "bf16x3")
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    setf = lambda: r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far,
+                               frame["support_fine"])
+    setf()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R = 24
+    lin = torch.linspace(0, 1, cfg.S_total, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, cfg.S_total).contiguous()
+    p = {k: t(v) for k, v in c["weights"].items()}
+    fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
+    fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}})
+    g = torch.Generator().manual_seed(51)
+
+    def step(i, graphs):
+        dr.USE_GRAPHS = graphs
+        o = t(rays["rays_o"][i * R:(i + 1) * R]).clone().requires_grad_(True)
+        d = t(rays["rays_d"][i * R:(i + 1) * R]).clone().requires_grad_(True)
+        pose = t(frame["pose"]).clone().requires_grad_(True)
+        out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], frozen_renderer=r)
+        cf, cr = torch.randn(R, cfg.C, generator=torch.Generator().manual_seed(100 + i)).to(dev), torch.randn(R, 3, generator=torch.Generator().manual_seed(200 + i)).to(dev)
+        loss = (out["feat"] * cf).sum() + (out["rgb"] * cr).sum() + out["depth"].sum()
+        gs = torch.autograd.grad(loss, [o, d, pose])
+        return [out[k].detach().clone() for k in ("rgb", "feat", "depth", "weights", "mask")] + [x.clone() for x in gs]
+    try:
+        ref = [step(i, False) for i in range(4)]
+        got = [step(i, True) for i in range(4)]      # step 0: first sight of the shape (ungraphed), steps 1..3: capture + replays
+        assert r._graphs[(R, False)].fwd is not None and r._graphs[(R, False)].bwd is not None, "the graphs were captured"
+        names = ("rgb", "feat", "depth", "weights", "mask", "g_o", "g_d", "g_pose")
+        for i, (a, b) in enumerate(zip(ref, got)):
+            for nm, x, y in zip(names, a, b):
+                assert torch.equal(x, y), (i, nm, float((x.float() - y.float()).abs().max()), float(x.float().abs().max()))
+        setf()                                        # a new frame: the graphs of the old one are dropped
+        again = step(1, True)
+        assert (R, False) in r._graphs and r._graphs[(R, False)] == "seen"
+        for x, y in zip(ref[1], again):
+            assert torch.equal(x, y)
+    finally:
+        dr.USE_GRAPHS = True

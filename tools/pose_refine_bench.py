@@ -40,10 +40,11 @@ for frozen in (False, True):   # False: everything eager (round 2); True: the wh
     for _ in range(2): step(frozen)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): g = step(frozen)
+    t_issue = (time.perf_counter() - t0) / steps
     torch.cuda.synchronize()
-    res[frozen] = ((time.perf_counter() - t0) / steps, torch.cuda.max_memory_allocated() / 2**30, g.clone())
+    res[frozen] = ((time.perf_counter() - t0) / steps, torch.cuda.max_memory_allocated() / 2**30, g.clone(), t_issue)
 dt = res[False][0]
-print(f"{R} rays x {cfg.S} samples: gradient step through the library (RenderFn: nl_render_rays_forward_keep / nl_render_rays_backward_kept) {res[True][0]*1e3:.1f} ms, peak memory {res[True][1]:.1f} GiB; "
+print(f"{R} rays x {cfg.S} samples: gradient step through the library (RenderFn: nl_render_rays_forward_keep / nl_render_rays_backward_kept) {res[True][0]*1e3:.1f} ms (CPU issue time {res[True][3]*1e3:.1f} ms: the pair is replayed as two HIP graphs), peak memory {res[True][1]:.1f} GiB; "
       f"relative difference of dL/dpose to the eager graph {float((res[True][2] - res[False][2]).abs().max() / res[False][2].abs().max()):.2e}")
 with torch.no_grad():
     o, d = dr.rays_from_pose(uv, K, pose)
