@@ -561,6 +561,10 @@ class HipRenderer:
         if ent == "seen":
             if max_bytes is not None and self.lib.nl_render_rays_keep_workspace_bytes(ct.byref(self.cfg), self.V, int(R), 0) > max_bytes:
                 return None
+            # (every captured shape owns its static workspace — gigabytes: at most two live, the older one makes room)
+            live = [k for k, v in reg.items() if isinstance(v, GraphedKeep)]
+            for k in live[:-1]:
+                reg[k] = "seen"
             ent = reg[key] = GraphedKeep(self, R, white_bkgd)
         return ent
 
