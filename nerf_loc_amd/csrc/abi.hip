@@ -76,8 +76,10 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
                                const float* g_ang, float* g_xyz, float* g_qc, float* g_vis, float* g_dd, float* sc_feat, float* sc_pfeat, const float* stats,
                                hipStream_t st);
 int nl_dec_train_row(void);
+size_t nl_dec_wpart_floats(void);
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
-                           const float* g_dd, float* part, float* g_xyz, float* tr, float* sc_vis, hipStream_t st);
+                           const float* g_dd, float* part, float* g_xyz, float* tr, float* const* decw, float* scratch, size_t scratch_floats, float* sc_vis,
+                           hipStream_t st);
 int nl_launch_blend_backward(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4,
                              const float* b4, const float* blw, const float* g_rgb_s, float* g_hA, float* g_pf, float* g_rgbv, float* g_ang, float* tr,
                              hipStream_t st);
@@ -933,7 +935,7 @@ void carve_mvb(Bump& b, const nl_config* c, int V, int64_t N, bool blend, MvBwdB
   }
   m.dtr = m.btr = m.ang = nullptr;
   if (train) {
-    m.dtr = b.take<float>((size_t)V * N * nl_dec_train_row());
+    if (c->precision == NL_PREC_F32) m.dtr = b.take<float>((size_t)V * N * nl_dec_train_row());   // (the MFMA decoder backward needs no rows)
     if (blend) { m.btr = b.take<float>((size_t)V * N * 68); m.ang = b.take<float>((size_t)V * N * 8 + 256); }
   }
 }
@@ -990,9 +992,11 @@ int mv_geom_dec_backward(const Ctx& x32, const nl_frame* f, const NlViews& vw, c
                                     blend ? m.gpf : nullptr, blend ? m.grgbv : nullptr, blend ? m.gang : nullptr, g_xyz, g_qc, m.gvis, m.gdd,
                                     tg ? tg->feat_maps : nullptr, tg && blend ? tg->pfeat_maps : nullptr, gg393 ? m.g393 : nullptr, x32.st));
   const bool decw = tg && tg->any(T_DEC, T_DEC + 24);
-  NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), x32.c->precision == NL_PREC_F32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N,
-                                m.gvis, m.gdd, m.gpart, g_xyz, decw ? m.dtr : nullptr, tg ? tg->vis_maps : nullptr, x32.st));
-  return decw ? dec_wgrads(tg, x32.st, m.dtr, (int64_t)vw.V * N) : NL_OK;
+  const bool f32 = x32.c->precision == NL_PREC_F32;   // fp32: rows for dec_wgrads; otherwise the MFMA kernel accumulates the 24 tensors' gradients itself
+  NL_TRY(nl_launch_dec_backward(vw, f->visf_hwc, x32.p<float>(x32.L.dec_w), f32 ? nullptr : x32.p<char>(x32.L.dec_mfma), xyz, N, m.gvis, m.gdd, m.gpart, g_xyz,
+                                decw && f32 ? m.dtr : nullptr, decw && !f32 ? tg->w + T_DEC : nullptr, tg ? tg->scratch : nullptr, tg ? tg->scratch_floats : 0,
+                                tg ? tg->vis_maps : nullptr, x32.st));
+  return decw && f32 ? dec_wgrads(tg, x32.st, m.dtr, (int64_t)vw.V * N) : NL_OK;
 }
 int do_mv_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* xyz, int64_t N, const float* gG, float* g_xyz, const MvBwdBufs& m,
                    const TrainOut* tg = nullptr) {
@@ -1798,6 +1802,7 @@ size_t nl_train_scratch_bytes(const nl_config* cfg) {
   size_t fl = nl_wgrad_scratch_floats(0, 1, (int)(mx + 256));
   const size_t ln = (size_t)258 * 2 * cfg->S * (cfg->W > 64 ? cfg->W : 64);   // the U-Net's LayerNorm tables: 2 S max(W, 64) sums + up to 256 partial rows of them
   if (ln > fl) fl = ln;
+  if (nl_dec_wpart_floats() > fl) fl = nl_dec_wpart_floats();   // the decoder backward's per-wave partial sets
   return sizeof(float) * fl;
 }
 size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t N) {

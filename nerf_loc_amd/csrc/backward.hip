@@ -1084,10 +1084,55 @@ __global__ __launch_bounds__(256) void dec_backward_kernel(const NlViews vw, con
 // one's two hidden layers in registers (16 + 16 per lane), and multiplies back through the TRANSPOSED weights (bf16 hi / lo fragments packed with K in
 // accumulator order, mvdec.h MVD_T; split-bf16: the incoming gradient's scale is arbitrary, fp16's range is not) into ONE accumulator whose register r
 // holds d/d(channel this lane tapped into register r).  48 + 4 x 24 MFMAs per 32 rows instead of ~40 k FMAs per row.
+//
+// TRAIN: the 24 decoder tensors' gradients in the same pass.  gW = dA^T H contracts over the tile's ROWS, which live in the lanes; both operands are
+// turned lane <-> register on the matrix pipe itself: D = S . P with S = the lane's own 16 values as the A operand (bf16 hi and lo planes separately: the
+// products with 1.0 are exact, so D holds the plane transposed bit for bit) and P a constant 0 / 1 fragment that maps k-slot (s, hh, t) to the feature it
+// carries.  D's lane = feature, its registers = the 32 rows in accumulator order — the same order for every operand, which is all a contraction needs.
+// 4 MFMAs per transposed 32 x 32 operand + 6 per product (split-bf16, as wgrad.hip), accumulated over the wave's tiles in 9 x 16 registers (W1, W2 of the
+// four decoders + one tile whose rows 2 d, 2 d + 1 are decoder d's output layer); biases = the transposed gradient's in-lane sums.  A wave leaves ONE
+// partial set (DEC_WP floats) behind; dec_wpart_reduce_kernel adds them in a fixed order.  Before: a 560-float row per (view, sample) through HBM (1.5 GB
+// per 65 k samples, written a dword per lane and row), a memset of it and 24 small launches.
+constexpr int DEC_WP = 9 * 1024 + 9 * 64;   // per wave: [k 9][lane 64][r 16] accumulators + [k 9][lane 64] bias partials (k: W1 d 0..3, W2 d 4..7, output layers 8)
+struct DecTrFrag { mvd_bf16x8 h[2], l[2]; };
+// lane <-> register turn of one 32 (rows) x 32 (features) operand; sh / sl = the lane's 16 values as bf16 hi / lo in register order; rowsum += the feature's
+// sum over this half's 16 rows
+template <int STEPS>
+__device__ __forceinline__ void dec_turn(const mvd_bf16x8 (&sh)[2], const mvd_bf16x8 (&sl)[2], const mvd_bf16x8 (&pm)[2], DecTrFrag& o, float* rowsum) {
+  mvd_f32x16 dh, dl;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dh[r] = 0.f; dl[r] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    dh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[s], pm[s], dh, 0, 0, 0);
+    dl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[s], pm[s], dl, 0, 0, 0);
+  }
+  if (rowsum) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += dh[r] + dl[r];
+    *rowsum += a;
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { o.h[s][t] = (__bf16)dh[8 * s + t]; o.l[s][t] = (__bf16)dl[8 * s + t]; }
+}
+// acc[lane = b's feature][register ~ a's feature] += sum over the 32 rows a . b
+__device__ __forceinline__ void dec_wacc(mvd_f32x16& acc, const DecTrFrag& a, const DecTrFrag& b) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s], b.h[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s], b.l[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s], b.h[s], acc, 0, 0, 0);
+  }
+}
+template <bool TRAIN>
 __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw, const float* __restrict__ visf, const uint4* __restrict__ dpack,
                                                                 const float* __restrict__ xyz, int N, int tiles_per_view, int total_tiles,
                                                                 const float* __restrict__ g_vis, const float* __restrict__ g_dd,
-                                                                float* __restrict__ part, float* __restrict__ tr, float* __restrict__ sc_vis) {
+                                                                float* __restrict__ part, float* __restrict__ wpart /* TRAIN: [wave][DEC_WP] */,
+                                                                float* __restrict__ sc_vis) {
   __shared__ uint4 sw[MVD_LDS_UINT4 + 2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, j = lane & 31;
@@ -1099,6 +1144,26 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
   const float* b1 = sf, *b2 = sf + 128, *w4p = sf + 256;
   typedef MvdOps<true> OP;
   const float ni = -1.f / vw.near_, fi = -1.f / vw.far_, span = vw.far_ - vw.near_;
+  // TRAIN: k-slot (s, hh, t) -> feature maps (identity for the tap's channels, accumulator order for hidden units / their gradients), weight-gradient accumulators
+  mvd_bf16x8 pmI[2], pmU[2];
+  mvd_f32x16 wacc[TRAIN ? 9 : 1];
+  float bsum[TRAIN ? 9 : 1];
+  if constexpr (TRAIN) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int r = 8 * s + t;
+        pmI[s][t] = (__bf16)((16 * s + 8 * hh + t == j) ? 1.f : 0.f);
+        pmU[s][t] = (__bf16)(((r & 3) + 8 * (r >> 2) + 4 * hh == j) ? 1.f : 0.f);
+      }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      bsum[k] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wacc[k][r] = 0.f;
+    }
+  }
   for (int tile = blockIdx.x * 4 + wave; tile < total_tiles; tile += gridDim.x * 4) {
     const int v = __builtin_amdgcn_readfirstlane(tile / tiles_per_view);
     const int n = (tile - v * tiles_per_view) * 32 + j;
@@ -1107,7 +1172,7 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     float* po = part + ((size_t)v * N + nn) * 3;
     const float gv = live ? g_vis[(size_t)v * N + nn] : 0.f, gd = live ? g_dd[(size_t)v * N + nn] : 0.f;
     if (__ballot(gv != 0.f || gd != 0.f) == 0ull) {
-      if (live && hh == 0) { po[0] = 0.f; po[1] = 0.f; po[2] = 0.f; }
+      if (!TRAIN && live && hh == 0) { po[0] = 0.f; po[1] = 0.f; po[2] = 0.f; }
       continue;
     }
     const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
@@ -1180,11 +1245,12 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     OP::v8 xh[2], xl[2];
     OP::split(x0, xh[0], xl[0]);
     OP::split(x1, xh[1], xl[1]);
-    // training rows: register r of half hh = unit / channel (r & 3) + 8 (r >> 2) + 4 hh (accumulators), 8 hh + t | 16 + 8 hh + t (the tap)
-    float* trr = tr && live ? tr + ((size_t)v * N + nn) * DEC_TR_ROW : nullptr;
-    if (trr) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { trr[8 * hh + t] = x0[t]; trr[16 + 8 * hh + t] = x1[t]; }
+    DecTrFrag tx;   // TRAIN: the tap, lane = channel, k = rows
+    if constexpr (TRAIN) {
+      mvd_bf16x8 sh[2], sl[2];
+      mvd_split_bf16(x0, sh[0], sl[0]);
+      mvd_split_bf16(x1, sh[1], sl[1]);
+      dec_turn<2>(sh, sl, pmI, tx, nullptr);
     }
     mvd_f32x16 gxa;
 #pragma unroll
@@ -1203,11 +1269,21 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
 #pragma unroll
       for (int r = 0; r < 16; ++r) h1[r] = nl_elu_fast(acc[r]);
       OP::v8 gh[2], gl[2];
+      DecTrFrag th1, th2;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) vv[t] = h1[8 * s2 + t];
         OP::split(vv, gh[s2], gl[s2]); }
+      if constexpr (TRAIN) {
+        mvd_bf16x8 sh[2], sl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) vv[t] = h1[8 * s2 + t];
+          mvd_split_bf16(vv, sh[s2], sl[s2]); }
+        dec_turn<2>(sh, sl, pmU, th1, nullptr);
+      }
       mvd_f32x16 acc2;
 #pragma unroll
       for (int g = 0; g < 4; ++g) { const float4 b = *(const float4*)(b2 + 32 * d + 8 * g + 4 * hh); acc2[4 * g] = b.x; acc2[4 * g + 1] = b.y; acc2[4 * g + 2] = b.z; acc2[4 * g + 3] = b.w; }
@@ -1217,21 +1293,44 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
         acc2 = OP::mfma(al, gh[s2], acc2); acc2 = OP::mfma(ah, gl[s2], acc2); acc2 = OP::mfma(ah, gh[s2], acc2);
       }
       // d/d(hidden 2 pre-activation): output weights (this half's 16 units) x ELU'
-      float ga[16];
+      float ga[16], h2v[TRAIN ? 16 : 1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float h2 = nl_elu_fast(acc2[r]);
         const float g2 = go[d][0] * w4p[((d * 2 + 0) * 2 + hh) * 16 + r] + go[d][1] * w4p[((d * 2 + 1) * 2 + hh) * 16 + r];
         ga[r] = g2 * (h2 > 0.f ? 1.f : h2 + 1.f);
-        if (trr) { float* q = trr + 32 + d * DEC_TR_D + (r & 3) + 8 * (r >> 2) + 4 * hh; q[0] = h1[r]; q[32] = h2; q[96] = ga[r]; }
+        if constexpr (TRAIN) h2v[r] = h2;
       }
-      if (trr && hh == 0) { trr[32 + d * DEC_TR_D + 128] = go[d][0]; trr[32 + d * DEC_TR_D + 129] = go[d][1]; }
+      if constexpr (TRAIN) {   // output layer: rows 2 d, 2 d + 1 of the ninth tile = d(out 0), d(out 1) x hidden 2
+        mvd_bf16x8 sh[2], sl[2], pg[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) vv[t] = h2v[8 * s2 + t];
+          mvd_split_bf16(vv, sh[s2], sl[s2]); }
+        dec_turn<2>(sh, sl, pmU, th2, nullptr);
+        float gv8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) gv8[t] = (hh == 0 && t < 2) ? go[d][t] : 0.f;
+        mvd_split_bf16(gv8, sh[0], sl[0]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pg[0][t] = (__bf16)((hh == 0 && t < 2 && j == 2 * d + t) ? 1.f : 0.f);
+        pg[1] = pg[0];   // (unused: one k-step)
+        DecTrFrag tgo;
+        dec_turn<1>(sh, sl, pg, tgo, &bsum[8]);
+        dec_wacc(wacc[8], tgo, th2);
+      }
       mvd_bf16x8 bh[2], bl[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) { float vv[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) vv[t] = ga[8 * s2 + t];
         mvd_split_bf16(vv, bh[s2], bl[s2]); }
+      if constexpr (TRAIN) {
+        DecTrFrag tda;
+        dec_turn<2>(bh, bl, pmU, tda, &bsum[4 + d]);
+        dec_wacc(wacc[4 + d], tda, th1);
+      }
       mvd_f32x16 accb;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accb[r] = 0.f;
@@ -1247,9 +1346,14 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const int r = 8 * s2 + t; vv[t] = accb[r] * (h1[r] > 0.f ? 1.f : h1[r] + 1.f);
-          if (trr) trr[32 + d * DEC_TR_D + 64 + (r & 3) + 8 * (r >> 2) + 4 * hh] = vv[t];
         }
         mvd_split_bf16(vv, bh[s2], bl[s2]); }
+      if constexpr (TRAIN) {
+        DecTrFrag tda;
+        dec_turn<2>(bh, bl, pmU, tda, &bsum[d]);
+        dec_wacc(wacc[d], tda, tx);
+      }
+      if constexpr (!TRAIN)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const mvd_bf16x8 ah = __builtin_bit_cast(mvd_bf16x8, swt[1024 + (d * 2 + s2) * 64 + lane]), al = __builtin_bit_cast(mvd_bf16x8, swt[1024 + 512 + (d * 2 + s2) * 64 + lane]);
@@ -1258,6 +1362,7 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
         gxa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s2], gxa, 0, 0, 0);
       }
     }
+    if constexpr (TRAIN) continue;   // the weight-gradient pass ends here: input gradients and the map's scatter-add are the other instantiation's
     float gix = 0.f, giy = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { gix = fmaf(gxa[r], dx[r], gix); giy = fmaf(gxa[r], dy[r], giy); }
@@ -1284,6 +1389,54 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
     if (bad) gde = 0.f;
     if (live && hh == 0) {
       po[0] = P[0] * gcx + P[4] * gcy + P[8] * gde; po[1] = P[1] * gcx + P[5] * gcy + P[9] * gde; po[2] = P[2] * gcx + P[6] * gcy + P[10] * gde;
+    }
+  }
+  if constexpr (TRAIN) {
+    float* wp = wpart + (size_t)(blockIdx.x * 4 + wave) * DEC_WP;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(float4*)(wp + ((size_t)k * 64 + lane) * 16 + 4 * q) = make_float4(wacc[k][4 * q], wacc[k][4 * q + 1], wacc[k][4 * q + 2], wacc[k][4 * q + 3]);
+      wp[9 * 1024 + k * 64 + lane] = bsum[k];
+    }
+  }
+}
+
+// tensors T_DEC + 6 d + {0: W1 (32,32), 1: b1, 2: W2 (32,32), 3: b2, 4: W3 (2|1, 32), 5: b3} += the waves' partial sets, in a fixed order (8 interleaved
+// slices of the waves per element, combined as a tree).  Block = 32 source elements x 8 slices.
+struct DecGradPtrs { float* t[24]; };
+__global__ __launch_bounds__(256) void dec_wpart_reduce_kernel(const float* __restrict__ wpart, int nwaves, const DecGradPtrs p) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, zz = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;   // [0, 9 * 1024): accumulators; [9 * 1024, 9 * 1024 + 9 * 32): biases (both halves of a lane pair)
+  float s = 0.f;
+  if (e < 9 * 1024) {
+    for (int w = zz; w < nwaves; w += 8) s += wpart[(size_t)w * DEC_WP + e];
+  } else if (e < 9 * 1024 + 9 * 32) {
+    const int k = (e - 9 * 1024) >> 5, n = (e - 9 * 1024) & 31;
+    for (int w = zz; w < nwaves; w += 8) s += wpart[(size_t)w * DEC_WP + 9 * 1024 + k * 64 + n] + wpart[(size_t)w * DEC_WP + 9 * 1024 + k * 64 + 32 + n];
+  }
+  red[zz][el] = s;
+  __syncthreads();
+  if (zz != 0 || e >= 9 * 1024 + 9 * 32) return;
+  const float v = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+  if (e < 9 * 1024) {
+    const int k = e >> 10, lane = (e >> 4) & 63, r = e & 15;
+    const int n = lane & 31, m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (k < 8) { float* o = p.t[6 * (k & 3) + (k < 4 ? 0 : 2)]; if (o) o[m * 32 + n] += v; }
+    else if (m < 8) {
+      const int d = m >> 1, oo = m & 1;
+      float* o = p.t[6 * d + 4];
+      if (o && (d < 2 || oo == 0)) o[oo * 32 + n] += v;
+    }
+  } else {
+    const int k = (e - 9 * 1024) >> 5, n = (e - 9 * 1024) & 31;
+    if (k < 8) { float* o = p.t[6 * (k & 3) + (k < 4 ? 1 : 3)]; if (o) o[n] += v; }
+    else if (n < 8) {
+      const int d = n >> 1, oo = n & 1;
+      float* o = p.t[6 * d + 5];
+      if (o && (d < 2 || oo == 0)) o[oo] += v;
     }
   }
 }
@@ -1443,15 +1596,31 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
 }
 
 int nl_dec_train_row(void) { return DEC_TR_ROW; }
+// decw: the 24 decoder tensors' gradient pointers (T_DEC order; entries may be null) or null.  fp32 mode emits the rows `tr` for abi.hip's dec_wgrads; the MFMA
+// kernel accumulates the weight gradients itself (one partial set per wave in `scratch`, >= nl_dec_wpart_floats() floats) and adds them here.
+size_t nl_dec_wpart_floats(void) { return (size_t)1024 * DEC_WP; }
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
-                           const float* g_dd, float* part /*(V,N,3) scratch*/, float* g_xyz, float* tr, float* sc_vis, hipStream_t st) {
+                           const float* g_dd, float* part /*(V,N,3) scratch*/, float* g_xyz, float* tr, float* const* decw, float* scratch, size_t scratch_floats,
+                           float* sc_vis, hipStream_t st) {
   if (N <= 0) return NL_OK;
-  if (tr) NL_CHECK_HIP(hipMemsetAsync(tr, 0, sizeof(float) * (size_t)vw.V * N * DEC_TR_ROW, st));   // rows without a gradient are skipped by the kernels
   if (dpack) {   // non-fp32 modes: the decoders on the matrix pipe
     const int tpv = (int)nl_cdiv(N, 32), total = tpv * vw.V;
-    const int blocks = (int)(nl_cdiv(total, 4) < 2048 ? nl_cdiv(total, 4) : 2048);
-    hipLaunchKernelGGL(dec_backward_mfma_kernel, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, g_vis, g_dd, part, tr, sc_vis);
+    if (decw) {
+      const int blocks = (int)(nl_cdiv(total, 4) < 256 ? nl_cdiv(total, 4) : 256);   // one workgroup per CU is all that is resident (276+ registers)
+      if (!scratch || scratch_floats < (size_t)blocks * 4 * DEC_WP) return NL_ERR_WORKSPACE;
+      hipLaunchKernelGGL(dec_backward_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, g_vis, g_dd, part,
+                         scratch, nullptr);
+      DecGradPtrs gp;
+      for (int i = 0; i < 24; ++i) gp.t[i] = decw[i];
+      hipLaunchKernelGGL(dec_wpart_reduce_kernel, dim3((unsigned)nl_cdiv(9 * 1024 + 9 * 32, 32)), dim3(256), 0, st, scratch, blocks * 4, gp);
+    }
+    {
+      const int blocks = (int)(nl_cdiv(total, 4) < 2048 ? nl_cdiv(total, 4) : 2048);
+      hipLaunchKernelGGL(dec_backward_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, g_vis, g_dd, part,
+                         nullptr, sc_vis);
+    }
   } else {
+    if (tr) NL_CHECK_HIP(hipMemsetAsync(tr, 0, sizeof(float) * (size_t)vw.V * N * DEC_TR_ROW, st));   // rows without a gradient are skipped by the kernel
     dim3 grid((unsigned)nl_cdiv(N, 256), (unsigned)vw.V);
     hipLaunchKernelGGL(dec_backward_kernel, grid, dim3(256), 0, st, vw, visf_hwc, dec_w, xyz, (int)N, g_vis, g_dd, part, tr, sc_vis);
   }
