@@ -534,15 +534,42 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
   }
 }
 
-// training: gradient of the gathered support features (knn_gather's backward, knn_utils.py:211-233 = index_add): one wave per (sample, neighbour) row
+// training: gradient of the gathered support features (knn_gather's backward, knn_utils.py:211-233 = index_add).  A wave takes 64 consecutive (sample,
+// neighbour) rows = 8 consecutive samples of a ray, whose neighbour sets overlap almost completely: the rows are grouped by support point with ballots
+// (wave-uniform), every group's rows are summed with lanes = channels, and ONE atomic per (point, channel) goes out — ~14 points per 64 rows instead of 64
+// rows, and no two waves of a ray hammering the same line back to back (0.81 -> 0.35 ms per training step).
 __global__ __launch_bounds__(256) void sp_feat_scatter_kernel(const float* __restrict__ gXF, int ld, int F, const int* __restrict__ idx, long long NK, int K, int M,
                                                               float* __restrict__ g_sp_feat) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= NK) return;
-  if ((int)(row % K) >= M) return;   // zero-filled neighbour
-  const int i = idx[row];
-  for (int c = lane; c < F; c += 64) atomicAdd(g_sp_feat + (size_t)i * F + c, gXF[(size_t)row * ld + c]);
+  const long long base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (base >= NK) return;
+  const long long row = base + lane;
+  const int key = (row < NK && (int)(row % K) < M) ? idx[row] : -1;   // (columns >= M are zero-filled neighbours)
+  unsigned long long todo = __ballot(key >= 0);
+  while (todo) {
+    const int k0 = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
+    const unsigned long long grp = __ballot(key == k0);
+    todo &= ~grp;
+    for (int c0 = 0; c0 < F; c0 += 64) {
+      const int c = c0 + lane;
+      const bool on = c < F;
+      const float* src = gXF + (size_t)base * ld + (on ? c : 0);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      unsigned long long g = grp;
+      while (g) {   // four rows in flight
+        const int r0 = __ffsll((long long)g) - 1; g &= g - 1;
+        const int r1 = g ? __ffsll((long long)g) - 1 : -1; g &= g - (g != 0);
+        const int r2 = g ? __ffsll((long long)g) - 1 : -1; g &= g - (g != 0);
+        const int r3 = g ? __ffsll((long long)g) - 1 : -1; g &= g - (g != 0);
+        const float v0 = on ? src[(size_t)r0 * ld] : 0.f;
+        const float v1 = on && r1 >= 0 ? src[(size_t)r1 * ld] : 0.f;
+        const float v2 = on && r2 >= 0 ? src[(size_t)r2 * ld] : 0.f;
+        const float v3 = on && r3 >= 0 ? src[(size_t)r3 * ld] : 0.f;
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+      }
+      if (on) atomicAdd(g_sp_feat + (size_t)k0 * F + c, (a0 + a1) + (a2 + a3));
+    }
+  }
 }
 
 // column sums of a (rows, M) matrix, coalesced: block = 64 columns x 4 row phases over one slab of rows; part[slab][M]
@@ -557,12 +584,17 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   __syncthreads();
   if (ph == 0 && c < M) part[(size_t)blockIdx.y * M + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nslab, int M, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= M) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nslab, int M, float* __restrict__ out) {
+  // 32 columns per block, 8 threads each over interleaved slabs, combined in a fixed order (one thread walking 256 slabs took 30 us)
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, zz = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + el;
   float s = 0.f;
-  for (int z = 0; z < nslab; ++z) s += part[(size_t)z * M + c];
-  out[c] += s;
+  if (c < M)
+    for (int z = zz; z < nslab; z += 8) s += part[(size_t)z * M + c];
+  red[zz][el] = s;
+  __syncthreads();
+  if (zz == 0 && c < M) out[c] += ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
 }  // namespace
@@ -575,14 +607,14 @@ int nl_launch_colsum(const float* Y, int ldy, int64_t rows, int M, float* out, f
   nslab = (int)nl_cdiv(rows, slab);
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)nl_cdiv(M, 64), (unsigned)nslab), dim3(256), 0, st, Y, ldy, (long long)rows, M, slab, scratch);
   NL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nl_cdiv(M, 256)), dim3(256), 0, st, scratch, nslab, M, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nl_cdiv(M, 32)), dim3(256), 0, st, scratch, nslab, M, out);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
 
 int nl_launch_sp_feat_scatter(const float* gXF, int ld, int F, const int* idx, int64_t N, int K, int64_t M, float* g_sp_feat, hipStream_t st) {
   if (N <= 0 || M <= 0) return NL_OK;
-  hipLaunchKernelGGL(sp_feat_scatter_kernel, dim3((unsigned)nl_cdiv(N * K, 4)), dim3(256), 0, st, gXF, ld, F, idx, (long long)(N * K), K,
+  hipLaunchKernelGGL(sp_feat_scatter_kernel, dim3((unsigned)nl_cdiv(N * K, 256)), dim3(256), 0, st, gXF, ld, F, idx, (long long)(N * K), K,
                      (int)(M > 0x7fffffff ? 0x7fffffff : M), g_sp_feat);
   NL_LAUNCH_CHECK();
   return NL_OK;
