@@ -693,8 +693,13 @@ __device__ __forceinline__ TapD make_tapd(const Taps& t, int Wm, int Hm) {
 // One wave per sample.  Inputs (each may be null = zero): g393 (N, ldg) gradient of the statistics row [mean F | var F | mean_dd, var_dd, mean_w];
 // g_pf (N*V, 32) gradient of the blend-projected feature taps; g_rgbv (N*V, 4) gradient of [tapped r, g, b | visibility]; g_ang (N*V, 4).
 // Outputs: g_xyz (N,3) (written), g_qc (N,3) or null, g_vis / g_dd (V,N) (written).
-template <int VT>
-__global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
+// SC (training, the maps' scatter-adds): a workgroup is EIGHT consecutive samples of a ray, whose taps in a view mostly fall on the same few texels.  For every
+// view a wave leaves its gradient vector, its four texel keys and tap weights in LDS (no barrier in the view loops: a barrier per view made the eight waves wait
+// for each other's tap loads and cost more than the atomics it saved); after ONE barrier a wave sums, for each texel it is the FIRST (wave, tap) of a view to name,
+// all the contributions to it (ballot over the view's 32 keys) and issues that texel's atomics: ~10 texels per view instead of 32 tap rows — the atomics were 1.2
+// of this kernel's 1.9 ms in a training step.  Waves past N run along with zero gradients and write nothing.
+template <int VT, bool SC>
+__global__ __launch_bounds__(SC ? 512 : 256) void mv_geom_backward_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
                                                                const float* __restrict__ feat, int C, const float* __restrict__ pfeat,
                                                                const float* __restrict__ xyz, int N, const float* __restrict__ vis_in,
                                                                const float* __restrict__ dd_in, const float* __restrict__ g393, int ldg,
@@ -704,10 +709,67 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
                                                                float* __restrict__ sc_feat /* training: (V,h,w,C) += , or null */,
                                                                float* __restrict__ sc_pfeat /* training: (V,h,w,32) +=, or null */,
                                                                const float* __restrict__ stats /* the forward's statistics rows (N, ldg) or null */) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+  constexpr int NW = SC ? 8 : 4;
+  __shared__ float sc_vec[SC ? VT : 1][SC ? NW : 1][SC ? 64 : 1][3];   // lane's channels lane, lane + 64, lane + 128 side by side
+  __shared__ float sc_pvec[SC ? VT : 1][SC ? NW : 1][SC ? 32 : 1];
+  __shared__ int sc_key[SC ? VT : 1][32];
+  __shared__ float sc_wt[SC ? VT : 1][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_raw = blockIdx.x * NW + wave;
+  if (!SC && n_raw >= N) return;
+  const bool act = n_raw < N;
+  const int n = act ? n_raw : N - 1;
   const int V = vw.V, F = C + 3;
+  // a view's texel keys / tap weights (wave-uniform values) into slot b
+  auto publish = [&](int b, const int (&o)[4], const float (&m)[4], float s_, float e_, float w_, float n_) __attribute__((always_inline)) {
+    if (lane < 4) {
+      const int kq = lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : o[3];
+      const float mq = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+      const float wq = lane == 0 ? s_ * e_ : lane == 1 ? s_ * w_ : lane == 2 ? n_ * e_ : n_ * w_;
+      sc_key[b][wave * 4 + lane] = (mq != 0.f && act) ? kq : -1;
+      sc_wt[b][wave * 4 + lane] = wq;
+    }
+  };
+  // the block's merge for one view (after the barrier): vec = sc_vec or sc_pvec
+  auto merge_scatter = [&](int b, const int (&o)[4], const float (&m)[4], float* __restrict__ dst, int Cn, int v, size_t fmapsz, bool pf) __attribute__((always_inline)) {
+    const int kk = sc_key[b][lane & 31];
+    const float ww = sc_wt[b][lane & 31];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int mykey = (m[k] != 0.f && act) ? o[k] : -1;
+      if (mykey < 0) continue;
+      unsigned mask = (unsigned)__ballot(kk == mykey);
+      // the texel's owner: one of the (wave, tap) pairs that name it, picked by the key (the first one would leave most of a ray's texels to wave 0)
+      int nth = (int)((unsigned)mykey % (unsigned)__popc(mask));
+      unsigned mm = mask;
+      while (nth-- > 0) mm &= mm - 1;
+      if (__ffs((int)mm) - 1 != wave * 4 + k) continue;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      while (mask) {   // two contributions in flight
+        const int b0 = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        const int b1 = mask ? __ffs((int)mask) - 1 : b0;
+        const float w0 = bk_rl(ww, b0), w1 = mask ? bk_rl(ww, b1) : 0.f;
+        mask &= mask - (mask != 0u);
+        if (pf) {
+          if (lane < 32) { const float p0_ = sc_pvec[b][b0 >> 2][lane], p1_ = sc_pvec[b][b1 >> 2][lane]; a0 = fmaf(w0, p0_, a0); a0 = fmaf(w1, p1_, a0); }
+        } else {
+          const float* q0 = sc_vec[b][b0 >> 2][lane];
+          const float* q1 = sc_vec[b][b1 >> 2][lane];
+          const float x0 = q0[0], y0 = q0[1], z0 = q0[2], x1 = q1[0], y1 = q1[1], z1 = q1[2];
+          a0 = fmaf(w0, x0, a0); a1 = fmaf(w0, y0, a1); a2 = fmaf(w0, z0, a2);
+          a0 = fmaf(w1, x1, a0); a1 = fmaf(w1, y1, a1); a2 = fmaf(w1, z1, a2);
+        }
+      }
+      float* sb = dst + (size_t)v * fmapsz * Cn + (size_t)mykey * Cn;
+      if (pf) { if (lane < 32) atomicAdd(sb + lane, a0); }
+      else {
+        if (lane < Cn) atomicAdd(sb + lane, a0);
+        if (lane + 64 < Cn) atomicAdd(sb + lane + 64, a1);
+        if (lane + 128 < Cn) atomicAdd(sb + lane + 128, a2);
+      }
+    }
+  };
   const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
   // ---------------------------------------------------------------- per-view scalars (lane = view)
   const int vl = lane < V ? lane : 0;
@@ -798,15 +860,10 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
             six = fmaf(gx, s * (t[1] - t[0]) + nn * (t[3] - t[2]), six);
             siy = fmaf(gx, e * (t[2] - t[0]) + w * (t[3] - t[1]), siy);
             sw += gm[j] * x + gv[j] * (d * d - 2.f * x * mean[j] * omW);
-            if (sc_feat && gx != 0.f) {   // grid_sample's backward towards the map (zeros padding: masked taps receive nothing)
-              float* sb = sc_feat + (size_t)v * fmap * C + ch;
-              if (m[0] != 0.f) atomicAdd(sb + (size_t)o[0] * C, gx * s * e);
-              if (m[1] != 0.f) atomicAdd(sb + (size_t)o[1] * C, gx * s * w);
-              if (m[2] != 0.f) atomicAdd(sb + (size_t)o[2] * C, gx * nn * e);
-              if (m[3] != 0.f) atomicAdd(sb + (size_t)o[3] * C, gx * nn * w);
-            }
+            if constexpr (SC) { if (sc_feat) sc_vec[v][wave][lane][j] = gx; }   // grid_sample's backward towards the map (zeros padding: masked taps receive nothing)
           }
         }
+        if constexpr (SC) { if (sc_feat) publish(v, o, m, s, e, w, nn); }
         float sixI = 0.f, siyI = 0.f;
         if (lane < 3) {
 #pragma unroll
@@ -839,12 +896,13 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
           const float gx = g_pf[((size_t)n * V + v) * 32 + lane];
           six = gx * (s * (t[1] - t[0]) + nn * (t[3] - t[2]));
           siy = gx * (e * (t[2] - t[0]) + w * (t[3] - t[1]));
-          if (sc_pfeat && gx != 0.f) {
-            float* sb = sc_pfeat + (size_t)v * fmap * 32 + lane;
-            if (m[0] != 0.f) atomicAdd(sb + (size_t)o[0] * 32, gx * s * e);
-            if (m[1] != 0.f) atomicAdd(sb + (size_t)o[1] * 32, gx * s * w);
-            if (m[2] != 0.f) atomicAdd(sb + (size_t)o[2] * 32, gx * nn * e);
-            if (m[3] != 0.f) atomicAdd(sb + (size_t)o[3] * 32, gx * nn * w);
+          if constexpr (SC) { if (sc_pfeat) sc_pvec[v][wave][lane] = gx; }
+        }
+        if constexpr (SC) {   // (the statistics part published this view's keys unless it did not run)
+          if (sc_pfeat && !(g393 && sc_feat)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[k] = bk_rli(tf.o[k], v); m[k] = bk_rl(tf.m[k], v); }
+            publish(v, o, m, bk_rl(tf.s, v), bk_rl(tf.e, v), bk_rl(tf.w, v), bk_rl(tf.n, v));
           }
         }
         if (lane < 3 && g_rgbv) {
@@ -857,6 +915,19 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
           siyI = gx * (ei * (t[2] - t[0]) + wi * (t[3] - t[1]));
         }
         acc_ix[v] += wave_sum(six); acc_iy[v] += wave_sum(siy); acc_ixI[v] += wave_sum(sixI); acc_iyI[v] += wave_sum(siyI);
+      }
+    }
+  }
+  if constexpr (SC) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        int o[4]; float m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = bk_rli(tf.o[k], v); m[k] = bk_rl(tf.m[k], v); }
+        if (g393 && sc_feat) merge_scatter(v, o, m, sc_feat, C, v, fmap, false);
+        if (g_pf && sc_pfeat) merge_scatter(v, o, m, sc_pfeat, 32, v, fmap, true);
       }
     }
   }
@@ -920,12 +991,11 @@ __global__ __launch_bounds__(256) void mv_geom_backward_kernel(const NlViews vw,
   if (vact) {
     gvis_out = gw / den - cross;
     if (g_rgbv) gvis_out += g_rgbv[((size_t)n * V + vl) * 4 + 3];
-    g_vis[(size_t)vl * N + n] = gvis_out;
-    g_dd[(size_t)vl * N + n] = gdd_out;
+    if (act) { g_vis[(size_t)vl * N + n] = gvis_out; g_dd[(size_t)vl * N + n] = gdd_out; }
   }
   gX = wave_sum(vact ? gX : 0.f); gY = wave_sum(vact ? gY : 0.f); gZ = wave_sum(vact ? gZ : 0.f);
   if (g_qc) { gq0 = wave_sum(vact ? gq0 : 0.f); gq1 = wave_sum(vact ? gq1 : 0.f); gq2 = wave_sum(vact ? gq2 : 0.f); }
-  if (lane == 0) {
+  if (lane == 0 && act) {
     g_xyz[3 * (size_t)n] = gX; g_xyz[3 * (size_t)n + 1] = gY; g_xyz[3 * (size_t)n + 2] = gZ;
     if (g_qc) { g_qc[3 * (size_t)n] = gq0; g_qc[3 * (size_t)n + 1] = gq1; g_qc[3 * (size_t)n + 2] = gq2; }
   }
@@ -1618,9 +1688,15 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
                                hipStream_t st) {
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)nl_cdiv(N, 4));
-#define NL_MGB(VT) hipLaunchKernelGGL((mv_geom_backward_kernel<VT>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, \
-                                      g393, ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, sc_feat, sc_pfeat, stats)
+  const bool sc = sc_feat || sc_pfeat;
+  dim3 grid((unsigned)nl_cdiv(N, sc ? 8 : 4));
+#define NL_MGB(VT)                                                                                                                                            \
+  do {                                                                                                                                                        \
+    if (sc) hipLaunchKernelGGL((mv_geom_backward_kernel<VT, true>), grid, dim3(512), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, g393, \
+                               ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, sc_feat, sc_pfeat, stats);                                                \
+    else hipLaunchKernelGGL((mv_geom_backward_kernel<VT, false>), grid, dim3(256), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, g393,   \
+                            ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, sc_feat, sc_pfeat, stats);                                                   \
+  } while (0)
   if (vw.V <= 4) NL_MGB(4); else if (vw.V <= 8) NL_MGB(8); else if (vw.V <= 10) NL_MGB(10); else NL_MGB(16);
 #undef NL_MGB
   NL_LAUNCH_CHECK();
