@@ -77,6 +77,7 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
                                hipStream_t st);
 int nl_dec_train_row(void);
 size_t nl_dec_wpart_floats(void);
+int nl_launch_copy_rows(const float* src, int lds, float* dst, int ldd, int64_t rows, int cols, bool add, hipStream_t st);
 int nl_launch_dec_backward(const NlViews& vw, const float* visf_hwc, const float* dec_w, const void* dpack, const float* xyz, int64_t N, const float* g_vis,
                            const float* g_dd, float* part, float* g_xyz, float* tr, float* const* decw, float* scratch, size_t scratch_floats, float* sc_vis,
                            hipStream_t st);
@@ -153,6 +154,7 @@ enum {
   G_UB_OUTA, G_UB_OUTB, G_UB_T1, G_UB_T2, G_UB_T3, G_UB_C3, G_UB_C2, G_UB_C1,   // ... of the ray U-Net's seven convolutions (do_unet_backward)
   G_BASE0_TF,                                                                    // training: base_mlp.0 towards its support-feature columns
   G_FEAT0_T, G_FEAT2_T,                                                          // whole-path backward: feat_mlp's two layers towards their inputs
+  G_BASE0_S,                                                                     // base_mlp.0's posenc + ray_diff_fc columns (the staged forward on the table T)
   G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
@@ -227,6 +229,7 @@ Layout make_layout(const nl_config* c) {
   set(G_BASE2_T, W, W, false);
   set(G_BASE0_T, W, 96, false);
   set(G_BASE0_TF, W, F, false);
+  set(G_BASE0_S, 90, W, false);
   set(G_FEAT0_T, W, W, false);
   set(G_FEAT2_T, C, W, false);
   set(G_OUTFC2_T, W, 64, false);
@@ -457,6 +460,7 @@ struct nl_frame {
   float* pfeat;             // (V,h,w,32) feature maps projected through the blend layer's feature columns
   const void* pfeat_for; uint64_t pfeat_gen;   // packed weights (address + pack generation) pfeat was computed with (lazily, first render of the frame)
   float* views_dev;         // device copy of the per-view matrices: [16][12] proj_ibr rows, then [16][3] camera centres
+  float *tr_gT, *tr_tmp;    // training scratch sized by the table: d loss / d T (M, W) and (M, ldf_of(C)) staging rows (pt_backward_only)
   float views_host[16 * 15];
   // side stream of the fused render path (exact KNN beside the multi-view gather): owned by the frame, created in nl_frame_create —
   // never lazily inside a render call (stream / event creation is illegal during graph capture) and never shared between frames, so two
@@ -550,7 +554,8 @@ struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; int ntap =
 struct TileMap { const int* map; const int* count; };
 struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0;
                 const float* sig_w = nullptr; const float* sig_b = nullptr; float* sig_out = nullptr;
-                unsigned* maskout = nullptr; const unsigned* maskin = nullptr; };   // out: destination when fused; mask*: sign bits (common.h: ep_maskout / ep_maskin)
+                unsigned* maskout = nullptr; const unsigned* maskin = nullptr;
+                const float* tab = nullptr; const int* tabidx = nullptr; int ldtab = 0, tabK = 0, tabM = 0; };   // out: destination when fused; mask*: sign bits (common.h: ep_maskout / ep_maskin)
 
 // fills the launch descriptor; *fused says whether the optional row epilogue will run inside the GEMM (else the caller runs it)
 int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, float* C, int ldc, int act,
@@ -592,7 +597,9 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.ep_scale = epi->scale; a.ep_eps = epi->eps;
     a.ep_sig_w = epi->sig_w; a.ep_sig_b = epi->sig_b; a.ep_sig_out = epi->sig_out;
     a.ep_maskout = epi->maskout; a.ep_maskin = epi->maskin;
+    a.ep_tab = epi->tab; a.ep_tabidx = epi->tabidx; a.ep_ldtab = epi->ldtab; a.ep_tabK = epi->tabK; a.ep_tabM = epi->tabM;
     if (nl_tgemm_supported(a, prec)) { a.C = epi->out; if (fused) *fused = true; }
+    else if (epi->tab) return NL_ERR_UNSUPPORTED;   // (no other kernel knows the table: the caller checks *fused first or keeps the full-width layer)
     else { a.epi = NL_EPI_NONE; a.ep_maskout = nullptr; a.ep_maskin = nullptr; }
   }
   if (tiles && !nl_tgemm_supported(a, prec)) { a.tile_map = nullptr; a.tile_count = nullptr; }   // generic kernels compute every row
@@ -801,12 +808,16 @@ void carve_ptb(Bump& b, const nl_config* c, int64_t N, int K, PtBwdBufs& p, bool
   p.gKV = b.take<float>(NK * 256); p.gA = b.take<float>(NK * W); p.gB = b.take<float>(NK * W); p.gX = b.take<float>(NK * 96);
   for (int i = 0; i < 3; ++i) p.mk[i] = b.take<unsigned>((NK / 32 + 8) * 256);   // LeakyReLU sign bits of the three base_mlp layers: 32 bytes per row
   p.aff = p.tr = p.gXF = nullptr;
-  if (train) { p.aff = b.take<float>((size_t)N * 2 * W); p.tr = b.take<float>(NK * 68); p.gXF = b.take<float>(NK * ldf_of(c->C)); }
+  if (train) {
+    p.aff = b.take<float>((size_t)N * 2 * W); p.tr = b.take<float>(NK * 68);
+    if (c->precision == NL_PREC_F32) p.gXF = b.take<float>(NK * ldf_of(c->C));   // (otherwise the support features' gradient goes through the table: pt_backward_only)
+  }
 }
 
 // dX = (dY . W) * LeakyReLU'(h): the mask inside the streaming GEMM's epilogue where that kernel runs, a separate pass otherwise (fp32 mode)
 // the layers' sign bits exist when the forward layers ran on the streaming kernel (every mode but fp32: pt_forward_staged checks it)
 inline bool pt_mask_bits(const Ctx& x) { return x.c->precision != NL_PREC_F32; }
+inline bool pt_table(const Ctx& x) { return x.c->precision != NL_PREC_F32; }   // base_mlp.0 through the per-frame table (pt_forward_staged)
 int gemm_lrelu_masked(const Ctx& x, int g, const SegSpec& s, int64_t M, float* out, int ld, const float* h, const unsigned* bits = nullptr) {
   if (x.c->precision != NL_PREC_F32 && (s.k & 31) == 0 && (((size_t)s.ptr) & 15) == 0 && (s.ld & 3) == 0 && (ld & 3) == 0 && (((size_t)h) & 15) == 0 && x.L.g[g].N <= 256) {
     RowEpi ep{h, ld, nullptr, nullptr, nullptr, 0.f, out, NL_EPI_NONE};
@@ -833,17 +844,23 @@ int pt_forward_staged(const Ctx& x, const nl_frame* f, const float* xyz, const f
   const int* idx = idx_in && d2_in ? idx_in : p.idx;
   const float* d2 = idx_in && d2_in ? d2_in : p.d2;
   if (idx == p.idx) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));   // (the caller may hand over the forward call's neighbours)
-  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, M, idx, d2, f->sp_xyz, f->sp_feat, F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
-                                inv_span, p.X, ldx, p.wscale, x.st));
+  // every mode but fp32: base_mlp.0 on the per-frame table T like the fused kernel — the encoded rows are the 96 posenc + ray_diff_fc columns only (the 195
+  // gathered feature columns per row are never written: 400 MB per 65 k samples), the layer's K is 96 instead of 288, and its epilogue adds T[neighbour]
+  const bool tab = pt_table(x);
+  if (tab) NL_TRY(ensure_ptt(x, f));
+  NL_TRY(nl_launch_point_encode(xyz, dir, dir_stride, dir_div, N, K, M, idx, d2, f->sp_xyz, f->sp_feat, tab ? 0 : F, f->sp_conf, f->sp_dir, x.p<float>(x.L.rd_w),
+                                inv_span, p.X, tab ? 96 : ldx, p.wscale, x.st));
   // (the encoded rows' pad columns are zero and so are the weights' pad rows: taking all ldx columns keeps the streaming kernel applicable)
   SegSpec sx{p.X, ldx, ldx, 0, 1}, s1{p.H1, W, W, 0, 1}, s2{p.H2, W, W, 0, 1}, s3{p.H3, W, W, 0, 1}, sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
+  if (tab) sx = SegSpec{p.X, 96, 96, 0, 1};
   if (pt_mask_bits(x)) {   // the layers also leave their outputs' signs as bits: the way back reads 32 bytes per row instead of the 1 KB activation row
-    const int gs[3] = {G_BASE0, G_BASE2, G_BASE4};
+    const int gs[3] = {tab ? G_BASE0_S : G_BASE0, G_BASE2, G_BASE4};
     const SegSpec* ss[3] = {&sx, &s1, &s2};
     float* hs[3] = {p.H1, p.H2, p.H3};
     for (int i = 0; i < 3; ++i) {
       RowEpi ep{nullptr, 0, nullptr, nullptr, nullptr, 0.f, hs[i], NL_EPI_NONE};
       ep.maskout = p.mk[i];
+      if (i == 0 && tab) { ep.tab = f->ptt; ep.tabidx = idx; ep.ldtab = W; ep.tabK = K; ep.tabM = (int)(M > 0x7fffffff ? 0x7fffffff : M); }
       bool streamed = false;
       NL_TRY(run_gemm(x, gs[i], ss[i], 1, NK, hs[i], W, NL_ACT_LRELU, 0, 0, 0, 1, 0, &ep, &streamed));
       if (!streamed) return NL_ERR_UNSUPPORTED;
@@ -893,7 +910,28 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
   NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2, bits ? p.mk[1] : nullptr));
   NL_TRY(wg(T_B2W, T_B2B, p.gB, W, W, p.H1, W, W, NK));
   NL_TRY(gemm_lrelu_masked(xb, G_BASE2_T, sb, NK, p.gA, W, p.H1, bits ? p.mk[0] : nullptr));
-  NL_TRY(wg(T_B0W, T_B0B, p.gA, W, W, p.X, ldx, F + 90, NK));
+  const bool tab = pt_table(x);
+  if (!tab) NL_TRY(wg(T_B0W, T_B0B, p.gA, W, W, p.X, ldx, F + 90, NK));
+  else if (tg) {
+    // base_mlp.0 on the table: its posenc / ray_diff_fc columns and the bias from the 96-wide rows; the feature columns and the support features through
+    // d T = the rows' gradients summed per support point (M, W): d W[:, :F] = d T^T . sp_feature, d sp_feature = d T . W[:, :F]
+    if (tg->w[T_B0W]) NL_TRY(nl_launch_wgrad(p.gA, W, W, p.X, 96, 90, NK, 0, 0, tg->w[T_B0W] + F, F + 90, 1, 0, tg->w[T_B0B], tg->scratch, tg->scratch_floats, x.st));
+    else if (tg->w[T_B0B]) NL_TRY(nl_launch_colsum(p.gA, W, NK, W, tg->w[T_B0B], tg->scratch, x.st));
+    if ((tg->w[T_B0W] || tg->sp_feat) && M > 0) {
+      const int ldf = ldf_of(f->C);
+      NL_CHECK_HIP(hipMemsetAsync(f->tr_gT, 0, sizeof(float) * (size_t)M * W, x.st));
+      NL_TRY(nl_launch_sp_feat_scatter(p.gA, W, W, idx, N, K, M, f->tr_gT, x.st));
+      if (tg->w[T_B0W]) {
+        NL_TRY(nl_launch_copy_rows(f->sp_feat, F, f->tr_tmp, ldf, M, F, false, x.st));   // (rows of 195 floats are not 16-byte aligned)
+        NL_TRY(nl_launch_wgrad(f->tr_gT, W, W, f->tr_tmp, ldf, F, M, 0, 0, tg->w[T_B0W], F + 90, 1, 0, nullptr, tg->scratch, tg->scratch_floats, x.st));
+      }
+      if (tg->sp_feat) {
+        SegSpec st_{f->tr_gT, W, W, 0, 1};
+        NL_TRY(run_gemm(xb, G_BASE0_TF, &st_, 1, M, f->tr_tmp, ldf, NL_ACT_NONE));
+        NL_TRY(nl_launch_copy_rows(f->tr_tmp, ldf, tg->sp_feat, F, M, F, true, x.st));
+      }
+    }
+  }
   NL_TRY(run_gemm(xb, G_BASE0_T, &sa, 1, NK, p.gX, 96, NL_ACT_NONE));
   const bool rdw = tg && (tg->w[T_RD0W] || tg->w[T_RD0B] || tg->w[T_RD2W] || tg->w[T_RD2B]);
   NL_TRY(nl_launch_point_encode_backward(xyz, dir, dir_stride, dir_div, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz,
@@ -902,7 +940,7 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
     NL_TRY(wg(T_RD2W, T_RD2B, p.tr + 36, 68, 27, p.tr + 4, 68, 16, NK));
     NL_TRY(wg(T_RD0W, T_RD0B, p.tr + 20, 68, 16, p.tr, 68, 4, NK));
   }
-  if (tg && tg->sp_feat) {   // the gathered support features (columns 0 .. F-1 of the encoded rows)
+  if (tg && tg->sp_feat && !tab) {   // the gathered support features (columns 0 .. F-1 of the encoded rows)
     const int ldf = ldf_of(f->C);
     NL_TRY(run_gemm(xb, G_BASE0_TF, &sa, 1, NK, p.gXF, ldf, NL_ACT_NONE));
     NL_TRY(nl_launch_sp_feat_scatter(p.gXF, ldf, F, idx, N, K, M, tg->sp_feat, x.st));
@@ -1558,6 +1596,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
                        (float*)((char*)packed + L.b32[G_BASE0_TF]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_TF]),
                        (unsigned short*)((char*)packed + L.blo[G_BASE0_TF]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_TF]), nl_tgemm_nrt(d.N), 0);
   }
+  P.block(G_BASE0_S, 0, t[T_B0W], F, F + 90, 1, 90);
   P.block(G_OUTFC2_T, 0, t[T_OUT2W], 0, 1, 64, W);
   P.block(G_FEAT0_T, 0, t[T_F0W], 0, 1, W, W);
   P.block(G_FEAT2_T, 0, t[T_F2W], 0, 1, W, C);
@@ -1653,7 +1692,8 @@ static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
   if (!desc_ok(cfg, d)) return 0;
   return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + nl_align_up((size_t)(d->M + 1) * cfg->W * 4, 256) +
-         nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + 1024;
+         nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + 1024 + nl_align_up((size_t)d->M * cfg->W * 4, 256) +
+         nl_align_up((size_t)d->M * nl_align_up(cfg->C + 3, 32) * 4, 256);
 }
 
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
@@ -1685,6 +1725,8 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
     f->pfeat = (float*)(p + nl_align_up((size_t)(d->M + 1) * cfg->W * 4, 256));
     f->pfeat_for = nullptr; f->pfeat_gen = 0;
     f->views_dev = (float*)((char*)f->pfeat + nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256));
+    f->tr_gT = (float*)((char*)f->views_dev + 1024);
+    f->tr_tmp = (float*)((char*)f->tr_gT + nl_align_up((size_t)d->M * cfg->W * 4, 256));
     memset(f->views_host, 0, sizeof(f->views_host));
     for (int v = 0; v < d->V; ++v) {
       memcpy(f->views_host + 12 * v, d->proj_ibr + 12 * v, 48);

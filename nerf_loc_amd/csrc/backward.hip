@@ -612,6 +612,24 @@ int nl_launch_colsum(const float* Y, int ldy, int64_t rows, int M, float* out, f
   return NL_OK;
 }
 
+// dst[r][c] (+)= src[r][c] for c < cols: rows whose leading dimensions are not multiples of 4 floats
+namespace {
+__global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long long rows, int cols, int add) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long long r = i / cols; const int c = (int)(i - r * cols);
+  const float v = src[(size_t)r * lds + c];
+  float* d = dst + (size_t)r * ldd + c;
+  *d = add ? *d + v : v;
+}
+}  // namespace
+int nl_launch_copy_rows(const float* src, int lds, float* dst, int ldd, int64_t rows, int cols, bool add, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return NL_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)nl_cdiv(rows * cols, 256)), dim3(256), 0, st, src, lds, dst, ldd, (long long)rows, cols, add ? 1 : 0);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
 int nl_launch_sp_feat_scatter(const float* gXF, int ld, int F, const int* idx, int64_t N, int K, int64_t M, float* g_sp_feat, hipStream_t st) {
   if (N <= 0 || M <= 0) return NL_OK;
   hipLaunchKernelGGL(sp_feat_scatter_kernel, dim3((unsigned)nl_cdiv(N * K, 256)), dim3(256), 0, st, gXF, ld, F, idx, (long long)(N * K), K,

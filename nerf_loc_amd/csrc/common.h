@@ -160,6 +160,9 @@ struct NlGemmArgs {
   // bit 16 (rt & 1) + 4 gq + e of dword rt >> 1 <-> column 32 rt + 8 gq + 4 hh + e) — written by a forward layer (ep_maskout), read back by the
   // NL_ACT_LRELU_MASK product of the backward pass (ep_maskin) instead of 1 KB of activations per row
   unsigned* ep_maskout; const unsigned* ep_maskin;
+  // plain epilogue, optional: + ep_tab[row_of(m)][slot(n)] (columns in accumulator order, as the fused kernel's table) before the activation, row_of(m) = ep_tabidx[m] if (m % ep_tabK) < ep_tabM else ep_tabM — the neural-point
+  // branch's first layer on the per-frame table (support features x their weight columns + bias; row ep_tabM = bias only: zero-filled neighbours)
+  const float* ep_tab; const int* ep_tabidx; int ep_ldtab, ep_tabK, ep_tabM;
 };
 enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1, NL_EPI_LNSLAB = 2 };
 // internal arithmetic of the segment GEMMs beyond the public nl_precision values: three-term split-FP16 (tgemm.hip), used by the backward passes for

@@ -397,6 +397,8 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
   unsigned mb[(NRT + 1) / 2];   // sign bits of this lane's outputs (ep_maskout) / of the forward layer's (ep_maskin)
 #pragma unroll
   for (int i = 0; i < (NRT + 1) / 2; ++i) mb[i] = 0u;
+  const float* trow = nullptr;   // this row's table row (ep_tab)
+  if (a.ep_tab) trow = a.ep_tab + (size_t)((int)((unsigned)m % (unsigned)a.ep_tabK) < a.ep_tabM ? a.ep_tabidx[m] : a.ep_tabM) * a.ep_ldtab;
   if (a.ep_maskin) {
     const uint4 mi = *(const uint4*)(a.ep_maskin + ((size_t)tile * 64 + lane) * 4);
     mb[0] = mi.x;
@@ -410,7 +412,11 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
       const int n = 32 * rt + 8 * gq + 4 * hh;
       const int sh = 16 * (rt & 1) + 4 * gq;
       if (n < a.N) {   // N % 4 == 0 and ldc % 4 == 0 are launch preconditions
-        const float4 b4 = *(const float4*)(sbias + n);
+        float4 b4 = *(const float4*)(sbias + n);
+        if (trow) {   // the table's columns are in accumulator order (point_fused.hip: pack_ptt_kernel): slot 32 rt + 16 hh + r holds feature 32 rt + (r & 3) + 8 (r >> 2) + 4 hh
+          const float4 t4 = *(const float4*)(trow + 32 * rt + 16 * hh + 4 * gq);
+          b4.x += t4.x; b4.y += t4.y; b4.z += t4.z; b4.w += t4.w;
+        }
         float4 v;
         if (a.act == NL_ACT_LRELU_MASK) {   // input gradient through a LeakyReLU: the mask comes from the forward output's sign
           if (a.ep_maskin) {
@@ -838,6 +844,9 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   if (precision == NL_PREC_F16X3_INTERNAL && (a.epi != NL_EPI_NONE || a.tile_map)) return false;   // plain products only
   if (a.act == NL_ACT_LRELU_MASK && (a.epi != NL_EPI_NONE || a.So > 0 || (!a.ep_maskin && (!a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))))) return false;
   if ((a.ep_maskout || a.ep_maskin) && (a.epi != NL_EPI_NONE || a.So > 0 || a.tile_map)) return false;
+  if (a.ep_tab && (a.epi != NL_EPI_NONE || a.So > 0 || a.tile_map || a.act == NL_ACT_LRELU_MASK || !a.ep_tabidx || a.ep_tabK <= 0 || (a.ep_ldtab & 3) ||
+                   (((size_t)a.ep_tab) & 15)))
+    return false;
   if (a.tile_map && (a.epi != NL_EPI_NONE || a.So > 0 || !a.tile_count)) return false;
   if (precision == NL_PREC_F32 || !a.Bst || a.N > 256 || (a.N & 3) || (a.ldc & 3) || (((size_t)a.C) & 15) || a.M <= 0 || !a.zeros) return false;
   if (a.epi == NL_EPI_LNROW && (a.N != 32 * nl_tgemm_nrt(a.N) || a.So > 0 || !a.ep_res || (a.ep_ldres & 3) || (((size_t)a.ep_res) & 15))) return false;
