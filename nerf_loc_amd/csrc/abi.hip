@@ -64,6 +64,8 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
 int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
                     float* gb, float* scratch, size_t scratch_floats, hipStream_t st);
 size_t nl_wgrad_scratch_floats(int64_t rows, int M, int N);
+int nl_launch_wgrad_multi(int nsub, const float* const* dY, int ldy, int M, const float* const* X, int ldx, int N, int64_t rows, const int* shift, int period,
+                          float* gW, int ldc, int cs, const int* co, float* gb, int bias_sub, float* scratch, size_t scratch_floats, hipStream_t st);
 int nl_launch_colsum(const float* Y, int ldy, int64_t rows, int M, float* out, float* scratch, hipStream_t st);
 int nl_launch_sp_feat_scatter(const float* gXF, int ld, int F, const int* idx, int64_t N, int K, int64_t M, float* g_sp_feat, hipStream_t st);
 int nl_launch_ln_agg_backward(const float* FC, const float* G, const float* gy, int64_t N, int W, const float* gamma, float eps, const float* wscale, float* gx,
@@ -90,6 +92,7 @@ int nl_launch_elu_mask(float* g, const float* e, size_t n, hipStream_t st);
 int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, const float* g_out, int ldgo, int pool,
                                    float* g_x, float* aff, hipStream_t st);
 int nl_launch_table_add_t(const float* t, float* g, int L, int Cc, hipStream_t st);
+int nl_launch_colsum_tables(const float* Y, int64_t rows, int L, int Cc, float* gw, float* gb, float* scratch, hipStream_t st);
 int nl_launch_ray_feat_sum(const float* z, const float* sigma, const float* ft, int64_t R, int S, int C, float* hc, float* wsum4, hipStream_t st);
 int nl_launch_sigma_backward(const float* geo, int64_t N, int W, const float* w, const float* b, const float* g_sigma, float* g_geo, float* gpre4, hipStream_t st);
 int nl_launch_gw_total(const float* g_wts, const float* g_feat, const float* b2, int64_t R, int S, int C, float* gw, const float* g_beta, const float* bv,
@@ -1228,13 +1231,7 @@ int unet_backward_only(const Ctx& xb, const Ctx& x32, const float* in, int64_t R
     const bool aff = gw || gb;
     NL_TRY(nl_launch_ln_slab_elu_backward(x, R, L, Cc, g(li), b(li), eps, go, ldgo, pool, gx, aff ? q.aff : nullptr, st));
     if (!aff) return NL_OK;
-    const int n = L * Cc;
-    float* sums = tg->scratch;                       // (2 n) sums, then the partials of nl_launch_colsum
-    NL_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 2 * n, st));
-    NL_TRY(nl_launch_colsum(q.aff, 2 * n, R, 2 * n, sums, sums + 2 * n, st));
-    if (gw) NL_TRY(nl_launch_table_add_t(sums, gw, L, Cc, st));
-    if (gb) NL_TRY(nl_launch_table_add_t(sums + n, gb, L, Cc, st));
-    return NL_OK;
+    return nl_launch_colsum_tables(q.aff, R, L, Cc, gw, gb, tg->scratch, st);   // sums over the rays, straight into the channel-major tables
   };
   // Conv1d(k = 3, padding 1) weight (co, ci_total, 3): one product per tap, the input rows shifted by tap - 1 inside each ray
   auto conv_wg = [&](int li, const float* dY, int co, const float* X, int ci, int ci_total, int ci0, int L, bool bias) -> int {
@@ -1242,9 +1239,10 @@ int unet_backward_only(const Ctx& xb, const Ctx& x32, const float* in, int64_t R
     float* gb = tg && bias ? tg->w[T_UNET + 4 * li + 1] : nullptr;
     if (!gw && gb) return nl_launch_colsum(dY, co, R * L, co, gb, tg->scratch, st);
     if (!gw) return NL_OK;
-    for (int k = 0; k < 3; ++k)
-      NL_TRY(nl_launch_wgrad(dY, co, co, X, ci, ci, R * L, k - 1, L, gw, ci_total * 3, 3, ci0 * 3 + k, k == 1 ? gb : nullptr, tg->scratch, tg->scratch_floats, st));
-    return NL_OK;
+    const float* dys[3] = {dY, dY, dY};
+    const float* xs[3] = {X, X, X};
+    const int sh[3] = {-1, 0, 1}, cos_[3] = {ci0 * 3, ci0 * 3 + 1, ci0 * 3 + 2};
+    return nl_launch_wgrad_multi(3, dys, co, co, xs, ci, ci, R * L, sh, L, gw, ci_total * 3, 3, cos_, gb, 1, tg->scratch, tg->scratch_floats, st);   // the three taps
   };
   // ConvTranspose1d(k = 3, stride 2, padding 1, output_padding 1) weight (ci_total, co, 3): y[2m] = x[m] w1, y[2m+1] = x[m] w2 + x[m+1] w0;
   // gy = the merged rows (R Li, 2 co) [even | odd]
@@ -1252,9 +1250,10 @@ int unet_backward_only(const Ctx& xb, const Ctx& x32, const float* in, int64_t R
     float* gw = tg ? tg->w[T_UNET + 4 * li] : nullptr;
     if (!gw) return NL_OK;
     float* base = gw + (size_t)ci0 * co * 3;
-    NL_TRY(nl_launch_wgrad(X, ci, ci, gy, 2 * co, co, R * Li, 0, 0, base, co * 3, 3, 1, nullptr, tg->scratch, tg->scratch_floats, st));
-    NL_TRY(nl_launch_wgrad(X, ci, ci, gy + co, 2 * co, co, R * Li, 0, 0, base, co * 3, 3, 2, nullptr, tg->scratch, tg->scratch_floats, st));
-    return nl_launch_wgrad(X, ci, ci, gy + co, 2 * co, co, R * Li, -1, Li, base, co * 3, 3, 0, nullptr, tg->scratch, tg->scratch_floats, st);
+    const float* dys[3] = {X, X, X};                       // (operand roles swapped: the weight's rows are the INPUT channels)
+    const float* xs[3] = {gy, gy + co, gy + co};
+    const int sh[3] = {0, 0, -1}, cos_[3] = {1, 2, 0};
+    return nl_launch_wgrad_multi(3, dys, ci, ci, xs, 2 * co, co, R * Li, sh, Li, base, co * 3, 3, cos_, nullptr, -1, tg->scratch, tg->scratch_floats, st);
   };
   auto convT_bias = [&](int li, const float* gy, int co, int Lo) -> int {
     float* gb = tg ? tg->w[T_UNET + 4 * li + 1] : nullptr;

@@ -597,7 +597,39 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   if (zz == 0 && c < M) out[c] += ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
 }
 
+// the same final pass for the U-Net's LayerNorm tables: columns [0, n) / [n, 2 n) are the (L, Cc) position-major sums of d gamma / d beta; the state_dict's
+// tables are channel-major: gw[c][l] += column l Cc + c
+__global__ __launch_bounds__(256) void colsum_final_tables_kernel(const float* __restrict__ part, int nslab, int L, int Cc, float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, zz = threadIdx.x >> 5;
+  const int n = L * Cc, c = blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (c < 2 * n)
+    for (int z = zz; z < nslab; z += 8) s += part[(size_t)z * 2 * n + c];
+  red[zz][el] = s;
+  __syncthreads();
+  if (zz != 0 || c >= 2 * n) return;
+  const float v = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+  const int e = c < n ? c : c - n;
+  float* g = c < n ? gw : gb;
+  if (g) { const int l = e / Cc, ch = e - l * Cc; g[(size_t)ch * L + l] += v; }
+}
+
 }  // namespace
+
+// gw (Cc, L) / gb (Cc, L) += the column sums of Y (rows, 2 L Cc) [d gamma | d beta], position-major; scratch: 256 * 2 L Cc floats.  Either table may be null.
+int nl_launch_colsum_tables(const float* Y, int64_t rows, int L, int Cc, float* gw, float* gb, float* scratch, hipStream_t st) {
+  if (rows <= 0 || L <= 0 || Cc <= 0) return NL_OK;
+  const int M = 2 * L * Cc;
+  int nslab = (int)(nl_cdiv(rows, 64) < 256 ? nl_cdiv(rows, 64) : 256);
+  const long long slab = nl_cdiv(rows, nslab);
+  nslab = (int)nl_cdiv(rows, slab);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)nl_cdiv(M, 64), (unsigned)nslab), dim3(256), 0, st, Y, M, (long long)rows, M, slab, scratch);
+  NL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_tables_kernel, dim3((unsigned)nl_cdiv(M, 32)), dim3(256), 0, st, scratch, nslab, L, Cc, gw, gb);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
 
 // out (M) += column sums of Y (rows, M; ld ldy); scratch: 256 * M floats
 int nl_launch_colsum(const float* Y, int ldy, int64_t rows, int M, float* out, float* scratch, hipStream_t st) {

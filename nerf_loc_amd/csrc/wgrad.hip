@@ -30,12 +30,14 @@ constexpr int WG_KG = 4 * WG_S;         // bytes per k-group (8 rows)
 constexpr int WG_PLANE = 4 * WG_KG;     // hi plane, then lo plane
 constexpr int WG_LDS = 2 * WG_PLANE;
 
+// up to three products of one shape in a launch (the taps of a convolution, the phases of a transposed one): blockIdx.z = sub * nsplit + split
 struct WgArgs {
-  const float* dY; int ldy; int M;
-  const float* X; int ldx; int N;
+  const float* dY[3]; int ldy; int M;
+  const float* X[3]; int ldx; int N;
   long long rows, rows_per_split;
-  int shift, period;
-  float* part;    // [nsplit][M][N]
+  int shift[3], period;
+  int nsplit, bias_sub;   // bias_sub: the sub-problem whose dY also gives the bias gradient (or -1)
+  float* part;    // [sub][nsplit][M][N]
   float* bpart;   // [nsplit][M] or null
 };
 
@@ -54,13 +56,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
   const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
   const bool isA = cg < 32;
   const int col0 = isA ? m0 + 4 * cg : n0 + 4 * (cg - 32);
-  const float* src = isA ? a.dY : a.X;
+  const int sub = blockIdx.z / a.nsplit, zsp = blockIdx.z - sub * a.nsplit;
+  const float* src = isA ? a.dY[sub] : a.X[sub];
   const int ld = isA ? a.ldy : a.ldx;
   const bool colok = col0 < (isA ? a.M : a.N);    // (the float4 may run up to 3 columns past M / N — inside the row, ld is a multiple of 4 — and is dropped at the end)
-  const int shift = isA ? 0 : a.shift;
-  const long long r_begin = (long long)blockIdx.z * a.rows_per_split;
+  const int shift = isA ? 0 : a.shift[sub];
+  const long long r_begin = (long long)zsp * a.rows_per_split;
   const long long r_end = min(a.rows, r_begin + a.rows_per_split);
-  const bool want_bias = a.bpart && blockIdx.y == 0 && isA;
+  const bool has_bias = a.bpart && sub == a.bias_sub;
+  const bool want_bias = has_bias && blockIdx.y == 0 && isA;
 
   float4 ld_[8];
   auto fetch = [&](long long r0) {
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
         }
     }
   }
-  float* part = a.part + (size_t)blockIdx.z * a.M * a.N;
+  float* part = a.part + (size_t)blockIdx.z * a.M * a.N;   // (= [sub][split])
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -144,13 +148,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
         if (m < a.M && n < a.N) part[(size_t)m * a.N + n] = acc[x][y][r];
       }
     }
-  if (a.bpart && blockIdx.y == 0) {
+  if (has_bias && blockIdx.y == 0) {
     if (isA) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) bsum[kg][4 * cg + c] = bs[c];
     }
     __syncthreads();
-    if (tid < 128 && m0 + tid < a.M) a.bpart[(size_t)blockIdx.z * a.M + m0 + tid] = (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
+    if (tid < 128 && m0 + tid < a.M) a.bpart[(size_t)zsp * a.M + m0 + tid] = (bsum[0][tid] + bsum[1][tid]) + (bsum[2][tid] + bsum[3][tid]);
   }
 }
 
@@ -165,13 +169,15 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgArgs a) {
   const int cg = tid & 15, kg = tid >> 4;          // loader role: columns 4 cg .. + 3 of the 64 (32 of dY | 32 of X), rows 8 kg .. + 7 of the 128
   const bool isA = cg < 8;
   const int col0 = isA ? 4 * cg : 4 * (cg - 8);
-  const float* src = isA ? a.dY : a.X;
+  const int sub = blockIdx.z / a.nsplit, zsp = blockIdx.z - sub * a.nsplit;
+  const float* src = isA ? a.dY[sub] : a.X[sub];
   const int ld = isA ? a.ldy : a.ldx;
   const bool colok = col0 < (isA ? a.M : a.N);
-  const int shift = isA ? 0 : a.shift;
-  const long long r_begin = (long long)blockIdx.z * a.rows_per_split;
+  const int shift = isA ? 0 : a.shift[sub];
+  const long long r_begin = (long long)zsp * a.rows_per_split;
   const long long r_end = min(a.rows, r_begin + a.rows_per_split);
-  const bool want_bias = a.bpart && isA;
+  const bool has_bias = a.bpart && sub == a.bias_sub;
+  const bool want_bias = has_bias && isA;
   float4 ld_[8];
   auto fetch = [&](long long r0) {
 #pragma unroll
@@ -244,21 +250,25 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgArgs a) {
     const int m = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3), n = l & 31;
     if (m < a.M && n < a.N) part[(size_t)m * a.N + n] = v;
   }
-  if (a.bpart && tid < 32 && tid < a.M) {
+  if (has_bias && tid < 32 && tid < a.M) {
     float v = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) v += bsum[g][tid];
-    a.bpart[(size_t)blockIdx.z * a.M + tid] = v;
+    a.bpart[(size_t)zsp * a.M + tid] = v;
   }
 }
 
-// gW[m * ldc + n * cs + co] += sum_z part[z][m][n]  (fixed order);  gb[m] += sum_z bpart[z][m]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int nsplit, int M, int N,
-                                                           float* __restrict__ gW, int ldc, int cs, int co, float* __restrict__ gb) {
+// gW[m * ldc + n * cs + co[sub]] += sum_z part[sub][z][m][n]  (fixed order; sub = blockIdx.y);  gb[m] += sum_z bpart[z][m] (with sub bias_sub)
+struct WgCo { int co[3]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part_all, const float* __restrict__ bpart, int nsplit, int M, int N,
+                                                           float* __restrict__ gW, int ldc, int cs, const WgCo co, int bias_sub, float* __restrict__ gb) {
   // 32 elements per block, 8 threads each over interleaved row ranges, combined in a fixed order
   __shared__ float red[8][32];
   const int el = threadIdx.x & 31, zz = threadIdx.x >> 5;
-  const int tot = M * N + (gb && bpart ? M : 0);
+  const int sub = blockIdx.y;
+  const float* part = part_all + (size_t)sub * nsplit * M * N;
+  const bool wb = gb && bpart && sub == bias_sub;
+  const int tot = M * N + (wb ? M : 0);
   const int e = blockIdx.x * 32 + el;
   float s = 0.f;
   if (e < tot) {
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   if (zz == 0 && e < tot) {
     const float v = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
-    if (e < M * N) { const int m = e / N, n = e - m * N; gW[(size_t)m * ldc + (size_t)n * cs + co] += v; }
+    if (e < M * N) { const int m = e / N, n = e - m * N; gW[(size_t)m * ldc + (size_t)n * cs + co.co[sub]] += v; }
     else gb[e - M * N] += v;
   }
 }
@@ -286,30 +296,44 @@ size_t nl_wgrad_scratch_floats(int64_t rows, int M, int N) {
 
 // gW (M, ldc...) += dY^T X over `rows` rows; gb (M) += column sums of dY (gb may be null).  ldy, ldx multiples of 4, pointers 16-byte aligned.
 // X rows are read at r + shift when period > 0 and (r % period) + shift stays inside [0, period), else as zero.
-int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
-                    float* gb, float* scratch, size_t scratch_floats, hipStream_t st) {
-  if (rows <= 0 || M <= 0 || N <= 0) return NL_OK;
-  if ((ldy & 3) || (ldx & 3) || ((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return NL_ERR_UNSUPPORTED;
-  if ((shift != 0 && period <= 0) || rows >= (1ll << 31)) return NL_ERR_BAD_ARG;
+// nsub (1..3) products of one shape in ONE launch pair: dY[i], X[i], shift[i] -> gW[m * ldc + n * cs + co[i]]; gb from dY[bias_sub] (-1: none)
+int nl_launch_wgrad_multi(int nsub, const float* const* dY, int ldy, int M, const float* const* X, int ldx, int N, int64_t rows, const int* shift, int period,
+                          float* gW, int ldc, int cs, const int* co, float* gb, int bias_sub, float* scratch, size_t scratch_floats, hipStream_t st) {
+  if (rows <= 0 || M <= 0 || N <= 0 || nsub <= 0) return NL_OK;
+  if (nsub > 3) return NL_ERR_BAD_ARG;
+  if ((ldy & 3) || (ldx & 3)) return NL_ERR_UNSUPPORTED;
+  for (int i = 0; i < nsub; ++i) {
+    if (((uintptr_t)dY[i] & 15) || ((uintptr_t)X[i] & 15)) return NL_ERR_UNSUPPORTED;
+    if (shift[i] != 0 && period <= 0) return NL_ERR_BAD_ARG;
+  }
+  if (rows >= (1ll << 31)) return NL_ERR_BAD_ARG;
+  if (!gb) bias_sub = -1;
   const bool small = M <= 32 && N <= 32;
   const int nbm = small ? 1 : (int)nl_cdiv(M, 128), nbn = small ? 1 : (int)nl_cdiv(N, 128);
-  int nsplit = small ? 256 : 1024 / (nbm * nbn);
+  int nsplit = (small ? 256 : 1024 / (nbm * nbn)) / nsub;   // the same number of workgroups (and of partial tiles) whatever nsub is
   const int64_t maxsplit = nl_cdiv(rows, small ? 1024 : 256);
   if (nsplit > maxsplit) nsplit = (int)maxsplit;
-  if (nsplit > 256) nsplit = 256;
+  if (nsplit > 256 / nsub) nsplit = 256 / nsub;
   if (nsplit < 1) nsplit = 1;
-  if ((size_t)nsplit * ((size_t)M * N + M) > scratch_floats) return NL_ERR_WORKSPACE;
+  if ((size_t)nsub * nsplit * ((size_t)M * N) + (size_t)nsplit * M > scratch_floats) return NL_ERR_WORKSPACE;
   WgArgs a;
-  a.dY = dY; a.ldy = ldy; a.M = M; a.X = X; a.ldx = ldx; a.N = N; a.rows = rows;
+  WgCo cc;
+  for (int i = 0; i < 3; ++i) { const int j = i < nsub ? i : 0; a.dY[i] = dY[j]; a.X[i] = X[j]; a.shift[i] = shift[j]; cc.co[i] = co[j]; }
+  a.ldy = ldy; a.M = M; a.ldx = ldx; a.N = N; a.rows = rows;
   a.rows_per_split = nl_align_up((size_t)nl_cdiv(rows, nsplit), 128);
   nsplit = (int)nl_cdiv(rows, a.rows_per_split);
-  a.shift = shift; a.period = period > 0 ? period : 1;
-  a.part = scratch; a.bpart = gb ? scratch + (size_t)nsplit * M * N : nullptr;
-  if (small) hipLaunchKernelGGL(wgrad_small_kernel, dim3(1, 1, nsplit), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad_kernel, dim3(nbm, nbn, nsplit), dim3(256), 0, st, a);
+  a.period = period > 0 ? period : 1;
+  a.nsplit = nsplit; a.bias_sub = bias_sub;
+  a.part = scratch; a.bpart = gb ? scratch + (size_t)nsub * nsplit * M * N : nullptr;
+  if (small) hipLaunchKernelGGL(wgrad_small_kernel, dim3(1, 1, nsplit * nsub), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad_kernel, dim3(nbm, nbn, nsplit * nsub), dim3(256), 0, st, a);
   NL_LAUNCH_CHECK();
   const int tot = M * N + (gb ? M : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nl_cdiv(tot, 32)), dim3(256), 0, st, a.part, a.bpart, nsplit, M, N, gW, ldc, cs, co, gb);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nl_cdiv(tot, 32), nsub), dim3(256), 0, st, a.part, a.bpart, nsplit, M, N, gW, ldc, cs, cc, bias_sub, gb);
   NL_LAUNCH_CHECK();
   return NL_OK;
+}
+int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
+                    float* gb, float* scratch, size_t scratch_floats, hipStream_t st) {
+  return nl_launch_wgrad_multi(1, &dY, ldy, M, &X, ldx, N, rows, &shift, period, gW, ldc, cs, &co, gb, 0, scratch, scratch_floats, st);
 }
