@@ -287,7 +287,8 @@ def main():
 
 def gradient_step(rnd, cfg, frame, rays, weights, dev):
     """Not the headline: one PoseOptimizer step (pose_optimizer.py:131-160: 512 rays, feature loss, forward + backward to the 4x4 pose) of the same
-    scene through the library's gradient path (fused forward, nl_render_rays_backward), after the timed region of the headline."""
+    scene through the library's gradient path (diff_render.RenderFn: nl_render_rays_forward_keep / nl_render_rays_backward_kept, replayed as two HIP graphs from
+    the second step on), after the timed region of the headline."""
     from nerf_loc_amd import diff_render as dr
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     Rg = min(512, cfg.R)
@@ -315,7 +316,7 @@ def gradient_step(rnd, cfg, frame, rays, weights, dev):
         g = one()
     torch.cuda.synchronize(dev)
     return {"what": f"PoseOptimizer step: {Rg} rays x {cfg.S} samples, forward + backward to the pose, frozen weights", "ms_per_step": (time.perf_counter() - t0) / n * 1e3,
-            "grad_finite": bool(torch.isfinite(g).all()), "path": "nl_render_rays (fused forward) + nl_render_rays_backward"}
+            "grad_finite": bool(torch.isfinite(g).all()), "path": "RenderFn: nl_render_rays_forward_keep + nl_render_rays_backward_kept (two HIP graphs from the second step on)"}
 
 
 def baseline_metric() -> str:
