@@ -165,7 +165,9 @@ int nl_get_rays(const float* K, const float* c2w, const float* uv, int H, int W,
 /* A frame keeps the DEVICE pointers of the descriptor (images, feature maps, support points: they must stay alive and unchanged
  * while the frame is used — call nl_frame_create again when the data changes) plus tables derived from them in frame_mem
  * (visibility maps repacked, KNN grid, and — built lazily on the first render with a given packed-weights blob and rebuilt when
- * that blob is re-packed — the per-point table T and the blend-projected feature maps).  A frame also owns the side stream (+ two
+ * that blob is re-packed — the per-point table T and the blend-projected feature maps; plus the scratch the training backward needs
+ * per support point: d loss / d T (M, W) and (M, align32(C + 3)) staging rows, used by nl_*_backward_train / nl_render_rays_backward in
+ * every mode but fp32).  A frame also owns the side stream (+ two
  * events) on which nl_render_rays runs the exact KNN beside the multi-view gather: created here, destroyed by nl_frame_destroy —
  * render calls never create streams or events (safe inside hipGraph capture from the first call on).  One frame must not be rendered
  * from two host threads / caller streams at the same time (like the reference module, a frame is not re-entrant); different frames are
