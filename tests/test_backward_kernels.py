@@ -147,7 +147,7 @@ def test_point_branch_backward_matches_autograd(case, precision, tol):
 def _mv_setup(case, precision="fp32", R_max=10):
     from nerf_loc_amd.renderer import HipRenderer
     from tests.golden_cases import build_case
-    c = build_case(case)
+    c = _view_count_case(case) if case.startswith("v") else build_case(case)
     cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
     dev = torch.device("cuda:0")
     r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
@@ -359,7 +359,8 @@ def test_point_branch_weight_gradients_match_autograd(case, precision, chunk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("offview", "fp32", None), ("c1", "fp32", 70), ("c1", "bf16x3", None)])
+@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("offview", "fp32", None), ("c1", "fp32", 70), ("c1", "bf16x3", None),
+                                                  ("v16", "bf16x3", None), ("v12", "bf16x3", 50), ("w128s64", "bf16x3", None)])
 def test_mv_aggregate_weight_gradients_match_autograd(case, precision, chunk):
     """nl_mv_aggregate_backward_train: gradients of out_fc, of the four NeuRay decoders (24 tensors), of the support feature maps (grid_sample's backward)
     and of the DepthFusionNet maps against autograd of diff_render._mv_aggregate in fp64."""
@@ -386,7 +387,8 @@ def test_mv_aggregate_weight_gradients_match_autograd(case, precision, chunk):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("offview", "fp32", None), ("c1", "fp32", 70), ("c1", "bf16x3", None)])
+@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("offview", "fp32", None), ("c1", "fp32", 70), ("c1", "bf16x3", None),
+                                                  ("v16", "bf16x3", None), ("w128s64", "bf16x3", None)])
 def test_blend_weight_gradients_match_autograd(case, precision, chunk):
     """nl_blend_backward_train: gradients of rgb_blending_mlp (layer 1's feature columns through the blend-projected maps, whose gradient the library returns
     as a map), the decoders, the feature maps and the DepthFusionNet maps against autograd of the eager blend in fp64."""
@@ -448,17 +450,29 @@ def test_ray_unet_weight_gradients_match_autograd(case, precision, chunk):
     _assert_param_grads({k: v.clone() for k, v in tg.weights.items()}, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=True)
 
 
+def _view_count_case(name):
+    """tiny scenes with 16 / 12 / 3 support views ("v16", "v12", "v3w64": the 16- and 4-view instantiations of the kernels whose shared-memory footprint and
+    view loops depend on the bucket — the training scatter of mv_geom_backward_kernel keeps one slot per view in LDS: 118 KB at 16)."""
+    from nerf_loc_amd.synth import make_frame, make_rays, make_weights
+    from tests.golden_cases import CASES
+    V = int("".join(ch for ch in name[1:3] if ch.isdigit()))
+    cfg = CASES["tiny_full"][0].replace(name=name, V=V, W=64 if name.endswith("w64") else 32, seed=900 + V)
+    frame = make_frame(cfg)
+    return {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,precision,train,chunk", [("tiny_full", "fp32", False, None), ("tiny_full", "fp32", False, 4), ("fewpts", "fp32", True, None),
                                                         ("tiny_full", "fp32", True, 5), ("offview", "bf16x3", False, 2), ("c1", "fp32", True, 3),
                                                         ("c1", "fp32", True, None), ("c1", "bf16x3", True, None), ("w128s64", "bf16x3", False, None), ("w128s64", "fp32", True, None),
-                                                        ("s192out", "fp32", True, 2), ("w256s128", "fp32", True, None)])
+                                                        ("s192out", "fp32", True, 2), ("w256s128", "fp32", True, None),
+                                                        ("v16", "bf16x3", True, None), ("v12", "bf16x3", True, 3), ("v3w64", "bf16x3", True, None)])
 def test_whole_path_backward_matches_the_stage_nodes(case, precision, train, chunk):
     """nl_render_rays_backward (one call for the whole path: RenderFn) against the chain of per-stage autograd nodes + eager heads: the same
     gradients w.r.t. the rays, the query pose and — train — every parameter tensor, the maps and the support features."""
     from nerf_loc_amd.renderer import HipRenderer
     from tests.golden_cases import build_case
-    c = build_case(case)
+    c = _view_count_case(case) if case.startswith("v") else build_case(case)
     cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
     dev = torch.device("cuda:0")
     r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
