@@ -1,6 +1,6 @@
 """Time one PoseOptimizer step (pose_optimizer.py:131-160: 512 rays, forward + backward to the pose) through the drop-in module's
 gradient path on the c2 scene, next to the HIP forward alone.  python tools/pose_refine_bench.py [rays] [steps]"""
-import os, sys, time
+import gc, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_loc_amd import diff_render as dr
@@ -38,6 +38,7 @@ res = {}
 for frozen in (False, True):   # False: everything eager (round 2); True: the whole path as one library node (diff_render.RenderFn)
     torch.cuda.reset_peak_memory_stats()
     for _ in range(2): step(frozen)
+    gc.collect()   # (no generation-2 pass of the interpreter inside the timed steps: tools/train_step_bench.py)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): g = step(frozen)
     t_issue = (time.perf_counter() - t0) / steps

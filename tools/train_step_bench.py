@@ -1,7 +1,7 @@
 """Time the render part of one training step (compute_render_loss, model.py:641-685: N_rand = 1024 rays x 64 samples, forward + backward to
 every parameter of the ray path, the feature maps, the DepthFusionNet maps and the support table) on the gradient path of the drop-in, with the
 library's training nodes (diff_render.*TrainFn) against the all-eager fp32 graph.  python tools/train_step_bench.py [rays] [samples] [W] [steps]"""
-import os, sys, time
+import gc, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_loc_amd import diff_render as dr
@@ -11,7 +11,7 @@ from nerf_loc_amd.synth import CONFIGS, make_frame, make_rays, make_weights
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 cfg = CONFIGS["c2"].replace(S=S, W=W)
 dev = torch.device("cuda:0")
 frame, weights = make_frame(cfg), make_weights(cfg)
@@ -50,6 +50,10 @@ res = {}
 for hip in (False, True):
     torch.cuda.reset_peak_memory_stats()
     for _ in range(2): step(hip)
+    # one full collection now: the eager pass leaves ~10^5 objects behind, and the generation-2 pass they eventually trigger (40-50 ms, the GPU idle
+    # meanwhile) used to land inside the five timed steps of the library's pass whenever the allocation count happened to cross the threshold there —
+    # +8 ms per step and a CPU "issue time" of 10-14 ms that earlier docs of this repo blamed on the host's load
+    gc.collect()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): l, gs = step(hip)
     t_issue = time.perf_counter() - t0
