@@ -19,6 +19,7 @@ q-projection counted once) / mean step duration from HIP events on the launch st
 timed on rank 0's host cores over a bounded ray sample of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -179,6 +180,10 @@ def main():
         for _ in range(warmup):
             step()
         drain()
+        # the interpreter's cyclic collector stays out of the timed region, as in timeit: a generation-2 pass is 40-50 ms of host time with the GPU idle
+        # (one landed in the gradient bench's five timed steps whenever its allocation counter happened to cross the threshold there)
+        gc.collect()
+        gc.disable()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -193,6 +198,7 @@ def main():
         if world > 1:
             dist.barrier()
         wall = time.perf_counter() - t0
+        gc.enable()
         dev_ms = ev0.elapsed_time(ev1)
         if world > 1:
             t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
@@ -309,6 +315,7 @@ def gradient_step(rnd, cfg, frame, rays, weights, dev):
         return torch.autograd.grad(loss, pose)[0]
     for _ in range(2):
         one()
+    gc.collect()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     n = 5
