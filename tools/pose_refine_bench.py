@@ -1,5 +1,5 @@
 """Time one PoseOptimizer step (pose_optimizer.py:131-160: 512 rays, forward + backward to the pose) through the drop-in module's
-gradient path on the c2 scene, next to the HIP forward alone.  python tools/pose_refine_bench.py [rays] [steps]"""
+gradient path on the c2 scene, next to the HIP forward alone.  python tools/pose_refine_bench.py [rays] [steps] [precision]"""
 import gc, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,8 @@ cfg = CONFIGS["c2"]
 dev = torch.device("cuda:0")
 frame, weights, rays = make_frame(cfg), make_weights(cfg), make_rays(cfg, make_frame(cfg))
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "bf16x3")
+precision = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
 r.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
 r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
 p = {k: t(v) for k, v in weights.items()}
