@@ -291,7 +291,8 @@ int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_fra
  * buffers: the caller zero-fills them once per step, every call — and every workspace chunk inside a call — accumulates.  Weight
  * gradients are reduced in a fixed order (split-K partial tiles, no atomics); the table gradients are scatter-adds (atomics, like
  * index_add / grid_sample's backward in the reference's autograd).  `packed` must hold the CURRENT weights (nl_pack_weights after every
- * optimizer step: ~0.5 ms). */
+ * optimizer step: ~0.5 ms).  The weight-gradient products read their operands as 16-byte rows: nl_config.C must be a multiple of 4 here
+ * (NL_ERR_UNSUPPORTED otherwise; the forward and the frozen-weight gradients take any C <= 192). */
 typedef struct nl_train_grads {
   float* const* weights;     /* HOST array of nl_num_weights() DEVICE pointers, tensor i laid out like state_dict[nl_weight_name(i)];
                               * NULL entries (and a NULL array) = that gradient is not wanted */

@@ -1600,10 +1600,16 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.block(G_FEAT0_T, 0, t[T_F0W], 0, 1, W, W);
   P.block(G_FEAT2_T, 0, t[T_F2W], 0, 1, W, C);
   {
-    const GemmDim& d = L.g[G_OUTFC0_T];   // out_fc.0.weight (64, 2F + 3): element [k = o][n = i]; no streaming layout (N > 256)
+    // out_fc.0.weight (64, 2F + 3): element [k = o][n = i].  416 columns at C = 192: generic kernels, no streaming layout; a narrower feature map (C <= 123) puts
+    // the product on the streaming kernel, whose weight stream must then exist (it was left zero-filled until tools/grad_fuzz.py: every gradient through the
+    // statistics rows vanished for such C in the non-fp32 modes)
+    const GemmDim& d = L.g[G_OUTFC0_T];
+    const bool stream = d.N <= 256;
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(64 * (2 * F + 3), 256)), dim3(256), 0, st, t[T_OUT0W], 0, 1, 2 * F + 3, 64, 2 * F + 3, 0,
                        (float*)((char*)packed + L.b32[G_OUTFC0_T]), (unsigned short*)((char*)packed + L.bhi[G_OUTFC0_T]),
-                       (unsigned short*)((char*)packed + L.blo[G_OUTFC0_T]), d.Kpad, d.Npad, (unsigned short*)nullptr, 8, 0);
+                       (unsigned short*)((char*)packed + L.blo[G_OUTFC0_T]), d.Kpad, d.Npad,
+                       stream ? (unsigned short*)((char*)packed + L.bst[G_OUTFC0_T]) : (unsigned short*)nullptr, nl_tgemm_nrt(d.N), 0, 0,
+                       stream ? (unsigned short*)((char*)packed + L.bsh[G_OUTFC0_T]) : (unsigned short*)nullptr);
   }
   {
     const GemmDim& d = L.g[G_BLENDA_T];   // the feature_agg columns of rgb_blending_mlp.0.weight (32, W + F + 5)

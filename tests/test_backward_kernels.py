@@ -1,6 +1,7 @@
 """HIP backward kernels, first slice: nl_composite_backward and nl_knn_backward against PyTorch autograd of the same
 expressions (fp32 and, as the yardstick for rounding, fp64).  End to end they run inside the gradient path: the pose / training-step
 gradient tests of tests/test_diff_render.py compare that path with the reference's own autograd goldens."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -360,7 +361,8 @@ def test_point_branch_weight_gradients_match_autograd(case, precision, chunk):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("offview", "fp32", None), ("c1", "fp32", 70), ("c1", "bf16x3", None),
-                                                  ("v16", "bf16x3", None), ("v12", "bf16x3", 50), ("w128s64", "bf16x3", None)])
+                                                  ("v16", "bf16x3", None), ("v12", "bf16x3", 50), ("w128s64", "bf16x3", None), ("v5c64", "bf16x3", None),
+                                                  ("v4c100", "bf16x3", None), ("v3c8", "bf16x3", None)])
 def test_mv_aggregate_weight_gradients_match_autograd(case, precision, chunk):
     """nl_mv_aggregate_backward_train: gradients of out_fc, of the four NeuRay decoders (24 tensors), of the support feature maps (grid_sample's backward)
     and of the DepthFusionNet maps against autograd of diff_render._mv_aggregate in fp64."""
@@ -456,7 +458,8 @@ def _view_count_case(name):
     from nerf_loc_amd.synth import make_frame, make_rays, make_weights
     from tests.golden_cases import CASES
     V = int("".join(ch for ch in name[1:3] if ch.isdigit()))
-    cfg = CASES["tiny_full"][0].replace(name=name, V=V, W=64 if name.endswith("w64") else 32, seed=900 + V)
+    C = int(name.split("c")[1]) if "c" in name[1:] else 192      # "v5c64": feature maps narrower than the reference's 192 channels
+    cfg = CASES["tiny_full"][0].replace(name=name, V=V, W=64 if name.endswith("w64") else 32, C=C, seed=900 + V)
     frame = make_frame(cfg)
     return {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
 
@@ -658,3 +661,46 @@ def test_graphed_refinement_steps_equal_the_ungraphed_ones():
             assert torch.equal(x, y)
     finally:
         dr.USE_GRAPHS = True
+
+
+@pytest.mark.gpu
+def test_random_scenes_training_gradients_match_eager_autograd():
+    """tools/grad_fuzz.py on a few random scenes: widths 32 ... 256, 1 ... 16 views, feature maps of 8 ... 192 channels, support sets smaller than K, odd
+    ray counts — every gradient of the whole-path training node in the parity mode and in the fp32 mode against autograd of the eager graph (the fixed cases
+    all use 192-channel maps; for C <= 123 a transposed product changes kernels, and its weight stream was missing until this check existed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("grad_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "grad_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(8, 7, verbose=False) < 5e-2
+
+
+@pytest.mark.gpu
+def test_training_refuses_feature_widths_that_are_not_multiples_of_four():
+    """The weight-gradient products read their operands as 16-byte rows: a feature width C with C % 4 != 0 (the forward and the frozen-weight gradients take it)
+    is refused by the training entry points with NL_ERR_UNSUPPORTED — loudly, not with wrong gradients."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from nerf_loc_amd.synth import SceneConfig, make_frame, make_rays, make_weights
+    cfg = SceneConfig("c31", R=8, S=32, W=64, V=5, H=32, Wimg=56, C=31, seed=77)
+    frame, weights = make_frame(cfg), make_weights(cfg)
+    rays = make_rays(cfg, frame)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "bf16x3")
+    r.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
+    fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}})
+    lin = torch.linspace(0, 1, cfg.S_total, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(8, cfg.S_total).contiguous()
+    for train in (False, True):
+        p = {k: t(v).requires_grad_(train) for k, v in weights.items()}
+        o, d, pose = t(rays["rays_o"][:8]).requires_grad_(True), t(rays["rays_d"][:8]).requires_grad_(True), t(frame["pose"]).clone().requires_grad_(True)
+        out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], frozen_renderer=None if train else r, train_renderer=r if train else None, whole_path=True)
+        loss = out["rgb"].sum() + out["feat"].sum()
+        if train:
+            with pytest.raises(RuntimeError, match="unsupported shape or option"):
+                torch.autograd.grad(loss, [o, d, pose] + [p[n] for n in dr.RENDER_PARAMS], allow_unused=True)
+        else:
+            g = torch.autograd.grad(loss, [o, d, pose])
+            assert all(torch.isfinite(x).all() for x in g)
