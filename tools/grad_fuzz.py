@@ -20,11 +20,15 @@ def run(ncases=20, seed0=0, verbose=True):
     for case in range(ncases):
         rng = np.random.default_rng(seed0 * 1000 + case)
         W = int(rng.choice([32, 64, 128, 256])); S = int(8 * rng.integers(2, 13)); V = int(rng.integers(1, 17)); C = int(rng.choice([8, 32, 60, 64, 100, 124, 128, 192]))
+        # the path under test: frozen weights (PoseOptimizer) or training; the whole path as one node (keep / kept pair, or the chunking pair over a small
+        # workspace) or one node per stage.  Frozen weights also take feature widths that are not multiples of 4
+        train = bool(rng.random() < 0.6); variant = str(rng.choice(["keep", "chunk", "stages"]))
+        if not train and rng.random() < 0.4: C = int(rng.choice([7, 31, 61, 101]))
         H, Wimg = int(8 * rng.integers(3, 9)), int(8 * rng.integers(3, 12)); R = int(rng.integers(1, 14))
         if os.environ.get("FORCE"):   # "W,S,V,C,H,Wimg,R"
             W, S, V, C, H, Wimg, R = [int(x) for x in os.environ["FORCE"].split(",")]
         cfg = SceneConfig(f"fuzz{case}", R=max(R, 2), S=S, W=W, V=V, H=H, Wimg=Wimg, C=C, seed=5000 + seed0 * 1000 + case)
-        print(f"case {case} config: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R}", flush=True)
+        print(f"case {case} config: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R} {'train' if train else 'frozen'} {variant}", flush=True)
         frame = make_frame(cfg); rays = make_rays(cfg, frame); weights = make_weights(cfg)
         if rng.random() < 0.25:   # fewer support points than K
             m = int(rng.integers(1, 8)); frame["support_fine"] = {k: np.ascontiguousarray(v[:m]) for k, v in frame["support_fine"].items()}
@@ -39,17 +43,29 @@ def run(ncases=20, seed0=0, verbose=True):
             r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "fp32" if prec == "eager" else prec)
             r.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
             r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
-            p = {k: t(v).requires_grad_(True) for k, v in weights.items()}
+            p = {k: t(v).requires_grad_(train) for k, v in weights.items()}
             fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
             sp = {k: t(v) for k, v in frame["support_fine"].items()}
-            fr["feat_fine_src"].requires_grad_(True); fr["vis_featmaps"].requires_grad_(True); sp["feature"].requires_grad_(True)
+            if train: fr["feat_fine_src"].requires_grad_(True); fr["vis_featmaps"].requires_grad_(True); sp["feature"].requires_grad_(True)
             fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": sp})
             o, d, pose = o0.clone().requires_grad_(True), d0.clone().requires_grad_(True), t(frame["pose"]).clone().requires_grad_(True)
-            out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], train_renderer=None if prec == "eager" else r, whole_path=True, beta=True)
-            loss = sum((out[k] * cot[k]).sum() for k in cot) + (out["beta"] * cot["depth"]).sum()
-            leaves = {"rays_o": o, "rays_d": d, "pose": pose, "feat_fine_src": fr["feat_fine_src"], "vis_featmaps": fr["vis_featmaps"], "support.feature": sp["feature"]}
-            leaves.update({n: p[n] for n in dr.RENDER_PARAMS})
-            gs = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+            use_beta = train and variant != "chunk"
+            keep_bytes, orig_bw = dr.KEEP_BYTES, r.render_rays_backward
+            if variant == "chunk" and prec != "eager":
+                dr.KEEP_BYTES = 0
+                wr = int(rng.integers(1, max(2, R)))
+                r.render_rays_backward = lambda *a, _o=orig_bw, _w=wr, **k: _o(*a, workspace_rays=_w, **k)
+            try:
+                out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], frozen_renderer=r if (prec != "eager" and not train) else None,
+                                          train_renderer=r if (prec != "eager" and train) else None, whole_path=variant != "stages", beta=use_beta)
+                loss = sum((out[k] * cot[k]).sum() for k in cot) + ((out["beta"] * cot["depth"]).sum() if use_beta else 0.0)
+                leaves = {"rays_o": o, "rays_d": d, "pose": pose}
+                if train:
+                    leaves.update({"feat_fine_src": fr["feat_fine_src"], "vis_featmaps": fr["vis_featmaps"], "support.feature": sp["feature"]})
+                    leaves.update({n: p[n] for n in dr.RENDER_PARAMS})
+                gs = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+            finally:
+                dr.KEEP_BYTES = keep_bytes
             res[prec] = ({k: v.detach() for k, v in out.items()}, dict(zip(leaves.keys(), gs)))
             del r
         (oe, ge), (o32_, g32_) = res["eager"], res["fp32"]
@@ -76,7 +92,7 @@ def run(ncases=20, seed0=0, verbose=True):
         if os.environ.get("VERBOSE"): print("   ", sorted(((round(v, 4), k) for k, v in errs.items()), reverse=True)[:14])
         fwd = max(float((o16[k].float() - o32[k].float()).abs().max() / max(float(o32[k].float().abs().max()), 1e-6)) for k in cot)
         worst_all = max(worst_all, worst[1])
-        print(f"case {case}: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R} M={M}: forward {fwd:.1e}, worst gradient L2-rel {worst[1]:.2e} ({worst[0]})", flush=True)
+        print(f"case {case}: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R} M={M} {'train' if train else 'frozen'} {variant}: forward {fwd:.1e}, worst gradient L2-rel {worst[1]:.2e} ({worst[0]})", flush=True)
         if not os.environ.get("FORCE"): assert fwd < 3e-4 and worst[1] < 5e-2, "MISMATCH"
     if verbose: print("all cases passed; worst gradient L2-rel", worst_all)
     return worst_all
