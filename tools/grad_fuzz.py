@@ -19,11 +19,13 @@ def run(ncases=20, seed0=0, verbose=True):
     worst_all = 0.0
     for case in range(ncases):
         rng = np.random.default_rng(seed0 * 1000 + case)
-        W = int(rng.choice([32, 64, 128, 256])); S = int(8 * rng.integers(2, 13)); V = int(rng.integers(1, 17)); C = int(rng.choice([8, 32, 60, 64, 100, 124, 128, 192]))
+        W = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256])); S = int(8 * rng.integers(2, 13)) if rng.random() < 0.7 else int(8 * rng.integers(13, 33)); V = int(rng.integers(1, 17)); C = int(rng.choice([8, 32, 60, 64, 100, 124, 128, 192]))
         # the path under test: frozen weights (PoseOptimizer) or training; the whole path as one node (keep / kept pair, or the chunking pair over a small
         # workspace) or one node per stage.  Frozen weights also take feature widths that are not multiples of 4
         train = bool(rng.random() < 0.6); variant = str(rng.choice(["keep", "chunk", "stages"]))
         if not train and rng.random() < 0.4: C = int(rng.choice([7, 31, 61, 101]))
+        if os.environ.get("FORCE_VARIANT"):   # "train|frozen,keep|chunk|stages"
+            tv, variant = os.environ["FORCE_VARIANT"].split(","); train = tv == "train"
         H, Wimg = int(8 * rng.integers(3, 9)), int(8 * rng.integers(3, 12)); R = int(rng.integers(1, 14))
         if os.environ.get("FORCE"):   # "W,S,V,C,H,Wimg,R"
             W, S, V, C, H, Wimg, R = [int(x) for x in os.environ["FORCE"].split(",")]
