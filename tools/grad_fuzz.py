@@ -78,6 +78,7 @@ def run(ncases=20, seed0=0, verbose=True):
             l2 = float((a - b).norm() / max(float(b.norm()), 1e-5 * max(float(v.abs().max()) for v in ge.values() if v is not None)))
             if l2 > we[1]: we = (k, l2)
         print(f"   fp32 mode vs eager autograd: worst L2-rel {we[1]:.2e} ({we[0]})")
+        assert we[1] < 5e-2, "MISMATCH (fp32 mode)"
         (o32, g32), (o16, g16) = res["eager"], res["bf16x3"]
         gmax = max(float(v.abs().max()) for v in g32.values() if v is not None)
         worst = ("", 0.0)
