@@ -24,13 +24,14 @@ def run(ncases=20, seed0=0, verbose=True):
         # workspace) or one node per stage.  Frozen weights also take feature widths that are not multiples of 4
         train = bool(rng.random() < 0.6); variant = str(rng.choice(["keep", "chunk", "stages"]))
         if not train and rng.random() < 0.4: C = int(rng.choice([7, 31, 61, 101]))
+        white = bool(rng.random() < 0.3)
         if os.environ.get("FORCE_VARIANT"):   # "train|frozen,keep|chunk|stages"
             tv, variant = os.environ["FORCE_VARIANT"].split(","); train = tv == "train"
         H, Wimg = int(8 * rng.integers(3, 9)), int(8 * rng.integers(3, 12)); R = int(rng.integers(1, 14))
         if os.environ.get("FORCE"):   # "W,S,V,C,H,Wimg,R"
             W, S, V, C, H, Wimg, R = [int(x) for x in os.environ["FORCE"].split(",")]
         cfg = SceneConfig(f"fuzz{case}", R=max(R, 2), S=S, W=W, V=V, H=H, Wimg=Wimg, C=C, seed=5000 + seed0 * 1000 + case)
-        print(f"case {case} config: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R} {'train' if train else 'frozen'} {variant}", flush=True)
+        print(f"case {case} config: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R} {'train' if train else 'frozen'} {variant}{' white' if white else ''}", flush=True)
         frame = make_frame(cfg); rays = make_rays(cfg, frame); weights = make_weights(cfg)
         if rng.random() < 0.25:   # fewer support points than K
             m = int(rng.integers(1, 8)); frame["support_fine"] = {k: np.ascontiguousarray(v[:m]) for k, v in frame["support_fine"].items()}
@@ -59,7 +60,7 @@ def run(ncases=20, seed0=0, verbose=True):
                 r.render_rays_backward = lambda *a, _o=orig_bw, _w=wr, **k: _o(*a, workspace_rays=_w, **k)
             try:
                 out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], frozen_renderer=r if (prec != "eager" and not train) else None,
-                                          train_renderer=r if (prec != "eager" and train) else None, whole_path=variant != "stages", beta=use_beta)
+                                          train_renderer=r if (prec != "eager" and train) else None, whole_path=variant != "stages", beta=use_beta, white_bkgd=white)
                 loss = sum((out[k] * cot[k]).sum() for k in cot) + ((out["beta"] * cot["depth"]).sum() if use_beta else 0.0)
                 leaves = {"rays_o": o, "rays_d": d, "pose": pose}
                 if train:
