@@ -433,3 +433,15 @@ def test_one_training_step_with_both_losses_shares_the_frame_state():
     # (the library itself is bit-reproducible on identical inputs: 500 identical whole-path training calls).  That flip is allowed; nothing else is.
     big = {k: e for k, e in errs.items() if e >= 2e-3}
     assert worst[1] < 2e-2 and all(k.startswith(("ray_unet.conv1.", "ray_unet.conv2.")) for k in big), (worst, big)
+
+
+@pytest.mark.gpu
+def test_random_scenes_module_training_step_matches_the_eager_graph():
+    """tools/module_fuzz.py on a few random scenes (2 ... 6 views, feature widths 32 ... 192, hidden widths 32 ... 128): the drop-in module's training step —
+    query_coarse + query_fine + compute_render_loss, one backward — with the library's training nodes in the parity mode against the module's all-eager fp32
+    graph: losses, descriptors, every parameter's and both feature maps' gradients (the fixed module-level cases all use the reference's 192-channel maps)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("module_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "module_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(4, 3) < 5e-2
