@@ -54,6 +54,10 @@ def run(ncases=6, seed0=0, precision="bf16x3"):
             g = {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
             g["feat_fine_src"], g["feat_coarse_src"] = data["feat_fine_src"].grad.clone(), data["feat_coarse_src"].grad.clone()
             res[hip] = (float(loss.detach()), desc_c.detach(), desc_f.detach(), g)
+            if hip:   # eval mode: the inference entry points (no autograd; stage kernels without the training nodes) on the same points
+                net.eval()
+                with torch.no_grad():
+                    res["eval"] = (net.query_coarse(data, pts)[0].detach(), net.query_fine(data, pts)[0].detach())
         (l0, c0, f0, g0), (l1, c1, f1, g1) = res[False], res[True]
         gmax = max(float(v.abs().max()) for v in g0.values())
         worst = ("", 0.0)
@@ -65,6 +69,9 @@ def run(ncases=6, seed0=0, precision="bf16x3"):
             l2 = float((a - b).norm() / max(float(b.norm()), 1e-5 * gmax))
             if l2 > worst[1]: worst = (k, l2)
         dc = float((c1 - c0).abs().max() / c0.abs().max()); df = float((f1 - f0).abs().max() / f0.abs().max())
+        ec, ef = res["eval"]
+        dce = float((ec - c0).abs().max() / c0.abs().max()); dfe = float((ef - f0).abs().max() / f0.abs().max())
+        assert dce < 2e-3 and dfe < 2e-3, ("eval-mode descriptors", dce, dfe)
         print(f"case {case}: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R}: loss {l0:.6f} vs {l1:.6f}, desc {dc:.1e} / {df:.1e}, worst gradient L2-rel {worst[1]:.2e} ({worst[0]})", flush=True)
         assert abs(l1 - l0) < 2e-3 * abs(l0) and dc < 2e-3 and df < 2e-3 and worst[1] < 5e-2, "MISMATCH"
         worst_all = max(worst_all, worst[1])
