@@ -37,7 +37,11 @@ def run(ncases=6, seed0=0, precision="bf16x3"):
             data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
             data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
             data["feat_coarse_src"] = data["feat_coarse_src"].clone().requires_grad_(True)
-            data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8, "image": t(frame["image"]) if "image" in frame else None})
+            trng = np.random.default_rng(cfg.seed + 2000)
+            img = trng.random((3, cfg.H, cfg.Wimg)).astype(np.float32)
+            pyr = trng.standard_normal((1, cfg.C, cfg.H // 2, cfg.Wimg // 2)).astype(np.float32)
+            data.update({"embedding_a": None, "H": frame["H"], "W": frame["W"], "stride_fine": 4, "stride_coarse": 8,
+                         "sample_coords": t(rays["pixel_coordinates"]), "img": t(img), "feat_pyramid": {"layer1": t(pyr)}})
             torch.manual_seed(1234 + case)   # sample_rays draws the pixels
             net = ConditionalNeRF(_args(cfg), precision=precision).to(dev).train()
             net.hip_training = hip
@@ -45,20 +49,20 @@ def run(ncases=6, seed0=0, precision="bf16x3"):
             desc_c, _, _ = net.query_coarse(data, pts)
             desc_f, _, _ = net.query_fine(data, pts)
             loss = (desc_c * tc).sum() / len(pts) + (desc_f * tf).sum() / len(pts)
-            try:
-                lr = net.compute_render_loss(data)[0]
-                loss = loss + lr
-            except KeyError:
-                lr = None
+            lr = net.compute_render_loss(data)[0]
+            loss = loss + lr
             loss.backward()
             g = {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
             g["feat_fine_src"], g["feat_coarse_src"] = data["feat_fine_src"].grad.clone(), data["feat_coarse_src"].grad.clone()
-            res[hip] = (float(loss.detach()), desc_c.detach(), desc_f.detach(), g)
+            res[hip] = (float(loss.detach()), desc_c.detach(), desc_f.detach(), g, float(lr.detach()))
             if hip:   # eval mode: the inference entry points (no autograd; stage kernels without the training nodes) on the same points
                 net.eval()
                 with torch.no_grad():
                     res["eval"] = (net.query_coarse(data, pts)[0].detach(), net.query_fine(data, pts)[0].detach())
-        (l0, c0, f0, g0), (l1, c1, f1, g1) = res[False], res[True]
+                    img_out = net.render_image(data)   # the whole image through the fused inference path (one library call)
+                    assert all(torch.isfinite(v.float()).all() for v in img_out.values()), "render_image"
+                    res["image"] = img_out
+        (l0, c0, f0, g0, r0), (l1, c1, f1, g1, r1) = res[False], res[True]
         gmax = max(float(v.abs().max()) for v in g0.values())
         worst = ("", 0.0)
         for k, b in g0.items():
@@ -72,7 +76,7 @@ def run(ncases=6, seed0=0, precision="bf16x3"):
         ec, ef = res["eval"]
         dce = float((ec - c0).abs().max() / c0.abs().max()); dfe = float((ef - f0).abs().max() / f0.abs().max())
         assert dce < 2e-3 and dfe < 2e-3, ("eval-mode descriptors", dce, dfe)
-        print(f"case {case}: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R}: loss {l0:.6f} vs {l1:.6f}, desc {dc:.1e} / {df:.1e}, worst gradient L2-rel {worst[1]:.2e} ({worst[0]})", flush=True)
+        print(f"case {case}: W={W} S={S} V={V} C={C} {H}x{Wimg} R={R}: loss {l0:.6f} vs {l1:.6f} (render {r0:.6f} vs {r1:.6f}), desc {dc:.1e} / {df:.1e}, worst gradient L2-rel {worst[1]:.2e} ({worst[0]})", flush=True)
         assert abs(l1 - l0) < 2e-3 * abs(l0) and dc < 2e-3 and df < 2e-3 and worst[1] < 5e-2, "MISMATCH"
         worst_all = max(worst_all, worst[1])
     return worst_all
