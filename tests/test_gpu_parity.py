@@ -495,3 +495,15 @@ def test_repeated_renders_are_bit_identical(precision):
         else:
             for k in cur:
                 assert torch.equal(cur[k], first[k]), (precision, k)
+
+
+def test_random_scenes_forward_matches_the_cpu_oracle():
+    """tools/forward_fuzz.py on a few random scenes: hidden widths 32 ... 256 in steps of 32, 8 ... 64 samples with and without the hierarchical branch, 1 ... 16
+    views, feature widths 5 ... 192 (odd ones too), support sets smaller than K, white background, single rays — fp32 and the parity mode against the CPU
+    oracle at 1e-4 (hierarchical: the renderer on the oracle's resampled depths at 1e-4, the resampled depths themselves at 2e-4 of the range)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("forward_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "forward_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(12, 9, verbose=False) < 1e-4
