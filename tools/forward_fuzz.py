@@ -52,7 +52,15 @@ def run(ncases=20, seed0=0, verbose=True):
                 for k in ("rgb", "depth", "weights", "feat"):
                     assert rel_err(e2e[k].cpu().numpy(), ref[k].numpy()) < 1e-3, (case, precision, k, "end to end")
                 z = zo
-            out = r.render_rays(rays["rays_o"], rays["rays_d"], frame["pose"][:3, 3], z_vals=z, white_bkgd=white)
+            # options that must not change the result beyond their documented bounds: per-ray query centres (the same centre for every ray here), no side
+            # stream, early termination at 1e-5
+            opt = int(rng.integers(0, 4))
+            qc = frame["pose"][:3, 3]
+            kw = {}
+            if opt == 1: qc = np.ascontiguousarray(np.broadcast_to(qc, (R, 3)))
+            elif opt == 2: kw["side_stream"] = False
+            elif opt == 3: kw["early_term_eps"] = 1e-5
+            out = r.render_rays(rays["rays_o"], rays["rays_d"], qc, z_vals=z, white_bkgd=white, **kw)
             assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy()), (case, precision, "mask")
             for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
                 e = rel_err(out[k].cpu().numpy(), ref[k].numpy())
