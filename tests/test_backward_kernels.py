@@ -672,7 +672,7 @@ def test_random_scenes_training_gradients_match_eager_autograd():
     spec = importlib.util.spec_from_file_location("grad_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "grad_fuzz.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(8, 7, verbose=False) < 5e-2
+    assert mod.run(8, 7, verbose=False) < 5e-2    # (the criteria themselves — per tensor, against fp64 autograd with fp32 autograd as the yardstick — are asserted inside)
 
 
 @pytest.mark.gpu
