@@ -8,9 +8,11 @@ A "step" = one `render_rays` pass (rows a2-a18 of SURVEY.md §8; for a hierarchi
 pass + inverse-CDF resampling) over one batch of R rays whose inputs are already resident in HBM; per-frame setup (weight
 packing, KNN grid, map repack) is outside the timed region, like the reference's cached `support_neural_points` /
 `vis_featmaps`.  With N>1 the per-ray outputs are joined by ONE RCCL all-gather inside the timed step, and
-  --scaling weak   (default for c1/c2/c5): every rank renders its own R-ray batch of the same frame; value = N * R / step;
-  --scaling strong (default for c3/c4, BASELINE's "one batch sharded over 2/4/8 GPUs"): ONE R-ray batch, rank r renders
-                   shard_range(R, r, N); value = R / step.
+  --scaling strong (the default for every config since round 4: BASELINE's "rays/sec at 1/2/4/8 GPUs" asks how much faster ONE batch gets):
+                   ONE R-ray batch, rank r renders shard_range(R, r, N); value = R / step;
+  --scaling weak   every rank renders its own R-ray batch of the same frame; value = N * R / step (true by construction up to the all-gather).
+With --scaling auto (default) an N>1 run times BOTH: `value` / `ms_per_step` / `scaling` are the STRONG numbers, `weak_scaling` carries the weak
+ones in the same line (`scaling_modes: "both"`), and `allgather` the measured latency of the step's one collective on its own.
 Rank 0 prints one JSON line.
 
 `roofline`: bound = MFMA; achieved = ALGORITHMIC flops of one step (SURVEY.md §8(d) formula: GEMM/conv MACs x2,
@@ -53,7 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16", "f16mx"])
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gradient-step", action="store_true", help="skip the (untimed for the headline) PoseOptimizer-step measurement")
@@ -63,7 +65,7 @@ def main():
                     help="early-termination compositing threshold (nl_render_opts); default: 1e-5 for c5 (BASELINE names it there), 0 = off otherwise")
     ap.add_argument("--no-side-stream", action="store_true", help="NL_RENDER_NO_SIDE_STREAM: every kernel on one stream (profiling kernels one at a time)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
-                    help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: strong for c3/c4)")
+                    help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: BOTH are timed, value = strong)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -116,57 +118,62 @@ def main():
     cfg = CONFIGS[args.config]
     R = args.rays or cfg.R            # weak: rays per rank; strong: rays of the one batch
     S = cfg.S_total
-    scaling = args.scaling if args.scaling != "auto" else ("strong" if args.config in ("c3", "c4") else "weak")
+    both = args.scaling == "auto" and world > 1          # N > 1 by default: the strong pass is the headline, the weak pass rides in the same line
+    scaling = args.scaling if args.scaling != "auto" else "strong"
     frame = make_frame(cfg)
-    counts = None
-    if scaling == "strong" and world > 1:
-        rays = make_rays(cfg, frame, R=R, seed_offset=1000)   # the SAME batch on every rank ...
-        lo, hi = shard_range(R, rank, world)                   # ... of which this rank renders a contiguous range
-        counts = [shard_range(R, r, world)[1] - shard_range(R, r, world)[0] for r in range(world)]
-        rays = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == R else v) for k, v in rays.items()}
-        u_all = make_u(cfg, R)[lo:hi] if cfg.N_importance > 0 else None
-        R_local = hi - lo
-    else:
-        rays = make_rays(cfg, frame, R=R, seed_offset=1000 + rank)  # every rank its own batch of pixels
-        u_all = make_u(cfg, R) if cfg.N_importance > 0 else None
-        R_local = R
+
+    def make_batch(mode):
+        """Host-side rays of this rank for one scaling mode -> (rays, uniforms, rays on this rank, rays per rank or None)."""
+        if mode == "strong" and world > 1:
+            rr = make_rays(cfg, frame, R=R, seed_offset=1000)   # the SAME batch on every rank ...
+            lo, hi = shard_range(R, rank, world)                 # ... of which this rank renders a contiguous range
+            cnt = [shard_range(R, r, world)[1] - shard_range(R, r, world)[0] for r in range(world)]
+            rr = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == R else v) for k, v in rr.items()}
+            return rr, (make_u(cfg, R)[lo:hi] if cfg.N_importance > 0 else None), hi - lo, cnt
+        rr = make_rays(cfg, frame, R=R, seed_offset=1000 + rank)  # every rank its own batch of pixels
+        return rr, (make_u(cfg, R) if cfg.N_importance > 0 else None), R, None
+    rays, u_all, R_local, counts = make_batch(scaling)
     weights = make_weights(cfg)
 
     rnd = HipRenderer(cfg.W, cfg.C, S, args.precision, device=f"cuda:{local_rank}")
     rnd.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
     rnd.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"],
                   cfg.near, cfg.far, frame["support_fine"])
-    o = torch.from_numpy(rays["rays_o"]).to(dev)
-    d = torch.from_numpy(rays["rays_d"]).to(dev)
     Sb = cfg.S                        # base samples (model.py:483-484); hierarchical configs add N_importance resampled depths
     t_lin = torch.linspace(0, 1, Sb)
-    z = torch.tensor(cfg.near, dtype=torch.float32) * (1 - t_lin) + torch.tensor(cfg.far, dtype=torch.float32) * t_lin  # model.py:451-458
-    z = z.expand(R_local, Sb).contiguous().to(dev)
+    z_row = torch.tensor(cfg.near, dtype=torch.float32) * (1 - t_lin) + torch.tensor(cfg.far, dtype=torch.float32) * t_lin  # model.py:451-458
     qc = frame["pose"][:3, 3]
     hier = cfg.N_importance > 0
     et_eps = args.early_term_eps if args.early_term_eps >= 0 else (1e-5 if args.config == "c5" else 0.0)
-    if hier:   # model.py:487-496: coarse NeuRay weights along the pixel rays -> sample_pdf with FIXED uniforms -> sort(cat)
-        pix = torch.from_numpy(rays["pixel_coordinates"]).to(dev)
-        u_dev = torch.from_numpy(u_all).to(dev)
-        Kq, pose_q = torch.from_numpy(rays["K"]), torch.from_numpy(rays["pose"])
+
+    def to_device(rr, uu, n_local, cnt):
+        b = {"o": torch.from_numpy(rr["rays_o"]).to(dev), "d": torch.from_numpy(rr["rays_d"]).to(dev), "z": z_row.expand(n_local, Sb).contiguous().to(dev),
+             "counts": cnt, "R_local": n_local}
+        if hier:   # model.py:487-496: coarse NeuRay weights along the pixel rays -> sample_pdf with FIXED uniforms -> sort(cat)
+            b.update({"pix": torch.from_numpy(rr["pixel_coordinates"]).to(dev), "u": torch.from_numpy(uu).to(dev),
+                      "Kq": torch.from_numpy(rr["K"]), "pose_q": torch.from_numpy(rr["pose"])})
+        return b
+    B = to_device(rays, u_all, R_local, counts)   # the batch `step()` renders (swapped for the weak pass of an N > 1 run)
 
     # N > 1: every step ends with ONE all-gather of the packed per-ray outputs.  It is started asynchronously (RCCL's stream) and
     # collected one step later, so the xGMI transfer of batch i overlaps the kernels of batch i + 1; drain() collects the last one
     # inside the timed region, so K timed steps = K renders + K completed gathers.
     pending = [None]
+    last_out = [None]
 
     def step():
-        zz = z
+        zz = B["z"]
         if hier:
-            zz, depth_coarse, _ = rnd.hierarchical_depths(pix, Kq, pose_q, z, u_dev, near=cfg.near, far=cfg.far)
-        out = rnd.render_rays(o, d, qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps, side_stream=not args.no_side_stream)
+            zz, depth_coarse, _ = rnd.hierarchical_depths(B["pix"], B["Kq"], B["pose_q"], B["z"], B["u"], near=cfg.near, far=cfg.far)
+        out = rnd.render_rays(B["o"], B["d"], qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps, side_stream=not args.no_side_stream)
         if hier:
             out["depth_coarse"] = depth_coarse
         if gather:
             prev = pending[0]
-            pending[0] = gather_ray_outputs_async(out, dist, counts)
+            pending[0] = gather_ray_outputs_async(out, dist, B["counts"])
             if prev is not None:
                 out = prev.result()
+        last_out[0] = out
         return out
 
     def drain():
@@ -229,6 +236,8 @@ def main():
         "metric": baseline_metric(), "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
+                                                            "f16mx": "f16mx (neural-point kernel: fp16 hi.hi + two MX-FP8 cross terms, 2.0 MFMA-equivalents per product; every other GEMM 3-term "
+                                                                     "split-bf16; fp32 accumulate; meets 1e-4)",
                                                             "bf16": "bf16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"{cfg.name}: {total_rays} rays x {S} samples" + (f" (64 coarse + {cfg.S} + {cfg.N_importance} resampled)" if hier else "")
@@ -254,8 +263,39 @@ def main():
             "name": "point_fused2_kernel", "launches": launches.value, "avg_ms": fused_ms.value / launches.value,
             "share_of_step": fused_ms.value / args.steps / (dev_ms / args.steps),
             "achieved": alg, "frac": alg / PEAK_BF16_TFLOPS, "unit": "TFLOP/s (algorithmic, SURVEY §8d)",
-            "executed_mfma_TFLOPs": 2.0 * mac_exec * (3 if args.precision == "bf16x3" else 1) * samples_per_launch / sec / 1e12,
+            "executed_mfma_TFLOPs": 2.0 * mac_exec * {"bf16x3": 3.0, "f16mx": 2.0}.get(args.precision, 1.0) * samples_per_launch / sec / 1e12,
         }
+
+    if gather:
+        # the step's one collective on its own: K blocking all-gathers of the last step's packed per-ray outputs (pack + RCCL + unpack), nothing else running —
+        # the latency a step would pay if it could not overlap it with the next batch's kernels (it can: gather_ray_outputs_async)
+        out_l = last_out[0]
+        for _ in range(2):
+            gather_ray_outputs_async(out_l, dist, B["counts"]).result()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gather_ray_outputs_async(out_l, dist, B["counts"]).result()
+        torch.cuda.synchronize()
+        ag = torch.tensor([(time.perf_counter() - t0) * 1e3 / args.steps], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+        from nerf_loc_amd.sharding import pack_outputs
+        nb = pack_outputs(out_l)[0]
+        result["allgather"] = {"ms_per_call_blocking": float(ag[0]), "bytes_per_rank": int(nb.numel() * 4), "bytes_total": int(nb.numel() * 4 * world),
+                               "note": "pack + all_gather_into_tensor + unpack of one step's per-ray outputs, alone on the device; inside the timed step it runs "
+                                       "asynchronously beside the next step's kernels"}
+    if both:
+        # the weak-scaling pass of the same run (every rank its own R-ray batch): reported beside the strong headline, never as `value`
+        rw, uw, nw, cw = make_batch("weak")
+        B = to_device(rw, uw, nw, cw)
+        wall_w, dev_ms_w = timed(args.steps, args.warmup)
+        result["weak_scaling"] = {"value": world * R * args.steps / wall_w, "unit": "rays/s", "ms_per_step": wall_w * 1e3 / args.steps,
+                                  "rays_per_gpu": R, "device_ms_per_step": dev_ms_w / args.steps,
+                                  "note": "every rank renders its own R-ray batch of the same frame + the all-gather: N x the one-GPU rate up to the collective"}
+        result["scaling_modes"] = "both"
 
     if args.also and world == 1:
         extra = {}
@@ -265,7 +305,7 @@ def main():
             n2 = max(3, args.steps // 2)
             extra[p] = {"rays_per_s": R * n2 / w2, "ms_per_step": w2 * 1e3 / n2, "roofline_frac": flops_step / (d2 * 1e-3 / n2) / 1e12 / PEAK_BF16_TFLOPS,
                         "note": {"bf16": "single bf16 MFMA per product: throughput mode, does NOT meet 1e-4", "fp32": "f32-input MFMA, generic kernels: strictest parity mode",
-                                 "bf16x3": "parity mode"}[p]}
+                                 "bf16x3": "parity mode (3-term split-bf16 everywhere)", "f16mx": "parity mode, fp16 + MX-FP8 cross terms in the neural-point kernel"}[p]}
         rnd.set_precision(args.precision)
         result["other_precisions"] = extra
 

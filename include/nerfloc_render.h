@@ -43,8 +43,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NL_ABI_VERSION 4   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
-                            * reserved fields validated, side stream owned by the nl_frame */
+#define NL_ABI_VERSION 5   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
+                            * reserved fields validated, side stream owned by the nl_frame; 5: NL_PREC_F16MX */
 #define NL_MAX_VIEWS 16
 #define NL_KNN_MAX_K 8
 
@@ -60,7 +60,12 @@ typedef enum nl_status {
 typedef enum nl_precision {
   NL_PREC_F32 = 0,     /* f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products/accumulation   */
   NL_PREC_BF16X3 = 1,  /* 3-term split-bf16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate: parity mode  */
-  NL_PREC_BF16 = 2     /* single bf16 MFMA, fp32 accumulate: throughput mode (does not meet 1e-4)       */
+  NL_PREC_BF16 = 2,    /* single bf16 MFMA, fp32 accumulate: throughput mode (does not meet 1e-4)       */
+  NL_PREC_F16MX = 3    /* round 4 — parity mode, 2.0 instead of 3 matrix instructions per product in the fused neural-point kernel (the
+                        * MFMA-bound kernel): fp16 hi.hi (v_mfma_f32_32x32x16_f16) + the two cross terms hi.lo / lo.hi on gfx950's block-scaled FP8 instruction
+                        * (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, power-of-two scales; the cross terms are 2^-11 of a product, so e4m3's 2^-4 leaves 2^-15).
+                        * Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as NL_PREC_BF16X3.  Activations of the
+                        * neural-point MLP beyond fp16's range (65504) saturate instead of overflowing (MODE.FP16_OVFL).                                     */
 } nl_precision;
 
 typedef struct nl_config {

@@ -252,13 +252,15 @@ class ConditionalNeRF(nn.Module):
         t = data["depth_range"]
         if not isinstance(t, torch.Tensor):
             return float(t[0][0]), float(t[0][1])
-        key = (t.data_ptr(), t._version, tuple(t.shape))
+        # The cache holds the TENSOR (a strong reference: its storage cannot be handed to another tensor while the entry lives) and compares object
+        # identity + version.  (address, version, shape) is not a key: the reference builds data['depth_range'] fresh every forward
+        # (nerf_pose_estimator.py:265), always version 0 and shape (1, 2), and the allocator reuses the address — round 3 served stale ranges that way.
         c = self.__dict__.get("_dr_cache")
-        if c is None or c[0] != key:
+        if c is None or c[0] is not t or c[1] != t._version:
             v = t[0].detach().cpu().tolist()
-            c = (key, float(v[0]), float(v[1]))
+            c = (t, t._version, float(v[0]), float(v[1]))
             self.__dict__["_dr_cache"] = c
-        return c[1], c[2]
+        return c[2], c[3]
 
     def _ensure_frame(self, data, level: str) -> HipRenderer:
         """(Re)build the HIP per-frame tables when the caller reset the caches (nerf_pose_estimator.py:289-290)."""
@@ -298,6 +300,19 @@ class ConditionalNeRF(nn.Module):
         if weights_graph:
             return {**dict(self.named_buffers()), **dict(self.named_parameters())}
         return {k: v.detach() for k, v in self.state_dict().items()}
+
+    @staticmethod
+    def _zero_grad_touch(p, *tensors):
+        """0 x (sum of the tensors whose gradient through the library's training nodes is IDENTICALLY zero): `base_mlp_agg_weight.*` (a softmax over K
+        identical rows, model.py:415) and — through the normalised neighbour weights times K identical rows (model.py:419-427) — the support confidences,
+        i.e. `confidence_mlp`.  The reference's autograd leaves ~1e-10 of rounding noise there; the library propagates nothing, which would leave
+        `.grad` None and make them "unused parameters" under DistributedDataParallel.  Adding this scalar to an output gives them exact zeros."""
+        ts = [p[n] for n in ("base_mlp_agg_weight.0.weight", "base_mlp_agg_weight.0.bias", "base_mlp_agg_weight.2.weight", "base_mlp_agg_weight.2.bias") if n in p]
+        ts += [t for t in tensors if isinstance(t, torch.Tensor)]
+        ts = [t for t in ts if t.requires_grad]
+        if not ts:
+            return 0.0
+        return sum(t.sum() for t in ts) * 0.0
 
     def _frame_dict(self, data, level: str, graph: bool):
         """`fr` of diff_render's functions for one level.  graph: per-frame caches with their graphs (training)."""
@@ -418,7 +433,7 @@ class ConditionalNeRF(nn.Module):
         p = self._graph_params(weights_graph)
         sp = fr["support"]
         if self.hip_training and weights_graph and xyz.is_cuda and not xyz.requires_grad and (direction is None or not direction.requires_grad) \
-                and len(sp["xyz"]) >= 1:
+                and len(sp["xyz"]) >= 1 and r.train_capable():
             # a training step: the aggregation and the neural-point branch as the library's training nodes (HIP forward; backward with the
             # gradients of their parameters, of the level's feature maps, of the DepthFusionNet maps and of the support features).  What the
             # matcher loss differentiates is 'feature_agg' (nerf_pose_estimator.py:316-320, 445-448, 465-468); 'weights' keeps its graph to the
@@ -431,14 +446,30 @@ class ConditionalNeRF(nn.Module):
                 _, rgb_feat, vis_ang, _ = r.mv_aggregate(xyz, data["pose"][:3, 3] if "pose" in data else torch.zeros(3))
                 d2, idx = r.knn(xyz, K)
             dist = d2.sqrt()
-            conf = sp["confidence"].squeeze(-1)[idx.long()] if len(sp["xyz"]) >= K else torch.zeros_like(dist)
+            conf = self._neighbour_confidence(sp, idx, K)
             w = (1.0 / torch.clamp(dist, min=1e-8)) * (1.0 / K) * conf
             w = w / torch.clamp(w.sum(1, keepdim=True), min=1e-8)
+            fa = fa + self._zero_grad_touch(p)
             feature = (fa / torch.clamp(w.sum(1, keepdim=True).detach(), min=1e-20)).unsqueeze(1).expand(-1, K, -1)
+            # (entries other than 'feature_agg' / 'weights' come back WITHOUT a graph on this path; callers that differentiate them use
+            #  diff_render.query_diff through `hip_training = False`)
             return {"feature_agg": fa, "feature": feature, "weights": w, "multiview_feature": rgb_feat[:, :, :self.C + 3],
                     "multiview_visibility": vis_ang[:, :, :1]}
         idx = r.knn(xyz.detach(), K)[1].long()
         return diff_render.query_diff(p, fr, xyz, direction, idx)
+
+    @staticmethod
+    def _neighbour_confidence(sp, idx, K):
+        """knn_gather(confidence, idx) as the reference's wrapper does it (knn_utils.py:211-220): with fewer than K support points the first M columns
+        are the real neighbours and only the columns k >= M are zero-filled (all K columns were zeroed here)."""
+        M = len(sp["xyz"])
+        if M == 0:
+            return torch.zeros(idx.shape, dtype=sp["confidence"].dtype, device=idx.device)
+        conf = sp["confidence"].reshape(-1)[idx.long().clamp(0, M - 1)]
+        if M < K:
+            conf = conf.clone()
+            conf[:, M:] = 0
+        return conf
 
     def _query_hip(self, data, xyz, level, direction, K):
         r = self._ensure_frame(data, level)
@@ -447,7 +478,7 @@ class ConditionalNeRF(nn.Module):
         fa, d2, idx = r.point_mlp(xyz, dirs, mv, K=K)
         sp = self.support_neural_points[level]
         dist = d2.sqrt()
-        conf = sp["confidence"].squeeze(-1)[idx.long()] if len(sp["xyz"]) >= K else torch.zeros_like(dist)
+        conf = self._neighbour_confidence(sp, idx, K)
         w = (1.0 / torch.clamp(dist, min=1e-8)) * (1.0 / K) * conf
         w = w / torch.clamp(w.sum(1, keepdim=True), min=1e-8)
         scale = w.sum(1, keepdim=True)
@@ -563,7 +594,9 @@ class ConditionalNeRF(nn.Module):
                                            white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
                                            beta=train and bool(self.args.render.use_render_uncertainty),
                                            frozen_renderer=None if train else r,   # eval: weights + support table are constants -> HIP backward of the point branch
-                                           train_renderer=r if train and self.hip_training else None)
+                                           train_renderer=r if train and self.hip_training and o.is_cuda and r.train_capable() else None)
+        if train and self.hip_training and o.is_cuda and r.train_capable():
+            out["rgb"] = out["rgb"] + self._zero_grad_touch(p, fr["support"]["confidence"])
         if not self.args.render.render_feature:
             out.pop("feat")
         if depth_coarse is not None:

@@ -52,14 +52,14 @@ bool nl_point_fused_supported(int W, int precision);
 int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
 size_t nl_point_stream2_bytes(int W);
 int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
-                          const float* rd_w, void* out, int W, int F, hipStream_t st);
+                          const float* rd_w, void* out, int W, int F, hipStream_t st, int mx = 0, int* mx_scratch = nullptr);
 bool nl_point_fused2_supported(int W, int precision);
 int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
                            size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
                            float* blA, int64_t M, int precision, hipStream_t st);
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
-int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st);
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false);
 // backward.hip: glue kernels of the neural-point branch's input gradient
 int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
                     float* gb, float* scratch, size_t scratch_floats, hipStream_t st);
@@ -168,7 +168,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bsh[G_COUNT], bias[G_COUNT];   // bsh: the weight stream in fp16 hi / lo (split-FP16 arithmetic)
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_stream2, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_mx_sc, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
   size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
   int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
@@ -177,7 +177,7 @@ struct Layout {
 
 bool cfg_ok(const nl_config* c) {
   return c && c->W >= 32 && c->W <= 256 && c->W % 32 == 0 && c->C > 0 && c->C <= 192 && c->S >= 8 && c->S <= 256 && c->S % 8 == 0 &&
-         c->precision >= 0 && c->precision <= 2;
+         c->precision >= 0 && c->precision <= 2;   // (NL_PREC_F16MX is normalised to BF16X3 + a flag at every entry point: NL_EFF_CFG)
 }
 
 Layout make_layout(const nl_config* c) {
@@ -282,6 +282,8 @@ Layout make_layout(const nl_config* c) {
   L.pt_bias = take(4 * 3 * (size_t)W);
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
   L.pt_stream2 = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);
+  L.pt_stream2_mx = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);   // NL_PREC_F16MX: f16 fragments + fp8 images of layers 2, 3, k / v
+  L.pt_mx_sc = take(4 * 64);                                                            // their per-chunk scale bytes while packing
   L.zeros = take(4096);
   L.total = off;
   return L;
@@ -556,6 +558,7 @@ void carve_render(Bump& b, const nl_config* c, int V, int64_t R, RenderBufs& rb)
 struct Ctx {
   const nl_config* c; Layout L; const char* pk; hipStream_t st;
   uint64_t has_bst = ~0ull, has_bsh = ~0ull;   // layers whose streaming-kernel images exist in pk (pack_info)
+  bool mx = false;                             // NL_PREC_F16MX: the fused neural-point kernel multiplies as fp16 hi.hi + two MX-FP8 cross terms (everything else: BF16X3)
   template <class T> const T* p(size_t off) const { return (const T*)(pk + off); }
 };
 
@@ -617,6 +620,13 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
 }
 
 #define NL_TRY(e) do { int _rc = (e); if (_rc != NL_OK) return _rc; } while (0)
+// First statement of every entry point that takes an nl_config: NL_PREC_F16MX is BF16X3 everywhere but in the fused neural-point kernel of the render path,
+// so the library works on a BF16X3 copy of the configuration and remembers the request in nl_mx_ (nl_render_rays_ex passes it on as Ctx::mx)
+#define NL_EFF_CFG(cfg)                                                                 \
+  nl_config nl_eff_cfg_;                                                                 \
+  bool nl_mx_ = false;                                                                   \
+  if ((cfg) && (cfg)->precision == NL_PREC_F16MX) { nl_eff_cfg_ = *(cfg); nl_eff_cfg_.precision = NL_PREC_BF16X3; (cfg) = &nl_eff_cfg_; nl_mx_ = true; } \
+  (void)nl_mx_
 
 // qrows != null: per-ray query centres (device, row = sample / S) instead of the one host-side centre qc
 NlViews with_query(const nl_frame* f, const float* qc, const float* qrows = nullptr, int S = 1) {
@@ -763,13 +773,14 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     a.xyz = xyz; a.dir = dir; a.dir_stride = dir_stride; a.dir_div = dir_div > 0 ? dir_div : 1;
     a.idx = p.idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
     a.wstream = x.p<uint4>(x.L.pt_stream); a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
-    a.wstream2 = x.p<uint4>(x.L.pt_stream2);
+    const bool mx = x.mx && x.c->precision == NL_PREC_BF16X3 && nl_point_fused2_supported(W, x.c->precision);
+    a.wstream2 = x.p<uint4>(mx ? x.L.pt_stream2_mx : x.L.pt_stream2);
     a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     const bool use_v1 = dbg_switch("NERFLOC_POINT_V1");
     int rc2 = NL_ERR_UNSUPPORTED;
-    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st);
+    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st, mx);
     if (rc2 == NL_ERR_UNSUPPORTED) rc2 = nl_launch_point_fused(a, W, x.c->precision, x.st);   // (e.g. more rows than 32-bit buffer offsets reach)
     NL_TRY(rc2);
     if (pe1) NL_CHECK_HIP(hipEventRecord(pe1, x.st));
@@ -1561,9 +1572,11 @@ const char* nl_strerror(int s) {
 int nl_num_weights(void) { return kNumWeights; }
 const char* nl_weight_name(int i) { return (i >= 0 && i < kNumWeights) ? kWeightNames[i] : nullptr; }
 
-size_t nl_packed_weights_bytes(const nl_config* cfg) { return cfg_ok(cfg) ? make_layout(cfg).total : 0; }
+size_t nl_packed_weights_bytes(const nl_config* cfg) {
+  NL_EFF_CFG(cfg); return cfg_ok(cfg) ? make_layout(cfg).total : 0; }
 
 int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* packed, size_t bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg) || !t || n != kNumWeights || !packed) return NL_ERR_BAD_ARG;
   for (int i = 0; i < n; ++i) if (!t[i]) return NL_ERR_BAD_ARG;
   const Layout L = make_layout(cfg);
@@ -1711,6 +1724,9 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     int rc = nl_pack_point_stream2(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], t[T_B2B], t[T_B4B], (const float*)((char*)packed + L.rd_w),
                                    (char*)packed + L.pt_stream2, W, F, st);
     if (rc != NL_OK) return rc;
+    rc = nl_pack_point_stream2(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], t[T_B2B], t[T_B4B], (const float*)((char*)packed + L.rd_w),
+                               (char*)packed + L.pt_stream2_mx, W, F, st, 1, (int*)((char*)packed + L.pt_mx_sc));
+    if (rc != NL_OK) return rc;
   }
   NL_LAUNCH_CHECK();
   static_assert(G_COUNT <= 64, "one bit per layer");
@@ -1726,6 +1742,7 @@ static bool desc_ok(const nl_config* c, const nl_frame_desc* d) {
 }
 
 size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
+  NL_EFF_CFG(cfg);
   if (!desc_ok(cfg, d)) return 0;
   return nl_align_up((size_t)d->V * d->vis_h * d->vis_w * 32 * 4, 256) + nl_knn_grid_bytes(d->M) + nl_align_up((size_t)(d->M + 1) * cfg->W * 4, 256) +
          nl_align_up((size_t)d->V * d->h * d->w * 32 * 4, 256) + 1024 + nl_align_up((size_t)d->M * cfg->W * 4, 256) +
@@ -1733,6 +1750,7 @@ size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* d) {
 }
 
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, size_t bytes, void* stream, nl_frame** out) {
+  NL_EFF_CFG(cfg);
   if (!desc_ok(cfg, d) || !mem || !out) return NL_ERR_BAD_ARG;
   if (bytes < nl_frame_bytes(cfg, d)) return NL_ERR_WORKSPACE;
   nl_frame* f = new (std::nothrow) nl_frame;
@@ -1805,6 +1823,7 @@ int nl_sample_points(const float* o, const float* d, int64_t R, int S, float nea
 }
 
 size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   Bump b{nullptr, 0}; MvBufs m; carve_mv(b, cfg, V, N, m); return b.off;
 }
@@ -1812,6 +1831,7 @@ size_t nl_mv_aggregate_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
 int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, int64_t N,
                     float* mv_feat, float* rgb_feat, float* vis_ang, int32_t* valid_s, float* blend1, float* rgbv, void* ws,
                     size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (N == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !valid_s || !ws || N < 0 || (blend1 && !rgbv)) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_mv_aggregate_workspace_bytes(cfg, f->views.V, N)) return NL_ERR_WORKSPACE;
@@ -1821,6 +1841,7 @@ int nl_mv_aggregate(const nl_config* cfg, const void* packed, const nl_frame* f,
 }
 
 size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   Bump b{nullptr, 0}; PtBufs p; carve_pt(b, cfg, N, 8, p, true); return b.off;
 }
@@ -1828,6 +1849,7 @@ size_t nl_point_mlp_workspace_bytes(const nl_config* cfg, int64_t N) {
 int nl_point_mlp(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
                  const float* mv_feat, int64_t N, int K, float* feature_agg, int32_t* knn_idx, float* knn_d2, void* ws, size_t ws_bytes,
                  void* stream) {
+  NL_EFF_CFG(cfg);
   if (N == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !feature_agg || !ws || N < 0 || K < 1 || K > 8) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_point_mlp_workspace_bytes(cfg, N)) return NL_ERR_WORKSPACE;
@@ -1864,12 +1886,14 @@ static int resolve_train(const nl_config* cfg, const nl_train_grads* g, TrainOut
 }
 
 size_t nl_point_mlp_backward_workspace_bytes(const nl_config* cfg, int64_t N) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   const int64_t n = N < 1 ? 1 : (N > (1 << 14) ? (1 << 14) : N);   // recommended: chunks of <= 16 384 samples (131 072 neighbour rows, ~1.1 GB at W = 256)
   return point_bwd_bytes(cfg, n);
 }
 
 size_t nl_train_scratch_bytes(const nl_config* cfg) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   const int F = cfg->C + 3;
   // the largest weight the split-K kernel is asked for: conv_out (W, 3 (W + 32)) is done one tap at a time -> W x (W + 32); out_fc.0 64 x (2F + 3); base_mlp.0 W x (F + 90)
@@ -1884,6 +1908,7 @@ size_t nl_train_scratch_bytes(const nl_config* cfg) {
   return sizeof(float) * fl;
 }
 size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t N) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   const int64_t n = N < 1 ? 1 : (N > (1 << 15) ? (1 << 15) : N);
   return point_bwd_bytes(cfg, n, true);
@@ -1891,12 +1916,14 @@ size_t nl_point_mlp_backward_train_workspace_bytes(const nl_config* cfg, int64_t
 int nl_point_mlp_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
                           const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
                           float* g_dir, float* g_mv_feat, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   return nl_point_mlp_backward_train(cfg, packed, f, xyz, dir, dir_stride, mv_feat, N, K, knn_idx, knn_d2, g_feature_agg, g_xyz, g_dir, g_mv_feat, nullptr, ws,
                                      ws_bytes, stream);
 }
 int nl_point_mlp_backward_train(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, const float* dir, int64_t dir_stride,
                                 const float* mv_feat, int64_t N, int K, const int32_t* knn_idx, const float* knn_d2, const float* g_feature_agg, float* g_xyz,
                                 float* g_dir, float* g_mv_feat, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !mv_feat || !g_feature_agg || !g_xyz || !ws || N < 0 || K < 1 || K > 8 || (g_dir && !dir)) return NL_ERR_BAD_ARG;
   const bool train = grads != nullptr;
@@ -1939,20 +1966,25 @@ static int64_t mv_bwd_chunk(const nl_config* cfg, int V, int64_t N, bool blend, 
   return lo < (1 << 18) ? lo : (1 << 18);
 }
 size_t nl_mv_aggregate_backward_train_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  NL_EFF_CFG(cfg);
   return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 15) ? (1 << 15) : N), false, true) : 0;
 }
 size_t nl_blend_backward_train_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  NL_EFF_CFG(cfg);
   return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 15) ? (1 << 15) : N), true, true) : 0;
 }
 size_t nl_mv_aggregate_backward_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  NL_EFF_CFG(cfg);
   return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 16) ? (1 << 16) : N), false) : 0;
 }
 int nl_mv_aggregate_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, int64_t N, const float* g_mv_feat, float* g_xyz,
                              void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   return nl_mv_aggregate_backward_train(cfg, packed, f, xyz, N, g_mv_feat, g_xyz, nullptr, ws, ws_bytes, stream);
 }
 int nl_mv_aggregate_backward_train(const nl_config* cfg, const void* packed, const nl_frame* f, const float* xyz, int64_t N, const float* g_mv_feat, float* g_xyz,
                                    const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !xyz || !g_mv_feat || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
   const bool train = grads != nullptr;
@@ -1971,10 +2003,12 @@ int nl_mv_aggregate_backward_train(const nl_config* cfg, const void* packed, con
 }
 
 size_t nl_blend_workspace_bytes(const nl_config* cfg, int V, int64_t N) {
+  NL_EFF_CFG(cfg);
   return cfg_ok(cfg) && V >= 1 && V <= NL_MAX_VIEWS ? mv_bwd_bytes(cfg, V, N < 1 ? 1 : (N > (1 << 16) ? (1 << 16) : N), true) : 0;
 }
 int nl_blend(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N, float* rgb_s,
              void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !qc || !xyz || !feature_agg || !rgb_s || !ws || N < 0) return NL_ERR_BAD_ARG;
   const int V = f->views.V, W = cfg->W;
@@ -1990,11 +2024,13 @@ int nl_blend(const nl_config* cfg, const void* packed, const nl_frame* f, const 
 }
 int nl_blend_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N,
                       const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   return nl_blend_backward_train(cfg, packed, f, qc, xyz, feature_agg, N, g_rgb_s, g_xyz, g_feature_agg, g_query_center, nullptr, ws, ws_bytes, stream);
 }
 int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* xyz, const float* feature_agg, int64_t N,
                             const float* g_rgb_s, float* g_xyz, float* g_feature_agg, float* g_query_center, const nl_train_grads* grads, void* ws,
                             size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (N == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || !qc || !xyz || !feature_agg || !g_rgb_s || !g_xyz || !ws || N < 0) return NL_ERR_BAD_ARG;
   const bool train = grads != nullptr;
@@ -2016,6 +2052,7 @@ int nl_blend_backward_train(const nl_config* cfg, const void* packed, const nl_f
 static size_t unet_bwd_bytes(const nl_config* cfg, int64_t r, bool train = false) { Bump b{nullptr, 0}; UnBwdBufs q; carve_unb(b, cfg, r, q, train); return b.off; }
 static size_t render_bwd_bytes(const nl_config* cfg, int V, int64_t r, bool train) { Bump b{nullptr, 0}; RbBufs a; carve_rb(b, cfg, V, r, a, train); return b.off; }
 size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg) || V < 1 || V > NL_MAX_VIEWS) return 0;
   const int64_t cap = (1 << 16) / cfg->S > 1 ? (1 << 16) / cfg->S : 1;   // recommended chunk: ~64 k samples (~70 KB of workspace per sample at W = 256)
   return render_bwd_bytes(cfg, V, R < 1 ? 1 : (R > cap ? cap : R), train != 0);
@@ -2023,6 +2060,7 @@ size_t nl_render_rays_backward_workspace_bytes(const nl_config* cfg, int V, int6
 int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_o,
                             const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_cotangents* g, float* g_rays_o, float* g_rays_d,
                             float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || (!query_center && !ray_centers) || !rays_o || !rays_d || !z_vals || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (g->reserved[0] != nullptr || (g->knn_idx == nullptr) != (g->knn_d2 == nullptr)) return NL_ERR_BAD_ARG;
@@ -2053,12 +2091,14 @@ int nl_render_rays_backward(const nl_config* cfg, const void* packed, const nl_f
 // walks back from them without recomputing.  The whole batch must fit the workspace as one chunk (NL_ERR_WORKSPACE otherwise: use nl_render_rays +
 // nl_render_rays_backward, which chunk).
 size_t nl_render_rays_keep_workspace_bytes(const nl_config* cfg, int V, int64_t R, int train) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg) || V < 1 || V > NL_MAX_VIEWS || R < 1) return 0;
   return render_bwd_bytes(cfg, V, R, train != 0);
 }
 int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_o,
                                 const float* rays_d, const float* z_vals, int64_t R, int white_bkgd, const nl_render_out* out, const nl_beta_head* beta, int train,
                                 void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || (!query_center && !ray_centers) || !rays_o || !rays_d || !z_vals || !out || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (beta && (!beta->weight || !beta->bias || !beta->beta)) return NL_ERR_BAD_ARG;
@@ -2074,6 +2114,7 @@ int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const 
 int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_d,
                                  int64_t R, int white_bkgd, const nl_render_cotangents* g, const nl_beta_head* beta, float* g_rays_o, float* g_rays_d,
                                  float* g_query_center_rows, const nl_train_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !f || (!query_center && !ray_centers) || !rays_d || !g || !g_rays_o || !g_rays_d || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (beta && (!beta->weight || !beta->bias || (beta->g_weight && !grads))) return NL_ERR_BAD_ARG;   // (the weight gradient's split-K scratch comes with `grads`)
@@ -2092,17 +2133,21 @@ int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const
 }
 
 size_t nl_ray_unet_backward_train_workspace_bytes(const nl_config* cfg, int64_t R) {
+  NL_EFF_CFG(cfg);
   return cfg_ok(cfg) ? unet_bwd_bytes(cfg, R < 1 ? 1 : (R > 1024 ? 1024 : R), true) : 0;
 }
 size_t nl_ray_unet_backward_workspace_bytes(const nl_config* cfg, int64_t R) {
+  NL_EFF_CFG(cfg);
   return cfg_ok(cfg) ? unet_bwd_bytes(cfg, R < 1 ? 1 : (R > 1024 ? 1024 : R)) : 0;   // recommended: chunks of <= 1024 rays
 }
 int nl_ray_unet_backward(const nl_config* cfg, const void* packed, const float* xin, int64_t R, const float* g_geo, float* g_x, void* ws, size_t ws_bytes,
                          void* stream) {
+  NL_EFF_CFG(cfg);
   return nl_ray_unet_backward_train(cfg, packed, xin, R, g_geo, g_x, nullptr, ws, ws_bytes, stream);
 }
 int nl_ray_unet_backward_train(const nl_config* cfg, const void* packed, const float* xin, int64_t R, const float* g_geo, float* g_x, const nl_train_grads* grads,
                                void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;
   if (!cfg_ok(cfg) || !packed || !xin || !g_geo || !g_x || !ws || R < 0) return NL_ERR_BAD_ARG;
   const bool train = grads != nullptr;
@@ -2123,11 +2168,13 @@ int nl_ray_unet_backward_train(const nl_config* cfg, const void* packed, const f
 }
 
 size_t nl_ray_unet_workspace_bytes(const nl_config* cfg, int64_t R) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   Bump b{nullptr, 0}; UnBufs u; carve_un(b, cfg, R, u); return b.off;
 }
 
 int nl_ray_unet(const nl_config* cfg, const void* packed, const float* xin, int64_t R, float* geo, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !xin || !geo || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_ray_unet_workspace_bytes(cfg, R)) return NL_ERR_WORKSPACE;
@@ -2137,6 +2184,7 @@ int nl_ray_unet(const nl_config* cfg, const void* packed, const float* xin, int6
 }
 
 size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   Bump b{nullptr, 0}; HdBufs h; carve_hd(b, cfg, V, R, h); return b.off;
 }
@@ -2144,6 +2192,7 @@ size_t nl_heads_composite_workspace_bytes(const nl_config* cfg, int V, int64_t R
 int nl_heads_composite(const nl_config* cfg, const void* packed, int V, const float* z, const float* FA, const float* geo,
                        const float* blend1, const float* rgbv, const int32_t* valid_s, int64_t R, int white,
                        const nl_render_out* out, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !z || !FA || !geo || !blend1 || !rgbv || !out || !ws || R < 0 || V < 1 || V > NL_MAX_VIEWS) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_heads_composite_workspace_bytes(cfg, V, R)) return NL_ERR_WORKSPACE;
@@ -2157,9 +2206,11 @@ static size_t render_bytes(const nl_config* cfg, int V, int64_t rc) {
   Bump b{nullptr, 0}; RenderBufs rb; carve_render(b, cfg, V, rc, rb); return b.off;
 }
 
-size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V) { return cfg_ok(cfg) ? render_bytes(cfg, V, 1) : 0; }
+size_t nl_render_rays_min_workspace_bytes(const nl_config* cfg, int V) {
+  NL_EFF_CFG(cfg); return cfg_ok(cfg) ? render_bytes(cfg, V, 1) : 0; }
 
 size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
+  NL_EFF_CFG(cfg);
   if (!cfg_ok(cfg)) return 0;
   int64_t rc = R < 1 ? 1 : R;
   const int64_t cap = (1 << 20) / cfg->S > 0 ? (1 << 20) / cfg->S : 1;  // ~1M samples per chunk (~12 GB of workspace at W=256, V=10): small grids in the U-Net fill the chip only at this size
@@ -2170,12 +2221,14 @@ size_t nl_render_rays_workspace_bytes(const nl_config* cfg, int V, int64_t R) {
 int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
                    const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
                    size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   return nl_render_rays_ex(cfg, packed, f, qc, rays_o, rays_d, z_vals, R, white, out, ws, ws_bytes, stream, nullptr);
 }
 
 int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
                       const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
                       size_t ws_bytes, void* stream, const nl_render_opts* opts) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   const float term_eps = opts ? opts->early_term_eps : 0.f;
   if (!(term_eps >= 0.f && term_eps < 1.f)) return NL_ERR_BAD_ARG;   // (written so that NaN is rejected)
@@ -2202,6 +2255,7 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
   }
   Bump b{(char*)ws, 0}; RenderBufs rb; carve_render(b, cfg, V, RC, rb);
   Ctx x = make_ctx(cfg, packed, stream);
+  x.mx = nl_mx_;
   const bool fork = f->side_ok && !(flags & NL_RENDER_NO_SIDE_STREAM) && nl_point_fused_supported(W, cfg->precision);
   for (int64_t r0 = 0; r0 < R; r0 += RC) {
     const int64_t rc = (R - r0 < RC) ? R - r0 : RC;
@@ -2249,6 +2303,7 @@ size_t nl_coarse_weights_workspace_bytes(int V, int64_t R, int Sc) {
 
 int nl_coarse_weights(const nl_config* cfg, const void* packed, const nl_frame* f, const float* w2c_kinv, const float* pix,
                       const float* zc, int64_t R, int Sc, float* weights, float* depth_coarse, void* ws, size_t ws_bytes, void* stream) {
+  NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   if (!cfg_ok(cfg) || !packed || !f || !w2c_kinv || !pix || !zc || !weights || !ws || R < 0) return NL_ERR_BAD_ARG;
   if (ws_bytes < nl_coarse_weights_workspace_bytes(f->views.V, R, Sc)) return NL_ERR_WORKSPACE;

@@ -167,7 +167,7 @@ struct NlGemmArgs {
 enum { NL_EPI_NONE = 0, NL_EPI_LNROW = 1, NL_EPI_LNSLAB = 2 };
 // internal arithmetic of the segment GEMMs beyond the public nl_precision values: three-term split-FP16 (tgemm.hip), used by the backward passes for
 // their recomputed forward; falls back to exact fp32 where the streaming kernel does not apply
-#define NL_PREC_F16X3_INTERNAL 3
+#define NL_PREC_F16X3_INTERNAL 16
 
 int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);
 // streaming transposed GEMM (tgemm.hip): bf16 modes, N <= 256, 16-B aligned segments

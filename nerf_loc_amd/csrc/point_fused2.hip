@@ -28,6 +28,8 @@
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -71,7 +73,8 @@ struct Geo {
   static constexpr int RES_RD = NBUF * SLOT;                 // resident: ray_diff_fc A fragments [layer][part][64] uint4
   static constexpr int RES_BIAS = RES_RD + 2 * PARTS * 64;   // resident: biases in accumulator order, floats [rd1 32 | rd2 32 | L2 W | L3 W]
   static constexpr int RES_ATT = RES_BIAS + (64 + 2 * W) / 4;   // attention weights [wave][head][32 rows] floats (wave-private)
-  static constexpr int LDS_U4 = RES_ATT + 4 * 4 * 32 / 4;
+  static constexpr int RES_SC = RES_ATT + 4 * 4 * 32 / 4;   // MX mode: E8M0 scale bytes of the chunks' fp8 weight images, ints [NC][2] = {w_hi8, w_lo8}
+  static constexpr int LDS_U4 = RES_SC + (2 * NC + 3) / 4;
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
   static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 10 : 10); }
   static constexpr int RL = cumks(NC) % 3 == 0 ? 3 : 4;   // A-fragment register ring (3 k-steps are live)
@@ -122,6 +125,28 @@ __device__ __forceinline__ unsigned lo2(float v0, float v1, unsigned hi) {
       : "=&v"(lo), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi));
   return lo;
 }
+// ---- "fp16 hi.hi + two MX-FP8 cross terms" (MX mode): hi = f16(v) (v_cvt_pk_f16_f32, saturating under MODE.FP16_OVFL),
+// lo = v - hi exactly (v_fma_mix_f32 reads the f16 half directly), fp8 images hi8 = e4m3(hi), lo8 = e4m3(lo * 2^11) (the matrix instruction's
+// block scale 2^-11 undoes the factor); two bytes land in the low (HALF = 0) or high (HALF = 1) half of their dword.
+__device__ __forceinline__ unsigned lrelu_hi2_f16(float& v0, float& v1) {
+  unsigned hi; float t0, t1;
+  asm("v_mul_f32 %3, 0x3c23d70a, %1\n\tv_mul_f32 %4, 0x3c23d70a, %2\n\tv_max_f32 %1, %1, %3\n\tv_max_f32 %2, %2, %4\n\tv_cvt_pk_f16_f32 %0, %1, %2"
+      : "=&v"(hi), "+v"(v0), "+v"(v1), "=&v"(t0), "=&v"(t1));
+  return hi;
+}
+template <int HALF>
+__device__ __forceinline__ void mx_bytes2(float v0, float v1, unsigned hi, unsigned& h8, unsigned& l8, float sc_lo) {
+  float t0, t1;
+  if (HALF == 0)
+    asm("v_fma_mix_f32 %2, %6, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_scalef32_pk_fp8_f16 %0, %6, 1.0\n\tv_cvt_scalef32_pk_fp8_f32 %1, %2, %3, %7"
+        : "+v"(h8), "+v"(l8), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi), "v"(sc_lo));
+  else
+    asm("v_fma_mix_f32 %2, %6, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_scalef32_pk_fp8_f16 %0, %6, 1.0 op_sel:[0,0,1]\n\tv_cvt_scalef32_pk_fp8_f32 %1, %2, %3, %7 op_sel:[0,0,0,1]"
+        : "+v"(h8), "+v"(l8), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi), "v"(sc_lo));
+}
+
 // hi/lo split of a pair: hi = bf16(v), lo = bf16(v - float(hi))
 template <bool X3>
 __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
@@ -149,13 +174,17 @@ __device__ __forceinline__ void sincos_d(double x, double& s, double& c) {
 
 struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; unsigned dir_one; int N, M; float inv_span; int ntiles; unsigned t_bytes; };
 
-template <int NRT, bool X3>
+// MX (with X3): layer 1 stays three-term split-bf16 (K = 96, issue-bound anyway); layers 2, 3 and the k / v projections multiply as
+// fp16 hi.hi + fp8(lo).fp8(hi) + fp8(hi).fp8(lo): per K = 64 slab 4 x v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 instead of 12 bf16 MFMAs.
+template <int NRT, bool X3, bool MX>
 __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
     float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
     const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const Pf2Scalars sc) {
+  static_assert(!MX || X3, "the MX mode extends the three-term mode");
   using GG = Geo<NRT, X3>;
   constexpr int W = GG::W, PARTS = GG::PARTS, MPK = GG::MPK, NC = GG::NC, SLOT = GG::SLOT;
+  if (MX) __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 / fp8 conversions saturate instead of producing inf / NaN
   // ONE __shared__ object, read through ONE native vector type with compile-time slot indices: hipcc then keeps the alias
   // information that lets SIInsertWaitcnts leave LDS reads alone while LDS-DMA writes are in flight
   __shared__ uint4 lds_all[GG::LDS_U4];
@@ -170,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     const uint4* src = p_wstream + (size_t)GG::STREAM_KB * 64;
     for (int i = tid; i < 2 * PARTS * 64; i += 256) lds_all[GG::RES_RD + i] = src[(i / (PARTS * 64)) * 128 + i % (PARTS * 64)];
     for (int i = tid; i < (64 + 2 * W) / 4; i += 256) lds_all[GG::RES_BIAS + i] = src[256 + i];
+    if (MX) for (int i = tid; i < (2 * NC + 3) / 4; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];
   }
   __syncthreads();
 
@@ -202,6 +232,12 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // storage every such insert keeps the whole old vector alive in the compiler's eyes — both ping-pong halves then stay live
   // around the tile loop (512 registers + 290 spills instead of ~400)
   unsigned Xh[2][2 * NRT][4], Xl[2][2 * NRT][4];
+  // MX mode: Xh holds f16 pairs; the fp8 images of a slab (4 k-steps) as the matrix instruction wants them: [buffer][slab][0 = hi8, 1 = lo8][8 dwords], byte
+  // u = 8 s + t of a lane <-> element t of k-step 4 q + s (the weight images use the same map: any bijection works as long as both operands share it)
+  unsigned X8[2][NRT / 2][2][8];
+  u32x4 w8[2][4];   // fp8 A operands of a slab, double-buffered by slab parity: [0..1] = w_hi8 (32 bytes per lane), [2..3] = w_lo8
+  const int* ssc = reinterpret_cast<const int*>(lds_all + GG::RES_SC);
+  const float sc_lo = 0.00048828125f;   // 2^-11
   unsigned Ph[GG::KS1][4], Pl[GG::KS1][4];
   u32x4 frh[GG::RL], frl[GG::RL];         // A-fragment ring, position = (running k-step) % RL
   // accumulator of chunk c = acc[c & 3].  Four, because the accumulator is INITIALISED by loads that must be in flight early:
@@ -222,6 +258,19 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
 
   auto mfma = [](const u32x4& a, const u32x4& b, const f32x16& c) __attribute__((always_inline)) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+  auto mfma_h = [](const u32x4& a, const u32x4& b, const f32x16& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  };
+  // fp8 (e4m3) x fp8, K = 64; sa / sb: E8M0 exponent of the operand's block scale (one value for every block here)
+  auto mfma_8 = [](const i32x8& a, const i32x8& b, const f32x16& c, int sa, int sb) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+  };
+  auto cat8 = [](const u32x4& a, const u32x4& b) __attribute__((always_inline)) {
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+  auto frag8 = [](const unsigned (&d)[8]) __attribute__((always_inline)) {
+    return i32x8{(int)d[0], (int)d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7]};
   };
 
   // LeakyReLU + split of a finished pair -> dword `d` of the destination fragments
@@ -393,6 +442,12 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     if (part == 0) frh[pos] = v; else frl[pos] = v;
   };
 
+  // MX mode: 16 of the 32 fp8 bytes per lane of slab q of chunk c (part 1 of the slot: [slab][w_hi8 lo16 | w_hi8 hi16 | w_lo8 lo16 | w_lo8 hi16][lane]) -> w8[parity][i]
+  auto read_w8 = [&](auto Cc, auto Qc, auto Ic) __attribute__((always_inline)) {
+    constexpr int c = GG::cm(decltype(Cc)::value), q = decltype(Qc)::value, i = decltype(Ic)::value;
+    w8[q & 1][i] = __builtin_bit_cast(u32x4, lds_all[(c % NBUF) * SLOT + (GG::ksi(c) + 4 * q + i) * 64 + lane]);
+  };
+
   // ---------------------------------------------------------------- epilogue micro-steps of chunk C, run inside region C+1
   auto epi_step = [&](auto Cc, auto Ec, auto PrevC) __attribute__((always_inline)) {
     constexpr int C = GG::cm(decltype(Cc)::value), E = decltype(Ec)::value;
@@ -403,7 +458,13 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       constexpr int p = E / SPP, sub = E % SPP;
       constexpr int out = L & 1;   // L1 -> X[0], L2 -> X[1], L3 -> X[0]
       constexpr int fo = 2 * RT + (p >> 2), d = p & 3;
-      if constexpr (sub == 0) {
+      if constexpr (MX) {
+        if constexpr (sub == 0) {
+          ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
+          ehi = lrelu_hi2_f16(ev0, ev1);
+          Xh[out][fo][d] = ehi;
+        } else mx_bytes2<d & 1>(ev0, ev1, ehi, X8[out][fo >> 2][0][2 * (fo & 3) + (d >> 1)], X8[out][fo >> 2][1][2 * (fo & 3) + (d >> 1)], sc_lo);
+      } else if constexpr (sub == 0) {
         ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
         ehi = lrelu_hi2(ev0, ev1);
         Xh[out][fo][d] = ehi;
@@ -452,7 +513,11 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // everything that is issued in the shadow of MFMA slot K of region G
   auto fill = [&](auto Gc, auto Kc) __attribute__((always_inline)) {
     constexpr int G = decltype(Gc)::value, K = decltype(Kc)::value;
-    constexpr int NKS = GG::nks(G), NS = MPK * NKS, NSD = MPK * (NKS - 1);
+    // slots of a region: one per MFMA (3 per k-step); an MX region has 8 units per slab (f16 MFMA = 1, fp8 MFMA = 2: its issue shadow is twice as long),
+    // its barrier sits in front of unit 8 (NSL - 1) + 3 (every LDS-DMA piece is issued before it), and a layer epilogue must be through before the last slab
+    constexpr int NKS = GG::nks(G);
+    constexpr bool MXR = MX && GG::layer(G) > 0;
+    constexpr int NS = MXR ? 2 * NKS : MPK * NKS, NSD = MXR ? 2 * NKS - 5 : MPK * (NKS - 1), NSEL = MXR ? 2 * NKS - 8 : NSD;
     // LDS-DMA pieces of chunk G+3 (its slot held chunk G-1, which every wave left behind at the previous barrier)
     if constexpr (K < NSD && !(KO & 4)) {
       constexpr int ND = GG::ppw(G + 3), d0 = K * ND / NSD, d1 = (K + 1) * ND / NSD;
@@ -483,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     {
       // A layer's last row tile is finished inside the first region of the NEXT layer, which consumes the fragments it produces
       // in its last two k-step groups (operands are assembled at the start of a group): layer epilogues end one group early
-      constexpr int NE = GG::epi_steps(G - 1), NSE = GG::layer(G - 1) < 3 ? NSD : NS;
+      constexpr int NE = GG::epi_steps(G - 1), NSE = GG::layer(G - 1) < 3 ? NSEL : NS;
       if constexpr (K < NSE && !((KO & 2) && GG::layer(G - 1) < 3) && !((KO & 8) && GG::layer(G - 1) == 3)) {
         constexpr int e0 = K * NE / NSE, e1 = (K + 1) * NE / NSE;
         static_for<e1 - e0>([&](auto Ec) __attribute__((always_inline)) {
@@ -506,6 +571,66 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
 #endif
     constexpr int L = GG::layer(G), NKS = GG::nks(G), AB = G & 3, CK = GG::cumks(G);
     constexpr bool ZI = L == 3;   // k / v projections have no bias: the first MFMA takes C = 0
+    constexpr bool NEXT_MX = MX && GG::layer(G + 1) > 0;   // the next chunk's part 1 holds fp8 images (its part 0: f16 fragments)
+    if constexpr (MX && L > 0) {
+      constexpr int NSL = NKS / 4, IN = (L + 1) & 1;
+      constexpr bool TR = L == 3 && GG::rt(G) >= 4;   // v heads: D = X . Wv^T (rows = neighbour rows) instead of D^T
+      const int swh = ssc[2 * GG::cm(G)], swl = ssc[2 * GG::cm(G) + 1];
+      static_for<NSL>([&](auto Qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(Qc)::value;
+        static_for<4>([&](auto Sc) __attribute__((always_inline)) {
+          constexpr int ks = 4 * q + decltype(Sc)::value, pos = GG::rpos(CK + ks);
+          if constexpr (ks == NKS - 1) {
+            if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+          const u32x4 bh = frag4(Xh[IN][ks]);
+          if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
+          else if constexpr (ks == NKS - 1) {
+            read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
+            read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+            if constexpr (!NEXT_MX) {   // the next tile's first layer-1 chunk: split-bf16 parts
+              read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 1>{});
+              read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 1>{});
+            }
+          }
+          const f32x16 c0 = (ZI && ks == 0) ? zero16 : acc[AB];
+          acc[AB] = TR ? mfma_h(bh, frh[pos], c0) : mfma_h(frh[pos], bh, c0);
+          fill(Gc, std::integral_constant<int, 8 * q + decltype(Sc)::value>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        // the two cross terms: w_hi8 x a_lo8 (block scale 2^-11 on the activations' side), w_lo8 x a_hi8 (the weights' lo image carries its own scale)
+        {
+          const i32x8 wa = cat8(w8[q & 1][0], w8[q & 1][1]), xb = frag8(X8[IN][q][1]);
+          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], 116, swh) : mfma_8(wa, xb, acc[AB], swh, 116);
+          if constexpr (q + 1 < NSL) {
+            read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 0>{});
+            read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 1>{});
+          } else if constexpr (NEXT_MX) {
+            read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+          }
+          fill(Gc, std::integral_constant<int, 8 * q + 4>{});
+          fill(Gc, std::integral_constant<int, 8 * q + 5>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const i32x8 wa = cat8(w8[q & 1][2], w8[q & 1][3]), xb = frag8(X8[IN][q][0]);
+          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], 127, swl) : mfma_8(wa, xb, acc[AB], swl, 127);
+          if constexpr (q + 1 < NSL) {
+            read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2>{});
+            read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 3>{});
+          } else if constexpr (NEXT_MX) {
+            read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+          }
+          fill(Gc, std::integral_constant<int, 8 * q + 6>{});
+          fill(Gc, std::integral_constant<int, 8 * q + 7>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    } else
     static_for<NKS>([&](auto Kc) __attribute__((always_inline)) {
       constexpr int ks = decltype(Kc)::value, pos = GG::rpos(CK + ks);
       if constexpr (ks == NKS - 1) {
@@ -528,6 +653,14 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         if constexpr (ks + 2 < NKS) {
           if constexpr (m == 0) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
           if constexpr (X3 && m == 1) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 1>{});
+        } else if constexpr (ks == NKS - 1 && NEXT_MX) {   // a layer-1 region hands over to an MX region: f16 fragments of its k-steps 0, 1 + the fp8 images of its slab 0
+          if constexpr (m == 0) {
+            read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
+            read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+          } else {
+            read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 1)>{});
+            read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 1) + 1>{});
+          }
         } else if constexpr (ks == NKS - 1) {
           if constexpr (m == 0) {
             read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
@@ -598,10 +731,68 @@ __device__ __forceinline__ int pf2_m(int r, int hh) { return (r & 3) + 8 * (r >>
 
 // Stream: chunk (layer, rt) = [part hi/lo][k-step][lane][8 bf16] in A-fragment order (lane: out row 32 rt + (lane & 31), k-slots
 // 8 (lane >> 5) + t); then the resident block: ray_diff_fc fragments [layer][part][lane][8] (4 KB) and the bias tables (floats).
+// f32 (already divided by the block scale) -> OCP e4m3 byte, round to nearest even, saturating at +-448 (what v_cvt_scalef32_pk_fp8_f32 does under FP16_OVFL)
+__device__ __forceinline__ unsigned char pf2_e4m3(float x) {
+  const unsigned char sg = x < 0.f ? 0x80 : 0;
+  const float a = fabsf(x);
+  if (!(a == a)) return sg | 0x7f;
+  if (a >= 448.f) return sg | 0x7e;
+  int e;
+  (void)frexpf(a, &e);            // a = m 2^e, m in [0.5, 1)
+  int E = e - 1;                  // a = 1.xxx 2^E
+  if (a == 0.f || E < -6) {       // subnormal grid: multiples of 2^-9
+    const int qn = (int)rintf(a * 512.f);
+    return sg | (unsigned char)qn;   // qn == 8 is the smallest normal (0x08): the encodings are contiguous
+  }
+  int qn = (int)rintf(ldexpf(a, 3 - E));   // 8 .. 16
+  if (qn == 16) { qn = 8; ++E; }
+  const int b = ((E + 7) << 3) | (qn - 8);
+  return sg | (unsigned char)(b > 0x7e ? 0x7e : b);
+}
+__device__ __forceinline__ unsigned short pf2_f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float pf2_h2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// the weight of (layer 1..3, output row, k-slot) exactly as the stream orders it
+__device__ __forceinline__ float pf2_weight(const float* w2, const float* w3, const float* wk, const float* wv, int layer, int orow, int fin, int W) {
+  if (layer == 1) return w2[(size_t)orow * W + fin];
+  if (layer == 2) return w3[(size_t)orow * W + fin];
+  return orow < 128 ? wk[(size_t)orow * W + fin] : wv[(size_t)(orow - 128) * W + fin];
+}
+
+// MX mode: E8M0 scale bytes of every chunk's fp8 images.  One block per chunk c of layers 1..3 (c = NRT .. NC-1): the largest |f16(w)| and the largest
+// |w - f16(w)| over the chunk's 32 rows x K, scale = the power of two that puts it at or below e4m3's 448.  sc[2 c] = w_hi8, sc[2 c + 1] = w_lo8.
+__global__ void pf2_mx_scale_kernel(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ wk, const float* __restrict__ wv,
+                                    int* __restrict__ sc, int NRT) {
+  const int W = 32 * NRT, c = blockIdx.x;
+  __shared__ float smh[256], sml[256];
+  float mh = 0.f, ml = 0.f;
+  if (c >= NRT) {
+    const int layer = c < 2 * NRT ? 1 : c < 3 * NRT ? 2 : 3, rt = c < 3 * NRT ? c % NRT : c - 3 * NRT;
+    for (int i = threadIdx.x; i < 32 * W; i += blockDim.x) {
+      const float v = pf2_weight(w2, w3, wk, wv, layer, 32 * rt + i / W, i % W, W);
+      const float h = pf2_h2f(pf2_f2h(v));
+      mh = fmaxf(mh, fabsf(h)); ml = fmaxf(ml, fabsf(v - h));
+    }
+  }
+  smh[threadIdx.x] = mh; sml[threadIdx.x] = ml;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { smh[threadIdx.x] = fmaxf(smh[threadIdx.x], smh[threadIdx.x + st]); sml[threadIdx.x] = fmaxf(sml[threadIdx.x], sml[threadIdx.x + st]); }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) {
+    const float m = threadIdx.x == 0 ? smh[0] : sml[0];
+    int e = -40;
+    if (m > 0.f) { int ex; const float fr = frexpf(m / 448.f, &ex); e = fr == 0.5f ? ex - 1 : ex; }   // ceil(log2(m / 448))
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    sc[2 * c + threadIdx.x] = 127 + e;
+  }
+}
+
 __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
                                           const float* __restrict__ wk, const float* __restrict__ wv, const float* __restrict__ b2,
                                           const float* __restrict__ b3, const float* __restrict__ rd_w, unsigned short* __restrict__ out,
-                                          int NRT, int F) {
+                                          int NRT, int F, int mx, const int* __restrict__ mxsc) {
   const int W = 32 * NRT, KSL = 2 * NRT;
   const long long n_l1 = (long long)NRT * 6 * 512, n_lw = (long long)NRT * KSL * 512, n_kv = (long long)8 * KSL * 512;
   const long long total = n_l1 + 2 * n_lw + n_kv;   // (chunk, k-step, lane, t) elements of one part
@@ -634,9 +825,24 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     if (layer == 0) base = (long long)rt * 2 * 6 * 512;
     else base = (long long)NRT * 2 * 6 * 512 + ((long long)(layer - 1) * NRT + rt) * 2 * KSL * 512;
     const long long in_part = ((long long)ks * 64 + lane) * 8 + t;
-    const unsigned short h = pf2_f2bf(v);
-    out[base + in_part] = h;
-    out[base + (long long)nks * 512 + in_part] = pf2_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+    if (mx && layer > 0) {
+      // MX chunk: part 0 = f16(w) in the same fragment order; part 1 = per slab q of 4 k-steps [w_hi8 bytes 0-15 | 16-31 | w_lo8 bytes 0-15 | 16-31][lane][16], byte
+      // u = 8 (ks & 3) + t of a lane <-> this element; hi8 = e4m3(f16(w) / s_hi), lo8 = e4m3((w - f16(w)) / s_lo), scales per chunk (pf2_mx_scale_kernel)
+      const int c = (layer - 1) * NRT + NRT + rt;   // chunk index (k / v heads: rt = 0..7 behind layer 3's base)
+      const unsigned short hb = pf2_f2h(v);
+      const float hf = pf2_h2f(hb);
+      out[base + in_part] = hb;
+      unsigned char* ob = reinterpret_cast<unsigned char*>(out + base + (long long)nks * 512);
+      const int q = ks >> 2, sI = ks & 3;
+      const float s_hi = ldexpf(1.f, mxsc[2 * c] - 127), s_lo = ldexpf(1.f, mxsc[2 * c + 1] - 127);
+      const long long bo = (((long long)(4 * q + (sI >> 1)) * 64 + lane) * 16) + 8 * (sI & 1) + t;
+      ob[bo] = pf2_e4m3(hf / s_hi);
+      ob[bo + 2 * 64 * 16] = pf2_e4m3((v - hf) / s_lo);
+    } else {
+      const unsigned short h = pf2_f2bf(v);
+      out[base + in_part] = h;
+      out[base + (long long)nks * 512 + in_part] = pf2_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+    }
   }
   // resident block
   const long long res = 2LL * (NRT * 6 + (2 * NRT + 8) * KSL) * 512;   // bf16 elements of the stream
@@ -657,6 +863,10 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     else { const int q = i - 64, l = q / W, c = q - l * W, rt = c >> 5, hh = (c >> 4) & 1, f = 32 * rt + pf2_m(c & 15, hh); v = l == 0 ? b2[f] : b3[f]; }
     bt[i] = v;
   }
+  if (mx && e < 2 * (3 * NRT + 8)) {   // the chunks' scale bytes behind the bias tables
+    int* st = reinterpret_cast<int*>(out + res + 2048) + 64 + 2 * W;
+    st[e] = mxsc[e];
+  }
 }
 
 int g_num_cu = 0;
@@ -668,12 +878,18 @@ size_t nl_point_stream2_bytes(int W) {
   return (size_t)2 * (NRT * 6 + (2 * NRT + 8) * 2 * NRT) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + 4096;   // + slack: bf16 L1 chunks copy 8 k-steps
 }
 
+// mx != 0: the stream of the MX mode (layer 1 split-bf16 as ever; layers 2, 3, k / v: f16 fragments + fp8 images + their scales); mx_scratch: >= 2 (3 W / 32 + 8) ints
 int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
-                          const float* rd_w, void* out, int W, int F, hipStream_t st) {
+                          const float* rd_w, void* out, int W, int F, hipStream_t st, int mx, int* mx_scratch) {
   const int NRT = W / 32;
   const long long total = ((long long)NRT * 6 + (2LL * NRT + 8) * 2 * NRT) * 512;
+  if (mx) {
+    if (!mx_scratch) return NL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pf2_mx_scale_kernel, dim3(3 * NRT + 8), dim3(256), 0, st, w2, w3, wk, wv, mx_scratch, NRT);
+    NL_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(pack_point_stream2_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv, b2, b3, rd_w,
-                     (unsigned short*)out, NRT, F);
+                     (unsigned short*)out, NRT, F, mx, mx_scratch);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
@@ -686,7 +902,7 @@ extern "C" __attribute__((visibility("default"))) int nl_debug_pf2_trace(unsigne
 
 bool nl_point_fused2_supported(int W, int precision) { return precision != NL_PREC_F32 && (W == 128 || W == 256); }
 
-int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st) {
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx) {
   if (a.N <= 0) return NL_OK;
   if (g_num_cu == 0) {
     int dev = 0;
@@ -708,12 +924,15 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
   const int nwg = sc.ntiles < g_num_cu ? (int)nl_xcd_grid(sc.ntiles) : g_num_cu;
   dim3 grid(nwg);
   const bool x3 = precision == NL_PREC_BF16X3;
-#define NL_PF2(NRT)                                                                                                                     \
-  do {                                                                                                                                  \
-    if (x3) hipLaunchKernelGGL((point_fused2_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz, \
-                               a.sp_dir, a.wstream2, sc);                                                                               \
-    else hipLaunchKernelGGL((point_fused2_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,  \
-                            a.sp_dir, a.wstream2, sc);                                                                                  \
+  if (mx && !x3) return NL_ERR_BAD_ARG;
+#define NL_PF2(NRT)                                                                                                                                  \
+  do {                                                                                                                                               \
+    if (mx) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,        \
+                               a.sp_dir, a.wstream2, sc);                                                                                            \
+    else if (x3) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz, \
+                                    a.sp_dir, a.wstream2, sc);                                                                                       \
+    else hipLaunchKernelGGL((point_fused2_kernel<NRT, false, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,        \
+                            a.sp_dir, a.wstream2, sc);                                                                                               \
   } while (0)
   if (W == 256) NL_PF2(8);
 #if PF2_KO == 0

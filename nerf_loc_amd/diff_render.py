@@ -168,7 +168,7 @@ class RenderFn(torch.autograd.Function):
             lease = gk.acquire() if gk is not None else None
             if lease is not None:
                 out = gk.forward(o, d, z, qc.detach().float())
-                ctx.graph, ctx.lease = gk, lease
+                ctx.graph, ctx.lease, ctx.graph_stamp = gk, lease, gk.fwd_count
                 ctx.save_for_backward(o, d, qc, z)
                 ctx.mark_non_differentiable(out["mask"])
                 return out["rgb"], out["depth"], out["depth_uncertainty"], out["feat"], out["weights"], out["mask"]
@@ -199,6 +199,8 @@ class RenderFn(torch.autograd.Function):
                                    blend_feat_maps=need[6] or "rgb_blending_mlp.0.weight" in names)
         gbeta_w = gbeta_b = None
         if getattr(ctx, "graph", None) is not None:   # (between this node's forward and backward the graphs' static buffers were not touched: one step at a time)
+            if ctx.graph.fwd_count != ctx.graph_stamp:
+                raise RuntimeError("RenderFn: the graphed keep buffers were overwritten by a later forward before this node's backward ran")
             go, gd, gq = ctx.graph.backward(g_rgb, g_depth, g_unc, g_feat, g_wts)
             ctx.graph = ctx.lease = None
             return (go if need[0] else None, gd if need[1] else None, gq.to(qc.dtype) if need[2] else None, None, None, None, None, None, None)
@@ -210,8 +212,14 @@ class RenderFn(torch.autograd.Function):
             go, gd, gq = ctx.r.render_rays_backward_kept(ctx.kept, g_rgb, g_depth, g_unc, g_feat, g_wts, want_g_query_center=need[2], train=tg)
             ctx.kept = None
         else:
+            # the recompute path — also what a SECOND backward of this node takes (retain_graph=True, autograd.grad twice): the graph / kept branches above
+            # consume their activations and run once; after that the forward is recomputed from the saved rays (the library searches the neighbours again
+            # when the node saved none).  The uncertainty head exists only in the keep / kept pair: no second pass for it.
+            if ctx.has_beta:
+                raise RuntimeError("RenderFn: the backward of a training node with the uncertainty head (beta) can run once (its kept activations were consumed)")
+            saved = ctx.saved_tensors
             go, gd, gq = ctx.r.render_rays_backward(o, d, z, qc, g_rgb, g_depth, g_unc, g_feat, g_wts, white_bkgd=ctx.white, want_g_query_center=need[2], train=tg,
-                                                    knn=(ctx.saved_tensors[4], ctx.saved_tensors[5]))
+                                                    knn=(saved[4], saved[5]) if len(saved) >= 6 else None)
         gmaps = gvis = gsp = None
         gw = {}
         if tg is not None:
@@ -614,7 +622,7 @@ def render_rays_diff(p: Dict[str, Tensor], fr: Dict, rays_o: Tensor, rays_d: Ten
     xyz = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]).reshape(-1, 3)
     dirs = rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3)
     frozen = frozen_renderer is not None and _hip_ok(xyz, dirs)
-    hip_train = not frozen and train_renderer is not None and _hip_ok(xyz, dirs) and fr["support"]["xyz"].shape[0] >= 1
+    hip_train = not frozen and train_renderer is not None and _hip_ok(xyz, dirs) and fr["support"]["xyz"].shape[0] >= 1 and train_renderer.train_capable()
     r = frozen_renderer if frozen else train_renderer
     beta_ok = not beta or (hip_train and KEEP_BYTES and "beta_mlp.0.weight" in p and
                            r.lib.nl_render_rays_keep_workspace_bytes(ct.byref(r.cfg), r.V, R, 1) <= KEEP_BYTES)   # (the uncertainty head lives in the keep / kept pair)

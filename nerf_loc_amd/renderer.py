@@ -49,6 +49,7 @@ class GraphedKeep:
         self.fwd = self.bwd = None
         self.stream = torch.cuda.Stream(device=dev)
         self._pool = {"busy": False}   # the static buffers serve ONE forward / backward pair at a time
+        self.fwd_count = 0             # generation of the kept activations: a node checks in backward that no later forward replaced them
 
     def acquire(self):
         """A lease on the static buffers (released when dropped), or None while another forward's backward is still pending."""
@@ -88,6 +89,7 @@ class GraphedKeep:
     def forward(self, o, d, z, q):
         self.o.copy_(o); self.d.copy_(d); self.z.copy_(z); self.q.copy_(q.reshape(-1, 3).expand(self.R, 3))
         self._run("fwd")
+        self.fwd_count += 1
         out = {k: v.clone() for k, v in self.out.items()}
         out["mask"] = out["mask"].view(torch.bool)
         return out
@@ -207,6 +209,17 @@ class HipRenderer:
         if not self._weights_loaded:
             raise RuntimeError("load_weights first")
         return self._weight_tensors[name]
+
+    def train_capable(self) -> bool:
+        """Whether the library's TRAINING nodes (`nl_*_backward_train`) take this configuration.  Their weight-gradient products read 16-byte rows:
+        nl_config.C must be a multiple of 4 (include/nerfloc_render.h, "training: weight gradients"; wgrad.hip returns NL_ERR_UNSUPPORTED otherwise) and
+        the scratch query must accept the configuration.  Probed BEFORE a forward pass chooses its autograd nodes: a refusal discovered inside
+        `loss.backward()` has no eager graph left to fall back to."""
+        ok = self.__dict__.get("_train_capable")
+        if ok is None:
+            ok = self.C % 4 == 0 and self.W <= 256 and int(self.lib.nl_train_scratch_bytes(ct.byref(self.cfg))) > 0
+            self._train_capable = ok
+        return ok
 
     def set_precision(self, precision: str) -> None:
         """All three weight layouts are packed at once, so switching is free."""

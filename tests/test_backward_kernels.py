@@ -672,7 +672,8 @@ def test_random_scenes_training_gradients_match_eager_autograd():
     spec = importlib.util.spec_from_file_location("grad_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "grad_fuzz.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(8, 7, verbose=False) < 5e-2    # (the criteria themselves — per tensor, against fp64 autograd with fp32 autograd as the yardstick — are asserted inside)
+    # round 4: 60 seeded scenes in the driver-run suite (was 8)
+    assert mod.run(int(os.environ.get("NERFLOC_FUZZ_GRAD", "60")), 7, verbose=False) < 5e-2    # (the criteria themselves — per tensor, against fp64 autograd with fp32 autograd as the yardstick — are asserted inside)
 
 
 @pytest.mark.gpu
@@ -704,3 +705,50 @@ def test_training_refuses_feature_widths_that_are_not_multiples_of_four():
         else:
             g = torch.autograd.grad(loss, [o, d, pose])
             assert all(torch.isfinite(x).all() for x in g)
+
+
+@pytest.mark.gpu
+def test_render_node_backward_can_run_twice():
+    """`RenderFn.backward` consumed its kept activations / graph and then fell through to a recompute branch that indexed tensors the node had
+    never saved (IndexError on the second `autograd.grad` of one forward, e.g. retain_graph=True).  The second pass now recomputes from the saved rays
+    (the library searches the neighbours again when none were saved): same gradients as the first pass to the recompute's rounding — for the kept pair,
+    for the graphed pair and for the chunking path."""
+    from nerf_loc_amd.renderer import HipRenderer
+    from tests.golden_cases import build_case
+    c = build_case("c1")
+    cfg, frame, rays = c["cfg"], c["frame"], c["rays"]
+    dev = torch.device("cuda:0")
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "fp32")
+    r.load_weights({k: torch.from_numpy(v) for k, v in c["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R = 16
+    lin = torch.linspace(0, 1, cfg.S_total, device=dev)
+    z = (cfg.near * (1 - lin) + cfg.far * lin).expand(R, cfg.S_total).contiguous()
+    p = {k: t(v) for k, v in c["weights"].items()}
+    fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
+    fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}})
+    cf = torch.randn(R, cfg.C, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def twice():
+        o = t(rays["rays_o"][:R]).clone().requires_grad_(True)
+        d = t(rays["rays_d"][:R]).clone().requires_grad_(True)
+        pose = t(frame["pose"]).clone().requires_grad_(True)
+        out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], frozen_renderer=r)
+        loss = (out["feat"] * cf).sum() + out["depth"].sum()
+        g1 = torch.autograd.grad(loss, [o, d, pose], retain_graph=True)
+        g2 = torch.autograd.grad(loss, [o, d, pose])
+        return g1, g2
+    keep, graphs = dr.KEEP_BYTES, dr.USE_GRAPHS
+    try:
+        for mode in ("kept", "graph", "chunking"):
+            dr.KEEP_BYTES = 0 if mode == "chunking" else keep
+            dr.USE_GRAPHS = mode == "graph"
+            if mode == "graph":
+                twice()   # first sight of the shape: the next call replays graphs
+            g1, g2 = twice()
+            for nm, a, b in zip(("g_o", "g_d", "g_pose"), g1, g2):
+                assert torch.isfinite(b).all()
+                assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-4, (mode, nm)
+    finally:
+        dr.KEEP_BYTES, dr.USE_GRAPHS = keep, graphs

@@ -444,4 +444,5 @@ def test_random_scenes_module_training_step_matches_the_eager_graph():
     spec = importlib.util.spec_from_file_location("module_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "module_fuzz.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(4, 3) < 5e-2
+    # round 4: 20 seeded scenes in the driver-run suite (was 4)
+    assert mod.run(int(os.environ.get("NERFLOC_FUZZ_MODULE", "20")), 3) < 5e-2

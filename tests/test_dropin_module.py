@@ -200,6 +200,36 @@ def test_cache_attributes_count_generations():
     assert "support_neural_points" not in net.state_dict() and "_support_neural_points" not in net.state_dict()
 
 
+def test_depth_range_is_read_from_the_tensor_the_caller_passed_not_from_a_reused_address():
+    """the reference builds data['depth_range'] fresh every forward (nerf_pose_estimator.py:265: torch.stack([near, far], 1)) — always
+    version 0, shape (1, 2), and the allocator hands the same address to the next one.  The per-tensor cache of the host read must therefore key on the
+    tensor OBJECT (and hold it), never on (address, version, shape): 200 consecutive frames with changing ranges, each tensor dropped before the next is
+    made, must all read back their own values (the address-keyed cache of round 3 served the previous frame's range for about every second one)."""
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    net = ConditionalNeRF(_args(CFG)).eval()
+    # deterministic form of the allocator's address reuse: every frame's tensor is a NEW object (version 0, shape (1, 2)) over the same memory
+    buf = np.zeros((1, 2), np.float32)
+    for i in range(50):
+        buf[0, 0], buf[0, 1] = 0.1 + 0.01 * i, 5.0 + 0.5 * i
+        data = {"depth_range": torch.from_numpy(buf)}
+        assert data["depth_range"]._version == 0
+        got = net._depth_range(data)
+        assert got == (float(buf[0, 0]), float(buf[0, 1])), (i, got)
+        assert net._depth_range(data) == got   # second read of the same tensor: served from the cache, same values
+        del data
+    # ... and the reference's own construction, tensors dropped before the next is made
+    for i in range(50):
+        near, far = 0.1 + 0.01 * i, 5.0 + 0.5 * i
+        data = {"depth_range": torch.stack([torch.tensor([near]), torch.tensor([far])], 1)}
+        assert net._depth_range(data) == (float(torch.tensor(near)), float(torch.tensor(far)))
+        del data
+    # an in-place update of the same tensor is seen too (version counter)
+    t = torch.tensor([[0.5, 2.0]])
+    assert net._depth_range({"depth_range": t}) == (0.5, 2.0)
+    t[0, 1] = 3.0
+    assert net._depth_range({"depth_range": t}) == (0.5, 3.0)
+
+
 def test_entry_points_without_a_gradient_path_refuse_autograd():
     """The detached HIP outputs must not silently swallow a gradient: entry points that have no gradient path say so (CPU: no renderer
     involved).  render_rays / points_2d_to_rays and — since round 3 — query / query_coarse / query_fine do have one

@@ -11,7 +11,7 @@ from tests.util import l2_rel, load_golden, oracle_inputs, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 5e-5, "bf16x3": 1e-4}
+TOL = {"fp32": 5e-5, "bf16x3": 1e-4, "f16mx": 1e-4}
 PLAIN = [n for n in CASES if CASES[n][0].N_importance == 0]
 
 
@@ -29,7 +29,7 @@ def _z(cfg, R):
     return sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(R, cfg.S).contiguous()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
 @pytest.mark.parametrize("name", PLAIN)
 def test_render_rays_matches_reference_golden(name, precision):
     cfg, full = CASES[name]
@@ -506,4 +506,5 @@ def test_random_scenes_forward_matches_the_cpu_oracle():
     spec = importlib.util.spec_from_file_location("forward_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "forward_fuzz.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(12, 9, verbose=False) < 1e-4
+    # round 4: 100 seeded scenes in the driver-run suite (was 12; the builder-side runs of tools/forward_fuzz.py cover 1 400)
+    assert mod.run(int(os.environ.get("NERFLOC_FUZZ_FORWARD", "100")), 9, verbose=False) < 1e-4

@@ -17,7 +17,10 @@ def run(ncases=20, seed0=0, verbose=True):
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     worst_all = 0.0
+    only = [int(x) for x in os.environ["ONLY"].split(",")] if os.environ.get("ONLY") else None   # re-run single cases of a sweep
     for case in range(ncases):
+        if only is not None and case not in only:
+            continue
         rng = np.random.default_rng(seed0 * 1000 + case)
         W = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256])); S = int(8 * rng.integers(2, 13)) if rng.random() < 0.7 else int(8 * rng.integers(13, 33)); V = int(rng.integers(1, 17)); C = int(rng.choice([8, 32, 60, 64, 100, 124, 128, 192]))
         # the path under test: frozen weights (PoseOptimizer) or training; the whole path as one node (keep / kept pair, or the chunking pair over a small
@@ -100,7 +103,10 @@ def run(ncases=20, seed0=0, verbose=True):
             if len(em) <= 5:   # frozen weights: rays and pose only
                 assert not big, (case, mode, big)
             else:
-                assert len(big) <= 4 and all(e < 0.5 for e in big.values()) and float(np.median(list(em.values()))) < 2e-3, (case, mode, big, float(np.median(list(em.values()))))
+                med, ymed = float(np.median(list(em.values()))), float(np.median([yard[k] for k in em if k in yard] or [0.0]))
+                if os.environ.get("VERBOSE"): print(f"    {mode}: median {med:.2e}, fp32-autograd yardstick median {ymed:.2e}; worst:", sorted(((round(v, 4), k) for k, v in em.items()), reverse=True)[:8], flush=True)
+                # the median bar follows the scene's conditioning like the per-tensor bar does: long rays (S > 128) at W = 256 put fp32 autograd itself at 2-5e-3
+                assert len(big) <= 4 and all(e < 0.5 for e in big.values()) and med < max(2e-3, 3 * ymed), (case, mode, big, med, ymed)
             for k, e in em.items():
                 errs[f"{mode}:{k}"] = e
                 if e > worst[1] and k not in big: worst = (f"{mode}:{k}", e)
