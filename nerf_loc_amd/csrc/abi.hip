@@ -35,6 +35,13 @@ int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R,
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
 int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st,
                     const int* n_alive = nullptr, int S = 1);
+int nl_launch_blend_taps(const NlViews& vw, const float* viewsdev, const float* pfeat, const float* blw, const float* xyz, const float* hA, const float* rgbv, int64_t N,
+                         const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st, const int* n_alive, int S);
+size_t nl_mv_front_pack_bytes();
+int nl_pack_mv_front(const float* w_outfc0, const float* b_outfc0, void* out, hipStream_t st);
+bool nl_mv_front_supported(int C, int V, int64_t N);
+int nl_launch_mv_front(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, const float* xyz, int64_t N, const float* vis_in,
+                       const float* dd_in, const void* pack, float* t64, int* valid_s, float* rgbv, hipStream_t st);
 int nl_launch_termination(const float* z_vals, const float* sigma, int64_t R, int S, float eps, int* n_alive, int* tile_list, int* tile_count, hipStream_t st);
 int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, const float* visf_hwc, const float* dec_w, const void* dpack,
                              int precision, const float* pix, const float* zc, int64_t R, int Sc, float* ws_alpha, float* ws_vis, float* ws_mask,
@@ -168,7 +175,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bsh[G_COUNT], bias[G_COUNT];   // bsh: the weight stream in fp16 hi / lo (split-FP16 arithmetic)
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_mx_sc, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
   size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
   int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
@@ -283,7 +290,8 @@ Layout make_layout(const nl_config* c) {
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
   L.pt_stream2 = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);
   L.pt_stream2_mx = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);   // NL_PREC_F16MX: f16 fragments + fp8 images of layers 2, 3, k / v
-  L.pt_mx_sc = take(4 * 64);                                                            // their per-chunk scale bytes while packing
+  L.pt_mx_sc = take(4 * 64);
+  L.mvf_pack = take(nl_mv_front_pack_bytes());                                          // out_fc.0 as register-resident A fragments of mv_front_kernel (C = 192)                                                            // their per-chunk scale bytes while packing
   L.zeros = take(4096);
   L.total = off;
   return L;
@@ -732,12 +740,22 @@ bool prof_arm(hipEvent_t* e0, hipEvent_t* e1) {
   return true;
 }
 
+// front (fused render path, C = 192, non-fp32 modes; round 4): statistics + out_fc.0 in mv_front_kernel — no statistics row, no per-(sample, view) blend rows
+// (bl1 is then not written: the blend tail recomputes its taps, do_heads_pre); rgbv still carries the tapped colours + visibility
 int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, int64_t N, float* G, float* rgb_feat,
-          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m, bool skip_g = false, const float* qrows = nullptr, int qS = 1) {
+          float* vis_ang, int* valid_s, float* bl1, float* rgbv, const MvBufs& m, bool skip_g = false, const float* qrows = nullptr, int qS = 1,
+          bool front = false) {
   const NlViews vw = with_query(f, qc, qrows, qS);
-  if (bl1) NL_TRY(ensure_pfeat(x, f));
+  if (bl1 || front) NL_TRY(ensure_pfeat(x, f));
   if (x.c->precision == NL_PREC_F32) NL_TRY(nl_launch_mv_vis(vw, f->visf_hwc, x.p<float>(x.L.dec_w), xyz, N, m.vis, m.dd, x.st));
   else NL_TRY(nl_launch_mv_vis_mfma(vw, f->visf_hwc, x.p<char>(x.L.dec_mfma), xyz, N, m.vis, m.dd, x.c->precision == NL_PREC_BF16X3, x.st));
+  if (front) {
+    NL_TRY(nl_launch_mv_front(vw, f->views_dev, f->images, f->feat, xyz, N, m.vis, m.dd, x.p<char>(x.L.mvf_pack), m.t64, valid_s, rgbv, x.st));
+    if (skip_g) return NL_OK;
+    SegSpec s1{m.t64, 64, 64, 0, 1};
+    NL_TRY(run_gemm(x, G_OUTFC2, &s1, 1, N, G, x.c->W, NL_ACT_ELU));
+    return NL_OK;
+  }
   NL_TRY(nl_launch_mv_stats(vw, f->views_dev, f->images, f->feat, f->C, xyz, N, m.vis, m.dd, m.g393, ldg_of(f->C), rgb_feat, vis_ang, valid_s, f->pfeat,
                             x.p<float>(x.L.blw), bl1, rgbv, x.st));
   SegSpec s0{m.g393, ldg_of(f->C), ldg_of(f->C), 0, 1};
@@ -1340,8 +1358,9 @@ int unet_backward_only(const Ctx& xb, const Ctx& x32, const float* in, int64_t R
 
 // the part of the heads that needs feature_agg only (not the density): feat_mlp.0, the per-sample blend projection, the blend tail
 // term == true: n_alive / tile_list of `h` are valid (nl_launch_termination ran): dead samples are skipped
+struct BlendTaps { NlViews vw; const float* viewsdev; const float* pfeat; const float* xyz; };   // bl1 == null: the blend tail recomputes its per-(sample, view) rows
 int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const float* rgbv, int64_t N, bool want_feat, const HdBufs& h, int parts = 7,
-                 bool term = false) {
+                 bool term = false, const BlendTaps* bt = nullptr) {
   const int W = x.c->W;
   if (want_feat && (parts & 1)) {
     SegSpec s0{FA, W, W, 0, 1};
@@ -1350,21 +1369,25 @@ int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const f
   }
   SegSpec sa{FA, W, W, 0, 1};
   if (parts & 2) NL_TRY(run_gemm(x, G_BLENDA, &sa, 1, N, h.blA, 32, NL_ACT_NONE));
-  if (parts & 4) NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
-                                        x.p<float>(x.L.bl4_b), h.rgb_s, x.st, term ? h.n_alive : nullptr, x.c->S));
+  if ((parts & 4) && !bl1) {
+    if (!bt) return NL_ERR_BAD_ARG;
+    NL_TRY(nl_launch_blend_taps(bt->vw, bt->viewsdev, bt->pfeat, x.p<float>(x.L.blw), bt->xyz, h.blA, rgbv, N, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b),
+                                x.p<float>(x.L.bl4_w), x.p<float>(x.L.bl4_b), h.rgb_s, x.st, term ? h.n_alive : nullptr, x.c->S));
+  } else if (parts & 4) NL_TRY(nl_launch_blend(h.blA, bl1, rgbv, N, V, x.p<float>(x.L.bl2_w), x.p<float>(x.L.bl2_b), x.p<float>(x.L.bl4_w),
+                                               x.p<float>(x.L.bl4_b), h.rgb_s, x.st, term ? h.n_alive : nullptr, x.c->S));
   return NL_OK;
 }
 
 int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
              const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false,
-             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0) {
+             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0, const BlendTaps* bt = nullptr) {
   const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
   if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
   const bool want_feat = out->feat != nullptr;
   const bool term = term_eps > 0.f && !pre_done;
   if (term) NL_TRY(nl_launch_termination(z, h.sigma, R, S, term_eps, h.n_alive, h.tile_list, h.tile_count, x.st));
-  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7 & ~chain_parts, term));   // chain_parts: what the chain kernel already produced
+  if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7 & ~chain_parts, term, bt));   // chain_parts: what the chain kernel already produced
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
                              want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st, term ? h.n_alive : nullptr));
   if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
@@ -1716,6 +1739,10 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.copy(t[T_BL4W], L.bl4_w, 16); P.copy(t[T_BL4B], L.bl4_b, 1);
   P.copy(t[T_LNW], L.ln_g, W); P.copy(t[T_LNB], L.ln_b, W);
   P.copy(t[T_B0B], L.pt_bias, W); P.copy(t[T_B2B], L.pt_bias + 4 * (size_t)W, W); P.copy(t[T_B4B], L.pt_bias + 8 * (size_t)W, W);
+  if (cfg->C == 192) {
+    int rc = nl_pack_mv_front(t[T_OUT0W], t[T_OUT0B], (char*)packed + L.mvf_pack, st);
+    if (rc != NL_OK) return rc;
+  }
   if (W == 64 || W == 128 || W == 256) {
     int rc = nl_pack_point_stream(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], (char*)packed + L.pt_stream, W, F, st);
     if (rc != NL_OK) return rc;
@@ -2276,8 +2303,10 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     // the stage output or when the separate launches run instead
     const bool use_chain = !dbg_switch("NERFLOC_NO_CHAIN") && W == 256 && cfg->precision != NL_PREC_F32 && N * 1024 <= 0x7fffffffll &&
                            nl_point_fused_supported(W, cfg->precision);
-    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg,
-                 ray_centers ? ray_centers + 3 * r0 : nullptr, S));
+    const bool front = !dbg_switch("NERFLOC_NO_FRONT") && cfg->precision != NL_PREC_F32 && nl_mv_front_supported(f->C, V, N);
+    NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, front ? nullptr : rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg,
+                 ray_centers ? ray_centers + 3 * r0 : nullptr, S, front));
+    BlendTaps bt{with_query(f, qc, ray_centers ? ray_centers + 3 * r0 : nullptr, S), f->views_dev, f->pfeat, rb.xyz};
     // per-sample viewing direction = its ray's direction (model.py:501-504): row = sample / S
     // with early termination feat_mlp.0 runs later, over the live tiles only; otherwise the chain kernel produces it right here
     bool chain_done = false;
@@ -2287,7 +2316,7 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
     bool have_sigma = false;
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts));
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -1,5 +1,5 @@
 // Ray sampling (rows a2-a3) and the post-U-Net heads + compositing (rows a14-a18).
-#include "common.h"
+#include "mvdec.h"
 
 namespace {
 
@@ -74,6 +74,105 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ hA
     }
     const float vis = rgbv[((size_t)n * V + v) * 4 + 3];
     o = (vis == 0.f) ? -1e9f : o;
+    lg[v] = o;
+    mx = fmaxf(mx, o);
+  }
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) { lg[v] = expf(lg[v] - mx); den += lg[v]; }
+  float r = 0.f, g = 0.f, b = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float wv = lg[v] / den;
+    const float* c = rgbv + ((size_t)n * V + v) * 4;
+    r += c[0] * wv; g += c[1] * wv; b += c[2] * wv;
+  }
+  rgb_s[3 * (size_t)n] = r; rgb_s[3 * (size_t)n + 1] = g; rgb_s[3 * (size_t)n + 2] = b;
+}
+
+// The same tail with the per-(sample, view) part of layer 1 RECOMPUTED instead of read back (round 4: mv_front_kernel no longer writes the N x V x 32 rows,
+// 0.7 GB out and in per config-2 batch): IBRNet projection of the sample into view v (ibrnet.py:169-192), the bilinear (zeros, align_corners = True) tap of
+// the per-frame projected feature map pfeat = W[:, feat] . featmap (32 channels: a linear layer commutes with the tap), the view-angle features
+// (ibrnet.py:144-167) and the [rgb | vis | angle] columns + bias (blw).  One lane per sample; views the sample is invisible in (vis == 0: logit masked to
+// -1e9, model.py:536) are skipped by the lane.  rgbv (N*V, 4) = tapped colours + visibility from mv_front_kernel.
+__global__ __launch_bounds__(256) void blend_taps_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ pfeat /*(V,h,w,32)*/,
+                                                         const float* __restrict__ blw /*[32][8], bias[32]*/, const float* __restrict__ xyz,
+                                                         const float* __restrict__ hA, const float* __restrict__ rgbv, int N,
+                                                         const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
+                                                         const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
+                                                         float* __restrict__ rgb_s, const int* __restrict__ n_alive, int S) {
+  using namespace nlmv;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (n_alive) {
+    const int r = n / S;
+    if (n - r * S >= n_alive[r]) { rgb_s[3 * (size_t)n] = 0.f; rgb_s[3 * (size_t)n + 1] = 0.f; rgb_s[3 * (size_t)n + 2] = 0.f; return; }
+  }
+  const int V = vw.V;
+  const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
+  float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+  if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(n / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+  float tq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
+  const float rq = 1.f / (sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f);
+  tq[0] *= rq; tq[1] *= rq; tq[2] *= rq;
+  float xa[32];   // per-sample part of layer 1 (feature_agg columns of rgb_blending_mlp.0)
+#pragma unroll
+  for (int i4 = 0; i4 < 8; ++i4) {
+    const float4 t = *(const float4*)(hA + (size_t)n * 32 + 4 * i4);
+    xa[4 * i4] = t.x; xa[4 * i4 + 1] = t.y; xa[4 * i4 + 2] = t.z; xa[4 * i4 + 3] = t.w;
+  }
+  const size_t fmap = (size_t)vw.h * vw.w;
+  float lg[NL_MAX_VIEWS];
+  float mx = -3.4e38f;
+  for (int v = 0; v < V; ++v) {
+    const float4 cv = *(const float4*)(rgbv + ((size_t)n * V + v) * 4);
+    float o = -1e9f;
+    if (cv.w != 0.f) {
+      const float4 p0 = *(const float4*)(viewsdev + 12 * v), p1 = *(const float4*)(viewsdev + 12 * v + 4), p2 = *(const float4*)(viewsdev + 12 * v + 8);
+      const float cx = fmaf(p0.z, Z, fmaf(p0.y, Y, p0.x * X)) + p0.w;
+      const float cy = fmaf(p1.z, Z, fmaf(p1.y, Y, p1.x * X)) + p1.w;
+      const float cz = fmaf(p2.z, Z, fmaf(p2.y, Y, p2.x * X)) + p2.w;
+      const float zc = fmaxf(cz, 1e-8f);
+      float px = cx / zc, py = cy / zc;
+      px = fminf(fmaxf(px, -1e6f), 1e6f);
+      py = fminf(fmaxf(py, -1e6f), 1e6f);
+      const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
+      const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
+      const Taps tf = make_taps<true, false>(xn, yn, vw.w, vw.h);
+      int of[4];
+      unpack_taps(pack_taps(tf, vw.w, vw.h), vw.w, of);
+      const float w0 = (tf.mn && tf.mw) ? tf.nw : 0.f, w1 = (tf.mn && tf.me) ? tf.ne : 0.f, w2t = (tf.ms && tf.mw) ? tf.sw : 0.f, w3 = (tf.ms && tf.me) ? tf.se : 0.f;
+      float tt[3] = {viewsdev[192 + 3 * v] - X, viewsdev[192 + 3 * v + 1] - Y, viewsdev[192 + 3 * v + 2] - Z};
+      const float rt = 1.f / (sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f);
+      tt[0] *= rt; tt[1] *= rt; tt[2] *= rt;
+      const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+      const float rd = 1.f / fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
+      const float in8[8] = {cv.x, cv.y, cv.z, cv.w, df[0] * rd, df[1] * rd, df[2] * rd, tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2]};
+      const float* pb = pfeat + (size_t)v * fmap * 32;
+      float x[32];
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 a = *(const float4*)(pb + (size_t)of[0] * 32 + 4 * c4), b = *(const float4*)(pb + (size_t)of[1] * 32 + 4 * c4);
+        const float4 c = *(const float4*)(pb + (size_t)of[2] * 32 + 4 * c4), d = *(const float4*)(pb + (size_t)of[3] * 32 + 4 * c4);
+        x[4 * c4] = fmaf(d.x, w3, fmaf(c.x, w2t, fmaf(b.x, w1, a.x * w0)));
+        x[4 * c4 + 1] = fmaf(d.y, w3, fmaf(c.y, w2t, fmaf(b.y, w1, a.y * w0)));
+        x[4 * c4 + 2] = fmaf(d.z, w3, fmaf(c.z, w2t, fmaf(b.z, w1, a.z * w0)));
+        x[4 * c4 + 3] = fmaf(d.w, w3, fmaf(c.w, w2t, fmaf(b.w, w1, a.w * w0)));
+      }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        float a = x[i] + blw[256 + i];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a = fmaf(blw[i * 8 + jj], in8[jj], a);
+        x[i] = nl_lrelu(xa[i] + a);
+      }
+      o = b4[0];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float a = b2[j];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) a = fmaf(w2[j * 32 + i], x[i], a);
+        o = fmaf(w4[j], nl_lrelu(a), o);
+      }
+    }
     lg[v] = o;
     mx = fmaxf(mx, o);
   }
@@ -266,6 +365,14 @@ int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t
                     const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st, const int* n_alive, int S) {
   if (N <= 0) return NL_OK;
   hipLaunchKernelGGL(blend_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, hA, h1, rgbv, (int)N, V, w2, b2, w4, b4, rgb_s, n_alive, S);
+  NL_LAUNCH_CHECK();
+  return NL_OK;
+}
+
+int nl_launch_blend_taps(const NlViews& vw, const float* viewsdev, const float* pfeat, const float* blw, const float* xyz, const float* hA, const float* rgbv, int64_t N,
+                         const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st, const int* n_alive, int S) {
+  if (N <= 0) return NL_OK;
+  hipLaunchKernelGGL(blend_taps_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, vw, viewsdev, pfeat, blw, xyz, hA, rgbv, (int)N, w2, b2, w4, b4, rgb_s, n_alive, S);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

@@ -161,19 +161,6 @@ __global__ void pack_mv_decoder_kernel(const float* __restrict__ dec /* packed V
   }
 }
 
-// The four tap offsets of one bilinear sample in one register: offset of the (clamped) north-west texel in bits 0-29, whether the
-// east column / south row is a different texel in bits 30 / 31.  Taps outside the map are clamped onto a valid texel; their
-// weights are zero.  unpack_taps runs on the scalar unit (the packed word comes from v_readlane).
-__device__ __forceinline__ unsigned pack_taps(const nlmv::Taps& t, int w, int h) {
-  const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
-  const int y0 = min(max(t.y0, 0), h - 1), y1 = min(max(t.y0 + 1, 0), h - 1);
-  return (unsigned)(y0 * w + x0) | ((unsigned)(x1 - x0) << 30) | ((unsigned)(y1 - y0) << 31);
-}
-__device__ __forceinline__ void unpack_taps(unsigned pk, int w, int (&o)[4]) {
-  const int base = (int)(pk & 0x3fffffffu), dx = (int)((pk >> 30) & 1u), dy = (pk >> 31) ? w : 0;
-  o[0] = base; o[1] = base + dx; o[2] = base + dy; o[3] = base + dy + dx;
-}
-
 __device__ __forceinline__ float rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 

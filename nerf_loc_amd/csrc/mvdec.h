@@ -41,6 +41,20 @@ __device__ __forceinline__ Taps make_taps(float xn, float yn, int Wm, int Hm) {
   return t;
 }
 
+// The four tap offsets of one bilinear sample in one register: offset of the (clamped) north-west texel in bits 0-29, whether the
+// east column / south row is a different texel in bits 30 / 31.  Taps outside the map are clamped onto a valid texel; their
+// weights are zero.  unpack_taps runs on the scalar unit (the packed word comes from v_readlane).
+__device__ __forceinline__ unsigned pack_taps(const Taps& t, int w, int h) {
+  const int x0 = min(max(t.x0, 0), w - 1), x1 = min(max(t.x0 + 1, 0), w - 1);
+  const int y0 = min(max(t.y0, 0), h - 1), y1 = min(max(t.y0 + 1, 0), h - 1);
+  return (unsigned)(y0 * w + x0) | ((unsigned)(x1 - x0) << 30) | ((unsigned)(y1 - y0) << 31);
+}
+__device__ __forceinline__ void unpack_taps(unsigned pk, int w, int (&o)[4]) {
+  const int base = (int)(pk & 0x3fffffffu), dx = (int)((pk >> 30) & 1u), dy = (pk >> 31) ? w : 0;
+  o[0] = base; o[1] = base + dx; o[2] = base + dy; o[3] = base + dy + dx;
+}
+
+
 // packed decoder weights: 4 x { W0[32][32], b0[32], W2[32][32], b2[32], W4[2][32] (row 1 zero if nout=1), b4[2] }
 constexpr int DEC_STRIDE = 1024 + 32 + 1024 + 32 + 64 + 2;
 
