@@ -262,6 +262,24 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
                       const float* rays_o, const float* rays_d, const float* z_vals, int64_t R, int white_bkgd,
                       const nl_render_out* out, void* ws, size_t ws_bytes, void* stream, const nl_render_opts* opts);
 
+/* Several FRAMES per call (replaces the reference's per-frame loop nerf_pose_estimator.py:289-290 + model.py:615-639 when a pose is scored
+ * against several retrieved support sets, or several query images are rendered at once): job i renders its rays against its own nl_frame — its own support
+ * views, tables and workspace — exactly as nl_render_rays_ex(cfg, packed, job.frame, ...) would (bit-identical outputs), but the jobs' launch chains are
+ * issued on library-owned streams forked from `stream` and joined back into it, so that PoseOptimizer-sized batches (512 rays: a fifth of the chip) of
+ * different frames fill the machine together.  Jobs that share a frame run one after the other on one stream.  The first call creates the streams (not
+ * capturable into a HIP graph; later calls are).  A single launch over frames with different tables would need per-ray table pointers in every kernel; it is
+ * not what this does. */
+typedef struct nl_render_job {
+  const nl_frame* frame;
+  const float* query_center;   /* HOST (3), or NULL with opts->ray_centers */
+  const float* rays_o; const float* rays_d; const float* z_vals;   /* as nl_render_rays */
+  int64_t R;
+  const nl_render_out* out;
+  void* ws; size_t ws_bytes;   /* this job's workspace (jobs run concurrently: no sharing) */
+  const nl_render_opts* opts;  /* or NULL */
+} nl_render_job;
+int nl_render_rays_multi(const nl_config* cfg, const void* packed, const nl_render_job* jobs, int32_t njobs, int32_t white_bkgd, void* stream);
+
 /* ---- backward kernels, first slice ---------------------------------------------------- */
 /* Gradient of the alpha compositing of nl_render_rays / nl_heads_composite (conditional_nerf/model.py:544-560, 597; what autograd
  * does for torch.cumprod & co. in the reference) w.r.t. its per-sample inputs.  The forward pass saves nothing: the transmittance is

@@ -2326,6 +2326,48 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
   return NL_OK;
 }
 
+// ---- several frames per call: fork / join over library-owned streams -----------------------------------------------------------------------
+namespace {
+struct MultiPool { std::mutex mu; std::vector<hipStream_t> st; std::vector<hipEvent_t> ev; hipEvent_t fork = nullptr; };
+MultiPool g_multi;
+}  // namespace
+
+int nl_render_rays_multi(const nl_config* cfg, const void* packed, const nl_render_job* jobs, int32_t njobs, int32_t white, void* stream) {
+  if (njobs == 0) return NL_OK;
+  if (!cfg || !packed || !jobs || njobs < 0) return NL_ERR_BAD_ARG;
+  for (int i = 0; i < njobs; ++i) if (!jobs[i].frame || !jobs[i].out || !jobs[i].ws) return NL_ERR_BAD_ARG;
+  if (njobs == 1) return nl_render_rays_ex(cfg, packed, jobs[0].frame, jobs[0].query_center, jobs[0].rays_o, jobs[0].rays_d, jobs[0].z_vals, jobs[0].R, white,
+                                           jobs[0].out, jobs[0].ws, jobs[0].ws_bytes, stream, jobs[0].opts);
+  // a lane (stream) per distinct frame: a frame's side stream and events serve one render call at a time
+  std::vector<int> lane_of(njobs);
+  std::vector<const nl_frame*> lanes;
+  for (int i = 0; i < njobs; ++i) {
+    int l = -1;
+    for (size_t k = 0; k < lanes.size(); ++k) if (lanes[k] == jobs[i].frame) { l = (int)k; break; }
+    if (l < 0) { l = (int)lanes.size(); lanes.push_back(jobs[i].frame); }
+    lane_of[i] = l;
+  }
+  std::lock_guard<std::mutex> lk(g_multi.mu);
+  while (g_multi.st.size() < lanes.size()) {
+    hipStream_t s; hipEvent_t e;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return NL_ERR_HIP;
+    g_multi.st.push_back(s); g_multi.ev.push_back(e);
+  }
+  if (!g_multi.fork && hipEventCreateWithFlags(&g_multi.fork, hipEventDisableTiming) != hipSuccess) return NL_ERR_HIP;
+  hipStream_t main = (hipStream_t)stream;
+  NL_CHECK_HIP(hipEventRecord(g_multi.fork, main));
+  for (size_t k = 0; k < lanes.size(); ++k) NL_CHECK_HIP(hipStreamWaitEvent(g_multi.st[k], g_multi.fork, 0));
+  int rc = NL_OK;
+  for (int i = 0; i < njobs && rc == NL_OK; ++i)
+    rc = nl_render_rays_ex(cfg, packed, jobs[i].frame, jobs[i].query_center, jobs[i].rays_o, jobs[i].rays_d, jobs[i].z_vals, jobs[i].R, white, jobs[i].out,
+                           jobs[i].ws, jobs[i].ws_bytes, g_multi.st[lane_of[i]], jobs[i].opts);
+  // join unconditionally: whatever was enqueued must be ordered before the caller's next work (and an active capture must stay well-formed)
+  for (size_t k = 0; k < lanes.size(); ++k) {
+    if (hipEventRecord(g_multi.ev[k], g_multi.st[k]) != hipSuccess || hipStreamWaitEvent(main, g_multi.ev[k], 0) != hipSuccess) rc = rc == NL_OK ? NL_ERR_HIP : rc;
+  }
+  return rc;
+}
+
 size_t nl_coarse_weights_workspace_bytes(int V, int64_t R, int Sc) {
   return 3 * nl_align_up((size_t)(V > 0 ? V : 1) * (R > 0 ? R : 1) * (Sc > 0 ? Sc : 1) * 4, 256);
 }

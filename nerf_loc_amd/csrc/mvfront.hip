@@ -27,6 +27,13 @@ typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned mf_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MF_KO
+#define MF_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no texel loads in phase B, 2 no phase B, 4 no colour taps in phase A, 8 no MFMA phase, 16 no staging writes
+#endif
+#ifndef MF_CPL
+#define MF_CPL 3
+#endif
+constexpr int MF_CPL_ = MF_CPL;    // channels per lane in phase B: 3 = all 64 lanes, 12-byte loads; 4 = lanes 0..47, 16-byte loads
 constexpr int MF_C = 192;          // feature channels (3 per lane)
 constexpr int MF_KS = 12;          // k-steps of 32: [mean 192 | variance 192]
 constexpr int MF_LD = 392;         // staging row stride in halves (384 + pad)
@@ -128,14 +135,14 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
       const Taps tf = make_taps<true, false>(xn, yn, vw.w, vw.h);
       const Taps ti = make_taps<true, false>(xn, yn, vw.Wimg, vw.H);
       // colour taps (zeros padding: masked weights, clamped offsets)
-      float rgb[3];
+      float rgb[3] = {0.f, 0.f, 0.f};
       {
         int oi[4];
         unpack_taps(pack_taps(ti, vw.Wimg, vw.H), vw.Wimg, oi);
         const float i0 = (ti.mn && ti.mw) ? ti.nw : 0.f, i1 = (ti.mn && ti.me) ? ti.ne : 0.f, i2 = (ti.ms && ti.mw) ? ti.sw : 0.f, i3 = (ti.ms && ti.me) ? ti.se : 0.f;
         const float* ib = images + (size_t)vl * 3 * HW;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < ((MF_KO & 4) ? 0 : 3); ++c) {
           const float* pl = ib + (size_t)c * HW;
           rgb[c] = fmaf(pl[oi[3]], i3, fmaf(pl[oi[2]], i2, fmaf(pl[oi[1]], i1, pl[oi[0]] * i0)));
         }
@@ -179,18 +186,22 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
     __builtin_amdgcn_wave_barrier();   // the slots are wave-private: LDS ordering within the wave is all phase B needs
 
     // ---------------------------------------------------------------- phase B: lane = channels 3 lane .. 3 lane + 2, view by view over the four samples
-    float a1[4][3], a2[4][3];
+    constexpr int CPL = MF_CPL_;
+    float a1[4][CPL], a2[4][CPL];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) a1[s][j] = a2[s][j] = 0.f;
-    const unsigned lch = 3u * (unsigned)lane;
-    for (int v = 0; v < V; ++v) {
+      for (int j = 0; j < CPL; ++j) a1[s][j] = a2[s][j] = 0.f;
+    const bool lact = CPL * lane < MF_C;
+    const unsigned lch = lact ? (unsigned)(CPL * lane) : 0u;   // (idle lanes re-read channel group 0: no exec-masked loads)
+    for (int v = 0; v < ((MF_KO & 2) ? 0 : V); ++v) {
       if (!((vmask >> v) & 1u)) continue;   // weight exactly 0 for all four samples: nothing of this view reaches a statistic (wave-uniform)
       const float* fb = feat + (size_t)v * fmap * MF_C;
-      float T[4][3];
+      float T[4][CPL];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) T[k][0] = T[k][1] = T[k][2] = 0.f;
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) T[k][j] = 0.f;
       unsigned cur = 0xffffffffu;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -198,19 +209,20 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
         const float4 c4 = *(const float4*)sl;      // (every lane reads the same address: an LDS broadcast)
         const float2 c2 = *(const float2*)(sl + 4);
         const unsigned cell = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c4.x));
-        if (cell != cur) {   // wave-uniform: the four texel rows of the new cell
+        if (cell != cur && !(MF_KO & 1)) {   // wave-uniform: the four texel rows of the new cell
           cur = cell;
           int o[4];
           unpack_taps(cell, vw.w, o);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float* p = fb + ((unsigned)o[k] * (unsigned)MF_C + lch);
-            T[k][0] = p[0]; T[k][1] = p[1]; T[k][2] = p[2];
+            if constexpr (CPL == 4) { const float4 t4 = *(const float4*)p; T[k][0] = t4.x; T[k][1] = t4.y; T[k][2] = t4.z; T[k][3] = t4.w; }
+            else { T[k][0] = p[0]; T[k][1] = p[1]; T[k][2] = p[2]; }
           }
         }
         const float w0 = c4.y, w1 = c4.z, w2 = c4.w, w3 = c2.x, wg = c2.y;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < CPL; ++j) {
           const float x = fmaf(T[3][j], w3, fmaf(T[2][j], w2, fmaf(T[1][j], w1, T[0][j] * w0)));
           const float t = wg * x;
           a1[s][j] += t;
@@ -220,16 +232,17 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
     }
     // every wave is through with the previous round's staging tile (its MFMA phase ended at a barrier) — this round's rows may be written
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < ((MF_KO & 16) ? 0 : 4); ++s) {
       const float Ws = wsumS[wave * 4 + s];
       const int row = wave * 4 + s;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < CPL; ++j) {
+        if (!lact) break;
         const float m = a1[s][j];
         const float vr = a2[s][j] - m * m * (2.f - Ws);   // sum w (x - m)^2 = sum w x^2 - m^2 (2 - sum w)
         const __bf16 mh = (__bf16)m, vh = (__bf16)vr;
         const __bf16 ml = (__bf16)(m - (float)mh), vl2 = (__bf16)(vr - (float)vh);
-        const int k = 3 * lane + j;
+        const int k = CPL * lane + j;
         st_hi[row * MF_LD + k] = __builtin_bit_cast(unsigned short, mh);
         st_lo[row * MF_LD + k] = __builtin_bit_cast(unsigned short, ml);
         st_hi[row * MF_LD + MF_C + k] = __builtin_bit_cast(unsigned short, vh);
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
       const int srow = 16 * half + col;
       mf_f32x4 acc = *(const mf_f32x4*)(partial + srow * 64 + 16 * nt + 4 * kq);
 #pragma unroll
-      for (int ks = 0; ks < MF_KS; ++ks) {
+      for (int ks = 0; ks < ((MF_KO & 8) ? 0 : MF_KS); ++ks) {
         const mf_u32x4 bh = *(const mf_u32x4*)(st_hi + srow * MF_LD + 32 * ks + 8 * kq);
         const mf_u32x4 bl = *(const mf_u32x4*)(st_lo + srow * MF_LD + 32 * ks + 8 * kq);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, wa[ks][1]), __builtin_bit_cast(mf_bf16x8, bh), acc, 0, 0, 0);

@@ -36,6 +36,7 @@ class SceneConfig:
     far: float = 5.0
     white_bkgd: bool = False
     seed: int = 1
+    lindisp: bool = False   # render.lindisp: base (and coarse) depths linear in disparity (model.py:451-458)
 
     @property
     def h(self) -> int:
@@ -262,6 +263,18 @@ def make_weights(cfg: SceneConfig, seed: int | None = None) -> Dict[str, np.ndar
                 fan_in = shp[1]
             a = rng.standard_normal(shp) * np.sqrt(2.0 / fan_in)
         out[name] = a.astype(F32)
+    return out
+
+
+def make_coord_desc_weights(cfg: "SceneConfig", seed: int = 0, matcher_dim: int = 192) -> Dict[str, np.ndarray]:
+    """Seeded weights of `coord_desc_mlp_{coarse,fine}` (model.py:115-131: 63 -> W -> W -> matcher_hidden_dim, the per-scene fine-tuning heads that
+    `use_scene_coord_memorization` adds — every shipped per-scene config turns it on)."""
+    rng = np.random.default_rng(seed + 7919)
+    out = {}
+    for lvl in ("coarse", "fine"):
+        for i, (n_out, n_in) in zip((0, 2, 4), ((cfg.W, 63), (cfg.W, cfg.W), (matcher_dim, cfg.W))):
+            out[f"coord_desc_mlp_{lvl}.{i}.weight"] = (rng.standard_normal((n_out, n_in)) / np.sqrt(n_in)).astype(F32)
+            out[f"coord_desc_mlp_{lvl}.{i}.bias"] = (0.1 * rng.standard_normal(n_out)).astype(F32)
     return out
 
 

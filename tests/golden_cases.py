@@ -24,6 +24,9 @@ CASES = {
     "s192out": (SceneConfig("s192out", R=12, S=192, W=256, V=10, H=64, Wimg=112, near=0.25, far=25.0, seed=19), False),
     # BASELINE config 5's shape class: hierarchical 64 coarse + 64 + 128 resampled = 192 samples, 16 views
     "hier192": (SceneConfig("hier192", R=12, S=64, N_importance=128, W=256, V=16, H=64, Wimg=64, seed=20), False),
+    # render.lindisp = True (model.py:451-458: depths linear in disparity), plain and hierarchical (round 4)
+    "lindisp": (TINY.replace(name="lindisp", lindisp=True, seed=23), True),
+    "hier_lindisp": (TINY.replace(name="hier_lindisp", S=16, N_importance=16, lindisp=True, seed=24), True),
 }
 
 

@@ -711,11 +711,9 @@ def test_training_with_feature_widths_that_are_not_multiples_of_four_takes_the_e
         if train:
             assert sum(x is not None for x in g[3:]) >= 80   # the eager graph reached the parameters
     # the library itself still says so when asked directly
-    xyz = (t(rays["rays_o"][:8])[:, None, :] + t(rays["rays_d"][:8])[:, None, :] * z[..., None]).reshape(-1, 3).contiguous()
-    G, _, _, _ = r.mv_aggregate(xyz, t(frame["pose"])[:3, 3])
-    tg = r.train_grads(list(dr.POINT_PARAMS), support_feature=True)
+    tg = r.train_grads(list(dr.RENDER_PARAMS), support_feature=True, feat_maps=True, vis_featmaps=True, blend_feat_maps=True)
     with pytest.raises(RuntimeError, match="unsupported shape or option"):
-        r.point_mlp_backward(xyz, None, G, torch.ones(xyz.shape[0], cfg.W, device=dev), K=8, train=tg)
+        r.render_rays_backward(t(rays["rays_o"][:8]), t(rays["rays_d"][:8]), z, t(frame["pose"])[:3, 3], g_rgb=torch.ones(8, 3, device=dev), train=tg)
 
 
 @pytest.mark.gpu

@@ -290,8 +290,8 @@ def _query_case(device):
     return case, cfg, data, t(pts), t(tc), t(tf)
 
 
-def _check_query_train(loss, desc_c, desc_f, ndc, named, data, tol):
-    g = np.load(os.path.join(GOLD, "train_query.npz"))
+def _check_query_train(loss, desc_c, desc_f, ndc, named, data, tol, coord=False):
+    g = np.load(os.path.join(GOLD, "train_query_coord.npz" if coord else "train_query.npz"))
     assert abs(float(loss.detach()) - float(g["loss"])) < tol * abs(float(g["loss"]))
     errs = {"desc_coarse": rel_err(desc_c.detach().cpu().numpy(), g["desc_coarse"]), "desc_fine": rel_err(desc_f.detach().cpu().numpy(), g["desc_fine"]),
             "pts3d_ndc": rel_err(ndc.detach().cpu().numpy(), g["pts3d_ndc"]),
@@ -322,7 +322,16 @@ def _check_query_train(loss, desc_c, desc_f, ndc, named, data, tol):
     return {k: e for k, e in errs.items() if k in want or k not in named}
 
 
-def test_query_training_gradients_through_the_dropin_match_reference_autograd_cpu(monkeypatch):
+def _query_weights(case, cfg, coord):
+    w = {k: torch.from_numpy(v) for k, v in case["weights"].items()}
+    if coord:   # use_scene_coord_memorization (model.py:115-131, 308-310, 338-340): desc += coord_desc_mlp(posenc(xyz)); golden train_query_coord.npz
+        from nerf_loc_amd.synth import make_coord_desc_weights
+        w.update({k: torch.from_numpy(v) for k, v in make_coord_desc_weights(cfg, cfg.seed).items()})
+    return w
+
+
+@pytest.mark.parametrize("coord", [False, True])
+def test_query_training_gradients_through_the_dropin_match_reference_autograd_cpu(monkeypatch, coord):
     """Train-mode query_coarse / query_fine on the drop-in module (round 2 returned detached descriptors here): the per-frame tables
     are built inside the graph and the gradient of a functional of desc_3d / desc_3d_fine reaches the 128 parameter tensors the
     reference's autograd reaches + both feature maps (tests/golden/train_query.npz).  CPU: the two library calls of this path — the
@@ -331,8 +340,8 @@ def test_query_training_gradients_through_the_dropin_match_reference_autograd_cp
     from tests.test_dropin_module import _args
     from nerf_loc_amd.conditional_nerf import ConditionalNeRF
     case, cfg, data, pts, tc, tf = _query_case("cpu")
-    net = ConditionalNeRF(_args(cfg)).train()
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    net = ConditionalNeRF(_args(cfg, coord)).train()
+    net.load_state_dict(_query_weights(case, cfg, coord), strict=True)
 
     class _Knn:
         def __init__(self, xyz): self.f = {K: knn_bruteforce(xyz.detach(), K) for K in (1, 8)}
@@ -349,8 +358,10 @@ def test_query_training_gradients_through_the_dropin_match_reference_autograd_cp
     loss = (desc_c * tc).sum() / len(pts) + (desc_f * tf).sum() / len(pts)
     loss.backward()
     # (5e-4: two small DepthFusionNet tensors sit at 2.7e-4 under a different fp32 summation order; the heads are at 1e-7, the CNN tensors around 5e-5)
-    errs = _check_query_train(loss, desc_c, desc_f, ndc, dict(net.named_parameters()), data, 5e-4)
+    errs = _check_query_train(loss, desc_c, desc_f, ndc, dict(net.named_parameters()), data, 5e-4, coord)
     assert float(np.median(list(errs.values()))) < 1e-4
+    if coord:
+        assert any(k.startswith("coord_desc_mlp_coarse") for k in errs) and any(k.startswith("coord_desc_mlp_fine") for k in errs)
     print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
     # eval mode under no_grad still takes the (HIP) inference path: without a GPU that raises instead of silently computing on the CPU
     net.eval()
@@ -360,24 +371,24 @@ def test_query_training_gradients_through_the_dropin_match_reference_autograd_cp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hip_nodes", [True, False])
-def test_query_training_gradients_through_the_dropin_match_reference_autograd_gpu(hip_nodes):
+@pytest.mark.parametrize("hip_nodes,coord", [(True, False), (False, False), (True, True)])
+def test_query_training_gradients_through_the_dropin_match_reference_autograd_gpu(hip_nodes, coord):
     """The same on the GPU: HIP KNN + HIP cross-view features, matcher-side gradients reach base_mlp.0.weight (and 127 more).
     hip_nodes: aggregation + neural-point branch as the library's training nodes (default) / the all-eager fp32 graph."""
     from tests.test_dropin_module import _args
     from nerf_loc_amd.conditional_nerf import ConditionalNeRF
     dev = torch.device("cuda:0")
     case, cfg, data, pts, tc, tf = _query_case(dev)
-    net = ConditionalNeRF(_args(cfg), precision="fp32").to(dev).train()
+    net = ConditionalNeRF(_args(cfg, coord), precision="fp32").to(dev).train()
     net.hip_training = hip_nodes
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
+    net.load_state_dict(_query_weights(case, cfg, coord), strict=True)
     net.support_neural_points = None
     net.multiview_aggregator.vis_featmaps = None
     desc_c, p3, ndc = net.query_coarse(data, pts)
     desc_f, _, _ = net.query_fine(data, pts)
     loss = (desc_c * tc).sum() / len(pts) + (desc_f * tf).sum() / len(pts)
     loss.backward()
-    errs = _check_query_train(loss, desc_c, desc_f, ndc, dict(net.named_parameters()), data, 3e-3)
+    errs = _check_query_train(loss, desc_c, desc_f, ndc, dict(net.named_parameters()), data, 3e-3, coord)
     assert float(np.median(list(errs.values()))) < 1e-3   # (MIOpen's convolutions put the per-frame CNN's tensors around 5e-4; the heads sit at 5e-6)
     print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
     # the graph path's forward equals the HIP inference path's descriptors

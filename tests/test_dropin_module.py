@@ -14,11 +14,11 @@ from tests.util import GOLDEN_DIR, load_golden, rel_err
 CFG = SceneConfig("setup", R=24, S=16, W=32, V=3, H=32, Wimg=48, seed=21)
 
 
-def _args(cfg):
+def _args(cfg, coord=False):
     return NS(multires=10, multires_views=4, i_embed=0, backbone2d_fpn_dim=cfg.C, model_3d_hidden_dim=cfg.W,
-              render=NS(N_samples=cfg.S, N_importance=cfg.N_importance, N_rand=1024, chunk=2048, lindisp=False, white_bkgd=False,
+              render=NS(N_samples=cfg.S, N_importance=cfg.N_importance, N_rand=1024, chunk=2048, lindisp=bool(cfg.lindisp), white_bkgd=False,
                         use_render_uncertainty=True, render_feature=True),
-              use_scene_coord_memorization=False, matcher_hidden_dim=192, use_depth_supervision=False, matching=NS(fine_num_3d_keypoints=1024))
+              use_scene_coord_memorization=bool(coord), matcher_hidden_dim=192, use_depth_supervision=False, matching=NS(fine_num_3d_keypoints=1024))
 
 
 def _weights(cfg):
@@ -37,6 +37,18 @@ def test_state_dict_contract_equals_reference():
     # strict load of a full reference-style checkpoint
     net = ConditionalNeRF(_args(CFG))
     net.load_state_dict(_weights(CFG), strict=True)
+    # ... and of a per-scene fine-tuned one: every shipped per-scene config (configs/7scenes/*.yaml, onepose/*.yaml) sets use_scene_coord_memorization, which
+    # adds the six tensors of coord_desc_mlp_{coarse,fine} (model.py:115-131); contract dumped from the reference by tools/gen_golden.py query
+    from nerf_loc_amd.synth import make_coord_desc_weights
+    want_c = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_contract_coord.json")))
+    net_c = ConditionalNeRF(_args(CFG, coord=True))
+    sd_c = net_c.state_dict()
+    assert set(sd_c) == set(want_c) and len(set(want_c) - set(want)) == 12, sorted(set(sd_c) ^ set(want_c))[:8]
+    for k, shp in want_c.items():
+        assert list(sd_c[k].shape) == shp, (k, tuple(sd_c[k].shape), shp)
+    wc = _weights(CFG)
+    wc.update({k: torch.from_numpy(v) for k, v in make_coord_desc_weights(CFG, CFG.seed).items()})
+    net_c.load_state_dict(wc, strict=True)
 
 
 def test_depth_fusion_cnn_matches_reference_vis_featmaps():

@@ -26,7 +26,7 @@ def _renderer(case, precision, **kw):
 
 def _z(cfg, R):
     from oracle.render_oracle import sample_depths
-    return sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(R, cfg.S).contiguous()
+    return sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far), cfg.lindisp).expand(R, cfg.S).contiguous()
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
@@ -187,14 +187,14 @@ def test_hierarchical_branch_matches_reference_golden(name):
     params, frame, rays = oracle_inputs(case)
     u = torch.from_numpy(case["u"])
     with torch.no_grad():
-        zb = orc.sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, cfg.S).contiguous()
-        zc = orc.sample_depths(64, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(cfg.R, 64).contiguous()
+        zb = orc.sample_depths(cfg.S, torch.tensor(cfg.near), torch.tensor(cfg.far), cfg.lindisp).expand(cfg.R, cfg.S).contiguous()
+        zc = orc.sample_depths(64, torch.tensor(cfg.near), torch.tensor(cfg.far), cfg.lindisp).expand(cfg.R, 64).contiguous()
         wc_o = orc.predict_weights_from_neuray(params, frame, rays, zc)
         zf = orc.sample_pdf(0.5 * (zc[:, :-1] + zc[:, 1:]), wc_o[:, 1:-1], cfg.N_importance, u)
         z_o = torch.sort(torch.cat([zb, zf], -1), -1)[0]
-    for precision in ("fp32", "bf16x3"):
+    for precision in ("fp32", "bf16x3", "f16mx"):
         r = _renderer(case, precision)
-        z, depth_coarse, wc = r.hierarchical_depths(case["rays"]["pixel_coordinates"], case["frame"]["K"], case["frame"]["pose"], zb, case["u"])
+        z, depth_coarse, wc = r.hierarchical_depths(case["rays"]["pixel_coordinates"], case["frame"]["K"], case["frame"]["pose"], zb, case["u"], lindisp=cfg.lindisp)
         assert rel_err(wc.cpu().numpy(), wc_o.numpy()) < 2e-5
         assert rel_err(depth_coarse.cpu().numpy(), g["depth_coarse"]) < 2e-5
         z_err = float((z.cpu() - z_o).abs().max()) / (cfg.far - cfg.near)

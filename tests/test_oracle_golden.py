@@ -19,7 +19,7 @@ def test_oracle_matches_reference_golden(name):
     g = load_golden(name)
     params, frame, rays = oracle_inputs(case)
     with torch.no_grad():
-        out = orc.render_rays(params, frame, rays, cfg.S, cfg.N_importance, u=torch.from_numpy(case["u"]), intermediates=True)
+        out = orc.render_rays(params, frame, rays, cfg.S, cfg.N_importance, u=torch.from_numpy(case["u"]), intermediates=True, lindisp=cfg.lindisp)
     # exact pieces
     assert np.array_equal(out["knn_d2"].numpy(), g["knn_d2"]), "KNN squared distances must be bit-exact"
     assert np.array_equal(out["mask"].numpy(), g["mask"])

@@ -17,6 +17,7 @@ Only outputs are written.  Nothing here travels to the GPU box except the .npz f
 """
 import ctypes
 import importlib
+import json
 import os
 import sys
 import types
@@ -86,11 +87,11 @@ def install_shims():
     return importlib.import_module("nerf_loc.models.conditional_nerf.model"), ku
 
 
-def ref_args(cfg):
+def ref_args(cfg, coord=False):
     return NS(multires=10, multires_views=4, i_embed=0, backbone2d_fpn_dim=cfg.C, model_3d_hidden_dim=cfg.W,
-              render=NS(N_samples=cfg.S, N_importance=cfg.N_importance, N_rand=1024, chunk=2048, lindisp=False,
+              render=NS(N_samples=cfg.S, N_importance=cfg.N_importance, N_rand=1024, chunk=2048, lindisp=bool(getattr(cfg, "lindisp", False)),
                         white_bkgd=False, use_render_uncertainty=True, render_feature=True),
-              use_scene_coord_memorization=False, matcher_hidden_dim=192, use_depth_supervision=False,
+              use_scene_coord_memorization=bool(coord), matcher_hidden_dim=192, use_depth_supervision=False,
               matching=NS(fine_num_3d_keypoints=1024))
 
 
@@ -318,7 +319,7 @@ def query_train_inputs(cfg, frame, seed):
     return pts.astype(np.float32), rng.standard_normal((len(pts), 192)).astype(np.float32), rng.standard_normal((len(pts), 192)).astype(np.float32)
 
 
-def run_query_train_case(model_mod, name="train_query"):
+def run_query_train_case(model_mod, name="train_query", coord=False):
     """The matcher-side training signal (nerf_pose_estimator.py:289-320, 445-468): in train() mode, caches reset, query_coarse(points)
     then query_fine(points) — the per-frame tables are built inside the graph — and a linear functional of the two descriptor sets
     back-propagated to EVERY parameter it reaches and to both feature maps."""
@@ -327,8 +328,14 @@ def run_query_train_case(model_mod, name="train_query"):
     frame = add_setup_inputs(cfg, make_frame(cfg))
     weights = dict(make_weights(cfg))
     weights.update(make_depth_fusion_weights(cfg.seed))
-    net = model_mod.ConditionalNeRF(ref_args(cfg)).train()
+    if coord:   # use_scene_coord_memorization = True (configs/7scenes/*.yaml, onepose/*.yaml): desc += coord_desc_mlp(posenc(xyz)), model.py:308-310, 338-340
+        from nerf_loc_amd.synth import make_coord_desc_weights
+        weights.update(make_coord_desc_weights(cfg, cfg.seed))
+    net = model_mod.ConditionalNeRF(ref_args(cfg, coord)).train()
     net.load_state_dict({k: t(v) for k, v in weights.items()}, strict=True)
+    if coord:
+        with open(os.path.join(ROOT, "tests", "golden", "state_dict_contract_coord.json"), "w") as fh:
+            json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, fh, indent=0, sort_keys=True)
     data = {k: t(frame[k]) for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "depth_range", "K", "pose")}
     data["feat_fine_src"] = data["feat_fine_src"].clone().requires_grad_(True)
     data["feat_coarse_src"] = data["feat_coarse_src"].clone().requires_grad_(True)
@@ -454,9 +461,11 @@ def main():
             run_grad_case(model_mod, ku, g)
         run_train_case(model_mod)
         run_train_case(model_mod, "train_hier", hier=True)
-        return run_query_train_case(model_mod)
+        run_query_train_case(model_mod)
+        return run_query_train_case(model_mod, "train_query_coord", coord=True)
     if len(sys.argv) > 1 and sys.argv[1] == "query":
-        return run_query_train_case(model_mod)
+        run_query_train_case(model_mod)
+        return run_query_train_case(model_mod, "train_query_coord", coord=True)
     names = sys.argv[1:] or list(CASES)
     for n in names:
         run_case(model_mod, ku, n)
@@ -468,6 +477,7 @@ def main():
         run_train_case(model_mod)
         run_train_case(model_mod, "train_hier", hier=True)
         run_query_train_case(model_mod)
+        run_query_train_case(model_mod, "train_query_coord", coord=True)
 
 
 if __name__ == "__main__":
