@@ -53,6 +53,11 @@ class NlRenderOpts(C.Structure):
     _fields_ = [("early_term_eps", C.c_float), ("flags", C.c_uint32), ("ray_centers", C.c_void_p), ("reserved", C.c_int32 * 4)]
 
 
+class NlRenderJob(C.Structure):   # include/nerfloc_render.h: nl_render_job
+    _fields_ = [("frame", C.c_void_p), ("query_center", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z_vals", C.c_void_p), ("R", C.c_int64),
+                ("out", C.POINTER(NlRenderOut)), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("opts", C.POINTER(NlRenderOpts))]
+
+
 class NlTrainGrads(C.Structure):
     _fields_ = [("weights", C.POINTER(C.c_void_p)), ("support_feature", C.c_void_p), ("feat_maps", C.c_void_p), ("vis_featmaps", C.c_void_p),
                 ("blend_feat_maps", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t), ("reserved", C.c_int32 * 4)]
@@ -100,6 +105,7 @@ SYMBOLS = [
     ("nl_render_rays_min_workspace_bytes", _Z, [_CFG, _I]),
     ("nl_render_rays", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P]),
     ("nl_render_rays_ex", _I, [_CFG, _P, _P, _P, _P, _P, _P, _L, _I, _OUT, _P, _Z, _P, C.POINTER(NlRenderOpts)]),
+    ("nl_render_rays_multi", _I, [_CFG, _P, C.POINTER(NlRenderJob), _I, _I, _P]),
     ("nl_setup_workspace_bytes", _Z, [_I, _I, _I, _I]),
     ("nl_cross_view_features", _I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _Z, _P]),
     ("nl_get_rays", _I, [_P, _P, _P, _I, _I, _L, _P, _P, _P]),

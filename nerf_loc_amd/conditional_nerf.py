@@ -603,6 +603,59 @@ class ConditionalNeRF(nn.Module):
             out["depth_coarse"] = depth_coarse
         return out
 
+    def _render_rays_multi(self, datas, rays_list, us=None):
+        """render_rays_frames for frames with DIFFERENT support sets (round 4; the reference resets its caches and loops: nerf_pose_estimator.py:289-290,
+        model.py:615-639): `datas[i]` is the `data` dict of frame i, `rays_list[i]` its rays.  Every frame gets its own renderer (frame tables, workspace)
+        from a pool; the per-frame setup runs frame by frame like the reference's, then ALL frames' rays go down in one library call
+        (nl_render_rays_multi: one launch chain per frame on library-owned streams).  Returns one output dict per frame, bit-identical to
+        `render_rays(datas[i], rays_list[i])`.  The module's caller-visible caches are left holding the LAST frame's tables."""
+        from .renderer import render_rays_multi
+        if len(datas) != len(rays_list):
+            raise ValueError("one rays dict per data dict")
+        base = self._renderer("fine")   # (packs the current weights if needed)
+        pool = self.__dict__.setdefault("_multi_pool", [])
+        while len(pool) < len(datas):
+            pool.append(HipRenderer(self.W, self.C, self.S, self._precision, device=str(base.device)))
+        ver = self._weights_version
+        sd = None
+        N = self.args.render.N_samples
+        jobs, dcs = [], []
+        for i, (data, rays) in enumerate(zip(datas, rays_list)):
+            r = pool[i]
+            if getattr(r, "_pool_weights_version", None) != ver or not r._weights_loaded:
+                if sd is None:
+                    sd = dict(self.state_dict())
+                    if "feat_mlp.0.weight" not in sd:
+                        z0 = next(self.parameters()).new_zeros
+                        sd.update({"feat_mlp.0.weight": z0(self.W, self.W), "feat_mlp.0.bias": z0(self.W), "feat_mlp.2.weight": z0(self.C, self.W),
+                                   "feat_mlp.2.bias": z0(self.C)})
+                r.load_weights(sd)
+                r._pool_weights_version = ver
+            # the per-frame setup, frame by frame (the reference's cache reset + rebuild)
+            self.support_neural_points = None
+            self.multiview_aggregator.vis_featmaps = None
+            self.build_support_neural_points(data)
+            sp = self.support_neural_points["fine"]
+            near, far = self._depth_range(data)
+            vis = self._vis_featmaps(data)
+            r.set_frame(data["topk_images"], data["feat_fine_src"].detach(), vis.detach(), data["topk_Ks"], data["topk_poses"], near, far,
+                        {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")})
+            rn, rf = rays["depth_range"]
+            o, d = rays["rays_o"], rays["rays_d"]
+            R = o.shape[0]
+            z = self.sample_depths(N, rn, rf).expand(R, N).contiguous()
+            if self.args.render.N_importance > 0:
+                u = us[i] if us is not None else torch.rand(R, self.args.render.N_importance, device=o.device)
+                z, dc, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=rn, far=rf, lindisp=bool(self.args.render.lindisp))
+                dcs.append(dc)
+            jobs.append((r, o, d, rays["pose"][:3, 3].detach(), {"z_vals": z, "white_bkgd": bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                                                                  "want_feat": bool(self.args.render.render_feature)}))
+        self._frame_token = {}   # (the single-frame renderers' tables no longer describe the module's caches)
+        outs = render_rays_multi(jobs)
+        for o_, dc in zip(outs, dcs):
+            o_["depth_coarse"] = dc
+        return outs
+
     def _render_rays(self, data, rays, u):
         r = self._ensure_frame(data, "fine")
         near, far = rays["depth_range"]
@@ -634,6 +687,8 @@ class ConditionalNeRF(nn.Module):
         Returns one output dict per frame, identical to render_rays(data_with_that_pose, rays)."""
         if self.training:
             raise NotImplementedError("render_rays_frames is an inference entry point")
+        if isinstance(data, (list, tuple)):
+            return self._render_rays_multi(list(data), rays_list, us)
         r = self._ensure_frame(data, "fine")
         N = self.args.render.N_samples
         os_, ds_, zs, cs, dcs, counts = [], [], [], [], [], []

@@ -753,6 +753,69 @@ class HipRenderer:
         return geo
 
 
+def render_rays_multi(jobs):
+    """Several frames — each a HipRenderer holding its own support set — in ONE library call (nl_render_rays_multi): job =
+    (renderer, rays_o, rays_d, query_center (3,) or (R, 3)[, kwargs: z_vals, white_bkgd, want_feat, early_term_eps]).  The renderers must be of one
+    configuration and hold the same weights (the first one's packed blob serves all).  Outputs are bit-identical to `renderer.render_rays(...)` per job;
+    the launch chains of the jobs run on library-owned streams forked from / joined into the current stream."""
+    jobs = list(jobs)
+    if not jobs:
+        return []
+    r0 = jobs[0][0]
+    dev, lib = r0.device, r0.lib
+    arr = (L.NlRenderJob * len(jobs))()
+    keep, outs = [], []
+    white = None
+    for i, job in enumerate(jobs):
+        r, o, d, qc = job[:4]
+        kw = dict(job[4]) if len(job) > 4 else {}
+        if (r.W, r.C, r.S, r.precision) != (r0.W, r0.C, r0.S, r0.precision):
+            raise ValueError("render_rays_multi: the renderers must share one configuration")
+        r._ready()
+        w = bool(kw.get("white_bkgd", False))
+        if white is None:
+            white = w
+        elif white != w:
+            raise ValueError("render_rays_multi: one white_bkgd for all jobs")
+        o, d = _dev_f32(o, dev), _dev_f32(d, dev)
+        R = o.shape[0]
+        z = kw.get("z_vals")
+        z = None if z is None else _dev_f32(z, dev)
+        qc_t = torch.as_tensor(qc).detach().float()
+        per_ray = qc_t.dim() == 2 or qc_t.is_cuda
+        if per_ray:
+            qc_t = qc_t.reshape(-1, 3).expand(R, 3).to(dev).contiguous()
+        else:
+            qc_t = qc_t.cpu().contiguous()
+        out = {"rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, r.S, device=dev),
+               "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev)}
+        if kw.get("want_feat", True):
+            out["feat"] = torch.empty(R, r.C, device=dev)
+        ro = L.NlRenderOut()
+        for k, t in out.items():
+            setattr(ro, k, t.data_ptr())
+        ws = r._workspace(r._ws_request or lib.nl_render_rays_workspace_bytes(ct.byref(r.cfg), r.V, R))
+        opts = L.NlRenderOpts()
+        opts.early_term_eps = float(kw.get("early_term_eps", 0.0))
+        if per_ray:
+            opts.ray_centers = qc_t.data_ptr()
+        a = arr[i]
+        a.frame, a.query_center = r._frame, (None if per_ray else qc_t.data_ptr())
+        a.rays_o, a.rays_d, a.z_vals, a.R = o.data_ptr(), d.data_ptr(), _ptr(z), R
+        a.out, a.ws, a.ws_bytes, a.opts = ct.pointer(ro), ws.data_ptr(), ws.numel(), ct.pointer(opts)
+        keep.append((o, d, z, qc_t, ro, opts, ws))
+        outs.append(out)
+    L.check(lib.nl_render_rays_multi(ct.byref(r0.cfg), r0.packed.data_ptr(), arr, len(jobs), int(bool(white)), r0._stream()), "nl_render_rays_multi")
+    cur = torch.cuda.current_stream(dev)
+    for tensors in keep:   # (the library's streams read these: the caching allocator must not recycle them before the current stream passed the join)
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
+    for out in outs:
+        out["mask"] = out["mask"].view(torch.bool)
+    return outs
+
+
 def render_rays_concurrent(jobs, streams=None):
     """Render several (renderer, rays_o, rays_d, query_center[, kwargs]) jobs — typically query frames with DIFFERENT support sets, one HipRenderer
     (frame tables, workspace, side stream) each — on separate HIP streams, so that the launch chains of small per-frame batches fill the chip together

@@ -710,10 +710,12 @@ def test_training_with_feature_widths_that_are_not_multiples_of_four_takes_the_e
         assert all(x is not None for x in g[:3])
         if train:
             assert sum(x is not None for x in g[3:]) >= 80   # the eager graph reached the parameters
-    # the library itself still says so when asked directly
+    # the library itself still says so when asked directly (the keep / kept pair a training step takes)
     tg = r.train_grads(list(dr.RENDER_PARAMS), support_feature=True, feat_maps=True, vis_featmaps=True, blend_feat_maps=True)
     with pytest.raises(RuntimeError, match="unsupported shape or option"):
-        r.render_rays_backward(t(rays["rays_o"][:8]), t(rays["rays_d"][:8]), z, t(frame["pose"])[:3, 3], g_rgb=torch.ones(8, 3, device=dev), train=tg)
+        kept = r.render_rays_keep(t(rays["rays_o"][:8]), t(rays["rays_d"][:8]), z, t(frame["pose"])[:3, 3], train=True)
+        assert kept is not None
+        r.render_rays_backward_kept(kept[1], g_rgb=torch.ones(8, 3, device=dev), g_feat=torch.ones(8, cfg.C, device=dev), train=tg)
 
 
 @pytest.mark.gpu

@@ -373,7 +373,8 @@ def test_ref_depth_loss_and_gradients_match_reference(case_name):
                        ("grad_mean_decoder_0_w", "multiview_aggregator.dist_decoder.mean_decoder.0.weight"),
                        ("grad_df_conv_out_w", "multiview_aggregator.depth_fusion.conv_out.weight"),
                        ("grad_df_conv1_w", "multiview_aggregator.depth_fusion.fuse_net.conv1.weight")):
-        assert rel_err(named[pname].grad.numpy(), g[key]) < 1e-4, (key, rel_err(named[pname].grad.numpy(), g[key]))
+        # (3e-4: the CNN's first-layer gradient sums thousands of terms in an order that follows the host's thread count — 1.4e-4 on a 256-core box, 3e-5 on 8 cores)
+        assert rel_err(named[pname].grad.numpy(), g[key]) < 3e-4, (key, rel_err(named[pname].grad.numpy(), g[key]))
     # the renderer's parameters are not reached by this loss
     assert named["base_mlp.0.weight"].grad is None
 
@@ -428,3 +429,42 @@ def test_several_query_frames_per_launch_equal_separate_calls():
             assert rel_err(got[k].cpu().numpy(), want[k].cpu().numpy()) < 1e-6, k
     # the frames do differ from each other (otherwise the centres would not matter)
     assert rel_err(singles[1]["rgb"][:16].cpu().numpy(), singles[0]["rgb"][:16].cpu().numpy()) > 1e-4
+
+
+@pytest.mark.gpu
+def test_frames_with_different_support_sets_in_one_call_equal_separate_calls():
+    """render_rays_frames with a LIST of data dicts (round 4; nl_render_rays_multi): three frames with three different support sets —
+    different scenes, and one of them a different number of rays — rendered by ONE library call are bit-identical to three render_rays calls with the caches
+    reset in between, the way the reference loops over frames (nerf_pose_estimator.py:289-290)."""
+    from tests.golden_cases import build_setup_case
+    dev = torch.device("cuda:0")
+    case = build_setup_case("setup")
+    net, data0, rd0 = _module_and_data(case, dev)
+    cfg = case["cfg"]
+    datas, rays_l, singles = [], [], []
+    for i, seed in enumerate((21, 77, 123)):
+        cfg_i = cfg.replace(seed=seed)
+        frame_i = add_setup_inputs(cfg_i, make_frame(cfg_i))
+        d_i = dict(data0)
+        for k in ("topk_images", "topk_depths", "topk_Ks", "topk_poses", "feat_fine_src", "feat_coarse_src", "K", "pose", "depth_range"):
+            d_i[k] = torch.from_numpy(np.ascontiguousarray(frame_i[k])).to(dev)
+        rays = net.points_2d_to_rays(rd0["pixel_coordinates"][: 24 - 5 * i], cfg.H, cfg.Wimg, d_i["K"], d_i["pose"])
+        rays["depth_range"] = rd0["depth_range"]
+        datas.append(d_i); rays_l.append(rays)
+        net.support_neural_points = None
+        net.multiview_aggregator.vis_featmaps = None
+        singles.append({k: v.clone() for k, v in net.render_rays(d_i, rays).items()})
+    outs = net.render_rays_frames(datas, rays_l)
+    assert len(outs) == 3
+    # (the library call itself is bit-identical to separate calls — tests/test_gpu_configs.py::test_render_rays_multi_is_bit_identical_to_separate_calls;
+    #  through the module the per-frame CNN runs again on MIOpen, whose results repeat to ~1e-6 only, like in test_frame_tables_follow_the_callers_cache_reset)
+    for got, want in zip(outs, singles):
+        assert torch.equal(got["mask"], want["mask"])
+        for k in ("rgb", "depth", "weights", "feat", "depth_uncertainty"):
+            assert got[k].shape == want[k].shape and rel_err(got[k].cpu().numpy(), want[k].cpu().numpy()) < 1e-5, k
+    assert rel_err(singles[1]["rgb"][:14].cpu().numpy(), singles[0]["rgb"][:14].cpu().numpy()) > 1e-3, "the frames must differ for this test to mean anything"
+    # the single-frame path still works afterwards (its renderer's tables are rebuilt for the module's current caches)
+    net.support_neural_points = None
+    net.multiview_aggregator.vis_featmaps = None
+    again = net.render_rays(datas[0], rays_l[0])
+    assert rel_err(again["rgb"].cpu().numpy(), singles[0]["rgb"].cpu().numpy()) < 1e-5

@@ -10,7 +10,8 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 cfg = CONFIGS["c2"]
 frame, weights = make_frame(cfg), make_weights(cfg)
 rays = make_rays(cfg, frame)
-r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "bf16x3")
+PREC = os.environ.get("PREC", "f16mx")
+r = HipRenderer(cfg.W, cfg.C, cfg.S_total, PREC)
 r.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
 r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
 dev = torch.device("cuda:0")
@@ -31,7 +32,7 @@ print(f"{F} query frames x {R} rays x {cfg.S} samples: one launch {one:.2f} ms (
 def other_frame(i):
     c = cfg.replace(seed=cfg.seed + 100 + i)
     fr = make_frame(c)
-    rr = HipRenderer(cfg.W, cfg.C, cfg.S_total, "bf16x3", workspace_bytes=None)
+    rr = HipRenderer(cfg.W, cfg.C, cfg.S_total, PREC, workspace_bytes=None)
     rr.packed = r.packed; rr._weights_loaded = True          # the same packed weights
     rr.set_frame(fr["topk_images"], fr["feat_fine_src"], fr["vis_featmaps"], fr["topk_Ks"], fr["topk_poses"], c.near, c.far, fr["support_fine"])
     ry = make_rays(c, fr)
@@ -48,3 +49,12 @@ a, b = serial(), concurrent()
 torch.cuda.synchronize()
 assert all(torch.equal(x[k], y[k]) for x, y in zip(a, b) for k in x), "concurrent rendering must be bit-identical to serial"
 print(f"{F} DIFFERENT support frames x {R} rays: one stream {ts:.2f} ms ({ts / F:.2f} per frame), {F} streams {tc:.2f} ms ({tc / F:.2f} per frame)")
+# ---- the same through ONE library call (round 4: nl_render_rays_multi — the fork / join over library-owned streams inside the C-ABI)
+from nerf_loc_amd.renderer import render_rays_multi
+def multi():
+    return render_rays_multi(frames)
+tm = timed(multi)
+c = multi()
+torch.cuda.synchronize()
+assert all(torch.equal(x[k], y[k]) for x, y in zip(a, c) for k in x), "nl_render_rays_multi must be bit-identical to separate calls"
+print(f"{F} DIFFERENT support frames x {R} rays: nl_render_rays_multi (one library call) {tm:.2f} ms ({tm / F:.2f} per frame)")
