@@ -55,12 +55,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16", "f16mx"])
+    ap.add_argument("--precision", default="f16mx", choices=["fp32", "bf16x3", "bf16", "f16mx"],
+                    help="f16mx (default since round 4): the parity mode with 2.0 instead of 3 MFMA-equivalents per product in the fused neural-point kernel")
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gradient-step", action="store_true", help="skip the (untimed for the headline) PoseOptimizer-step measurement")
     ap.add_argument("--force-gather", action="store_true", help="run the N>1 collective path on one GPU (single-rank RCCL group): a functional check")
-    ap.add_argument("--also", default="bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
+    ap.add_argument("--also", default="bf16x3,bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
     ap.add_argument("--early-term-eps", type=float, default=-1.0,
                     help="early-termination compositing threshold (nl_render_opts); default: 1e-5 for c5 (BASELINE names it there), 0 = off otherwise")
     ap.add_argument("--no-side-stream", action="store_true", help="NL_RENDER_NO_SIDE_STREAM: every kernel on one stream (profiling kernels one at a time)")
@@ -390,11 +391,13 @@ def hbm_traffic(config: str, precision: str):
     by tools/hbm_traffic.py; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  A constant read from a committed
     file, NOT measured in this run: it carries the fingerprint of the kernel sources it was measured on and says whether that is
     the build being benchmarked.  None when no committed measurement matches the workload."""
-    for name in ("r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+    for name in ("r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
-        if config != "c2" or precision != "bf16x3" or not os.path.exists(path):
+        if config != "c2" or not os.path.exists(path):
             continue
         d = json.load(open(path))
+        if d.get("precision", "bf16x3") != precision:
+            continue
         sha = d.get("sources_sha")
         return {"GB_per_step": d["fetch_GB_per_step_x2_gfx950_correction"] + d["write_GB_per_step"], "write_GB_per_step": d["write_GB_per_step"],
                 "source": f"profiles/{name} (separate rocprofv3 --pmc passes, not this run)", "measured_on_sources": sha,

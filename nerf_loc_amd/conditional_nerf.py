@@ -175,7 +175,7 @@ class ConditionalNeRF(nn.Module):
         self.__dict__["_sp_gen"] = self.__dict__.get("_sp_gen", 0) + 1
         self.__dict__["_sp_from_hip"] = False   # set by _build_support_hip: tables this module built itself, without a graph
 
-    def __init__(self, args, activation_func=None, precision: str = "bf16x3", device: Optional[str] = None):
+    def __init__(self, args, activation_func=None, precision: str = "f16mx", device: Optional[str] = None):
         super().__init__()
         self.args = copy.deepcopy(args)
         C, W = args.backbone2d_fpn_dim, args.model_3d_hidden_dim

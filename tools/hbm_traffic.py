@@ -18,9 +18,10 @@ def total(dbpath, counter):
 
 def main():
     fdb, wdb, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    prec = sys.argv[5] if len(sys.argv) > 5 else "f16mx"
     import bench
     f_kb, w_kb = total(fdb, "FETCH_SIZE"), total(wdb, "WRITE_SIZE")
-    d = {"config": "c2 bf16x3", "render_steps_in_run": steps,
+    d = {"config": f"c2 {prec}", "precision": prec, "render_steps_in_run": steps,
          "fetch_GB_per_step_raw": f_kb * 1024 / steps / 1e9,
          "fetch_GB_per_step_x2_gfx950_correction": 2 * f_kb * 1024 / steps / 1e9,
          "write_GB_per_step": w_kb * 1024 / steps / 1e9,
