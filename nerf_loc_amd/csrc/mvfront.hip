@@ -37,9 +37,13 @@ constexpr int MF_CPL_ = MF_CPL;    // channels per lane in phase B: 3 = all 64 l
 constexpr int MF_C = 192;          // feature channels (3 per lane)
 constexpr int MF_KS = 12;          // k-steps of 32: [mean 192 | variance 192]
 constexpr int MF_LD = 392;         // staging row stride in halves (384 + pad)
-constexpr int MF_NS = 32;          // samples per round (8 waves x 4)
+#ifndef MF_NW
+#define MF_NW 8
+#endif
+constexpr int MF_NWAVES = MF_NW;   // waves per workgroup: 8 (two per SIMD) or 4 (one per SIMD: leaves half of the register file to co-resident kernels — the exact KNN on the side stream)
+constexpr int MF_NS = 4 * MF_NWAVES;   // samples per round (4 per wave)
 constexpr int MF_SLOT = 8;         // dwords per (sample, view): packed cell, 4 tap weights, view weight, 2 unused
-constexpr int MF_LDS_BYTES = 2 * MF_NS * MF_LD * 2 + MF_NS * 64 * 4 + 8 * 4 * 16 * MF_SLOT * 4 + MF_NS * 4;
+constexpr int MF_LDS_BYTES = 2 * MF_NS * MF_LD * 2 + MF_NS * 64 * 4 + MF_NWAVES * 4 * 16 * MF_SLOT * 4 + MF_NS * 4;
 
 __device__ __forceinline__ float mf_sum16(float v) {   // sum over an aligned group of 16 lanes (a DPP row), result in all 16
   v = nl_sum8(v);
@@ -75,7 +79,7 @@ __global__ void pack_mv_front_kernel(const float* __restrict__ w /*(64, 393)*/, 
   }
 }
 
-__global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
+__global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
                                                           const float* __restrict__ feat /*(V,h,w,192)*/, const float* __restrict__ xyz, int N,
                                                           const float* __restrict__ vis_in, const float* __restrict__ dd_in,
                                                           const mf_u32x4* __restrict__ wpack, const float* __restrict__ w9g, float* __restrict__ t64,
@@ -85,14 +89,14 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
   unsigned short* st_lo = st_hi + MF_NS * MF_LD;
   float* partial = reinterpret_cast<float*>(st_lo + MF_NS * MF_LD);   // [32][64]
   float* slots = partial + MF_NS * 64;                                  // [8 waves][4 samples][16 views][MF_SLOT]
-  float* wsumS = slots + 8 * 4 * 16 * MF_SLOT;                          // [32]
+  float* wsumS = slots + MF_NWAVES * 4 * 16 * MF_SLOT;                  // [MF_NS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int V = vw.V;
   const int HW = vw.H * vw.Wimg;
   const size_t fmap = (size_t)vw.h * vw.w;
 
   // ---- resident: this wave's slice of out_fc.0 (n-tile nt) as A fragments, the small columns' row of output unit `lane`
-  const int nt = wave & 3, half = wave >> 2;
+  const int nt = wave & 3, half = wave >> 2;   // (4 waves: every wave one n-tile, one half of 16 samples)
   mf_u32x4 wa[MF_KS][2];
 #pragma unroll
   for (int ks = 0; ks < MF_KS; ++ks) {
@@ -194,7 +198,13 @@ __global__ __launch_bounds__(512, 1) void mv_front_kernel(const NlViews vw, cons
       for (int j = 0; j < CPL; ++j) a1[s][j] = a2[s][j] = 0.f;
     const bool lact = CPL * lane < MF_C;
     const unsigned lch = lact ? (unsigned)(CPL * lane) : 0u;   // (idle lanes re-read channel group 0: no exec-masked loads)
-    for (int v = 0; v < ((MF_KO & 2) ? 0 : V); ++v) {
+    // The eight waves of a workgroup walk neighbouring samples: started on the same view they would miss on the same cold texel rows at the same moment
+    // (eight requests to L2 per row, all waiting for the slowest).  Every wave starts its view loop at a different view — a function of the wave's position in
+    // its RAY, so that a sample's summation order does not depend on how the batch was chunked — and finds most rows already fetched by a neighbour.
+    const int rot = (int)(((unsigned)n0 % (unsigned)(vw.qS > 0 ? vw.qS : 1)) >> 2) % V;
+    for (int vi = 0; vi < ((MF_KO & 2) ? 0 : V); ++vi) {
+      int v = vi + rot;
+      v = v >= V ? v - V : v;
       if (!((vmask >> v) & 1u)) continue;   // weight exactly 0 for all four samples: nothing of this view reaches a statistic (wave-uniform)
       const float* fb = feat + (size_t)v * fmap * MF_C;
       float T[4][CPL];
@@ -301,7 +311,7 @@ int nl_launch_mv_front(const NlViews& vw, const float* viewsdev, const float* im
   const int blocks = nrounds < g_mf_cus ? (int)nl_xcd_grid(nrounds) : g_mf_cus;
   const int rpb = (int)nl_cdiv(nrounds, blocks);
   const float* w9 = reinterpret_cast<const float*>((const char*)pack + (size_t)4 * MF_KS * 2 * 64 * 16);
-  hipLaunchKernelGGL(mv_front_kernel, dim3(blocks), dim3(512), MF_LDS_BYTES, st, vw, viewsdev, images, feat, xyz, (int)N, vis_in, dd_in, (const mf_u32x4*)pack, w9, t64,
+  hipLaunchKernelGGL(mv_front_kernel, dim3(blocks), dim3(64 * MF_NWAVES), MF_LDS_BYTES, st, vw, viewsdev, images, feat, xyz, (int)N, vis_in, dd_in, (const mf_u32x4*)pack, w9, t64,
                      valid_s, rgbv, nrounds, rpb);
   NL_LAUNCH_CHECK();
   return NL_OK;

@@ -1,12 +1,8 @@
-#!/usr/bin/env python3
-"""Times the multi-view front end alone (mv_vis + mv_front through nl_render_rays is not separable from outside: this times whole c2 steps in f16mx; differences
-between libraries built with knock-outs (NERFLOC_LIB) give the share of each ingredient)."""
-import os, sys, time
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
 from nerf_loc_amd.renderer import HipRenderer
 from nerf_loc_amd.synth import CONFIGS, make_frame, make_rays, make_weights
-cfg = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
+cfg = CONFIGS["c2"]
 frame, weights = make_frame(cfg), make_weights(cfg)
 rays = make_rays(cfg, frame, seed_offset=1000)
 r = HipRenderer(cfg.W, cfg.C, cfg.S_total, "f16mx")
@@ -16,8 +12,9 @@ o, d = torch.from_numpy(rays["rays_o"]).cuda(), torch.from_numpy(rays["rays_d"])
 lin = torch.linspace(0, 1, cfg.S)
 z = (torch.tensor(cfg.near) * (1 - lin) + torch.tensor(cfg.far) * lin).expand(cfg.R, cfg.S).contiguous().cuda()
 qc = frame["pose"][:3, 3]
-for _ in range(3): r.render_rays(o, d, qc, z_vals=z, side_stream=False)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): r.render_rays(o, d, qc, z_vals=z, side_stream=False)
-torch.cuda.synchronize()
-print(f"{os.environ.get('NERFLOC_LIB', 'default')[-20:]}: {(time.perf_counter() - t0) * 50:.3f} ms per step (serial)")
+for ss in (False, True):
+    for _ in range(3): r.render_rays(o, d, qc, z_vals=z, side_stream=ss)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): r.render_rays(o, d, qc, z_vals=z, side_stream=ss)
+    torch.cuda.synchronize()
+    print(f"{os.environ.get('NERFLOC_LIB', 'default')[-22:]} side_stream={ss}: {(time.perf_counter() - t0) * 50:.3f} ms per step")
