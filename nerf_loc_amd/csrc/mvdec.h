@@ -175,11 +175,22 @@ __device__ __forceinline__ void mvd_load_lds(uint4* sw, const uint4* __restrict_
 }
 
 template <bool X3> struct MvdOps;
+typedef unsigned mvd_u32x4 __attribute__((ext_vector_type(4)));
 template <> struct MvdOps<true> {
   typedef mvd_f16x8 v8;
+  // hi = f16(v), lo = f16(v - hi): per pair v_cvt_pk_f16_f32 | 2 x v_fma_mix_f32 (reads the f16 half directly: no v_cvt_f32_f16, no separate subtraction) |
+  // v_cvt_pk_f16_f32 = 2 vector instructions per value instead of 3.5 (round 4: the kernel is bound by its vector instruction count, profiles/r4_pmc_sq.csv)
   static __device__ __forceinline__ void split(const float (&v)[8], v8& hi, v8& lo) {
+    mvd_u32x4 h, l;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { const _Float16 h = (_Float16)v[t]; hi[t] = h; lo[t] = (_Float16)(v[t] - (float)h); }
+    for (int t = 0; t < 4; ++t) {
+      unsigned hp, lp; float l0, l1;
+      asm("v_cvt_pk_f16_f32 %0, %3, %4\n\tv_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+          : "=&v"(hp), "=&v"(l0), "=&v"(l1) : "v"(v[2 * t]), "v"(v[2 * t + 1]));
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(l0), "v"(l1));
+      h[t] = hp; l[t] = lp;
+    }
+    hi = __builtin_bit_cast(v8, h); lo = __builtin_bit_cast(v8, l);
   }
   static __device__ __forceinline__ mvd_f32x16 mfma(v8 a, v8 b, mvd_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
@@ -196,6 +207,18 @@ template <> struct MvdOps<false> {
 __device__ __forceinline__ void mvd_split_bf16(const float (&v)[8], mvd_bf16x8& hi, mvd_bf16x8& lo) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) { const __bf16 h = (__bf16)v[t]; hi[t] = h; lo[t] = (__bf16)(v[t] - (float)h); }
+}
+
+// ELU of two values at once (x > 0 ? x : exp(x) - 1 with the exponential on the hardware exp2 unit, as nl_elu_fast): the scale by log2(e) and the -1 are ONE packed
+// instruction each for the pair (v_pk_mul_f32, v_pk_add_f32) — 8 vector instructions per pair instead of 10
+typedef float mvd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mvd_elu2(float& a, float& b) {
+  const mvd_f32x2 x = {a, b};
+  const mvd_f32x2 y = x * mvd_f32x2{1.4426950408889634f, 1.4426950408889634f};
+  mvd_f32x2 e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+  e = e - mvd_f32x2{1.f, 1.f};
+  a = x[0] > 0.f ? x[0] : e[0];
+  b = x[1] > 0.f ? x[1] : e[1];
 }
 
 // this lane's 16 channels of the bilinear (border, align_corners = False) tap of the channels-last 32-channel visibility map at
@@ -219,10 +242,11 @@ __device__ __forceinline__ void mvd_tap16(const float* __restrict__ base /* view
       const float4 a = *(const float4*)(base + o00 + co), b = *(const float4*)(base + o01 + co);
       const float4 c = *(const float4*)(base + o10 + co), d = *(const float4*)(base + o11 + co);
       float* dst = g ? x1 : x0;
-      dst[4 * c4 + 0] = a.x * w00 + b.x * w01 + c.x * w10 + d.x * w11;
-      dst[4 * c4 + 1] = a.y * w00 + b.y * w01 + c.y * w10 + d.y * w11;
-      dst[4 * c4 + 2] = a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11;
-      dst[4 * c4 + 3] = a.w * w00 + b.w * w01 + c.w * w10 + d.w * w11;
+      // (explicit fma chains: the file is built with -ffp-contract=off, which costs 7 instructions per tap sum instead of 4)
+      dst[4 * c4 + 0] = fmaf(d.x, w11, fmaf(c.x, w10, fmaf(b.x, w01, a.x * w00)));
+      dst[4 * c4 + 1] = fmaf(d.y, w11, fmaf(c.y, w10, fmaf(b.y, w01, a.y * w00)));
+      dst[4 * c4 + 2] = fmaf(d.z, w11, fmaf(c.z, w10, fmaf(b.z, w01, a.z * w00)));
+      dst[4 * c4 + 3] = fmaf(d.w, w11, fmaf(c.w, w10, fmaf(b.w, w01, a.w * w00)));
     }
   }
 }
@@ -264,7 +288,9 @@ __device__ __forceinline__ void mvd_decode_tile(const uint4* sw, int lane, const
     for (int s = 0; s < 2; ++s) {
       float vv[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) vv[t] = nl_elu_fast(acc[8 * s + t]);
+      for (int t = 0; t < 8; ++t) vv[t] = acc[8 * s + t];
+#pragma unroll
+      for (int t = 0; t < 8; t += 2) mvd_elu2(vv[t], vv[t + 1]);
       OP::split(vv, gh[s], gl[s]);
     }
     mvd_f32x16 acc2;
@@ -285,7 +311,9 @@ __device__ __forceinline__ void mvd_decode_tile(const uint4* sw, int lane, const
     }
     float h2[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h2[r] = nl_elu_fast(acc2[r]);
+    for (int r = 0; r < 16; ++r) h2[r] = acc2[r];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mvd_elu2(h2[r], h2[r + 1]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       float p = 0.f;
