@@ -80,7 +80,10 @@ def test_per_frame_setup_has_no_cpu_path():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case_name,precision,tol", [("setup", "fp32", 1e-4), ("setup", "bf16x3", 2e-4), ("setup_holes", "bf16x3", 2e-4)])
+# (round 4: stage B — the per-frame CNN on MIOpen included — is held to BASELINE's 1e-4 as well; measured with tools/e2e_check.py: vis_featmaps 2.4e-5 / 4.8e-5,
+#  worst output 1.3e-5 (setup) / 6.3e-5 (setup_holes: desc_fine), the same in every mode — it is the CNN's summation order, not the renderer)
+@pytest.mark.parametrize("case_name,precision,tol", [("setup", "fp32", 1e-4), ("setup", "bf16x3", 1e-4), ("setup", "f16mx", 1e-4), ("setup_holes", "bf16x3", 1e-4),
+                                                     ("setup_holes", "f16mx", 1e-4)])
 def test_dropin_end_to_end_matches_reference(case_name, precision, tol):
     """Same calls the reference's pose estimator makes: caches reset -> render_rays builds the frame (DepthFusionNet,
     back-projection, confidence) and renders; then descriptor queries.  Tolerance: setup (CNN on ROCm vs CPU) + renderer."""
