@@ -1288,6 +1288,7 @@ __global__ __launch_bounds__(256) void dec_backward_mfma_kernel(const NlViews vw
   __shared__ uint4 sw[MVD_LDS_UINT4 + 2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, j = lane & 31;
+  __builtin_amdgcn_s_setreg(1473, 1);   // MODE.FP16_OVFL: the split-fp16 conversions of the recomputed forward saturate instead of overflowing to inf
   mvd_load_lds<true>(sw, dpack, tid, 256);
   for (int i = tid; i < 2048; i += 256) sw[MVD_LDS_UINT4 + i] = dpack[MVD_T + i];
   __syncthreads();

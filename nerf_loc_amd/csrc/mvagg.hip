@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void mv_vis_mfma_kernel(const NlViews vw, cons
   __shared__ uint4 sw[MVD_LDS_UINT4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, j = lane & 31;
+  if (X3) __builtin_amdgcn_s_setreg(1473, 1);   // MODE.FP16_OVFL: the split-fp16 conversions saturate instead of overflowing to inf
   mvd_load_lds<X3>(sw, dpack, tid, 256);
   __syncthreads();
 

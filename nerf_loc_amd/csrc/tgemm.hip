@@ -87,6 +87,9 @@ __device__ unsigned long long tg_trace[64];
 template <int NRT, int NW, bool X3, int EPI, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c,
                                                             const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
+  // split-FP16 arithmetic (the backward passes' recomputed forward): MODE.FP16_OVFL makes the f32 -> f16 conversions SATURATE at 65504 instead of producing inf,
+  // so an activation beyond fp16's range costs accuracy, not a NaN gradient (tests/test_backward_kernels.py::test_huge_feature_maps_...)
+  if (F16) __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1)
   constexpr int PARTS = X3 ? 2 : 1;
   constexpr int PIECES = PARTS * 2 * NRT;   // 1-KB pieces of weights per chunk
   // waves that stage weights: all of them, or the first four of a six-wave workgroup (S = 192 / 96 slabs: a ray = six / three row tiles; 8 ... 32
