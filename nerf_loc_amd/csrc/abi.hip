@@ -548,6 +548,12 @@ void carve_hd(Bump& b, const nl_config* c, int V, int64_t R, HdBufs& h) {
   h.n_alive = b.take<int>((size_t)R); h.tile_list = b.take<int>(N / 32 + 2); h.tile_count = b.take<int>(1);
 }
 
+// whether the fused render path runs statistics + out_fc.0 in mv_front_kernel and recomputes the blend taps (round 4): a function of the configuration alone,
+// so that workspace sizing and the render call agree
+inline bool front_path(const nl_config* c, int V) {
+  return !dbg_switch("NERFLOC_NO_FRONT") && c->precision != NL_PREC_F32 && nl_mv_front_supported(c->C, V, 1);
+}
+
 struct RenderBufs {
   float *xyz, *z, *G, *bl1, *rgbv, *FA, *geo; int* valid_s;
   MvBufs mv; PtBufs pt; UnBufs un; HdBufs hd;
@@ -556,7 +562,11 @@ void carve_render(Bump& b, const nl_config* c, int V, int64_t R, RenderBufs& rb)
   const size_t N = (size_t)R * c->S;
   rb.xyz = b.take<float>(N * 3); rb.z = b.take<float>(N);
   rb.G = b.take<float>(N * c->W);
-  rb.bl1 = b.take<float>(N * V * 32); rb.rgbv = b.take<float>(N * V * 4);
+  // the blend layer's per-(sample, view) rows exist only where mv_front_kernel + blend_taps_kernel do not apply (other feature widths, fp32 mode, debug switch):
+  // at config 2 that is 0.67 GB of the chunk's workspace
+  rb.bl1 = front_path(c, V) ? nullptr : b.take<float>(N * V * 32);
+  rb.rgbv = b.take<float>(N * V * 4);
+  // (the statistics row of the old path is not needed then either, but carve_mv serves the stage API too)
   rb.valid_s = b.take<int>(N);
   rb.FA = b.take<float>(N * c->W); rb.geo = b.take<float>(N * c->W);
   carve_mv(b, c, V, N, rb.mv); carve_pt(b, c, N, 8, rb.pt); carve_un(b, c, R, rb.un); carve_hd(b, c, V, R, rb.hd);
@@ -2303,7 +2313,7 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     // the stage output or when the separate launches run instead
     const bool use_chain = !dbg_switch("NERFLOC_NO_CHAIN") && W == 256 && cfg->precision != NL_PREC_F32 && N * 1024 <= 0x7fffffffll &&
                            nl_point_fused_supported(W, cfg->precision);
-    const bool front = !dbg_switch("NERFLOC_NO_FRONT") && cfg->precision != NL_PREC_F32 && nl_mv_front_supported(f->C, V, N);
+    const bool front = front_path(cfg, V) && f->C == cfg->C && nl_mv_front_supported(f->C, V, N) && rb.bl1 == nullptr;
     NL_TRY(do_mv(x, f, qc, rb.xyz, N, rb.G, nullptr, nullptr, rb.valid_s, front ? nullptr : rb.bl1, rb.rgbv, rb.mv, use_chain && !out->mv_feature_agg,
                  ray_centers ? ray_centers + 3 * r0 : nullptr, S, front));
     BlendTaps bt{with_query(f, qc, ray_centers ? ray_centers + 3 * r0 : nullptr, S), f->views_dev, f->pfeat, rb.xyz};

@@ -294,7 +294,7 @@ int nl_pack_mv_front(const float* w_outfc0, const float* b_outfc0, void* out, hi
   return NL_OK;
 }
 
-bool nl_mv_front_supported(int C, int V, int64_t N) { return C == MF_C && V >= 1 && V <= 16 && N > 0 && N * 64 * 4 <= 0x7fffffffll * 4; }
+bool nl_mv_front_supported(int C, int V, int64_t N) { return C == MF_C && V >= 1 && V <= NL_MAX_VIEWS && N > 0 && N <= 0x7fffffffll / 32; }   // (int sample indices; rounds of 32)
 
 // statistics + out_fc.0 of N samples: t64 (N, 64) hidden rows (post-ELU), valid_s (N), rgbv (N, V, 4) = tapped colours + visibility
 int nl_launch_mv_front(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, const float* xyz, int64_t N, const float* vis_in,
