@@ -305,8 +305,9 @@ int nl_launch_mv_front(const NlViews& vw, const float* viewsdev, const float* im
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
     g_mf_cus = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-    if (hipFuncSetAttribute((const void*)mv_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) != hipSuccess) return NL_ERR_HIP;
   }
+  // (per device, and the call is a table look-up: set every time rather than remembered per process)
+  if (hipFuncSetAttribute((const void*)mv_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) != hipSuccess) return NL_ERR_HIP;
   const int nrounds = (int)nl_cdiv(N, MF_NS);
   const int blocks = nrounds < g_mf_cus ? (int)nl_xcd_grid(nrounds) : g_mf_cus;
   const int rpb = (int)nl_cdiv(nrounds, blocks);
