@@ -28,7 +28,7 @@ typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned mf_u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef MF_KO
-#define MF_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no texel loads in phase B, 2 no phase B, 4 no colour taps in phase A, 8 no MFMA phase, 16 no staging writes
+#define MF_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no texel loads in phase B, 2 no phase B, 4 no colour taps in phase A, 8 no MFMA phase, 16 no staging writes, 64 every texel fetch from texel 0 (all cache hits)
 #endif
 #ifndef MF_CPL
 #define MF_CPL 3
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
         if (cell != cur && !(MF_KO & 1)) {   // wave-uniform: the four texel rows of the new cell
           cur = cell;
           int o[4];
-          unpack_taps(cell, vw.w, o);
+          unpack_taps((MF_KO & 64) ? (cell & 0xc0000000u) : cell, vw.w, o);   // (knock-out 64: every fetch from texel 0 of the view — all hits)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float* p = fb + ((unsigned)o[k] * (unsigned)MF_C + lch);

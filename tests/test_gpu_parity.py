@@ -246,9 +246,10 @@ def c2():
     return {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": make_weights(cfg)}
 
 
-def test_full_size_properties_c2(c2):
+@pytest.mark.parametrize("prec", ["f16mx", "bf16x3"])
+def test_full_size_properties_c2(c2, prec):
     cfg = c2["cfg"]
-    r = _renderer(c2, "bf16x3")
+    r = _renderer(c2, prec)
     o, d = c2["rays"]["rays_o"], c2["rays"]["rays_d"]
     qc = c2["frame"]["pose"][:3, 3]
     z = _z(cfg, cfg.R)
@@ -267,7 +268,7 @@ def test_full_size_properties_c2(c2):
     from nerf_loc_amd import _lib
     import ctypes as ct
     small = _lib.load().nl_render_rays_workspace_bytes(ct.byref(r.cfg), r.V, 96)
-    r2 = _renderer(c2, "bf16x3", workspace_bytes=small)
+    r2 = _renderer(c2, prec, workspace_bytes=small)
     c = r2.render_rays(o, d, qc, z_vals=z)
     for k in a:
         assert torch.equal(a[k], c[k]), k
@@ -279,22 +280,27 @@ def test_full_size_properties_c2(c2):
 
 
 def test_full_size_sampled_rays_match_oracle_c2(c2):
-    """64 of the 4096 rays of the headline workload against the CPU oracle (bf16x3, 1e-4)."""
+    """64 of the 4096 rays of the headline workload against the CPU oracle (both parity modes, 1e-4)."""
     from oracle import render_oracle as orc
     cfg = c2["cfg"]
     sel = np.arange(0, cfg.R, cfg.R // 64)[:64]
     r = _renderer(c2, "bf16x3")
     z = _z(cfg, len(sel))
-    out = r.render_rays(c2["rays"]["rays_o"][sel], c2["rays"]["rays_d"][sel], c2["frame"]["pose"][:3, 3], z_vals=z)
+    outs = {}
+    for prec in ("bf16x3", "f16mx"):
+        r.set_precision(prec)
+        outs[prec] = r.render_rays(c2["rays"]["rays_o"][sel], c2["rays"]["rays_d"][sel], c2["frame"]["pose"][:3, 3], z_vals=z)
+    out = outs["bf16x3"]
     params = {k: torch.from_numpy(v) for k, v in c2["weights"].items()}
     sub = {k: (torch.from_numpy(v[sel]) if k in ("rays_o", "rays_d", "pixel_coordinates") else (torch.from_numpy(v) if isinstance(v, np.ndarray) else v))
            for k, v in c2["rays"].items()}
     torch.set_num_threads(16)
     with torch.no_grad():
         ref = orc.render_rays(params, orc.to_torch(c2["frame"]), sub, cfg.S, knn_threads=16)
-    assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
-    for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
-        assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 1e-4, (k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
+    for prec, out in outs.items():
+        assert np.array_equal(out["mask"].cpu().numpy(), ref["mask"].numpy())
+        for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat"):
+            assert rel_err(out[k].cpu().numpy(), ref[k].numpy()) < 1e-4, (prec, k, rel_err(out[k].cpu().numpy(), ref[k].numpy()))
 
 
 # ------------------------------------------------------------------ empty and ragged ray batches

@@ -84,7 +84,7 @@ def run(ncases=20, seed0=0, verbose=True):
 
         keep = ~borderline_rays(cfg, frame, rays, zref)
         worst = ("", 0.0)
-        for precision in ("fp32", "bf16x3"):
+        for precision in ("fp32", "bf16x3", "f16mx"):   # (f16mx differs from bf16x3 where the fused neural-point kernel runs: W = 128, 256)
             r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
             r.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
             r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])

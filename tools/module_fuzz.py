@@ -17,7 +17,7 @@ def _args(cfg):
               use_scene_coord_memorization=False, matcher_hidden_dim=192, use_depth_supervision=False, matching=NS(fine_num_3d_keypoints=1024))
 
 
-def run(ncases=6, seed0=0, precision="bf16x3"):
+def run(ncases=6, seed0=0, precision="f16mx"):
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     worst_all = 0.0
