@@ -66,7 +66,7 @@ int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale
                            float* blA, int64_t M, int precision, hipStream_t st);
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
-int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false);
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false, float* keep_kv = nullptr, unsigned* const* keep_mk = nullptr);
 // backward.hip: glue kernels of the neural-point branch's input gradient
 int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
                     float* gb, float* scratch, size_t scratch_floats, hipStream_t st);
@@ -175,7 +175,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bsh[G_COUNT], bias[G_COUNT];   // bsh: the weight stream in fp16 hi / lo (split-FP16 arithmetic)
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_stream2_f16, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
   size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
   int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
@@ -290,6 +290,7 @@ Layout make_layout(const nl_config* c) {
   L.pt_stream = take((W == 64 || W == 128 || W == 256) ? nl_point_stream_bytes(W) : 256);
   L.pt_stream2 = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);
   L.pt_stream2_mx = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);   // NL_PREC_F16MX: f16 fragments + fp8 images of layers 2, 3, k / v
+  L.pt_stream2_f16 = take((W == 128 || W == 128 * 2) ? nl_point_stream2_bytes(W) : 256);  // split-FP16 stream: the gradient path's fused forward (pt_forward_keep_fused)
   L.pt_mx_sc = take(4 * 64);
   L.mvf_pack = take(nl_mv_front_pack_bytes());                                          // out_fc.0 as register-resident A fragments of mv_front_kernel (C = 192)                                                            // their per-chunk scale bytes while packing
   L.zeros = take(4096);
@@ -938,6 +939,35 @@ int pt_forward_staged(const Ctx& x, const nl_frame* f, const float* xyz, const f
   NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
   return run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE);
 }
+// Frozen weights (pose refinement: no weight gradient wants the layers' activations), W = 128 / 256, K = 8, non-fp32 modes: the branch's forward as ONE launch of the
+// fused neural-point kernel in split-FP16 (point_fused2_kernel<NRT, true, false, F16, KEEP>) that also leaves the k / v rows and the three layers' sign bits — what
+// pt_backward_only reads — instead of an encode kernel, four (N x 8)-row GEMMs through HBM and an attention kernel (round 4: 1.7 -> 0.6 ms of a 512-ray step).
+bool pt_keep_fused_ok(const Ctx& x, const nl_frame* f, int64_t N, int K) {
+  return !dbg_switch("NERFLOC_NO_KEEP_FUSED") && K == 8 && x.c->precision == NL_PREC_F16X3_INTERNAL && nl_point_fused2_supported(x.c->W, NL_PREC_BF16X3) && f->M >= 1 &&
+         N * 8 * 1024 <= 0x7fffffffll && ((int64_t)f->M + 1) * x.c->W * 4 <= 0x7fffffffll;
+}
+int pt_forward_keep_fused(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N,
+                          const PtBwdBufs& p, const int* idx_in, const float* d2_in) {
+  const int W = x.c->W, K = 8;
+  const int* idx = idx_in && d2_in ? idx_in : p.idx;
+  const float* d2 = idx_in && d2_in ? d2_in : p.d2;
+  if (idx == p.idx) NL_TRY(nl_knn_search(&f->grid, xyz, N, K, p.idx, p.d2, x.st));
+  NL_TRY(ensure_ptt(x, f));
+  NL_TRY(nl_launch_wscale(idx, d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
+  SegSpec sg{G, W, W, 0, 1}, so{p.O, 128, 128, 0, 1};
+  NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
+  NlPointFusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xyz = xyz; a.dir = dir; a.dir_stride = dir_stride; a.dir_div = dir_div > 0 ? dir_div : 1;
+  a.idx = idx; a.Q = p.Q; a.O = p.O; a.ptt = f->ptt; a.sp_xyz = f->sp_xyz; a.sp_dir = f->sp_dir;
+  a.wstream = nullptr; a.bias = x.p<float>(x.L.pt_bias); a.rd_w = x.p<float>(x.L.rd_w);
+  a.wstream2 = x.p<uint4>(x.L.pt_stream2_f16);
+  a.N = (int)N; a.M = (int)(f->M > 0x7fffffff ? 0x7fffffff : f->M); a.inv_span = 1.f / (f->views.far_ - f->views.near_);
+  unsigned* mk[3] = {p.mk[0], p.mk[1], p.mk[2]};
+  NL_TRY(nl_launch_point_fused2(a, W, NL_PREC_BF16X3, x.st, false, p.KV, mk));
+  return run_gemm(x, G_FC, &so, 1, N, p.FCo, W, NL_ACT_NONE);
+}
+
 int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N,
                      int K, const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in, const float* d2_in,
                      const TrainOut* tg) {
@@ -1013,7 +1043,8 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
 int do_point_backward(const Ctx& xb, const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, const float* G, int64_t N, int K,
                       const float* gFA, float* g_xyz, float* g_dir, float* g_G, const PtBwdBufs& p, const int* idx_in = nullptr, const float* d2_in = nullptr,
                       const TrainOut* tg = nullptr) {
-  NL_TRY(pt_forward_staged(x, f, xyz, dir, dir_stride, 1, G, N, K, p, idx_in, d2_in));
+  if (!tg && dir && pt_keep_fused_ok(x, f, N, K)) NL_TRY(pt_forward_keep_fused(x, f, xyz, dir, dir_stride, 1, G, N, p, idx_in, d2_in));
+  else NL_TRY(pt_forward_staged(x, f, xyz, dir, dir_stride, 1, G, N, K, p, idx_in, d2_in));
   return pt_backward_only(xb, x, f, xyz, dir, dir_stride, 1, G, N, K, gFA, g_xyz, g_dir, g_G, p, idx_in, d2_in, tg);
 }
 
@@ -1435,7 +1466,7 @@ void carve_rb(Bump& b, const nl_config* c, int V, int64_t R, RbBufs& a, bool tra
 struct RbCot { const float *g_rgb, *g_depth, *g_unc, *g_feat, *g_wts; const int* idx; const float* d2; };
 // the staged forward of the whole path into the workspace (everything the way back reads).  want_feat: feat_mlp.0's hidden rows too
 int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, const float* qrows, const float* rays_o, const float* rays_d, const float* z, int64_t R,
-                          bool want_feat, const int* knn_idx, const float* knn_d2, const RbBufs& a) {
+                          bool want_feat, const int* knn_idx, const float* knn_d2, const RbBufs& a, bool frozen = false) {
   const int W = x32.c->W, S = x32.c->S;
   const int64_t N = R * S;
   hipStream_t st = x32.st;
@@ -1444,7 +1475,8 @@ int render_forward_staged(const Ctx& x32, const nl_frame* f, const float* qc, co
   NL_TRY(nl_launch_sample_points(rays_o, rays_d, R, S, f->views.near_, f->views.far_, z, a.zc, a.xyz, st));
   NL_TRY(mv_recompute(x32, f, vw, a.xyz, N, a.m));                       // visibility / depth difference, statistics rows, the blend's per-view part
   NL_TRY(mv_outfc_forward(x32, f, N, a.m));                              // -> G
-  NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, knn_idx, knn_d2));
+  if (frozen && pt_keep_fused_ok(x32, f, N, 8)) NL_TRY(pt_forward_keep_fused(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, a.p, knn_idx, knn_d2));
+  else NL_TRY(pt_forward_staged(x32, f, a.xyz, rays_d, 3, S, a.m.G, N, 8, a.p, knn_idx, knn_d2));
   NL_TRY(nl_launch_ln_agg(a.p.FCo, a.m.G, N, W, x32.p<float>(x32.L.ln_g), x32.p<float>(x32.L.ln_b), eps_ln, a.p.wscale, a.FA, st));
   NL_TRY(do_unet(x32, a.FA, R, a.q.geo, a.q.u));
   NL_TRY(nl_launch_sigma(a.q.geo, N, W, x32.p<float>(x32.L.sig_w), x32.p<float>(x32.L.sig_b), a.sigma, st));
@@ -1511,7 +1543,7 @@ int render_backward_staged(const Ctx& xb, const Ctx& x32, const nl_frame* f, con
 }
 int do_render_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const float* qc, const float* qrows, const float* rays_o, const float* rays_d, const float* z,
                        int64_t R, int white, const RbCot& ct, float* g_o, float* g_d, float* g_qc_rows, const RbBufs& a, const TrainOut* tg) {
-  NL_TRY(render_forward_staged(x32, f, qc, qrows, rays_o, rays_d, z, R, ct.g_feat != nullptr, ct.idx, ct.d2, a));
+  NL_TRY(render_forward_staged(x32, f, qc, qrows, rays_o, rays_d, z, R, ct.g_feat != nullptr, ct.idx, ct.d2, a, tg == nullptr));
   return render_backward_staged(xb, x32, f, qc, qrows, rays_d, R, white, ct, g_o, g_d, g_qc_rows, a, tg);
 }
 // the per-ray outputs from the staged forward's workspace (the gradient path's forward values: split-FP16 arithmetic in the bf16 modes)
@@ -1763,6 +1795,9 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     if (rc != NL_OK) return rc;
     rc = nl_pack_point_stream2(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], t[T_B2B], t[T_B4B], (const float*)((char*)packed + L.rd_w),
                                (char*)packed + L.pt_stream2_mx, W, F, st, 1, (int*)((char*)packed + L.pt_mx_sc));
+    if (rc != NL_OK) return rc;
+    rc = nl_pack_point_stream2(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], t[T_B2B], t[T_B4B], (const float*)((char*)packed + L.rd_w),
+                               (char*)packed + L.pt_stream2_f16, W, F, st, 2, nullptr);
     if (rc != NL_OK) return rc;
   }
   NL_LAUNCH_CHECK();
@@ -2145,7 +2180,7 @@ int nl_render_rays_forward_keep(const nl_config* cfg, const void* packed, const 
   if (ws_bytes < render_bwd_bytes(cfg, V, R, train != 0)) return NL_ERR_WORKSPACE;
   BwdCtx B; make_bwd_ctx(B, cfg, packed, stream);
   Bump b{(char*)ws, 0}; RbBufs a; carve_rb(b, cfg, V, R, a, train != 0);
-  NL_TRY(render_forward_staged(B.x32, f, query_center, ray_centers, rays_o, rays_d, z_vals, R, out->feat != nullptr, nullptr, nullptr, a));
+  NL_TRY(render_forward_staged(B.x32, f, query_center, ray_centers, rays_o, rays_d, z_vals, R, out->feat != nullptr, nullptr, nullptr, a, train == 0));
   return render_outputs_staged(B.x32, f, R, white_bkgd, out, a, beta);
 }
 int nl_render_rays_backward_kept(const nl_config* cfg, const void* packed, const nl_frame* f, const float* query_center, const float* ray_centers, const float* rays_d,

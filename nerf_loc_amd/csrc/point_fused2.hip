@@ -24,6 +24,7 @@
 //     so only the first tile of a workgroup waits for LDS-DMA latency;
 //   * ray_diff_fc (4 -> 16 -> 27) runs on the matrix pipe too (6 MFMAs) and each half-wave computes only the positional-encoding
 //     octaves of its own k-slots (half 0: octaves 0-4, half 1: 5-9; three fp64 sin/cos + four fp64 double-angle steps per axis).
+#include <string.h>
 #include <utility>
 #include "common.h"
 
@@ -45,7 +46,7 @@ __device__ unsigned long long pf2_trace[256];   // debug: cycle counter at every
 #endif
 constexpr int NBUF = 4;   // LDS ring slots; chunk c lives in slot c % 4, chunks c+1 .. c+3 are in flight while c is consumed
 
-template <int NRT, bool X3>
+template <int NRT, bool X3, bool KEEP = false>
 struct Geo {
   static constexpr int W = 32 * NRT, PARTS = X3 ? 2 : 1, MPK = X3 ? 3 : 1;   // MPK: MFMAs per k-step
   static constexpr int KSL = 2 * NRT;        // k-steps of the wide layers (K = W)
@@ -76,7 +77,8 @@ struct Geo {
   static constexpr int RES_SC = RES_ATT + 4 * 4 * 32 / 4;   // MX mode: E8M0 scale bytes of the chunks' fp8 weight images, ints [NC][2] = {w_hi8, w_lo8}
   static constexpr int LDS_U4 = RES_SC + (2 * NC + 3) / 4;
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
-  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 10 : 10); }
+  // (KEEP: + 4 row stores of a k head / 4 x 4 dword stores of a v head: the rows nl_attn_backward reads)
+  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 10 : 10) + (KEEP ? 4 : 0); }
   static constexpr int RL = cumks(NC) % 3 == 0 ? 3 : 4;   // A-fragment register ring (3 k-steps are live)
   static constexpr int rpos(int runks) { return runks % RL; }
   static_assert(NC % NBUF == 0 && cumks(NC) % RL == 0, "ring positions must be tile-periodic");
@@ -157,6 +159,21 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigne
   }
 }
 
+// split-FP16 variants (F16 mode: the gradient path's forward, 2^-22 products): hi = f16(v), lo = f16(v - hi)
+__device__ __forceinline__ unsigned lo2_f16(float v0, float v1, unsigned hi) {
+  unsigned lo; float t0, t1;
+  asm("v_fma_mix_f32 %1, %5, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %5, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_cvt_pk_f16_f32 %0, %1, %2"
+      : "=&v"(lo), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi));
+  return lo;
+}
+template <bool X3, bool F16>
+__device__ __forceinline__ void split2f(float v0, float v1, unsigned& hi, unsigned& lo) {
+  if constexpr (F16) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    lo = lo2_f16(v0, v1, hi);
+  } else split2<X3>(v0, v1, hi, lo);
+}
+
 // branch-free sin/cos in fp64 (|x| up to ~1e5): Cody-Waite reduction to [-pi/4, pi/4] + Taylor (error < 1e-11)
 __device__ __forceinline__ void sincos_d(double x, double& s, double& c) {
   const double kd = rint(x * 0.63661977236758134308);
@@ -176,15 +193,22 @@ struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; 
 
 // MX (with X3): layer 1 stays three-term split-bf16 (K = 96, issue-bound anyway); layers 2, 3 and the k / v projections multiply as
 // fp16 hi.hi + fp8(lo).fp8(hi) + fp8(hi).fp8(lo): per K = 64 slab 4 x v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 instead of 12 bf16 MFMAs.
-template <int NRT, bool X3, bool MX>
+// F16 (with X3, without MX): every layer in three-term split-FP16 (2^-22 products: what the gradient path's forward needs so that its LeakyReLU sign decisions are the
+// fp32 function's).  KEEP: the kernel also leaves what the frozen-weight way back reads — the k / v rows (N x 8, 256) and the SIGN of the three
+// layers' outputs as bits in the streaming GEMM's ep_maskin layout ([32-row tile][lane][4 dwords]) — so that the staged forward of the branch (an encode kernel,
+// four (N x 8)-row GEMMs through HBM, an attention kernel) is one launch.
+struct Pf2Keep { float* kv; unsigned* mk[3]; unsigned kv_bytes, mk_bytes; };
+template <int NRT, bool X3, bool MX, bool F16 = false, bool KEEP = false>
 __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
     float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
-    const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const Pf2Scalars sc) {
+    const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const Pf2Scalars sc, const Pf2Keep keep) {
   static_assert(!MX || X3, "the MX mode extends the three-term mode");
-  using GG = Geo<NRT, X3>;
+  static_assert(!F16 || (X3 && !MX), "split-FP16 is a three-term mode");
+  static_assert(!KEEP || F16, "the kept masks must come from the split-FP16 forward");
+  using GG = Geo<NRT, X3, KEEP>;
   constexpr int W = GG::W, PARTS = GG::PARTS, MPK = GG::MPK, NC = GG::NC, SLOT = GG::SLOT;
-  if (MX) __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 / fp8 conversions saturate instead of producing inf / NaN
+  if (MX || F16) __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 / fp8 conversions saturate instead of producing inf / NaN
   // ONE __shared__ object, read through ONE native vector type with compile-time slot indices: hipcc then keeps the alias
   // information that lets SIInsertWaitcnts leave LDS reads alone while LDS-DMA writes are in flight
   __shared__ uint4 lds_all[GG::LDS_U4];
@@ -214,6 +238,16 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p_ptt, 0, (int)sc.t_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)p_Q, 0, sc.N * 512, 0x00020000);
   const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)p_O, 0, sc.N * 512, 0x00020000);
+  // KEEP: k / v rows and the three layers' sign bits (rows / tiles past the end are dropped by the bounds check)
+  const __amdgpu_buffer_rsrc_t rKV = __builtin_amdgcn_make_buffer_rsrc((void*)keep.kv, 0, KEEP ? (int)keep.kv_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM0 = __builtin_amdgcn_make_buffer_rsrc((void*)keep.mk[0], 0, KEEP ? (int)keep.mk_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM1 = __builtin_amdgcn_make_buffer_rsrc((void*)keep.mk[1], 0, KEEP ? (int)keep.mk_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rM2 = __builtin_amdgcn_make_buffer_rsrc((void*)keep.mk[2], 0, KEEP ? (int)keep.mk_bytes : 0, 0x00020000);
+  unsigned kmask[4] = {0u, 0u, 0u, 0u};
+  int tile_prev = 0;
+  // byte offsets into the k / v rows: the wave's first row of the tile, this lane's row.  (The first tile's region 0 runs the "previous tile's" last v head on
+  // whatever the accumulator holds: out of range = dropped, like ooff_prev)
+  unsigned kvtile = 0, kvtile_prev = 0x80000000u, kvrow = 0;
   const unsigned wvoff = wave * 1024 + lane * 16;   // piece p = 4 i + wave of a chunk
   uint4* lw = lds_all + wave * 64;
   unsigned soff = 0;                                // running stream offset of the next piece (scalar)
@@ -257,7 +291,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   float* satt = reinterpret_cast<float*>(lds_all + GG::RES_ATT) + wave * 128;
 
   auto mfma = [](const u32x4& a, const u32x4& b, const f32x16& c) __attribute__((always_inline)) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   };
   auto mfma_h = [](const u32x4& a, const u32x4& b, const f32x16& c) __attribute__((always_inline)) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   auto finish_pair = [&](float v0, float v1, unsigned& dh, unsigned& dl) __attribute__((always_inline)) {
     v0 = vmax(v0, v0 * 0.01f); v1 = vmax(v1, v1 * 0.01f);
     unsigned h = 0, l = 0;
-    split2<X3>(v0, v1, h, l);
+    split2f<X3, F16>(v0, v1, h, l);
     dh = h;
     if (X3) dl = l;
   };
@@ -347,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       else if constexpr (C == 3) {
         prd[2] /= pq[0];
         unsigned h0 = 0, l0 = 0, h1 = 0, l1 = 0;
-        split2<X3>(prd[0], prd[1], h0, l0); split2<X3>(prd[2], prd[3], h1, l1);
+        split2f<X3, F16>(prd[0], prd[1], h0, l0); split2f<X3, F16>(prd[2], prd[3], h1, l1);
         rdbh[0] = hh ? 0u : h0; rdbh[1] = hh ? 0u : h1;   // k-slots 0..3 of half 0
         if (X3) { rdbl[0] = hh ? 0u : l0; rdbl[1] = hh ? 0u : l1; }
       } else if constexpr (C == 4 || C == 7) {   // ray_diff_fc layers on the matrix pipe (model.py:36-39)
@@ -396,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       } else if constexpr (C >= 39 && C < 54) {
         constexpr int f = (C - 39) / 3, a = (C - 39) % 3, p = 5 * a + f;
         unsigned h = 0, l = 0;
-        split2<X3>((float)ss[a], (float)scs[a], h, l);
+        split2f<X3, F16>((float)ss[a], (float)scs[a], h, l);
         Ph[p / 4][p & 3] = h;
         if (X3) Pl[p / 4][p & 3] = l;
         if constexpr (f < 4) {
@@ -406,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         }
       } else {
         unsigned h = 0, l = 0;
-        split2<X3>(hh ? poff[2] : poff[0], hh ? 0.f : poff[1], h, l);
+        split2f<X3, F16>(hh ? poff[2] : poff[0], hh ? 0.f : poff[1], h, l);
         Ph[3][3] = h;
         if (X3) Pl[3][3] = l;
       }
@@ -466,9 +501,18 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         } else mx_bytes2<d & 1>(ev0, ev1, ehi, X8[out][fo >> 2][0][2 * (fo & 3) + (d >> 1)], X8[out][fo >> 2][1][2 * (fo & 3) + (d >> 1)], sc_lo);
       } else if constexpr (sub == 0) {
         ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
-        ehi = lrelu_hi2(ev0, ev1);
+        ehi = F16 ? lrelu_hi2_f16(ev0, ev1) : lrelu_hi2(ev0, ev1);
         Xh[out][fo][d] = ehi;
-      } else Xl[out][fo][d] = lo2(ev0, ev1, ehi);
+        if constexpr (KEEP) {   // sign bits of the layer's outputs: bit 16 (RT & 1) + r of dword RT >> 1 <-> accumulator register r of row tile RT
+          if constexpr (RT == 0 && p == 0) { kmask[0] = kmask[1] = kmask[2] = kmask[3] = 0u; }
+          kmask[RT >> 1] |= ((ev0 > 0.f ? 1u : 0u) | (ev1 > 0.f ? 2u : 0u)) << (16 * (RT & 1) + 2 * p);
+        }
+      } else {
+        Xl[out][fo][d] = F16 ? lo2_f16(ev0, ev1, ehi) : lo2(ev0, ev1, ehi);
+        if constexpr (KEEP && RT == NRT - 1 && p == 7)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{kmask[0], NRT > 2 ? kmask[1] : 0u, NRT > 4 ? kmask[2] : 0u, NRT > 4 ? kmask[3] : 0u},
+                                                 L == 0 ? rM0 : L == 1 ? rM1 : rM2, (unsigned)((PREV ? tile_prev : tile) * 4 + wave) * 1024u + lane * 16u, 0, 0);
+      }
     } else if constexpr (RT < 4) {   // k projection of head RT: scores, softmax over the 8 neighbours (lanes) of a sample
       if constexpr (E < 4) {
         if constexpr (E == 0) ap = Qr[0][0] * acc[AB][0]; else ap = fmaf(Qr[E][0], acc[AB][4 * E], ap);
@@ -482,7 +526,14 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       else if constexpr (E == 6) aee = expf(ap - amx);
       else if constexpr (E == 7) ase = nl_sum8(aee);
       else if constexpr (E == 8) att[RT] = aee / ase;
-      else satt[RT * 32 + j] = att[RT];   // both halves hold the same value; every lane writes (no divergent store, no branch)
+      else if constexpr (E == 9) satt[RT * 32 + j] = att[RT];   // both halves hold the same value; every lane writes (no divergent store, no branch)
+      else {   // KEEP: the k rows of head RT: row = lane's neighbour row, columns 32 RT + 8 g + 4 hh .. + 3
+        constexpr int g = E - 10;
+        // (a float copy first: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0 whatever the index)
+        const float k0 = acc[AB][4 * g], k1 = acc[AB][4 * g + 1], k2 = acc[AB][4 * g + 2], k3 = acc[AB][4 * g + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(k0), __float_as_uint(k1), __float_as_uint(k2), __float_as_uint(k3)},
+                                               rKV, kvrow + (unsigned)(32 * RT + 8 * g + 4 * hh) * 4u, 0, 0);
+      }
     } else {
       // v projection of head h, computed TRANSPOSED (activations = A operand): lane = output dim n, registers = neighbour rows
       // m(r, hh) = (r & 3) + 8 (r >> 2) + 4 hh, i.e. sample r >> 2, neighbours (r & 3) + 4 hh.  The attention-weighted sum over the
@@ -499,13 +550,21 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       } else if constexpr (E == 8) {
         ov[0] += __shfl_xor(ov[0], 32, 64); ov[1] += __shfl_xor(ov[1], 32, 64);
         ov[2] += __shfl_xor(ov[2], 32, 64); ov[3] += __shfl_xor(ov[3], 32, 64);
-      } else {
+      } else if constexpr (E == 9) {
         // lanes of half 0 store dim n of the wave's 4 samples; half 1 and samples past N are out of range (dropped by the bounds check)
         const unsigned oo = (PREV ? ooff_prev : ooff_cur) + 4 * 32 * h;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[0]), rO, oo, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[1]), rO, oo + 512, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[2]), rO, oo + 1024, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov[3]), rO, oo + 1536, 0, 0);
+      } else {   // KEEP: the v values of head h: lane = dim, registers = neighbour rows m(r, hh) -> column 128 + 32 h + lane's dim of those rows
+        constexpr int g = E - 10;
+        const unsigned base = (PREV ? kvtile_prev : kvtile) + (unsigned)(128 + 32 * h + j) * 4u;
+        static_for<4>([&](auto Rc) __attribute__((always_inline)) {
+          constexpr int r = 4 * g + decltype(Rc)::value;
+          const float vr = acc[AB][r];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vr), rKV, base + (unsigned)((r & 3) + 8 * (r >> 2) + 4 * hh) * 1024u, 0, 0);
+        });
       }
     }
   };
@@ -692,6 +751,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   });
   static_for<NPRO>(pro_step);   // the first tile's prologue, back to back
   toff = pn_toff; qoff = pn_qoff; ooff_cur = pn_ooff;
+  kvtile = ((unsigned)tile * 128u + (unsigned)wave * 32u) * 1024u; kvrow = kvtile + (unsigned)j * 1024u;
   load_T(std::integral_constant<int, 0>{}, toff); load_T(std::integral_constant<int, 1>{}, toff);
   wait_vmcnt<GG::ppw(1) + GG::ppw(2)>();   // conservative: the prologue's own loads are younger than every piece
   __builtin_amdgcn_s_barrier();
@@ -713,7 +773,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     ++trace_it;
 #endif
     ooff_prev = ooff_cur; ooff_cur = pn_ooff; toff = pn_toff; qoff = pn_qoff;
+    tile_prev = tile; kvtile_prev = kvtile;
     tile = pn_tile;
+    kvtile = ((unsigned)tile * 128u + (unsigned)wave * 32u) * 1024u; kvrow = kvtile + (unsigned)j * 1024u;
     if (tile >= sc.ntiles) break;
   }
   // the last v head of the last tile
@@ -825,7 +887,7 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     if (layer == 0) base = (long long)rt * 2 * 6 * 512;
     else base = (long long)NRT * 2 * 6 * 512 + ((long long)(layer - 1) * NRT + rt) * 2 * KSL * 512;
     const long long in_part = ((long long)ks * 64 + lane) * 8 + t;
-    if (mx && layer > 0) {
+    if (mx == 1 && layer > 0) {
       // MX chunk: part 0 = f16(w) in the same fragment order; part 1 = per slab q of 4 k-steps [w_hi8 bytes 0-15 | 16-31 | w_lo8 bytes 0-15 | 16-31][lane][16], byte
       // u = 8 (ks & 3) + t of a lane <-> this element; hi8 = e4m3(f16(w) / s_hi), lo8 = e4m3((w - f16(w)) / s_lo), scales per chunk (pf2_mx_scale_kernel)
       const int c = (layer - 1) * NRT + NRT + rt;   // chunk index (k / v heads: rt = 0..7 behind layer 3's base)
@@ -838,6 +900,10 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
       const long long bo = (((long long)(4 * q + (sI >> 1)) * 64 + lane) * 16) + 8 * (sI & 1) + t;
       ob[bo] = pf2_e4m3(hf / s_hi);
       ob[bo + 2 * 64 * 16] = pf2_e4m3((v - hf) / s_lo);
+    } else if (mx == 2) {   // split-FP16 stream (F16 mode): hi = f16(w), lo = f16(w - hi), every layer
+      const unsigned short h = pf2_f2h(v);
+      out[base + in_part] = h;
+      out[base + (long long)nks * 512 + in_part] = pf2_f2h(v - pf2_h2f(h));
     } else {
       const unsigned short h = pf2_f2bf(v);
       out[base + in_part] = h;
@@ -851,9 +917,15 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     float v = 0.f;
     if (l == 0) { if (i < 16 && hh == 0 && t < 4) v = rd_w[i * 4 + t]; }
     else if (i < 27) v = rd_w[80 + i * 16 + pf2_m(t, hh)];
-    const unsigned short h = pf2_f2bf(v);
-    out[res + (long long)l * 1024 + lane * 8 + t] = h;
-    out[res + (long long)l * 1024 + 512 + lane * 8 + t] = pf2_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+    if (mx == 2) {
+      const unsigned short h = pf2_f2h(v);
+      out[res + (long long)l * 1024 + lane * 8 + t] = h;
+      out[res + (long long)l * 1024 + 512 + lane * 8 + t] = pf2_f2h(v - pf2_h2f(h));
+    } else {
+      const unsigned short h = pf2_f2bf(v);
+      out[res + (long long)l * 1024 + lane * 8 + t] = h;
+      out[res + (long long)l * 1024 + 512 + lane * 8 + t] = pf2_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
+    }
   }
   if (e < 64 + 2 * W) {   // bias tables in accumulator order [rt][hh][r]
     float* bt = reinterpret_cast<float*>(out + res + 2048);
@@ -863,7 +935,7 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     else { const int q = i - 64, l = q / W, c = q - l * W, rt = c >> 5, hh = (c >> 4) & 1, f = 32 * rt + pf2_m(c & 15, hh); v = l == 0 ? b2[f] : b3[f]; }
     bt[i] = v;
   }
-  if (mx && e < 2 * (3 * NRT + 8)) {   // the chunks' scale bytes behind the bias tables
+  if (mx == 1 && e < 2 * (3 * NRT + 8)) {   // the chunks' scale bytes behind the bias tables
     int* st = reinterpret_cast<int*>(out + res + 2048) + 64 + 2 * W;
     st[e] = mxsc[e];
   }
@@ -878,12 +950,13 @@ size_t nl_point_stream2_bytes(int W) {
   return (size_t)2 * (NRT * 6 + (2 * NRT + 8) * 2 * NRT) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + 4096;   // + slack: bf16 L1 chunks copy 8 k-steps
 }
 
-// mx != 0: the stream of the MX mode (layer 1 split-bf16 as ever; layers 2, 3, k / v: f16 fragments + fp8 images + their scales); mx_scratch: >= 2 (3 W / 32 + 8) ints
+// mx = 1: the stream of the MX mode (layer 1 split-bf16 as ever; layers 2, 3, k / v: f16 fragments + fp8 images + their scales); mx_scratch: >= 2 (3 W / 32 + 8) ints
+// mx = 2: the split-FP16 stream (every layer hi / lo in fp16: the gradient path's forward)
 int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, const float* b2, const float* b3,
                           const float* rd_w, void* out, int W, int F, hipStream_t st, int mx, int* mx_scratch) {
   const int NRT = W / 32;
   const long long total = ((long long)NRT * 6 + (2LL * NRT + 8) * 2 * NRT) * 512;
-  if (mx) {
+  if (mx == 1) {
     if (!mx_scratch) return NL_ERR_BAD_ARG;
     hipLaunchKernelGGL(pf2_mx_scale_kernel, dim3(3 * NRT + 8), dim3(256), 0, st, w2, w3, wk, wv, mx_scratch, NRT);
     NL_LAUNCH_CHECK();
@@ -902,7 +975,8 @@ extern "C" __attribute__((visibility("default"))) int nl_debug_pf2_trace(unsigne
 
 bool nl_point_fused2_supported(int W, int precision) { return precision != NL_PREC_F32 && (W == 128 || W == 256); }
 
-int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx) {
+// keep_kv != null (with the split-FP16 stream in a.wstream2): the F16 + KEEP instance — also writes the k / v rows (N x 8, 256) and the three layers' sign bits
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx, float* keep_kv, unsigned* const* keep_mk) {
   if (a.N <= 0) return NL_OK;
   if (g_num_cu == 0) {
     int dev = 0;
@@ -925,14 +999,24 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
   dim3 grid(nwg);
   const bool x3 = precision == NL_PREC_BF16X3;
   if (mx && !x3) return NL_ERR_BAD_ARG;
+  Pf2Keep kp;
+  memset(&kp, 0, sizeof(kp));
+  if (keep_kv) {
+    if (mx || !keep_mk || (int64_t)a.N * 8 * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;
+    kp.kv = keep_kv; kp.mk[0] = keep_mk[0]; kp.mk[1] = keep_mk[1]; kp.mk[2] = keep_mk[2];
+    kp.kv_bytes = (unsigned)((int64_t)a.N * 8 * 1024);
+    kp.mk_bytes = (unsigned)(nl_cdiv((int64_t)a.N * 8, 32) * 1024);
+  }
 #define NL_PF2(NRT)                                                                                                                                  \
   do {                                                                                                                                               \
-    if (mx) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,        \
-                               a.sp_dir, a.wstream2, sc);                                                                                            \
+    if (keep_kv) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, false, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
+                                    a.sp_xyz, a.sp_dir, a.wstream2, sc, kp);                                                                         \
+    else if (mx) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,   \
+                                    a.sp_dir, a.wstream2, sc, kp);                                                                                   \
     else if (x3) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz, \
-                                    a.sp_dir, a.wstream2, sc);                                                                                       \
+                                    a.sp_dir, a.wstream2, sc, kp);                                                                                   \
     else hipLaunchKernelGGL((point_fused2_kernel<NRT, false, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,        \
-                            a.sp_dir, a.wstream2, sc);                                                                                               \
+                            a.sp_dir, a.wstream2, sc, kp);                                                                                           \
   } while (0)
   if (W == 256) NL_PF2(8);
 #if PF2_KO == 0

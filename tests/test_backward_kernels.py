@@ -313,7 +313,8 @@ def _assert_param_grads(got, ref32, ref64, tol, what, exact_forward):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("c1", "fp32", None), ("c1", "bf16x3", 100), ("w256s128", "bf16x3", None)])
+@pytest.mark.parametrize("case,precision,chunk", [("tiny_full", "fp32", None), ("c1", "fp32", None), ("c1", "bf16x3", 100), ("w256s128", "bf16x3", None),
+                                                  ("w128s64", "bf16x3", None)])
 def test_point_branch_weight_gradients_match_autograd(case, precision, chunk):
     """nl_point_mlp_backward_train: the gradients of the branch's 16 parameter tensors and of the support table's features, against autograd of the
     eager restatement (fp64).  chunk: a workspace for fewer samples than N — the weight gradients accumulate over the chunks."""
@@ -350,10 +351,14 @@ def test_point_branch_weight_gradients_match_autograd(case, precision, chunk):
     tg = r.train_grads(POINT_PARAMS, support_feature=True)
     gx, gd, gg = r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), train=tg, workspace_samples=chunk)
     gx0, gd0, gg0 = r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), workspace_samples=chunk)
-    assert torch.equal(gx, gx0) and torch.equal(gd, gd0) and torch.equal(gg, gg0), "the input gradients do not depend on the training outputs"
+    if case in ("w256s128", "w128s64"):   # W = 128 / 256, K = 8, frozen weights: the forward is the fused keep kernel (pt_forward_keep_fused), the same split-FP16 products summed in another order
+        for a, b in ((gx, gx0), (gd, gd0), (gg, gg0)):
+            assert float((a - b).norm() / b.norm()) < 1e-4, "the input gradients do not depend on the training outputs"
+    else:
+        assert torch.equal(gx, gx0) and torch.equal(gd, gd0) and torch.equal(gg, gg0), "the input gradients do not depend on the training outputs"
     got = {k: v.clone() for k, v in tg.weights.items()}
     got["support.feature"] = tg.support_feature.clone()
-    _assert_param_grads(got, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=case != "w256s128")
+    _assert_param_grads(got, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=case not in ("w256s128", "w128s64"))
     # a second call ADDS
     r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), train=tg, workspace_samples=chunk)
     assert rel_err(tg.weights["base_mlp.2.weight"].cpu().numpy(), 2 * got["base_mlp.2.weight"].cpu().numpy()) < 1e-6
