@@ -67,6 +67,10 @@ int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false, float* keep_kv = nullptr, unsigned* const* keep_mk = nullptr);
+bool nl_point_bwd_chain_supported(int W);
+size_t nl_point_bwd_stream_bytes(int W);
+int nl_pack_point_bwd_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
+int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const void* wstream, float* gx, int64_t NK, int W, hipStream_t st);
 // backward.hip: glue kernels of the neural-point branch's input gradient
 int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
                     float* gb, float* scratch, size_t scratch_floats, hipStream_t st);
@@ -175,7 +179,7 @@ struct Layout {
   GemmDim g[G_COUNT];
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bsh[G_COUNT], bias[G_COUNT];   // bsh: the weight stream in fp16 hi / lo (split-FP16 arithmetic)
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
-  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_stream2_f16, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t pt_stream, pt_stream2, pt_stream2_mx, pt_stream2_f16, pt_bwd_stream, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
   size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
   int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
@@ -291,6 +295,7 @@ Layout make_layout(const nl_config* c) {
   L.pt_stream2 = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);
   L.pt_stream2_mx = take((W == 128 || W == 256) ? nl_point_stream2_bytes(W) : 256);   // NL_PREC_F16MX: f16 fragments + fp8 images of layers 2, 3, k / v
   L.pt_stream2_f16 = take((W == 128 || W == 128 * 2) ? nl_point_stream2_bytes(W) : 256);  // split-FP16 stream: the gradient path's fused forward (pt_forward_keep_fused)
+  L.pt_bwd_stream = take(nl_point_bwd_chain_supported(W) ? nl_point_bwd_stream_bytes(W) : 256);   // transposed weights of the branch's rows: the frozen-weight way back (point_bwd.hip)
   L.pt_mx_sc = take(4 * 64);
   L.mvf_pack = take(nl_mv_front_pack_bytes());                                          // out_fc.0 as register-resident A fragments of mv_front_kernel (C = 192)                                                            // their per-chunk scale bytes while packing
   L.zeros = take(4096);
@@ -998,6 +1003,13 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
     NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
   }
   const bool bits = pt_mask_bits(x);
+  // frozen weights, W = 128 / 256: the four (N x 8)-row products with the LeakyReLU masks in between as ONE launch that keeps the rows in registers (point_bwd.hip)
+  if (!tg && bits && pt_table(x) && !dbg_switch("NERFLOC_NO_BWD_CHAIN") && nl_point_bwd_chain_supported(W) && NK * 1024 <= 0x7fffffffll) {
+    const unsigned* mk[3] = {p.mk[0], p.mk[1], p.mk[2]};
+    NL_TRY(nl_launch_point_bwd_chain(p.gKV, mk, x.p<char>(x.L.pt_bwd_stream), p.gX, NK, W, x.st));
+    return nl_launch_point_encode_backward(xyz, dir, dir_stride, dir_div, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz, g_dir,
+                                           nullptr, x.st);
+  }
   NL_TRY(gemm_lrelu_masked(xb, G_KV_T, skv, NK, p.gA, W, p.H3, bits ? p.mk[2] : nullptr));
   NL_TRY(wg(T_B4W, T_B4B, p.gA, W, W, p.H2, W, W, NK));
   NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2, bits ? p.mk[1] : nullptr));
@@ -1798,6 +1810,8 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
     if (rc != NL_OK) return rc;
     rc = nl_pack_point_stream2(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], t[T_B2B], t[T_B4B], (const float*)((char*)packed + L.rd_w),
                                (char*)packed + L.pt_stream2_f16, W, F, st, 2, nullptr);
+    if (rc != NL_OK) return rc;
+    rc = nl_pack_point_bwd_stream(t[T_B0W], t[T_B2W], t[T_B4W], t[T_WK], t[T_WV], (char*)packed + L.pt_bwd_stream, W, F, st);
     if (rc != NL_OK) return rc;
   }
   NL_LAUNCH_CHECK();

@@ -28,15 +28,19 @@ N, W, K = xyz.shape[0], cfg.W, 8
 NK = N * K
 ldx = (cfg.C + 3 + 90 + 31) // 32 * 32
 
-def run(staged):
-    if staged: os.environ["NERFLOC_NO_KEEP_FUSED"] = "1"
-    else: os.environ.pop("NERFLOC_NO_KEEP_FUSED", None)
+def run(staged, chain=False):
+    for k, on in (("NERFLOC_NO_KEEP_FUSED", staged), ("NERFLOC_NO_BWD_CHAIN", not chain)):
+        if on: os.environ[k] = "1"
+        else: os.environ.pop(k, None)
     r._ws = None
     out = r.point_mlp_backward(xyz, dirs, G, cot)
     torch.cuda.synchronize()
     return [v.cpu().numpy() for v in out], r._ws.cpu().numpy().copy()
 
 (gs, ws_s), (gf, ws_f) = run(True), run(False)
+gc, ws_c = run(True, chain=True)   # the same staged forward; the four row products of the way back as one launch (point_bwd.hip)
+for n, a, b in zip(("g_xyz", "g_dir", "g_G"), gs, gc):
+    print(n, "chained way back vs staged rel", float(np.abs(a - b).max() / np.abs(a).max()))
 for n, a, b in zip(("g_xyz", "g_dir", "g_G"), gs, gf):
     print(n, "fused vs staged rel", float(np.abs(a - b).max() / np.abs(a).max()))
 # carve_ptb's order (abi.hip): every take is 256-byte aligned
@@ -56,6 +60,11 @@ for nm, nb in names:
         x = a ^ b
         bits = int(sum(bin(int(v)).count("1") for v in x[x != 0]))
         print(nm, "differing sign bits", bits, "of", NK * W, "| words differing", int((x != 0).sum()), "first", np.nonzero(x)[0][:6])
+    elif nm == "gX":
+        a, b = ws_s[o_:o_ + nb].view(np.float32).reshape(NK, 96), ws_c[o_:o_ + nb].view(np.float32).reshape(NK, 96)
+        err = np.abs(a - b).max(1) / np.abs(a).max()
+        print("gX chained vs staged: max diff / max", float(err.max()), "| rows beyond 1e-4:", int((err > 1e-4).sum()), "of", NK, "| L2-rel", float(np.linalg.norm(a - b) / np.linalg.norm(a)),
+              "| first bad rows", np.nonzero(err > 1e-4)[0][:8], "| pad columns max", float(np.abs(b[:, 90:]).max()))
     elif nm in ("KV", "Q", "O", "FCo", "wscale", "idx"):
         dt = np.int32 if nm == "idx" else np.float32
         a, b = ws_s[o_:o_ + nb].view(dt), ws_f[o_:o_ + nb].view(dt)
