@@ -534,6 +534,109 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
   }
 }
 
+// The same with frozen weights and K = 8, LANE = one (sample, neighbour) row: the row's 90 gradient columns, its positional-encoding derivative (one fp64 sin / cos per
+// axis + the double-angle recurrence, like the forward kernel) and the whole ray_diff_fc 4 -> 16 -> 27 forward + backward (~1000 FMAs against wave-uniform weights, which
+// the compiler keeps in SGPRs) stay in the lane; the 8 rows of a sample are summed with three DPP steps.  The wave-per-sample kernel above walks the neighbours one after
+// the other with five wave reductions each: 0.44 ms per 512-ray pose step against 0.06 ms here.
+__device__ __forceinline__ void bk_sincos_d(double x, double& s, double& c) {   // Cody-Waite to [-pi/4, pi/4] + Taylor (error < 1e-11), branch-free
+  const double kd = rint(x * 0.63661977236758134308);
+  const int k = (int)kd;
+  double r = fma(-kd, 1.5707963267948966, x);
+  r = fma(-kd, 6.123233995736766e-17, r);
+  const double r2 = r * r;
+  const double ps = r + r * r2 * (-1.0 / 6 + r2 * (1.0 / 120 + r2 * (-1.0 / 5040 + r2 * (1.0 / 362880 + r2 * (-1.0 / 39916800)))));
+  const double pc = 1.0 + r2 * (-0.5 + r2 * (1.0 / 24 + r2 * (-1.0 / 720 + r2 * (1.0 / 40320 + r2 * (-1.0 / 3628800 + r2 * (1.0 / 479001600))))));
+  const bool sw = k & 1;
+  const double ss = sw ? pc : ps, cc = sw ? ps : pc;
+  s = (k & 2) ? -ss : ss;
+  c = ((k + 1) & 2) ? -cc : cc;
+}
+__global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ dir, int dir_stride, int dir_div,
+                                                                         int N, int M, const int* __restrict__ idx, const float* __restrict__ sp_xyz,
+                                                                         const float* __restrict__ sp_dir, const float* __restrict__ rd_w, float inv_span,
+                                                                         const float* __restrict__ gX, int ldg, float* __restrict__ g_xyz, float* __restrict__ g_dir) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = (int)(row & 7);
+  const long long nl = row >> 3;
+  const bool live = nl < N;
+  const int n = (int)(live ? nl : N - 1);
+  const bool have = k < M;
+  const int i = idx[(size_t)n * 8 + k];
+  const float* grow = gX + ((size_t)n * 8 + k) * ldg;
+  float g[92];
+#pragma unroll
+  for (int c = 0; c < 23; ++c) { const float4 v = *(const float4*)(grow + 4 * c); g[4 * c] = v.x; g[4 * c + 1] = v.y; g[4 * c + 2] = v.z; g[4 * c + 3] = v.w; }
+  const float q[3] = {xyz[3 * (size_t)n], xyz[3 * (size_t)n + 1], xyz[3 * (size_t)n + 2]};
+  float go[3];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const float off = (q[ax] - (have ? sp_xyz[3 * (size_t)i + ax] : 0.f)) * inv_span;
+    double sn, cs;
+    bk_sincos_d((double)off, sn, cs);
+    double a = (double)g[ax];
+    double sc2 = 1.0;
+#pragma unroll
+    for (int f = 0; f < 10; ++f) {   // columns 3 + 6 f + ax = sin(2^f off), 3 + 6 f + 3 + ax = cos(2^f off)  (utils.py:5-35)
+      a += sc2 * ((double)g[3 + 6 * f + ax] * cs - (double)g[6 + 6 * f + ax] * sn);
+      const double s2 = 2.0 * sn * cs;
+      cs = fma(-2.0 * sn, sn, 1.0);
+      sn = s2;
+      sc2 *= 2.0;
+    }
+    go[ax] = (float)a;
+  }
+  float gd[3] = {0.f, 0.f, 0.f};
+  if (dir) {   // (kernel-uniform) ray_diff_fc (model.py:36-39, 396-399): 4 -> 16 -> 27, LeakyReLU after both
+    const size_t dr = (size_t)(n / dir_div) * dir_stride;
+    const float dx = dir[dr], dy = dir[dr + 1], dz = dir[dr + 2];
+    const float ndx = have ? sp_dir[4 * (size_t)i] : 0.f, ndy = have ? sp_dir[4 * (size_t)i + 1] : 0.f, ndz = have ? sp_dir[4 * (size_t)i + 2] : 0.f;
+    const float rr0 = dx - ndx, rr1 = dy - ndy, rr2 = dz - ndz;
+    const float nrm = sqrtf(rr0 * rr0 + rr1 * rr1 + rr2 * rr2), nr = nrm + 1e-8f;
+    const float r0 = rr0 / nr, r1 = rr1 / nr, r2 = rr2 / nr, r3 = dx * ndx + dy * ndy + dz * ndz;
+    const float* w2 = rd_w + 80;
+    float a1[16], h[16], gh[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float t = rd_w[64 + j];
+      t = fmaf(rd_w[j * 4 + 0], r0, t); t = fmaf(rd_w[j * 4 + 1], r1, t); t = fmaf(rd_w[j * 4 + 2], r2, t); t = fmaf(rd_w[j * 4 + 3], r3, t);
+      a1[j] = t; h[j] = nl_lrelu(t); gh[j] = 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < 27; ++l) {
+      float a2 = w2[27 * 16 + l];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a2 = fmaf(w2[l * 16 + j], h[j], a2);
+      const float ga2 = g[63 + l] * (a2 > 0.f ? 1.f : 0.01f);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gh[j] = fmaf(w2[l * 16 + j], ga2, gh[j]);
+    }
+    float gr0 = 0.f, gr1 = 0.f, gr2 = 0.f, gr3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float ga1 = gh[j] * (a1[j] > 0.f ? 1.f : 0.01f);
+      gr0 = fmaf(rd_w[j * 4 + 0], ga1, gr0); gr1 = fmaf(rd_w[j * 4 + 1], ga1, gr1); gr2 = fmaf(rd_w[j * 4 + 2], ga1, gr2); gr3 = fmaf(rd_w[j * 4 + 3], ga1, gr3);
+    }
+    // u = rr / (|rr| + 1e-8): du_i/drr_j = delta_ij / nr - rr_i rr_j / (|rr| nr^2)  (0 at rr = 0, like torch.norm's subgradient)
+    const float gdot = gr0 * rr0 + gr1 * rr1 + gr2 * rr2;
+    const float cc = nrm > 0.f ? gdot / (nrm * nr * nr) : 0.f;
+    gd[0] = gr0 / nr - rr0 * cc + gr3 * ndx;
+    gd[1] = gr1 / nr - rr1 * cc + gr3 * ndy;
+    gd[2] = gr2 / nr - rr2 * cc + gr3 * ndz;
+  }
+  // the sample's 8 rows are 8 neighbouring lanes
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    float a = go[ax], b = gd[ax];
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
+    go[ax] = a; gd[ax] = b;
+  }
+  if (live && k == 0) {
+    g_xyz[3 * (size_t)n] = go[0] * inv_span; g_xyz[3 * (size_t)n + 1] = go[1] * inv_span; g_xyz[3 * (size_t)n + 2] = go[2] * inv_span;
+    if (g_dir) { g_dir[3 * (size_t)n] = gd[0]; g_dir[3 * (size_t)n + 1] = gd[1]; g_dir[3 * (size_t)n + 2] = gd[2]; }
+  }
+}
+
 // training: gradient of the gathered support features (knn_gather's backward, knn_utils.py:211-233 = index_add).  A wave takes 64 consecutive (sample,
 // neighbour) rows = 8 consecutive samples of a ray, whose neighbour sets overlap almost completely: the rows are grouped by support point with ballots
 // (wave-uniform), every group's rows are summed with lanes = channels, and ONE atomic per (point, channel) goes out — ~14 points per 64 rows instead of 64
@@ -707,6 +810,12 @@ int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
                                     float* g_dir, float* tr, hipStream_t st) {
   if (N <= 0) return NL_OK;
+  if (!tr && K == 8 && (ldg & 3) == 0 && ldg >= 92 && (((size_t)gX) & 15) == 0) {   // frozen weights: lane = row
+    hipLaunchKernelGGL(point_encode_backward_rows_kernel, dim3((unsigned)nl_cdiv(N * 8, 256)), dim3(256), 0, st, xyz, dir, dir_stride, dir_div > 0 ? dir_div : 1, (int)N,
+                       (int)(M > 0x7fffffff ? 0x7fffffff : M), idx, sp_xyz, sp_dir, rd_w, inv_span, gX, ldg, g_xyz, dir ? g_dir : nullptr);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+  }
   hipLaunchKernelGGL(point_encode_backward_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, xyz, dir, dir_stride, dir_div > 0 ? dir_div : 1, (int)N, K,
                      (int)(M > 0x7fffffff ? 0x7fffffff : M), idx, sp_xyz, sp_dir, rd_w, inv_span, gX, ldg, g_xyz, dir ? g_dir : nullptr, tr);
   NL_LAUNCH_CHECK();

@@ -351,11 +351,12 @@ def test_point_branch_weight_gradients_match_autograd(case, precision, chunk):
     tg = r.train_grads(POINT_PARAMS, support_feature=True)
     gx, gd, gg = r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), train=tg, workspace_samples=chunk)
     gx0, gd0, gg0 = r.point_mlp_backward(xyz, dirs, G, cot, K=8, knn=(d2, idx), workspace_samples=chunk)
-    if case in ("w256s128", "w128s64"):   # W = 128 / 256, K = 8, frozen weights: the forward is the fused keep kernel (pt_forward_keep_fused), the same split-FP16 products summed in another order
-        for a, b in ((gx, gx0), (gd, gd0), (gg, gg0)):
-            assert float((a - b).norm() / b.norm()) < 1e-4, "the input gradients do not depend on the training outputs"
-    else:
-        assert torch.equal(gx, gx0) and torch.equal(gd, gd0) and torch.equal(gg, gg0), "the input gradients do not depend on the training outputs"
+    # the input gradients do not depend on the training outputs.  (Not bit for bit: with frozen weights the encode columns' way back is the lane-per-row kernel
+    # (fp64 sin / cos recurrence, another summation order), and for W = 128 / 256, K = 8 the forward is the fused keep kernel and the four row products are one chain
+    # launch: pt_forward_keep_fused, point_bwd.hip)
+    lim = 1e-4 if case in ("w256s128", "w128s64") else 2e-5
+    for a, b in ((gx, gx0), (gd, gd0), (gg, gg0)):
+        assert float((a - b).norm() / b.norm()) < lim, "the input gradients do not depend on the training outputs"
     got = {k: v.clone() for k, v in tg.weights.items()}
     got["support.feature"] = tg.support_feature.clone()
     _assert_param_grads(got, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=case not in ("w256s128", "w128s64"))
