@@ -1160,6 +1160,259 @@ __global__ __launch_bounds__(SC ? 512 : 256) void mv_geom_backward_kernel(const 
   }
 }
 
+
+// The same with frozen maps (no scatter-adds) and EIGHT CONSECUTIVE SAMPLES PER WAVE, lane = 8 * sample + j — the layout of the forward's mv_stats8_kernel (mvagg.hip),
+// for the same reason: with a wave per sample every bilinear tap is its own row fetch and every per-view total its own 64-lane reduction (50 of them per sample,
+// back to back with the gathers they wait for: 0.70 ms per 512-ray pose step).  Here
+//   phase A   lane (s, j) projects sample s into views j and j + 8: clamped texel offsets, tap validity and weights of the feature map and of the image -> one
+//             24-dword slot per (sample, view) in LDS; the views' weights and their sums by three DPP steps over the sample's 8 lanes
+//   phase B   per 32-channel chunk lane (s, j) owns channels 32 i + 4 j .. + 3 (one 16-byte load per tap, shared cache lines between the samples of a ray);
+//             the per-view totals d/d ix, d/d iy, d/d weight stay in the lane (5 VT registers) over all chunks, the colour planes (lanes j < 3) and the
+//             blend's 32 projected channels, and are summed over the sample's 8 lanes ONCE at the end
+//   tail      lane (s, j) runs views j and j + 8 through pixel -> camera -> world, the view angles and the weight normalisation
+// Needs the forward's statistics rows when g393 is given (the weighted means) and C % 4 == 0.
+template <int VT>
+__global__ __launch_bounds__(256) void mv_geom_backward8_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ images,
+                                                                const float* __restrict__ feat, int C, const float* __restrict__ pfeat,
+                                                                const float* __restrict__ xyz, int N, const float* __restrict__ vis_in,
+                                                                const float* __restrict__ dd_in, const float* __restrict__ g393, int ldg,
+                                                                const float* __restrict__ g_pf, const float* __restrict__ g_rgbv,
+                                                                const float* __restrict__ g_ang, float* __restrict__ g_xyz, float* __restrict__ g_qc,
+                                                                float* __restrict__ g_vis, float* __restrict__ g_dd, const float* __restrict__ stats) {
+  __shared__ float4 slot[4][8][VT][6];   // [wave][sample][view]: feature map {offsets}, {validity}, {e, w, s, n}; image likewise
+  __shared__ float swg[4][8][VT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s8 = lane >> 3, j = lane & 7;
+  const int n_raw = blockIdx.x * 32 + wave * 8 + s8;
+  const bool act = n_raw < N;
+  const int n = act ? n_raw : N - 1;
+  const int V = vw.V, F = C + 3;
+  const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
+  auto sum8 = [](float v) __attribute__((always_inline)) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
+  struct Proj { float cz, zc, pxr, pyr; bool clx, cly; float4 p0, p1, p2; float xn, yn; };
+  auto project = [&](int vl) __attribute__((always_inline)) {
+    Proj q;
+    q.p0 = *(const float4*)(viewsdev + 12 * vl); q.p1 = *(const float4*)(viewsdev + 12 * vl + 4); q.p2 = *(const float4*)(viewsdev + 12 * vl + 8);
+    const float cx = fmaf(q.p0.z, Z, fmaf(q.p0.y, Y, q.p0.x * X)) + q.p0.w, cy = fmaf(q.p1.z, Z, fmaf(q.p1.y, Y, q.p1.x * X)) + q.p1.w;
+    q.cz = fmaf(q.p2.z, Z, fmaf(q.p2.y, Y, q.p2.x * X)) + q.p2.w;
+    q.zc = fmaxf(q.cz, 1e-8f);
+    q.pxr = cx / q.zc; q.pyr = cy / q.zc;
+    const float px = fminf(fmaxf(q.pxr, -1e6f), 1e6f), py = fminf(fmaxf(q.pyr, -1e6f), 1e6f);
+    q.clx = !(q.pxr > -1e6f && q.pxr < 1e6f); q.cly = !(q.pyr > -1e6f && q.pyr < 1e6f);
+    q.xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f; q.yn = 2.f * py / (float)(vw.H - 1) - 1.f;
+    return q;
+  };
+  // ---------------------------------------------------------------- phase A
+  float a_vis[2], a_dd[2], a_wgt[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int v = j + 8 * p;
+    const bool vact = v < V && v < VT;
+    const int vl = vact ? v : 0;
+    const Proj q = project(vl);
+    const TapD tf = make_tapd(make_taps<true, false>(q.xn, q.yn, vw.w, vw.h), vw.w, vw.h);
+    const TapD ti = make_tapd(make_taps<true, false>(q.xn, q.yn, vw.Wimg, vw.H), vw.Wimg, vw.H);
+    if (v < VT) {
+      float4* sl = slot[wave][s8][v];
+      sl[0] = make_float4(__int_as_float(tf.o[0]), __int_as_float(tf.o[1]), __int_as_float(tf.o[2]), __int_as_float(tf.o[3]));
+      sl[1] = make_float4(tf.m[0], tf.m[1], tf.m[2], tf.m[3]);
+      sl[2] = make_float4(tf.e, tf.w, tf.s, tf.n);
+      sl[3] = make_float4(__int_as_float(ti.o[0]), __int_as_float(ti.o[1]), __int_as_float(ti.o[2]), __int_as_float(ti.o[3]));
+      sl[4] = make_float4(ti.m[0], ti.m[1], ti.m[2], ti.m[3]);
+      sl[5] = make_float4(ti.e, ti.w, ti.s, ti.n);
+    }
+    a_vis[p] = vact ? vis_in[(size_t)vl * N + n] : 0.f;
+    a_dd[p] = vact ? dd_in[(size_t)vl * N + n] : 0.f;
+  }
+  const float vsum = sum8(a_vis[0] + a_vis[1]);
+  a_wgt[0] = a_vis[0] / (vsum + 1e-8f); a_wgt[1] = a_vis[1] / (vsum + 1e-8f);
+  const float omW = 1.f - sum8(a_wgt[0] + a_wgt[1]);   // 1 - sum of the weights (> 0 by the 1e-8)
+  const float mdd = sum8(a_dd[0] * a_wgt[0] + a_dd[1] * a_wgt[1]);
+  if (j < VT) swg[wave][s8][j] = a_wgt[0];
+  if (j + 8 < VT) swg[wave][s8][j + 8] = a_wgt[1];
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase B
+  float aix[VT], aiy[VT], aixI[VT], aiyI[VT], aw[VT];
+#pragma unroll
+  for (int v = 0; v < VT; ++v) aix[v] = aiy[v] = aixI[v] = aiyI[v] = aw[v] = 0.f;
+  const size_t fmap = (size_t)vw.h * vw.w, imap = (size_t)vw.H * vw.Wimg;
+  auto tap4 = [](const float* base, size_t stride, const float4& so, const float4& sm, float4 (&t)[4]) __attribute__((always_inline)) {
+    t[0] = *(const float4*)(base + (size_t)__float_as_int(so.x) * stride); t[1] = *(const float4*)(base + (size_t)__float_as_int(so.y) * stride);
+    t[2] = *(const float4*)(base + (size_t)__float_as_int(so.z) * stride); t[3] = *(const float4*)(base + (size_t)__float_as_int(so.w) * stride);
+    t[0].x *= sm.x; t[0].y *= sm.x; t[0].z *= sm.x; t[0].w *= sm.x;
+    t[1].x *= sm.y; t[1].y *= sm.y; t[1].z *= sm.y; t[1].w *= sm.y;
+    t[2].x *= sm.z; t[2].y *= sm.z; t[2].z *= sm.z; t[2].w *= sm.z;
+    t[3].x *= sm.w; t[3].y *= sm.w; t[3].z *= sm.w; t[3].w *= sm.w;
+  };
+  if (g393) {
+    const float* g = g393 + (size_t)n * ldg;
+    const float* sr = stats + (size_t)n * ldg;
+    for (int ch0 = 0; ch0 < C; ch0 += 32) {
+      const int chr = ch0 + 4 * j;
+      const bool cok = chr < C;
+      const int ch = cok ? chr : 0;
+      float mean[4], gm[4], gv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { mean[c] = cok ? sr[3 + ch + c] : 0.f; gm[c] = cok ? g[3 + ch + c] : 0.f; gv[c] = cok ? g[F + 3 + ch + c] : 0.f; }
+#pragma unroll
+      for (int v = 0; v < VT; ++v) {
+        if (v < V) {
+          const float4 so = slot[wave][s8][v][0], sm = slot[wave][s8][v][1], sf = slot[wave][s8][v][2];
+          const float e = sf.x, w = sf.y, s = sf.z, nn = sf.w, wg = swg[wave][s8][v];
+          float4 t[4];
+          tap4(feat + (size_t)v * fmap * C + ch, (size_t)C, so, sm, t);
+          const float t0[4] = {t[0].x, t[0].y, t[0].z, t[0].w}, t1[4] = {t[1].x, t[1].y, t[1].z, t[1].w}, t2[4] = {t[2].x, t[2].y, t[2].z, t[2].w},
+                      t3[4] = {t[3].x, t[3].y, t[3].z, t[3].w};
+          float six = 0.f, siy = 0.f, sw = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float x = (s * e * t0[c] + s * w * t1[c]) + (nn * e * t2[c] + nn * w * t3[c]);
+            const float d = x - mean[c];
+            const float gx = wg * (gm[c] + 2.f * gv[c] * (d - mean[c] * omW));
+            six = fmaf(gx, s * (t1[c] - t0[c]) + nn * (t3[c] - t2[c]), six);
+            siy = fmaf(gx, e * (t2[c] - t0[c]) + w * (t3[c] - t1[c]), siy);
+            sw += gm[c] * x + gv[c] * (d * d - 2.f * x * mean[c] * omW);
+          }
+          aix[v] += six; aiy[v] += siy; aw[v] += sw;
+        }
+      }
+    }
+    // the colour planes: lanes j < 3
+    {
+      const int pl = j < 3 ? j : 0;
+      const float on = j < 3 ? 1.f : 0.f;
+      const float meanc = sr[pl], gmc = g[pl] * on, gvc = g[F + pl] * on;
+#pragma unroll
+      for (int v = 0; v < VT; ++v) {
+        if (v < V) {
+          const float4 so = slot[wave][s8][v][3], sm = slot[wave][s8][v][4], sf = slot[wave][s8][v][5];
+          const float ei = sf.x, wi = sf.y, si = sf.z, ni = sf.w, wg = swg[wave][s8][v];
+          const float* ib = images + (size_t)v * 3 * imap + (size_t)pl * imap;
+          const float t0 = ib[__float_as_int(so.x)] * sm.x, t1 = ib[__float_as_int(so.y)] * sm.y, t2 = ib[__float_as_int(so.z)] * sm.z, t3 = ib[__float_as_int(so.w)] * sm.w;
+          const float x = (si * ei * t0 + si * wi * t1) + (ni * ei * t2 + ni * wi * t3);
+          const float d = x - meanc;
+          const float gx = wg * (gmc + 2.f * gvc * (d - meanc * omW));
+          aixI[v] += gx * (si * (t1 - t0) + ni * (t3 - t2));
+          aiyI[v] += gx * (ei * (t2 - t0) + wi * (t3 - t1));
+          aw[v] += gmc * x + gvc * (d * d - 2.f * x * meanc * omW);
+        }
+      }
+    }
+  }
+  // ---------------------------------------------------------------- blend part: blend-projected feature taps (32 channels) and tapped colours
+  if (g_pf) {
+    const int pl = j < 3 ? j : 0;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (v < V) {
+        const float4 so = slot[wave][s8][v][0], sm = slot[wave][s8][v][1], sf = slot[wave][s8][v][2];
+        const float e = sf.x, w = sf.y, s = sf.z, nn = sf.w;
+        float4 t[4];
+        tap4(pfeat + (size_t)v * fmap * 32 + 4 * j, 32, so, sm, t);
+        const float4 gx4 = *(const float4*)(g_pf + ((size_t)n * V + v) * 32 + 4 * j);
+        const float t0[4] = {t[0].x, t[0].y, t[0].z, t[0].w}, t1[4] = {t[1].x, t[1].y, t[1].z, t[1].w}, t2[4] = {t[2].x, t[2].y, t[2].z, t[2].w},
+                    t3[4] = {t[3].x, t[3].y, t[3].z, t[3].w}, gx[4] = {gx4.x, gx4.y, gx4.z, gx4.w};
+        float six = 0.f, siy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          six = fmaf(gx[c], s * (t1[c] - t0[c]) + nn * (t3[c] - t2[c]), six);
+          siy = fmaf(gx[c], e * (t2[c] - t0[c]) + w * (t3[c] - t1[c]), siy);
+        }
+        aix[v] += six; aiy[v] += siy;
+        if (g_rgbv) {
+          const float4 io = slot[wave][s8][v][3], im = slot[wave][s8][v][4], iff = slot[wave][s8][v][5];
+          const float ei = iff.x, wi = iff.y, si = iff.z, ni = iff.w;
+          const float* ib = images + (size_t)v * 3 * imap + (size_t)pl * imap;
+          const float u0 = ib[__float_as_int(io.x)] * im.x, u1 = ib[__float_as_int(io.y)] * im.y, u2 = ib[__float_as_int(io.z)] * im.z, u3 = ib[__float_as_int(io.w)] * im.w;
+          const float gc = j < 3 ? g_rgbv[((size_t)n * V + v) * 4 + pl] : 0.f;
+          aixI[v] += gc * (si * (u1 - u0) + ni * (u3 - u2));
+          aiyI[v] += gc * (ei * (u2 - u0) + wi * (u3 - u1));
+        }
+      }
+    }
+  }
+  // the sample's 8 lanes -> every lane holds the totals; lane (s, j) keeps those of views j and j + 8
+  float gix[2] = {0.f, 0.f}, giy[2] = {0.f, 0.f}, gixI[2] = {0.f, 0.f}, giyI[2] = {0.f, 0.f}, gwv[2] = {0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < VT; ++v) {
+    if (v < V) {
+      const float a = sum8(aix[v]), b = sum8(aiy[v]), c = sum8(aixI[v]), d = sum8(aiyI[v]), e = sum8(aw[v]);
+      if (j == (v & 7)) { gix[v >> 3] = a; giy[v >> 3] = b; gixI[v >> 3] = c; giyI[v >> 3] = d; gwv[v >> 3] = e; }
+    }
+  }
+  // ---------------------------------------------------------------- per-view scalar backward: lane (s, j) = views j, j + 8
+  float gX = 0.f, gY = 0.f, gZ = 0.f, gq0 = 0.f, gq1 = 0.f, gq2 = 0.f, gdd_out[2] = {0.f, 0.f}, gwa[2] = {0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int v = j + 8 * p;
+    const bool vact = v < V && v < VT;
+    const int vl = vact ? v : 0;
+    float gw = gwv[p];
+    if (vact) {
+      const Proj q = project(vl);
+      // pixel -> camera -> world (ibrnet.py:183-188).  ix = px (w - 1) / (Wimg - 1) for the feature map, = px for the image.
+      float gpx = gix[p] * ((float)(vw.w - 1) / (float)(vw.Wimg - 1)) + gixI[p], gpy = giy[p] * ((float)(vw.h - 1) / (float)(vw.H - 1)) + giyI[p];
+      if (q.clx) gpx = 0.f;
+      if (q.cly) gpy = 0.f;
+      const float gcx = gpx / q.zc, gcy = gpy / q.zc, gcz = q.cz > 1e-8f ? -(gpx * q.pxr + gpy * q.pyr) / q.zc : 0.f;
+      gX += q.p0.x * gcx + q.p1.x * gcy + q.p2.x * gcz; gY += q.p0.y * gcx + q.p1.y * gcy + q.p2.y * gcz; gZ += q.p0.z * gcx + q.p1.z * gcy + q.p2.z * gcz;
+      if (g_ang) {   // view angles (ibrnet.py:144-167)
+        const float4 ga = *(const float4*)(g_ang + ((size_t)n * V + vl) * 4);
+        float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+        if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(n / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+        const float rq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
+        const float nq = sqrtf(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2]), dq = nq + 1e-6f;
+        const float tq[3] = {rq[0] / dq, rq[1] / dq, rq[2] / dq};
+        const float rt[3] = {viewsdev[192 + 3 * vl] - X, viewsdev[192 + 3 * vl + 1] - Y, viewsdev[192 + 3 * vl + 2] - Z};
+        const float nt = sqrtf(rt[0] * rt[0] + rt[1] * rt[1] + rt[2] * rt[2]), dt = nt + 1e-6f;
+        const float tt[3] = {rt[0] / dt, rt[1] / dt, rt[2] / dt};
+        const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+        const float ndf = sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), nd = fmaxf(ndf, 1e-6f);
+        float gdf[3] = {ga.x / nd, ga.y / nd, ga.z / nd};
+        if (ndf > 1e-6f) {   // u = df / |df|
+          const float dotg = (ga.x * df[0] + ga.y * df[1] + ga.z * df[2]) / (nd * nd * nd);
+          gdf[0] -= df[0] * dotg; gdf[1] -= df[1] * dotg; gdf[2] -= df[2] * dotg;
+        }
+        const float gtq[3] = {gdf[0] + ga.w * tt[0], gdf[1] + ga.w * tt[1], gdf[2] + ga.w * tt[2]};
+        const float gtt[3] = {-gdf[0] + ga.w * tq[0], -gdf[1] + ga.w * tq[1], -gdf[2] + ga.w * tq[2]};
+        // t = r / (|r| + 1e-6): dt_i/dr_j = delta_ij / d - r_i r_j / (|r| d^2)
+        const float cq = nq > 0.f ? (gtq[0] * rq[0] + gtq[1] * rq[1] + gtq[2] * rq[2]) / (nq * dq * dq) : 0.f;
+        const float grq[3] = {gtq[0] / dq - rq[0] * cq, gtq[1] / dq - rq[1] * cq, gtq[2] / dq - rq[2] * cq};
+        const float ct = nt > 0.f ? (gtt[0] * rt[0] + gtt[1] * rt[1] + gtt[2] * rt[2]) / (nt * dt * dt) : 0.f;
+        const float grt[3] = {gtt[0] / dt - rt[0] * ct, gtt[1] / dt - rt[1] * ct, gtt[2] / dt - rt[2] * ct};
+        gX -= grq[0] + grt[0]; gY -= grq[1] + grt[1]; gZ -= grq[2] + grt[2];
+        gq0 += grq[0]; gq1 += grq[1]; gq2 += grq[2];
+      }
+      if (g393) {   // depth-difference statistics + mean weight (multiview_aggregator.py:202-216) -> d/d weight, d/d depth difference
+        const float* g = g393 + (size_t)n * ldg;
+        const float gmd = g[2 * F], gvd = g[2 * F + 1], gmw = g[2 * F + 2];
+        const float d = a_dd[p] - mdd;
+        gw += gmd * a_dd[p] + gvd * (d * d - 2.f * a_dd[p] * mdd * omW) + gmw / (float)V;
+        gdd_out[p] = a_wgt[p] * (gmd + 2.f * gvd * (d - mdd * omW));
+      }
+    }
+    gwa[p] = vact ? gw : 0.f;
+  }
+  // weights = vis / (sum vis + 1e-8): d/d vis_v = gw_v / (S + eps) - sum_u gw_u vis_u / (S + eps)^2
+  const float den = vsum + 1e-8f;
+  const float cross = sum8(gwa[0] * a_vis[0] + gwa[1] * a_vis[1]) / (den * den);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int v = j + 8 * p;
+    if (v < V && v < VT) {
+      float go = gwa[p] / den - cross;
+      if (g_rgbv) go += g_rgbv[((size_t)n * V + v) * 4 + 3];
+      if (act) { g_vis[(size_t)v * N + n] = go; g_dd[(size_t)v * N + n] = gdd_out[p]; }
+    }
+  }
+  gX = sum8(gX); gY = sum8(gY); gZ = sum8(gZ);
+  if (g_qc) { gq0 = sum8(gq0); gq1 = sum8(gq1); gq2 = sum8(gq2); }
+  if (j == 0 && act) {
+    g_xyz[3 * (size_t)n] = gX; g_xyz[3 * (size_t)n + 1] = gY; g_xyz[3 * (size_t)n + 2] = gZ;
+    if (g_qc) { g_qc[3 * (size_t)n] = gq0; g_qc[3 * (size_t)n + 1] = gq1; g_qc[3 * (size_t)n + 2] = gq2; }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -1849,6 +2102,15 @@ int nl_launch_mv_geom_backward(const NlViews& vw, const float* viewsdev, const f
   if (N <= 0) return NL_OK;
   if (C > 192) return NL_ERR_UNSUPPORTED;
   const bool sc = sc_feat || sc_pfeat;
+  if (!sc && (!g393 || stats) && (C & 3) == 0 && vw.V <= 16 && (!g_pf || pfeat)) {   // frozen maps: eight samples per wave
+    dim3 grid8((unsigned)nl_cdiv(N, 32));
+#define NL_MGB8(VT) hipLaunchKernelGGL((mv_geom_backward8_kernel<VT>), grid8, dim3(256), 0, st, vw, viewsdev, images, feat, C, pfeat, xyz, (int)N, vis_in, dd_in, g393, \
+                                       ldg, g_pf, g_rgbv, g_ang, g_xyz, g_qc, g_vis, g_dd, stats)
+    if (vw.V <= 4) NL_MGB8(4); else if (vw.V <= 8) NL_MGB8(8); else if (vw.V <= 10) NL_MGB8(10); else NL_MGB8(16);
+#undef NL_MGB8
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+  }
   dim3 grid((unsigned)nl_cdiv(N, sc ? 8 : 4));
 #define NL_MGB(VT)                                                                                                                                            \
   do {                                                                                                                                                        \

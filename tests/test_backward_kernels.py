@@ -388,7 +388,9 @@ def test_mv_aggregate_weight_gradients_match_autograd(case, precision, chunk):
     ref32, ref64 = eager(torch.float32), eager(torch.float64)
     tg = r.train_grads(names, feat_maps=True, vis_featmaps=True)
     gx = r.mv_aggregate_backward(xyz, cot, train=tg, workspace_samples=chunk)
-    assert torch.equal(gx, r.mv_aggregate_backward(xyz, cot, workspace_samples=chunk))
+    # (training scatters into the maps with a wave per sample; frozen maps take eight samples per wave — mv_geom_backward8_kernel: the same sums in another order)
+    gx0 = r.mv_aggregate_backward(xyz, cot, workspace_samples=chunk)
+    assert float((gx - gx0).norm() / gx0.norm()) < 2e-5, "the input gradient does not depend on the training outputs"
     got = {k: v.clone() for k, v in tg.weights.items()}
     got["feat_fine_src"], got["vis_featmaps"] = tg.feat_maps.clone(), tg.vis_featmaps.contiguous().clone()
     _assert_param_grads(got, ref32, ref64, 3e-4, f"{case}/{precision}", exact_forward=True)
