@@ -70,7 +70,8 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
 bool nl_point_bwd_chain_supported(int W);
 size_t nl_point_bwd_stream_bytes(int W);
 int nl_pack_point_bwd_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
-int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const void* wstream, float* gx, int64_t NK, int W, hipStream_t st);
+int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const void* wstream, float* gx, int64_t NK, int W, hipStream_t st, const float* q = nullptr,
+                              const float* kv = nullptr, const float* go = nullptr, float* gq = nullptr);
 // backward.hip: glue kernels of the neural-point branch's input gradient
 int nl_launch_wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int64_t rows, int shift, int period, float* gW, int ldc, int cs, int co,
                     float* gb, float* scratch, size_t scratch_floats, hipStream_t st);
@@ -994,6 +995,24 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
   NL_TRY(wg(T_FC, -1, p.gpre, W, W, p.O, 128, 128, N));
   SegSpec sp{p.gpre, W, W, 0, 1}, sgq{p.gQ, 128, 128, 0, 1}, skv{p.gKV, 256, 256, 0, 1}, sa{p.gA, W, W, 0, 1}, sb{p.gB, W, W, 0, 1};
   NL_TRY(run_gemm(xb, G_FC_T, &sp, 1, N, p.gO, 128, NL_ACT_NONE));
+  // frozen weights, W = 128 / 256, K = 8: the attention's way back, the four (N x 8)-row products and the LeakyReLU masks in between as ONE launch that keeps the rows
+  // in registers (point_bwd.hip); d query comes back from it
+  const bool chain = !tg && K == 8 && pt_mask_bits(x) && pt_table(x) && !dbg_switch("NERFLOC_NO_BWD_CHAIN") && nl_point_bwd_chain_supported(W) && NK * 1024 <= 0x7fffffffll;
+  const bool chain_att = chain && !dbg_switch("NERFLOC_NO_BWD_ATT");
+  if (chain) {
+    const unsigned* mk[3] = {p.mk[0], p.mk[1], p.mk[2]};
+    if (chain_att) NL_TRY(nl_launch_point_bwd_chain(nullptr, mk, x.p<char>(x.L.pt_bwd_stream), p.gX, NK, W, x.st, p.Q, p.KV, p.gO, p.gQ));
+    else {
+      NL_TRY(nl_launch_attn_backward(p.Q, p.KV, p.gO, N, K, p.gQ, p.gKV, x.st));
+      NL_TRY(nl_launch_point_bwd_chain(p.gKV, mk, x.p<char>(x.L.pt_bwd_stream), p.gX, NK, W, x.st));
+    }
+    if (g_G) {   // residual path + query projection
+      NL_TRY(run_gemm(xb, G_Q_T, &sgq, 1, N, p.FCo, W, NL_ACT_NONE));   // (FCo is free from here on)
+      NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
+    }
+    return nl_launch_point_encode_backward(xyz, dir, dir_stride, dir_div, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz, g_dir,
+                                           nullptr, x.st);
+  }
   NL_TRY(nl_launch_attn_backward(p.Q, p.KV, p.gO, N, K, p.gQ, p.gKV, x.st));
   NL_TRY(wg(T_WQ, -1, p.gQ, 128, 128, G, W, W, N));
   NL_TRY(wg(T_WK, -1, p.gKV, 256, 128, p.H3, W, W, NK));
@@ -1003,13 +1022,6 @@ int pt_backward_only(const Ctx& xb, const Ctx& x, const nl_frame* f, const float
     NL_TRY(nl_launch_add(p.gpre, p.FCo, g_G, (size_t)N * W, x.st));
   }
   const bool bits = pt_mask_bits(x);
-  // frozen weights, W = 128 / 256: the four (N x 8)-row products with the LeakyReLU masks in between as ONE launch that keeps the rows in registers (point_bwd.hip)
-  if (!tg && bits && pt_table(x) && !dbg_switch("NERFLOC_NO_BWD_CHAIN") && nl_point_bwd_chain_supported(W) && NK * 1024 <= 0x7fffffffll) {
-    const unsigned* mk[3] = {p.mk[0], p.mk[1], p.mk[2]};
-    NL_TRY(nl_launch_point_bwd_chain(p.gKV, mk, x.p<char>(x.L.pt_bwd_stream), p.gX, NK, W, x.st));
-    return nl_launch_point_encode_backward(xyz, dir, dir_stride, dir_div, N, K, M, idx, f->sp_xyz, f->sp_dir, x.p<float>(x.L.rd_w), inv_span, p.gX, 96, g_xyz, g_dir,
-                                           nullptr, x.st);
-  }
   NL_TRY(gemm_lrelu_masked(xb, G_KV_T, skv, NK, p.gA, W, p.H3, bits ? p.mk[2] : nullptr));
   NL_TRY(wg(T_B4W, T_B4B, p.gA, W, W, p.H2, W, W, NK));
   NL_TRY(gemm_lrelu_masked(xb, G_BASE4_T, sa, NK, p.gB, W, p.H2, bits ? p.mk[1] : nullptr));

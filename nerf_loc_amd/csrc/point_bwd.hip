@@ -82,7 +82,9 @@ __device__ __forceinline__ unsigned pb_lo2(float v0, float v1, unsigned hi) {
 }
 
 struct PbArgs {
-  const float* gkv;          // (NK, 256) d k | d v rows
+  const float* q; const float* kv; const float* go; float* gq;   // ATT: query (N, 128), kept k | v rows (NK, 256), d attention output (N, 128) -> d query (N, 128)
+  unsigned q_bytes;
+  const float* gkv;          // !ATT: (NK, 256) d k | d v rows
   const unsigned* mk[3];     // sign bits of the forward layers 1..3 ([32-row tile][lane][4 dwords])
   const uint4* wstream;
   float* gx;                 // (NK, 96)
@@ -90,7 +92,9 @@ struct PbArgs {
   int ntiles;
 };
 
-template <int NRT>
+// ATT: the tile's d kv rows are not read but made — the attention's way back (ibrnet.py:89-108; backward.hip: attn_backward_kernel) runs in the prologue: lane (row,
+// half) holds exactly the 16 dims per head that its B-operand k-slots want, the softmax over a sample's 8 neighbours is three DPP steps, d query is written from here.
+template <int NRT, bool ATT>
 __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a) {
   using GG = BGeo<NRT>;
   constexpr int NC = GG::NC, SLOT = GG::SLOT;
@@ -104,7 +108,10 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   // every access of the tile loop goes through buffer instructions (point_fused2.hip: exact vmcnt bookkeeping by the compiler, scalar piece offsets, out-of-range
   // offsets read zero / are dropped: rows past the end need no branch)
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wstream, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)a.gkv, 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc((void*)(ATT ? a.kv : a.gkv), 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)a.q, 0, ATT ? (int)a.q_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rGO = __builtin_amdgcn_make_buffer_rsrc((void*)a.go, 0, ATT ? (int)a.q_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rGQ = __builtin_amdgcn_make_buffer_rsrc((void*)a.gq, 0, ATT ? (int)a.q_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rM0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.mk[0], 0, (int)a.mk_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rM1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.mk[1], 0, (int)a.mk_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rM2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.mk[2], 0, (int)a.mk_bytes, 0x00020000);
@@ -127,7 +134,10 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   unsigned Xh[2][GG::KSM][4], Xl[2][GG::KSM][4];
   pb_u32x4 frh[GG::RL], frl[GG::RL];   // A-fragment ring, position = (running k-step) % RL
   pb_f32x16 acc[2];                    // accumulator of chunk c = acc[c & 1]: region G accumulates one while the epilogue of G-1 drains the other
-  pb_f32x4 raw[4][2];                  // input rows in flight: k-step e of the next tile sits in raw[e & 3] until it is split three events later
+  pb_f32x4 raw[4][2];                  // !ATT: input rows in flight: k-step e of the next tile sits in raw[e & 3] until it is split three events later
+  pb_f32x4 qv[4], gov[4], kk[4], vv[4];   // ATT: this lane's 16 dims of the head being worked on: query, d output (per sample), k, v (per row)
+  float asc = 0.f, agp = 0.f, amx = 0.f, aee = 0.f, aat = 0.f, ags = 0.f, agsq = 0.f;
+  unsigned qoff = 0, gqoff = 0, pn_qoff = 0, pn_gqoff = 0;
   pb_u32x4 mkw[3];                     // the tile's sign bits of forward layers 3, 2, 1 (= way-back layers 0, 1, 2)
   float ev0 = 0.f, ev1 = 0.f;
   unsigned ehi = 0;
@@ -161,7 +171,60 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
       raw[e & 3][1] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, off + 64u * e + 16u, 0, 0));
     }
   };
+  // ATT: 13 events per head h (= encode-column region h): 0 the 16 loads | 1-4 scores, softmax, its way back | 5-8 d k / d v -> k-steps 2 h + u / 8 + 2 h + u of X[1] |
+  // 9-12 d query (summed over the sample's 8 rows) -> HBM
+  auto att_event = [&](auto Hc, auto Ec, unsigned qo, unsigned ko, unsigned gqo) __attribute__((always_inline)) {
+    constexpr int h = decltype(Hc)::value, e = decltype(Ec)::value;
+    constexpr float itemp = 1.0f / 5.656854249492381f;   // temperature sqrt(d_k) (ibrnet.py:84)
+    if constexpr (e == 0) {
+      pb_static_for<4>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value;
+        constexpr unsigned o = 128u * h + 64u * (i >> 1) + 16u * (i & 1);
+        qv[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, qo + o, 0, 0));
+        gov[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rGO, qo + o, 0, 0));
+        kk[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, ko + o, 0, 0));
+        vv[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, ko + 512u + o, 0, 0));
+      });
+    } else if constexpr (e == 1) {
+      float x = 0.f, y = 0.f;
+      pb_static_for<16>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value >> 2, c = decltype(Ic)::value & 3;
+        x = fmaf(qv[i][c], kk[i][c], x); y = fmaf(gov[i][c], vv[i][c], y);
+      });
+      asc = x; agp = y;
+    } else if constexpr (e == 2) {
+      asc += __shfl_xor(asc, 32, 64); agp += __shfl_xor(agp, 32, 64);
+      asc *= itemp;
+      amx = nl_max8(asc);
+    } else if constexpr (e == 3) {
+      aee = expf(asc - amx);
+      aat = aee / nl_sum8(aee);
+    } else if constexpr (e == 4) {
+      ags = aat * (agp - nl_sum8(aat * agp));   // softmax backward -> d score
+      agsq = ags * itemp;
+    } else if constexpr (e < 9) {
+      constexpr int kind = (e - 5) >> 1, u = (e - 5) & 1, ks = (kind ? 8 : 0) + 2 * h + u;
+      pb_static_for<4>([&](auto Dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(Dc)::value, i = 2 * u + (d >> 1), c0 = 2 * (d & 1);
+        const float v0 = kind ? aat * gov[i][c0] : agsq * qv[i][c0], v1 = kind ? aat * gov[i][c0 + 1] : agsq * qv[i][c0 + 1];
+        const unsigned hw = pb_cvt_pk_bf16(v0, v1);
+        Xh[1][ks][d] = hw;
+        Xl[1][ks][d] = pb_lo2(v0, v1, hw);
+      });
+    } else {
+      constexpr int i = e - 9;
+      const float x0 = nl_sum8(ags * kk[i][0]) * itemp, x1 = nl_sum8(ags * kk[i][1]) * itemp, x2 = nl_sum8(ags * kk[i][2]) * itemp, x3 = nl_sum8(ags * kk[i][3]) * itemp;
+      __builtin_amdgcn_raw_buffer_store_b128(pb_u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, rGQ,
+                                             gqo + 128u * h + 64u * (i >> 1) + 16u * (i & 1), 0, 0);
+    }
+  };
   auto row_off = [&](int t) __attribute__((always_inline)) { return (unsigned)(t * 128 + wave * 32 + j); };
+  auto set_att_off = [&](int t, unsigned& io, unsigned& qo, unsigned& gqo) __attribute__((always_inline)) {
+    const unsigned r = row_off(t);
+    io = r * 1024u + 32u * hh;
+    qo = (r >> 3) * 512u + 32u * hh;               // the row's sample
+    gqo = (r & 7u) ? 0x80000000u : qo;             // the sample's first row stores d query (the others: out of range = dropped)
+  };
   auto load_mask = [&](auto Lc, int t) __attribute__((always_inline)) {   // way-back layer L reads the sign bits of forward layer 3 - L
     constexpr int L = decltype(Lc)::value;
     mkw[L] = __builtin_bit_cast(pb_u32x4, __builtin_amdgcn_raw_buffer_load_b128(L == 0 ? rM2 : L == 1 ? rM1 : rM0, (unsigned)(t * 4 + wave) * 1024u + lane * 16u, 0, 0));
@@ -213,10 +276,23 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
     if constexpr (K == 0 && G == NRT - 2) load_mask(std::integral_constant<int, 1>{}, tile);
     if constexpr (K == 0 && G == 2 * NRT - 2) load_mask(std::integral_constant<int, 2>{}, tile);
     // the next tile's input rows, under the encode-column regions
-    if constexpr (G >= 3 * NRT) {
+    if constexpr (G >= 3 * NRT && !ATT) {
       if constexpr (K == 0 && G == 3 * NRT) pn_inoff = row_off(pn_tile) * 1024u + 32u * hh;
       constexpr int s = (G - 3 * NRT) * NS + K, T = 4 * NS, e0 = s * EV / T, e1 = (s + 1) * EV / T;
       pb_static_for<e1 - e0>([&](auto Ic) __attribute__((always_inline)) { pro_event(std::integral_constant<int, e0 + decltype(Ic)::value>{}, pn_inoff); });
+    }
+    if constexpr (G >= 3 * NRT && ATT) {   // head G - 3 NRT: the loads first, the arithmetic under the region's second half
+      constexpr int h = G - 3 * NRT, H2 = NS / 2;
+      if constexpr (K == 0) {
+        if constexpr (h == 0) set_att_off(pn_tile, pn_inoff, pn_qoff, pn_gqoff);
+        att_event(std::integral_constant<int, h>{}, std::integral_constant<int, 0>{}, pn_qoff, pn_inoff, pn_gqoff);
+      }
+      if constexpr (K >= H2) {
+        constexpr int e0 = 1 + (K - H2) * 12 / H2, e1 = 1 + (K - H2 + 1) * 12 / H2;
+        pb_static_for<e1 - e0>([&](auto Ic) __attribute__((always_inline)) {
+          att_event(std::integral_constant<int, h>{}, std::integral_constant<int, e0 + decltype(Ic)::value>{}, pn_qoff, pn_inoff, pn_gqoff);
+        });
+      }
     }
     // epilogue of the previous chunk (a layer's last row tile is finished inside the first region of the NEXT layer, which consumes the fragments it produces
     // in its last two k-steps: layer epilogues end one k-step early)
@@ -272,9 +348,16 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   pb_static_for<3>([&](auto Cc) __attribute__((always_inline)) {
     pb_static_for<GG::ppw(decltype(Cc)::value)>([&](auto Ic) __attribute__((always_inline)) { dma_piece(Cc, Ic); });
   });
-  inoff = row_off(tile) * 1024u + 32u * hh;
   load_mask(std::integral_constant<int, 0>{}, tile);
-  pb_static_for<EV>([&](auto Ec) __attribute__((always_inline)) { pro_event(Ec, inoff); });
+  if constexpr (ATT) {
+    set_att_off(tile, inoff, qoff, gqoff);
+    pb_static_for<4>([&](auto Hc) __attribute__((always_inline)) {
+      pb_static_for<13>([&](auto Ec) __attribute__((always_inline)) { att_event(Hc, Ec, qoff, inoff, gqoff); });
+    });
+  } else {
+    inoff = row_off(tile) * 1024u + 32u * hh;
+    pb_static_for<EV>([&](auto Ec) __attribute__((always_inline)) { pro_event(Ec, inoff); });
+  }
   pb_wait_vmcnt<GG::ppw(1) + GG::ppw(2)>();   // conservative: the prologue's own loads are younger than every piece of chunk 0
   __builtin_amdgcn_s_barrier();
   read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1)>{}, std::integral_constant<int, 0>{});
@@ -354,8 +437,10 @@ int nl_pack_point_bwd_stream(const float* w1, const float* w2, const float* w3, 
   return NL_OK;
 }
 
-// gkv (NK, 256) -> gx (NK, 96): the four transposed products of the branch's rows with the forward's sign bits mk[0..2] (forward layers 1..3) in between
-int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const void* wstream, float* gx, int64_t NK, int W, hipStream_t st) {
+// gkv (NK, 256) -> gx (NK, 96): the four transposed products of the branch's rows with the forward's sign bits mk[0..2] (forward layers 1..3) in between.
+// att (gkv == null): the attention's way back in front — q (N, 128), kv (NK = 8 N, 256), go (N, 128) -> gq (N, 128) and the d kv rows, which never leave the registers
+int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const void* wstream, float* gx, int64_t NK, int W, hipStream_t st, const float* q,
+                              const float* kv, const float* go, float* gq) {
   if (NK <= 0) return NL_OK;
   if (!nl_point_bwd_chain_supported(W) || NK * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   if (g_pb_num_cu == 0) {
@@ -366,12 +451,20 @@ int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const
   }
   PbArgs a;
   memset(&a, 0, sizeof(a));
+  const bool att = gkv == nullptr;
+  if (att && (!q || !kv || !go || !gq || (NK & 7))) return NL_ERR_BAD_ARG;
+  a.q = q; a.kv = kv; a.go = go; a.gq = gq; a.q_bytes = (unsigned)(NK / 8 * 512);
   a.gkv = gkv; a.mk[0] = mk[0]; a.mk[1] = mk[1]; a.mk[2] = mk[2]; a.wstream = (const uint4*)wstream; a.gx = gx;
   a.in_bytes = (unsigned)(NK * 1024); a.mk_bytes = (unsigned)(nl_cdiv(NK, 32) * 1024); a.out_bytes = (unsigned)(NK * 384);
   a.ntiles = (int)nl_cdiv(NK, 128);
   const int nwg = a.ntiles < g_pb_num_cu ? (int)nl_xcd_grid(a.ntiles) : g_pb_num_cu;
-  if (W == 256) hipLaunchKernelGGL((point_bwd_chain_kernel<8>), dim3(nwg), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((point_bwd_chain_kernel<4>), dim3(nwg), dim3(256), 0, st, a);
+  if (W == 256) {
+    if (att) hipLaunchKernelGGL((point_bwd_chain_kernel<8, true>), dim3(nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((point_bwd_chain_kernel<8, false>), dim3(nwg), dim3(256), 0, st, a);
+  } else {
+    if (att) hipLaunchKernelGGL((point_bwd_chain_kernel<4, true>), dim3(nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((point_bwd_chain_kernel<4, false>), dim3(nwg), dim3(256), 0, st, a);
+  }
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

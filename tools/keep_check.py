@@ -28,8 +28,8 @@ N, W, K = xyz.shape[0], cfg.W, 8
 NK = N * K
 ldx = (cfg.C + 3 + 90 + 31) // 32 * 32
 
-def run(staged, chain=False):
-    for k, on in (("NERFLOC_NO_KEEP_FUSED", staged), ("NERFLOC_NO_BWD_CHAIN", not chain)):
+def run(staged, chain=False, att=False):
+    for k, on in (("NERFLOC_NO_KEEP_FUSED", staged), ("NERFLOC_NO_BWD_CHAIN", not chain), ("NERFLOC_NO_BWD_ATT", not att)):
         if on: os.environ[k] = "1"
         else: os.environ.pop(k, None)
     r._ws = None
@@ -41,6 +41,9 @@ def run(staged, chain=False):
 gc, ws_c = run(True, chain=True)   # the same staged forward; the four row products of the way back as one launch (point_bwd.hip)
 for n, a, b in zip(("g_xyz", "g_dir", "g_G"), gs, gc):
     print(n, "chained way back vs staged rel", float(np.abs(a - b).max() / np.abs(a).max()))
+ga, ws_a = run(True, chain=True, att=True)   # ... with the attention's way back inside the chain kernel's prologue
+for n, a, b in zip(("g_xyz", "g_dir", "g_G"), gs, ga):
+    print(n, "chained + attention way back vs staged rel", float(np.abs(a - b).max() / np.abs(a).max()))
 for n, a, b in zip(("g_xyz", "g_dir", "g_G"), gs, gf):
     print(n, "fused vs staged rel", float(np.abs(a - b).max() / np.abs(a).max()))
 # carve_ptb's order (abi.hip): every take is 256-byte aligned
@@ -65,6 +68,9 @@ for nm, nb in names:
         err = np.abs(a - b).max(1) / np.abs(a).max()
         print("gX chained vs staged: max diff / max", float(err.max()), "| rows beyond 1e-4:", int((err > 1e-4).sum()), "of", NK, "| L2-rel", float(np.linalg.norm(a - b) / np.linalg.norm(a)),
               "| first bad rows", np.nonzero(err > 1e-4)[0][:8], "| pad columns max", float(np.abs(b[:, 90:]).max()))
+    elif nm == "gQ":
+        a, b = ws_s[o_:o_ + nb].view(np.float32), ws_a[o_:o_ + nb].view(np.float32)
+        print("gQ attention-in-chain vs staged: max diff / max", float(np.abs(a - b).max() / np.abs(a).max()))
     elif nm in ("KV", "Q", "O", "FCo", "wscale", "idx"):
         dt = np.int32 if nm == "idx" else np.float32
         a, b = ws_s[o_:o_ + nb].view(dt), ws_f[o_:o_ + nb].view(dt)
