@@ -627,8 +627,7 @@ __global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const f
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     float a = go[ax], b = gd[ax];
-    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
+    a = nl_sum8(a); b = nl_sum8(b);
     go[ax] = a; gd[ax] = b;
   }
   if (live && k == 0) {
@@ -1187,7 +1186,7 @@ __global__ __launch_bounds__(256) void mv_geom_backward8_kernel(const NlViews vw
   const int n = act ? n_raw : N - 1;
   const int V = vw.V, F = C + 3;
   const float X = xyz[3 * (size_t)n], Y = xyz[3 * (size_t)n + 1], Z = xyz[3 * (size_t)n + 2];
-  auto sum8 = [](float v) __attribute__((always_inline)) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
+  auto sum8 = [](float v) __attribute__((always_inline)) { return nl_sum8(v); };   // three DPP steps over the sample's 8 lanes
   struct Proj { float cz, zc, pxr, pyr; bool clx, cly; float4 p0, p1, p2; float xn, yn; };
   auto project = [&](int vl) __attribute__((always_inline)) {
     Proj q;
