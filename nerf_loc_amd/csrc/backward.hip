@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void point_encode_backward_kernel(const float*
   }
 }
 
-// The same with frozen weights and K = 8, LANE = one (sample, neighbour) row: the row's 90 gradient columns, its positional-encoding derivative (one fp64 sin / cos per
+// The same for K = 8 with LANE = one (sample, neighbour) row: the row's 90 gradient columns, its positional-encoding derivative (one fp64 sin / cos per
 // axis + the double-angle recurrence, like the forward kernel) and the whole ray_diff_fc 4 -> 16 -> 27 forward + backward (~1000 FMAs against wave-uniform weights, which
 // the compiler keeps in SGPRs) stay in the lane; the 8 rows of a sample are summed with three DPP steps.  The wave-per-sample kernel above walks the neighbours one after
 // the other with five wave reductions each: 0.44 ms per 512-ray pose step against 0.06 ms here.
@@ -554,7 +554,8 @@ __device__ __forceinline__ void bk_sincos_d(double x, double& s, double& c) {   
 __global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ dir, int dir_stride, int dir_div,
                                                                          int N, int M, const int* __restrict__ idx, const float* __restrict__ sp_xyz,
                                                                          const float* __restrict__ sp_dir, const float* __restrict__ rd_w, float inv_span,
-                                                                         const float* __restrict__ gX, int ldg, float* __restrict__ g_xyz, float* __restrict__ g_dir) {
+                                                                         const float* __restrict__ gX, int ldg, float* __restrict__ g_xyz, float* __restrict__ g_dir,
+                                                                         float* __restrict__ tr /* training: (N*8, 68) rows for ray_diff_fc's weight gradients, or null */) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   const int k = (int)(row & 7);
   const long long nl = row >> 3;
@@ -586,9 +587,10 @@ __global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const f
     go[ax] = (float)a;
   }
   float gd[3] = {0.f, 0.f, 0.f};
-  if (dir) {   // (kernel-uniform) ray_diff_fc (model.py:36-39, 396-399): 4 -> 16 -> 27, LeakyReLU after both
-    const size_t dr = (size_t)(n / dir_div) * dir_stride;
-    const float dx = dir[dr], dy = dir[dr + 1], dz = dir[dr + 2];
+  if (dir || tr) {   // (kernel-uniform) ray_diff_fc (model.py:36-39, 396-399): 4 -> 16 -> 27, LeakyReLU after both
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (dir) { const size_t dr = (size_t)(n / dir_div) * dir_stride; dx = dir[dr]; dy = dir[dr + 1]; dz = dir[dr + 2]; }
+    else if (M > 0) { const int i0 = idx[(size_t)n * 8]; dx = sp_dir[4 * (size_t)i0]; dy = sp_dir[4 * (size_t)i0 + 1]; dz = sp_dir[4 * (size_t)i0 + 2]; }   // model.py:391-392
     const float ndx = have ? sp_dir[4 * (size_t)i] : 0.f, ndy = have ? sp_dir[4 * (size_t)i + 1] : 0.f, ndz = have ? sp_dir[4 * (size_t)i + 2] : 0.f;
     const float rr0 = dx - ndx, rr1 = dy - ndy, rr2 = dz - ndz;
     const float nrm = sqrtf(rr0 * rr0 + rr1 * rr1 + rr2 * rr2), nr = nrm + 1e-8f;
@@ -607,6 +609,7 @@ __global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const f
 #pragma unroll
       for (int j = 0; j < 16; ++j) a2 = fmaf(w2[l * 16 + j], h[j], a2);
       const float ga2 = g[63 + l] * (a2 > 0.f ? 1.f : 0.01f);
+      g[63 + l] = ga2;   // (kept for the training rows)
 #pragma unroll
       for (int j = 0; j < 16; ++j) gh[j] = fmaf(w2[l * 16 + j], ga2, gh[j]);
     }
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const f
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const float ga1 = gh[j] * (a1[j] > 0.f ? 1.f : 0.01f);
+      gh[j] = ga1;
       gr0 = fmaf(rd_w[j * 4 + 0], ga1, gr0); gr1 = fmaf(rd_w[j * 4 + 1], ga1, gr1); gr2 = fmaf(rd_w[j * 4 + 2], ga1, gr2); gr3 = fmaf(rd_w[j * 4 + 3], ga1, gr3);
     }
     // u = rr / (|rr| + 1e-8): du_i/drr_j = delta_ij / nr - rr_i rr_j / (|rr| nr^2)  (0 at rr = 0, like torch.norm's subgradient)
@@ -622,6 +626,16 @@ __global__ __launch_bounds__(256) void point_encode_backward_rows_kernel(const f
     gd[0] = gr0 / nr - rr0 * cc + gr3 * ndx;
     gd[1] = gr1 / nr - rr1 * cc + gr3 * ndy;
     gd[2] = gr2 / nr - rr2 * cc + gr3 * ndz;
+    if (tr && live) {   // rows for ray_diff_fc's weight gradients: [input 4 | hidden 16 | d hidden 16 | d output 32 (27 used)]
+      float4* t = (float4*)(tr + ((size_t)n * 8 + k) * 68);
+      t[0] = make_float4(r0, r1, r2, r3);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { t[1 + c] = make_float4(h[4 * c], h[4 * c + 1], h[4 * c + 2], h[4 * c + 3]); t[5 + c] = make_float4(gh[4 * c], gh[4 * c + 1], gh[4 * c + 2], gh[4 * c + 3]); }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) t[9 + c] = make_float4(g[63 + 4 * c], g[64 + 4 * c], g[65 + 4 * c], g[66 + 4 * c]);
+      t[15] = make_float4(g[87], g[88], g[89], 0.f);
+      t[16] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   // the sample's 8 rows are 8 neighbouring lanes
 #pragma unroll
@@ -809,9 +823,9 @@ int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
                                     float* g_dir, float* tr, hipStream_t st) {
   if (N <= 0) return NL_OK;
-  if (!tr && K == 8 && (ldg & 3) == 0 && ldg >= 92 && (((size_t)gX) & 15) == 0) {   // frozen weights: lane = row
+  if (K == 8 && (ldg & 3) == 0 && ldg >= 92 && ((((size_t)gX) | ((size_t)tr)) & 15) == 0) {   // lane = row
     hipLaunchKernelGGL(point_encode_backward_rows_kernel, dim3((unsigned)nl_cdiv(N * 8, 256)), dim3(256), 0, st, xyz, dir, dir_stride, dir_div > 0 ? dir_div : 1, (int)N,
-                       (int)(M > 0x7fffffff ? 0x7fffffff : M), idx, sp_xyz, sp_dir, rd_w, inv_span, gX, ldg, g_xyz, dir ? g_dir : nullptr);
+                       (int)(M > 0x7fffffff ? 0x7fffffff : M), idx, sp_xyz, sp_dir, rd_w, inv_span, gX, ldg, g_xyz, dir ? g_dir : nullptr, tr);
     NL_LAUNCH_CHECK();
     return NL_OK;
   }
