@@ -267,7 +267,34 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
   }
   if (o_feat && ft) {
     __builtin_amdgcn_wave_barrier();
-    // lanes across channels, serial over samples; weights broadcast from LDS (written by this wave only)
+    // lanes across channels, serial over samples; weights broadcast from LDS (written by this wave only).  Four channels per lane and four samples in flight where
+    // the rows allow it: at 512 rays (a rank's shard of config 2 on 8 GPUs) there are two waves per CU and the loop is pure load latency (68 -> 25 us)
+    if ((C & 3) == 0 && (((size_t)ft | (size_t)o_feat) & 15) == 0) {
+      for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + 4 * lane;
+        if (c < C) {
+          const float* fp = ft + (size_t)r * S * C + c;
+          float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+          int s = 0;
+          for (; s + 4 <= na; s += 4) {
+            const float4 f0 = *(const float4*)(fp + (size_t)s * C), f1 = *(const float4*)(fp + (size_t)(s + 1) * C), f2 = *(const float4*)(fp + (size_t)(s + 2) * C),
+                         f3 = *(const float4*)(fp + (size_t)(s + 3) * C);
+            const float w0 = wsh[wv][s], w1 = wsh[wv][s + 1], w2 = wsh[wv][s + 2], w3 = wsh[wv][s + 3];
+            a0.x = fmaf(w0, f0.x, a0.x); a0.y = fmaf(w0, f0.y, a0.y); a0.z = fmaf(w0, f0.z, a0.z); a0.w = fmaf(w0, f0.w, a0.w);
+            a1.x = fmaf(w1, f1.x, a1.x); a1.y = fmaf(w1, f1.y, a1.y); a1.z = fmaf(w1, f1.z, a1.z); a1.w = fmaf(w1, f1.w, a1.w);
+            a2.x = fmaf(w2, f2.x, a2.x); a2.y = fmaf(w2, f2.y, a2.y); a2.z = fmaf(w2, f2.z, a2.z); a2.w = fmaf(w2, f2.w, a2.w);
+            a3.x = fmaf(w3, f3.x, a3.x); a3.y = fmaf(w3, f3.y, a3.y); a3.z = fmaf(w3, f3.z, a3.z); a3.w = fmaf(w3, f3.w, a3.w);
+          }
+          for (; s < na; ++s) {
+            const float4 f0 = *(const float4*)(fp + (size_t)s * C);
+            const float w0 = wsh[wv][s];
+            a0.x = fmaf(w0, f0.x, a0.x); a0.y = fmaf(w0, f0.y, a0.y); a0.z = fmaf(w0, f0.z, a0.z); a0.w = fmaf(w0, f0.w, a0.w);
+          }
+          *(float4*)(o_feat + (size_t)r * C + c) = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                                                               (a0.w + a1.w) + (a2.w + a3.w));
+        }
+      }
+    } else
     for (int c0 = 0; c0 < C; c0 += 64) {
       const int c = c0 + lane;
       float acc = 0.f;
