@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   QueryCtx c;
   c.org0 = gpp->origin[0]; c.org1 = gpp->origin[1]; c.org2 = gpp->origin[2];
   c.cell = gpp->cell; c.slack = 1e-3f * c.cell;
+  const float inv_cell = gpp->inv_cell;
   bool prev_full = false;   // the previous query of this wave found K neighbours, whose sorted-array positions are
   unsigned ppos = 0;        // in ppos (lane k < K)
 
@@ -332,8 +333,31 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   int* leaf_s = s_leaf_s[wv];
   int* leaf_l = s_leaf_l[wv];
   int nfront = 1, nleaf = 0;
-  if (lane == 0) { front[0] = 0u; fxyz[0] = 0u; }
   const u64 lt_mask = (1ull << lane) - 1ull;
+  // Start level: with a bound U the search region is the ball's bounding box, which at the smallest level where it spans at most two nodes per axis is covered by
+  // <= 8 nodes — the frontier starts there instead of at the root (near a surface: level 1-2 of 6; every skipped level is a 60-instruction batch of this wave).
+  // (Wave-uniform arithmetic; the box is widened by the rounding slack and one cell, and every child still passes the exact box test below.)
+  int Lstart = GRID_BITS;
+#ifndef NL_KNN_NO_START_LEVEL
+  if (U < 3.0e38f) {
+    const float r = sqrtf(U * 1.000001f) + c.slack;
+    const int lo0 = min(max((int)floorf((c.qx - r - c.org0) * inv_cell) - 1, 0), GRID_N - 1), hi0 = min(max((int)floorf((c.qx + r - c.org0) * inv_cell) + 1, 0), GRID_N - 1);
+    const int lo1 = min(max((int)floorf((c.qy - r - c.org1) * inv_cell) - 1, 0), GRID_N - 1), hi1 = min(max((int)floorf((c.qy + r - c.org1) * inv_cell) + 1, 0), GRID_N - 1);
+    const int lo2 = min(max((int)floorf((c.qz - r - c.org2) * inv_cell) - 1, 0), GRID_N - 1), hi2 = min(max((int)floorf((c.qz + r - c.org2) * inv_cell) + 1, 0), GRID_N - 1);
+    int Ls = 1;
+    while (Ls < GRID_BITS && (((hi0 >> Ls) - (lo0 >> Ls)) > 1 || ((hi1 >> Ls) - (lo1 >> Ls)) > 1 || ((hi2 >> Ls) - (lo2 >> Ls)) > 1)) ++Ls;
+    Ls = __builtin_amdgcn_readfirstlane(Ls);
+    if (Ls < GRID_BITS) {
+      Lstart = Ls;
+      const unsigned nx = (unsigned)(lo0 >> Ls) + (lane & 1), ny = (unsigned)(lo1 >> Ls) + ((lane >> 1) & 1), nz = (unsigned)(lo2 >> Ls) + ((lane >> 2) & 1);
+      const bool ok = lane < 8 && nx <= (unsigned)(hi0 >> Ls) && ny <= (unsigned)(hi1 >> Ls) && nz <= (unsigned)(hi2 >> Ls);
+      const u64 mk = __ballot(ok);
+      if (ok) { const int pos = __popcll(mk & lt_mask); front[pos] = morton3(nx, ny, nz); fxyz[pos] = nx | (ny << 10) | (nz << 20); }
+      nfront = __popcll(mk);
+    }
+  }
+#endif
+  if (Lstart == GRID_BITS && lane == 0) { front[0] = 0u; fxyz[0] = 0u; }
 
   // leaves hold <= 16 points each: four leaves per 64-lane batch, one per 16-lane slot (no prefix sums, no index search)
   auto flush_leaves = [&]() {
@@ -350,7 +374,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
     if (best.full()) U = fminf(U, __uint_as_float(best.td));
   };
 
-  for (int L = GRID_BITS; L > 0; --L) {
+  for (int L = Lstart; L > 0; --L) {
     int nnext = 0;
     const int sh = 3 * (L - 1);
     for (int base = 0; base < nfront; base += 8) {
