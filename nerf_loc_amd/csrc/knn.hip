@@ -189,8 +189,12 @@ struct BestK {
 };
 
 // Merge one candidate per lane (kd = bits(dist2), ki = idx; 0xffffffff/0xffffffff = none) into the best list.
+#ifndef KNN_KO
+#define KNN_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no selection loop, 2 no leaf candidates, 4 no breadth-first descent
+#endif
 template <int K>
 __device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigned ki, unsigned kp) {
+  if (KNN_KO & 1) { best.d ^= kd & 1u; return; }
   while (true) {
     const bool cont = kd < best.td || (kd == best.td && ki < best.ti);
     if (__ballot(cont) == 0ull) break;
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
 
   // leaves hold <= 16 points each: four leaves per 64-lane batch, one per 16-lane slot (no prefix sums, no index search)
   auto flush_leaves = [&]() {
+    if (KNN_KO & 2) { nleaf = 0; return; }
     constexpr int SL = LEAF_COUNT_MAX;   // lanes per slot
     for (int b = 0; b < nleaf; b += 64 / SL) {
       const int e = b + lane / SL;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
     if (best.full()) U = fminf(U, __uint_as_float(best.td));
   };
 
-  for (int L = Lstart; L > 0; --L) {
+  for (int L = (KNN_KO & 4) ? 0 : Lstart; L > 0; --L) {
     int nnext = 0;
     const int sh = 3 * (L - 1);
     for (int base = 0; base < nfront; base += 8) {
