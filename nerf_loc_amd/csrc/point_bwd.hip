@@ -23,6 +23,9 @@ typedef unsigned int pb_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifdef PB_TRACE
+__device__ unsigned long long pb_trace[256];   // debug (tools/pb_trace.py): cycle counter at every region start of four tiles (block 0, wave 0)
+#endif
 constexpr int PB_NBUF = 4;   // LDS ring slots; chunk c lives in slot c % 4, chunks c+1 .. c+3 are in flight while c is consumed
 
 template <int NRT>
@@ -135,7 +138,10 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   pb_u32x4 frh[GG::RL], frl[GG::RL];   // A-fragment ring, position = (running k-step) % RL
   pb_f32x16 acc[2];                    // accumulator of chunk c = acc[c & 1]: region G accumulates one while the epilogue of G-1 drains the other
   pb_f32x4 raw[4][2];                  // !ATT: input rows in flight: k-step e of the next tile sits in raw[e & 3] until it is split three events later
-  pb_f32x4 qv[4], gov[4], kk[4], vv[4];   // ATT: this lane's 16 dims of the head being worked on: query, d output (per sample), k, v (per row)
+  // ATT: this lane's 16 dims of a head: query, d output (per sample), k, v (per row) — two sets: head h + 1 is in flight (a whole region ahead: the loads are lane = row
+  // gathers with HBM latency; issued half a region ahead they cost 6 000 idle cycles per head) while head h is worked on.  (The allocator finds the second set in the
+  // k-steps of X[1] that the later heads have not written yet.)
+  pb_f32x4 qv[2][4], gov[2][4], kk[2][4], vv[2][4];
   float asc = 0.f, agp = 0.f, amx = 0.f, aee = 0.f, aat = 0.f, ags = 0.f, agsq = 0.f;
   unsigned qoff = 0, gqoff = 0, pn_qoff = 0, pn_gqoff = 0;
   pb_u32x4 mkw[3];                     // the tile's sign bits of forward layers 3, 2, 1 (= way-back layers 0, 1, 2)
@@ -173,23 +179,28 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   };
   // ATT: 13 events per head h (= encode-column region h): 0 the 16 loads | 1-4 scores, softmax, its way back | 5-8 d k / d v -> k-steps 2 h + u / 8 + 2 h + u of X[1] |
   // 9-12 d query (summed over the sample's 8 rows) -> HBM
+  // load l (0..15) of head h.  One at a time between the MFMAs: a burst of lane = row gathers parks the wave at issue
+  // (the CU's address unit takes ~32 cycles per k / v instruction and its four waves issue in step) — 16 back to back cost 5 000 idle cycles per head
+  auto att_load = [&](auto Hc, auto Lc, unsigned qo, unsigned ko) __attribute__((always_inline)) {
+    // order: k quads 0..3 | v quads 0..3 | query | d output — the four quads of a head's k (v) are the four 32-byte quarters of the SAME 128-byte line of every row: issued
+    // next to each other the line is fetched once (32 KB of vector L1 hold one head's k + v lines of the CU's four waves, nothing more)
+    constexpr int h = decltype(Hc)::value, l = decltype(Lc)::value, i = l & 3, w = l < 4 ? 2 : l < 8 ? 3 : l < 12 ? 0 : 1;
+    constexpr unsigned o = 128u * h + 64u * (i >> 1) + 16u * (i & 1);
+    if constexpr (w == 0) qv[h & 1][i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, qo + o, 0, 0));
+    else if constexpr (w == 1) gov[h & 1][i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rGO, qo + o, 0, 0));
+    else if constexpr (w == 2) kk[h & 1][i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, ko + o, 0, 0));
+    else vv[h & 1][i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, ko + 512u + o, 0, 0));
+  };
   auto att_event = [&](auto Hc, auto Ec, unsigned qo, unsigned ko, unsigned gqo) __attribute__((always_inline)) {
     constexpr int h = decltype(Hc)::value, e = decltype(Ec)::value;
     constexpr float itemp = 1.0f / 5.656854249492381f;   // temperature sqrt(d_k) (ibrnet.py:84)
-    if constexpr (e == 0) {
-      pb_static_for<4>([&](auto Ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(Ic)::value;
-        constexpr unsigned o = 128u * h + 64u * (i >> 1) + 16u * (i & 1);
-        qv[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, qo + o, 0, 0));
-        gov[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rGO, qo + o, 0, 0));
-        kk[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, ko + o, 0, 0));
-        vv[i] = __builtin_bit_cast(pb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rIn, ko + 512u + o, 0, 0));
-      });
+    if constexpr (e == 0) {   // (the first tile: all 16 at once)
+      pb_static_for<16>([&](auto Lc) __attribute__((always_inline)) { att_load(Hc, Lc, qo, ko); });
     } else if constexpr (e == 1) {
       float x = 0.f, y = 0.f;
       pb_static_for<16>([&](auto Ic) __attribute__((always_inline)) {
         constexpr int i = decltype(Ic)::value >> 2, c = decltype(Ic)::value & 3;
-        x = fmaf(qv[i][c], kk[i][c], x); y = fmaf(gov[i][c], vv[i][c], y);
+        x = fmaf(qv[h & 1][i][c], kk[h & 1][i][c], x); y = fmaf(gov[h & 1][i][c], vv[h & 1][i][c], y);
       });
       asc = x; agp = y;
     } else if constexpr (e == 2) {
@@ -206,14 +217,14 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
       constexpr int kind = (e - 5) >> 1, u = (e - 5) & 1, ks = (kind ? 8 : 0) + 2 * h + u;
       pb_static_for<4>([&](auto Dc) __attribute__((always_inline)) {
         constexpr int d = decltype(Dc)::value, i = 2 * u + (d >> 1), c0 = 2 * (d & 1);
-        const float v0 = kind ? aat * gov[i][c0] : agsq * qv[i][c0], v1 = kind ? aat * gov[i][c0 + 1] : agsq * qv[i][c0 + 1];
+        const float v0 = kind ? aat * gov[h & 1][i][c0] : agsq * qv[h & 1][i][c0], v1 = kind ? aat * gov[h & 1][i][c0 + 1] : agsq * qv[h & 1][i][c0 + 1];
         const unsigned hw = pb_cvt_pk_bf16(v0, v1);
         Xh[1][ks][d] = hw;
         Xl[1][ks][d] = pb_lo2(v0, v1, hw);
       });
     } else {
       constexpr int i = e - 9;
-      const float x0 = nl_sum8(ags * kk[i][0]) * itemp, x1 = nl_sum8(ags * kk[i][1]) * itemp, x2 = nl_sum8(ags * kk[i][2]) * itemp, x3 = nl_sum8(ags * kk[i][3]) * itemp;
+      const float x0 = nl_sum8(ags * kk[h & 1][i][0]) * itemp, x1 = nl_sum8(ags * kk[h & 1][i][1]) * itemp, x2 = nl_sum8(ags * kk[h & 1][i][2]) * itemp, x3 = nl_sum8(ags * kk[h & 1][i][3]) * itemp;
       __builtin_amdgcn_raw_buffer_store_b128(pb_u32x4{__float_as_uint(x0), __float_as_uint(x1), __float_as_uint(x2), __float_as_uint(x3)}, rGQ,
                                              gqo + 128u * h + 64u * (i >> 1) + 16u * (i & 1), 0, 0);
     }
@@ -281,17 +292,26 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
       constexpr int s = (G - 3 * NRT) * NS + K, T = 4 * NS, e0 = s * EV / T, e1 = (s + 1) * EV / T;
       pb_static_for<e1 - e0>([&](auto Ic) __attribute__((always_inline)) { pro_event(std::integral_constant<int, e0 + decltype(Ic)::value>{}, pn_inoff); });
     }
-    if constexpr (G >= 3 * NRT && ATT) {   // head G - 3 NRT: the loads first, the arithmetic under the region's second half
-      constexpr int h = G - 3 * NRT, H2 = NS / 2;
-      if constexpr (K == 0) {
-        if constexpr (h == 0) set_att_off(pn_tile, pn_inoff, pn_qoff, pn_gqoff);
-        att_event(std::integral_constant<int, h>{}, std::integral_constant<int, 0>{}, pn_qoff, pn_inoff, pn_gqoff);
+    if constexpr (ATT) {   // head h is worked on under encode-column region h; its 16 loads went out one by one under the region before
+      if constexpr (G >= 3 * NRT - 1 && G < 3 * NRT + 3) {
+        constexpr int hl = G - (3 * NRT - 1);   // the head whose loads this region issues
+        if constexpr (K == 0 && hl == 0) set_att_off(pn_tile, pn_inoff, pn_qoff, pn_gqoff);
+        // (in the region's FIRST half: the arithmetic of this head starts half a region into the next one — a whole region of latency cover for the last load)
+        if constexpr (K < NS / 2) {
+          constexpr int l0 = K * 16 / (NS / 2), l1 = (K + 1) * 16 / (NS / 2);
+          pb_static_for<l1 - l0>([&](auto Ic) __attribute__((always_inline)) {
+            att_load(std::integral_constant<int, hl>{}, std::integral_constant<int, l0 + decltype(Ic)::value>{}, pn_qoff, pn_inoff);
+          });
+        }
       }
-      if constexpr (K >= H2) {
-        constexpr int e0 = 1 + (K - H2) * 12 / H2, e1 = 1 + (K - H2 + 1) * 12 / H2;
-        pb_static_for<e1 - e0>([&](auto Ic) __attribute__((always_inline)) {
-          att_event(std::integral_constant<int, h>{}, std::integral_constant<int, e0 + decltype(Ic)::value>{}, pn_qoff, pn_inoff, pn_gqoff);
-        });
+      if constexpr (G >= 3 * NRT) {
+        constexpr int h = G - 3 * NRT, S0 = NS / 2, H2 = NS - S0;
+        if constexpr (K >= S0) {
+          constexpr int e0 = 1 + (K - S0) * 12 / H2, e1 = 1 + (K - S0 + 1) * 12 / H2;
+          pb_static_for<e1 - e0>([&](auto Ic) __attribute__((always_inline)) {
+            att_event(std::integral_constant<int, h>{}, std::integral_constant<int, e0 + decltype(Ic)::value>{}, pn_qoff, pn_inoff, pn_gqoff);
+          });
+        }
       }
     }
     // epilogue of the previous chunk (a layer's last row tile is finished inside the first region of the NEXT layer, which consumes the fragments it produces
@@ -306,8 +326,16 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   };
 
   // ---------------------------------------------------------------- one region = one output row tile accumulated over all K
+  int trace_it = 0;
+  (void)trace_it;
   auto region = [&](auto Gc) __attribute__((always_inline)) {
     constexpr int G = decltype(Gc)::value;
+#ifdef PB_TRACE
+    if (blockIdx.x == 0 && wave == 0 && trace_it < 4) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) pb_trace[trace_it * 64 + G] = t;
+    }
+#endif
     constexpr int L = GG::layer(G), NKS = GG::nks(G), AB = G & 1, CK = GG::cumks(G);
     pb_static_for<NKS>([&](auto Kc) __attribute__((always_inline)) {
       constexpr int ks = decltype(Kc)::value, pos = GG::rpos(CK + ks);
@@ -369,6 +397,13 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
     pn_tile = tile + (int)nwg;   // rows past the end read zero: the last tile prepares a tile that is never computed
     outoff = row_off(tile) * 384u;
     pb_static_for<NC>(region);
+#ifdef PB_TRACE
+    if (blockIdx.x == 0 && wave == 0 && trace_it < 4) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0) pb_trace[trace_it * 64 + NC] = t;
+    }
+    ++trace_it;
+#endif
     tile = pn_tile;
     if (tile >= a.ntiles) break;
   }
@@ -422,6 +457,11 @@ int g_pb_num_cu = 0;
 
 }  // namespace
 
+#ifdef PB_TRACE
+extern "C" __attribute__((visibility("default"))) int nl_debug_pb_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pb_trace), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
+}
+#endif
 bool nl_point_bwd_chain_supported(int W) { return W == 128 || W == 256; }
 size_t nl_point_bwd_stream_bytes(int W) {
   const int NRT = W / 32;
