@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
   using GG = BGeo<NRT>;
   constexpr int NC = GG::NC, SLOT = GG::SLOT;
   __shared__ uint4 lds_all[PB_NBUF * SLOT];
+  // (the ring's upper 64 KB through one opaque base whose offsets fit ds_read's immediate: point_fused2.hip)
+  typedef __attribute__((address_space(3))) uint4 lds_u4;
+  lds_u4* lds_hi = (lds_u4*)lds_all + 4096 + (threadIdx.x & 63);
+  asm volatile("" : "+v"(lds_hi));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31;
   const unsigned nwg = gridDim.x;
@@ -246,7 +250,10 @@ __global__ __launch_bounds__(256, 1) void point_bwd_chain_kernel(const PbArgs a)
     constexpr int G = decltype(Gc)::value, t = decltype(Tc)::value, part = decltype(Pc)::value;
     constexpr int c = t >= GG::nks(G) ? GG::cm(G + 1) : GG::cm(G), ks = t >= GG::nks(G) ? t - GG::nks(G) : t;
     constexpr int pos = GG::rpos(GG::cumks(GG::cm(G)) + t);
-    const pb_u32x4 v = __builtin_bit_cast(pb_u32x4, lds_all[(c % PB_NBUF) * SLOT + (part * GG::nks(c) + ks) * 64 + lane]);
+    constexpr int li = (c % PB_NBUF) * SLOT + (part * GG::nks(c) + ks) * 64;
+    pb_u32x4 v;
+    if constexpr (li >= 4096) v = __builtin_bit_cast(pb_u32x4, lds_hi[li - 4096]);
+    else v = __builtin_bit_cast(pb_u32x4, lds_all[li + lane]);
     if (part == 0) frh[pos] = v; else frl[pos] = v;
   };
 

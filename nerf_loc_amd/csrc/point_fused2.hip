@@ -212,6 +212,12 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // ONE __shared__ object, read through ONE native vector type with compile-time slot indices: hipcc then keeps the alias
   // information that lets SIInsertWaitcnts leave LDS reads alone while LDS-DMA writes are in flight
   __shared__ uint4 lds_all[GG::LDS_U4];
+  // upper 64 KB of the ring through ONE opaque base (every offset fits ds_read's 16-bit immediate): without it the compiler keeps ~60 separate "base + constant"
+  // addresses in AGPRs and re-reads one before every second fragment read (344 of the tile's 1 018 v_accvgpr_read_b32; 8 068 -> 7 565 instructions per tile, kernel -2.3 %).
+  // (Still the same __shared__ object for the alias analysis: the waits around the LDS-DMA writes stay as they were — checked in the ISA.)
+  typedef __attribute__((address_space(3))) uint4 lds_u4;
+  lds_u4* lds_hi = (lds_u4*)lds_all + 4096 + (threadIdx.x & 63);
+  asm volatile("" : "+v"(lds_hi));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31, kk = j & 7;
   const unsigned nwg = gridDim.x;
@@ -473,14 +479,19 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     constexpr int G = decltype(Gc)::value, t = decltype(Tc)::value, part = decltype(Pc)::value;
     constexpr int c = t >= GG::nks(G) ? GG::cm(G + 1) : GG::cm(G), ks = t >= GG::nks(G) ? t - GG::nks(G) : t;
     constexpr int pos = GG::rpos(GG::cumks(GG::cm(G)) + t);
-    const u32x4 v = __builtin_bit_cast(u32x4, lds_all[(c % NBUF) * SLOT + (part * GG::ksi(c) + ks) * 64 + lane]);
+    constexpr int li = (c % NBUF) * SLOT + (part * GG::ksi(c) + ks) * 64;
+    u32x4 v;
+    if constexpr (li >= 4096 && li < 8192) v = __builtin_bit_cast(u32x4, lds_hi[li - 4096]);
+    else v = __builtin_bit_cast(u32x4, lds_all[li + lane]);
     if (part == 0) frh[pos] = v; else frl[pos] = v;
   };
 
   // MX mode: 16 of the 32 fp8 bytes per lane of slab q of chunk c (part 1 of the slot: [slab][w_hi8 lo16 | w_hi8 hi16 | w_lo8 lo16 | w_lo8 hi16][lane]) -> w8[parity][i]
   auto read_w8 = [&](auto Cc, auto Qc, auto Ic) __attribute__((always_inline)) {
     constexpr int c = GG::cm(decltype(Cc)::value), q = decltype(Qc)::value, i = decltype(Ic)::value;
-    w8[q & 1][i] = __builtin_bit_cast(u32x4, lds_all[(c % NBUF) * SLOT + (GG::ksi(c) + 4 * q + i) * 64 + lane]);
+    constexpr int li = (c % NBUF) * SLOT + (GG::ksi(c) + 4 * q + i) * 64;
+    if constexpr (li >= 4096 && li < 8192) w8[q & 1][i] = __builtin_bit_cast(u32x4, lds_hi[li - 4096]);
+    else w8[q & 1][i] = __builtin_bit_cast(u32x4, lds_all[li + lane]);
   };
 
   // ---------------------------------------------------------------- epilogue micro-steps of chunk C, run inside region C+1
