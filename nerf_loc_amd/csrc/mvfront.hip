@@ -131,7 +131,10 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
       float px = cx / zc, py = cy / zc;
       px = fminf(fmaxf(px, -1e6f), 1e6f);
       py = fminf(fmaxf(py, -1e6f), 1e6f);
-      const bool m1 = vact && (px <= (float)vw.Wimg - 1.f) && (px >= 0.f) && (py <= (float)vw.H - 1.f) && (py >= 0.f) && (cz > 0.f);
+      // (the two bounds as SCALAR registers: as hoisted vector registers they were spilled to scratch and reloaded — with a full vmcnt(0) drain — three times per round)
+      const float wm1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)vw.Wimg - 1.f)));
+      const float hm1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)vw.H - 1.f)));
+      const bool m1 = vact && (px <= wm1) && (px >= 0.f) && (py <= hm1) && (py >= 0.f) && (cz > 0.f);
       const unsigned long long bm = __ballot(m1);
       const int cnt1 = __popc((unsigned)(bm >> (16 * s)) & 0xffffu);
       const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
@@ -151,8 +154,9 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
           rgb[c] = fmaf(pl[oi[3]], i3, fmaf(pl[oi[2]], i2, fmaf(pl[oi[1]], i1, pl[oi[0]] * i0)));
         }
       }
-      const float vis = vact ? vis_in[(size_t)vl * N + nn] : 0.f;
-      const float dd = vact ? dd_in[(size_t)vl * N + nn] : 0.f;
+      const unsigned vo = (unsigned)vl * (unsigned)N + (unsigned)nn;   // V N < 2^31 (nl_mv_front_supported): a 32-bit offset from the scalar base, no hoisted 64-bit lane pointer
+      const float vis = vact ? vis_in[vo] : 0.f;
+      const float dd = vact ? dd_in[vo] : 0.f;
       const float vsum = mf_sum16(vis);
       const float wgt = vis / (vsum + 1e-8f);
       vmask = 0;
@@ -172,7 +176,11 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
       float* sl = myslots + (size_t)(s * 16 + v) * MF_SLOT;
       *(float4*)sl = make_float4(__uint_as_float(pack_taps(tf, vw.w, vw.h)), (tf.mn && tf.mw) ? tf.nw : 0.f, (tf.mn && tf.me) ? tf.ne : 0.f, (tf.ms && tf.mw) ? tf.sw : 0.f);
       *(float2*)(sl + 4) = make_float2((tf.ms && tf.me) ? tf.se : 0.f, wgt);
-      if (v == 0) wsumS[wave * 4 + s] = wsum;
+      {   // (the slot's address re-derived per round from an opaque copy of s: hoisted, it was one vector register too many — a scratch reload with a full drain per round)
+        int s_o = s;
+        asm volatile("" : "+v"(s_o));
+        if (v == 0) wsumS[wave * 4 + s_o] = wsum;
+      }
       if (live && vact) *(float4*)(rgbv + ((size_t)n * V + v) * 4) = make_float4(rgb[0], rgb[1], rgb[2], vis);
       if (live && v == 0) valid_s[n] = cnt1 > 1 ? 1 : 0;
       // the nine small columns + bias of out_fc.0 for the wave's four samples: lane = output unit
@@ -275,7 +283,9 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, wa[ks][0]), __builtin_bit_cast(mf_bf16x8, bh), acc, 0, 0, 0);
       }
       const int ng = round * MF_NS + srow;
-      if (ng < N) *(float4*)(t64 + (size_t)ng * 64 + 16 * nt + 4 * kq) = make_float4(nl_elu(acc[0]), nl_elu(acc[1]), nl_elu(acc[2]), nl_elu(acc[3]));
+      // (the round's rows from a SCALAR base + a small lane offset: a hoisted 64-bit lane pointer was the last value this kernel spilled to scratch)
+      float* trow = t64 + (size_t)__builtin_amdgcn_readfirstlane(round * MF_NS) * 64;
+      if (ng < N) *(float4*)(trow + (srow * 64 + 16 * nt + 4 * kq)) = make_float4(nl_elu(acc[0]), nl_elu(acc[1]), nl_elu(acc[2]), nl_elu(acc[3]));
     }
     __syncthreads();   // the staging tile and the partial rows are free again
   }
