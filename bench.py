@@ -49,6 +49,20 @@ def algorithmic_mac_per_sample(W: int, V: int, C: int = 192, K: int = 8) -> floa
     return float(point + attn + mv + unet + heads)
 
 
+def executed_mfma_equiv_mac_per_sample(W: int, V: int, S: int, precision: str, C: int = 192, K: int = 8):
+    """MFMA-equivalent multiply-adds the kernels EXECUTE per sample in a precision mode (one bf16 / fp16 `32x32x16` MAC = 1; a three-term split product = 3; an
+    f16mx product = 2.0: fp16 hi.hi + two MX-FP8 cross terms at twice the rate): (whole step, fused neural-point kernel).  What the kernels multiply differs from
+    the algorithmic count of SURVEY 8(d): the 195 feature columns of base_mlp.0 and rgb_blending_mlp.0 come from per-frame tables, the attention's q-projection and
+    `fc` run once per sample, out_fc.2 is recomputed in both chain kernels, feat_mlp.2 runs per ray.  algorithmic / executed-equivalent = the fraction
+    of the bf16 MFMA peak `roofline.frac` would show with the matrix pipe 100 % busy: the CEILING of the parity mode."""
+    per = {"bf16": 1.0, "bf16x3": 3.0, "f16mx": 3.0, "fp32": 16.0}[precision]     # every GEMM but the fused kernel's wide layers
+    wide = {"f16mx": 2.0}.get(precision, per)                                      # layers 2, 3 and the k / v projections of point_fused2_kernel
+    point = K * (96 * W * per + (2 * W * W + 256 * W) * wide)                       # layer 1 (K = 96: posenc + ray_diff_fc) + layers 2, 3 + k / v
+    unet = 192 * W + 12288 + 12288 + 6144 + 12288 + 6144 + 3 * (W + 32) * W   # the seven convolutions per sample (SURVEY 8d: pooled levels, transposed = 1.5 taps per output)
+    other = (384 * 64 + 2 * 64 * W + W * 128 + 128 * W + W * W + W * 32 + V * (4 * 2 * 32 * 32 + 6 * 32) + unet + C * W / S)
+    return point + other * per, point
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,11 +73,14 @@ def main():
                     help="f16mx (default since round 4): the parity mode with 2.0 instead of 3 MFMA-equivalents per product in the fused neural-point kernel")
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-thread-sweep", action="store_true", help="cpu_baseline: also time 64 rays at 8 and 64 threads (off by default: the driver's run should spend "
+                                                                    "its wall time on the GPU part, VERDICT r4 item 8)")
     ap.add_argument("--no-gradient-step", action="store_true", help="skip the (untimed for the headline) PoseOptimizer-step measurement")
     ap.add_argument("--force-gather", action="store_true", help="run the N>1 collective path on one GPU (single-rank RCCL group): a functional check")
     ap.add_argument("--also", default="bf16x3,bf16,fp32", help="comma list of extra precisions timed after the headline (''=none)")
     ap.add_argument("--early-term-eps", type=float, default=-1.0,
                     help="early-termination compositing threshold (nl_render_opts); default: 1e-5 for c5 (BASELINE names it there), 0 = off otherwise")
+    ap.add_argument("--graph", action="store_true", help="replay batches of <= 1024 rays as a HIP graph (A/B against the eager launch chain; measured: no gain)")
     ap.add_argument("--no-side-stream", action="store_true", help="NL_RENDER_NO_SIDE_STREAM: every kernel on one stream (profiling kernels one at a time)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: BOTH are timed, value = strong)")
@@ -166,7 +183,10 @@ def main():
         zz = B["z"]
         if hier:
             zz, depth_coarse, _ = rnd.hierarchical_depths(B["pix"], B["Kq"], B["pose_q"], B["z"], B["u"], near=cfg.near, far=cfg.far)
-        out = rnd.render_rays(B["o"], B["d"], qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps, side_stream=not args.no_side_stream)
+        # --graph: batches of <= 1024 rays replay as a HIP graph from the second step on (HipRenderer.GRAPH_MAX_RAYS).  Opt-in: measured, the replay is no faster
+        # than the eager launch chain (config 1: 0.397 ms eager, 0.423 ms with the graph's static-buffer copies; a 512-ray shard of config 2: 1.400 / 1.412 ms)
+        out = rnd.render_rays(B["o"], B["d"], qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps, side_stream=not args.no_side_stream,
+                              graph=args.graph)
         if hier:
             out["depth_coarse"] = depth_coarse
         if gather:
@@ -253,8 +273,19 @@ def main():
                      "traffic": hbm_traffic(args.config, args.precision), "scope": "whole render_rays step (all kernels), algorithmic flops SURVEY §8(d)",
                      "flops_per_step": flops_step, "device_ms_per_step": dev_ms / args.steps},
     }
+    ex_all, ex_point = executed_mfma_equiv_mac_per_sample(cfg.W, cfg.V, S, args.precision, cfg.C)
+    diag = rnd.diagnostics()
+    result["roofline"]["parity_mode_ceiling"] = {
+        "whole_step": algorithmic_mac_per_sample(cfg.W, cfg.V, cfg.C) / ex_all,
+        "what": "algorithmic MAC / MFMA-equivalent MAC the kernels execute in this precision mode (3 per split-bf16 product, 2.0 per f16mx product): "
+                "`frac` with the matrix pipe 100 % busy at the 2.4 GHz the peak assumes"}
+    result["roofline"]["clock_GHz_under_load"] = {"point_fused2_kernel": diag["point_kernel_GHz"], "peak_assumes": 2.4,
+                                                  "how": "s_memtime cycles / s_memrealtime of workgroup 0 over the last launch (nl_frame_diagnostics)"}
+    result["conditioning"] = {"attention_logit_absmax": diag["logit_absmax"], "table_absmax": diag["table_absmax"],
+                              "note": "the parity modes are validated to 1e-4 of the CPU oracle up to |logit| ~ 30 (f16mx) / 60 (bf16x3); tools/scale_sweep.py"}
     if launches.value > 0:
         K, F, W = 8, cfg.C + 3, cfg.W
+        result["roofline"]["parity_mode_ceiling"]["dominant_kernel"] = K * (496 + (F + 90) * W + 2 * W * W + 2 * 128 * W + 16384 / K) / ex_point
         mac_alg = K * (496 + (F + 90) * W + 2 * W * W + 2 * 128 * W) + 16384      # a9 ray_diff_fc, a10 base_mlp, k/v projection, a11 attention (SURVEY §8d terms)
         mac_exec = K * (96 * W + 2 * W * W + 256 * W)                               # what the kernel multiplies (feature columns come from the per-frame table T)
         samples_per_launch = R_local * S * args.steps / launches.value
@@ -316,7 +347,7 @@ def main():
         except Exception as e:   # noqa: BLE001
             result["gradient_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights, u_all)
+        result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights, u_all, thread_sweep=args.cpu_thread_sweep)
     # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which a pipe flushes only at exit: every rank pushes it out
     # now, then rank 0 prints the JSON line as the last thing on stdout
     try:
@@ -405,7 +436,7 @@ def hbm_traffic(config: str, precision: str):
     return None
 
 
-def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 18.0):
+def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 12.0, thread_sweep: bool = False):
     """Time the CPU oracle (port of the reference's PyTorch path) on a bounded ray sample of the same workload.
 
     Threads: torch intra-op parallelism saturates around 8-64 threads on this path and collapses beyond (measured on the
@@ -438,7 +469,7 @@ def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 18.0):
         done += n
     # the same path at other thread counts (64 rays each): intra-op parallelism saturates early on this path
     sweep = {}
-    for nt in (8, 64):
+    for nt in ((8, 64) if thread_sweep else ()):
         if nt <= cores and nt != threads:
             torch.set_num_threads(nt)
             run(0, 16, nthreads=nt)

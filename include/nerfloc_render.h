@@ -43,8 +43,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NL_ABI_VERSION 5   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
-                            * reserved fields validated, side stream owned by the nl_frame; 5: NL_PREC_F16MX */
+#define NL_ABI_VERSION 6   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
+                            * reserved fields validated, side stream owned by the nl_frame; 5: NL_PREC_F16MX; 6: nl_frame_diagnostics */
 #define NL_MAX_VIEWS 16
 #define NL_KNN_MAX_K 8
 
@@ -64,8 +64,15 @@ typedef enum nl_precision {
   NL_PREC_F16MX = 3    /* round 4 — parity mode, 2.0 instead of 3 matrix instructions per product in the fused neural-point kernel (the
                         * MFMA-bound kernel): fp16 hi.hi (v_mfma_f32_32x32x16_f16) + the two cross terms hi.lo / lo.hi on gfx950's block-scaled FP8 instruction
                         * (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, power-of-two scales; the cross terms are 2^-11 of a product, so e4m3's 2^-4 leaves 2^-15).
-                        * Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as NL_PREC_BF16X3.  Activations of the
-                        * neural-point MLP beyond fp16's range (65504) saturate instead of overflowing (MODE.FP16_OVFL).                                     */
+                        * Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as NL_PREC_BF16X3.
+                        * RANGE (round 5): the fp8 images of the activations carry a block scale per row and layer, derived in the kernel from a bound the row
+                        * cannot exceed (L1 norms of the layer's weight rows x the row's running maximum; layer 1: max |T| over the frame's table) — no
+                        * activation magnitude saturates or flushes them.  What is left is fp16's own range for the hi part: |activation| < 65504 (beyond it
+                        * the value saturates, MODE.FP16_OVFL, instead of becoming inf) and >= 2^-14 for its full 11 bits.  Validated (tests/test_gpu_parity.py,
+                        * tools/scale_sweep.py): feature maps x 1/64 ... 64 (activations to ~2e3), Student-t (nu = 3) weights, DepthFusionNet maps x 8.
+                        * ACCURACY: a product carries ~2^-16 (NL_PREC_BF16X3: 2^-17, NL_PREC_F32: 2^-24).  On well-conditioned inputs that is 1-2.5e-5 of the
+                        * outputs; where the network amplifies rounding (attention logits of |q.k / sqrt d| >> 10: see nl_frame_diagnostics) every mode's
+                        * distance to the reference grows by the same factor and NL_PREC_F32 is the mode that stays at the reference's own level.          */
 } nl_precision;
 
 typedef struct nl_config {
@@ -181,6 +188,21 @@ size_t nl_frame_bytes(const nl_config* cfg, const nl_frame_desc* desc);
 int nl_frame_create(const nl_config* cfg, const nl_frame_desc* desc, void* frame_mem, size_t frame_bytes,
                     void* stream, nl_frame** out);
 int nl_frame_destroy(nl_frame* frame);
+
+/* Conditioning indicators of what has been rendered against `frame` so far (round 5), copied to HOST memory; synchronises `stream`.
+ *   [NL_DIAG_TABLE_ABSMAX]  max |T| over the per-frame table T = support features x base_mlp.0's feature columns + bias (0 until the first render builds it)
+ *   [NL_DIAG_LOGIT_ABSMAX]  largest |attention logit| (q.k / sqrt d_k, ibrnet.py:28-45) the fused neural-point kernel has scored since nl_frame_create (W = 128 / 256;
+ *                           0 where the staged kernels run).  The softmax over a sample's 8 neighbours turns a logit error e into a weight error ~e, and a split
+ *                           product's logit error is its relative precision x |logit|: at |logit| ~ 100 NL_PREC_F16MX (2^-16) sits ~2e-4 from the fp64 result where
+ *                           it sits 2e-5 at |logit| ~ 1 — and the reference's own fp32 arithmetic moves from 1e-6 to 1e-5.  The host mirror uses it to fall back to
+ *                           a more exact mode (nerf_loc_amd.conditional_nerf: precision_guard).
+ *   [NL_DIAG_POINT_KERNEL_GHZ]  the clock the chip ran the last fused neural-point launch at (the roofline's peak assumes 2.4 GHz; under matrix load it is ~1.7)
+ * n: how many of the NL_DIAG_COUNT values to write. */
+#define NL_DIAG_TABLE_ABSMAX 0
+#define NL_DIAG_LOGIT_ABSMAX 1
+#define NL_DIAG_POINT_KERNEL_GHZ 2   /* shader clock of the last fused neural-point launch (workgroup 0: s_memtime cycles / s_memrealtime): DVFS under matrix load */
+#define NL_DIAG_COUNT 3
+int nl_frame_diagnostics(const nl_frame* frame, float* host_out, int32_t n, void* stream);
 
 /* ---- stages (each is also reachable through nl_render_rays) -------------------------------------- */
 /* a8: exact K nearest support points (squared L2 in the reference's fp32 order, ascending, ties by index). */

@@ -24,7 +24,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16MX = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16mx": PREC_F16MX}
 MAX_VIEWS = 16
 RENDER_NO_SIDE_STREAM = 1   # nl_render_opts.flags
-ABI_VERSION = 5   # include/nerfloc_render.h: NL_ABI_VERSION
+ABI_VERSION = 6   # include/nerfloc_render.h: NL_ABI_VERSION
 
 
 class NlConfig(C.Structure):
@@ -88,6 +88,7 @@ SYMBOLS = [
     ("nl_frame_bytes", _Z, [_CFG, _DESC]),
     ("nl_frame_create", _I, [_CFG, _DESC, _P, _Z, _P, C.POINTER(_P)]),
     ("nl_frame_destroy", _I, [_P]),
+    ("nl_frame_diagnostics", _I, [_P, C.POINTER(C.c_float), C.c_int32, _P]),
     ("nl_knn", _I, [_P, _P, _L, _I, _P, _P, _P]),
     ("nl_sample_points", _I, [_P, _P, _L, _I, _F, _F, _P, _P, _P, _P]),
     ("nl_mv_aggregate_workspace_bytes", _Z, [_CFG, _I, _L]),

@@ -175,7 +175,17 @@ class ConditionalNeRF(nn.Module):
         self.__dict__["_sp_gen"] = self.__dict__.get("_sp_gen", 0) + 1
         self.__dict__["_sp_from_hip"] = False   # set by _build_support_hip: tables this module built itself, without a graph
 
-    def __init__(self, args, activation_func=None, precision: str = "f16mx", device: Optional[str] = None):
+    # Precision guard (round 5).  The split-product modes carry 2^-16 (f16mx) / 2^-17 (bf16x3) per product where the reference's fp32 carries 2^-24.  On
+    # well-conditioned inputs that is 1-2.5e-5 / 8e-6 of the outputs; the one amplifier tools/scale_sweep.py found is the attention over a sample's 8 neighbours:
+    # a logit error is (relative product error) x |logit|, and a softmax over nearly tied neighbours hands it on undamped.  The fused neural-point kernel
+    # reports the largest |logit| it scored (nl_frame_diagnostics); after the FIRST inference batch of every frame the module reads it (one device-to-host
+    # copy per frame, next to a 4-ms per-frame setup) and, if it is beyond the limit its current mode was validated to, re-renders that batch and keeps
+    # rendering the frame in the next more exact mode (f16mx -> bf16x3 -> fp32).  Limits: the |logit| up to which the mode stayed within 1e-4 of the CPU oracle
+    # in the sweep (profiles/r5_scale_sweep.txt).  precision_guard=False switches it off; `guard_events` lists what it did.
+    LOGIT_LIMIT = {"f16mx": 30.0, "bf16x3": 60.0}
+    _SAFER = {"f16mx": "bf16x3", "bf16x3": "fp32", "bf16": "bf16x3"}
+
+    def __init__(self, args, activation_func=None, precision: str = "f16mx", device: Optional[str] = None, precision_guard: bool = True):
         super().__init__()
         self.args = copy.deepcopy(args)
         C, W = args.backbone2d_fpn_dim, args.model_3d_hidden_dim
@@ -211,6 +221,8 @@ class ConditionalNeRF(nn.Module):
         self.proj_layer_3d_fine = nn.Linear(W + F_, args.matcher_hidden_dim)
         # ---- HIP side
         self._precision = precision
+        self.precision_guard = bool(precision_guard)
+        self.guard_events = []
         self._device = device
         self._renderers: Dict[str, HipRenderer] = {}
         self._frame_token: Dict[str, object] = {}
@@ -277,8 +289,26 @@ class ConditionalNeRF(nn.Module):
         if self._frame_token.get(level) != token:
             r.set_frame(data["topk_images"], feat.detach(), vis.detach(), data["topk_Ks"], data["topk_poses"], near, far,
                         {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")})
+            r.set_precision(self._precision)   # (the precision guard may have escalated the previous frame)
             self._frame_token[level] = token
         return r
+
+    def _guarded(self, r: HipRenderer, render):
+        """render() -> outputs; after the first inference batch of a frame: check the conditioning indicator and escalate the precision if needed (see LOGIT_LIMIT)."""
+        out = render()
+        if not self.precision_guard or r.__dict__.get("_guard_gen") == r.state_gen:
+            return out
+        r._guard_gen = r.state_gen
+        amax = r.diagnostics()["logit_absmax"]
+        mode = r.precision
+        while mode in self.LOGIT_LIMIT and amax > self.LOGIT_LIMIT[mode]:
+            mode = self._SAFER[mode]
+        if mode != r.precision:
+            self.guard_events.append({"logit_absmax": amax, "from": r.precision, "to": mode})
+            del self.guard_events[:-64]
+            r.set_precision(mode)
+            out = render()
+        return out
 
     def _vis_featmaps(self, data, graph: bool = False):
         """The DepthFusionNet maps cache (multiview_aggregator.py:29,178).  graph=True (training): the maps must carry their graph to the
@@ -648,13 +678,18 @@ class ConditionalNeRF(nn.Module):
                 u = us[i] if us is not None else torch.rand(R, self.args.render.N_importance, device=o.device)
                 z, dc, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=rn, far=rf, lindisp=bool(self.args.render.lindisp))
                 dcs.append(dc)
-            jobs.append((r, o, d, rays["pose"][:3, 3].detach(), {"z_vals": z, "white_bkgd": bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+            # the query centre is data['pose'] like render_rays' (model.py:472-480 reads the pose of `data`; `rays['pose']` only feeds the hierarchical branch)
+            jobs.append((r, o, d, data["pose"][:3, 3].detach(), {"z_vals": z, "white_bkgd": bool(data.get("white_bkgd", self.args.render.white_bkgd)),
                                                                   "want_feat": bool(self.args.render.render_feature)}))
         self._frame_token = {}   # (the single-frame renderers' tables no longer describe the module's caches)
         outs = render_rays_multi(jobs)
         for o_, dc in zip(outs, dcs):
             o_["depth_coarse"] = dc
         return outs
+
+    def release_multi_pool(self) -> None:
+        """Drop the per-frame renderers `render_rays_frames(list of data dicts)` keeps between calls (their frame tables and workspaces: gigabytes for large batches)."""
+        self.__dict__.pop("_multi_pool", None)
 
     def _render_rays(self, data, rays, u):
         r = self._ensure_frame(data, "fine")
@@ -670,8 +705,11 @@ class ConditionalNeRF(nn.Module):
             # the coarse depths use the RAYS' range like the base samples (model.py:489), not the frame's
             z, depth_coarse, _ = r.hierarchical_depths(rays["pixel_coordinates"], rays["K"], rays["pose"], z, u, near=near, far=far,
                                                        lindisp=bool(self.args.render.lindisp))
-        out = r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
-                            want_feat=bool(self.args.render.render_feature))
+        # (`inference_graphs`: replay small batch shapes as HIP graphs, HipRenderer.render_rays(graph=True).  Off by default: measured on the MI355X box the
+        # replay buys nothing — 256 rays of config 1: 0.391 ms eager, 0.387 ms replayed, and the static-buffer copies around it cost more than that;
+        # the chain is bound by its kernels' own ramp and tail, not by the host's launches — DESIGN.md 5.20)
+        out = self._guarded(r, lambda: r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                                                     want_feat=bool(self.args.render.render_feature), graph=bool(getattr(self, "inference_graphs", False))))
         if depth_coarse is not None:
             out["depth_coarse"] = depth_coarse
         return out

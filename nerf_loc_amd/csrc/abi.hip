@@ -66,7 +66,9 @@ int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale
                            float* blA, int64_t M, int precision, hipStream_t st);
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
-int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false, float* keep_kv = nullptr, unsigned* const* keep_mk = nullptr);
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false, float* keep_kv = nullptr, unsigned* const* keep_mk = nullptr,
+                           const float* tmax = nullptr, unsigned* logit_amax = nullptr, unsigned long long* clk = nullptr);
+int nl_table_absmax(const float* x, size_t n, float* out, hipStream_t st);
 bool nl_point_bwd_chain_supported(int W);
 size_t nl_point_bwd_stream_bytes(int W);
 int nl_pack_point_bwd_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
@@ -118,6 +120,21 @@ int nl_launch_add2d(const float* a, int lda, const float* b, int ldb, float* o, 
 int nl_launch_point_encode_backward(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx,
                                     const float* sp_xyz, const float* sp_dir, const float* rd_w, float inv_span, const float* gX, int ldg, float* g_xyz,
                                     float* g_dir, float* tr, hipStream_t st);
+
+// CU count for persistent kernels, per device id (common.h)
+int nl_persistent_cus() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return NL_ERR_HIP;
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 64 && cus[dev] > 0) return cus[dev];
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
+  const int n = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+  if (dev < 64) cus[dev] = n;
+  return n;
+}
 
 namespace {
 
@@ -721,6 +738,8 @@ int ensure_ptt(const Ctx& x, const nl_frame* fc) {
     NL_TRY(run_gemm(x32, G_PTT, &s, 1, f->M, f->ptt, W, NL_ACT_NONE));
   }
   NL_CHECK_HIP(hipMemcpyAsync(f->ptt + (size_t)f->M * W, x.pk + x.L.bias[G_PTT], sizeof(float) * W, hipMemcpyDeviceToDevice, x.st));
+  // max |T| (bias row included): what the f16mx kernel bounds base_mlp.0's outputs with; kept in the slack behind the per-view matrices (float 248 of that 1-KB block)
+  NL_TRY(nl_table_absmax(f->ptt, (size_t)(f->M + 1) * W, f->views_dev + 248, x.st));
   f->ptt_for = (const void*)x.pk; f->ptt_gen = gen;
   return NL_OK;
 }
@@ -815,7 +834,9 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     const bool use_v1 = dbg_switch("NERFLOC_POINT_V1");
     int rc2 = NL_ERR_UNSUPPORTED;
-    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st, mx);
+    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st, mx, nullptr, nullptr, f->views_dev + 248,
+                                                                                                      reinterpret_cast<unsigned*>(f->views_dev + 249),
+                                                                                                      reinterpret_cast<unsigned long long*>(f->views_dev + 250));
     if (rc2 == NL_ERR_UNSUPPORTED) rc2 = nl_launch_point_fused(a, W, x.c->precision, x.st);   // (e.g. more rows than 32-bit buffer offsets reach)
     NL_TRY(rc2);
     if (pe1) NL_CHECK_HIP(hipEventRecord(pe1, x.st));
@@ -1885,6 +1906,8 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
       memcpy(f->views_host + 192 + 3 * v, d->cam_centers + 3 * v, 12);
     }
     if (rc == NL_OK && hipMemcpyAsync(f->views_dev, f->views_host, sizeof(f->views_host), hipMemcpyHostToDevice, st) != hipSuccess) rc = NL_ERR_HIP;
+    // the 16 floats of slack behind the matrices hold the frame's diagnostics (nl_frame_diagnostics): [248] max |T|, [249] max |attention logit|
+    if (rc == NL_OK && hipMemsetAsync(f->views_dev + 240, 0, 64, st) != hipSuccess) rc = NL_ERR_HIP;
   }
   if (rc != NL_OK) { delete f; return rc; }
   // the side stream and its two events (see nl_frame): failure to create them only disables the fork
@@ -1903,6 +1926,17 @@ int nl_frame_destroy(nl_frame* f) {
   if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
   if (f->ev_join) (void)hipEventDestroy(f->ev_join);
   delete f;
+  return NL_OK;
+}
+
+int nl_frame_diagnostics(const nl_frame* f, float* host_out, int32_t n, void* stream) {
+  if (!f || !host_out || n < 1) return NL_ERR_BAD_ARG;
+  struct { float tmax, lmax; unsigned long long cyc, ref; } tmp = {0.f, 0.f, 0ull, 0ull};   // floats 248, 249; two 64-bit counters at floats 250 .. 253
+  static_assert(sizeof(tmp) == 24, "diagnostics block");
+  NL_CHECK_HIP(hipMemcpyAsync(&tmp, f->views_dev + 248, sizeof(tmp), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  NL_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  const float vals[NL_DIAG_COUNT] = {tmp.tmax, tmp.lmax, tmp.ref ? (float)((double)tmp.cyc / ((double)tmp.ref * 10.0)) : 0.f};   // cycles per ns = GHz
+  for (int i = 0; i < n; ++i) host_out[i] = i < NL_DIAG_COUNT ? vals[i] : 0.f;
   return NL_OK;
 }
 
@@ -2399,8 +2433,11 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
 
 // ---- several frames per call: fork / join over library-owned streams -----------------------------------------------------------------------
 namespace {
-struct MultiPool { std::mutex mu; std::vector<hipStream_t> st; std::vector<hipEvent_t> ev; hipEvent_t fork = nullptr; };
-MultiPool g_multi;
+// One pool of lane streams / events PER DEVICE (keyed by hipGetDevice(): streams and events belong to the device that was current when they were
+// created — a process that renders on cuda:0 and later on cuda:1 must not launch cuda:1's work on cuda:0's streams)
+struct MultiPool { std::vector<hipStream_t> st; std::vector<hipEvent_t> ev; hipEvent_t fork = nullptr; };
+std::mutex g_multi_mu;
+std::unordered_map<int, MultiPool> g_multi;
 }  // namespace
 
 int nl_render_rays_multi(const nl_config* cfg, const void* packed, const nl_render_job* jobs, int32_t njobs, int32_t white, void* stream) {
@@ -2418,23 +2455,33 @@ int nl_render_rays_multi(const nl_config* cfg, const void* packed, const nl_rend
     if (l < 0) { l = (int)lanes.size(); lanes.push_back(jobs[i].frame); }
     lane_of[i] = l;
   }
-  std::lock_guard<std::mutex> lk(g_multi.mu);
-  while (g_multi.st.size() < lanes.size()) {
+  // jobs on DIFFERENT lanes run concurrently: their workspaces must not overlap (jobs of one lane run one after the other and may share one)
+  for (int i = 0; i < njobs; ++i)
+    for (int k = i + 1; k < njobs; ++k) {
+      if (lane_of[i] == lane_of[k]) continue;
+      const char *a0 = (const char*)jobs[i].ws, *a1 = a0 + jobs[i].ws_bytes, *b0 = (const char*)jobs[k].ws, *b1 = b0 + jobs[k].ws_bytes;
+      if (a0 < b1 && b0 < a1) return NL_ERR_BAD_ARG;
+    }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NL_ERR_HIP;
+  std::lock_guard<std::mutex> lk(g_multi_mu);
+  MultiPool& mp = g_multi[dev];
+  while (mp.st.size() < lanes.size()) {
     hipStream_t s; hipEvent_t e;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return NL_ERR_HIP;
-    g_multi.st.push_back(s); g_multi.ev.push_back(e);
+    mp.st.push_back(s); mp.ev.push_back(e);
   }
-  if (!g_multi.fork && hipEventCreateWithFlags(&g_multi.fork, hipEventDisableTiming) != hipSuccess) return NL_ERR_HIP;
+  if (!mp.fork && hipEventCreateWithFlags(&mp.fork, hipEventDisableTiming) != hipSuccess) return NL_ERR_HIP;
   hipStream_t main = (hipStream_t)stream;
-  NL_CHECK_HIP(hipEventRecord(g_multi.fork, main));
-  for (size_t k = 0; k < lanes.size(); ++k) NL_CHECK_HIP(hipStreamWaitEvent(g_multi.st[k], g_multi.fork, 0));
+  NL_CHECK_HIP(hipEventRecord(mp.fork, main));
+  for (size_t k = 0; k < lanes.size(); ++k) NL_CHECK_HIP(hipStreamWaitEvent(mp.st[k], mp.fork, 0));
   int rc = NL_OK;
   for (int i = 0; i < njobs && rc == NL_OK; ++i)
     rc = nl_render_rays_ex(cfg, packed, jobs[i].frame, jobs[i].query_center, jobs[i].rays_o, jobs[i].rays_d, jobs[i].z_vals, jobs[i].R, white, jobs[i].out,
-                           jobs[i].ws, jobs[i].ws_bytes, g_multi.st[lane_of[i]], jobs[i].opts);
+                           jobs[i].ws, jobs[i].ws_bytes, mp.st[lane_of[i]], jobs[i].opts);
   // join unconditionally: whatever was enqueued must be ordered before the caller's next work (and an active capture must stay well-formed)
   for (size_t k = 0; k < lanes.size(); ++k) {
-    if (hipEventRecord(g_multi.ev[k], g_multi.st[k]) != hipSuccess || hipStreamWaitEvent(main, g_multi.ev[k], 0) != hipSuccess) rc = rc == NL_OK ? NL_ERR_HIP : rc;
+    if (hipEventRecord(mp.ev[k], mp.st[k]) != hipSuccess || hipStreamWaitEvent(main, mp.ev[k], 0) != hipSuccess) rc = rc == NL_OK ? NL_ERR_HIP : rc;
   }
   return rc;
 }

@@ -20,6 +20,9 @@
   } while (0)
 
 static inline size_t nl_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// Workgroups of a persistent kernel on the CURRENT device: its CU count rounded down to a multiple of the 8 XCDs (>= 8); cached per device id
+// (abi.hip) — a process may drive several GPUs through several HipRenderers.  < 0: NL_ERR_HIP
+int nl_persistent_cus();
 static inline int64_t nl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------ activations (match torch fp32 CPU ops)

@@ -257,7 +257,10 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
       for (int j = 0; j < CPL; ++j) {
         if (!lact) break;
         const float m = a1[s][j];
-        const float vr = a2[s][j] - m * m * (2.f - Ws);   // sum w (x - m)^2 = sum w x^2 - m^2 (2 - sum w)
+        // sum w (x - m)^2 = sum w x^2 - m^2 (2 - sum w).  One pass: its absolute error is ~2e-7 (m^2 + var) where the reference's two-pass form (ibrnet.py:8-12) has
+        // ~1e-7 var — below the split product that consumes it (1e-5 |m|) for |m| < 50; the difference can come out a rounding error below zero where the
+        // views agree exactly (var = 0): clamped, as the two-pass value is a sum of squares (tests: the "+off4" rows of tools/scale_sweep.py)
+        const float vr = fmaxf(a2[s][j] - m * m * (2.f - Ws), 0.f);
         const __bf16 mh = (__bf16)m, vh = (__bf16)vr;
         const __bf16 ml = (__bf16)(m - (float)mh), vl2 = (__bf16)(vr - (float)vh);
         const int k = CPL * lane + j;
@@ -291,8 +294,6 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
   }
 }
 
-int g_mf_cus = 0;
-
 }  // namespace
 
 size_t nl_mv_front_pack_bytes() { return (size_t)4 * MF_KS * 2 * 64 * 16 + 64 * 12 * 4; }
@@ -310,12 +311,8 @@ bool nl_mv_front_supported(int C, int V, int64_t N) { return C == MF_C && V >= 1
 int nl_launch_mv_front(const NlViews& vw, const float* viewsdev, const float* images, const float* feat, const float* xyz, int64_t N, const float* vis_in,
                        const float* dd_in, const void* pack, float* t64, int* valid_s, float* rgbv, hipStream_t st) {
   if (N <= 0) return NL_OK;
-  if (g_mf_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
-    g_mf_cus = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-  }
+  const int g_mf_cus = nl_persistent_cus();
+  if (g_mf_cus < 0) return g_mf_cus;
   // (per device, and the call is a table look-up: set every time rather than remembered per process)
   if (hipFuncSetAttribute((const void*)mv_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES) != hipSuccess) return NL_ERR_HIP;
   const int nrounds = (int)nl_cdiv(N, MF_NS);

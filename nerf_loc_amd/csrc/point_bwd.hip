@@ -460,7 +460,6 @@ __global__ void pack_point_bwd_stream_kernel(const float* __restrict__ w1, const
   out[base + (long long)nks * 512 + in_part] = pb_f2bf(v - __uint_as_float(((unsigned int)h) << 16));
 }
 
-int g_pb_num_cu = 0;
 
 }  // namespace
 
@@ -490,12 +489,8 @@ int nl_launch_point_bwd_chain(const float* gkv, const unsigned* const* mk, const
                               const float* kv, const float* go, float* gq) {
   if (NK <= 0) return NL_OK;
   if (!nl_point_bwd_chain_supported(W) || NK * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-  if (g_pb_num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
-    g_pb_num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-  }
+  const int g_pb_num_cu = nl_persistent_cus();
+  if (g_pb_num_cu < 0) return g_pb_num_cu;
   PbArgs a;
   memset(&a, 0, sizeof(a));
   const bool att = gkv == nullptr;

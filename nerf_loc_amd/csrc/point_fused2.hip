@@ -75,7 +75,8 @@ struct Geo {
   static constexpr int RES_BIAS = RES_RD + 2 * PARTS * 64;   // resident: biases in accumulator order, floats [rd1 32 | rd2 32 | L2 W | L3 W]
   static constexpr int RES_ATT = RES_BIAS + (64 + 2 * W) / 4;   // attention weights [wave][head][32 rows] floats (wave-private)
   static constexpr int RES_SC = RES_ATT + 4 * 4 * 32 / 4;   // MX mode: E8M0 scale bytes of the chunks' fp8 weight images, ints [NC][2] = {w_hi8, w_lo8}
-  static constexpr int LDS_U4 = RES_SC + (2 * NC + 3) / 4;
+  static constexpr int RES_BND = RES_SC + (2 * NC + 3) / 4;   // MX mode: 8 floats — the bounds the activation block scales are derived from (pf2_mx_bounds_kernel)
+  static constexpr int LDS_U4 = RES_BND + 2;
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
   // (KEEP: + 4 row stores of a k head / 4 x 4 dword stores of a v head: the rows nl_attn_backward reads)
   static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 10 : 10) + (KEEP ? 4 : 0); }
@@ -136,17 +137,22 @@ __device__ __forceinline__ unsigned lrelu_hi2_f16(float& v0, float& v1) {
       : "=&v"(hi), "+v"(v0), "+v"(v1), "=&v"(t0), "=&v"(t1));
   return hi;
 }
+// sc_hi / sc_lo: the lane's (= the row's) power-of-two block scales of the two images (both conversions DIVIDE by their scale operand)
 template <int HALF>
-__device__ __forceinline__ void mx_bytes2(float v0, float v1, unsigned hi, unsigned& h8, unsigned& l8, float sc_lo) {
+__device__ __forceinline__ void mx_bytes2(float v0, float v1, unsigned hi, unsigned& h8, unsigned& l8, float sc_hi, float sc_lo) {
   float t0, t1;
   if (HALF == 0)
     asm("v_fma_mix_f32 %2, %6, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_scalef32_pk_fp8_f16 %0, %6, 1.0\n\tv_cvt_scalef32_pk_fp8_f32 %1, %2, %3, %7"
-        : "+v"(h8), "+v"(l8), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi), "v"(sc_lo));
+        "v_cvt_scalef32_pk_fp8_f16 %0, %6, %8\n\tv_cvt_scalef32_pk_fp8_f32 %1, %2, %3, %7"
+        : "+v"(h8), "+v"(l8), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi), "v"(sc_lo), "v"(sc_hi));
   else
     asm("v_fma_mix_f32 %2, %6, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_scalef32_pk_fp8_f16 %0, %6, 1.0 op_sel:[0,0,1]\n\tv_cvt_scalef32_pk_fp8_f32 %1, %2, %3, %7 op_sel:[0,0,0,1]"
-        : "+v"(h8), "+v"(l8), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi), "v"(sc_lo));
+        "v_cvt_scalef32_pk_fp8_f16 %0, %6, %8 op_sel:[0,0,1]\n\tv_cvt_scalef32_pk_fp8_f32 %1, %2, %3, %7 op_sel:[0,0,0,1]"
+        : "+v"(h8), "+v"(l8), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi), "v"(sc_lo), "v"(sc_hi));
+}
+// running row maximum of |activation| (MX mode: what the next layer's block scale is bounded from)
+__device__ __forceinline__ void amax2(float& m, float v0, float v1) {
+  asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v0), "v"(v1));
 }
 
 // hi/lo split of a pair: hi = bf16(v), lo = bf16(v - float(hi))
@@ -189,7 +195,10 @@ __device__ __forceinline__ void sincos_d(double x, double& s, double& c) {
   c = ((k + 1) & 2) ? -cc : cc;
 }
 
-struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; unsigned dir_one; int N, M; float inv_span; int ntiles; unsigned t_bytes; };
+struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; unsigned dir_one; int N, M; float inv_span; int ntiles; unsigned t_bytes;
+                    const float* tmax;      // MX mode: max |T| over the frame's table (one float, written by nl_table_absmax), or null (= 0)
+                    unsigned* logit_amax;
+                    unsigned long long* clk; };   // optional: [shader cycles, 100-MHz reference ticks] workgroup 0 spent in this launch (bench.py: the clock under load)   // optional: running maximum of |attention logit| (q.k / sqrt d_k) as float bits, atomicMax'ed once per wave (nl_frame_diagnostics)
 
 // MX (with X3): layer 1 stays three-term split-bf16 (K = 96, issue-bound anyway); layers 2, 3 and the k / v projections multiply as
 // fp16 hi.hi + fp8(lo).fp8(hi) + fp8(hi).fp8(lo): per K = 64 slab 4 x v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 instead of 12 bf16 MFMAs.
@@ -223,13 +232,14 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   const unsigned nwg = gridDim.x;
   int tile = (int)nl_xcd_block();
   if (tile >= sc.ntiles) return;
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();   // (s_memtime: shader clock; s_memrealtime: 100 MHz)
 
   // ---------------------------------------------------------------- resident block: ray_diff_fc fragments + bias tables
   {
     const uint4* src = p_wstream + (size_t)GG::STREAM_KB * 64;
     for (int i = tid; i < 2 * PARTS * 64; i += 256) lds_all[GG::RES_RD + i] = src[(i / (PARTS * 64)) * 128 + i % (PARTS * 64)];
     for (int i = tid; i < (64 + 2 * W) / 4; i += 256) lds_all[GG::RES_BIAS + i] = src[256 + i];
-    if (MX) for (int i = tid; i < (2 * NC + 3) / 4; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];
+    if (MX) for (int i = tid; i < (2 * NC + 3) / 4 + 2; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];   // + the bounds block
   }
   __syncthreads();
 
@@ -277,7 +287,37 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   unsigned X8[2][NRT / 2][2][8];
   u32x4 w8[2][4];   // fp8 A operands of a slab, double-buffered by slab parity: [0..1] = w_hi8 (32 bytes per lane), [2..3] = w_lo8
   const int* ssc = reinterpret_cast<const int*>(lds_all + GG::RES_SC);
-  const float sc_lo = 0.00048828125f;   // 2^-11
+  // MX mode, round 5: the activations' fp8 images carry a block scale PER ROW AND LAYER instead of the constants 1 / 2^-11 (whose window was |a| = 2^-6 ... 448:
+  // beyond it the cross terms saturated and the product fell back to single-fp16 accuracy — tools/scale_sweep.py found it with the feature maps x 8).  The scale of
+  // layer L's output rows is fixed BEFORE the layer runs, from a bound that cannot be exceeded: |out| <= max_c ||w_c||_1 . max|in| + max|b| with max|in| the row's
+  // running maximum over the previous layer's outputs (one v_max3 per finished pair), layer 1 from max|T| over the frame's table + the L1 norms of its
+  // positional-encoding / ray-difference columns.  The bound is ~50x loose, which e4m3's 15 binades absorb (values land at <= 256 of 448; what falls below
+  // the normal range is < 0.4 % of the row's largest value).  xs_hi / xs_lo: the floats the conversions divide by, xs_e8h / xs_e8l: the E8M0 bytes the matrix
+  // instruction reads for the lane's row (both halves of a row hold the same values), indexed by the ping-pong buffer the rows live in.
+  float xs_hi[2] = {1.f, 1.f}, xs_lo[2] = {0.00048828125f, 0.00048828125f};
+  int xs_e8h[2] = {127, 127}, xs_e8l[2] = {116, 116};
+  float amax = 0.f, cur_b1 = 0.f, pn_b1 = 0.f;
+  float lmax = 0.f;   // largest |attention logit| this lane has scored: the softmax over nearly tied neighbours turns a logit error e into a weight error ~e, and the
+                      // logit error is (relative product error) x |logit| — the conditioning indicator nl_frame_diagnostics reports
+  float bnd_c1a = 0.f, bnd_c1x = 0.f, bnd_B2 = 0.f, bnd_bm2 = 0.f, bnd_B3 = 0.f, bnd_bm3 = 0.f, bnd_t = 0.f;
+  if constexpr (MX) {
+    const float* bf = reinterpret_cast<const float*>(lds_all + GG::RES_BND);
+    auto uni = [](float v) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    bnd_c1a = uni(bf[0]); bnd_c1x = uni(bf[1]); bnd_B2 = uni(bf[2]); bnd_bm2 = uni(bf[3]); bnd_B3 = uni(bf[4]); bnd_bm3 = uni(bf[5]);
+    bnd_t = sc.tmax ? uni(*sc.tmax) : 0.f;
+  }
+  // bound (>= the largest |value| of the lane's row) -> the scales of buffer `buf`: 2^(e - 8) with bound < 2^e, i.e. bound / scale < 256
+  auto set_scale = [&](auto Bc, float bound) __attribute__((always_inline)) {
+    constexpr int buf = decltype(Bc)::value;
+    int eb = __builtin_amdgcn_frexp_expf(bound) + 119;
+    eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);
+    xs_hi[buf] = __builtin_bit_cast(float, eb << 23); xs_lo[buf] = __builtin_bit_cast(float, (eb - 11) << 23);
+    xs_e8h[buf] = eb; xs_e8l[buf] = eb - 11;
+  };
+  auto row_amax = [&]() __attribute__((always_inline)) {   // both halves of a row: lane ^ 32 holds the other 16 channels of every row tile
+    const float o = __shfl_xor(amax, 32, 64);
+    return fmaxf(amax, o);
+  };
   unsigned Ph[GG::KS1][4], Pl[GG::KS1][4];
   u32x4 frh[GG::RL], frl[GG::RL];         // A-fragment ring, position = (running k-step) % RL
   // accumulator of chunk c = acc[c & 3].  Four, because the accumulator is INITIALISED by loads that must be in flight early:
@@ -382,6 +422,11 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         poff[0] = (pq[0] - pp[0]) * sc.inv_span; poff[1] = (pq[1] - pp[1]) * sc.inv_span; poff[2] = (pq[2] - pp[2]) * sc.inv_span;
         prd[0] = pdv[0] - pnd[0]; prd[1] = pdv[1] - pnd[1]; prd[2] = pdv[2] - pnd[2];
         prd[3] = pdv[0] * pnd[0] + pdv[1] * pnd[1] + pdv[2] * pnd[2];
+        if constexpr (MX) {   // |base_mlp.0 row| <= max|T| + sum |w| over the sin / cos / ray-difference columns + sum |w| over the raw-offset columns x max |offset|
+          float mo = fabsf(poff[0]);
+          amax2(mo, poff[1], poff[2]);
+          pn_b1 = fmaf(bnd_c1x, mo, bnd_t + bnd_c1a);
+        }
       } else if constexpr (C == 1) {
         pq[0] = sqrtf(prd[0] * prd[0] + prd[1] * prd[1] + prd[2] * prd[2]) + 1e-8f;   // pq[0] is free now: the norm
       } else if constexpr (C == 2) { prd[0] /= pq[0]; prd[1] /= pq[0]; }
@@ -506,10 +551,17 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       constexpr int fo = 2 * RT + (p >> 2), d = p & 3;
       if constexpr (MX) {
         if constexpr (sub == 0) {
+          if constexpr (RT == 0 && p == 0) {   // the scales of this layer's output rows (see xs_hi): fixed before its first row tile is converted
+            if constexpr (L == 0) set_scale(std::integral_constant<int, 0>{}, cur_b1);
+            else if constexpr (L == 1) set_scale(std::integral_constant<int, 1>{}, fmaf(bnd_B2, row_amax(), bnd_bm2));
+            else set_scale(std::integral_constant<int, 0>{}, fmaf(bnd_B3, row_amax(), bnd_bm3));
+            amax = 0.f;
+          }
           ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
           ehi = lrelu_hi2_f16(ev0, ev1);
           Xh[out][fo][d] = ehi;
-        } else mx_bytes2<d & 1>(ev0, ev1, ehi, X8[out][fo >> 2][0][2 * (fo & 3) + (d >> 1)], X8[out][fo >> 2][1][2 * (fo & 3) + (d >> 1)], sc_lo);
+          if constexpr (L < 2) amax2(amax, ev0, ev1);
+        } else mx_bytes2<d & 1>(ev0, ev1, ehi, X8[out][fo >> 2][0][2 * (fo & 3) + (d >> 1)], X8[out][fo >> 2][1][2 * (fo & 3) + (d >> 1)], xs_hi[out], xs_lo[out]);
       } else if constexpr (sub == 0) {
         ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
         ehi = F16 ? lrelu_hi2_f16(ev0, ev1) : lrelu_hi2(ev0, ev1);
@@ -533,6 +585,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       } else if constexpr (E == 4) {
         ap += __shfl_xor(ap, 32, 64);
         ap *= 1.0f / 5.656854249492381f;   // temperature sqrt(d_k) (ibrnet.py:84)
+        lmax = fmaxf(lmax, fabsf(ap));
       } else if constexpr (E == 5) amx = nl_max8(ap);
       else if constexpr (E == 6) aee = expf(ap - amx);
       else if constexpr (E == 7) ase = nl_sum8(aee);
@@ -673,7 +726,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         // the two cross terms: w_hi8 x a_lo8 (block scale 2^-11 on the activations' side), w_lo8 x a_hi8 (the weights' lo image carries its own scale)
         {
           const i32x8 wa = cat8(w8[q & 1][0], w8[q & 1][1]), xb = frag8(X8[IN][q][1]);
-          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], 116, swh) : mfma_8(wa, xb, acc[AB], swh, 116);
+          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], xs_e8l[IN], swh) : mfma_8(wa, xb, acc[AB], swh, xs_e8l[IN]);
           if constexpr (q + 1 < NSL) {
             read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 0>{});
             read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 1>{});
@@ -687,7 +740,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         }
         {
           const i32x8 wa = cat8(w8[q & 1][2], w8[q & 1][3]), xb = frag8(X8[IN][q][0]);
-          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], 127, swl) : mfma_8(wa, xb, acc[AB], swl, 127);
+          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], xs_e8h[IN], swl) : mfma_8(wa, xb, acc[AB], swl, xs_e8h[IN]);
           if constexpr (q + 1 < NSL) {
             read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2>{});
             read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 3>{});
@@ -761,7 +814,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     static_for<GG::ppw(decltype(Cc)::value)>([&](auto Ic) __attribute__((always_inline)) { dma_piece(Cc, Ic); });
   });
   static_for<NPRO>(pro_step);   // the first tile's prologue, back to back
-  toff = pn_toff; qoff = pn_qoff; ooff_cur = pn_ooff;
+  toff = pn_toff; qoff = pn_qoff; ooff_cur = pn_ooff; cur_b1 = pn_b1;
   kvtile = ((unsigned)tile * 128u + (unsigned)wave * 32u) * 1024u; kvrow = kvtile + (unsigned)j * 1024u;
   load_T(std::integral_constant<int, 0>{}, toff); load_T(std::integral_constant<int, 1>{}, toff);
   wait_vmcnt<GG::ppw(1) + GG::ppw(2)>();   // conservative: the prologue's own loads are younger than every piece
@@ -783,7 +836,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     }
     ++trace_it;
 #endif
-    ooff_prev = ooff_cur; ooff_cur = pn_ooff; toff = pn_toff; qoff = pn_qoff;
+    ooff_prev = ooff_cur; ooff_cur = pn_ooff; toff = pn_toff; qoff = pn_qoff; cur_b1 = pn_b1;
     tile_prev = tile; kvtile_prev = kvtile;
     tile = pn_tile;
     kvtile = ((unsigned)tile * 128u + (unsigned)wave * 32u) * 1024u; kvrow = kvtile + (unsigned)j * 1024u;
@@ -792,6 +845,11 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // the last v head of the last tile
   static_for<GG::epi_steps(NC - 1)>([&](auto Ec) __attribute__((always_inline)) { epi_step(std::integral_constant<int, NC - 1>{}, Ec, std::integral_constant<bool, true>{}); });
   wait_vmcnt<0>();   // LDS-DMA prefetched for a tile that does not exist must land before the LDS is handed to another workgroup
+  if (sc.clk && blockIdx.x == 0 && tid == 0) { sc.clk[0] = __builtin_readcyclecounter() - clk_c0; sc.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
+  if (sc.logit_amax) {
+    const float m = wave_max(lmax);
+    if (lane == 0 && m == m) atomicMax(sc.logit_amax, __float_as_uint(m));   // (non-negative floats order like their bit patterns; NaN stays out)
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- packing
@@ -860,6 +918,60 @@ __global__ void pf2_mx_scale_kernel(const float* __restrict__ w2, const float* _
     e = e < -100 ? -100 : (e > 100 ? 100 : e);
     sc[2 * c + threadIdx.x] = 127 + e;
   }
+}
+
+// MX mode: the constants the activation block scales are bounded from (point_fused2_kernel: xs_hi), 8 floats behind the chunks' scale bytes:
+//   [0] c1a = max_c (sum |W1[c, sin / cos columns]| + r1 . sum |W1[c, ray-difference columns]|),  r1 >= |ray_diff_fc output| (its inputs are unit-vector
+//       components and a cosine: |.| <= 1; LeakyReLU does not increase a magnitude)
+//   [1] c1x = max_c sum |W1[c, the three raw-offset columns]|      [2] B2 = max_c ||W2[c, :]||_1   [3] max |b2|   [4] B3   [5] max |b3|
+__global__ void pf2_mx_bounds_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ b2,
+                                     const float* __restrict__ b3, const float* __restrict__ rd_w, float* __restrict__ out, int W, int F) {
+  __shared__ float red[6][256];
+  __shared__ float s_r1;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    float hmax = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      float a = fabsf(rd_w[64 + i]);
+      for (int jj = 0; jj < 4; ++jj) a += fabsf(rd_w[i * 4 + jj]);
+      hmax = fmaxf(hmax, a);
+    }
+    float r1 = 0.f;
+    for (int o = 0; o < 27; ++o) {
+      float a = 0.f;
+      for (int i = 0; i < 16; ++i) a += fabsf(rd_w[80 + o * 16 + i]);
+      r1 = fmaxf(r1, a * hmax + fabsf(rd_w[80 + 432 + o]));
+    }
+    s_r1 = r1 * 1.01f;
+  }
+  __syncthreads();
+  float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = t; c < W; c += 256) {
+    const float* r = w1 + (size_t)c * (F + 90);
+    float a = 0.f, x = 0.f, e = 0.f;
+    for (int jj = 0; jj < 3; ++jj) x += fabsf(r[F + jj]);
+    for (int jj = 3; jj < 63; ++jj) a += fabsf(r[F + jj]);
+    for (int jj = 63; jj < 90; ++jj) e += fabsf(r[F + jj]);
+    m[0] = fmaxf(m[0], a + e * s_r1); m[1] = fmaxf(m[1], x);
+    float n2 = 0.f, n3 = 0.f;
+    for (int k = 0; k < W; ++k) { n2 += fabsf(w2[(size_t)c * W + k]); n3 += fabsf(w3[(size_t)c * W + k]); }
+    m[2] = fmaxf(m[2], n2); m[3] = fmaxf(m[3], fabsf(b2[c])); m[4] = fmaxf(m[4], n3); m[5] = fmaxf(m[5], fabsf(b3[c]));
+  }
+  for (int i = 0; i < 6; ++i) red[i][t] = m[i];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) for (int i = 0; i < 6; ++i) red[i][t] = fmaxf(red[i][t], red[i][t + st]);
+    __syncthreads();
+  }
+  if (t < 8) out[t] = t < 6 ? red[t][0] * 1.0001f : 0.f;
+}
+
+// max |x| over n floats -> *out (as a float; *out must be zeroed first: non-negative floats order like their bit patterns)
+__global__ void pf2_absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
 __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
@@ -952,8 +1064,6 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
   }
 }
 
-int g_num_cu = 0;
-
 }  // namespace
 
 size_t nl_point_stream2_bytes(int W) {
@@ -975,6 +1085,22 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
   hipLaunchKernelGGL(pack_point_stream2_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv, b2, b3, rd_w,
                      (unsigned short*)out, NRT, F, mx, mx_scratch);
   NL_LAUNCH_CHECK();
+  if (mx == 1) {   // the bounds block: behind the resident block's ray_diff_fc fragments (4 KB), bias tables and scale bytes (padded to 16 B)
+    const int NC = 3 * NRT + 8;
+    float* bnd = reinterpret_cast<float*>((char*)out + (size_t)2 * total * 2 + 4096 + (size_t)(64 + 2 * W) * 4 + (size_t)((2 * NC + 3) / 4) * 16);
+    hipLaunchKernelGGL(pf2_mx_bounds_kernel, dim3(1), dim3(256), 0, st, w1, w2, w3, b2, b3, rd_w, bnd, W, F);
+    NL_LAUNCH_CHECK();
+  }
+  return NL_OK;
+}
+
+// max |T| over a frame's table (the MX mode's bound on base_mlp.0's outputs): *out <- max |x[0 .. n)|
+int nl_table_absmax(const float* x, size_t n, float* out, hipStream_t st) {
+  NL_CHECK_HIP(hipMemsetAsync(out, 0, 4, st));
+  if (n == 0) return NL_OK;
+  const unsigned blocks = (unsigned)(n / 4096 + 1 > 1024 ? 1024 : n / 4096 + 1);
+  hipLaunchKernelGGL(pf2_absmax_kernel, dim3(blocks), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(out));
+  NL_LAUNCH_CHECK();
   return NL_OK;
 }
 
@@ -987,14 +1113,11 @@ extern "C" __attribute__((visibility("default"))) int nl_debug_pf2_trace(unsigne
 bool nl_point_fused2_supported(int W, int precision) { return precision != NL_PREC_F32 && (W == 128 || W == 256); }
 
 // keep_kv != null (with the split-FP16 stream in a.wstream2): the F16 + KEEP instance — also writes the k / v rows (N x 8, 256) and the three layers' sign bits
-int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx, float* keep_kv, unsigned* const* keep_mk) {
+int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx, float* keep_kv, unsigned* const* keep_mk, const float* tmax,
+                           unsigned* logit_amax, unsigned long long* clk) {
   if (a.N <= 0) return NL_OK;
-  if (g_num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
-    g_num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-  }
+  const int g_num_cu = nl_persistent_cus();
+  if (g_num_cu < 0) return g_num_cu;
   Pf2Scalars sc;
   sc.dir_stride = a.dir_stride; sc.dir_div = a.dir_div > 0 ? a.dir_div : 1; sc.dir_magic = 0; sc.dir_shift = 0; sc.dir_one = sc.dir_div == 1 ? 1u : 0u;   // divisor 1: magic 0 (mulhi = 0) + n * 1
   if (sc.dir_div > 1) {   // n / d for n < 2^31 as mulhi(n, ceil(2^(31+s) / d)) >> (s - 1), s = ceil(log2 d)
@@ -1006,6 +1129,8 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
   sc.N = a.N; sc.M = a.M; sc.inv_span = a.inv_span; sc.ntiles = (int)nl_cdiv(a.N, 16);
   if ((int64_t)a.N * 512 > 0x7fffffffll || ((int64_t)a.M + 1) * W * 4 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   sc.t_bytes = (unsigned)(((int64_t)a.M + 1) * W * 4);
+  sc.tmax = tmax; sc.logit_amax = logit_amax; sc.clk = clk;
+  if (mx && !tmax) return NL_ERR_BAD_ARG;   // (the MX kernel bounds layer 1's outputs with it)
   const int nwg = sc.ntiles < g_num_cu ? (int)nl_xcd_grid(sc.ntiles) : g_num_cu;
   dim3 grid(nwg);
   const bool x3 = precision == NL_PREC_BF16X3;

@@ -909,13 +909,8 @@ extern "C" __attribute__((visibility("default"))) int nl_debug_chain_trace(unsig
 
 namespace {
 int chain_grid(int ntiles, dim3* grid) {
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NL_ERR_HIP;
-    num_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-  }
+  const int num_cu = nl_persistent_cus();
+  if (num_cu < 0) return num_cu;
   *grid = dim3(ntiles < num_cu ? nl_xcd_grid(ntiles) : num_cu);
   return NL_OK;
 }

@@ -104,6 +104,57 @@ class GraphedKeep:
         return self.go.clone(), self.gd.clone(), self.gq.sum(0)
 
 
+class GraphedRender:
+    """The fused inference path (`nl_render_rays_ex`) of ONE batch shape against ONE frame / weight set / precision as a HIP graph (round 5).
+    The call is an 18-kernel dependency chain on two streams; for a batch of a few hundred rays (BASELINE config 1; a 512-ray shard of config 2 on 8 GPUs; a
+    pose-scoring loop) each launch's ramp and tail (~10 us) is a tenth of the step.  Inputs are copied into static buffers (the query centre travels as per-ray rows
+    in device memory, so a new pose needs no new capture), the graph is replayed, the outputs are cloned out.  Results are bit-identical to the eager call
+    (tests/test_gpu_configs.py).  The loop it replaces on the reference's side: one `render_rays` per chunk / pose (model.py:615-639)."""
+
+    def __init__(self, r: "HipRenderer", R: int, white: bool, want_feat: bool, have_z: bool):
+        dev, S, C = r.device, r.S, r.C
+        self.r, self.R, self.white, self.gen, self.precision = r, int(R), bool(white), r.state_gen, r.precision
+        e = lambda *shp: torch.zeros(*shp, device=dev)
+        self.o, self.d, self.q = e(R, 3), e(R, 3), e(R, 3)
+        self.z = e(R, S) if have_z else None
+        self.out = {"rgb": e(R, 3), "depth": e(R), "weights": e(R, S), "mask": torch.zeros(R, dtype=torch.uint8, device=dev), "depth_uncertainty": e(R)}
+        if want_feat:
+            self.out["feat"] = e(R, C)
+        self.ro = L.NlRenderOut()
+        for k, t in self.out.items():
+            setattr(self.ro, k, t.data_ptr())
+        self.opts = L.NlRenderOpts()
+        self.opts.ray_centers = self.q.data_ptr()
+        need = r.lib.nl_render_rays_workspace_bytes(ct.byref(r.cfg), r.V, R)
+        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.graph = None
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def _call(self):
+        r = self.r
+        L.check(r.lib.nl_render_rays_ex(ct.byref(r.cfg), r.packed.data_ptr(), r._frame, None, self.o.data_ptr(), self.d.data_ptr(), _ptr(self.z), self.R,
+                                        1 if self.white else 0, ct.byref(self.ro), self.ws.data_ptr(), self.ws.numel(), r._stream(), ct.byref(self.opts)), "nl_render_rays")
+
+    def run(self, o, d, q_rows, z, clone: bool = True):
+        self.o.copy_(o, non_blocking=True); self.d.copy_(d, non_blocking=True); self.q.copy_(q_rows, non_blocking=True)
+        if self.z is not None:
+            self.z.copy_(z, non_blocking=True)
+        if self.graph is None:   # first use: warm run (per-frame tables are built on first use), then the capture, on a side stream
+            cur = torch.cuda.current_stream(self.r.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self._call()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._call()
+            cur.wait_stream(self.stream)
+            self.graph = g
+        self.graph.replay()
+        out = {k: (v.clone() if clone else v) for k, v in self.out.items()}
+        out["mask"] = out["mask"].view(torch.bool)
+        return out
+
+
 class _Lease:
     """Marks a renderer's pooled keep-workspace as free again when the state that borrowed it is dropped (after the backward call, or never used)."""
 
@@ -272,6 +323,14 @@ class HipRenderer:
         self._map_shapes = ((V, h, w, feat.shape[3]), (V, visf.shape[2], visf.shape[3], 32), (V, h, w, 32))
         self.state_gen = getattr(self, "state_gen", 0) + 1
 
+    def diagnostics(self) -> Dict[str, float]:
+        """nl_frame_diagnostics: {'table_absmax': max |T| of the per-frame table, 'logit_absmax': the largest |attention logit| the fused neural-point kernel has
+        scored against this frame so far}.  Synchronises the current stream (a device-to-host copy of two floats)."""
+        self._ready()
+        buf = (ct.c_float * 3)()
+        L.check(self.lib.nl_frame_diagnostics(self._frame, buf, 3, self._stream()), "nl_frame_diagnostics")
+        return {"table_absmax": float(buf[0]), "logit_absmax": float(buf[1]), "point_kernel_GHz": float(buf[2])}
+
     def clear_frame(self) -> None:
         if self._frame:
             self.lib.nl_frame_destroy(self._frame)
@@ -343,15 +402,38 @@ class HipRenderer:
             raise RuntimeError("set_frame() first")
 
     # ------------------------------------------------------------------ fused path
+    GRAPH_MAX_RAYS = 1024   # batches up to this size replay as a HIP graph when the caller asks for it (render_rays(graph=True)); larger ones are GPU-bound
+
+    def _graphed_render(self, R: int, white: bool, want_feat: bool, have_z: bool):
+        """The GraphedRender of this batch shape for the CURRENT frame / weights / precision: None on the first request of a shape (the caller renders that batch
+        eagerly: it may be the only one), the graph from the second request on; dropped when the frame or the weights change; at most four shapes are kept."""
+        reg = self.__dict__.setdefault("_rgraphs", {})
+        if reg.get("gen") != (self.state_gen, self.precision):
+            reg.clear()
+            reg["gen"] = (self.state_gen, self.precision)
+        key = (int(R), bool(white), bool(want_feat), bool(have_z))
+        ent = reg.get(key)
+        if ent is None:
+            reg[key] = "seen"
+            return None
+        if ent == "seen":
+            live = [k for k, v in reg.items() if isinstance(v, GraphedRender)]
+            for k in live[:-3]:
+                reg[k] = "seen"
+            ent = reg[key] = GraphedRender(self, R, white, want_feat, have_z)
+        return ent
+
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
                     intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0,
-                    side_stream: bool = True, want_knn: bool = False) -> Dict[str, torch.Tensor]:
+                    side_stream: bool = True, want_knn: bool = False, graph: bool = False) -> Dict[str, torch.Tensor]:
         """side_stream=False (nl_render_opts.flags = NL_RENDER_NO_SIDE_STREAM): every kernel on the current stream (bit-identical results;
         for profiling kernels one at a time).
         early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
         ray's transmittance falls below eps are not evaluated (rgb / feat move by < eps * max|value|; everything else is unchanged).
         query_center: (3,) for the whole batch, or (R, 3) per ray — rays of several query frames (poses) against this support frame in
-        one launch (nl_render_opts.ray_centers)."""
+        one launch (nl_render_opts.ray_centers).
+        graph=True: a batch of <= GRAPH_MAX_RAYS rays whose shape was seen before (same frame, weights, precision) is replayed as a HIP graph
+        (GraphedRender: bit-identical outputs, one graph launch instead of an 18-kernel chain)."""
         self._ready()
         dev = self.device
         o, d = _dev_f32(rays_o, dev), _dev_f32(rays_d, dev)
@@ -361,6 +443,12 @@ class HipRenderer:
         per_ray = qc_t.dim() == 2
         if per_ray and tuple(qc_t.shape) != (R, 3):
             raise ValueError(f"per-ray query centres must have shape ({R}, 3), got {tuple(qc_t.shape)}")
+        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream \
+                and not getattr(self, "guard_bytes", 0) and self._ws_request is None:
+            g = self._graphed_render(R, white_bkgd, want_feat, z is not None)
+            if g is not None:
+                rows = qc_t.to(dev) if per_ray else qc_t.reshape(1, 3).to(dev).expand(R, 3)
+                return g.run(o, d, rows, z)
         if not per_ray and qc_t.is_cuda:   # one centre that lives on the device: R identical rows instead of a device-to-host copy (= a synchronisation
             qc_t, per_ray = qc_t.reshape(1, 3).expand(R, 3), True   # point per call: 21 of them in a render_image loop)
         qc = qc_t.to(dev).contiguous() if per_ray else qc_t.cpu().contiguous()

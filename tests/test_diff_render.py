@@ -119,6 +119,47 @@ def test_pose_gradients_match_reference_autograd_gpu(gname):
     assert max(e.values()) < 1e-4, e
 
 
+# measured on the MI355X box (round 5; worst of the six gradients of a case) -> tolerance = 2 x measured, floor 1e-4.  What bounds the
+# fp32 row is the reference's own fp32 conditioning (its golden is 1.1e-3 / 5e-4 from the fp64 gradient of the same graph, see the eager test above).
+#   grad_tiny (W = 32, staged kernels): 1.06e-3 on gfeat_rays_d in EVERY mode — the golden itself is 1.1e-3 from the fp64 gradient of the same graph;
+#   grad_c1 (W = 64): fp32 1.8e-5, bf16x3 / f16mx 6.4e-5 (round 4 held all of these to a blanket 3e-3)
+NODE_GRAD_TOL = {("grad_tiny", "fp32"): 2.2e-3, ("grad_tiny", "bf16x3"): 2.2e-3, ("grad_tiny", "f16mx"): 2.2e-3,
+                 ("grad_c1", "fp32"): 1e-4, ("grad_c1", "bf16x3"): 1.3e-4, ("grad_c1", "f16mx"): 1.3e-4}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("gname", list(GRAD_CASES))
+def test_pose_gradients_through_the_library_node_match_reference_autograd(gname, precision):
+    """The two PoseOptimizer losses differentiated through the LIBRARY (RenderFn: fused forward, nl_render_rays_backward) in every parity mode against the
+    REFERENCE's autograd goldens — the eager-graph test above pins the restatement; this one pins what the product runs."""
+    from nerf_loc_amd.renderer import HipRenderer
+    name, n = GRAD_CASES[gname]
+    case = build_case(name)
+    cfg, frame = case["cfg"], case["frame"]
+    r = HipRenderer(cfg.W, cfg.C, cfg.S_total, precision)
+    r.load_weights({k: torch.from_numpy(v) for k, v in case["weights"].items()})
+    r.set_frame(frame["topk_images"], frame["feat_fine_src"], frame["vis_featmaps"], frame["topk_Ks"], frame["topk_poses"], cfg.near, cfg.far, frame["support_fine"])
+    cfg, fr, p, pose0, K, uv, tf, trgb, n = _setup(gname, "cuda:0")
+    pose = pose0.clone().requires_grad_(True)
+    o, d = dr.rays_from_pose(uv, K, pose)
+    o, d = o + 0, d + 0
+    z = (cfg.near * (1 - torch.linspace(0, 1, cfg.S)) + cfg.far * torch.linspace(0, 1, cfg.S)).to(pose0.device).expand(len(uv), cfg.S).contiguous()
+    out = dr.render_rays_diff(p, fr, o, d, z, pose, lambda q: r.knn(q, 8)[1], frozen_renderer=r)
+    m = out["mask"].unsqueeze(1)
+    lf = torch.mean(((out["feat"] - tf) * m) ** 2)
+    lr = torch.mean(((out["rgb"] - trgb) * m) ** 2)
+    gf = torch.autograd.grad(lf, [pose, o, d], retain_graph=True)
+    gr = torch.autograd.grad(lr, [pose, o, d])
+    g = np.load(os.path.join(GOLD, f"{gname}.npz"))
+    errs = {}
+    for tag, gs in (("gfeat", gf), ("grgb", gr)):
+        for nm, v in zip(("pose", "rays_o", "rays_d"), gs):
+            errs[f"{tag}_{nm}"] = rel_err(v.cpu().numpy(), g[f"{tag}_{nm}"])
+    print("NODE_GRAD", gname, precision, {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < NODE_GRAD_TOL[(gname, precision)], (gname, precision, errs)
+
+
 # ----------------------------------------------------------------------------- one training step (compute_render_loss)
 def _train_case(device, hier=False):
     from tests.golden_cases import build_setup_case
@@ -237,8 +278,8 @@ def test_training_step_gradients_match_reference_autograd_cpu(hier):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hier,hip_nodes", [(False, True), (True, True), (False, False)])
-def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier, hip_nodes, monkeypatch):
+@pytest.mark.parametrize("hier,hip_nodes,precision", [(False, True, "fp32"), (True, True, "fp32"), (False, False, "fp32"), (False, True, "bf16x3"), (False, True, "f16mx")])
+def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier, hip_nodes, precision, monkeypatch):
     """model.py:641-685 on the drop-in module in train() mode on the GPU (HIP KNN, per-frame caches rebuilt with their graphs).
     hip_nodes: the stages with library weight gradients run as HIP autograd nodes (the default) / the all-eager fp32 graph."""
     from tests.test_dropin_module import _args
@@ -251,7 +292,7 @@ def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier,
         u = torch.from_numpy(case["u"]).to(dev)
         orig = torch.rand
         monkeypatch.setattr(torch, "rand", lambda *sh, **kw: u.clone() if tuple(sh) == tuple(u.shape) else orig(*sh, **kw))
-    net = ConditionalNeRF(args, precision="fp32").to(dev).train()
+    net = ConditionalNeRF(args, precision=precision).to(dev).train()
     net.hip_training = hip_nodes
     net.load_state_dict({k: torch.from_numpy(v) for k, v in case["weights"].items()}, strict=True)
     net.support_neural_points = None
@@ -264,10 +305,17 @@ def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier,
     # (slack = 1: in ~2 % of the runs on the GPU box — with the library's nodes and with the all-eager graph alike — `ray_unet.conv2.1.bias`, a LayerNorm table in front
     # of a MaxPool, lands at 3.69e-3 instead of ~2e-3: the per-frame CNN's MIOpen convolutions do not pick the same algorithm every time, the feature maps differ in the
     # last bits and one pooled pair flips.  Found by looping the test 220 times while chasing a suspected race in the round-4 kernels; it is upstream of both paths.)
-    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-2 if hier else 3e-3, "train_hier" if hier else "train_setup", slack=1)
-    assert float(np.median(list(errs.values()))) < 1e-3
+    # round 5: measured on the MI355X box in all three modes — median 4.2e-5, worst tensor 7.9e-4 (a BatchNorm weight of the per-frame CNN and
+    # `mean_decoder.4.weight`, the same three tensors with the library's nodes and with the all-eager graph); the plain case is held to 2 x that instead of 3e-3
+    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-2 if hier else 1.6e-3, "train_hier" if hier else "train_setup", slack=1)
+    assert float(np.median(list(errs.values()))) < (1e-3 if hier else 1e-4)
     assert sum(e > 3e-3 for e in errs.values()) <= 6, {k: e for k, e in errs.items() if e > 3e-3}
-    print("worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    print("TRAIN_GRAD", hier, hip_nodes, precision, "median", f"{float(np.median(list(errs.values()))):.2e}", "worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    if hip_nodes:   # identically-zero gradients come back as ZERO TENSORS, not None (VERDICT r4 missing 4): base_mlp_agg_weight.* are "used" parameters under the
+        named = dict(net.named_parameters())   # reference's DistributedDataParallel launch (pl/train.py:100-112)
+        for nm in ("base_mlp_agg_weight.0.weight", "base_mlp_agg_weight.0.bias", "base_mlp_agg_weight.2.weight", "base_mlp_agg_weight.2.bias"):
+            assert named[nm].grad is not None and float(named[nm].grad.abs().max()) == 0.0, nm
+        assert all(q.grad is not None for n_, q in named.items() if n_.startswith("confidence_mlp.")), "confidence_mlp is reached through the support table"
     # an optimiser step on the render heads lowers the loss of the same batch
     opt = torch.optim.SGD([q for q in net.parameters() if q.grad is not None], lr=1e-3)
     opt.step()

@@ -376,8 +376,10 @@ def test_ref_depth_loss_and_gradients_match_reference(case_name):
                        ("grad_mean_decoder_0_w", "multiview_aggregator.dist_decoder.mean_decoder.0.weight"),
                        ("grad_df_conv_out_w", "multiview_aggregator.depth_fusion.conv_out.weight"),
                        ("grad_df_conv1_w", "multiview_aggregator.depth_fusion.fuse_net.conv1.weight")):
-        # (3e-4: the CNN's first-layer gradient sums thousands of terms in an order that follows the host's thread count — 1.4e-4 on a 256-core box, 3e-5 on 8 cores)
-        assert rel_err(named[pname].grad.numpy(), g[key]) < 3e-4, (key, rel_err(named[pname].grad.numpy(), g[key]))
+        # 1e-4 for everything but the per-frame CNN's tensors: a depth_fusion gradient sums thousands of terms in an order that follows the host's
+        # thread count — 1.4e-4 on a 256-core box, 3e-5 on 8 cores — so those two get 3e-4; the decoders' gradients are held to the bar they always met
+        tol = 3e-4 if ".depth_fusion." in pname else 1e-4
+        assert rel_err(named[pname].grad.numpy(), g[key]) < tol, (key, rel_err(named[pname].grad.numpy(), g[key]))
     # the renderer's parameters are not reached by this loss
     assert named["base_mlp.0.weight"].grad is None
 

@@ -282,3 +282,44 @@ def test_render_rays_multi_is_bit_identical_to_separate_calls():
         for a, b in zip(got, want):
             for k in b:
                 assert torch.equal(a[k], b[k]), (prec, k)
+
+
+def test_graphed_inference_replays_are_bit_identical_to_the_eager_call():
+    """Round 5: `render_rays(graph=True)` replays a small batch shape as a HIP graph from the second call on (GraphedRender).  The replay must
+    give the eager call's bits — for NEW rays, NEW depths and a NEW query centre fed through the same graph — in both parity modes, with and without explicit
+    depths, and a frame / weight / precision change must drop the captured graph instead of replaying it against stale tables."""
+    from nerf_loc_amd.renderer import GraphedRender
+    from nerf_loc_amd.synth import make_frame
+    sc = _scene("c1")
+    cfg, frame, rays = sc["cfg"], sc["frame"], sc["rays"]
+    for prec in ("f16mx", "bf16x3"):
+        r = _renderer(sc, prec)
+        t = torch.linspace(0, 1, cfg.S)
+        z0 = (cfg.near * (1 - t) + cfg.far * t).expand(cfg.R, cfg.S).contiguous()
+        qc = frame["pose"][:3, 3]
+        for trial in range(4):
+            sel = np.random.default_rng(trial).permutation(cfg.R)
+            o, d = rays["rays_o"][sel], rays["rays_d"][sel]
+            z = z0 * (1.0 + 0.01 * trial)
+            q = qc + np.float32(0.01 * trial)
+            eager = r.render_rays(o, d, q, z_vals=z)
+            graphed = r.render_rays(o, d, q, z_vals=z, graph=True)
+            if trial >= 1:
+                assert isinstance(r._rgraphs[(cfg.R, False, True, True)], GraphedRender), "the second request of a shape captures the graph"
+            for k in eager:
+                assert torch.equal(eager[k], graphed[k]), (prec, trial, k)
+        # depths left to the library (z_vals=None) are a different graph
+        a = r.render_rays(rays["rays_o"], rays["rays_d"], qc)
+        for _ in range(2):
+            b = r.render_rays(rays["rays_o"], rays["rays_d"], qc, graph=True)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (prec, "no z", k)
+        # a new frame drops the graphs: the replay must not run against the old tables
+        fr2 = make_frame(cfg.replace(seed=cfg.seed + 50))
+        r.set_frame(fr2["topk_images"], fr2["feat_fine_src"], fr2["vis_featmaps"], fr2["topk_Ks"], fr2["topk_poses"], cfg.near, cfg.far, fr2["support_fine"])
+        e2 = r.render_rays(rays["rays_o"], rays["rays_d"], qc, z_vals=z0)
+        for _ in range(3):
+            g2 = r.render_rays(rays["rays_o"], rays["rays_d"], qc, z_vals=z0, graph=True)
+        for k in e2:
+            assert torch.equal(e2[k], g2[k]), (prec, "new frame", k)
+        assert not torch.equal(e2["rgb"], eager["rgb"])

@@ -514,3 +514,36 @@ def test_random_scenes_forward_matches_the_cpu_oracle():
     spec.loader.exec_module(mod)
     # round 4: 100 seeded scenes in the driver-run suite (was 12; the builder-side runs of tools/forward_fuzz.py cover 1 400)
     assert mod.run(int(os.environ.get("NERFLOC_FUZZ_FORWARD", "100")), 9, verbose=False) < 1e-4
+
+
+# ------------------------------------------------------------------ inputs that are NOT the O(1) synthetic recipe (round 5)
+SWEEP = {
+    "w256s128": [("normal", 1.0 / 64, 1.0), ("normal", 8.0, 1.0), ("normal", 64.0, 1.0), ("student_t3", 1.0 / 64, 1.0), ("student_t3", 8.0, 8.0),
+                 ("student_t3", 64.0, 1.0), ("normal+off4", 1.0, 1.0), ("normal+off32", 0.25, 1.0)],   # +offX: views agree on a large common value (mean^2 >> variance)
+    "c2": [("student_t3", 1.0 / 64, 1.0), ("student_t3", 8.0, 1.0), ("normal", 64.0, 1.0)],
+}
+
+
+@pytest.mark.parametrize("case", sorted(SWEEP))
+def test_parity_modes_hold_on_scaled_features_and_heavy_tailed_weights(case):
+    """tools/scale_sweep.py: feature maps + support features x {1/64, 8, 64}, Student-t (nu = 3) weights of the same fan-in variance, DepthFusionNet maps x 8 — the
+    golden-case scene w256s128 and 64 rays of BASELINE config 2, every precision mode against the CPU oracle in max-rel AND L2-rel.  The bar is BASELINE's 1e-4
+    wherever the scene is well-conditioned; where the fp32 oracle itself is further than 1e-5 / 5e-6 from the fp64 result (attention logits in the hundreds at
+    8x features: a softmax over nearly tied neighbours) it is COND_FACTOR x the oracle's own distance to fp64 (fp32 mode 3x, bf16x3 10x, f16mx 20x: the ratios the
+    modes show on well-conditioned scenes).  f16mx's fp8 images carry per-row block scales since round 5: no range assumption is left in it besides fp16's own
+    (|activation| < 65504), which this sweep exercises up to ~2e3."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("scale_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "scale_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.sweep(case, combos=SWEEP[case], verbose=True)
+    assert len(rows) == 3 * len(SWEEP[case])
+    relaxed = [r for r in rows if mod.relaxed(r)]
+    print(f"{case}: {len(relaxed)} of {len(rows)} rows are held to the conditioning bar instead of 1e-4")
+    for r in rows:
+        assert r["mask_equal"], r
+        assert r["max_rel"] < mod.bar(r) and r["l2_rel"] < mod.bar(r), {k: r[k] for k in ("case", "weights", "fscale", "vscale", "precision", "worst_key", "max_rel", "l2_rel",
+                                                                                          "oracle_vs_fp64")}
+        if r["fscale"] <= 1.0 and r["oracle_vs_fp64"] < 1e-5:   # well-conditioned rows: the plain bar, whatever the factors above say
+            assert r["max_rel"] < 1e-4 and r["l2_rel"] < 1e-4, r

@@ -53,6 +53,7 @@ def borderline_rays(cfg, frame, rays, z):
 def run(ncases=20, seed0=0, verbose=True):
     from oracle import render_oracle as orc
     worst_all = 0.0
+    n_relaxed = 0   # scenes in which some output was held to 3 x (oracle vs fp64) instead of 1e-4 (how often the relaxed branch is used)
     for case in range(ncases):
         rng = np.random.default_rng(31000 + 1000 * seed0 + case)
         W = int(32 * rng.integers(1, 9)); S = int(8 * rng.integers(1, 9)); V = int(rng.integers(1, 17)); C = int(rng.choice([5, 8, 31, 32, 61, 64, 100, 128, 192]))
@@ -82,6 +83,7 @@ def run(ncases=20, seed0=0, verbose=True):
         e64 = eager64(cfg, frame, weights, rays, zref, white)
         cond = {k: rel_err(ref[k].numpy().astype(np.float64), e64[k]) for k in ("rgb", "depth", "weights", "depth_uncertainty", "feat")}
 
+        n_relaxed += int(3 * max(cond.values()) > 1e-4)
         keep = ~borderline_rays(cfg, frame, rays, zref)
         worst = ("", 0.0)
         for precision in ("fp32", "bf16x3", "f16mx"):   # (f16mx differs from bf16x3 where the fused neural-point kernel runs: W = 128, 256)
@@ -124,7 +126,8 @@ def run(ncases=20, seed0=0, verbose=True):
         print(f"case {case}: W={W} S={S}+{NI} V={V} C={C} {H}x{Wimg} R={R} M={frame['support_fine']['xyz'].shape[0]}{' white' if white else ''}: worst {worst[1]:.1e} ({worst[0]})", flush=True)
         if not os.environ.get("FORCE"): assert worst[1] < 1e-4 or worst[1] < 3 * max(cond.values()), "MISMATCH"   # (ill-conditioned outputs: no worse than 3x the fp32 oracle)
         worst_all = max(worst_all, worst[1])
-    if verbose: print("all cases passed; worst", worst_all)
+    print(f"forward fuzz: {ncases} scenes, worst error vs fp64 {worst_all:.2e}; scenes whose bar was 3 x (oracle vs fp64) > 1e-4: {n_relaxed}", flush=True)
+    run.last_relaxed = n_relaxed
     return worst_all
 
 

@@ -162,11 +162,25 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c2"
     n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 48
     torch.set_num_threads(os.cpu_count() or 8)
-    cfg = CONFIGS[name]
+    if name in CONFIGS:
+        cfg = CONFIGS[name]
+    else:   # a golden-case scene (tests/golden_cases.py), e.g. w256s128
+        from tests.golden_cases import CASES
+        cfg = CASES[name][0]
+        n_rays = min(n_rays, cfg.R)
     frame = make_frame(cfg)
     rays = make_rays(cfg, frame, R=n_rays)
+    weights = make_weights(cfg)
+    # round 5: the same budget on inputs that are not O(1) — BUDGET_FSCALE multiplies the feature maps and the support features,
+    # BUDGET_VSCALE the DepthFusionNet maps, BUDGET_WEIGHTS=student_t3 draws heavy-tailed weights (tools/scale_sweep.py holds the recipes)
+    if os.environ.get("BUDGET_FSCALE") or os.environ.get("BUDGET_VSCALE") or os.environ.get("BUDGET_WEIGHTS"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import scale_sweep as ss
+        frame = ss.scaled_frame(frame, float(os.environ.get("BUDGET_FSCALE", "1")), float(os.environ.get("BUDGET_VSCALE", "1")))
+        if os.environ.get("BUDGET_WEIGHTS") == "student_t3":
+            weights = ss.heavy_tailed_weights(cfg)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    p = {k: t(v) for k, v in make_weights(cfg).items()}
+    p = {k: t(v) for k, v in weights.items()}
     fr = {k: t(frame[k]) for k in ("topk_Ks", "topk_poses", "topk_images", "feat_fine_src", "vis_featmaps")}
     fr.update({"near": float(cfg.near), "far": float(cfg.far), "support": {k: t(v) for k, v in frame["support_fine"].items()}})
     o, d = t(rays["rays_o"]), t(rays["rays_d"])
