@@ -181,8 +181,9 @@ class ConditionalNeRF(nn.Module):
     # reports the largest |logit| it scored (nl_frame_diagnostics); after the FIRST inference batch of every frame the module reads it (one device-to-host
     # copy per frame, next to a 4-ms per-frame setup) and, if it is beyond the limit its current mode was validated to, re-renders that batch and keeps
     # rendering the frame in the next more exact mode (f16mx -> bf16x3 -> fp32).  Limits: the |logit| up to which the mode stayed within 1e-4 of the CPU oracle
-    # in the sweep (profiles/r5_scale_sweep.txt).  precision_guard=False switches it off; `guard_events` lists what it did.
-    LOGIT_LIMIT = {"f16mx": 30.0, "bf16x3": 60.0}
+    # on every scene of the sweep (profiles/r5_scale_sweep.txt: f16mx 8.1e-5 at |logit| 142 and 1.2e-4 at 271; bf16x3 4.2e-5 at 475 and 0.9-1.7e-4 at ~1000; the
+    # synthetic BASELINE scenes sit at 4-6).  precision_guard=False switches it off; `guard_events` lists what it did.
+    LOGIT_LIMIT = {"f16mx": 100.0, "bf16x3": 500.0}
     _SAFER = {"f16mx": "bf16x3", "bf16x3": "fp32", "bf16": "bf16x3"}
 
     def __init__(self, args, activation_func=None, precision: str = "f16mx", device: Optional[str] = None, precision_guard: bool = True):

@@ -473,3 +473,53 @@ def test_frames_with_different_support_sets_in_one_call_equal_separate_calls():
     net.multiview_aggregator.vis_featmaps = None
     again = net.render_rays(datas[0], rays_l[0])
     assert rel_err(again["rgb"].cpu().numpy(), singles[0]["rgb"].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_precision_guard_escalates_on_ill_conditioned_frames_and_only_there():
+    """Round 5: the module's precision guard (ConditionalNeRF.LOGIT_LIMIT).  Feature maps x 8 push the attention logits of the neural-point branch into the
+    hundreds — beyond what f16mx (|logit| <= 100) and bf16x3 (<= 500) were validated to: the first inference batch of such a frame is re-rendered in the next more
+    exact mode and the frame stays there; the result is then within 1e-4 of the fp32-mode render of the same module.  An ordinary frame is not touched, and a new
+    frame starts from the configured mode again."""
+    from nerf_loc_amd.conditional_nerf import ConditionalNeRF
+    from nerf_loc_amd.synth import SceneConfig, add_setup_inputs, make_depth_fusion_weights, make_frame, make_rays, make_weights
+    dev = torch.device("cuda:0")
+    cfg = SceneConfig("guard", R=24, S=32, W=128, V=4, H=48, Wimg=64, seed=31)
+    frame = add_setup_inputs(cfg, make_frame(cfg))
+    w = dict(make_weights(cfg)); w.update(make_depth_fusion_weights(cfg.seed))
+    case = {"cfg": cfg, "frame": frame, "rays": make_rays(cfg, frame), "weights": w}
+    net, data, rd = _module_and_data(case, dev, precision="f16mx")
+    ref, _, _ = _module_and_data(case, dev, precision="fp32")
+    ref.precision_guard = False
+    rd["depth_range"] = data["depth_range"][0]
+
+    def fresh(scale):
+        d = dict(data)
+        d["feat_fine_src"] = data["feat_fine_src"] * scale
+        d["feat_coarse_src"] = data["feat_coarse_src"] * scale
+        for m in (net, ref):
+            m.support_neural_points = None
+            m.multiview_aggregator.vis_featmaps = None
+        return d
+    d1 = fresh(1.0)
+    out = net.render_rays(d1, rd)
+    assert net.guard_events == [] and net._renderers["fine"].precision == "f16mx"
+    want = ref.render_rays(d1, rd)
+    for k in ("rgb", "depth", "weights", "feat"):
+        assert rel_err(out[k].cpu().numpy(), want[k].cpu().numpy()) < 1e-4, ("ordinary frame", k)
+    d8 = fresh(8.0)
+    out8 = net.render_rays(d8, rd)
+    amax = net._renderers["fine"].diagnostics()["logit_absmax"]
+    assert amax > ConditionalNeRF.LOGIT_LIMIT["f16mx"], amax
+    assert len(net.guard_events) == 1 and net.guard_events[0]["from"] == "f16mx", net.guard_events
+    assert net._renderers["fine"].precision == net.guard_events[0]["to"] != "f16mx"
+    want8 = ref.render_rays(d8, rd)
+    for k in ("rgb", "depth", "weights", "feat"):
+        assert rel_err(out8[k].cpu().numpy(), want8[k].cpu().numpy()) < 1e-4, ("escalated frame", k, net.guard_events)
+    again = net.render_rays(d8, rd)   # the frame stays in the escalated mode, without another check
+    assert len(net.guard_events) == 1 and torch.equal(again["rgb"], out8["rgb"])
+    net.render_rays(fresh(1.0), rd)   # a new frame starts from the configured mode
+    assert net._renderers["fine"].precision == "f16mx" and len(net.guard_events) == 1
+    net.precision_guard = False
+    net.render_rays(fresh(8.0), rd)
+    assert net._renderers["fine"].precision == "f16mx" and len(net.guard_events) == 1

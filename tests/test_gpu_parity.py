@@ -526,12 +526,12 @@ SWEEP = {
 
 @pytest.mark.parametrize("case", sorted(SWEEP))
 def test_parity_modes_hold_on_scaled_features_and_heavy_tailed_weights(case):
-    """tools/scale_sweep.py: feature maps + support features x {1/64, 8, 64}, Student-t (nu = 3) weights of the same fan-in variance, DepthFusionNet maps x 8 — the
-    golden-case scene w256s128 and 64 rays of BASELINE config 2, every precision mode against the CPU oracle in max-rel AND L2-rel.  The bar is BASELINE's 1e-4
-    wherever the scene is well-conditioned; where the fp32 oracle itself is further than 1e-5 / 5e-6 from the fp64 result (attention logits in the hundreds at
-    8x features: a softmax over nearly tied neighbours) it is COND_FACTOR x the oracle's own distance to fp64 (fp32 mode 3x, bf16x3 10x, f16mx 20x: the ratios the
-    modes show on well-conditioned scenes).  f16mx's fp8 images carry per-row block scales since round 5: no range assumption is left in it besides fp16's own
-    (|activation| < 65504), which this sweep exercises up to ~2e3."""
+    """tools/scale_sweep.py: feature maps + support features x {1/64, 8, 64}, Student-t (nu = 3) weights of the same fan-in variance, DepthFusionNet maps x 8, feature maps
+    with a large common offset — the golden-case scene w256s128 and 64 rays of BASELINE config 2, every precision mode against the CPU oracle in max-rel AND L2-rel.
+    Each mode is held to BASELINE's 1e-4 (3 x the fp32 oracle's own distance to the fp64 result where that is larger: tools/forward_fuzz.py's bar) on every scene
+    INSIDE its validated conditioning range — max |attention logit| <= 100 for f16mx, <= 500 for bf16x3 (ConditionalNeRF.LOGIT_LIMIT), any for fp32 — and on the
+    scenes beyond it the mode the module's precision guard selects must hold that bar.  f16mx's fp8 images carry per-row block scales since round 5: no range
+    assumption is left in it besides fp16's own (|activation| < 65504), which this sweep exercises up to ~2e3."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("scale_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "scale_sweep.py"))
@@ -539,11 +539,7 @@ def test_parity_modes_hold_on_scaled_features_and_heavy_tailed_weights(case):
     spec.loader.exec_module(mod)
     rows = mod.sweep(case, combos=SWEEP[case], verbose=True)
     assert len(rows) == 3 * len(SWEEP[case])
-    relaxed = [r for r in rows if mod.relaxed(r)]
-    print(f"{case}: {len(relaxed)} of {len(rows)} rows are held to the conditioning bar instead of 1e-4")
-    for r in rows:
-        assert r["mask_equal"], r
-        assert r["max_rel"] < mod.bar(r) and r["l2_rel"] < mod.bar(r), {k: r[k] for k in ("case", "weights", "fscale", "vscale", "precision", "worst_key", "max_rel", "l2_rel",
-                                                                                          "oracle_vs_fp64")}
-        if r["fscale"] <= 1.0 and r["oracle_vs_fp64"] < 1e-5:   # well-conditioned rows: the plain bar, whatever the factors above say
-            assert r["max_rel"] < 1e-4 and r["l2_rel"] < 1e-4, r
+    print(f"{case}: {sum(not mod.in_range(r) for r in rows)} of {len(rows)} rows are outside their mode's validated range (the guard escalates there); "
+          f"{sum(mod.relaxed(r) for r in rows)} are held to 3 x (oracle vs fp64) instead of 1e-4")
+    assert mod.check(rows) == []
+    assert any(not mod.in_range(r) for r in rows) and any(mod.in_range(r) and r["precision"] == "f16mx" for r in rows), "the sweep must cross the validated range"
