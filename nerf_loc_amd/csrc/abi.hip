@@ -63,7 +63,7 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
 bool nl_point_fused2_supported(int W, int precision);
 int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
                            size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
-                           float* blA, int64_t M, int precision, hipStream_t st);
+                           float* blA, int64_t M, int precision, hipStream_t st, bool frag_out = false);
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false, float* keep_kv = nullptr, unsigned* const* keep_mk = nullptr,
@@ -187,6 +187,7 @@ enum {
   G_BASE0_TF,                                                                    // training: base_mlp.0 towards its support-feature columns
   G_FEAT0_T, G_FEAT2_T,                                                          // whole-path backward: feat_mlp's two layers towards their inputs
   G_BASE0_S,                                                                     // base_mlp.0's posenc + ray_diff_fc columns (the staged forward on the table T)
+  G_CONV1F, G_CONVOUTF,   // conv1 / conv_out with the feature_agg channels of every 32-block in ACCUMULATOR order: their input is the chain kernel's fragment image
   G_COUNT
 };
 enum { U_CONV1 = 0, U_CONV2, U_CONV3, U_T3, U_T2, U_T1, U_OUT, U_COUNT };
@@ -241,6 +242,8 @@ Layout make_layout(const nl_config* c) {
   set(G_BLENDAP, W, 32, false);
   set(G_QP, W, 128, false);
   set(G_CONVOUT, 3 * (W + 32), W, true);
+  set(G_CONV1F, 3 * W, 64, true);
+  set(G_CONVOUTF, 3 * (W + 32), W, true);
   set(G_FEAT0, W, W, true);
   // feat_mlp's last Linear is applied AFTER compositing (it is linear): K = [composited hidden (W) | sum of weights (1)],
   // the bias row multiplies the weight sum (model.py:594-597)
@@ -427,11 +430,12 @@ struct Packer {
   }
   // conv taps over concatenated sources: weight (co, ci, 3); K index = tap-major then source channels
   // K order = per source (channel range [c0, c0 + wd) of the ci input channels), per 32-channel block, per tap: see NlGemmSeg::ntap
-  void conv3(int g, const float* w, const float* b, int ci, const int* widths, int nsrc) {
+  // perm_mask bit s: source s arrives as a fragment image (NlGemmSeg::frag): its 32-channel blocks in accumulator order (pack_block_kernel: perm)
+  void conv3(int g, const float* w, const float* b, int ci, const int* widths, int nsrc, unsigned perm_mask = 0) {
     int k0 = 0, c0 = 0;
     for (int sidx = 0; sidx < nsrc; ++sidx) {
       for (int cb = 0; cb < widths[sidx] / 32; ++cb)
-        for (int j = 0; j < 3; ++j) { block(g, k0, w, (c0 + 32 * cb) * 3 + j, ci * 3, 3, 32); k0 += 32; }
+        for (int j = 0; j < 3; ++j) { block(g, k0, w, (c0 + 32 * cb) * 3 + j, ci * 3, 3, 32, (perm_mask >> sidx) & 1); k0 += 32; }
       c0 += widths[sidx];
     }
     copy(b, L->bias[g], L->g[g].N);
@@ -604,7 +608,7 @@ struct Ctx {
   template <class T> const T* p(size_t off) const { return (const T*)(pk + off); }
 };
 
-struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; int ntap = 1; };
+struct SegSpec { const float* ptr; int ld; int k; int ioff; int rdiv; int ntap = 1; int frag = 0; };   // frag: NlGemmSeg::frag
 
 struct TileMap { const int* map; const int* count; };
 struct RowEpi { const float* res; int ldres; const float* gamma; const float* beta; const float* scale; float eps; float* out; int kind = NL_EPI_LNROW; int pool = 0;
@@ -627,6 +631,7 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
     a.seg[i].rdiv = segs[i].rdiv > 0 ? segs[i].rdiv : 1;
     a.seg[i].vec = ((((size_t)segs[i].ptr) & 15) == 0 && (segs[i].ld & 3) == 0) ? 1 : 0;
     a.seg[i].ntap = segs[i].ntap > 1 ? segs[i].ntap : 1;
+    a.seg[i].frag = segs[i].frag;
     if (a.seg[i].ntap > 1 && (segs[i].k & 31)) return NL_ERR_BAD_ARG;
     ksum += ((segs[i].k + 31) & ~31) * a.seg[i].ntap;   // every segment occupies round_up(k, 32) slots of K-space (one k-tile = one segment)
   }
@@ -806,7 +811,7 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
 // chain != null && chain->t64 != null (fused render path, W = 256, bf16 modes): the query rows before the branch and fc + LayerNorm +
 // scale, feat_mlp.0 (chain->fth, may be null) and the blend projection (chain->blA) after it run as two chain kernels that recompute
 // the multiview feature rows G from out_fc's hidden rows t64 (G is then not read here and need not exist); *chain->done reports it
-struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; };
+struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; bool fa_frag = false; };   // fa_frag: FA leaves the chain kernel as a fragment image
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
              float* FA, const PtBufs& p, SideJoin* knn_done = nullptr, const ChainOut* chain = nullptr) {
   const int W = x.c->W, F = f->C + 3;
@@ -857,7 +862,7 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   if (t64) {   // (the caller checked W, precision and the 32-bit offset range before leaving G unmaterialised)
     NL_TRY(nl_launch_sample_chain(p.O, t64, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_OUTFC2],
                                   x.p<float>(x.L.bias[G_OUTFC2]), x.L.bst[G_FC], x.L.bst[G_FEAT0P], x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA,
-                                  chain->fth, chain->blA, N, x.c->precision, x.st));
+                                  chain->fth, chain->blA, N, x.c->precision, x.st, chain->fa_frag));
     if (chain->done) *chain->done = true;
     return NL_OK;
   }
@@ -1240,8 +1245,9 @@ int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const fl
 // *sigma_done is set; otherwise the caller runs sigma_kernel on geo
 // need_geo == false: the caller only wants the density (model.py:525 is the sole consumer of the U-Net's output); when the density
 // head runs inside conv_out's epilogue the (N, W) output rows are then never written (0.5 GB per config-2 batch)
+// in_frag: `in` is feature_agg as the chain kernel's fragment image (NlGemmSeg::frag) instead of fp32 rows
 int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr,
-            bool need_geo = true) {
+            bool need_geo = true, bool in_frag = false) {
   const int W = x.c->W, S = x.c->S;
   // the two phases of every transposed convolution as one launch (bf16 modes; the fp32 kernels keep the separate phases)
   static const bool no_merge = dbg_switch("NERFLOC_NO_TMERGE");
@@ -1251,11 +1257,16 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   auto gl = [&](int i) { return x.p<float>(x.L.un_gl[i]); };   // accumulator-lane order: what the GEMM's fused LayerNorm reads
   auto bl = [&](int i) { return x.p<float>(x.L.un_bl[i]); };
   const float eps = 1e-5f;
+  // feature_agg's two consumers take their weights with the channels of every 32-block in accumulator order in the bf16 modes (G_CONV1F / G_CONVOUTF, streaming
+  // kernel): from the chain kernel's fragment image (in_frag) or from fp32 rows read in that order — the same products in the same order either way
+  const bool korder = in_frag || ((x.c->precision == NL_PREC_BF16X3 || x.c->precision == NL_PREC_BF16) && !dbg_switch("NERFLOC_NO_FRAG") && (((size_t)in) & 15) == 0 &&
+                                  ((x.has_bst >> G_CONV1F) & 1) && ((x.has_bst >> G_CONVOUTF) & 1));
+  const int fa_mode = in_frag ? 1 : (korder ? 2 : 0);
   {  // conv1: W -> 64 over S
-    SegSpec s[1] = {{in, W, W, 0, 1, 3}};   // 3 taps, interleaved per 32-channel block
+    SegSpec s[1] = {{in, W, W, 0, 1, 3, fa_mode}};   // 3 taps, interleaved per 32-channel block
     const RowEpi ep{nullptr, 0, gl(U_CONV1), bl(U_CONV1), nullptr, eps, u.c1, NL_EPI_LNSLAB, 1};   // LN + ELU + MaxPool inside the GEMM when one workgroup = one ray
     bool fused = false;
-    NL_TRY(run_gemm(x, G_CONV1, s, 1, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
+    NL_TRY(run_gemm(x, korder ? G_CONV1F : G_CONV1, s, 1, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
   }
   {  // conv2: 64 -> 128 over S/2
@@ -1314,12 +1325,12 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     if (!tfused) NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
   }
   {  // conv_out on cat[in, x2]
-    SegSpec s[2] = {{in, W, W, 0, 1, 3}, {u.x2, 32, 32, 0, 1, 3}};
+    SegSpec s[2] = {{in, W, W, 0, 1, 3, fa_mode}, {u.x2, 32, 32, 0, 1, 3}};
     RowEpi ep{nullptr, 0, gl(U_OUT), bl(U_OUT), nullptr, eps, geo, NL_EPI_LNSLAB, 0};
     if (sigma_out) { ep.sig_w = x.p<float>(x.L.sig_w); ep.sig_b = x.p<float>(x.L.sig_b); ep.sig_out = sigma_out; }
     bool fused = false;
     if (!need_geo && sigma_out) ep.out = nullptr;   // (the unfused fallback below still writes `geo`)
-    NL_TRY(run_gemm(x, G_CONVOUT, s, 2, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
+    NL_TRY(run_gemm(x, korder ? G_CONVOUTF : G_CONVOUT, s, 2, R * S, u.outr, W, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.outr, R, S, W, g(U_OUT), b(U_OUT), eps, geo, nullptr, x.st));
     if (sigma_done) *sigma_done = fused && sigma_out;
   }
@@ -1772,6 +1783,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   const float* const* un = t + T_UNET;
   { const int w1[1] = {W}, w2[1] = {64}, w3[1] = {128};
     P.conv3(G_CONV1, un[0], un[1], W, w1, 1);
+    P.conv3(G_CONV1F, un[0], un[1], W, w1, 1, 1u);
     P.conv3(G_CONV2, un[4], un[5], 64, w2, 1);
     P.conv3(G_CONV3, un[8], un[9], 128, w3, 1); }
   P.convT(G_T3E, G_T3O, un[12], un[13], 128, 128);
@@ -1780,7 +1792,7 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.convT_merged(G_T3M, un[12], un[13], 128, 128);
   P.convT_merged(G_T2M, un[16], un[17], 256, 64);
   P.convT_merged(G_T1M, un[20], un[21], 128, 32);
-  { const int wo[2] = {W, 32}; P.conv3(G_CONVOUT, un[24], un[25], W + 32, wo, 2); }
+  { const int wo[2] = {W, 32}; P.conv3(G_CONVOUT, un[24], un[25], W + 32, wo, 2); P.conv3(G_CONVOUTF, un[24], un[25], W + 32, wo, 2, 1u); }
   P.conv3_dgrad(G_UB_OUTA, un[24], W, W + 32, 0, W);
   P.conv3_dgrad(G_UB_OUTB, un[24], W, W + 32, W, 32);
   P.convT_dgrad(G_UB_T1, un[20], 128, 32);
@@ -2416,11 +2428,14 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
     // with early termination feat_mlp.0 runs later, over the live tiles only; otherwise the chain kernel produces it right here
     bool chain_done = false;
     const bool want_feat = out->feat != nullptr;
-    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr};
+    // feature_agg has two consumers left on this path — conv1 and conv_out, three taps each: the chain kernel hands it over as the split-bf16 fragments it
+    // holds anyway (same bytes in the same buffer) unless someone wants the fp32 rows: the stage output, or feat_mlp.0 over the live tiles of an early-terminated batch
+    const bool fa_frag = use_chain && !dbg_switch("NERFLOC_NO_FRAG") && (N & 31) == 0 && !out->feature_agg && !(want_feat && term_eps > 0.f);
+    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
     bool have_sigma = false;
-    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr));
+    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag));
     NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -129,6 +129,12 @@ struct NlGemmSeg {
   int ntap;          // 1, or T > 1 (k % 32 == 0): conv taps interleaved per 32-channel block — the segment spans T*k slots of
                      // K-space ordered [block k/32][tap 0..T-1][32]; tap t reads row offset ioff + t - T/2.  Neighbouring chunks then
                      // re-read the same rows (+-1), which L1 still holds; tap-major order streams the source T times through L2
+  int frag;          // 1 (tgemm.hip only; k % 32 == 0): `ptr` is a FRAGMENT-NATIVE split-bf16 image instead of fp32 rows — [32-row tile][k-step of 16][hi | lo][lane][8 bf16],
+                     // lane = (row & 31) + 32 hh holding the k-slots 8 hh .. 8 hh + 7 of the k-step, i.e. exactly the B fragments the consumer's MFMAs take: what
+                     // sample_chain_kernel<.., FRAGOUT> writes for feature_agg (channels of every 32-block in ACCUMULATOR order: the layer's weights are packed to
+                     // match, G_CONV1F / G_CONVOUTF).  The consumer loads 16-byte pieces that are contiguous across the wave and converts nothing (round 5).
+                     // 2: fp32 rows as ever, but the layer's K order inside every 32-block is that accumulator order (the same packed weights serve both source
+                     // formats, so a batch renders to the same bits whichever format its chunk took)
 };
 struct NlGemmArgs {
   NlGemmSeg seg[NL_GEMM_MAX_SEG];

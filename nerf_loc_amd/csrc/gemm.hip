@@ -313,6 +313,7 @@ int launch_bn(const NlGemmArgs& a, int precision, hipStream_t st) {
 int nl_gemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   if (a.M <= 0) return NL_OK;
   if (nl_tgemm_supported(a, precision)) return nl_tgemm_launch(a, precision, st);
+  for (int s = 0; s < a.nseg; ++s) if (a.seg[s].frag) return NL_ERR_UNSUPPORTED;   // a fragment-native source is the streaming kernel's alone
   if (a.epi != NL_EPI_NONE || a.act == NL_ACT_LRELU_MASK) return NL_ERR_UNSUPPORTED;   // callers check nl_tgemm_supported() before asking for a fused epilogue
   if (a.N <= 64) return launch_bn<64>(a, precision, st);
   // 128-wide column blocks also for N = 256, in every precision: 2 waves/SIMD instead of 1 hides the tile-load latency better than the

@@ -138,6 +138,13 @@ __device__ __forceinline__ unsigned lrelu_hi2_f16(float& v0, float& v1) {
   return hi;
 }
 // sc_hi / sc_lo: the lane's (= the row's) power-of-two block scales of the two images (both conversions DIVIDE by their scale operand)
+// ... + the running row maximum of |value| in the same statement (an asm boundary costs a compiler-inserted s_nop: 120 per tile as a separate v_max3)
+__device__ __forceinline__ unsigned lrelu_hi2_f16_amax(float& v0, float& v1, float& m) {
+  unsigned hi; float t0, t1;
+  asm("v_mul_f32 %3, 0x3c23d70a, %1\n\tv_mul_f32 %4, 0x3c23d70a, %2\n\tv_max_f32 %1, %1, %3\n\tv_max_f32 %2, %2, %4\n\tv_max3_f32 %5, |%1|, |%2|, %5\n\tv_cvt_pk_f16_f32 %0, %1, %2"
+      : "=&v"(hi), "+v"(v0), "+v"(v1), "=&v"(t0), "=&v"(t1), "+v"(m));
+  return hi;
+}
 template <int HALF>
 __device__ __forceinline__ void mx_bytes2(float v0, float v1, unsigned hi, unsigned& h8, unsigned& l8, float sc_hi, float sc_lo) {
   float t0, t1;
@@ -558,9 +565,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
             amax = 0.f;
           }
           ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
-          ehi = lrelu_hi2_f16(ev0, ev1);
+          if constexpr (L < 2) ehi = lrelu_hi2_f16_amax(ev0, ev1, amax); else ehi = lrelu_hi2_f16(ev0, ev1);
           Xh[out][fo][d] = ehi;
-          if constexpr (L < 2) amax2(amax, ev0, ev1);
         } else mx_bytes2<d & 1>(ev0, ev1, ehi, X8[out][fo >> 2][0][2 * (fo & 3) + (d >> 1)], X8[out][fo >> 2][1][2 * (fo & 3) + (d >> 1)], xs_hi[out], xs_lo[out]);
       } else if constexpr (sub == 0) {
         ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];

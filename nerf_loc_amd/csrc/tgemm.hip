@@ -140,7 +140,9 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
   };
   // activation fragments of chunk c: 2 k-steps x 8 floats of this lane's source row, straight into registers.  Conv halo
   // rows and rows >= M read a device zero page instead (no masking arithmetic).
-  auto act_ptr = [&](int c) __attribute__((always_inline)) -> const float* {
+  // fr (wave-uniform) = NlGemmSeg::frag of the chunk's segment.  1: a fragment-native split-bf16 image — the four 16-byte pieces of the lane are
+  // [k-step 0: hi | lo | k-step 1: hi | lo], 1 KB apart; 0 / 2: fp32 rows, 2 k-steps x 8 floats
+  auto act_ptr = [&](int c, int& fr) __attribute__((always_inline)) -> const float* {
     const int k0 = 32 * c;
     const int s = tg_find_seg(a, k0);
     const NlGemmSeg& sg = a.seg[s];
@@ -158,14 +160,24 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
       ok = ok && i >= 0 && i < a.Li;
       row = q * a.Li + i;
     }
-    return (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + 8 * hh;
+    fr = F16 ? 0 : sg.frag;
+    if (fr == 1) return ok ? sg.ptr + ((size_t)(row >> 5) * (sg.k >> 4) + (kbase >> 4)) * 512 + ((row & 31) + 32 * hh) * 4 : p_zeros;
+    // fp32 rows: k-slot 8 hh + t of a k-step is channel 8 hh + t (natural order), or (frag == 2: the layer's weights are packed for the chain kernel's
+    // fragments) channel (t & 3) + 8 (t >> 2) + 4 hh of the step's 16 — two 16-byte loads either way
+    return (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + (fr == 2 ? 4 : 8) * hh;
   };
-  auto load_act = [&](int c, float4 (&raw)[4]) __attribute__((always_inline)) {
-    const float* p = act_ptr(c);
+  auto act_off = [](int fr, int pc) __attribute__((always_inline)) { return fr == 1 ? 256 * pc : 16 * (pc >> 1) + (fr == 2 ? 8 : 4) * (pc & 1); };
+  auto load_act = [&](int c, float4 (&raw)[4], int& fr) __attribute__((always_inline)) {
+    const float* p = act_ptr(c, fr);
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) raw[pc] = *(const float4*)(p + 16 * (pc >> 1) + 4 * (pc & 1));
+    for (int pc = 0; pc < 4; ++pc) raw[pc] = *(const float4*)(p + act_off(fr, pc));
   };
-  auto convert = [&](const float4 (&raw)[4], tg_bf16x8 (&bh)[2], tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
+  auto convert = [&](const float4 (&raw)[4], int fr, tg_bf16x8 (&bh)[2], tg_bf16x8 (&bl)[2]) __attribute__((always_inline)) {
+    if (fr == 1) {   // (wave-uniform branch around vector moves only: the MFMAs stay in one block)
+      bh[0] = __builtin_bit_cast(tg_bf16x8, raw[0]); bl[0] = __builtin_bit_cast(tg_bf16x8, raw[1]);
+      bh[1] = __builtin_bit_cast(tg_bf16x8, raw[2]); bl[1] = __builtin_bit_cast(tg_bf16x8, raw[3]);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const float v[8] = {raw[2 * ks].x, raw[2 * ks].y, raw[2 * ks].z, raw[2 * ks].w,
@@ -214,32 +226,35 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
   // (the accumulators must stay in AGPRs).
   tg_bf16x8 wreg[NPW];
   float4 raw[4];
+  int raw_fr = 0;   // what `raw` holds (see act_ptr)
   auto clampc = [&](int c) { return c < NC ? c : NC - 1; };
-  load_act(0, raw); load_w(0, wreg);
+  load_act(0, raw, raw_fr); load_w(0, wreg);
   store_w(0, wreg);
   __syncthreads();
   for (int g = 0; g < NC; ++g) {   // one straight-line body, no control flow around the MFMAs (accumulators stay put)
     TG_T(g < 40 ? g : 40);
     tg_bf16x8 bh[2], bl[2];
-    convert(raw, bh, bl);
+    convert(raw, raw_fr, bh, bl);
     // The next chunk's 4 activation loads (lane = row: ~64 cycles each in the CU's address unit) and NPW weight loads go out one at a
     // time between the MFMA groups instead of as a burst in front of them: a burst makes every wave of the workgroup wait at issue
     // (first half of the chunk only: the weights are stored to LDS right after it; chunks of fewer row tiles are too short for this and
     // keep the loads in front)
     if constexpr (NRT == 8) {
-      const float* ap = act_ptr(clampc(g + 1));
+      int nfr = 0;
+      const float* ap = act_ptr(clampc(g + 1), nfr);
       const tg_bf16x8* wp = w_ptr(clampc(g + 1));
       compute(g & 1, bh, bl, [&](int tt) __attribute__((always_inline)) {
         constexpr int NLD = 4 + NPW, nh = NRT;   // slots 0 .. NRT-1
 #pragma unroll
         for (int l = 0; l < NLD; ++l)
           if (l * nh / NLD == tt) {
-            if (l < 4) raw[l] = *(const float4*)(ap + 16 * (l >> 1) + 4 * (l & 1));
+            if (l < 4) raw[l] = *(const float4*)(ap + act_off(nfr, l));
             else if (stager) wreg[l - 4] = wp[NWS * (l - 4) * 64];
           }
       });
+      raw_fr = nfr;
     } else {
-      load_act(clampc(g + 1), raw);
+      load_act(clampc(g + 1), raw, raw_fr);
       load_w(clampc(g + 1), wreg);
       compute(g & 1, bh, bl, [](int) __attribute__((always_inline)) {});
     }
@@ -520,8 +535,12 @@ struct ChainGeo {
   }
 };
 
-template <bool X3, bool FEAT, bool QUERY>
+// FRAGOUT (chain program only; round 5): feature_agg leaves the kernel as the split-bf16 B fragments the LayerNorm epilogue builds anyway (Xh / Xl: feat_mlp.0's
+// operand) in the fragment-native layout of NlGemmSeg::frag — 32 coalesced 1-KB stores per tile instead of 32 row stores — and the ray U-Net's conv1 / conv_out
+// (three taps each) load them as they are: no fp32 row loads (lane = row: 64 cache lines per instruction), no hi / lo split per tap.  Same bytes, same values.
+template <bool X3, bool FEAT, bool QUERY, bool FRAGOUT = false>
 __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a, const int ntiles) {
+  static_assert(!(FRAGOUT && QUERY), "the query program has no feature_agg");
   using Geo = ChainGeo<QUERY>;
   constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = Geo::NCH, NB = 4;
   constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per ring slot (sized for 8 row tiles)
@@ -535,7 +554,9 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
   // stores go through buffer descriptors: rows past M (and the deferred stores of the tile before the first) carry an out-of-range
   // offset and are dropped, so every store instruction is always issued and the vmcnt bookkeeping below is exact
   constexpr unsigned DROP = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)(QUERY ? a.Q : a.FA), 0, a.M * (QUERY ? 512 : 1024), 0x00020000);
+  // (FRAGOUT: whole 32-row tiles of 32 KB; a tile past the last row is out of range and dropped like a row past M otherwise)
+  const __amdgpu_buffer_rsrc_t rFA = __builtin_amdgcn_make_buffer_rsrc((void*)(QUERY ? a.Q : a.FA), 0, FRAGOUT ? ((a.M + 31) >> 5) * 32768 : a.M * (QUERY ? 512 : 1024),
+                                                                       0x00020000);
   const __amdgpu_buffer_rsrc_t rFT = __builtin_amdgcn_make_buffer_rsrc((void*)(FEAT ? a.fth : a.FA), 0, a.M * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBL = __builtin_amdgcn_make_buffer_rsrc((void*)a.blA, 0, a.M * 128, 0x00020000);
   for (int i = tid; i < 256; i += 256) {
@@ -585,6 +606,15 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
                                            rowoff + (32 * rt + 8 * gq) * 4, 0, 0);
   };
 
+  // feature_agg store q (0..31) of the current tile: fp32 row piece q of `fa`, or (FRAGOUT) fragment q & 3 = [hi k-step 0 | hi k-step 1 | lo 0 | lo 1] of row tile q >> 2
+  unsigned fragoff = 0;   // byte offset of this lane's 16 bytes in the tile's first fragment block
+  auto store_FA = [&](int q, unsigned rowoff) __attribute__((always_inline)) {
+    if constexpr (FRAGOUT) {
+      const int rt = q >> 2, w = q & 3, sI = w & 1, part = w >> 1;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tg_u32x4, part ? Xl[2 * rt + sI] : Xh[2 * rt + sI]), rFA,
+                                             fragoff + (unsigned)(((2 * rt + sI) * 2 + part) * 1024), 0, 0);
+    } else store_fa(q, rFA, rowoff);
+  };
   // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`; filler(step) runs between the MFMA groups
   auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2], auto& dst, auto&& filler) __attribute__((always_inline)) {
     constexpr int NRT = decltype(Nc)::value, nt = 2 * NRT;
@@ -667,6 +697,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
     int m_n, mm_n; bool mok_n;
     row_of(tile_next < ntiles ? tile_next : tile, m_n, mm_n, mok_n);
     const unsigned row1k = mok_c ? (unsigned)m_c * 1024u + 16u * hh : DROP;   // this lane's row in the (N, 256) outputs
+    fragoff = (unsigned)(tile * 4 + wave) * 32768u + (unsigned)lane * 16u;
     tg_static_for<NCH>([&](auto Cc) __attribute__((always_inline)) {
       constexpr int c = decltype(Cc)::value, kd = Geo::kind(c), g = Geo::idx(c);
       // chunk c must have landed: younger operations are the pieces of chunks c+1, c+2 and the other traffic issued since chunk c-3
@@ -695,7 +726,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           if constexpr (kd == CK_G2) load_oraw(4 * g + k, mm_c);
           else if constexpr (kd == CK_FC && g < 2) load_oraw(8 + 4 * g + k, mm_c);
           else if constexpr (kd == CK_FC) { if constexpr (FEAT) store_fa(16 + 4 * (g - 2) + k, rFT, prev_row); }   // previous tile's rows 16..23
-          else if constexpr (kd == CK_F0) { if (k < 3) store_fa(8 + 3 * g + k, rFA, row1k); else load_traw(g, mm_n); }
+          else if constexpr (kd == CK_F0) { if (k < 3) store_FA(8 + 3 * g + k, row1k); else load_traw(g, mm_n); }
         }
       };
       auto mem_fill = [&](int tt) __attribute__((always_inline)) { if ((tt & 3) == 1) mem_op(tt >> 2); };
@@ -778,7 +809,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
           // row tiles 0..3: the previous tile's last rows (they sit in fa[6], fa[7], overwritten in iterations 6, 7); 4..7: this tile's first
           if (rt < 4) { if constexpr (FEAT) { store_fa(24 + 2 * rt, rFT, prev_row); store_fa(25 + 2 * rt, rFT, prev_row); } }
-          else { store_fa(2 * (rt - 4), rFA, row1k); store_fa(2 * (rt - 4) + 1, rFA, row1k); }
+          else { store_FA(2 * (rt - 4), row1k); store_FA(2 * (rt - 4) + 1, row1k); }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -857,6 +888,7 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   for (int s = 0; s < a.nseg; ++s) {
     const NlGemmSeg& g = a.seg[s];
     if (!g.vec || (g.k & 31) || g.rdiv > 1 || g.ld < g.k || g.ntap < 1) return false;
+    if (g.frag && precision == NL_PREC_F16X3_INTERNAL) return false;   // (split-bf16 fragments / accumulator K order: the bf16 modes only)
   }
   return true;
 }
@@ -919,9 +951,9 @@ int chain_grid(int ntiles, dim3* grid) {
 // feature_agg (+ feat_mlp.0's rows when fth != null, + the blend projection) from the attention rows O and out_fc's hidden rows T64
 int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
                            size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
-                           float* blA, int64_t M, int precision, hipStream_t st) {
+                           float* blA, int64_t M, int precision, hipStream_t st, bool frag_out) {
   if (M <= 0) return NL_OK;
-  if ((int64_t)M * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  if ((int64_t)(M + 31) * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   const int ntiles = (int)nl_cdiv(M, 128);
   dim3 grid;
   if (chain_grid(ntiles, &grid) != NL_OK) return NL_ERR_HIP;
@@ -930,10 +962,15 @@ int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale
   a.off_g2 = (unsigned)off_g2; a.off_fc = (unsigned)off_fc; a.off_f0 = (unsigned)off_f0; a.off_ba = (unsigned)off_ba;
   a.bias_g2 = bias_g2; a.bias_f0 = bias_f0; a.FA = FA; a.fth = fth; a.blA = blA; a.M = (int)M;
   const bool x3 = precision == NL_PREC_BF16X3;
-  if (x3 && fth) hipLaunchKernelGGL((sample_chain_kernel<true, true, false>), grid, dim3(256), 0, st, a, ntiles);
-  else if (x3) hipLaunchKernelGGL((sample_chain_kernel<true, false, false>), grid, dim3(256), 0, st, a, ntiles);
-  else if (fth) hipLaunchKernelGGL((sample_chain_kernel<false, true, false>), grid, dim3(256), 0, st, a, ntiles);
-  else hipLaunchKernelGGL((sample_chain_kernel<false, false, false>), grid, dim3(256), 0, st, a, ntiles);
+#define NL_CHAIN(FR)                                                                                                            \
+  do {                                                                                                                          \
+    if (x3 && fth) hipLaunchKernelGGL((sample_chain_kernel<true, true, false, FR>), grid, dim3(256), 0, st, a, ntiles);         \
+    else if (x3) hipLaunchKernelGGL((sample_chain_kernel<true, false, false, FR>), grid, dim3(256), 0, st, a, ntiles);          \
+    else if (fth) hipLaunchKernelGGL((sample_chain_kernel<false, true, false, FR>), grid, dim3(256), 0, st, a, ntiles);         \
+    else hipLaunchKernelGGL((sample_chain_kernel<false, false, false, FR>), grid, dim3(256), 0, st, a, ntiles);                 \
+  } while (0)
+  if (frag_out) NL_CHAIN(true); else NL_CHAIN(false);
+#undef NL_CHAIN
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
 
