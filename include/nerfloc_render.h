@@ -288,8 +288,9 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
  * against several retrieved support sets, or several query images are rendered at once): job i renders its rays against its own nl_frame — its own support
  * views, tables and workspace — exactly as nl_render_rays_ex(cfg, packed, job.frame, ...) would (bit-identical outputs), but the jobs' launch chains are
  * issued on library-owned streams forked from `stream` and joined back into it, so that PoseOptimizer-sized batches (512 rays: a fifth of the chip) of
- * different frames fill the machine together.  Jobs that share a frame run one after the other on one stream.  The first call creates the streams (not
- * capturable into a HIP graph; later calls are).  A single launch over frames with different tables would need per-ray table pointers in every kernel; it is
+ * different frames fill the machine together.  Jobs that share a frame run one after the other on one stream.  The first call ON A DEVICE creates that device's
+ * streams (one pool per device, keyed by hipGetDevice(): a process may render on several GPUs; that call is not capturable into a HIP graph, later ones are).  Jobs
+ * of different frames run concurrently: their workspaces must not overlap (NL_ERR_BAD_ARG otherwise); jobs of one frame may share one.  A single launch over frames with different tables would need per-ray table pointers in every kernel; it is
  * not what this does. */
 typedef struct nl_render_job {
   const nl_frame* frame;

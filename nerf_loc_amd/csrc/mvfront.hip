@@ -36,7 +36,9 @@ typedef unsigned mf_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MF_CPL_ = MF_CPL;    // channels per lane in phase B: 3 = all 64 lanes, 12-byte loads; 4 = lanes 0..47, 16-byte loads
 constexpr int MF_C = 192;          // feature channels (3 per lane)
 constexpr int MF_KS = 12;          // k-steps of 32: [mean 192 | variance 192]
-constexpr int MF_LD = 392;         // staging row stride in halves (384 + pad)
+constexpr int MF_LD = 400;         // staging row stride in halves (384 + pad): 200 dwords = 8 (mod 64) — the MFMA phase's ds_read_b128 (lane = (row, k-quarter), 16-lane
+                                   // groups {0-3, 12-15, 20-27} ...) then start on 16 distinct 4-bank slots; 392 (= 4 mod 64) put rows c and c - 1 of neighbouring quarters on one slot:
+                                   // a 2-way conflict in every group (SQ_LDS_BANK_CONFLICT 2.2e8 per launch in round 4; no measurable time: the phase hides behind the tap loads)
 #ifndef MF_NW
 #define MF_NW 8
 #endif
