@@ -669,6 +669,7 @@ class ConditionalNeRF(nn.Module):
             sp = self.support_neural_points["fine"]
             near, far = self._depth_range(data)
             vis = self._vis_featmaps(data)
+            r.set_precision(self._precision)
             r.set_frame(data["topk_images"], data["feat_fine_src"].detach(), vis.detach(), data["topk_Ks"], data["topk_poses"], near, far,
                         {k: sp[k].detach() for k in ("xyz", "feature", "confidence", "direction")})
             rn, rf = rays["depth_range"]
@@ -684,6 +685,21 @@ class ConditionalNeRF(nn.Module):
                                                                   "want_feat": bool(self.args.render.render_feature)}))
         self._frame_token = {}   # (the single-frame renderers' tables no longer describe the module's caches)
         outs = render_rays_multi(jobs)
+        if self.precision_guard:   # the conditioning check of `_guarded`, per frame: a frame beyond its mode's validated range is rendered again in the safer mode
+            for i, job in enumerate(jobs):
+                r = job[0]
+                amax = r.diagnostics()["logit_absmax"]
+                mode = r.precision
+                while mode in self.LOGIT_LIMIT and amax > self.LOGIT_LIMIT[mode]:
+                    mode = self._SAFER[mode]
+                if mode != r.precision:
+                    self.guard_events.append({"logit_absmax": amax, "from": r.precision, "to": mode, "frame": i})
+                    del self.guard_events[:-64]
+                    r.set_precision(mode)
+                    dc = outs[i].get("depth_coarse")
+                    outs[i] = r.render_rays(job[1], job[2], job[3], **job[4])
+                    if dc is not None:
+                        outs[i]["depth_coarse"] = dc
         for o_, dc in zip(outs, dcs):
             o_["depth_coarse"] = dc
         return outs
@@ -743,8 +759,9 @@ class ConditionalNeRF(nn.Module):
                 dcs.append(dc)
             os_.append(o); ds_.append(d); zs.append(z); counts.append(R)
             cs.append(rays["pose"][:3, 3].detach().to(o.device).expand(R, 3))
-        out = r.render_rays(torch.cat(os_), torch.cat(ds_), torch.cat(cs).contiguous(), z_vals=torch.cat(zs),
-                            white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)), want_feat=bool(self.args.render.render_feature))
+        O_, D_, C_, Z_ = torch.cat(os_), torch.cat(ds_), torch.cat(cs).contiguous(), torch.cat(zs)
+        out = self._guarded(r, lambda: r.render_rays(O_, D_, C_, z_vals=Z_, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                                                     want_feat=bool(self.args.render.render_feature)))
         outs = [dict(zip(out.keys(), parts)) for parts in zip(*(torch.split(v, counts) for v in out.values()))]
         for o_, dc in zip(outs, dcs):
             o_["depth_coarse"] = dc

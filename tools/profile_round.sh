@@ -2,7 +2,7 @@
 # Collect the measurements a round's docs cite, on the GPU box (run through gpurun): bench lines of every BASELINE config, rocprofv3 kernel
 # traces (with and without the side stream) + the timeline of one step, the separate PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE) and the HBM
 # traffic summary, the pose-refinement step.  Usage: bash tools/profile_round.sh <tag>   -> gpurun_out/<tag>/ (copy what is cited into profiles/)
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
