@@ -282,7 +282,8 @@ def main():
     result["roofline"]["clock_GHz_under_load"] = {"point_fused2_kernel": diag["point_kernel_GHz"], "peak_assumes": 2.4,
                                                   "how": "s_memtime cycles / s_memrealtime of workgroup 0 over the last launch (nl_frame_diagnostics)"}
     result["conditioning"] = {"attention_logit_absmax": diag["logit_absmax"], "table_absmax": diag["table_absmax"],
-                              "note": "the parity modes are validated to 1e-4 of the CPU oracle up to |logit| ~ 30 (f16mx) / 60 (bf16x3); tools/scale_sweep.py"}
+                              "note": "conditioning indicator of DESIGN.md 2.3: the parity modes are validated to 1e-4 of the CPU oracle up to max |attention logit| = 100 (f16mx) / 500 (bf16x3) "
+                                      "(tools/scale_sweep.py, profiles/r5_scale_sweep.txt); the drop-in module escalates the precision beyond that"}
     if launches.value > 0:
         K, F, W = 8, cfg.C + 3, cfg.W
         result["roofline"]["parity_mode_ceiling"]["dominant_kernel"] = K * (496 + (F + 90) * W + 2 * W * W + 2 * 128 * W + 16384 / K) / ex_point
