@@ -271,16 +271,28 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // byte offsets into the k / v rows: the wave's first row of the tile, this lane's row.  (The first tile's region 0 runs the "previous tile's" last v head on
   // whatever the accumulator holds: out of range = dropped, like ooff_prev)
   unsigned kvtile = 0, kvtile_prev = 0x80000000u, kvrow = 0;
-  const unsigned wvoff = wave * 1024 + lane * 16;   // piece p = 4 i + wave of a chunk
-  uint4* lw = lds_all + wave * 64;
-  unsigned soff = 0;                                // running stream offset of the next piece (scalar)
+  // Wave w loads the ppw(c) CONSECUTIVE 1-KB pieces [w ppw, (w + 1) ppw) of a chunk, in groups of four: ONE scalar stream offset and ONE M0 (LDS base) per group, the
+  // piece inside its group through the instruction's 12-bit offset, which the hardware adds to the memory address AND to the LDS address (round 5: pieces p = 4 i + w lay
+  // 4 KB apart, every one of a tile's 216 needed its own s_mov m0 + s_addk: 432 of the tile loop's ~6 800 issue slots; now ~110)
+  const unsigned wvoff = lane * 16;
+  constexpr int PPW_L1 = GG::ppw(0), PPW_W = GG::ppw(NRT);   // pieces per wave: layer-1 chunks, wide chunks
+  typedef __attribute__((address_space(3))) uint4 lds_u4q;
+  lds_u4q* const lwL1 = (lds_u4q*)lds_all + wave * (PPW_L1 * 64);
+  lds_u4q* const lwW = (lds_u4q*)lds_all + wave * (PPW_W * 64);
+  const unsigned wdelta = (unsigned)wave * (unsigned)((PPW_W - PPW_L1) * 1024);   // a wave's offset inside a wide chunk minus its offset inside a layer-1 chunk
+  unsigned soff = 0;                                // running stream offset of the current group (scalar), the wave's share included
   auto dma_piece = [&](auto Cc, auto Ic) __attribute__((always_inline)) {
-    constexpr int c = GG::cm(decltype(Cc)::value), i = decltype(Ic)::value;
-    constexpr int want = GG::gkb(c) * 1024 + i * 4096;
-    constexpr int prev = i == 0 ? GG::gkb(c - 1) * 1024 + (GG::ppw(c - 1) - 1) * 4096 : want - 4096;   // gkb wraps: chunk -1 = NC-1
-    soff += (unsigned)(want - prev);   // pieces are issued in stream order: one scalar add per piece
-    asm volatile("" : "+s"(soff));     // opaque, so that the offsets are not re-materialised (and hoisted) as 225 constants
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + (c % NBUF) * SLOT + i * 256), 16, wvoff, soff, 0, 0);
+    constexpr int c = GG::cm(decltype(Cc)::value), i = decltype(Ic)::value, g = i / 4, r = i % 4;
+    if constexpr (r == 0) {
+      constexpr int cp = g == 0 ? GG::cm(c - 1) : c, gp = g == 0 ? (GG::ppw(c - 1) - 1) / 4 : g - 1;   // the group issued before this one (gkb wraps: chunk -1 = NC-1)
+      constexpr int want = GG::gkb(c) * 1024 + g * 4096, prev = GG::gkb(cp) * 1024 + gp * 4096;
+      soff += (unsigned)(want - prev);   // groups are issued in stream order: one scalar add per group
+      if constexpr (g == 0 && GG::ppw(c) > GG::ppw(c - 1)) soff += wdelta;
+      if constexpr (g == 0 && GG::ppw(c) < GG::ppw(c - 1)) soff -= wdelta;
+      asm volatile("" : "+s"(soff));     // opaque, so that the offsets are not re-materialised (and hoisted) as constants
+    }
+    lds_u4q* const base = GG::ppw(c) == PPW_L1 ? lwL1 : lwW;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + (c % NBUF) * SLOT + g * 256), 16, wvoff, soff, r * 1024, 0);
   };
 
   // ---------------------------------------------------------------- register state
@@ -815,7 +827,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   };
 
   // ---------------------------------------------------------------- pipeline start
-  soff = (unsigned)(GG::gkb(NC - 1) * 1024 + (GG::ppw(NC - 1) - 1) * 4096);   // the "previous piece" of the very first one
+  soff = (unsigned)(GG::gkb(NC - 1) * 1024 + ((GG::ppw(NC - 1) - 1) / 4) * 4096) + (unsigned)wave * (unsigned)(GG::ppw(NC - 1) * 1024);   // the "previous group" of the very first one
   static_for<3>([&](auto Cc) __attribute__((always_inline)) {
     static_for<GG::ppw(decltype(Cc)::value)>([&](auto Ic) __attribute__((always_inline)) { dma_piece(Cc, Ic); });
   });
