@@ -192,12 +192,19 @@ struct BestK {
 #ifndef KNN_KO
 #define KNN_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no selection loop, 2 no leaf candidates, 4 no breadth-first descent
 #endif
+#ifdef KNN_STATS   // debug build: step counts over one search, printed by nl_knn_search (tools/build_variant.sh stats knn.hip -DKNN_STATS)
+__device__ unsigned long long knn_stats[16];
+#define KNN_CNT(i, v) do { if (__lane_id() == 0) atomicAdd(&knn_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define KNN_CNT(i, v)
+#endif
 template <int K>
 __device__ __forceinline__ void select_into(BestK<K>& best, unsigned kd, unsigned ki, unsigned kp) {
   if (KNN_KO & 1) { best.d ^= kd & 1u; return; }
   while (true) {
     const bool cont = kd < best.td || (kd == best.td && ki < best.ti);
     if (__ballot(cont) == 0ull) break;
+    KNN_CNT(2, 1);
     const unsigned dmin = wave_umin(cont ? kd : 0xffffffffu);
     const bool tie = cont && kd == dmin;
     const u64 tm = __ballot(tie);
@@ -254,17 +261,22 @@ __device__ __forceinline__ void candidate(const QueryCtx& c, const float4* __res
 }
 
 // one contiguous range [rs, rs+len) (wave-uniform), 64 candidates at a time
-template <int K, bool DEDUPE>
-__device__ __forceinline__ void scan_range(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, BestK<K>& best,
+// (sink(kd, ki, position): what becomes of the batch's candidates — the selection loop, or the deferred list of knn_wave_kernel)
+template <int K, bool DEDUPE, class Sink>
+__device__ __forceinline__ void scan_range(const QueryCtx& c, const float4* __restrict__ sorted, int rs, int len, int lane, BestK<K>& best, Sink&& sink,
                                            bool dedupe_now = true, unsigned ubits = 0xffffffffu) {
   for (int base = 0; base < len; base += 64) {
+    KNN_CNT(3, 1);
     unsigned kd, ki;
     candidate<K, DEDUPE>(c, sorted, base + lane < len, rs + base + lane, best, kd, ki, dedupe_now, ubits);
-    select_into<K>(best, kd, ki, (unsigned)(rs + base + lane));
+    sink(kd, ki, (unsigned)(rs + base + lane));
   }
 }
 
-constexpr int FRONT_CAP = 256;   // frontier entries per wave (nodes kept as leaves beyond that)
+#ifndef KNN_FRONT_CAP
+#define KNN_FRONT_CAP 128   // (256 -> 128 in round 5: 15 KB of LDS per workgroup instead of 23.5 = 8 waves per SIMD instead of 6: 0.80 -> 0.70 ms at config 2; a fuller frontier spills into coarse leaves, exact either way)
+#endif
+constexpr int FRONT_CAP = KNN_FRONT_CAP;   // frontier entries per wave (nodes kept as leaves beyond that)
 constexpr int LEAF_CAP = 128;
 constexpr int LEAF_COUNT_MAX = 8;   // nodes with <= this many points are scanned instead of expanded; also the slot width
 
@@ -274,6 +286,8 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
                                                        int Kout, int* __restrict__ idx_out, float* __restrict__ d2_out) {
   __shared__ unsigned s_front[4][2][FRONT_CAP], s_fxyz[4][2][FRONT_CAP];   // Morton prefix; cell coordinates x | y << 10 | z << 20
   __shared__ int s_leaf_s[4][LEAF_CAP], s_leaf_l[4][LEAF_CAP];
+  __shared__ u64 s_ckey[4][64];        // deferred selection: the keys within the bound, in arrival order ...
+  __shared__ unsigned s_cpos[4][64];   // ... and their positions in the sorted array
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n0 = __builtin_amdgcn_readfirstlane((nl_xcd_block() * 4 + wv) * SPW);
   QueryCtx c;
@@ -281,7 +295,10 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   c.cell = gpp->cell; c.slack = 1e-3f * c.cell;
   const float inv_cell = gpp->inv_cell;
   bool prev_full = false;   // the previous query of this wave found K neighbours, whose sorted-array positions are
-  unsigned ppos = 0;        // in ppos (lane k < K)
+  unsigned ppos = 0;        // in ppos of the lanes with pkeep set (lane k < K after a selection-loop query; the lanes that held them after a deferred one)
+  bool pkeep = false;
+  u64* const ckey = s_ckey[wv];
+  unsigned* const cpos = s_cpos[wv];
 
   // A wave answers SPW consecutive queries (neighbouring samples of a ray).  Only the first one pays for phase 1: the K
   // neighbours of the previous query, re-measured from this one, give the bound instead.
@@ -294,6 +311,32 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   best.clear();
   float U;
   const bool dedupe_now = !prev_full;   // phase 1 below pre-fills the list; otherwise it starts empty and no point is seen twice
+  // DEFERRED SELECTION (round 5).  With the bound of the previous query's neighbours (within a few percent of the K-th distance) only ~10 candidates per query pass
+  // `dist2 <= U`, and at least K do (those neighbours themselves).  Feeding them to the selection loop one by one (a wave-min, two ballots and an insert each: ~40 vector
+  // instructions x 10.4 per query = a third of the kernel's instructions, KNN_STATS build) is replaced by: append each batch's survivors to a list in LDS (one ballot +
+  // prefix count per batch), and at the end give every entry its RANK among them (one 64-bit compare per pair: 2 v_readlane + v_cmp_lt_u64 + v_addc per entry) — the
+  // entries of rank < K ARE the answer, already in their output slots.  Same keys, same order: the (dist2 bits, idx) tuples are unique.  U does not tighten during such
+  // a query (it is tight already).  A list that would pass 64 entries is poured into the selection loop's list and the query continues there (exact either way).
+  bool deferred = prev_full;
+  int ncand = 0;
+  auto pour = [&]() __attribute__((always_inline)) {   // the deferred list -> the selection loop's list; the query goes on undeferred
+    unsigned kd = 0xffffffffu, ki = 0xffffffffu, kp = 0;
+    if (lane < ncand) { const u64 k = ckey[lane]; kd = (unsigned)(k >> 32); ki = (unsigned)k; kp = cpos[lane]; }
+    select_into<K>(best, kd, ki, kp);
+    ncand = 0;
+    deferred = false;
+  };
+  const u64 lt_mask = (1ull << lane) - 1ull;
+  auto sink = [&](unsigned kd, unsigned ki, unsigned kp) __attribute__((always_inline)) {
+    if (!deferred) { select_into<K>(best, kd, ki, kp); return; }
+    const bool v = ki != 0xffffffffu;
+    const u64 mv = __ballot(v);
+    if (mv == 0ull) return;
+    const int cn = __popcll(mv);
+    if (ncand + cn > 64) { pour(); select_into<K>(best, kd, ki, kp); return; }
+    if (v) { const int pos = ncand + __popcll(mv & lt_mask); ckey[pos] = ((u64)kd << 32) | (u64)ki; cpos[pos] = kp; }
+    ncand += cn;
+  };
   if (!prev_full) {
     // -------------------------------------------------------------- phase 1: greedy descent -> upper bound U
     unsigned m = 0, mx = 0, my = 0, mz = 0;   // Morton prefix and cell coordinates of the node being descended (wave-uniform)
@@ -315,13 +358,13 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       --L;
     }
     const int rs0 = starts[m << (3 * L)], len0 = starts[(m + 1) << (3 * L)] - rs0;
-    scan_range<K, false>(c, sorted, rs0, len0, lane, best);
+    scan_range<K, false>(c, sorted, rs0, len0, lane, best, sink);
     U = best.full() ? __uint_as_float(best.td) : 3.4e38f;
   } else {
     // upper bound from the previous query's neighbours (lane k < K re-measures its k-th one): the largest of their K
     // distances to this query bounds this query's K-th distance, and is usually within a few percent of it
     float dprev = 0.f;
-    if (lane < K) {
+    if (pkeep) {
       const float4 pt = sorted[ppos];
       const float ddx = c.qx - pt.x, ddy = c.qy - pt.y, ddz = c.qz - pt.z;
       dprev = __fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz));
@@ -337,7 +380,6 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   int* leaf_s = s_leaf_s[wv];
   int* leaf_l = s_leaf_l[wv];
   int nfront = 1, nleaf = 0;
-  const u64 lt_mask = (1ull << lane) - 1ull;
   // Start level: with a bound U the search region is the ball's bounding box, which at the smallest level where it spans at most two nodes per axis is covered by
   // <= 8 nodes — the frontier starts there instead of at the root (near a surface: level 1-2 of 6; every skipped level is a 60-instruction batch of this wave).
   // (Wave-uniform arithmetic; the box is widened by the rounding slack and one cell, and every child still passes the exact box test below.)
@@ -362,27 +404,30 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   }
 #endif
   if (Lstart == GRID_BITS && lane == 0) { front[0] = 0u; fxyz[0] = 0u; }
+  KNN_CNT(4, Lstart); KNN_CNT(5, prev_full ? 0 : 1); KNN_CNT(6 + Lstart, 1);
 
   // leaves hold <= 16 points each: four leaves per 64-lane batch, one per 16-lane slot (no prefix sums, no index search)
   auto flush_leaves = [&]() {
     if (KNN_KO & 2) { nleaf = 0; return; }
     constexpr int SL = LEAF_COUNT_MAX;   // lanes per slot
     for (int b = 0; b < nleaf; b += 64 / SL) {
+      KNN_CNT(1, 1);
       const int e = b + lane / SL;
       const bool ok = e < nleaf;
       const int rs = ok ? leaf_s[e] : 0, ln = ok ? leaf_l[e] : 0;
       unsigned kd, ki;
       candidate<K, true>(c, sorted, (lane % SL) < ln, rs + (lane % SL), best, kd, ki, dedupe_now, __float_as_uint(U));
-      select_into<K>(best, kd, ki, (unsigned)(rs + (lane % SL)));
+      sink(kd, ki, (unsigned)(rs + (lane % SL)));
     }
     nleaf = 0;
-    if (best.full()) U = fminf(U, __uint_as_float(best.td));
+    if (best.full()) U = fminf(U, __uint_as_float(best.td));   // (never full while the query is deferred)
   };
 
   for (int L = (KNN_KO & 4) ? 0 : Lstart; L > 0; --L) {
     int nnext = 0;
     const int sh = 3 * (L - 1);
     for (int base = 0; base < nfront; base += 8) {
+      KNN_CNT(0, 1);
       const int ni = base + (lane >> 3);
       bool keep = false, leaf = false;
       unsigned mc = 0, cxyz = 0;
@@ -412,7 +457,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
       while (mbig) {
         const int src = __builtin_ctzll(mbig);
         mbig &= mbig - 1;
-        scan_range<K, true>(c, sorted, __builtin_amdgcn_readlane(rs, src), __builtin_amdgcn_readlane(cnt, src), lane, best, dedupe_now, __float_as_uint(U));
+        scan_range<K, true>(c, sorted, __builtin_amdgcn_readlane(rs, src), __builtin_amdgcn_readlane(cnt, src), lane, best, sink, dedupe_now, __float_as_uint(U));
         if (best.full()) U = fminf(U, __uint_as_float(best.td));
       }
       const bool small = lf && cnt <= LEAF_COUNT_MAX;
@@ -430,14 +475,34 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   }
   if (nleaf > 0) flush_leaves();
 
-  if (lane < Kout && lane < K) {
-    const unsigned bd = best.d, bi = best.i;   // lane k holds the k-th best
-    const bool ok = bi != 0xffffffffu;
-    idx_out[(size_t)n * Kout + lane] = ok ? (int)bi : 0;
-    d2_out[(size_t)n * Kout + lane] = ok ? __uint_as_float(bd) : 0.f;
+  if (deferred && ncand < K) pour();   // (cannot happen: the previous neighbours lie within the bound; kept so that the slots past the list are written below)
+  if (deferred) {
+    const u64 mine = lane < ncand ? ckey[lane] : ~0ull;
+    const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
+    int rank = 0;
+    for (int jj = 0; jj < ncand; ++jj) {   // wave-uniform trip count; entry jj as a scalar pair against every lane's own key
+      const u64 kj = ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, jj) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)mlo, jj);
+      rank += kj < mine ? 1 : 0;
+    }
+    const bool win = lane < ncand && rank < K;
+    if (win && rank < Kout) {
+      idx_out[(size_t)n * Kout + rank] = (int)mlo;
+      d2_out[(size_t)n * Kout + rank] = __uint_as_float(mhi);
+    }
+    prev_full = true;
+    pkeep = win;
+    ppos = cpos[lane];
+  } else {
+    if (lane < Kout && lane < K) {
+      const unsigned bd = best.d, bi = best.i;   // lane k holds the k-th best
+      const bool ok = bi != 0xffffffffu;
+      idx_out[(size_t)n * Kout + lane] = ok ? (int)bi : 0;
+      d2_out[(size_t)n * Kout + lane] = ok ? __uint_as_float(bd) : 0.f;
+    }
+    prev_full = best.full();
+    pkeep = lane < K;
+    ppos = best.p;
   }
-  prev_full = best.full();
-  ppos = best.p;
   }   // queries of this wave
 }
 
@@ -502,5 +567,19 @@ int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* i
   else { if (big) NL_KNN(8, 16); else NL_KNN(8, 4); }
 #undef NL_KNN
   NL_LAUNCH_CHECK();
+#ifdef KNN_STATS
+  {
+    unsigned long long h[16];
+    hipStreamSynchronize(st);
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_stats), sizeof(h));
+    fprintf(stderr, "knn stats per query (N = %lld): frontier batches %.2f, leaf batches %.2f, selection iterations %.2f, range batches %.2f, start level %.2f, phase-1 %.3f; start-level histogram",
+            (long long)N, (double)h[0] / N, (double)h[1] / N, (double)h[2] / N, (double)h[3] / N, (double)h[4] / N, (double)h[5] / N);
+    for (int l = 0; l <= GRID_BITS; ++l) fprintf(stderr, " %d:%.3f", l, (double)h[6 + l] / N);
+    fprintf(stderr, "\n");
+    hipMemset(nullptr, 0, 0);
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(knn_stats), z, sizeof(z));
+  }
+#endif
   return NL_OK;
 }
