@@ -69,7 +69,11 @@ def test_bf16_throughput_mode_error_is_reported_not_hidden(name):
 
 @pytest.mark.parametrize("n,m,K,kind", [(5000, 3000, 8, "cloud"), (4096, 20000, 8, "sheets"), (2000, 5, 8, "few"), (3000, 700, 1, "cloud"),
                                          (2000, 900, 8, "lattice"), (1500, 1, 8, "one"), (1000, 2000, 8, "far"), (1003, 4000, 8, "cloud"), (37, 500, 1, "cloud"),
-                                         (4096, 6000, 8, "rays"), (600, 300, 8, "dupes"), (1500, 4000, 8, "aniso"), (1200, 9, 8, "rays")])
+                                         (4096, 6000, 8, "rays"), (600, 300, 8, "dupes"), (1500, 4000, 8, "aniso"), (1200, 9, 8, "rays"),
+                                         # ~190 exact ties per location: the deferred-selection list (64 entries) overflows into the selection loop
+                                         (600, 1300, 8, "dupes"),
+                                         # a render-sized batch: the 16-queries-per-wave instance (N >= 2^18)
+                                         (262144 + 37, 2500, 8, "rays")])
 def test_knn_exact_vs_oracle(n, m, K, kind):
     from nerf_loc_amd.renderer import HipRenderer
     from oracle import render_oracle as orc
