@@ -34,19 +34,27 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 
 namespace {
 
 #ifndef PF2_KO
-#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention
+#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention, 16 the second cross-term matrix instruction of every slab skipped (its reads and fills stay): the matrix-pipe time fp6 cross terms would take
 #endif
 constexpr int KO = PF2_KO;
+#ifndef PF2_MX_FP6
+#define PF2_MX_FP6 1   // the cross terms of NL_PREC_F16MX: 1 = MX-FP6 (e2m3, 8 passes per K = 64: 1.5 matrix-instruction equivalents per product), 0 = MX-FP8 (e4m3, 16 passes: 2.0)
+#endif
+constexpr int MXK = PF2_MX_FP6 ? 2 : 1;   // the one MX instance this library carries (pack and launch agree by construction)
 #ifdef PF2_TRACE
 __device__ unsigned long long pf2_trace[256];   // debug: cycle counter at every region start of one tile (block 0, wave 0)
 #endif
 constexpr int NBUF = 4;   // LDS ring slots; chunk c lives in slot c % 4, chunks c+1 .. c+3 are in flight while c is consumed
 
-template <int NRT, bool X3, bool KEEP = false>
+template <int NRT, bool X3, bool KEEP = false, bool MX6 = false>
 struct Geo {
   static constexpr int W = 32 * NRT, PARTS = X3 ? 2 : 1, MPK = X3 ? 3 : 1;   // MPK: MFMAs per k-step
   static constexpr int KSL = 2 * NRT;        // k-steps of the wide layers (K = W)
@@ -79,7 +87,7 @@ struct Geo {
   static constexpr int LDS_U4 = RES_BND + 2;
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
   // (KEEP: + 4 row stores of a k head / 4 x 4 dword stores of a v head: the rows nl_attn_backward reads)
-  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) : (rt(c) < 4 ? 10 : 10) + (KEEP ? 4 : 0); }
+  static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) + (MX6 && (rt(c) & 1) ? 2 : 0) : (rt(c) < 4 ? 10 : 10) + (KEEP ? 4 : 0); }
   static constexpr int RL = cumks(NC) % 3 == 0 ? 3 : 4;   // A-fragment register ring (3 k-steps are live)
   static constexpr int rpos(int runks) { return runks % RL; }
   static_assert(NC % NBUF == 0 && cumks(NC) % RL == 0, "ring positions must be tile-periodic");
@@ -179,6 +187,24 @@ __device__ __forceinline__ unsigned lo2_f16(float v0, float v1, unsigned hi) {
       : "=&v"(lo), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi));
   return lo;
 }
+// residuals of a pair as floats: v - float(hi half) (exact)
+__device__ __forceinline__ void lo2_f32(float v0, float v1, unsigned hi, float& l0, float& l1) {
+  asm("v_fma_mix_f32 %0, %4, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %4, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l0), "=&v"(l1) : "v"(v0), "v"(v1), "v"(hi));
+}
+// The two fp6 packing conversions as asm statements with EARLY-CLOBBER results: hipcc 7.2 lets the builtins' 6-register result overlap the scale operand (seen:
+// v_cvt_scalef32_2xpk16_fp6_f32 v[206:211], v[122:137], v[138:153], v206), and the multi-pass instruction then reads a scale it has already overwritten — one slab of
+// one layer came out with garbage residuals (found with tools/mx6_debug.py: only K slab 2 of base_mlp.4 was off).
+__device__ __forceinline__ u32x6 cvt_pk32_fp6_f16(u32x16 h, float sc) {
+  u32x6 r;
+  asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(r) : "v"(h), "v"(sc));
+  return r;
+}
+__device__ __forceinline__ u32x6 cvt_2xpk16_fp6_f32(f32x16 a, f32x16 b, float sc) {
+  u32x6 r;
+  asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(sc));
+  return r;
+}
 template <bool X3, bool F16>
 __device__ __forceinline__ void split2f(float v0, float v1, unsigned& hi, unsigned& lo) {
   if constexpr (F16) {
@@ -214,7 +240,7 @@ struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; 
 // layers' outputs as bits in the streaming GEMM's ep_maskin layout ([32-row tile][lane][4 dwords]) — so that the staged forward of the branch (an encode kernel,
 // four (N x 8)-row GEMMs through HBM, an attention kernel) is one launch.
 struct Pf2Keep { float* kv; unsigned* mk[3]; unsigned kv_bytes, mk_bytes; };
-template <int NRT, bool X3, bool MX, bool F16 = false, bool KEEP = false>
+template <int NRT, bool X3, int MX, bool F16 = false, bool KEEP = false>
 __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
     float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
@@ -222,7 +248,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   static_assert(!MX || X3, "the MX mode extends the three-term mode");
   static_assert(!F16 || (X3 && !MX), "split-FP16 is a three-term mode");
   static_assert(!KEEP || F16, "the kept masks must come from the split-FP16 forward");
-  using GG = Geo<NRT, X3, KEEP>;
+  constexpr bool MX6 = MX == 2, MX8 = MX == 1;   // cross terms on MX-FP6 (e2m3) / MX-FP8 (e4m3)
+  using GG = Geo<NRT, X3, KEEP, MX6>;
   constexpr int W = GG::W, PARTS = GG::PARTS, MPK = GG::MPK, NC = GG::NC, SLOT = GG::SLOT;
   if (MX || F16) __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 / fp8 conversions saturate instead of producing inf / NaN
   // ONE __shared__ object, read through ONE native vector type with compile-time slot indices: hipcc then keeps the alias
@@ -234,6 +261,10 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   typedef __attribute__((address_space(3))) uint4 lds_u4;
   lds_u4* lds_hi = (lds_u4*)lds_all + 4096 + (threadIdx.x & 63);
   asm volatile("" : "+v"(lds_hi));
+  // (MX-FP6: the 8-byte tails of the fp6 images — lane stride 8 — through a second opaque base of the same kind)
+  typedef __attribute__((address_space(3))) u32x2 lds_u2;
+  lds_u2* lds_hi8 = (lds_u2*)((lds_u4*)lds_all + 4096) + (threadIdx.x & 63);
+  if constexpr (MX6) asm volatile("" : "+v"(lds_hi8));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31, kk = j & 7;
   const unsigned nwg = gridDim.x;
@@ -246,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     const uint4* src = p_wstream + (size_t)GG::STREAM_KB * 64;
     for (int i = tid; i < 2 * PARTS * 64; i += 256) lds_all[GG::RES_RD + i] = src[(i / (PARTS * 64)) * 128 + i % (PARTS * 64)];
     for (int i = tid; i < (64 + 2 * W) / 4; i += 256) lds_all[GG::RES_BIAS + i] = src[256 + i];
-    if (MX) for (int i = tid; i < (2 * NC + 3) / 4 + 2; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];   // + the bounds block
+    if (MX8) for (int i = tid; i < (2 * NC + 3) / 4 + 2; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];   // + the bounds block
   }
   __syncthreads();
 
@@ -305,6 +336,20 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // u = 8 s + t of a lane <-> element t of k-step 4 q + s (the weight images use the same map: any bijection works as long as both operands share it)
   unsigned X8[2][NRT / 2][2][8];
   u32x4 w8[2][4];   // fp8 A operands of a slab, double-buffered by slab parity: [0..1] = w_hi8 (32 bytes per lane), [2..3] = w_lo8
+  // ---- MX-FP6 (MX == 2, round 5): the two cross terms on e2m3 elements, 8 passes per K = 64 instead of 16 (profiles/ubench_mx6_rowtile.txt: conversions, layouts, timing).
+  // A lane's 32 values of a slab are ONE MX block with its own power-of-two scale — 2^(floor(log2 max) - 2), from the values themselves: the largest lands in [4, 8) of e2m3's
+  // 7.5 — for the activations (per row, slab and image; the residual image takes the hi image's scale x 2^-11) and for the weights (per output row and half-slab, from the
+  // packing kernel: byte q of the chunk's two scale dwords).  The f16 B fragments of a slab live in ONE 16-register vector (Xh16): v_cvt_scalef32_pk32_fp6_f16 packs the hi
+  // image from it in one instruction, the matrix instructions read its 4-register quarters; v_cvt_scalef32_2xpk16_fp6_f32 packs the residuals of two row tiles (interleaved:
+  // position 2 i <- first operand, 2 i + 1 <- second; the weights' hi image is stored in that order).
+  u32x16 Xh16[2][NRT / 2];              // [buffer][slab]: dword 4 s + d = fragment dword d of k-step 4 q + s
+  unsigned X6[2][NRT / 2][2][6];        // [buffer][slab][0 = hi6, 1 = lo6][6 dwords]: position P = bits 6 P .. 6 P + 5
+  u32x4 w6a[2][2]; u32x2 w6b[2][2];     // fp6 A operands of a slab, [slab parity][0 = w_hi6, 1 = w_lo6]: dwords 0-3 | 4-5
+  u32x2 wsc6 = {0u, 0u};                // the chunk's weight-scale dwords {w_hi6, w_lo6}: byte q = E8M0 of slab q for this lane's row and K half
+  unsigned xs6h[2] = {0u, 0u}, xs6l[2] = {0u, 0u};   // activation scale bytes [buffer]: byte q = slab q (hi image | residual image = hi - 11)
+  unsigned hp6[2][8];                   // f16 pairs of the two row tiles a slab is made of (until the slab is complete)
+  float lo6t[2][16];                    // their residuals
+  float scf6 = 1.f;
   const int* ssc = reinterpret_cast<const int*>(lds_all + GG::RES_SC);
   // MX mode, round 5: the activations' fp8 images carry a block scale PER ROW AND LAYER instead of the constants 1 / 2^-11 (whose window was |a| = 2^-6 ... 448:
   // beyond it the cross terms saturated and the product fell back to single-fp16 accuracy — tools/scale_sweep.py found it with the feature maps x 8).  The scale of
@@ -319,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   float lmax = 0.f;   // largest |attention logit| this lane has scored: the softmax over nearly tied neighbours turns a logit error e into a weight error ~e, and the
                       // logit error is (relative product error) x |logit| — the conditioning indicator nl_frame_diagnostics reports
   float bnd_c1a = 0.f, bnd_c1x = 0.f, bnd_B2 = 0.f, bnd_bm2 = 0.f, bnd_B3 = 0.f, bnd_bm3 = 0.f, bnd_t = 0.f;
-  if constexpr (MX) {
+  if constexpr (MX8) {
     const float* bf = reinterpret_cast<const float*>(lds_all + GG::RES_BND);
     auto uni = [](float v) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     bnd_c1a = uni(bf[0]); bnd_c1x = uni(bf[1]); bnd_B2 = uni(bf[2]); bnd_bm2 = uni(bf[3]); bnd_B3 = uni(bf[4]); bnd_bm3 = uni(bf[5]);
@@ -441,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         poff[0] = (pq[0] - pp[0]) * sc.inv_span; poff[1] = (pq[1] - pp[1]) * sc.inv_span; poff[2] = (pq[2] - pp[2]) * sc.inv_span;
         prd[0] = pdv[0] - pnd[0]; prd[1] = pdv[1] - pnd[1]; prd[2] = pdv[2] - pnd[2];
         prd[3] = pdv[0] * pnd[0] + pdv[1] * pnd[1] + pdv[2] * pnd[2];
-        if constexpr (MX) {   // |base_mlp.0 row| <= max|T| + sum |w| over the sin / cos / ray-difference columns + sum |w| over the raw-offset columns x max |offset|
+        if constexpr (MX8) {   // |base_mlp.0 row| <= max|T| + sum |w| over the sin / cos / ray-difference columns + sum |w| over the raw-offset columns x max |offset|
           float mo = fabsf(poff[0]);
           amax2(mo, poff[1], poff[2]);
           pn_b1 = fmaf(bnd_c1x, mo, bnd_t + bnd_c1a);
@@ -558,6 +603,28 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     else w8[q & 1][i] = __builtin_bit_cast(u32x4, lds_all[li + lane]);
   };
 
+  // MX-FP6: the images of slab q of chunk c: part 1 of the slot = per slab [w_hi6 dwords 0-3 | w_hi6 dwords 4-5 | w_lo6 dwords 0-3 | w_lo6 dwords 4-5][lane] = 1 K + 512 + 1 K + 512 bytes
+  auto read_w6 = [&](auto Cc, auto Qc, auto Ic) __attribute__((always_inline)) {
+    constexpr int c = GG::cm(decltype(Cc)::value), q = decltype(Qc)::value, i = decltype(Ic)::value;
+    constexpr int lb = ((c % NBUF) * SLOT + GG::ksi(c) * 64) * 16 + q * 3072 + (i >> 1) * 1536 + (i & 1) * 1024;   // byte offset in the LDS object
+    if constexpr ((i & 1) == 0) {
+      constexpr int li = lb / 16;
+      if constexpr (li >= 4096 && li < 8192) w6a[q & 1][i >> 1] = __builtin_bit_cast(u32x4, lds_hi[li - 4096]);
+      else w6a[q & 1][i >> 1] = __builtin_bit_cast(u32x4, lds_all[li + lane]);
+    } else {
+      constexpr int l8 = lb / 8;
+      if constexpr (l8 >= 8192 && l8 < 16384) w6b[q & 1][i >> 1] = lds_hi8[l8 - 8192];
+      else w6b[q & 1][i >> 1] = ((const lds_u2*)(lds_u4*)lds_all)[l8 + lane];
+    }
+  };
+  // ... and the chunk's two scale dwords: behind the images (8 bytes per lane at 28 K of the slot for W = 256)
+  auto read_wsc6 = [&](auto Cc) __attribute__((always_inline)) {
+    constexpr int c = GG::cm(decltype(Cc)::value);
+    constexpr int l8 = (((c % NBUF) * SLOT + GG::ksi(c) * 64) * 16 + (NRT / 2) * 3072) / 8;
+    if constexpr (l8 >= 8192 && l8 < 16384) wsc6 = lds_hi8[l8 - 8192];
+    else wsc6 = ((const lds_u2*)(lds_u4*)lds_all)[l8 + lane];
+  };
+
   // ---------------------------------------------------------------- epilogue micro-steps of chunk C, run inside region C+1
   auto epi_step = [&](auto Cc, auto Ec, auto PrevC) __attribute__((always_inline)) {
     constexpr int C = GG::cm(decltype(Cc)::value), E = decltype(Ec)::value;
@@ -568,7 +635,35 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       constexpr int p = E / SPP, sub = E % SPP;
       constexpr int out = L & 1;   // L1 -> X[0], L2 -> X[1], L3 -> X[0]
       constexpr int fo = 2 * RT + (p >> 2), d = p & 3;
-      if constexpr (MX) {
+      if constexpr (MX6) {
+        constexpr int par = RT & 1, q = RT >> 1;
+        if constexpr (E < 16 && sub == 0) {
+          if constexpr (par == 0 && p == 0) amax = 0.f;   // a slab's block: this tile's and the next one's 16 values of the lane
+          ev0 = acc[AB][2 * p]; ev1 = acc[AB][2 * p + 1];
+          ehi = lrelu_hi2_f16_amax(ev0, ev1, amax);
+          hp6[par][p] = ehi;
+        } else if constexpr (E < 16) {
+          lo2_f32(ev0, ev1, ehi, lo6t[par][2 * p], lo6t[par][2 * p + 1]);
+        } else if constexpr (E == 16) {   // the slab is complete: block scale 2^(ex - 3) for amax = m 2^ex, m in [0.5, 1); the hi image from the f16 fragments
+          int eb = __builtin_amdgcn_frexp_expf(amax) + 124;
+          eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);   // (12: the residual image's byte eb - 11 stays positive; an all-zero block takes any scale)
+          scf6 = __builtin_bit_cast(float, eb << 23);
+          if constexpr (q == 0) { xs6h[out] = (unsigned)eb; xs6l[out] = (unsigned)(eb - 11); }
+          else { xs6h[out] |= (unsigned)eb << (8 * q); xs6l[out] |= (unsigned)(eb - 11) << (8 * q); }
+          const u32x16 H = {hp6[0][0], hp6[0][1], hp6[0][2], hp6[0][3], hp6[0][4], hp6[0][5], hp6[0][6], hp6[0][7],
+                            hp6[1][0], hp6[1][1], hp6[1][2], hp6[1][3], hp6[1][4], hp6[1][5], hp6[1][6], hp6[1][7]};
+          Xh16[out][q] = H;
+          const u32x6 r = cvt_pk32_fp6_f16(H, scf6);
+          X6[out][q][0][0] = r[0]; X6[out][q][0][1] = r[1]; X6[out][q][0][2] = r[2]; X6[out][q][0][3] = r[3]; X6[out][q][0][4] = r[4]; X6[out][q][0][5] = r[5];
+        } else {   // the residual image: two row tiles interleaved, scale x 2^-11
+          const f32x16 l0 = {lo6t[0][0], lo6t[0][1], lo6t[0][2], lo6t[0][3], lo6t[0][4], lo6t[0][5], lo6t[0][6], lo6t[0][7],
+                             lo6t[0][8], lo6t[0][9], lo6t[0][10], lo6t[0][11], lo6t[0][12], lo6t[0][13], lo6t[0][14], lo6t[0][15]};
+          const f32x16 l1 = {lo6t[1][0], lo6t[1][1], lo6t[1][2], lo6t[1][3], lo6t[1][4], lo6t[1][5], lo6t[1][6], lo6t[1][7],
+                             lo6t[1][8], lo6t[1][9], lo6t[1][10], lo6t[1][11], lo6t[1][12], lo6t[1][13], lo6t[1][14], lo6t[1][15]};
+          const u32x6 r = cvt_2xpk16_fp6_f32(l0, l1, scf6 * 0.00048828125f);
+          X6[out][q][1][0] = r[0]; X6[out][q][1][1] = r[1]; X6[out][q][1][2] = r[2]; X6[out][q][1][3] = r[3]; X6[out][q][1][4] = r[4]; X6[out][q][1][5] = r[5];
+        }
+      } else if constexpr (MX) {
         if constexpr (sub == 0) {
           if constexpr (RT == 0 && p == 0) {   // the scales of this layer's output rows (see xs_hi): fixed before its first row tile is converted
             if constexpr (L == 0) set_scale(std::integral_constant<int, 0>{}, cur_b1);
@@ -658,7 +753,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     // its barrier sits in front of unit 8 (NSL - 1) + 3 (every LDS-DMA piece is issued before it), and a layer epilogue must be through before the last slab
     constexpr int NKS = GG::nks(G);
     constexpr bool MXR = MX && GG::layer(G) > 0;
-    constexpr int NS = MXR ? 2 * NKS : MPK * NKS, NSD = MXR ? 2 * NKS - 5 : MPK * (NKS - 1), NSEL = MXR ? 2 * NKS - 8 : NSD;
+    // (MX-FP6: its cross-term instructions take 8 passes like the f16 ones — 6 units per slab, the barrier in front of unit 6 (NSL - 1) + 3)
+    constexpr int NS = MXR ? (MX6 ? 6 * (NKS / 4) : 2 * NKS) : MPK * NKS, NSD = MXR ? (MX6 ? 6 * (NKS / 4) - 3 : 2 * NKS - 5) : MPK * (NKS - 1),
+                  NSEL = MXR ? (MX6 ? 6 * (NKS / 4) - 6 : 2 * NKS - 8) : NSD;
     // LDS-DMA pieces of chunk G+3 (its slot held chunk G-1, which every wave left behind at the previous barrier)
     if constexpr (K < NSD && !(KO & 4)) {
       constexpr int ND = GG::ppw(G + 3), d0 = K * ND / NSD, d1 = (K + 1) * ND / NSD;
@@ -713,7 +810,57 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     constexpr int L = GG::layer(G), NKS = GG::nks(G), AB = G & 3, CK = GG::cumks(G);
     constexpr bool ZI = L == 3;   // k / v projections have no bias: the first MFMA takes C = 0
     constexpr bool NEXT_MX = MX && GG::layer(G + 1) > 0;   // the next chunk's part 1 holds fp8 images (its part 0: f16 fragments)
-    if constexpr (MX && L > 0) {
+    if constexpr (MX6 && L > 0) {
+      constexpr int NSL = NKS / 4, IN = (L + 1) & 1;
+      constexpr bool TR = L == 3 && GG::rt(G) >= 4;   // v heads: D = X . Wv^T (rows = neighbour rows) instead of D^T
+      read_wsc6(Gc);
+      static_for<NSL>([&](auto Qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(Qc)::value;
+        static_for<4>([&](auto Sc) __attribute__((always_inline)) {
+          constexpr int sI = decltype(Sc)::value, ks = 4 * q + sI, pos = GG::rpos(CK + ks);
+          if constexpr (ks == NKS - 1) {
+            if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+          const u32x4 bh = __builtin_shufflevector(Xh16[IN][q], Xh16[IN][q], 4 * sI, 4 * sI + 1, 4 * sI + 2, 4 * sI + 3);
+          if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
+          else if constexpr (ks == NKS - 1) {
+            read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
+            read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+            if constexpr (!NEXT_MX) {   // the next tile's first layer-1 chunk: split-bf16 parts
+              read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 1>{});
+              read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 1>{});
+            }
+          }
+          const f32x16 c0 = (ZI && ks == 0) ? zero16 : acc[AB];
+          acc[AB] = TR ? mfma_h(bh, frh[pos], c0) : mfma_h(frh[pos], bh, c0);
+          fill(Gc, std::integral_constant<int, 6 * q + sI>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        // the two cross terms, 8 passes each: w_hi6 x a_lo6, w_lo6 x a_hi6; scales: byte q of the weights' and of the activations' scale dwords
+        static_for<2>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int im = decltype(Ic)::value;   // 0: w_hi6 x a_lo6, 1: w_lo6 x a_hi6
+          const i32x8 wa = {(int)w6a[q & 1][im][0], (int)w6a[q & 1][im][1], (int)w6a[q & 1][im][2], (int)w6a[q & 1][im][3], (int)w6b[q & 1][im][0], (int)w6b[q & 1][im][1], 0, 0};
+          const unsigned(&xd)[6] = X6[IN][q][1 - im];
+          const i32x8 xb = {(int)xd[0], (int)xd[1], (int)xd[2], (int)xd[3], (int)xd[4], (int)xd[5], 0, 0};
+          const int sw = (int)wsc6[im], sx = (int)(im == 0 ? xs6l[IN] : xs6h[IN]);
+          if constexpr (!((KO & 16) && im == 1) && !((KO & 32) && im == 0) && !((KO & 64) && q >= 2) && !((KO & 128) && q < 2)) {   // (32 / 64 / 128: debugging knock-outs of single cross terms)
+            if constexpr (TR) acc[AB] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xb, wa, acc[AB], 2, 2, q, sx, q, sw);
+            else acc[AB] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[AB], 2, 2, q, sw, q, sx);
+          }
+          if constexpr (q + 1 < NSL) {
+            read_w6(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2 * im>{});
+            read_w6(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2 * im + 1>{});
+          } else if constexpr (NEXT_MX) {
+            read_w6(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * im>{});
+            read_w6(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * im + 1>{});
+          }
+          fill(Gc, std::integral_constant<int, 6 * q + 4 + im>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    } else if constexpr (MX && L > 0) {
       constexpr int NSL = NKS / 4, IN = (L + 1) & 1;
       constexpr bool TR = L == 3 && GG::rt(G) >= 4;   // v heads: D = X . Wv^T (rows = neighbour rows) instead of D^T
       const int swh = ssc[2 * GG::cm(G)], swl = ssc[2 * GG::cm(G) + 1];
@@ -758,7 +905,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         }
         {
           const i32x8 wa = cat8(w8[q & 1][2], w8[q & 1][3]), xb = frag8(X8[IN][q][0]);
-          acc[AB] = TR ? mfma_8(xb, wa, acc[AB], xs_e8h[IN], swl) : mfma_8(wa, xb, acc[AB], swl, xs_e8h[IN]);
+          if constexpr (!(KO & 16)) acc[AB] = TR ? mfma_8(xb, wa, acc[AB], xs_e8h[IN], swl) : mfma_8(wa, xb, acc[AB], swl, xs_e8h[IN]);
+          else asm volatile("" :: "v"(wa), "v"(xb));
           if constexpr (q + 1 < NSL) {
             read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2>{});
             read_w8(Gc, std::integral_constant<int, q + 1>{}, std::integral_constant<int, 3>{});
@@ -798,6 +946,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
           if constexpr (m == 0) {
             read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
             read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+          } else if constexpr (MX6) {
+            read_w6(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 1)>{});
+            read_w6(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 1) + 1>{});
           } else {
             read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 1)>{});
             read_w8(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (m - 1) + 1>{});
@@ -1028,7 +1179,8 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     if (layer == 0) base = (long long)rt * 2 * 6 * 512;
     else base = (long long)NRT * 2 * 6 * 512 + ((long long)(layer - 1) * NRT + rt) * 2 * KSL * 512;
     const long long in_part = ((long long)ks * 64 + lane) * 8 + t;
-    if (mx == 1 && layer > 0) {
+    if (mx == 3 && layer > 0) out[base + in_part] = pf2_f2h(v);   // MX-FP6: the f16 fragments; pack_point_mx6_kernel writes the images and their scales
+    else if (mx == 1 && layer > 0) {
       // MX chunk: part 0 = f16(w) in the same fragment order; part 1 = per slab q of 4 k-steps [w_hi8 bytes 0-15 | 16-31 | w_lo8 bytes 0-15 | 16-31][lane][16], byte
       // u = 8 (ks & 3) + t of a lane <-> this element; hi8 = e4m3(f16(w) / s_hi), lo8 = e4m3((w - f16(w)) / s_lo), scales per chunk (pf2_mx_scale_kernel)
       const int c = (layer - 1) * NRT + NRT + rt;   // chunk index (k / v heads: rt = 0..7 behind layer 3's base)
@@ -1082,6 +1234,61 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
   }
 }
 
+// MX-FP6 images of the wide chunks (layers 2, 3, k / v heads): one thread = one MX block = (chunk, slab q, lane, image).  The 32 weights of output row 32 rt + (lane & 31)
+// whose k-slots belong to half lane >> 5 of slab q, in the POSITION order of the activation image they meet in the matrix instruction:
+//   image 0 = w_hi6 = e2m3(f16(w)) meets the residual image (v_cvt_scalef32_2xpk16_fp6_f32: position P <- row tile 2 q + (P & 1), accumulator register P >> 1,
+//             i.e. k-step 4 q + 2 (P & 1) + (P >> 4), element (P >> 1) & 7);
+//   image 1 = w_lo6 = e2m3(w - f16(w)) meets the hi image (v_cvt_scalef32_pk32_fp6_f16: position P <- k-step 4 q + (P >> 3), element P & 7).
+// Block scale 2^(floor(log2 max) - 2) (the largest magnitude lands in [4, 8); e2m3 saturates at 7.5: at most its own half-ulp), stored as E8M0 byte q of the lane's scale dword.
+// Chunk image in the stream (32 KB): [f16 fragments 16 K][per slab: w_hi6 dwords 0-3 (1 K) | 4-5 (512) | w_lo6 dwords 0-3 | 4-5][behind the images (28 K for W = 256): scale dwords {w_hi6, w_lo6} per lane]
+__device__ __forceinline__ unsigned pf2_e2m3(float a) {   // a >= 0, already divided by the block scale; round to nearest even, saturating
+  if (!(a < 7.5f)) return 31u;
+  if (a < 1.f) return (unsigned)rintf(a * 8.f);   // subnormals 0 .. 0.875; 8 = the smallest normal (encodings are contiguous)
+  const int e = a < 2.f ? 0 : a < 4.f ? 1 : 2;
+  unsigned m = (unsigned)rintf(ldexpf(a, 3 - e));   // 8 .. 16
+  unsigned c = ((unsigned)(e + 1) << 3) + (m - 8u);    // m == 16 carries into the exponent
+  return c > 31u ? 31u : c;
+}
+__global__ void pack_point_mx6_kernel(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ wk, const float* __restrict__ wv,
+                                      unsigned char* __restrict__ out, int NRT) {
+  const int W = 32 * NRT, KSL = 2 * NRT, NSL = NRT / 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nwide = 2 * NRT + 8;
+  if (e >= nwide * NSL * 64 * 2) return;
+  const int im = e & 1, lane = (e >> 1) & 63, q = (e >> 7) % NSL, cw = (e >> 7) / NSL;   // cw: wide chunk 0 .. 2 NRT + 7
+  const int layer = cw < NRT ? 1 : cw < 2 * NRT ? 2 : 3, rt = cw < 2 * NRT ? cw % NRT : cw - 2 * NRT;
+  const int hh = lane >> 5, orow = 32 * rt + (lane & 31);
+  float v[32], mx = 0.f;
+  for (int P = 0; P < 32; ++P) {
+    const int sI = im == 0 ? 2 * (P & 1) + (P >> 4) : (P >> 3), t = im == 0 ? (P >> 1) & 7 : (P & 7);
+    const int ks = 4 * q + sI;
+    const int fin = 32 * (ks >> 1) + pf2_m(8 * (ks & 1) + t, hh);
+    const float w = pf2_weight(w2, w3, wk, wv, layer, orow, fin, W);
+    const float h = pf2_h2f(pf2_f2h(w));
+    v[P] = im == 0 ? h : w - h;
+    mx = fmaxf(mx, fabsf(v[P]));
+  }
+  int E = -60;
+  if (mx > 0.f) { int ex; (void)frexpf(mx, &ex); E = ex - 1; }   // mx = 1.xxx 2^E
+  int sb = E - 2 + 127;
+  sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+  const float inv = ldexpf(1.f, 127 - sb);
+  unsigned d[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  for (int P = 0; P < 32; ++P) {
+    const unsigned c = pf2_e2m3(fabsf(v[P]) * inv) | (v[P] < 0.f ? 32u : 0u);
+    const int b = 6 * P;
+    d[b >> 5] |= c << (b & 31);
+    if ((b & 31) > 26) d[(b >> 5) + 1] |= c >> (32 - (b & 31));
+  }
+  // chunk base in the stream: the layer-1 chunks (12 KB each) first, then 32 KB per wide chunk
+  unsigned char* cb = out + (size_t)NRT * 2 * 6 * 1024 + (size_t)cw * 2 * KSL * 1024;
+  unsigned* a = reinterpret_cast<unsigned*>(cb + (size_t)KSL * 1024 + (size_t)q * 3072 + (size_t)im * 1536 + (size_t)lane * 16);
+  a[0] = d[0]; a[1] = d[1]; a[2] = d[2]; a[3] = d[3];
+  unsigned* b2 = reinterpret_cast<unsigned*>(cb + (size_t)KSL * 1024 + (size_t)q * 3072 + (size_t)im * 1536 + 1024 + (size_t)lane * 8);
+  b2[0] = d[4]; b2[1] = d[5];
+  cb[(size_t)KSL * 1024 + (size_t)NSL * 3072 + lane * 8 + im * 4 + q] = (unsigned char)sb;
+}
+
 }  // namespace
 
 size_t nl_point_stream2_bytes(int W) {
@@ -1095,6 +1302,15 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
                           const float* rd_w, void* out, int W, int F, hipStream_t st, int mx, int* mx_scratch) {
   const int NRT = W / 32;
   const long long total = ((long long)NRT * 6 + (2LL * NRT + 8) * 2 * NRT) * 512;
+  const bool mx6 = mx == 1 && MXK == 2;   // NL_PREC_F16MX with fp6 cross terms (W = 256 has 28.5 of a chunk's 32 KB in use, W = 128 less)
+  if (mx6) {
+    if (W != 128 && W != 256) return NL_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_point_stream2_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv, b2, b3, rd_w, (unsigned short*)out, NRT, F, 3, nullptr);
+    NL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_point_mx6_kernel, dim3((unsigned)nl_cdiv((long long)(2 * NRT + 8) * (NRT / 2) * 128, 256)), dim3(256), 0, st, w2, w3, wk, wv, (unsigned char*)out, NRT);
+    NL_LAUNCH_CHECK();
+    return NL_OK;
+  }
   if (mx == 1) {
     if (!mx_scratch) return NL_ERR_BAD_ARG;
     hipLaunchKernelGGL(pf2_mx_scale_kernel, dim3(3 * NRT + 8), dim3(256), 0, st, w2, w3, wk, wv, mx_scratch, NRT);
@@ -1163,13 +1379,13 @@ int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipS
   }
 #define NL_PF2(NRT)                                                                                                                                  \
   do {                                                                                                                                               \
-    if (keep_kv) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, false, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
+    if (keep_kv) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, 0, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
                                     a.sp_xyz, a.sp_dir, a.wstream2, sc, kp);                                                                         \
-    else if (mx) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,   \
+    else if (mx) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, MXK>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,   \
                                     a.sp_dir, a.wstream2, sc, kp);                                                                                   \
-    else if (x3) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz, \
+    else if (x3) hipLaunchKernelGGL((point_fused2_kernel<NRT, true, 0>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz, \
                                     a.sp_dir, a.wstream2, sc, kp);                                                                                   \
-    else hipLaunchKernelGGL((point_fused2_kernel<NRT, false, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,        \
+    else hipLaunchKernelGGL((point_fused2_kernel<NRT, false, 0>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, a.sp_xyz,        \
                             a.sp_dir, a.wstream2, sc, kp);                                                                                           \
   } while (0)
   if (W == 256) NL_PF2(8);

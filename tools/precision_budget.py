@@ -54,6 +54,30 @@ def mx8(x):
     return q.reshape(xp.shape)[..., :K]
 
 
+def mx6(x, fmt="e2m3", ref=None, shift=0.0):
+    """x (..., K) -> its MX-FP6 image, dequantised: blocks of 32 along K share the power-of-two scale 2^(floor(log2 max) - 2) (the block's largest magnitude lands in
+    [4, 8): e2m3's 7.5 saturates at most one half-ulp), elements rounded to nearest e2m3 (grid 0.125 below 2, 0.25 below 4, 0.5 up to 7.5)."""
+    K = x.shape[-1]
+    pad = (-K) % 32
+    xp = F.pad(x, (0, pad)) if pad else x
+    b = xp.reshape(*xp.shape[:-1], -1, 32)
+    m = b.abs().amax(-1, keepdim=True)
+    if ref is not None:   # the scale of another tensor's blocks, shifted (the kernel: the residual image takes the hi image's scale x 2^-11)
+        rp = F.pad(ref, (0, pad)) if pad else ref
+        m = rp.reshape(*rp.shape[:-1], -1, 32).abs().amax(-1, keepdim=True)
+    sc = torch.exp2(torch.floor(torch.log2(m.clamp_min(1e-38))) - 2.0 + shift)
+    a = (b / sc).abs()
+    if fmt == "e2m3":
+        step = torch.where(a < 2.0, torch.full_like(a, 0.125), torch.where(a < 4.0, torch.full_like(a, 0.25), torch.full_like(a, 0.5)))
+        q = (torch.round(a / step) * step).clamp_max(7.5)
+    else:   # e2m1 (fp4): 0, .5, 1, 1.5, 2, 3, 4, 6
+        step = torch.where(a < 2.0, torch.full_like(a, 0.5), torch.where(a < 4.0, torch.full_like(a, 1.0), torch.full_like(a, 2.0)))
+        q = (torch.round(a / step) * step).clamp_max(6.0)
+    q = torch.sign(b) * q * sc
+    q = torch.where(m > 0, q, torch.zeros_like(q))
+    return q.reshape(xp.shape)[..., :K]
+
+
 def emu_linear(x, w, mode):
     """x (..., K) @ w (N, K)^T in the emulated arithmetic, fp32 accumulate (torch's fp32 matmul on the rounded operands)."""
     if mode == "fp32":
@@ -62,6 +86,13 @@ def emu_linear(x, w, mode):
         xh, xl = split(x, torch.float16)
         wh, wl = split(w, torch.float16)
         return xh @ wh.t() + mx8(xl) @ mx8(wh).t() + mx8(xh) @ mx8(wl).t()
+    if mode in ("f16mx6", "f16mx4"):
+        f = "e2m3" if mode == "f16mx6" else "e2m1"
+        xh, xl = split(x, torch.float16)
+        wh, wl = split(w, torch.float16)
+        if mode == "f16mx6":   # as the kernel does it: the activations' residual image on the hi image's block scale x 2^-11
+            return xh @ wh.t() + mx6(x - xh, f, ref=xh, shift=-11.0) @ mx6(wh, f).t() + mx6(xh, f) @ mx6(w - wh, f).t()
+        return xh @ wh.t() + mx6(x - xh, f) @ mx6(wh, f).t() + mx6(xh, f) @ mx6(w - wh, f).t()
     dt = torch.bfloat16 if mode.startswith("bf16") else torch.float16
     kind = mode[mode.index("x"):]
     xh, xl = split(x, dt)
@@ -206,6 +237,8 @@ def main():
     table = {}
     print(f"{'group':34s} " + " ".join(f"{m:>9s}" for m in MODES) + "    (worst output, max-rel-to-max)")
     for g, pres in GROUPS.items():
+        if os.environ.get("BUDGET_GROUPS") and not any(t in g for t in os.environ["BUDGET_GROUPS"].split(",")):
+            continue
         row = {}
         for m in MODES:
             out = render({pre: m for pre in pres})
@@ -231,7 +264,10 @@ def main():
                            ("x3, w_ks+w_qs f16x1", ["base_mlp_attn.w_ks", "base_mlp_attn.w_qs"], "f16x1"),
                            ("x3, w_ks+w_qs f16x2a", ["base_mlp_attn.w_ks", "base_mlp_attn.w_qs"], "f16x2a"),
                            ("x3, point branch f16mx8", ["base_mlp.", "base_mlp_attn.w_ks", "base_mlp_attn.w_vs"], "f16mx8"),
-                           ("x3, conv_out f16mx8", ["ray_unet.conv_out"], "f16mx8")):
+                           ("x3, conv_out f16mx8", ["ray_unet.conv_out"], "f16mx8"),
+                           ("x3, point branch f16mx6", ["base_mlp.2", "base_mlp.4", "base_mlp_attn.w_ks", "base_mlp_attn.w_vs"], "f16mx6"),
+                           ("x3, point branch f16mx8 (L2, L3, k, v)", ["base_mlp.2", "base_mlp.4", "base_mlp_attn.w_ks", "base_mlp_attn.w_vs"], "f16mx8"),
+                           ("x3, point branch f16mx4", ["base_mlp.2", "base_mlp.4", "base_mlp_attn.w_ks", "base_mlp_attn.w_vs"], "f16mx4")):
         if os.environ.get("BUDGET_MODES") and m not in MODES:
             continue
         a = dict(base)
