@@ -67,7 +67,9 @@ struct Geo {
   static constexpr int rt(int g) { return cm(g) < 3 * NRT ? cm(g) % NRT : cm(g) - 3 * NRT; }
   static constexpr int nks(int g) { return layer(g) == 0 ? KS1 : KSL; }
   static constexpr int ksi(int g) { return layer(g) == 0 ? KS1I : KSL; }       // k-steps per part in the LDS image
-  static constexpr int ppw(int g) { return PARTS * ksi(g) / 4; }               // LDS-DMA pieces (1 KB) per wave
+  // LDS-DMA pieces (1 KB) per wave.  MX-FP6, W = 256: a wide chunk has 28 of its 32 KB in use (16 K of f16 fragments + 4 slabs x 3 K of fp6 images; the weights' scale
+  // dwords are resident) — 7 pieces per wave instead of 8 (W = 128: 14 of 16 KB do not divide by four waves: the whole chunk is copied)
+  static constexpr int ppw(int g) { return layer(g) > 0 && MX6 && NRT == 8 ? 7 : PARTS * ksi(g) / 4; }
   static constexpr int gkb(int g) {   // offset of chunk g in the global stream, in KB; the stream always holds both parts
     int o = 0;
     for (int i = 0; i < cm(g); ++i) o += 2 * nks(i);
@@ -84,7 +86,8 @@ struct Geo {
   static constexpr int RES_ATT = RES_BIAS + (64 + 2 * W) / 4;   // attention weights [wave][head][32 rows] floats (wave-private)
   static constexpr int RES_SC = RES_ATT + 4 * 4 * 32 / 4;   // MX mode: E8M0 scale bytes of the chunks' fp8 weight images, ints [NC][2] = {w_hi8, w_lo8}
   static constexpr int RES_BND = RES_SC + (2 * NC + 3) / 4;   // MX mode: 8 floats — the bounds the activation block scales are derived from (pf2_mx_bounds_kernel)
-  static constexpr int LDS_U4 = RES_BND + 2;
+  static constexpr int RES_SC6 = RES_BND + 2;   // MX-FP6: the wide chunks' weight-scale dwords [chunk 2 NRT + 8][lane 64] x {w_hi6, w_lo6} (pack_point_mx6_kernel)
+  static constexpr int LDS_U4 = RES_SC6 + (MX6 ? (2 * NRT + 8) * 32 : 0);
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
   // (KEEP: + 4 row stores of a k head / 4 x 4 dword stores of a v head: the rows nl_attn_backward reads)
   static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) + (MX6 && (rt(c) & 1) ? 2 : 0) : (rt(c) < 4 ? 10 : 10) + (KEEP ? 4 : 0); }
@@ -265,6 +268,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   typedef __attribute__((address_space(3))) u32x2 lds_u2;
   lds_u2* lds_hi8 = (lds_u2*)((lds_u4*)lds_all + 4096) + (threadIdx.x & 63);
   if constexpr (MX6) asm volatile("" : "+v"(lds_hi8));
+  lds_u2* lds_res8 = (lds_u2*)((lds_u4*)lds_all + NBUF * SLOT) + (threadIdx.x & 63);   // ... and the resident block behind the ring
+  if constexpr (MX6) asm volatile("" : "+v"(lds_res8));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31, kk = j & 7;
   const unsigned nwg = gridDim.x;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     for (int i = tid; i < 2 * PARTS * 64; i += 256) lds_all[GG::RES_RD + i] = src[(i / (PARTS * 64)) * 128 + i % (PARTS * 64)];
     for (int i = tid; i < (64 + 2 * W) / 4; i += 256) lds_all[GG::RES_BIAS + i] = src[256 + i];
     if (MX8) for (int i = tid; i < (2 * NC + 3) / 4 + 2; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];   // + the bounds block
+    if (MX6) for (int i = tid; i < (2 * NRT + 8) * 32; i += 256) lds_all[GG::RES_SC6 + i] = src[256 + (64 + 2 * W) / 4 + (2 * NC + 3) / 4 + 2 + i];
   }
   __syncthreads();
 
@@ -617,12 +623,10 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       else w6b[q & 1][i >> 1] = ((const lds_u2*)(lds_u4*)lds_all)[l8 + lane];
     }
   };
-  // ... and the chunk's two scale dwords: behind the images (8 bytes per lane at 28 K of the slot for W = 256)
+  // ... and the chunk's two scale dwords: resident (8 bytes per lane and wide chunk)
   auto read_wsc6 = [&](auto Cc) __attribute__((always_inline)) {
     constexpr int c = GG::cm(decltype(Cc)::value);
-    constexpr int l8 = (((c % NBUF) * SLOT + GG::ksi(c) * 64) * 16 + (NRT / 2) * 3072) / 8;
-    if constexpr (l8 >= 8192 && l8 < 16384) wsc6 = lds_hi8[l8 - 8192];
-    else wsc6 = ((const lds_u2*)(lds_u4*)lds_all)[l8 + lane];
+    wsc6 = lds_res8[(GG::RES_SC6 - NBUF * SLOT) * 2 + (c - NRT) * 64];
   };
 
   // ---------------------------------------------------------------- epilogue micro-steps of chunk C, run inside region C+1
@@ -1240,7 +1244,7 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
 //             i.e. k-step 4 q + 2 (P & 1) + (P >> 4), element (P >> 1) & 7);
 //   image 1 = w_lo6 = e2m3(w - f16(w)) meets the hi image (v_cvt_scalef32_pk32_fp6_f16: position P <- k-step 4 q + (P >> 3), element P & 7).
 // Block scale 2^(floor(log2 max) - 2) (the largest magnitude lands in [4, 8); e2m3 saturates at 7.5: at most its own half-ulp), stored as E8M0 byte q of the lane's scale dword.
-// Chunk image in the stream (32 KB): [f16 fragments 16 K][per slab: w_hi6 dwords 0-3 (1 K) | 4-5 (512) | w_lo6 dwords 0-3 | 4-5][behind the images (28 K for W = 256): scale dwords {w_hi6, w_lo6} per lane]
+// Chunk image in the stream (32 KB): [f16 fragments 16 K][per slab: w_hi6 dwords 0-3 (1 K) | 4-5 (512) | w_lo6 dwords 0-3 | 4-5]; the scale dwords {w_hi6, w_lo6} per (wide chunk, lane): a table in the resident block
 __device__ __forceinline__ unsigned pf2_e2m3(float a) {   // a >= 0, already divided by the block scale; round to nearest even, saturating
   if (!(a < 7.5f)) return 31u;
   if (a < 1.f) return (unsigned)rintf(a * 8.f);   // subnormals 0 .. 0.875; 8 = the smallest normal (encodings are contiguous)
@@ -1286,14 +1290,18 @@ __global__ void pack_point_mx6_kernel(const float* __restrict__ w2, const float*
   a[0] = d[0]; a[1] = d[1]; a[2] = d[2]; a[3] = d[3];
   unsigned* b2 = reinterpret_cast<unsigned*>(cb + (size_t)KSL * 1024 + (size_t)q * 3072 + (size_t)im * 1536 + 1024 + (size_t)lane * 8);
   b2[0] = d[4]; b2[1] = d[5];
-  cb[(size_t)KSL * 1024 + (size_t)NSL * 3072 + lane * 8 + im * 4 + q] = (unsigned char)sb;
+  // the scale byte: resident table behind the stream's bias tables, scale ints and bounds block
+  const int NC = 3 * NRT + 8;
+  unsigned char* tab = out + ((size_t)NRT * 12 + (size_t)(2 * NRT + 8) * 2 * KSL) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + (size_t)((2 * NC + 3) / 4 + 2) * 16;
+  tab[((size_t)cw * 64 + lane) * 8 + im * 4 + q] = (unsigned char)sb;
 }
 
 }  // namespace
 
 size_t nl_point_stream2_bytes(int W) {
   const int NRT = W / 32;
-  return (size_t)2 * (NRT * 6 + (2 * NRT + 8) * 2 * NRT) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + 4096;   // + slack: bf16 L1 chunks copy 8 k-steps
+  return (size_t)2 * (NRT * 6 + (2 * NRT + 8) * 2 * NRT) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + 4096   // + slack: bf16 L1 chunks copy 8 k-steps
+         + (size_t)(2 * NRT + 8) * 512;                                                                      // + MX-FP6: the weight-scale table
 }
 
 // mx = 1: the stream of the MX mode (layer 1 split-bf16 as ever; layers 2, 3, k / v: f16 fragments + fp8 images + their scales); mx_scratch: >= 2 (3 W / 32 + 8) ints
