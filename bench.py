@@ -51,12 +51,12 @@ def algorithmic_mac_per_sample(W: int, V: int, C: int = 192, K: int = 8) -> floa
 
 def executed_mfma_equiv_mac_per_sample(W: int, V: int, S: int, precision: str, C: int = 192, K: int = 8):
     """MFMA-equivalent multiply-adds the kernels EXECUTE per sample in a precision mode (one bf16 / fp16 `32x32x16` MAC = 1; a three-term split product = 3; an
-    f16mx product = 2.0: fp16 hi.hi + two MX-FP8 cross terms at twice the rate): (whole step, fused neural-point kernel).  What the kernels multiply differs from
+    f16mx product = 1.5: fp16 hi.hi + two MX-FP6 cross terms at four times the rate — round 5; MX-FP8 at twice the rate = 2.0 before): (whole step, fused neural-point kernel).  What the kernels multiply differs from
     the algorithmic count of SURVEY 8(d): the 195 feature columns of base_mlp.0 and rgb_blending_mlp.0 come from per-frame tables, the attention's q-projection and
     `fc` run once per sample, out_fc.2 is recomputed in both chain kernels, feat_mlp.2 runs per ray.  algorithmic / executed-equivalent = the fraction
     of the bf16 MFMA peak `roofline.frac` would show with the matrix pipe 100 % busy: the CEILING of the parity mode."""
     per = {"bf16": 1.0, "bf16x3": 3.0, "f16mx": 3.0, "fp32": 16.0}[precision]     # every GEMM but the fused kernel's wide layers
-    wide = {"f16mx": 2.0}.get(precision, per)                                      # layers 2, 3 and the k / v projections of point_fused2_kernel
+    wide = {"f16mx": 1.5}.get(precision, per)                                      # layers 2, 3 and the k / v projections of point_fused2_kernel
     point = K * (96 * W * per + (2 * W * W + 256 * W) * wide)                       # layer 1 (K = 96: posenc + ray_diff_fc) + layers 2, 3 + k / v
     unet = 192 * W + 12288 + 12288 + 6144 + 12288 + 6144 + 3 * (W + 32) * W   # the seven convolutions per sample (SURVEY 8d: pooled levels, transposed = 1.5 taps per output)
     other = (384 * 64 + 2 * 64 * W + W * 128 + 128 * W + W * W + W * 32 + V * (4 * 2 * 32 * 32 + 6 * 32) + unet + C * W / S)
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2")
     ap.add_argument("--precision", default="f16mx", choices=["fp32", "bf16x3", "bf16", "f16mx"],
-                    help="f16mx (default since round 4): the parity mode with 2.0 instead of 3 MFMA-equivalents per product in the fused neural-point kernel")
+                    help="f16mx (default since round 4): the parity mode with 1.5 (round 5: MX-FP6 cross terms; round 4: 2.0, MX-FP8) instead of 3 MFMA-equivalents per product in the fused neural-point kernel")
     ap.add_argument("--rays", type=int, default=0, help="override rays per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-thread-sweep", action="store_true", help="cpu_baseline: also time 64 rays at 8 and 64 threads (off by default: the driver's run should spend "
@@ -257,7 +257,7 @@ def main():
         "metric": baseline_metric(), "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
-                                                            "f16mx": "f16mx (neural-point kernel: fp16 hi.hi + two MX-FP8 cross terms, 2.0 MFMA-equivalents per product; every other GEMM 3-term "
+                                                            "f16mx": "f16mx (neural-point kernel: fp16 hi.hi + two MX-FP6 cross terms, 1.5 MFMA-equivalents per product; every other GEMM 3-term "
                                                                      "split-bf16; fp32 accumulate; meets 1e-4)",
                                                             "bf16": "bf16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
@@ -277,7 +277,7 @@ def main():
     diag = rnd.diagnostics()
     result["roofline"]["parity_mode_ceiling"] = {
         "whole_step": algorithmic_mac_per_sample(cfg.W, cfg.V, cfg.C) / ex_all,
-        "what": "algorithmic MAC / MFMA-equivalent MAC the kernels execute in this precision mode (3 per split-bf16 product, 2.0 per f16mx product): "
+        "what": "algorithmic MAC / MFMA-equivalent MAC the kernels execute in this precision mode (3 per split-bf16 product, 1.5 per f16mx product): "
                 "`frac` with the matrix pipe 100 % busy at the 2.4 GHz the peak assumes"}
     result["roofline"]["clock_GHz_under_load"] = {"point_fused2_kernel": diag["point_kernel_GHz"], "peak_assumes": 2.4,
                                                   "how": "s_memtime cycles / s_memrealtime of workgroup 0 over the last launch (nl_frame_diagnostics)"}
@@ -296,7 +296,8 @@ def main():
             "name": "point_fused2_kernel", "launches": launches.value, "avg_ms": fused_ms.value / launches.value,
             "share_of_step": fused_ms.value / args.steps / (dev_ms / args.steps),
             "achieved": alg, "frac": alg / PEAK_BF16_TFLOPS, "unit": "TFLOP/s (algorithmic, SURVEY §8d)",
-            "executed_mfma_TFLOPs": 2.0 * mac_exec * {"bf16x3": 3.0, "f16mx": 2.0}.get(args.precision, 1.0) * samples_per_launch / sec / 1e12,
+            "executed_mfma_TFLOPs": 2.0 * (K * 96 * W * {"bf16x3": 3.0, "f16mx": 3.0}.get(args.precision, 1.0) + (mac_exec - K * 96 * W) * {"bf16x3": 3.0, "f16mx": 1.5}.get(args.precision, 1.0))
+                                    * samples_per_launch / sec / 1e12,   # (layer 1 stays three-term split-bf16 in f16mx)
         }
 
     if gather:
@@ -338,7 +339,7 @@ def main():
             n2 = max(3, args.steps // 2)
             extra[p] = {"rays_per_s": R * n2 / w2, "ms_per_step": w2 * 1e3 / n2, "roofline_frac": flops_step / (d2 * 1e-3 / n2) / 1e12 / PEAK_BF16_TFLOPS,
                         "note": {"bf16": "single bf16 MFMA per product: throughput mode, does NOT meet 1e-4", "fp32": "f32-input MFMA, generic kernels: strictest parity mode",
-                                 "bf16x3": "parity mode (3-term split-bf16 everywhere)", "f16mx": "parity mode, fp16 + MX-FP8 cross terms in the neural-point kernel"}[p]}
+                                 "bf16x3": "parity mode (3-term split-bf16 everywhere)", "f16mx": "parity mode, fp16 + MX-FP6 cross terms in the neural-point kernel"}[p]}
         rnd.set_precision(args.precision)
         result["other_precisions"] = extra
 

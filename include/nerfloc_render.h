@@ -61,15 +61,18 @@ typedef enum nl_precision {
   NL_PREC_F32 = 0,     /* f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products/accumulation   */
   NL_PREC_BF16X3 = 1,  /* 3-term split-bf16 MFMA (hi*hi + hi*lo + lo*hi), fp32 accumulate: parity mode  */
   NL_PREC_BF16 = 2,    /* single bf16 MFMA, fp32 accumulate: throughput mode (does not meet 1e-4)       */
-  NL_PREC_F16MX = 3    /* round 4 — parity mode, 2.0 instead of 3 matrix instructions per product in the fused neural-point kernel (the
-                        * MFMA-bound kernel): fp16 hi.hi (v_mfma_f32_32x32x16_f16) + the two cross terms hi.lo / lo.hi on gfx950's block-scaled FP8 instruction
-                        * (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, power-of-two scales; the cross terms are 2^-11 of a product, so e4m3's 2^-4 leaves 2^-15).
-                        * Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as NL_PREC_BF16X3.
-                        * RANGE (round 5): the fp8 images of the activations carry a block scale per row and layer, derived in the kernel from a bound the row
-                        * cannot exceed (L1 norms of the layer's weight rows x the row's running maximum; layer 1: max |T| over the frame's table) — no
-                        * activation magnitude saturates or flushes them.  What is left is fp16's own range for the hi part: |activation| < 65504 (beyond it
-                        * the value saturates, MODE.FP16_OVFL, instead of becoming inf) and >= 2^-14 for its full 11 bits.  Validated (tests/test_gpu_parity.py,
-                        * tools/scale_sweep.py): feature maps x 1/64 ... 64 (activations to ~2e3), Student-t (nu = 3) weights, DepthFusionNet maps x 8.
+  NL_PREC_F16MX = 3    /* round 4 / 5 — parity mode, 1.5 (round 4: 2.0) instead of 3 matrix-instruction equivalents per product in the fused neural-point kernel
+                        * (the MFMA-bound kernel): fp16 hi.hi (v_mfma_f32_32x32x16_f16) + the two cross terms hi.lo / lo.hi on gfx950's
+                        * block-scaled instruction v_mfma_scale_f32_32x32x64_f8f6f4 — since round 5 with FP6 (e2m3) operands, 8 passes per K = 64 where FP8 takes 16
+                        * (the cross terms are 2^-11 of a product: three mantissa bits leave 2^-15, whether the element is e4m3 or e2m3; what e2m3 lacks is range,
+                        * which the block scales supply).  Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as
+                        * NL_PREC_BF16X3.
+                        * RANGE: every MX block — a row's 32 values of one K half-slab — carries its own power-of-two scale 2^(floor(log2 max) - 2), taken from the
+                        * values themselves: in the kernel for the activations (per row, slab and layer; the residual image uses the same scale x 2^-11), at
+                        * packing time for the weights (per output row and half-slab).  No activation or weight magnitude saturates or flushes a block.  What is
+                        * left is fp16's own range for the hi part: |activation| < 65504 (beyond it the value saturates, MODE.FP16_OVFL, instead of becoming inf)
+                        * and >= 2^-14 for its full 11 bits.  Validated (tests/test_gpu_parity.py, tools/scale_sweep.py): feature maps x 1/64 ... 64 (activations
+                        * to ~2e3), Student-t (nu = 3) weights, DepthFusionNet maps x 8.
                         * ACCURACY: a product carries ~2^-16 (NL_PREC_BF16X3: 2^-17, NL_PREC_F32: 2^-24).  On well-conditioned inputs that is 1-2.5e-5 of the
                         * outputs; where the network amplifies rounding (attention logits of |q.k / sqrt d| >> 10: see nl_frame_diagnostics) every mode's
                         * distance to the reference grows by the same factor and NL_PREC_F32 is the mode that stays at the reference's own level.          */

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("NERFLOC_LIB") or os.path.join(_HERE, "csrc", "libnerf
 NL_OK = 0
 NL_ERR_BAD_ARG, NL_ERR_UNSUPPORTED, NL_ERR_WORKSPACE, NL_ERR_HIP, NL_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16MX = 0, 1, 2, 3
-# "f16mx" (round 4): BF16X3 everywhere except the fused neural-point kernel of render_rays, which multiplies as fp16 hi.hi + two MX-FP8 cross terms
+# "f16mx" (round 4): BF16X3 everywhere except the fused neural-point kernel of render_rays, which multiplies as fp16 hi.hi + two MX cross terms (FP6 elements since round 5, FP8 in round 4)
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16mx": PREC_F16MX}
 MAX_VIEWS = 16
 RENDER_NO_SIDE_STREAM = 1   # nl_render_opts.flags

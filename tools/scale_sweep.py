@@ -218,10 +218,15 @@ def check(rows):
 
 
 if __name__ == "__main__":
-    cases = sys.argv[1:] or ["w256s128", "c2"]
+    calibration = "--calibration" in sys.argv   # part 2 of profiles/r5_scale_sweep.txt: the |logit| ranges the precision guard's limits come from
+    cases = [a for a in sys.argv[1:] if not a.startswith("--")] or (["w256s128"] if calibration else ["w256s128", "c2"])
     rows = []
     for c in cases:
-        rows += sweep(c, vscales=(1.0,) if c == "c2" else (1.0, 8.0))
+        if calibration:
+            rows += sweep(c, fscales=(1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0))
+            rows += sweep(c, combos=[("normal+off4", 1.0, 1.0), ("normal+off32", 1.0, 1.0), ("normal+off100", 1.0, 1.0)])
+        else:
+            rows += sweep(c, vscales=(1.0,) if c == "c2" else (1.0, 8.0))
     bad = check(rows)
     for b in bad:
         print("FAIL", b)
