@@ -396,10 +396,180 @@ int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t
   return NL_OK;
 }
 
+// Round 5: the same function with lanes = (sample row r, channel octet g) instead of lane = sample.  What bound the lane-per-sample kernel was not its ~900 vector
+// instructions per (sample, view) but its taps: 32 sixteen-byte loads per lane and view, every lane on its own 128-byte texel row — the CU's address unit takes ~64
+// cycles per such instruction (tools/ubench/vmem_issue.hip; `r5_pmc_sq*.csv`: 2.7e6 load instructions per launch, waves waiting 63 % of their cycles).  Here a wave walks
+// 16 consecutive samples; the four lanes of a row own 8 of the projected map's 32 channels each: a tap is TWO loads per lane, and one instruction touches 16 texel rows
+// instead of 64.  Per view: phase A (lane = (row, view of a group of four): projection, tap cell / weights, view-angle features -> a 48-byte LDS slot, wave-private),
+// phase B (lane = (row, octet): 8 loads, the 8 x 8 [rgb | vis | angle] columns of layer 1 in registers, LeakyReLU), then rgb_blending_mlp.2 (32 -> 16) as three
+// v_mfma_f32_16x16x32_bf16 (split-bf16 like every parity-mode product; its A fragments are built from the fp32 weights at kernel start) — the lane's octet IS its slice of
+// the B operand — LeakyReLU, the 16 -> 1 layer as 4 FMAs + two cross-lane adds, and a streaming softmax over the views (no per-view array).
+typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float bt_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned bt_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BT_SLOT = 12;   // dwords per (row, view): [cell, w0, w1, w2 | w3, angle 0-2 | angle 3, -, -, -]
+__global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ pfeat /*(V,h,w,32)*/,
+                                                              const float* __restrict__ blw /*[32][8], bias[32]*/, const float* __restrict__ xyz,
+                                                              const float* __restrict__ hA, const float* __restrict__ rgbv, int N,
+                                                              const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
+                                                              const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
+                                                              float* __restrict__ rgb_s, const int* __restrict__ n_alive, int S) {
+  using namespace nlmv;
+  __shared__ __attribute__((aligned(16))) float slots[4][16][NL_MAX_VIEWS][BT_SLOT];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r = lane & 15, g = lane >> 4;
+  const int V = vw.V;
+  // ---- resident: layer 1's small columns for the lane's 8 channels, layer 2 as A fragments (row n = r, k = 8 g + t), the output layer's slice
+  float wl[8][8], bl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bl[j] = blw[256 + 8 * g + j];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) wl[j][jj] = blw[(8 * g + j) * 8 + jj];
+  }
+  bt_u32x4 ah, al;
+  {
+    unsigned hw[8], lw[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float w = w2[r * 32 + 8 * g + t];
+      unsigned u = __float_as_uint(w);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      hw[t] = u >> 16;
+      unsigned v = __float_as_uint(w - __uint_as_float(hw[t] << 16));
+      v += 0x7fffu + ((v >> 16) & 1u);
+      lw[t] = v >> 16;
+    }
+    ah = bt_u32x4{hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16)};
+    al = bt_u32x4{lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16)};
+  }
+  float b2q[4], w4q[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { b2q[t] = b2[4 * g + t]; w4q[t] = w4[4 * g + t]; }
+  const float b4v = b4[0];
+  const size_t fmap = (size_t)vw.h * vw.w;
+  float (*myslots)[NL_MAX_VIEWS][BT_SLOT] = slots[wave];
+
+  const int n = (blockIdx.x * 4 + wave) * 16 + r;
+  const bool live = n < N;
+  const int nn = live ? n : N - 1;
+  bool alive = live;
+  if (n_alive) { const int ry = nn / S; alive = live && (nn - ry * S) < n_alive[ry]; }
+  const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
+  float qc0 = vw.qcam[0], qc1 = vw.qcam[1], qc2 = vw.qcam[2];
+  if (vw.qrows) { const float* qr = vw.qrows + 3 * (size_t)(nn / vw.qS); qc0 = qr[0]; qc1 = qr[1]; qc2 = qr[2]; }
+  float tq[3] = {qc0 - X, qc1 - Y, qc2 - Z};
+  const float rq = 1.f / (sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2]) + 1e-6f);
+  tq[0] *= rq; tq[1] *= rq; tq[2] *= rq;
+  float xa[8];   // per-sample part of layer 1 (feature_agg columns of rgb_blending_mlp.0), the lane's octet
+  {
+    const float4 t0 = *(const float4*)(hA + (size_t)nn * 32 + 8 * g), t1 = *(const float4*)(hA + (size_t)nn * 32 + 8 * g + 4);
+    xa[0] = t0.x; xa[1] = t0.y; xa[2] = t0.z; xa[3] = t0.w; xa[4] = t1.x; xa[5] = t1.y; xa[6] = t1.z; xa[7] = t1.w;
+  }
+  // ---- phase A: lane = (row r, view 4 i + g)
+  for (int v0 = 0; v0 < V; v0 += 4) {
+    const int v = v0 + g;
+    if (v < V) {
+      const float4 p0 = *(const float4*)(viewsdev + 12 * v), p1 = *(const float4*)(viewsdev + 12 * v + 4), p2 = *(const float4*)(viewsdev + 12 * v + 8);
+      const float cx = fmaf(p0.z, Z, fmaf(p0.y, Y, p0.x * X)) + p0.w;
+      const float cy = fmaf(p1.z, Z, fmaf(p1.y, Y, p1.x * X)) + p1.w;
+      const float cz = fmaf(p2.z, Z, fmaf(p2.y, Y, p2.x * X)) + p2.w;
+      const float zc = fmaxf(cz, 1e-8f);
+      float px = cx / zc, py = cy / zc;
+      px = fminf(fmaxf(px, -1e6f), 1e6f);
+      py = fminf(fmaxf(py, -1e6f), 1e6f);
+      const float xn = 2.f * px / (float)(vw.Wimg - 1) - 1.f;
+      const float yn = 2.f * py / (float)(vw.H - 1) - 1.f;
+      const Taps tf = make_taps<true, false>(xn, yn, vw.w, vw.h);
+      const float w0 = (tf.mn && tf.mw) ? tf.nw : 0.f, w1 = (tf.mn && tf.me) ? tf.ne : 0.f, w2t = (tf.ms && tf.mw) ? tf.sw : 0.f, w3 = (tf.ms && tf.me) ? tf.se : 0.f;
+      float tt[3] = {viewsdev[192 + 3 * v] - X, viewsdev[192 + 3 * v + 1] - Y, viewsdev[192 + 3 * v + 2] - Z};
+      const float rt = 1.f / (sqrtf(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]) + 1e-6f);
+      tt[0] *= rt; tt[1] *= rt; tt[2] *= rt;
+      const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
+      const float rd = 1.f / fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
+      float* sl = myslots[r][v];
+      *(float4*)sl = make_float4(__uint_as_float(pack_taps(tf, vw.w, vw.h)), w0, w1, w2t);
+      *(float4*)(sl + 4) = make_float4(w3, df[0] * rd, df[1] * rd, df[2] * rd);
+      sl[8] = tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // the slots are wave-private
+
+  // ---- phase B: lane = (row r, channels 8 g .. 8 g + 7), streaming softmax over the views.  (Measured, same box: this kernel 289 us, the lane-per-sample kernel 284-291 us at
+  // config 2; 81 -> ~50 us on a 512-ray shard.  Both read the same 2.7 GB of texel rows per launch — 5.2 M (sample, view) pairs x 4 taps x 128 bytes — and that, not the
+  // arithmetic, is the bound at full size: with the next view's taps prefetched into a second register set the kernel took 346 us.  Sharing a cell's rows between the
+  // consecutive samples that fall into it, as mv_front_kernel does, is what would cut it.)
+  float m = -3.4e38f, den = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float4 cv = *(const float4*)(rgbv + ((size_t)nn * V + v) * 4);
+    const bool vis = alive && cv.w != 0.f;
+    float o = -1e9f;
+    if (__ballot(vis) != 0ull) {   // (wave-uniform: views none of the 16 samples is visible in are skipped)
+      const float* sl = myslots[r][v];
+      const float4 s0 = *(const float4*)sl, s1 = *(const float4*)(sl + 4);
+      const float a7 = sl[8];
+      int of[4];
+      unpack_taps(__float_as_uint(s0.x), vw.w, of);
+      const float* pb = pfeat + (size_t)v * fmap * 32 + 8 * g;
+      float x[8];
+      {
+        const float4 a0 = *(const float4*)(pb + (size_t)of[0] * 32), a1 = *(const float4*)(pb + (size_t)of[0] * 32 + 4);
+        const float4 c0 = *(const float4*)(pb + (size_t)of[1] * 32), c1 = *(const float4*)(pb + (size_t)of[1] * 32 + 4);
+        const float4 d0 = *(const float4*)(pb + (size_t)of[2] * 32), d1 = *(const float4*)(pb + (size_t)of[2] * 32 + 4);
+        const float4 e0 = *(const float4*)(pb + (size_t)of[3] * 32), e1 = *(const float4*)(pb + (size_t)of[3] * 32 + 4);
+        const float w0 = s0.y, w1 = s0.z, w2t = s0.w, w3 = s1.x;
+        x[0] = fmaf(e0.x, w3, fmaf(d0.x, w2t, fmaf(c0.x, w1, a0.x * w0))); x[1] = fmaf(e0.y, w3, fmaf(d0.y, w2t, fmaf(c0.y, w1, a0.y * w0)));
+        x[2] = fmaf(e0.z, w3, fmaf(d0.z, w2t, fmaf(c0.z, w1, a0.z * w0))); x[3] = fmaf(e0.w, w3, fmaf(d0.w, w2t, fmaf(c0.w, w1, a0.w * w0)));
+        x[4] = fmaf(e1.x, w3, fmaf(d1.x, w2t, fmaf(c1.x, w1, a1.x * w0))); x[5] = fmaf(e1.y, w3, fmaf(d1.y, w2t, fmaf(c1.y, w1, a1.y * w0)));
+        x[6] = fmaf(e1.z, w3, fmaf(d1.z, w2t, fmaf(c1.z, w1, a1.z * w0))); x[7] = fmaf(e1.w, w3, fmaf(d1.w, w2t, fmaf(c1.w, w1, a1.w * w0)));
+      }
+      const float in8[8] = {cv.x, cv.y, cv.z, cv.w, s1.y, s1.z, s1.w, a7};
+      unsigned hh[8], hl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = x[j] + bl[j];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a = fmaf(wl[j][jj], in8[jj], a);
+        const float hv = nl_lrelu(xa[j] + a);
+        unsigned u = __float_as_uint(hv);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        hh[j] = u >> 16;
+        unsigned w = __float_as_uint(hv - __uint_as_float(hh[j] << 16));
+        w += 0x7fffu + ((w >> 16) & 1u);
+        hl[j] = w >> 16;
+      }
+      const bt_u32x4 bh = {hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+      const bt_u32x4 blo = {hl[0] | (hl[1] << 16), hl[2] | (hl[3] << 16), hl[4] | (hl[5] << 16), hl[6] | (hl[7] << 16)};
+      bt_f32x4 acc = {b2q[0], b2q[1], b2q[2], b2q[3]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, al), __builtin_bit_cast(bt_bf16x8, bh), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, ah), __builtin_bit_cast(bt_bf16x8, blo), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, ah), __builtin_bit_cast(bt_bf16x8, bh), acc, 0, 0, 0);
+      float op = w4q[0] * nl_lrelu(acc[0]);
+      op = fmaf(w4q[1], nl_lrelu(acc[1]), op); op = fmaf(w4q[2], nl_lrelu(acc[2]), op); op = fmaf(w4q[3], nl_lrelu(acc[3]), op);
+      op += __shfl_xor(op, 16, 64);
+      op += __shfl_xor(op, 32, 64);
+      o = vis ? op + b4v : -1e9f;
+    }
+    const float mn = fmaxf(m, o);
+    const float sc = expf(m - mn), e = expf(o - mn);
+    den = fmaf(den, sc, e);
+    cr = fmaf(cr, sc, cv.x * e); cg = fmaf(cg, sc, cv.y * e); cb = fmaf(cb, sc, cv.z * e);
+    m = mn;
+  }
+  if (live && g == 0) {
+    const float inv = alive ? 1.f / den : 0.f;
+    rgb_s[3 * (size_t)n] = cr * inv; rgb_s[3 * (size_t)n + 1] = cg * inv; rgb_s[3 * (size_t)n + 2] = cb * inv;
+  }
+}
+
 int nl_launch_blend_taps(const NlViews& vw, const float* viewsdev, const float* pfeat, const float* blw, const float* xyz, const float* hA, const float* rgbv, int64_t N,
                          const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st, const int* n_alive, int S) {
   if (N <= 0) return NL_OK;
+#ifdef NL_BLEND_TAPS_V1   // (A/B builds: the lane-per-sample kernel of round 4)
   hipLaunchKernelGGL(blend_taps_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, vw, viewsdev, pfeat, blw, xyz, hA, rgbv, (int)N, w2, b2, w4, b4, rgb_s, n_alive, S);
+#else
+  hipLaunchKernelGGL(blend_taps_mfma_kernel, dim3((unsigned)nl_cdiv(N, 64)), dim3(256), 0, st, vw, viewsdev, pfeat, blw, xyz, hA, rgbv, (int)N, w2, b2, w4, b4, rgb_s, n_alive, S);
+#endif
   NL_LAUNCH_CHECK();
   return NL_OK;
 }
