@@ -404,29 +404,30 @@ int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t
 // phase B (lane = (row, octet): 8 loads, the 8 x 8 [rgb | vis | angle] columns of layer 1 in registers, LeakyReLU), then rgb_blending_mlp.2 (32 -> 16) as three
 // v_mfma_f32_16x16x32_bf16 (split-bf16 like every parity-mode product; its A fragments are built from the fp32 weights at kernel start) — the lane's octet IS its slice of
 // the B operand — LeakyReLU, the 16 -> 1 layer as 4 FMAs + two cross-lane adds, and a streaming softmax over the views (no per-view array).
+namespace {
 typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float bt_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned bt_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BT_SLOT = 12;   // dwords per (row, view): [cell, w0, w1, w2 | w3, angle 0-2 | angle 3, -, -, -]
-__global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ pfeat /*(V,h,w,32)*/,
+constexpr int BT_SLOT = 9;    // dwords per (row, view): cell, w0 .. w3, the four view-angle features (an odd stride: dword accesses, no bank conflicts; 24 KB at 10 views)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void blend_taps_mfma_kernel(const NlViews vw, const float* __restrict__ viewsdev, const float* __restrict__ pfeat /*(V,h,w,32)*/,
                                                               const float* __restrict__ blw /*[32][8], bias[32]*/, const float* __restrict__ xyz,
                                                               const float* __restrict__ hA, const float* __restrict__ rgbv, int N,
                                                               const float* __restrict__ w2 /*[16][32]*/, const float* __restrict__ b2,
                                                               const float* __restrict__ w4 /*[16]*/, const float* __restrict__ b4,
                                                               float* __restrict__ rgb_s, const int* __restrict__ n_alive, int S) {
   using namespace nlmv;
-  __shared__ __attribute__((aligned(16))) float slots[4][16][NL_MAX_VIEWS][BT_SLOT];
+  // Dynamic LDS: [288 floats: layer 1's small columns [32][8] + bias [32]] [4 waves][16 rows][V views][BT_SLOT].  The kernel is latency-bound (a dependent chain per view),
+  // so it is built for waves in flight: the small columns are read from LDS (a broadcast per octet group) instead of held in 72 registers (156 -> 83), the slots are sized by
+  // the frame's view count (24 KB at 10 views): 6 waves per SIMD where the first version had 3
+  extern __shared__ __attribute__((aligned(16))) float bt_lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 15, g = lane >> 4;
   const int V = vw.V;
-  // ---- resident: layer 1's small columns for the lane's 8 channels, layer 2 as A fragments (row n = r, k = 8 g + t), the output layer's slice
-  float wl[8][8], bl[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    bl[j] = blw[256 + 8 * g + j];
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) wl[j][jj] = blw[(8 * g + j) * 8 + jj];
-  }
+  for (int i = threadIdx.x; i < 288; i += 256) bt_lds[i] = blw[i];
+  __syncthreads();
+  const float* wls = bt_lds + 64 * g;        // rows 8 g .. 8 g + 7 of the [32][8] block
+  const float* bls = bt_lds + 256 + 8 * g;
+  // ---- resident: layer 2 as A fragments (row n = r, k = 8 g + t), the output layer's slice
   bt_u32x4 ah, al;
   {
     unsigned hw[8], lw[8];
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, 
   for (int t = 0; t < 4; ++t) { b2q[t] = b2[4 * g + t]; w4q[t] = w4[4 * g + t]; }
   const float b4v = b4[0];
   const size_t fmap = (size_t)vw.h * vw.w;
-  float (*myslots)[NL_MAX_VIEWS][BT_SLOT] = slots[wave];
+  float* const myslots = bt_lds + 288 + (size_t)wave * 16 * V * BT_SLOT;   // [row][view][BT_SLOT]
 
   const int n = (blockIdx.x * 4 + wave) * 16 + r;
   const bool live = n < N;
@@ -487,16 +488,16 @@ __global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, 
       tt[0] *= rt; tt[1] *= rt; tt[2] *= rt;
       const float df[3] = {tq[0] - tt[0], tq[1] - tt[1], tq[2] - tt[2]};
       const float rd = 1.f / fmaxf(sqrtf(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]), 1e-6f);
-      float* sl = myslots[r][v];
-      *(float4*)sl = make_float4(__uint_as_float(pack_taps(tf, vw.w, vw.h)), w0, w1, w2t);
-      *(float4*)(sl + 4) = make_float4(w3, df[0] * rd, df[1] * rd, df[2] * rd);
+      float* sl = myslots + ((size_t)r * V + v) * BT_SLOT;
+      sl[0] = __uint_as_float(pack_taps(tf, vw.w, vw.h)); sl[1] = w0; sl[2] = w1; sl[3] = w2t; sl[4] = w3;
+      sl[5] = df[0] * rd; sl[6] = df[1] * rd; sl[7] = df[2] * rd;
       sl[8] = tq[0] * tt[0] + tq[1] * tt[1] + tq[2] * tt[2];
     }
   }
   __builtin_amdgcn_wave_barrier();   // the slots are wave-private
 
-  // ---- phase B: lane = (row r, channels 8 g .. 8 g + 7), streaming softmax over the views.  (Measured, same box: this kernel 289 us, the lane-per-sample kernel 284-291 us at
-  // config 2; 81 -> ~50 us on a 512-ray shard.  Both read the same 2.7 GB of texel rows per launch — 5.2 M (sample, view) pairs x 4 taps x 128 bytes — and that, not the
+  // ---- phase B: lane = (row r, channels 8 g .. 8 g + 7), streaming softmax over the views.  (Measured, same box: the first version of this kernel — small columns in registers, static slots: 3 waves per SIMD — 289 us,
+  // the lane-per-sample kernel 284-291 us at config 2.  Both read the same 2.7 GB of texel rows per launch — 5.2 M (sample, view) pairs x 4 taps x 128 bytes — and that, not the
   // arithmetic, is the bound at full size: with the next view's taps prefetched into a second register set the kernel took 346 us.  Sharing a cell's rows between the
   // consecutive samples that fall into it, as mv_front_kernel does, is what would cut it.)
   float m = -3.4e38f, den = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
@@ -505,8 +506,8 @@ __global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, 
     const bool vis = alive && cv.w != 0.f;
     float o = -1e9f;
     if (__ballot(vis) != 0ull) {   // (wave-uniform: views none of the 16 samples is visible in are skipped)
-      const float* sl = myslots[r][v];
-      const float4 s0 = *(const float4*)sl, s1 = *(const float4*)(sl + 4);
+      const float* sl = myslots + ((size_t)r * V + v) * BT_SLOT;
+      const float4 s0 = make_float4(sl[0], sl[1], sl[2], sl[3]), s1 = make_float4(sl[4], sl[5], sl[6], sl[7]);
       const float a7 = sl[8];
       int of[4];
       unpack_taps(__float_as_uint(s0.x), vw.w, of);
@@ -527,9 +528,10 @@ __global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, 
       unsigned hh[8], hl[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float a = x[j] + bl[j];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) a = fmaf(wl[j][jj], in8[jj], a);
+        float a = x[j] + bls[j];
+        const float4 wa = *(const float4*)(wls + 8 * j), wb = *(const float4*)(wls + 8 * j + 4);
+        a = fmaf(wa.x, in8[0], a); a = fmaf(wa.y, in8[1], a); a = fmaf(wa.z, in8[2], a); a = fmaf(wa.w, in8[3], a);
+        a = fmaf(wb.x, in8[4], a); a = fmaf(wb.y, in8[5], a); a = fmaf(wb.z, in8[6], a); a = fmaf(wb.w, in8[7], a);
         const float hv = nl_lrelu(xa[j] + a);
         unsigned u = __float_as_uint(hv);
         u += 0x7fffu + ((u >> 16) & 1u);
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(256) void blend_taps_mfma_kernel(const NlViews vw, 
     rgb_s[3 * (size_t)n] = cr * inv; rgb_s[3 * (size_t)n + 1] = cg * inv; rgb_s[3 * (size_t)n + 2] = cb * inv;
   }
 }
+}  // namespace
 
 int nl_launch_blend_taps(const NlViews& vw, const float* viewsdev, const float* pfeat, const float* blw, const float* xyz, const float* hA, const float* rgbv, int64_t N,
                          const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st, const int* n_alive, int S) {
@@ -568,7 +571,8 @@ int nl_launch_blend_taps(const NlViews& vw, const float* viewsdev, const float* 
 #ifdef NL_BLEND_TAPS_V1   // (A/B builds: the lane-per-sample kernel of round 4)
   hipLaunchKernelGGL(blend_taps_kernel, dim3((unsigned)nl_cdiv(N, 256)), dim3(256), 0, st, vw, viewsdev, pfeat, blw, xyz, hA, rgbv, (int)N, w2, b2, w4, b4, rgb_s, n_alive, S);
 #else
-  hipLaunchKernelGGL(blend_taps_mfma_kernel, dim3((unsigned)nl_cdiv(N, 64)), dim3(256), 0, st, vw, viewsdev, pfeat, blw, xyz, hA, rgbv, (int)N, w2, b2, w4, b4, rgb_s, n_alive, S);
+  const size_t lds = (288 + (size_t)4 * 16 * vw.V * BT_SLOT) * sizeof(float);   // <= 38 KB at 16 views
+  hipLaunchKernelGGL(blend_taps_mfma_kernel, dim3((unsigned)nl_cdiv(N, 64)), dim3(256), lds, st, vw, viewsdev, pfeat, blw, xyz, hA, rgbv, (int)N, w2, b2, w4, b4, rgb_s, n_alive, S);
 #endif
   NL_LAUNCH_CHECK();
   return NL_OK;
