@@ -181,7 +181,7 @@ class ConditionalNeRF(nn.Module):
     # reports the largest |logit| it scored (nl_frame_diagnostics); after the FIRST inference batch of every frame the module reads it (one device-to-host
     # copy per frame, next to a 4-ms per-frame setup) and, if it is beyond the limit its current mode was validated to, re-renders that batch and keeps
     # rendering the frame in the next more exact mode (f16mx -> bf16x3 -> fp32).  Limits: the |logit| up to which the mode stayed within 1e-4 of the CPU oracle
-    # on every scene of the sweep (profiles/r5_scale_sweep.txt: f16mx 8.1e-5 at |logit| 142 and 1.2e-4 at 271; bf16x3 4.2e-5 at 475 and 0.9-1.7e-4 at ~1000; the
+    # on every scene of the sweep (profiles/r5_scale_sweep.txt, MX-FP6 build: f16mx 7.2e-5 at |logit| 95, 9.3e-5 at 142, 8.5e-5 at 275 and 1.7e-4 at 462; bf16x3 4.2e-5 at 475 and 0.9-1.7e-4 at ~1000; the
     # synthetic BASELINE scenes sit at 4-6).  precision_guard=False switches it off; `guard_events` lists what it did.
     LOGIT_LIMIT = {"f16mx": 100.0, "bf16x3": 500.0}
     _SAFER = {"f16mx": "bf16x3", "bf16x3": "fp32", "bf16": "bf16x3"}
