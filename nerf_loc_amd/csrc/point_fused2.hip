@@ -42,7 +42,7 @@ typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 namespace {
 
 #ifndef PF2_KO
-#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention, 16 the second cross-term matrix instruction of every slab skipped (its reads and fills stay): the matrix-pipe time fp6 cross terms would take
+#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention, 256 no barriers in the tile loop (what the waves' skew costs), 16 the second cross-term matrix instruction of every slab skipped (its reads and fills stay): the matrix-pipe time fp6 cross terms would take
 #endif
 constexpr int KO = PF2_KO;
 #ifndef PF2_MX_FP6
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
           if constexpr (ks == NKS - 1) {
             if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
           }
           const u32x4 bh = __builtin_shufflevector(Xh16[IN][q], Xh16[IN][q], 4 * sI, 4 * sI + 1, 4 * sI + 2, 4 * sI + 3);
           if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
           if constexpr (ks == NKS - 1) {
             if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
           }
           const u32x4 bh = frag4(Xh[IN][ks]);
           if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         // slot reads; its last fragments are in registers already
         if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
       }
       auto bsel = [&](auto Hi) __attribute__((always_inline)) {
         if constexpr (L == 0) { if constexpr (decltype(Hi)::value) return frag4(Ph[ks]); else return frag4(Pl[ks]); }
