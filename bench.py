@@ -57,7 +57,8 @@ def executed_mfma_equiv_mac_per_sample(W: int, V: int, S: int, precision: str, C
     of the bf16 MFMA peak `roofline.frac` would show with the matrix pipe 100 % busy: the CEILING of the parity mode."""
     per = {"bf16": 1.0, "bf16x3": 3.0, "f16mx": 3.0, "fp32": 16.0}[precision]     # every GEMM but the fused kernel's wide layers
     wide = {"f16mx": 1.5}.get(precision, per)                                      # layers 2, 3 and the k / v projections of point_fused2_kernel
-    point = K * (96 * W * per + (2 * W * W + 256 * W) * wide)                       # layer 1 (K = 96: posenc + ray_diff_fc) + layers 2, 3 + k / v
+    l1 = {"f16mx": 10.0 / 6.0}.get(precision, per)                                 # layer 1 of point_fused2_kernel in f16mx: 6 f16 + 4 fp6 matrix instructions for its 6 k-steps (slab 1 is half empty)
+    point = K * (96 * W * l1 + (2 * W * W + 256 * W) * wide)                        # layer 1 (K = 96: posenc + ray_diff_fc) + layers 2, 3 + k / v
     unet = 192 * W + 12288 + 12288 + 6144 + 12288 + 6144 + 3 * (W + 32) * W   # the seven convolutions per sample (SURVEY 8d: pooled levels, transposed = 1.5 taps per output)
     other = (384 * 64 + 2 * 64 * W + W * 128 + 128 * W + W * W + W * 32 + V * (4 * 2 * 32 * 32 + 6 * 32) + unet + C * W / S)
     return point + other * per, point
@@ -296,8 +297,8 @@ def main():
             "name": "point_fused2_kernel", "launches": launches.value, "avg_ms": fused_ms.value / launches.value,
             "share_of_step": fused_ms.value / args.steps / (dev_ms / args.steps),
             "achieved": alg, "frac": alg / PEAK_BF16_TFLOPS, "unit": "TFLOP/s (algorithmic, SURVEY §8d)",
-            "executed_mfma_TFLOPs": 2.0 * (K * 96 * W * {"bf16x3": 3.0, "f16mx": 3.0}.get(args.precision, 1.0) + (mac_exec - K * 96 * W) * {"bf16x3": 3.0, "f16mx": 1.5}.get(args.precision, 1.0))
-                                    * samples_per_launch / sec / 1e12,   # (layer 1 stays three-term split-bf16 in f16mx)
+            "executed_mfma_TFLOPs": 2.0 * (K * 96 * W * {"bf16x3": 3.0, "f16mx": 10.0 / 6.0}.get(args.precision, 1.0) + (mac_exec - K * 96 * W) * {"bf16x3": 3.0, "f16mx": 1.5}.get(args.precision, 1.0))
+                                    * samples_per_launch / sec / 1e12,   # (f16mx, layer 1: 10 matrix instructions of 8 passes for 6 k-steps)
         }
 
     if gather:

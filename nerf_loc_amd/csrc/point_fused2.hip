@@ -48,6 +48,10 @@ constexpr int KO = PF2_KO;
 #ifndef PF2_MX_FP6
 #define PF2_MX_FP6 1   // the cross terms of NL_PREC_F16MX: 1 = MX-FP6 (e2m3, 8 passes per K = 64: 1.5 matrix-instruction equivalents per product), 0 = MX-FP8 (e4m3, 16 passes: 2.0)
 #endif
+#ifndef PF2_L1_MX
+#define PF2_L1_MX 1   // MX-FP6: layer 1 (K = 96: positional encoding + ray_diff_fc outputs) also as fp16 hi.hi + two fp6 cross terms (6 + 4 matrix instructions of 8 passes instead of 18)
+#endif
+constexpr bool L1MX = PF2_L1_MX;
 constexpr int MXK = PF2_MX_FP6 ? 2 : 1;   // the one MX instance this library carries (pack and launch agree by construction)
 #ifdef PF2_TRACE
 __device__ unsigned long long pf2_trace[256];   // debug: cycle counter at every region start of one tile (block 0, wave 0)
@@ -87,7 +91,7 @@ struct Geo {
   static constexpr int RES_SC = RES_ATT + 4 * 4 * 32 / 4;   // MX mode: E8M0 scale bytes of the chunks' fp8 weight images, ints [NC][2] = {w_hi8, w_lo8}
   static constexpr int RES_BND = RES_SC + (2 * NC + 3) / 4;   // MX mode: 8 floats — the bounds the activation block scales are derived from (pf2_mx_bounds_kernel)
   static constexpr int RES_SC6 = RES_BND + 2;   // MX-FP6: the wide chunks' weight-scale dwords [chunk 2 NRT + 8][lane 64] x {w_hi6, w_lo6} (pack_point_mx6_kernel)
-  static constexpr int LDS_U4 = RES_SC6 + (MX6 ? (2 * NRT + 8) * 32 : 0);
+  static constexpr int LDS_U4 = RES_SC6 + (MX6 ? (L1MX ? NC : 2 * NRT + 8) * 32 : 0);
   // micro-steps of a finished chunk's epilogue: layers: 8 pairs x (LeakyReLU + hi | lo); k head: 9; v head: 4 x (4 sums + store)
   // (KEEP: + 4 row stores of a k head / 4 x 4 dword stores of a v head: the rows nl_attn_backward reads)
   static constexpr int epi_steps(int c) { return layer(c) < 3 ? 8 * (X3 ? 2 : 1) + (MX6 && (rt(c) & 1) ? 2 : 0) : (rt(c) < 4 ? 10 : 10) + (KEEP ? 4 : 0); }
@@ -190,6 +194,12 @@ __device__ __forceinline__ unsigned lo2_f16(float v0, float v1, unsigned hi) {
       : "=&v"(lo), "=&v"(t0), "=&v"(t1) : "v"(v0), "v"(v1), "v"(hi));
   return lo;
 }
+// f16 pair of two values + the running maximum of their magnitudes (layer-1 operands of the MX-FP6 path: no activation in between)
+__device__ __forceinline__ unsigned hi2_f16_amax(float v0, float v1, float& m) {
+  unsigned hi;
+  asm("v_max3_f32 %1, |%2|, |%3|, %1\n\tv_cvt_pk_f16_f32 %0, %2, %3" : "=&v"(hi), "+v"(m) : "v"(v0), "v"(v1));
+  return hi;
+}
 // residuals of a pair as floats: v - float(hi half) (exact)
 __device__ __forceinline__ void lo2_f32(float v0, float v1, unsigned hi, float& l0, float& l1) {
   asm("v_fma_mix_f32 %0, %4, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %4, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     for (int i = tid; i < 2 * PARTS * 64; i += 256) lds_all[GG::RES_RD + i] = src[(i / (PARTS * 64)) * 128 + i % (PARTS * 64)];
     for (int i = tid; i < (64 + 2 * W) / 4; i += 256) lds_all[GG::RES_BIAS + i] = src[256 + i];
     if (MX8) for (int i = tid; i < (2 * NC + 3) / 4 + 2; i += 256) lds_all[GG::RES_SC + i] = src[256 + (64 + 2 * W) / 4 + i];   // + the bounds block
-    if (MX6) for (int i = tid; i < (2 * NRT + 8) * 32; i += 256) lds_all[GG::RES_SC6 + i] = src[256 + (64 + 2 * W) / 4 + (2 * NC + 3) / 4 + 2 + i];
+    if (MX6) for (int i = tid; i < (L1MX ? NC : 2 * NRT + 8) * 32; i += 256) lds_all[GG::RES_SC6 + i] = src[256 + (64 + 2 * W) / 4 + (2 * NC + 3) / 4 + 2 + i];
   }
   __syncthreads();
 
@@ -356,6 +366,14 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   unsigned hp6[2][8];                   // f16 pairs of the two row tiles a slab is made of (until the slab is complete)
   float lo6t[2][16];                    // their residuals
   float scf6 = 1.f;
+  // layer 1 in the same arithmetic (L1MX): its B operands of the tile — slab 0 = k-steps 0-3 (positional encoding + raw offsets), slab 1 = k-steps 4, 5 (ray_diff_fc outputs) + two
+  // empty k-steps — as f16 fragments (P16), fp6 images (P6[slab][0 = hi, 1 = residual]) and the two scale-byte registers; pp* / plo*: pairs and residuals until a slab is complete
+  u32x16 P16[2];
+  unsigned P6[2][2][6];
+  unsigned pxs6h = 0u, pxs6l = 0u;
+  unsigned pp0[16], pp1[8];
+  float plo0[32], plo1[16];
+  float pam0 = 0.f, pam1 = 0.f;
   const int* ssc = reinterpret_cast<const int*>(lds_all + GG::RES_SC);
   // MX mode, round 5: the activations' fp8 images carry a block scale PER ROW AND LAYER instead of the constants 1 / 2^-11 (whose window was |a| = 2^-6 ... 448:
   // beyond it the cross terms saturated and the product fell back to single-fp16 accuracy — tools/scale_sweep.py found it with the feature maps x 8).  The scale of
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   f32x4 pb[4];
   double sx[3], skd[3], sr[3], sr2[3], su[3], sw[3], ss[3], scs[3];
   int skq[3];
-  constexpr int NPL = 2, NPC = 55, NPRO = NPL + NPC;   // load steps, compute steps
+  constexpr int NPL = 2, NPC = (MX6 && L1MX) ? 57 : 55, NPRO = NPL + NPC;   // load steps, compute steps (L1MX: + the two slabs' packing conversions)
   auto pro_step = [&](auto Ic) __attribute__((always_inline)) {
     constexpr int I = decltype(Ic)::value;
     if constexpr (I == 0) {   // ---- loads that depend on the tile number only
@@ -527,8 +545,16 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         finish_pair(pa[4 * g + 2] + pb[g][2], pa[4 * g + 3] + pb[g][3], hidh[2 * g + 1], hidl[2 * g + 1]);
       } else if constexpr (C >= 8 && C <= 11) {   // output layer -> k-steps 4, 5
         constexpr int g = C - 8;
+        if constexpr (MX6 && L1MX) {   // k-steps 4, 5 = dwords 2 g, 2 g + 1 of slab 1
+          if constexpr (g == 0) pam1 = 0.f;
+          float v0 = pa[4 * g] + pb[g][0], v1 = pa[4 * g + 1] + pb[g][1], v2 = pa[4 * g + 2] + pb[g][2], v3 = pa[4 * g + 3] + pb[g][3];
+          v0 = vmax(v0, v0 * 0.01f); v1 = vmax(v1, v1 * 0.01f); v2 = vmax(v2, v2 * 0.01f); v3 = vmax(v3, v3 * 0.01f);
+          pp1[2 * g] = hi2_f16_amax(v0, v1, pam1); pp1[2 * g + 1] = hi2_f16_amax(v2, v3, pam1);
+          lo2_f32(v0, v1, pp1[2 * g], plo1[4 * g], plo1[4 * g + 1]); lo2_f32(v2, v3, pp1[2 * g + 1], plo1[4 * g + 2], plo1[4 * g + 3]);
+        } else {
         finish_pair(pa[4 * g] + pb[g][0], pa[4 * g + 1] + pb[g][1], Ph[4 + g / 2][(2 * g) & 3], Pl[4 + g / 2][(2 * g) & 3]);
         finish_pair(pa[4 * g + 2] + pb[g][2], pa[4 * g + 3] + pb[g][3], Ph[4 + g / 2][(2 * g + 1) & 3], Pl[4 + g / 2][(2 * g + 1) & 3]);
+        }
       } else if constexpr (C >= 12 && C < 39) {
         // ---- positional encoding (utils.py:5-35).  Half hh owns octaves 5 hh .. 5 hh + 4 of every axis: value e = 10 a + 2 f' + comp
         // (comp 0 = sin, 1 = cos), then e = 30, 31 = raw (x, y) for half 0 and (z, 0) for half 1.  One accurate fp64 evaluation per
@@ -551,20 +577,55 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         }
       } else if constexpr (C >= 39 && C < 54) {
         constexpr int f = (C - 39) / 3, a = (C - 39) % 3, p = 5 * a + f;
+        if constexpr (MX6 && L1MX) {   // pair p = dword p of slab 0
+          if constexpr (C == 39) pam0 = 0.f;
+          const float v0 = (float)ss[a], v1 = (float)scs[a];
+          pp0[p] = hi2_f16_amax(v0, v1, pam0);
+          lo2_f32(v0, v1, pp0[p], plo0[2 * p], plo0[2 * p + 1]);
+        } else {
         unsigned h = 0, l = 0;
         split2f<X3, F16>((float)ss[a], (float)scs[a], h, l);
         Ph[p / 4][p & 3] = h;
         if (X3) Pl[p / 4][p & 3] = l;
+        }
         if constexpr (f < 4) {
           const double s2 = 2.0 * ss[a] * scs[a];
           scs[a] = fma(-2.0 * ss[a], ss[a], 1.0);
           ss[a] = s2;
         }
-      } else {
+      } else if constexpr (C == 54) {
+        if constexpr (MX6 && L1MX) {
+          const float v0 = hh ? poff[2] : poff[0], v1 = hh ? 0.f : poff[1];
+          pp0[15] = hi2_f16_amax(v0, v1, pam0);
+          lo2_f32(v0, v1, pp0[15], plo0[30], plo0[31]);
+        } else {
         unsigned h = 0, l = 0;
         split2f<X3, F16>(hh ? poff[2] : poff[0], hh ? 0.f : poff[1], h, l);
         Ph[3][3] = h;
         if (X3) Pl[3][3] = l;
+        }
+      } else {   // L1MX: a slab of the layer-1 operands is complete — block scale, the f16 fragments as one vector, the two fp6 images (as in the layers' epilogues)
+        constexpr int q = C - 55;
+        int eb = __builtin_amdgcn_frexp_expf(q == 0 ? pam0 : pam1) + 124;
+        eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);
+        const float sf = __builtin_bit_cast(float, eb << 23);
+        if constexpr (q == 0) { pxs6h = (unsigned)eb; pxs6l = (unsigned)(eb - 11); }
+        else { pxs6h |= (unsigned)eb << 8; pxs6l |= (unsigned)(eb - 11) << 8; }
+        u32x16 H;
+        f32x16 l0, l1;
+        if constexpr (q == 0) {
+          H = u32x16{pp0[0], pp0[1], pp0[2], pp0[3], pp0[4], pp0[5], pp0[6], pp0[7], pp0[8], pp0[9], pp0[10], pp0[11], pp0[12], pp0[13], pp0[14], pp0[15]};
+          l0 = f32x16{plo0[0], plo0[1], plo0[2], plo0[3], plo0[4], plo0[5], plo0[6], plo0[7], plo0[8], plo0[9], plo0[10], plo0[11], plo0[12], plo0[13], plo0[14], plo0[15]};
+          l1 = f32x16{plo0[16], plo0[17], plo0[18], plo0[19], plo0[20], plo0[21], plo0[22], plo0[23], plo0[24], plo0[25], plo0[26], plo0[27], plo0[28], plo0[29], plo0[30], plo0[31]};
+        } else {
+          H = u32x16{pp1[0], pp1[1], pp1[2], pp1[3], pp1[4], pp1[5], pp1[6], pp1[7], 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+          l0 = f32x16{plo1[0], plo1[1], plo1[2], plo1[3], plo1[4], plo1[5], plo1[6], plo1[7], plo1[8], plo1[9], plo1[10], plo1[11], plo1[12], plo1[13], plo1[14], plo1[15]};
+          l1 = zero16;
+        }
+        P16[q] = H;
+        const u32x6 rh = cvt_pk32_fp6_f16(H, sf), rl = cvt_2xpk16_fp6_f32(l0, l1, sf * 0.00048828125f);
+        P6[q][0][0] = rh[0]; P6[q][0][1] = rh[1]; P6[q][0][2] = rh[2]; P6[q][0][3] = rh[3]; P6[q][0][4] = rh[4]; P6[q][0][5] = rh[5];
+        P6[q][1][0] = rl[0]; P6[q][1][1] = rl[1]; P6[q][1][2] = rl[2]; P6[q][1][3] = rl[3]; P6[q][1][4] = rl[4]; P6[q][1][5] = rl[5];
       }
     }
   };
@@ -626,7 +687,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   // ... and the chunk's two scale dwords: resident (8 bytes per lane and wide chunk)
   auto read_wsc6 = [&](auto Cc) __attribute__((always_inline)) {
     constexpr int c = GG::cm(decltype(Cc)::value);
-    wsc6 = lds_res8[(GG::RES_SC6 - NBUF * SLOT) * 2 + (c - NRT) * 64];
+    wsc6 = lds_res8[(GG::RES_SC6 - NBUF * SLOT) * 2 + (L1MX ? c : c - NRT) * 64];
   };
 
   // ---------------------------------------------------------------- epilogue micro-steps of chunk C, run inside region C+1
@@ -756,10 +817,11 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
     // slots of a region: one per MFMA (3 per k-step); an MX region has 8 units per slab (f16 MFMA = 1, fp8 MFMA = 2: its issue shadow is twice as long),
     // its barrier sits in front of unit 8 (NSL - 1) + 3 (every LDS-DMA piece is issued before it), and a layer epilogue must be through before the last slab
     constexpr int NKS = GG::nks(G);
+    constexpr bool L1R = MX6 && L1MX && GG::layer(G) == 0;   // a layer-1 region in the MX-FP6 arithmetic: 10 units, the barrier in front of unit 7
     constexpr bool MXR = MX && GG::layer(G) > 0;
     // (MX-FP6: its cross-term instructions take 8 passes like the f16 ones — 6 units per slab, the barrier in front of unit 6 (NSL - 1) + 3)
-    constexpr int NS = MXR ? (MX6 ? 6 * (NKS / 4) : 2 * NKS) : MPK * NKS, NSD = MXR ? (MX6 ? 6 * (NKS / 4) - 3 : 2 * NKS - 5) : MPK * (NKS - 1),
-                  NSEL = MXR ? (MX6 ? 6 * (NKS / 4) - 6 : 2 * NKS - 8) : NSD;
+    constexpr int NS = L1R ? 10 : MXR ? (MX6 ? 6 * (NKS / 4) : 2 * NKS) : MPK * NKS, NSD = L1R ? 7 : MXR ? (MX6 ? 6 * (NKS / 4) - 3 : 2 * NKS - 5) : MPK * (NKS - 1),
+                  NSEL = L1R ? 8 : MXR ? (MX6 ? 6 * (NKS / 4) - 6 : 2 * NKS - 8) : NSD;
     // LDS-DMA pieces of chunk G+3 (its slot held chunk G-1, which every wave left behind at the previous barrier)
     if constexpr (K < NSD && !(KO & 4)) {
       constexpr int ND = GG::ppw(G + 3), d0 = K * ND / NSD, d1 = (K + 1) * ND / NSD;
@@ -813,8 +875,49 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
 #endif
     constexpr int L = GG::layer(G), NKS = GG::nks(G), AB = G & 3, CK = GG::cumks(G);
     constexpr bool ZI = L == 3;   // k / v projections have no bias: the first MFMA takes C = 0
-    constexpr bool NEXT_MX = MX && GG::layer(G + 1) > 0;   // the next chunk's part 1 holds fp8 images (its part 0: f16 fragments)
-    if constexpr (MX6 && L > 0) {
+    constexpr bool NEXT_MX = MX && (GG::layer(G + 1) > 0 || (MX6 && L1MX));   // the next chunk's part 1 holds fp8 / fp6 images (its part 0: f16 fragments)
+    if constexpr (MX6 && L1MX && L == 0) {
+      // layer 1 on the same arithmetic: slab 0 = k-steps 0-3, slab 1 = k-steps 4, 5 (+ two empty ones: zero positions in both operands' images); 6 + 4 matrix instructions of
+      // 8 passes; units: 0-3 | 4, 5 | 6, 7 | 8, 9, the barrier in front of unit 7
+      read_wsc6(Gc);
+      static_for<2>([&](auto Qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(Qc)::value, NKQ = q == 0 ? 4 : 2;
+        static_for<NKQ>([&](auto Sc) __attribute__((always_inline)) {
+          constexpr int sI = decltype(Sc)::value, ks = 4 * q + sI, pos = GG::rpos(CK + ks);
+          if constexpr (ks == NKS - 1) {
+            if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
+          }
+          const u32x4 bh = __builtin_shufflevector(P16[q], P16[q], 4 * sI, 4 * sI + 1, 4 * sI + 2, 4 * sI + 3);
+          if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
+          else if constexpr (ks == NKS - 1) {
+            read_frag(Gc, std::integral_constant<int, NKS>{}, std::integral_constant<int, 0>{});
+            read_frag(Gc, std::integral_constant<int, NKS + 1>{}, std::integral_constant<int, 0>{});
+          }
+          acc[AB] = mfma_h(frh[pos], bh, acc[AB]);   // (the accumulator starts from the table row: load_T)
+          fill(Gc, std::integral_constant<int, 6 * q + sI>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<2>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int im = decltype(Ic)::value;   // 0: w_hi6 x a_lo6, 1: w_lo6 x a_hi6
+          const i32x8 wa = {(int)w6a[q & 1][im][0], (int)w6a[q & 1][im][1], (int)w6a[q & 1][im][2], (int)w6a[q & 1][im][3], (int)w6b[q & 1][im][0], (int)w6b[q & 1][im][1], 0, 0};
+          const unsigned(&xd)[6] = P6[q][1 - im];
+          const i32x8 xb = {(int)xd[0], (int)xd[1], (int)xd[2], (int)xd[3], (int)xd[4], (int)xd[5], 0, 0};
+          const int sw = (int)wsc6[im], sx = (int)(im == 0 ? pxs6l : pxs6h);
+          acc[AB] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xb, acc[AB], 2, 2, q, sw, q, sx);
+          if constexpr (q == 0) {
+            read_w6(Gc, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * im>{});
+            read_w6(Gc, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * im + 1>{});
+          } else {
+            read_w6(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * im>{});
+            read_w6(std::integral_constant<int, G + 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * im + 1>{});
+          }
+          fill(Gc, std::integral_constant<int, q == 0 ? 4 + im : 8 + im>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    } else if constexpr (MX6 && L > 0) {
       constexpr int NSL = NKS / 4, IN = (L + 1) & 1;
       constexpr bool TR = L == 3 && GG::rt(G) >= 4;   // v heads: D = X . Wv^T (rows = neighbour rows) instead of D^T
       read_wsc6(Gc);
@@ -994,7 +1097,9 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   __builtin_amdgcn_s_barrier();
   read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1)>{}, std::integral_constant<int, 0>{});
   read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1) + 1>{}, std::integral_constant<int, 0>{});
-  if constexpr (X3) {
+  if constexpr (MX6 && L1MX) {   // chunk 0's slab-0 images instead of its lo fragments
+    static_for<4>([&](auto Ic) __attribute__((always_inline)) { read_w6(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Ic); });
+  } else if constexpr (X3) {
     read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1)>{}, std::integral_constant<int, 1>{});
     read_frag(std::integral_constant<int, NC - 1>{}, std::integral_constant<int, GG::nks(NC - 1) + 1>{}, std::integral_constant<int, 1>{});
   }
@@ -1183,7 +1288,7 @@ __global__ void pack_point_stream2_kernel(const float* __restrict__ w1, const fl
     if (layer == 0) base = (long long)rt * 2 * 6 * 512;
     else base = (long long)NRT * 2 * 6 * 512 + ((long long)(layer - 1) * NRT + rt) * 2 * KSL * 512;
     const long long in_part = ((long long)ks * 64 + lane) * 8 + t;
-    if (mx == 3 && layer > 0) out[base + in_part] = pf2_f2h(v);   // MX-FP6: the f16 fragments; pack_point_mx6_kernel writes the images and their scales
+    if (mx == 3 && (layer > 0 || L1MX)) out[base + in_part] = pf2_f2h(v);   // MX-FP6: the f16 fragments; pack_point_mx6_kernel writes the images and their scales
     else if (mx == 1 && layer > 0) {
       // MX chunk: part 0 = f16(w) in the same fragment order; part 1 = per slab q of 4 k-steps [w_hi8 bytes 0-15 | 16-31 | w_lo8 bytes 0-15 | 16-31][lane][16], byte
       // u = 8 (ks & 3) + t of a lane <-> this element; hi8 = e4m3(f16(w) / s_hi), lo8 = e4m3((w - f16(w)) / s_lo), scales per chunk (pf2_mx_scale_kernel)
@@ -1253,21 +1358,37 @@ __device__ __forceinline__ unsigned pf2_e2m3(float a) {   // a >= 0, already div
   unsigned c = ((unsigned)(e + 1) << 3) + (m - 8u);    // m == 16 carries into the exponent
   return c > 31u ? 31u : c;
 }
-__global__ void pack_point_mx6_kernel(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ wk, const float* __restrict__ wv,
-                                      unsigned char* __restrict__ out, int NRT) {
+// (L1MX: the layer-1 chunks too — chunk index c = 0 .. NC - 1, layer-1 chunks hold 6 k-steps = slab 0 + half of slab 1, the k-slots of k-steps 6, 7 are zero)
+__global__ void pack_point_mx6_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ wk,
+                                      const float* __restrict__ wv, unsigned char* __restrict__ out, int NRT, int F) {
   const int W = 32 * NRT, KSL = 2 * NRT, NSL = NRT / 2;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nwide = 2 * NRT + 8;
-  if (e >= nwide * NSL * 64 * 2) return;
-  const int im = e & 1, lane = (e >> 1) & 63, q = (e >> 7) % NSL, cw = (e >> 7) / NSL;   // cw: wide chunk 0 .. 2 NRT + 7
-  const int layer = cw < NRT ? 1 : cw < 2 * NRT ? 2 : 3, rt = cw < 2 * NRT ? cw % NRT : cw - 2 * NRT;
+  const int nwide = 2 * NRT + 8, nch = L1MX ? NRT + nwide : nwide;
+  if (e >= nch * NSL * 64 * 2) return;
+  const int im = e & 1, lane = (e >> 1) & 63, q = (e >> 7) % NSL, ci = (e >> 7) / NSL;
+  const int c = L1MX ? ci : ci + NRT;              // chunk index 0 .. NC - 1
+  const int cw = c - NRT;                          // wide chunk 0 .. 2 NRT + 7 (negative: a layer-1 chunk)
+  if (c < NRT && q >= 2) return;                   // layer 1: two slabs
+  const int layer = c < NRT ? 0 : cw < NRT ? 1 : cw < 2 * NRT ? 2 : 3, rt = c < NRT ? c : cw < 2 * NRT ? cw % NRT : cw - 2 * NRT;
   const int hh = lane >> 5, orow = 32 * rt + (lane & 31);
   float v[32], mx = 0.f;
   for (int P = 0; P < 32; ++P) {
     const int sI = im == 0 ? 2 * (P & 1) + (P >> 4) : (P >> 3), t = im == 0 ? (P >> 1) & 7 : (P & 7);
     const int ks = 4 * q + sI;
-    const int fin = 32 * (ks >> 1) + pf2_m(8 * (ks & 1) + t, hh);
-    const float w = pf2_weight(w2, w3, wk, wv, layer, orow, fin, W);
+    float w = 0.f;
+    if (layer == 0) {   // the column map of pack_point_stream2_kernel's layer-1 branch
+      int col = -1;
+      if (ks < 4) {
+        const int ee = 8 * ks + t;
+        if (ee < 30) { const int a = ee / 10, rem = ee - 10 * a, f = (rem >> 1) + 5 * hh, comp = rem & 1; col = F + 3 + 6 * f + 3 * comp + a; }
+        else if (ee == 30) col = hh ? F + 2 : F;
+        else col = hh ? -1 : F + 1;
+      } else if (ks < 6) { const int o = pf2_m(8 * (ks - 4) + t, hh); col = o < 27 ? F + 63 + o : -1; }
+      if (col >= 0) w = w1[(size_t)orow * (F + 90) + col];
+    } else {
+      const int fin = 32 * (ks >> 1) + pf2_m(8 * (ks & 1) + t, hh);
+      w = pf2_weight(w2, w3, wk, wv, layer, orow, fin, W);
+    }
     const float h = pf2_h2f(pf2_f2h(w));
     v[P] = im == 0 ? h : w - h;
     mx = fmaxf(mx, fabsf(v[P]));
@@ -1284,16 +1405,17 @@ __global__ void pack_point_mx6_kernel(const float* __restrict__ w2, const float*
     d[b >> 5] |= c << (b & 31);
     if ((b & 31) > 26) d[(b >> 5) + 1] |= c >> (32 - (b & 31));
   }
-  // chunk base in the stream: the layer-1 chunks (12 KB each) first, then 32 KB per wide chunk
-  unsigned char* cb = out + (size_t)NRT * 2 * 6 * 1024 + (size_t)cw * 2 * KSL * 1024;
-  unsigned* a = reinterpret_cast<unsigned*>(cb + (size_t)KSL * 1024 + (size_t)q * 3072 + (size_t)im * 1536 + (size_t)lane * 16);
+  // chunk base in the stream: the layer-1 chunks (12 KB each: 6 KB of f16 fragments + 2 slabs of images) first, then 32 KB per wide chunk
+  unsigned char* cb = c < NRT ? out + (size_t)c * 2 * 6 * 1024 : out + (size_t)NRT * 2 * 6 * 1024 + (size_t)cw * 2 * KSL * 1024;
+  const size_t f16b = c < NRT ? 6 * 1024 : (size_t)KSL * 1024;   // bytes of f16 fragments in front of the images
+  unsigned* a = reinterpret_cast<unsigned*>(cb + f16b + (size_t)q * 3072 + (size_t)im * 1536 + (size_t)lane * 16);
   a[0] = d[0]; a[1] = d[1]; a[2] = d[2]; a[3] = d[3];
-  unsigned* b2 = reinterpret_cast<unsigned*>(cb + (size_t)KSL * 1024 + (size_t)q * 3072 + (size_t)im * 1536 + 1024 + (size_t)lane * 8);
+  unsigned* b2 = reinterpret_cast<unsigned*>(cb + f16b + (size_t)q * 3072 + (size_t)im * 1536 + 1024 + (size_t)lane * 8);
   b2[0] = d[4]; b2[1] = d[5];
   // the scale byte: resident table behind the stream's bias tables, scale ints and bounds block
   const int NC = 3 * NRT + 8;
   unsigned char* tab = out + ((size_t)NRT * 12 + (size_t)(2 * NRT + 8) * 2 * KSL) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + (size_t)((2 * NC + 3) / 4 + 2) * 16;
-  tab[((size_t)cw * 64 + lane) * 8 + im * 4 + q] = (unsigned char)sb;
+  tab[((size_t)(L1MX ? c : cw) * 64 + lane) * 8 + im * 4 + q] = (unsigned char)sb;
 }
 
 }  // namespace
@@ -1301,7 +1423,7 @@ __global__ void pack_point_mx6_kernel(const float* __restrict__ w2, const float*
 size_t nl_point_stream2_bytes(int W) {
   const int NRT = W / 32;
   return (size_t)2 * (NRT * 6 + (2 * NRT + 8) * 2 * NRT) * 1024 + 4096 + (size_t)(64 + 2 * W) * 4 + 4096   // + slack: bf16 L1 chunks copy 8 k-steps
-         + (size_t)(2 * NRT + 8) * 512;                                                                      // + MX-FP6: the weight-scale table
+         + (size_t)(3 * NRT + 8) * 512;                                                                      // + MX-FP6: the weight-scale table (every chunk)
 }
 
 // mx = 1: the stream of the MX mode (layer 1 split-bf16 as ever; layers 2, 3, k / v: f16 fragments + fp8 images + their scales); mx_scratch: >= 2 (3 W / 32 + 8) ints
@@ -1315,7 +1437,7 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
     if (W != 128 && W != 256) return NL_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_point_stream2_kernel, dim3((unsigned)nl_cdiv(total, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv, b2, b3, rd_w, (unsigned short*)out, NRT, F, 3, nullptr);
     NL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pack_point_mx6_kernel, dim3((unsigned)nl_cdiv((long long)(2 * NRT + 8) * (NRT / 2) * 128, 256)), dim3(256), 0, st, w2, w3, wk, wv, (unsigned char*)out, NRT);
+    hipLaunchKernelGGL(pack_point_mx6_kernel, dim3((unsigned)nl_cdiv((long long)(3 * NRT + 8) * (NRT / 2) * 128, 256)), dim3(256), 0, st, w1, w2, w3, wk, wv, (unsigned char*)out, NRT, F);
     NL_LAUNCH_CHECK();
     return NL_OK;
   }
