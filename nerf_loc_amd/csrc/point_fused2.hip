@@ -246,8 +246,10 @@ struct Pf2Scalars { int dir_stride, dir_div; unsigned dir_magic; int dir_shift; 
                     unsigned* logit_amax;
                     unsigned long long* clk; };   // optional: [shader cycles, 100-MHz reference ticks] workgroup 0 spent in this launch (bench.py: the clock under load)   // optional: running maximum of |attention logit| (q.k / sqrt d_k) as float bits, atomicMax'ed once per wave (nl_frame_diagnostics)
 
-// MX (with X3): layer 1 stays three-term split-bf16 (K = 96, issue-bound anyway); layers 2, 3 and the k / v projections multiply as
+// MX (with X3) = 1, round 4: layer 1 stays three-term split-bf16 (K = 96, issue-bound anyway); layers 2, 3 and the k / v projections multiply as
 // fp16 hi.hi + fp8(lo).fp8(hi) + fp8(hi).fp8(lo): per K = 64 slab 4 x v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 instead of 12 bf16 MFMAs.
+// MX = 2, round 5 (the instance the library carries, PF2_MX_FP6): the same two cross terms on fp6 (e2m3) operands — 8 passes instead of 16 — with a power-of-two scale per
+// 32-value block taken from the values themselves; every layer, layer 1 included (PF2_L1_MX).  DESIGN.md 2.4.
 // F16 (with X3, without MX): every layer in three-term split-FP16 (2^-22 products: what the gradient path's forward needs so that its LeakyReLU sign decisions are the
 // fp32 function's).  KEEP: the kernel also leaves what the frozen-weight way back reads — the k / v rows (N x 8, 256) and the SIGN of the three
 // layers' outputs as bits in the streaming GEMM's ep_maskin layout ([32-row tile][lane][4 dwords]) — so that the staged forward of the branch (an encode kernel,
