@@ -83,6 +83,9 @@ def main():
                     help="early-termination compositing threshold (nl_render_opts); default: 1e-5 for c5 (BASELINE names it there), 0 = off otherwise")
     ap.add_argument("--graph", action="store_true", help="replay batches of <= 1024 rays as a HIP graph (A/B against the eager launch chain; measured: no gain)")
     ap.add_argument("--no-side-stream", action="store_true", help="NL_RENDER_NO_SIDE_STREAM: every kernel on one stream (profiling kernels one at a time)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
+                    help="after the headline: this many seconds of back-to-back steps of the same workload -> `sustained` (0 = skip; N = 1 only)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="report `parity` but do not fail the run (rc 3) when it is above 1e-4")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N>1: weak = R rays per rank, strong = one R-ray batch sharded over the ranks (auto: BOTH are timed, value = strong)")
     args = ap.parse_args()
@@ -131,7 +134,7 @@ def main():
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from nerf_loc_amd.renderer import HipRenderer
-    from nerf_loc_amd.sharding import gather_ray_outputs_async, shard_range
+    from nerf_loc_amd.sharding import ShardedRenderLoop, gather_ray_outputs_async, shard_range
     from nerf_loc_amd.synth import make_u
 
     cfg = CONFIGS[args.config]
@@ -174,13 +177,13 @@ def main():
         return b
     B = to_device(rays, u_all, R_local, counts)   # the batch `step()` renders (swapped for the weak pass of an N > 1 run)
 
-    # N > 1: every step ends with ONE all-gather of the packed per-ray outputs.  It is started asynchronously (RCCL's stream) and
-    # collected one step later, so the xGMI transfer of batch i overlaps the kernels of batch i + 1; drain() collects the last one
-    # inside the timed region, so K timed steps = K renders + K completed gathers.
-    pending = [None]
+    # N > 1: every step ends with ONE all-gather of the packed per-ray outputs — the product's own sharded step (nerf_loc_amd/sharding.py: ShardedRenderLoop,
+    # the pipelined form of render_rays_sharded): the gather is started asynchronously (RCCL's stream) and collected one step later, so the xGMI transfer of
+    # batch i overlaps the kernels of batch i + 1; drain() collects the last one inside the timed region, so K timed steps = K renders + K completed gathers.
+    loop = [None]
     last_out = [None]
 
-    def step():
+    def render_local():
         zz = B["z"]
         if hier:
             zz, depth_coarse, _ = rnd.hierarchical_depths(B["pix"], B["Kq"], B["pose_q"], B["z"], B["u"], near=cfg.near, far=cfg.far)
@@ -190,20 +193,21 @@ def main():
                               graph=args.graph)
         if hier:
             out["depth_coarse"] = depth_coarse
+        return out
+
+    def step():
         if gather:
-            prev = pending[0]
-            pending[0] = gather_ray_outputs_async(out, dist, B["counts"])
-            if prev is not None:
-                out = prev.result()
+            if loop[0] is None or loop[0].counts is not B["counts"]:
+                loop[0] = ShardedRenderLoop(dist, B["counts"])
+            out = loop[0].step(render_local)
+            last_out[0] = loop[0].last_local
+            return out
+        out = render_local()
         last_out[0] = out
         return out
 
     def drain():
-        if pending[0] is not None:
-            res = pending[0].result()
-            pending[0] = None
-            return res
-        return None
+        return loop[0].drain() if loop[0] is not None else None
 
     def timed(steps, warmup):
         for _ in range(warmup):
@@ -237,6 +241,8 @@ def main():
 
     wall, dev_ms = timed(args.steps, args.warmup)
     ms_per_step = wall * 1e3 / args.steps
+    # the outputs of the LAST timed step of this rank (the batch is the same every step): what `parity` below compares with the CPU oracle
+    headline_out = {k: v.clone() for k, v in last_out[0].items()}
 
     # dominant kernel (fused neural-point kernel): HIP events around each of its launches, on the
     # stream it is launched on, over a second pass of the same steps (the events themselves are outside `value`)
@@ -344,13 +350,17 @@ def main():
         rnd.set_precision(args.precision)
         result["other_precisions"] = extra
 
+    if world == 1 and args.sustained_seconds > 0:
+        result["sustained"] = sustained(step, drain, rnd, R, args.sustained_seconds, ms_per_step)
+
     if rank == 0 and world == 1 and not args.no_gradient_step and not hier and args.precision != "fp32":
         try:   # (an extra next to the headline: whatever happens here must not cost the line)
             result["gradient_step"] = gradient_step(rnd, cfg, frame, rays, weights, torch.device(f"cuda:{local_rank}"))
         except Exception as e:   # noqa: BLE001
             result["gradient_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, frame, rays, weights, u_all, thread_sweep=args.cpu_thread_sweep)
+        result["cpu_baseline"], result["parity"] = cpu_baseline(cfg, frame, rays, weights, u_all, thread_sweep=args.cpu_thread_sweep, gpu_out=headline_out,
+                                                                precision=args.precision)
     # RCCL prints its version banner (NCCL_DEBUG=VERSION) through C stdio, which a pipe flushes only at exit: every rank pushes it out
     # now, then rank 0 prints the JSON line as the last thing on stdout
     try:
@@ -364,6 +374,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+        par = result.get("parity")
+        if par is not None and not par["ok"] and not args.no_parity_gate:
+            print(f"bench.py: parity of the timed batch against the CPU oracle is above {par['bar']:g}: {par['max_rel']}", file=sys.stderr)
+            raise SystemExit(3)
 
 
 def gradient_step(rnd, cfg, frame, rays, weights, dev):
@@ -399,6 +413,45 @@ def gradient_step(rnd, cfg, frame, rays, weights, dev):
     torch.cuda.synchronize(dev)
     return {"what": f"PoseOptimizer step: {Rg} rays x {cfg.S} samples, forward + backward to the pose, frozen weights", "ms_per_step": (time.perf_counter() - t0) / n * 1e3,
             "grad_finite": bool(torch.isfinite(g).all()), "path": "RenderFn: nl_render_rays_forward_keep + nl_render_rays_backward_kept (two HIP graphs from the second step on)"}
+
+
+def sustained(step, drain, rnd, R, seconds, burst_ms):
+    """>= `seconds` of back-to-back steps of the headline workload (same batch, same mode), in blocks of 64 steps with one synchronisation per block (the host
+    runs ahead inside a block like in the timed region).  The headline is a 0.1-s burst; on a part whose dominant kernel is power-limited the
+    steady state may sit lower — this says by how much.  Clock: nl_frame_diagnostics' shader clock of the fused neural-point kernel's last launch, read after the
+    first and after the last block."""
+    block = 64
+    for _ in range(3):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    ghz_first = ghz_last = None
+    blocks = []
+    gc.collect()
+    gc.disable()
+    t_start = time.perf_counter()
+    n = 0
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n += block
+        blocks.append((t1 - t0) * 1e3 / block)
+        if ghz_first is None:
+            ghz_first = rnd.diagnostics()["point_kernel_GHz"]
+        if t1 - t_start >= seconds:
+            break
+    total = time.perf_counter() - t_start
+    gc.enable()
+    ghz_last = rnd.diagnostics()["point_kernel_GHz"]
+    rate = R * n / total
+    return {"seconds": total, "steps": n, "rays_per_s": rate, "ms_per_step": total * 1e3 / n, "ms_per_step_first_block": blocks[0], "ms_per_step_last_block": blocks[-1],
+            "ms_per_step_worst_block": max(blocks), "clock_GHz_first": ghz_first, "clock_GHz_last": ghz_last, "vs_burst": (burst_ms / (total * 1e3 / n)),
+            "note": "back-to-back steps of the headline workload after the headline's timed burst (64-step blocks, one sync + one 12-byte diagnostics read per block, "
+                    "both inside the time); `value` stays the burst the contract defines (exactly K steps); vs_burst = sustained rate / burst rate"}
 
 
 def baseline_metric() -> str:
@@ -439,7 +492,7 @@ def hbm_traffic(config: str, precision: str):
     return None
 
 
-def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 12.0, thread_sweep: bool = False):
+def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 12.0, thread_sweep: bool = False, gpu_out=None, precision: str = ""):
     """Time the CPU oracle (port of the reference's PyTorch path) on a bounded ray sample of the same workload.
 
     Threads: torch intra-op parallelism saturates around 8-64 threads on this path and collapses beyond (measured on the
@@ -452,20 +505,26 @@ def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 12.0, 
     p = {k: torch.from_numpy(v) for k, v in weights.items()}
     fr = orc.to_torch(frame)
 
+    keep = None
+
     def run(lo, hi, timers=None, nthreads=threads):
         sub = {k: (torch.from_numpy(v[lo:hi]) if k in ("rays_o", "rays_d", "pixel_coordinates") else (torch.from_numpy(v) if isinstance(v, np.ndarray) else v))
                for k, v in rays.items()}
         uu = None if u_all is None else torch.from_numpy(u_all[lo:hi])   # fixed uniforms for sample_pdf (reference: torch.rand)
         t0 = time.perf_counter()
         with torch.no_grad():
-            orc.render_rays(p, fr, sub, cfg.S, cfg.N_importance, u=uu, knn_threads=nthreads, timers=timers)
-        return time.perf_counter() - t0
+            ref = orc.render_rays(p, fr, sub, cfg.S, cfg.N_importance, u=uu, knn_threads=nthreads, timers=timers)
+        dt = time.perf_counter() - t0
+        if keep is not None:
+            keep.append((lo, hi, {k: ref[k].numpy() for k in PARITY_KEYS + ("mask", "z_vals") if k in ref}))
+        return dt
 
     run(0, 16)                          # warm-up (first-touch, thread pool)
     t = run(0, 64)
     total = int(max(64, min(len(rays["rays_o"]), 64 * budget_s / max(t, 1e-3))))
     total = min(total - total % 64, 1024)
     timers, t_all, done = {}, 0.0, 0
+    keep = [] if gpu_out is not None else None   # (run() appends the oracle's outputs of the timed chunks from here on)
     while done < total:
         n = min(256, total - done)
         t_all += run(done, done + n, timers)
@@ -477,12 +536,53 @@ def cpu_baseline(cfg, frame, rays, weights, u_all=None, budget_s: float = 12.0, 
             torch.set_num_threads(nt)
             run(0, 16, nthreads=nt)
             sweep[str(nt)] = round(64 / run(0, 64, nthreads=nt), 1)
+    kept, keep = keep, None
     torch.set_num_threads(threads)
     sweep[str(threads)] = round(total / t_all, 1)
+    parity = parity_block(cfg, frame, rays, kept, gpu_out, precision) if gpu_out is not None else None
     return {"value": total / t_all, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{total} rays x {cfg.S_total} samples of the same workload in 256-ray chunks, {t_all:.1f} s, {threads} of {cores} host cores",
             "rays_per_s_by_threads": sweep,
-            "stage_seconds": {k: round(v, 3) for k, v in timers.items()}}
+            "stage_seconds": {k: round(v, 3) for k, v in timers.items()}}, parity
+
+
+PARITY_KEYS = ("rgb", "depth", "weights", "depth_uncertainty", "feat")
+PARITY_BAR = 1e-4
+
+
+def parity_block(cfg, frame, rays, kept, gpu_out, precision):
+    """Parity of THE RUN THAT WAS TIMED: the rows of the headline batch the CPU oracle rendered for `cpu_baseline` against the same rows of the
+    GPU's last timed step.  max_rel = max |gpu - oracle| / max |oracle| per output over the compared rays (the metric of every parity test, north_star's "1e-4
+    rel"), l2_rel = ||gpu - oracle|| / ||oracle||; mask_equal = the valid-ray mask bit for bit.  Rays with a sample within 1e-3 pixel of a support view's image
+    border are hard-threshold cases of the reference's in-image test (two correct fp32 evaluations may differ: synth.borderline_rays): they are compared and
+    counted separately (`borderline`), the gate is on the others."""
+    from nerf_loc_amd.synth import borderline_rays
+    rows = np.concatenate([np.arange(lo, hi) for lo, hi, _ in kept])
+    ref = {k: np.concatenate([o[k] for _, _, o in kept], 0) for k in kept[0][2]}
+    got = {k: gpu_out[k][torch.from_numpy(rows).to(gpu_out[k].device)].cpu().numpy() for k in PARITY_KEYS + ("mask",)}
+    border = borderline_rays(cfg, frame, rays["rays_o"][rows], rays["rays_d"][rows], ref["z_vals"])
+    core = ~border
+
+    def rel(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)) if a.size else 0.0
+
+    def l2(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)) if a.size else 0.0
+    max_rel = {k: rel(got[k][core], ref[k][core]) for k in PARITY_KEYS}
+    l2_rel = {k: l2(got[k][core], ref[k][core]) for k in PARITY_KEYS}
+    mask_equal = bool(np.array_equal(got["mask"][core].astype(bool), ref["mask"][core].astype(bool)))
+    b_rel = {k: rel(got[k][border], ref[k][core | border]) for k in PARITY_KEYS} if border.any() else {}
+    if border.any():   # (denominator: the whole sample's max |oracle|, so that the two groups are on one scale)
+        b_rel = {k: float(np.abs(got[k][border].astype(np.float64) - ref[k][border].astype(np.float64)).max() / max(np.abs(ref[k].astype(np.float64)).max(), 1e-30))
+                 for k in PARITY_KEYS}
+    ok = mask_equal and max(max_rel.values()) < PARITY_BAR and max(l2_rel.values()) < PARITY_BAR
+    return {"rays": int(core.sum()), "of": f"rows {int(rows[0])}..{int(rows[-1])} of the timed batch (the cpu_baseline sample)", "precision": precision, "bar": PARITY_BAR,
+            "max_rel": max_rel, "l2_rel": l2_rel, "mask_equal": mask_equal, "ok": bool(ok),
+            "borderline": {"rays": int(border.sum()), "max_rel": b_rel,
+                           "mask_equal": bool(np.array_equal(got["mask"][border].astype(bool), ref["mask"][border].astype(bool))),
+                           "note": "rays with a sample within 1e-3 px of a support view's image border (hard thresholds of the reference's in-image test): reported, not gated"}}
 
 
 if __name__ == "__main__":

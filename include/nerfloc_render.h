@@ -43,8 +43,9 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define NL_ABI_VERSION 6   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
-                            * reserved fields validated, side stream owned by the nl_frame; 5: NL_PREC_F16MX; 6: nl_frame_diagnostics */
+#define NL_ABI_VERSION 7   /* 2: nl_render_rays_ex / nl_render_opts (early termination, per-ray query centres); 3: nl_render_opts.flags,
+                            * reserved fields validated, side stream owned by the nl_frame; 5: NL_PREC_F16MX; 6: nl_frame_diagnostics;
+                            * 7: NL_RENDER_PRECISION_GUARD (the precision guard at the boundary), NL_DIAG_GUARD_* */
 #define NL_MAX_VIEWS 16
 #define NL_KNN_MAX_K 8
 
@@ -194,8 +195,8 @@ int nl_frame_destroy(nl_frame* frame);
 
 /* Conditioning indicators of what has been rendered against `frame` so far (round 5), copied to HOST memory; synchronises `stream`.
  *   [NL_DIAG_TABLE_ABSMAX]  max |T| over the per-frame table T = support features x base_mlp.0's feature columns + bias (0 until the first render builds it)
- *   [NL_DIAG_LOGIT_ABSMAX]  largest |attention logit| (q.k / sqrt d_k, ibrnet.py:28-45) the fused neural-point kernel has scored since nl_frame_create (W = 128 / 256;
- *                           0 where the staged kernels run).  The softmax over a sample's 8 neighbours turns a logit error e into a weight error ~e, and a split
+ *   [NL_DIAG_LOGIT_ABSMAX]  largest |attention logit| (q.k / sqrt d_k, ibrnet.py:28-45) the neural-point branch has scored since nl_frame_create (round 6: every kernel
+ *                           that scores logits reports it — the fused kernels of W = 128 / 256 and W = 64 and the staged attention kernel; a NaN logit is recorded as +inf).  The softmax over a sample's 8 neighbours turns a logit error e into a weight error ~e, and a split
  *                           product's logit error is its relative precision x |logit|: at |logit| ~ 100 NL_PREC_F16MX (2^-16) sits ~2e-4 from the fp64 result where
  *                           it sits 2e-5 at |logit| ~ 1 — and the reference's own fp32 arithmetic moves from 1e-6 to 1e-5.  The host mirror uses it to fall back to
  *                           a more exact mode (nerf_loc_amd.conditional_nerf: precision_guard).
@@ -204,7 +205,9 @@ int nl_frame_destroy(nl_frame* frame);
 #define NL_DIAG_TABLE_ABSMAX 0
 #define NL_DIAG_LOGIT_ABSMAX 1
 #define NL_DIAG_POINT_KERNEL_GHZ 2   /* shader clock of the last fused neural-point launch (workgroup 0: s_memtime cycles / s_memrealtime): DVFS under matrix load */
-#define NL_DIAG_COUNT 3
+#define NL_DIAG_GUARD_PRECISION 3    /* the nl_precision the last NL_RENDER_PRECISION_GUARD call against this frame produced its outputs in (-1: no guarded call yet) */
+#define NL_DIAG_GUARD_ESCALATIONS 4  /* how many times a guarded call moved this frame to a more exact mode (0, 1 or 2 over a frame's life) */
+#define NL_DIAG_COUNT 5
 int nl_frame_diagnostics(const nl_frame* frame, float* host_out, int32_t n, void* stream);
 
 /* ---- stages (each is also reachable through nl_render_rays) -------------------------------------- */
@@ -275,7 +278,17 @@ typedef struct nl_render_opts {
 #define NL_RENDER_NO_SIDE_STREAM 1u   /* keep every kernel on the caller's stream: no fork of the exact KNN onto the frame's side stream
                                        * (results are bit-identical either way; for profiling one kernel at a time and for callers that
                                        * must not see a second stream) */
-#define NL_RENDER_FLAGS_ALL 1u
+#define NL_RENDER_PRECISION_GUARD 2u  /* round 6 (ABI 7) — the precision guard AT the boundary: after the batch the library reads the frame's conditioning indicator
+                                       * (NL_DIAG_LOGIT_ABSMAX: one 4-byte device-to-host copy; the call SYNCHRONISES `stream`) and, while it lies beyond the range the
+                                       * mode of the outputs was validated to — NL_GUARD_LOGIT_LIMIT_* below, DESIGN.md 2.3 — renders THIS batch again in the next more
+                                       * exact mode (NL_PREC_F16MX -> NL_PREC_BF16X3 -> NL_PREC_F32; NL_PREC_BF16 is a throughput mode and is left alone).  The frame
+                                       * then stays in that mode for every later guarded call (until nl_frame_create), so the second pass is paid once per frame;
+                                       * NL_DIAG_GUARD_PRECISION / NL_DIAG_GUARD_ESCALATIONS say what happened.  A NaN logit counts as beyond every range.  Every batch
+                                       * of a frame is checked, not only the first (the indicator is cumulative: a later batch with larger logits escalates when it
+                                       * arrives).  Not capturable into a HIP graph (the synchronisation); NL_ERR_BAD_ARG in nl_render_rays_multi with more than one job. */
+#define NL_RENDER_FLAGS_ALL 3u
+#define NL_GUARD_LOGIT_LIMIT_F16MX 50.0f    /* tools/scale_sweep.py (profiles/r5_scale_sweep.txt): f16mx <= 5.1e-5 of the CPU oracle up to |logit| 64, 7.2e-5 at 95, 9.3e-5 at 142 */
+#define NL_GUARD_LOGIT_LIMIT_BF16X3 500.0f  /* bf16x3 <= 4.2e-5 up to |logit| 475, 0.3-1.7e-4 at ~1000 */
 
 /* rays_o, rays_d (R,3); z_vals (R,S) or NULL to generate linspace(near,far,S) (model.py:451-458,483-484). */
 int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* frame, const float* query_center,

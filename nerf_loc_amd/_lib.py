@@ -24,7 +24,11 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16MX = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16mx": PREC_F16MX}
 MAX_VIEWS = 16
 RENDER_NO_SIDE_STREAM = 1   # nl_render_opts.flags
-ABI_VERSION = 6   # include/nerfloc_render.h: NL_ABI_VERSION
+RENDER_PRECISION_GUARD = 2  # nl_render_opts.flags (ABI 7): the library checks the conditioning indicator after the batch and re-renders it in a more exact mode if needed
+GUARD_LOGIT_LIMIT = {"f16mx": 50.0, "bf16x3": 500.0}   # include/nerfloc_render.h: NL_GUARD_LOGIT_LIMIT_* (tests/test_abi_symbols.py holds the two in step)
+PRECISION_NAMES = {PREC_F32: "fp32", PREC_BF16X3: "bf16x3", PREC_BF16: "bf16", PREC_F16MX: "f16mx"}
+DIAG_COUNT = 5
+ABI_VERSION = 7   # include/nerfloc_render.h: NL_ABI_VERSION
 
 
 class NlConfig(C.Structure):

@@ -33,6 +33,7 @@ from .depth_fusion import DepthFusionNet
 from .frame_setup import backproject_support
 from .frame_setup import get_rays as _hip_get_rays
 from . import diff_render
+from ._lib import GUARD_LOGIT_LIMIT as _GUARD_LOGIT_LIMIT
 from .renderer import HipRenderer
 
 
@@ -175,15 +176,18 @@ class ConditionalNeRF(nn.Module):
         self.__dict__["_sp_gen"] = self.__dict__.get("_sp_gen", 0) + 1
         self.__dict__["_sp_from_hip"] = False   # set by _build_support_hip: tables this module built itself, without a graph
 
-    # Precision guard (round 5).  The split-product modes carry 2^-16 (f16mx) / 2^-17 (bf16x3) per product where the reference's fp32 carries 2^-24.  On
-    # well-conditioned inputs that is 1-2.5e-5 / 8e-6 of the outputs; the one amplifier tools/scale_sweep.py found is the attention over a sample's 8 neighbours:
-    # a logit error is (relative product error) x |logit|, and a softmax over nearly tied neighbours hands it on undamped.  The fused neural-point kernel
-    # reports the largest |logit| it scored (nl_frame_diagnostics); after the FIRST inference batch of every frame the module reads it (one device-to-host
-    # copy per frame, next to a 4-ms per-frame setup) and, if it is beyond the limit its current mode was validated to, re-renders that batch and keeps
-    # rendering the frame in the next more exact mode (f16mx -> bf16x3 -> fp32).  Limits: the |logit| up to which the mode stayed within 1e-4 of the CPU oracle
-    # on every scene of the sweep (profiles/r5_scale_sweep.txt, MX-FP6 build: f16mx 7.2e-5 at |logit| 95, 9.3e-5 at 142, 8.5e-5 at 275 and 1.7e-4 at 462; bf16x3 4.2e-5 at 475 and 0.9-1.7e-4 at ~1000; the
-    # synthetic BASELINE scenes sit at 4-6).  precision_guard=False switches it off; `guard_events` lists what it did.
-    LOGIT_LIMIT = {"f16mx": 100.0, "bf16x3": 500.0}
+    # Precision guard (round 5; at the C-ABI since round 6).  The split-product modes carry 2^-16 (f16mx) / 2^-17 (bf16x3) per product where the reference's fp32
+    # carries 2^-24.  On well-conditioned inputs that is 1-2.5e-5 / 8e-6 of the outputs; the one amplifier tools/scale_sweep.py found is the attention over a
+    # sample's 8 neighbours: a logit error is (relative product error) x |logit|, and a softmax over nearly tied neighbours hands it on undamped.  The kernels of
+    # the neural-point branch report the largest |logit| they scored, and the LIBRARY acts on it: every inference batch goes down with
+    # NL_RENDER_PRECISION_GUARD (include/nerfloc_render.h, ABI 7) — after the batch it reads the indicator and, beyond the limit the current mode was validated
+    # to, renders that batch again and keeps the frame in the next more exact mode (f16mx -> bf16x3 -> fp32).  EVERY batch of a frame is checked (round 5 checked
+    # the first only: a chunked render_image could pass on a benign first chunk — ADVICE r5), a NaN logit counts as beyond every limit, and the staged kernels
+    # of W = 32 / 64 report the indicator too.  Limits (NL_GUARD_LOGIT_LIMIT_*): the |logit| up to which the mode stayed within 1e-4 of the CPU oracle on every
+    # scene of the sweep with margin (profiles/r5_scale_sweep.txt, MX-FP6 build: f16mx 5.1e-5 at |logit| 64, 7.2e-5 at 95, 9.3e-5 at 142, 1.7e-4 at 462 — the
+    # limit is 50 since round 6, it was 100; bf16x3 4.2e-5 at 475 and 0.9-1.7e-4 at ~1000; the synthetic BASELINE scenes sit at 4-6).
+    # precision_guard=False switches it off; `guard_events` lists what it did.
+    LOGIT_LIMIT = dict(_GUARD_LOGIT_LIMIT)
     _SAFER = {"f16mx": "bf16x3", "bf16x3": "fp32", "bf16": "bf16x3"}
 
     def __init__(self, args, activation_func=None, precision: str = "f16mx", device: Optional[str] = None, precision_guard: bool = True):
@@ -295,20 +299,18 @@ class ConditionalNeRF(nn.Module):
         return r
 
     def _guarded(self, r: HipRenderer, render):
-        """render() -> outputs; after the first inference batch of a frame: check the conditioning indicator and escalate the precision if needed (see LOGIT_LIMIT)."""
-        out = render()
-        if not self.precision_guard or r.__dict__.get("_guard_gen") == r.state_gen:
-            return out
-        r._guard_gen = r.state_gen
-        amax = r.diagnostics()["logit_absmax"]
-        mode = r.precision
-        while mode in self.LOGIT_LIMIT and amax > self.LOGIT_LIMIT[mode]:
-            mode = self._SAFER[mode]
-        if mode != r.precision:
-            self.guard_events.append({"logit_absmax": amax, "from": r.precision, "to": mode})
+        """render(precision_guard) -> outputs of one inference batch.  With the guard on the batch goes down with NL_RENDER_PRECISION_GUARD: the library checks the
+        conditioning indicator after EVERY batch and re-renders in a more exact mode where needed (see LOGIT_LIMIT); here the renderer's configured mode follows
+        the frame's (so that the stage calls of the same frame — descriptor queries — run in it too) and the event is recorded."""
+        if not self.precision_guard:
+            return render(False)
+        out = render(True)
+        d = r.diagnostics()
+        mode = d["guard_precision"]
+        if mode is not None and mode != r.precision:
+            self.guard_events.append({"logit_absmax": d["logit_absmax"], "from": r.precision, "to": mode})
             del self.guard_events[:-64]
             r.set_precision(mode)
-            out = render()
         return out
 
     def _vis_featmaps(self, data, graph: bool = False):
@@ -725,8 +727,9 @@ class ConditionalNeRF(nn.Module):
         # (`inference_graphs`: replay small batch shapes as HIP graphs, HipRenderer.render_rays(graph=True).  Off by default: measured on the MI355X box the
         # replay buys nothing — 256 rays of config 1: 0.391 ms eager, 0.387 ms replayed, and the static-buffer copies around it cost more than that;
         # the chain is bound by its kernels' own ramp and tail, not by the host's launches — DESIGN.md 5.20)
-        out = self._guarded(r, lambda: r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
-                                                     want_feat=bool(self.args.render.render_feature), graph=bool(getattr(self, "inference_graphs", False))))
+        out = self._guarded(r, lambda g: r.render_rays(o, d, data["pose"][:3, 3], z_vals=z, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                                                       want_feat=bool(self.args.render.render_feature), graph=bool(getattr(self, "inference_graphs", False)),
+                                                       precision_guard=g))
         if depth_coarse is not None:
             out["depth_coarse"] = depth_coarse
         return out
@@ -760,8 +763,8 @@ class ConditionalNeRF(nn.Module):
             os_.append(o); ds_.append(d); zs.append(z); counts.append(R)
             cs.append(rays["pose"][:3, 3].detach().to(o.device).expand(R, 3))
         O_, D_, C_, Z_ = torch.cat(os_), torch.cat(ds_), torch.cat(cs).contiguous(), torch.cat(zs)
-        out = self._guarded(r, lambda: r.render_rays(O_, D_, C_, z_vals=Z_, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
-                                                     want_feat=bool(self.args.render.render_feature)))
+        out = self._guarded(r, lambda g: r.render_rays(O_, D_, C_, z_vals=Z_, white_bkgd=bool(data.get("white_bkgd", self.args.render.white_bkgd)),
+                                                       want_feat=bool(self.args.render.render_feature), precision_guard=g))
         outs = [dict(zip(out.keys(), parts)) for parts in zip(*(torch.split(v, counts) for v in out.values()))]
         for o_, dc in zip(outs, dcs):
             o_["depth_coarse"] = dc
@@ -788,6 +791,14 @@ class ConditionalNeRF(nn.Module):
         if "target_mask" in data:
             out["rgb"] = out["rgb"] * data["target_mask"][:, :, None].float()
         return out
+
+    def render_image_sharded(self, data, dist):
+        """render_image with the image's rays sharded over the ranks of an initialised process group and ONE all-gather of the per-ray outputs
+        (nerf_loc_amd/sharding.py; no counterpart in the reference, whose render_image walks `render.chunk` pieces on one device: model.py:615-633).
+        Every rank gets the whole image, bit-identical to render_image(data)."""
+        from .sharding import render_image_sharded
+        self._refuse_autograd("render_image_sharded", data.get("pose"), data.get("K"))
+        return render_image_sharded(self, data, dist)
 
     def compute_render_loss(self, data):
         """model.py:641-685 (+ losses.py:23-93): one training step's render loss and PSNR on the gradient path (`_render_rays_grad`)."""

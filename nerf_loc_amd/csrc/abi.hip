@@ -28,7 +28,7 @@ int nl_launch_mv_stats(const NlViews& vw, const float* viewsdev, const float* im
 int nl_launch_point_encode(const float* xyz, const float* dir, int dir_stride, int dir_div, int64_t N, int K, int64_t M, const int* idx, const float* d2,
                            const float* sp_xyz, const float* sp_feat, int F, const float* sp_conf, const float* sp_dir, const float* rd_w,
                            float inv_span, float* X, int ldx, float* wscale, hipStream_t st);
-int nl_launch_attn(const float* Q, const float* KV, int64_t N, int K, float* O, hipStream_t st);
+int nl_launch_attn(const float* Q, const float* KV, int64_t N, int K, float* O, hipStream_t st, unsigned* logit_amax = nullptr);
 int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const float* gamma, const float* beta, float eps, const float* wscale, float* out, hipStream_t st);
 int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
@@ -513,6 +513,10 @@ struct nl_frame {
   // never lazily inside a render call (stream / event creation is illegal during graph capture) and never shared between frames, so two
   // renderers on two caller streams do not record into each other's events.  side_ok == false: everything runs on the caller's stream.
   hipStream_t side; hipEvent_t ev_fork, ev_join; bool side_ok;
+  // precision guard (NL_RENDER_PRECISION_GUARD): the mode guarded calls render this frame in once one of them found the conditioning indicator beyond the
+  // configured mode's validated range (-1: none yet), how often that happened, and the mode the last guarded call's outputs were produced in.  Host-side
+  // state of a frame that is documented as not re-entrant; mutable because render calls take the frame as const.
+  mutable int guard_prec = -1; mutable int guard_escalations = 0; mutable int guard_last_prec = -1;
 };
 
 namespace {
@@ -838,6 +842,7 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     const bool use_v1 = dbg_switch("NERFLOC_POINT_V1");
+    a.logit_amax = reinterpret_cast<unsigned*>(f->views_dev + 249);   // (read by the v1 kernel; the v2 launcher takes it as a parameter)
     int rc2 = NL_ERR_UNSUPPORTED;
     if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st, mx, nullptr, nullptr, f->views_dev + 248,
                                                                                                       reinterpret_cast<unsigned*>(f->views_dev + 249),
@@ -856,7 +861,7 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     NL_TRY(run_gemm(x, G_BASE2, &s1, 1, MK, p.H2, W, NL_ACT_LRELU));
     NL_TRY(run_gemm(x, G_BASE4, &s2, 1, MK, p.H1, W, NL_ACT_LRELU));
     NL_TRY(run_gemm(x, G_KV, &s1, 1, MK, p.KV, 256, NL_ACT_NONE));
-    NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st));
+    NL_TRY(nl_launch_attn(p.Q, p.KV, N, K, p.O, x.st, reinterpret_cast<unsigned*>(f->views_dev + 249)));   // (the staged path reports the conditioning indicator too)
   }
   if (chain && chain->done) *chain->done = false;
   if (t64) {   // (the caller checked W, precision and the 32-bit offset range before leaving G unmaterialised)
@@ -1947,7 +1952,8 @@ int nl_frame_diagnostics(const nl_frame* f, float* host_out, int32_t n, void* st
   static_assert(sizeof(tmp) == 24, "diagnostics block");
   NL_CHECK_HIP(hipMemcpyAsync(&tmp, f->views_dev + 248, sizeof(tmp), hipMemcpyDeviceToHost, (hipStream_t)stream));
   NL_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  const float vals[NL_DIAG_COUNT] = {tmp.tmax, tmp.lmax, tmp.ref ? (float)((double)tmp.cyc / ((double)tmp.ref * 10.0)) : 0.f};   // cycles per ns = GHz
+  const float vals[NL_DIAG_COUNT] = {tmp.tmax, tmp.lmax, tmp.ref ? (float)((double)tmp.cyc / ((double)tmp.ref * 10.0)) : 0.f,   // cycles per ns = GHz
+                                     (float)f->guard_last_prec, (float)f->guard_escalations};
   for (int i = 0; i < n; ++i) host_out[i] = i < NL_DIAG_COUNT ? vals[i] : 0.f;
   return NL_OK;
 }
@@ -2369,9 +2375,50 @@ int nl_render_rays(const nl_config* cfg, const void* packed, const nl_frame* f, 
   return nl_render_rays_ex(cfg, packed, f, qc, rays_o, rays_d, z_vals, R, white, out, ws, ws_bytes, stream, nullptr);
 }
 
+}  // extern "C" (interrupted for two internal helpers)
+
+namespace {
+// exactness order of the precision modes (the enum's numbers are historical): BF16 < F16MX < BF16X3 < F32
+int prec_rank(int p) { return p == NL_PREC_BF16 ? 0 : p == NL_PREC_F16MX ? 1 : p == NL_PREC_BF16X3 ? 2 : 3; }
+// the |attention logit| up to which a mode stayed within 1e-4 of the CPU oracle on every scene of tools/scale_sweep.py; <= 0: no limit known
+float guard_limit(int p) { return p == NL_PREC_F16MX ? NL_GUARD_LOGIT_LIMIT_F16MX : p == NL_PREC_BF16X3 ? NL_GUARD_LOGIT_LIMIT_BF16X3 : 0.f; }
+int guard_safer(int p) { return p == NL_PREC_F16MX ? NL_PREC_BF16X3 : NL_PREC_F32; }
+int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o, const float* rays_d, const float* z_vals,
+                     int64_t R, int white, const nl_render_out* out, void* ws, size_t ws_bytes, void* stream, const nl_render_opts* opts);
+}  // namespace
+
+extern "C" {
 int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
                       const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
                       size_t ws_bytes, void* stream, const nl_render_opts* opts) {
+  if (!opts || !(opts->flags & NL_RENDER_PRECISION_GUARD) || !cfg || !f || R <= 0)
+    return render_rays_impl(cfg, packed, f, qc, rays_o, rays_d, z_vals, R, white, out, ws, ws_bytes, stream, opts);
+  // ---- NL_RENDER_PRECISION_GUARD: render, read the frame's conditioning indicator (one 4-byte copy + a stream synchronisation), and while it is beyond the
+  // validated range of the mode the outputs were produced in, render THIS batch again in the next more exact mode.  The frame stays in that mode for every
+  // later guarded call (a frame whose attention logits are large once has them large in every batch), so the extra pass is paid once per frame.
+  nl_config c = *cfg;
+  if (f->guard_prec >= 0 && prec_rank(f->guard_prec) > prec_rank(c.precision)) c.precision = f->guard_prec;
+  for (;;) {
+    const int rc = render_rays_impl(&c, packed, f, qc, rays_o, rays_d, z_vals, R, white, out, ws, ws_bytes, stream, opts);
+    if (rc != NL_OK) return rc;
+    f->guard_last_prec = c.precision;
+    const float limit = guard_limit(c.precision);
+    if (limit <= 0.f) return NL_OK;
+    float amax = 0.f;
+    NL_CHECK_HIP(hipMemcpyAsync(&amax, f->views_dev + 249, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NL_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (amax <= limit) return NL_OK;   // (the kernels record a NaN logit as +inf: it escalates)
+    c.precision = guard_safer(c.precision);
+    f->guard_prec = c.precision;
+    ++f->guard_escalations;
+  }
+}
+}  // extern "C"
+
+namespace {
+int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f, const float* qc, const float* rays_o,
+                     const float* rays_d, const float* z_vals, int64_t R, int white, const nl_render_out* out, void* ws,
+                     size_t ws_bytes, void* stream, const nl_render_opts* opts) {
   NL_EFF_CFG(cfg);
   if (R == 0) return NL_OK;   // empty batch: nothing to do, data pointers may be null
   const float term_eps = opts ? opts->early_term_eps : 0.f;
@@ -2445,7 +2492,9 @@ int nl_render_rays_ex(const nl_config* cfg, const void* packed, const nl_frame* 
   }
   return NL_OK;
 }
+}  // namespace
 
+extern "C" {
 // ---- several frames per call: fork / join over library-owned streams -----------------------------------------------------------------------
 namespace {
 // One pool of lane streams / events PER DEVICE (keyed by hipGetDevice(): streams and events belong to the device that was current when they were
@@ -2461,6 +2510,8 @@ int nl_render_rays_multi(const nl_config* cfg, const void* packed, const nl_rend
   for (int i = 0; i < njobs; ++i) if (!jobs[i].frame || !jobs[i].out || !jobs[i].ws) return NL_ERR_BAD_ARG;
   if (njobs == 1) return nl_render_rays_ex(cfg, packed, jobs[0].frame, jobs[0].query_center, jobs[0].rays_o, jobs[0].rays_d, jobs[0].z_vals, jobs[0].R, white,
                                            jobs[0].out, jobs[0].ws, jobs[0].ws_bytes, stream, jobs[0].opts);
+  // the precision guard synchronises its stream after every job: with concurrent lanes it would serialise them — callers check nl_frame_diagnostics per frame instead
+  for (int i = 0; i < njobs; ++i) if (jobs[i].opts && (jobs[i].opts->flags & NL_RENDER_PRECISION_GUARD)) return NL_ERR_BAD_ARG;
   // a lane (stream) per distinct frame: a frame's side stream and events serve one render call at a time
   std::vector<int> lane_of(njobs);
   std::vector<const nl_frame*> lanes;

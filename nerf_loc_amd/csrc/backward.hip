@@ -2332,7 +2332,7 @@ int nl_launch_ln_slab_elu_backward(const float* x, int64_t R, int L, int Cc, con
   return NL_OK;
 }
 // g (Cc, L) += t (L, Cc)^T   (the library keeps the U-Net's LayerNorm tables position-major; the state_dict is channel-major)
-__global__ void table_add_t_kernel(const float* __restrict__ t, float* __restrict__ g, int L, int Cc) {
+static __global__ void table_add_t_kernel(const float* __restrict__ t, float* __restrict__ g, int L, int Cc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * Cc) return;
   const int c = i / L, l = i - c * L;

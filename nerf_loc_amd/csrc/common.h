@@ -36,6 +36,10 @@ __device__ __forceinline__ float nl_elu(float x) { return x > 0.f ? x : expm1f(x
 // (written as a median: e^x - 1 >= x everywhere, so for x > 0 the order is 0 < x <= e^x - 1 and for x < 0 it is x <= e^x - 1 < 0 — the middle value is ELU(x)
 // in both cases: ONE instruction, v_med3_f32, instead of compare + select.  Where the rounded e^x - 1 lands a rounding error below x (|x| < ~1e-3) the median
 // returns the other of two values that differ by <= 1.2e-7 — the absolute error the e^x - 1 branch has there anyway; round 5)
+// NaN: v_med3_f32 with a NaN operand falls back to min3 — ELU(NaN) comes out as 0, not NaN (the compare + select it replaced handed the NaN on).  Its callers are the
+// NeuRay decoders (mvdec.h), whose inputs are bilinear taps of the per-frame CNN's maps; a NaN there is a NaN of the frame's inputs, which the decoders' first-layer
+// products still carry into the hidden units of the OTHER rows of the tap (the outputs stay non-finite in practice: tests feed finite maps only), but this function
+// by itself does not propagate it — use nl_elu where that matters.
 __device__ __forceinline__ float nl_elu_fast(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
 __device__ __forceinline__ float nl_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float nl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
@@ -118,6 +122,7 @@ struct NlPointFusedArgs {
   int N, M;
   float inv_span;
   const uint4* wstream2;   // v2 stream (pack_point_stream2_kernel): row-tile-major chunks + resident block
+  unsigned* logit_amax = nullptr;   // optional (v1 kernel; the v2 launcher takes it as a parameter): running max |attention logit| as float bits (nl_frame_diagnostics)
 };
 
 // ------------------------------------------------------------------ generic segment GEMM (gemm.hip)

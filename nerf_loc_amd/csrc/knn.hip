@@ -319,8 +319,17 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
   // a query (it is tight already).  A list that would pass 64 entries is poured into the selection loop's list and the query continues there (exact either way).
   bool deferred = prev_full;
   int ncand = 0;
+  // The list is written at a computed position by one lane and read back at [lane] by another: a cross-lane hand-over through LDS inside one wave.  LDS operations
+  // of a wave execute in order and the compiler must assume the store and the load alias, so this was correct without any fence — implicitly.  The
+  // release / acquire pair at wavefront scope + the wave barrier state it; they cost nothing in the ISA (no instruction besides the waits that were there).
+  auto lds_list_handover = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   auto pour = [&]() __attribute__((always_inline)) {   // the deferred list -> the selection loop's list; the query goes on undeferred
     unsigned kd = 0xffffffffu, ki = 0xffffffffu, kp = 0;
+    lds_list_handover();
     if (lane < ncand) { const u64 k = ckey[lane]; kd = (unsigned)(k >> 32); ki = (unsigned)k; kp = cpos[lane]; }
     select_into<K>(best, kd, ki, kp);
     ncand = 0;
@@ -477,6 +486,7 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(const float* __restrict__
 
   if (deferred && ncand < K) pour();   // (cannot happen: the previous neighbours lie within the bound; kept so that the slots past the list are written below)
   if (deferred) {
+    lds_list_handover();
     const u64 mine = lane < ncand ? ckey[lane] : ~0ull;
     const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
     int rank = 0;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void point_encode_kernel(
 
 // One wave per sample. Q (N,128) ; KV (N*K, 256) = [k-proj 128 | v-proj 128] ; O (N,128)
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, const float* __restrict__ KV, int N, int K,
-                                                   float* __restrict__ O) {
+                                                   float* __restrict__ O, unsigned* __restrict__ logit_amax) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, 
   float sc[NL_KNN_MAX_K];
   float2 vv[NL_KNN_MAX_K];
   float mx = -3.4e38f;
+  float lmax = 0.f;
 #pragma unroll
   for (int k = 0; k < NL_KNN_MAX_K; ++k) {
     if (k < K) {
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, 
       float p = q0 * kk.x + q1 * kk.y;
       p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 8, 64);
       sc[k] = p;
+      lmax = (p == p) ? fmaxf(lmax, fabsf(p)) : __builtin_inff();   // conditioning indicator (nl_frame_diagnostics); a NaN logit counts as +inf
       mx = fmaxf(mx, p);
     } else { sc[k] = -3.4e38f; vv[k] = make_float2(0.f, 0.f); }
   }
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ Q, 
 #pragma unroll
   for (int k = 0; k < NL_KNN_MAX_K; ++k) { float a = sc[k] / den; o0 += a * vv[k].x; o1 += a * vv[k].y; }
   *(float2*)(O + (size_t)n * 128 + 2 * lane) = make_float2(o0, o1);
+  if (logit_amax) {   // (read first, L2-resident: an atomic only when this wave raises the maximum)
+    const float m = wave_max(lmax);
+    if (lane == 0 && __float_as_uint(m) > *(volatile const unsigned*)logit_amax) atomicMax(logit_amax, __float_as_uint(m));
+  }
 }
 
 // One wave per sample: y = LayerNorm(fc + G; eps) * gamma + beta, times wscale -> feature_agg
@@ -169,9 +175,9 @@ int nl_launch_point_encode(const float* xyz, const float* dir, int dir_stride, i
   return NL_OK;
 }
 
-int nl_launch_attn(const float* Q, const float* KV, int64_t N, int K, float* O, hipStream_t st) {
+int nl_launch_attn(const float* Q, const float* KV, int64_t N, int K, float* O, hipStream_t st, unsigned* logit_amax) {
   if (N <= 0) return NL_OK;
-  hipLaunchKernelGGL(attn_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, Q, KV, (int)N, K, O);
+  hipLaunchKernelGGL(attn_kernel, dim3((unsigned)nl_cdiv(N, 4)), dim3(256), 0, st, Q, KV, (int)N, K, O, logit_amax);
   NL_LAUNCH_CHECK();
   return NL_OK;
 }

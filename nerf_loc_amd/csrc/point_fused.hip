@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
     const float* __restrict__ p_xyz, const float* __restrict__ p_dir, const int* __restrict__ p_idx, const float* __restrict__ p_Q,
     float* __restrict__ p_O, const float* __restrict__ p_ptt, const float* __restrict__ p_sp_xyz,
     const float* __restrict__ p_sp_dir, const uint4* __restrict__ p_wstream, const float* __restrict__ p_bias,
-    const float* __restrict__ p_rd_w, const PfScalars sc) {
+    const float* __restrict__ p_rd_w, const PfScalars sc, unsigned* __restrict__ p_logit_amax) {
   const float* __restrict__ rd_w = p_rd_w;
   const PfView a = {p_xyz, p_dir, sc.dir_stride, sc.dir_div, p_idx, p_Q, p_O, p_ptt, p_sp_xyz, p_sp_dir, p_wstream,
                     p_bias, p_rd_w, sc.N, sc.M, sc.inv_span};
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
   const float inv_temp = 1.0f / 5.656854249492381f;
   const float* qrow = a.Q + (size_t)nn * 128;
   float att[4];
+  float lmax = 0.f;   // conditioning indicator (nl_frame_diagnostics): the largest |attention logit| scored; NaN counts as +inf
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     float p = 0.f;
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
       p = fmaf(q4.w * inv_temp, acc[h][4 * g + 3], p);
     }
     p += __shfl_xor(p, 32, 64);
+    lmax = (p == p) ? fmaxf(lmax, fabsf(p)) : __builtin_inff();
     const float mx = nl_max8(p);          // over the 8 neighbours (lanes) of a sample
     const float e = expf(p - mx);
     att[h] = e / nl_sum8(e);
@@ -349,6 +351,10 @@ __global__ __launch_bounds__(256, 1) void point_fused_kernel(
       }
       if (live && kk == 0) *(float4*)(a.O + (size_t)n * 128 + 32 * h + 8 * g + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
     }
+  }
+  if (p_logit_amax) {   // one atomic per wave at most: the running maximum is read first (L2-resident) and only a larger value is written
+    const float m = wave_max(live ? lmax : 0.f);
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile const unsigned*)p_logit_amax) atomicMax(p_logit_amax, __float_as_uint(m));
   }
 }
 
@@ -490,9 +496,9 @@ int nl_launch_point_fused(const NlPointFusedArgs& a, int W, int precision, hipSt
   do {                                                                                                       \
     const PfScalars sc{a.dir_stride, a.dir_div, a.N, a.M, a.inv_span};                                       \
     if (x3) hipLaunchKernelGGL((point_fused_kernel<NRT, true>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
-                               a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                           \
+                               a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc, a.logit_amax);             \
     else hipLaunchKernelGGL((point_fused_kernel<NRT, false>), grid, dim3(256), 0, st, a.xyz, a.dir, a.idx, a.Q, a.O, a.ptt, \
-                            a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc);                              \
+                            a.sp_xyz, a.sp_dir, a.wstream, a.bias, a.rd_w, sc, a.logit_amax);                \
   } while (0)
   if (W == 256) NL_PF(8);
   else if (W == 128) NL_PF(4);

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
       } else if constexpr (E == 4) {
         ap += __shfl_xor(ap, 32, 64);
         ap *= 1.0f / 5.656854249492381f;   // temperature sqrt(d_k) (ibrnet.py:84)
-        lmax = fmaxf(lmax, fabsf(ap));
+        lmax = (ap == ap) ? fmaxf(lmax, fabsf(ap)) : __builtin_inff();   // a NaN logit counts as beyond every mode's validated range (fmaxf alone would drop it)
       } else if constexpr (E == 5) amx = nl_max8(ap);
       else if constexpr (E == 6) aee = expf(ap - amx);
       else if constexpr (E == 7) ase = nl_sum8(aee);
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   if (sc.clk && blockIdx.x == 0 && tid == 0) { sc.clk[0] = __builtin_readcyclecounter() - clk_c0; sc.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
   if (sc.logit_amax) {
     const float m = wave_max(lmax);
-    if (lane == 0 && m == m) atomicMax(sc.logit_amax, __float_as_uint(m));   // (non-negative floats order like their bit patterns; NaN stays out)
+    if (lane == 0) atomicMax(sc.logit_amax, __float_as_uint(m));   // (non-negative floats order like their bit patterns; a NaN logit was recorded as +inf above)
   }
 }
 

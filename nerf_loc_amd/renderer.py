@@ -327,9 +327,10 @@ class HipRenderer:
         """nl_frame_diagnostics: {'table_absmax': max |T| of the per-frame table, 'logit_absmax': the largest |attention logit| the fused neural-point kernel has
         scored against this frame so far}.  Synchronises the current stream (a device-to-host copy of two floats)."""
         self._ready()
-        buf = (ct.c_float * 3)()
-        L.check(self.lib.nl_frame_diagnostics(self._frame, buf, 3, self._stream()), "nl_frame_diagnostics")
-        return {"table_absmax": float(buf[0]), "logit_absmax": float(buf[1]), "point_kernel_GHz": float(buf[2])}
+        buf = (ct.c_float * L.DIAG_COUNT)()
+        L.check(self.lib.nl_frame_diagnostics(self._frame, buf, L.DIAG_COUNT, self._stream()), "nl_frame_diagnostics")
+        return {"table_absmax": float(buf[0]), "logit_absmax": float(buf[1]), "point_kernel_GHz": float(buf[2]),
+                "guard_precision": L.PRECISION_NAMES.get(int(buf[3])), "guard_escalations": int(buf[4])}
 
     def clear_frame(self) -> None:
         if self._frame:
@@ -425,8 +426,12 @@ class HipRenderer:
 
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
                     intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0,
-                    side_stream: bool = True, want_knn: bool = False, graph: bool = False) -> Dict[str, torch.Tensor]:
-        """side_stream=False (nl_render_opts.flags = NL_RENDER_NO_SIDE_STREAM): every kernel on the current stream (bit-identical results;
+                    side_stream: bool = True, want_knn: bool = False, graph: bool = False, precision_guard: bool = False) -> Dict[str, torch.Tensor]:
+        """precision_guard=True (nl_render_opts.flags = NL_RENDER_PRECISION_GUARD, ABI 7): the LIBRARY checks the frame's conditioning indicator after the batch
+        (max |attention logit|; one 4-byte copy + a stream synchronisation) and renders the batch again in the next more exact mode (f16mx -> bf16x3 -> fp32) while
+        it lies beyond the validated range of the mode the outputs were produced in; the frame then stays in that mode for later guarded calls
+        (`diagnostics()['guard_precision']`).  Off by default: the synchronisation keeps the host from running ahead of the device.
+        side_stream=False (nl_render_opts.flags = NL_RENDER_NO_SIDE_STREAM): every kernel on the current stream (bit-identical results;
         for profiling kernels one at a time).
         early_term_eps > 0: early-termination compositing (nl_render_opts): colours / features of the samples behind the point where a
         ray's transmittance falls below eps are not evaluated (rgb / feat move by < eps * max|value|; everything else is unchanged).
@@ -443,7 +448,7 @@ class HipRenderer:
         per_ray = qc_t.dim() == 2
         if per_ray and tuple(qc_t.shape) != (R, 3):
             raise ValueError(f"per-ray query centres must have shape ({R}, 3), got {tuple(qc_t.shape)}")
-        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream \
+        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream and not precision_guard \
                 and not getattr(self, "guard_bytes", 0) and self._ws_request is None:
             g = self._graphed_render(R, white_bkgd, want_feat, z is not None)
             if g is not None:
@@ -475,10 +480,12 @@ class HipRenderer:
         if per_ray:
             opts.ray_centers = qc.data_ptr()
         if not side_stream:
-            opts.flags = L.RENDER_NO_SIDE_STREAM
+            opts.flags |= L.RENDER_NO_SIDE_STREAM
+        if precision_guard:
+            opts.flags |= L.RENDER_PRECISION_GUARD
         L.check(self.lib.nl_render_rays_ex(ct.byref(self.cfg), self.packed.data_ptr(), self._frame, None if per_ray else qc.data_ptr(), o.data_ptr(),
                                            d.data_ptr(), _ptr(z), R, int(bool(white_bkgd)), ct.byref(ro), ws.data_ptr(), ws.numel(), self._stream(),
-                                           ct.byref(opts) if (early_term_eps > 0 or per_ray or not side_stream) else None), "nl_render_rays")
+                                           ct.byref(opts) if (early_term_eps > 0 or per_ray or not side_stream or precision_guard) else None), "nl_render_rays")
         out["mask"] = out["mask"].view(torch.bool)   # 0 / 1 bytes reinterpreted: no conversion kernel
         if intermediates:
             out["sigma"] = out["sigma"].view(R, S)

@@ -168,6 +168,27 @@ def make_rays(cfg: SceneConfig, frame: Dict[str, np.ndarray], R: int | None = No
     }
 
 
+def borderline_rays(cfg: SceneConfig, frame: Dict[str, np.ndarray], rays_o: np.ndarray, rays_d: np.ndarray, z: np.ndarray, tol_px: float = 1e-3) -> np.ndarray:
+    """(R,) bool: rays with a sample that projects within `tol_px` pixel of an image border of some support view (or within 1e-4 of its camera plane).  The
+    in-image masks of the reference (ibrnet.py:169-199, neuray_ops.py) are hard thresholds on fp32 projections, so such a sample is inside for one summation
+    order of the projection and outside for another (seen: y = 60.49999 against the bound 60.5, visibility 0.99 vs 0) and the ray's outputs legitimately differ
+    between two correct fp32 evaluations.  Parity comparisons report these rays separately (tools/forward_fuzz.py, bench.py `parity`, the full-batch test)."""
+    o, d = np.asarray(rays_o, np.float64), np.asarray(rays_d, np.float64)
+    x = o[:, None, :] + d[:, None, :] * np.asarray(z, np.float64)[..., None]
+    flag = np.zeros(x.shape[0], bool)
+    for v in range(frame["topk_poses"].shape[0]):
+        w2c = np.linalg.inv(frame["topk_poses"][v].astype(np.float64))
+        pc = x @ w2c[:3, :3].T + w2c[:3, 3]
+        uv = pc @ frame["topk_Ks"][v].astype(np.float64)[:3, :3].T
+        px, py, pz = uv[..., 0] / uv[..., 2], uv[..., 1] / uv[..., 2], pc[..., 2]
+        near = np.abs(pz) < 1e-4
+        for val, size in ((px, cfg.Wimg), (py, cfg.H)):
+            for b in (-0.5, 0.0, size - 1.0, size - 0.5):
+                near |= np.abs(val - b) < tol_px
+        flag |= near.any(1)
+    return flag
+
+
 def make_u(cfg: SceneConfig, R: int | None = None) -> np.ndarray:
     """Uniform draws for sample_pdf (the reference hard-wires torch.rand, utils.py:96)."""
     R = cfg.R if R is None else R

@@ -552,7 +552,8 @@ def render_rays(p: Dict[str, Tensor], frame: Dict, rays: Dict, n_samples: int, n
     if timers is not None:
         timers["ray_unet"] = timers.get("ray_unet", 0.0) + (t1 - t0)
         timers["heads_composite"] = timers.get("heads_composite", 0.0) + (time.perf_counter() - t1)
-    out = {"rgb": rgb, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": dunc, "feat": feat}
+    out = {"rgb": rgb, "depth": depth, "weights": wts, "mask": valid, "depth_uncertainty": dunc, "feat": feat,
+           "z_vals": z}   # (the depths the samples were placed at: not an output of model.py:577-598; callers use it to find hard-threshold border samples)
     if depth_coarse is not None:
         out["depth_coarse"] = depth_coarse
     if intermediates:

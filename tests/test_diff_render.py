@@ -188,7 +188,7 @@ def _train_case(device, hier=False):
     return case, cfg, data, rays
 
 
-def _check_train(loss, psnr, named, gfeat, tol, gname="train_setup", slack=0, cap=2.0):
+def _check_train(loss, psnr, named, gfeat, tol, gname="train_setup", slack=0, cap=2.0, slack_names=None):
     g = np.load(os.path.join(GOLD, f"{gname}.npz"))
     assert abs(float(loss.detach()) - float(g["loss"])) < tol * abs(float(g["loss"])), (float(loss.detach()), float(g["loss"]))
     assert abs(float(psnr.detach()) - float(g["psnr"])) < tol * abs(float(g["psnr"]))
@@ -220,8 +220,10 @@ def _check_train(loss, psnr, named, gfeat, tol, gname="train_setup", slack=0, ca
     reached = {k for k, v in named.items() if v.grad is not None and float(v.grad.abs().max()) > 1e-5 * gmax}
     assert reached == {k.split(":", 1)[1] for k in g.files if k.startswith(("grad:", "gsub:")) and float(np.abs(g[k]).max()) > 1e-5 * gmax}
     bad = {k: e for k, e in errs.items() if not e < tol}
-    # slack: that many tensors may sit between tol and cap x tol (GPU runs: see the caller)
+    # slack: that many tensors may sit between tol and cap x tol (GPU runs: see the caller); slack_names: ... and only tensors whose name ends in one of these
+    # (round 6, ADVICE r5: the escape hatch covers the named MaxPool-tie tensors, not whichever tensor happens to regress)
     assert len(bad) <= slack and all(e < cap * tol for e in bad.values()), bad
+    assert slack_names is None or all(k.endswith(tuple(slack_names)) for k in bad), bad
     return errs
 
 
@@ -309,7 +311,8 @@ def test_compute_render_loss_through_the_dropin_matches_reference_autograd(hier,
     # `mean_decoder.4.weight`, the same three tensors with the library's nodes and with the all-eager graph); the plain case is held to 2 x that instead of 3e-3
     # (end of round 5: with the bar at 1.6e-3 the MaxPool-tie event above is THREE tensors over it — caught once in a 25-run loop of this test on the GPU box, fp32 mode:
     # `ray_unet.conv2.1.bias` 3.69e-3, `ray_unet.conv2.1.weight` 2.61e-3, `vis_decoder.4.bias` 2.01e-3 — so the slack is three tensors below 2.5 x the bar (4e-3), not one below 2 x)
-    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-2 if hier else 1.6e-3, "train_hier" if hier else "train_setup", slack=3, cap=2.5)
+    errs = _check_train(loss, psnr, dict(net.named_parameters()), data["feat_fine_src"].grad, 2e-2 if hier else 1.6e-3, "train_hier" if hier else "train_setup", slack=3, cap=2.5,
+                        slack_names=None if hier else ("ray_unet.conv2.1.bias", "ray_unet.conv2.1.weight", "vis_decoder.4.bias"))
     assert float(np.median(list(errs.values()))) < (1e-3 if hier else 1e-4)
     assert sum(e > 3e-3 for e in errs.values()) <= 6, {k: e for k, e in errs.items() if e > 3e-3}
     print("TRAIN_GRAD", hier, hip_nodes, precision, "median", f"{float(np.median(list(errs.values()))):.2e}", "worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])

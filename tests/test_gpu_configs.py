@@ -172,7 +172,7 @@ def test_render_opts_are_validated_and_streams_do_not_interfere():
         return ra.lib.nl_render_rays_ex(ct.byref(ra.cfg), ra.packed.data_ptr(), ra._frame, qch.data_ptr(), o.data_ptr(), d.data_ptr(), None, 16, 0,
                                         ct.byref(ro), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream, ct.byref(opts))
     assert call(L.NlRenderOpts()) == L.NL_OK
-    for bad in (dict(flags=2), dict(flags=0x80000000), dict(early_term_eps=float("nan")), dict(early_term_eps=1.0), dict(early_term_eps=-0.5)):
+    for bad in (dict(flags=4), dict(flags=0x80000000), dict(early_term_eps=float("nan")), dict(early_term_eps=1.0), dict(early_term_eps=-0.5)):
         op = L.NlRenderOpts()
         for k, v in bad.items():
             setattr(op, k, v)
@@ -323,3 +323,89 @@ def test_graphed_inference_replays_are_bit_identical_to_the_eager_call():
         for k in e2:
             assert torch.equal(e2[k], g2[k]), (prec, "new frame", k)
         assert not torch.equal(e2["rgb"], eager["rgb"])
+
+
+def test_precision_guard_at_the_boundary_checks_every_batch():
+    """NL_RENDER_PRECISION_GUARD (ABI 7): the LIBRARY keeps a C-ABI caller / `HipRenderer` alone inside the validated range of its
+    mode.  A frame whose feature maps are scaled until SOME rays score attention logits beyond f16mx's limit and others do not:
+      * an unguarded render leaves the mode alone and reports the indicator;
+      * a guarded render of the benign rays stays in f16mx (no escalation) — and the guarded render of the other rays, a LATER batch of the same frame, is
+        re-rendered in the next mode (round 5's module-level guard looked at the first batch of a frame only); the outputs are bit-identical to rendering that
+        batch in that mode directly and within 1e-4 of the fp32 mode; the frame then stays there (the benign rays now come out in the safer mode too);
+      * a new frame starts from the configured mode."""
+    import importlib.util
+    import os
+    from nerf_loc_amd import _lib as L
+    from nerf_loc_amd.renderer import HipRenderer
+    from nerf_loc_amd.synth import SceneConfig, make_frame, make_rays, make_weights
+    spec = importlib.util.spec_from_file_location("scale_sweep", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "scale_sweep.py"))
+    sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sweep)
+    cfg = SceneConfig("guard_abi", R=48, S=32, W=128, V=4, H=48, Wimg=64, seed=31)
+    base, rays, weights = make_frame(cfg), None, make_weights(cfg)
+    rays = make_rays(cfg, base)
+    limit = L.GUARD_LOGIT_LIMIT["f16mx"]
+    z = _zbase(cfg, cfg.R)
+    qc = base["pose"][:3, 3]
+
+    def renderer(fr, prec="f16mx"):
+        r = HipRenderer(cfg.W, cfg.C, cfg.S, prec)
+        r.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
+        r.set_frame(fr["topk_images"], fr["feat_fine_src"], fr["vis_featmaps"], fr["topk_Ks"], fr["topk_poses"], cfg.near, cfg.far, fr["support_fine"])
+        return r
+    o, d = rays["rays_o"], rays["rays_d"]
+    chosen = None
+    for fscale in (2.0, 2.5, 3.0, 3.5, 4.0, 5.0, 6.0):   # |logit| grows about quadratically with the feature scale: find the scale that splits the batch
+        fr = sweep.scaled_frame(base, fscale=fscale)
+        per_ray = []
+        for i in range(cfg.R):
+            r = renderer(fr)    # (a fresh frame per ray: the indicator is cumulative per frame)
+            r.render_rays(o[i:i + 1], d[i:i + 1], qc, z_vals=z[i:i + 1])
+            per_ray.append(r.diagnostics()["logit_absmax"])
+        per_ray = np.array(per_ray)
+        benign, ill = np.where(per_ray < 0.8 * limit)[0], np.where(per_ray > 1.25 * limit)[0]
+        if len(benign) >= 4 and len(ill) >= 4 and per_ray.max() < L.GUARD_LOGIT_LIMIT["bf16x3"]:
+            chosen = (fscale, fr, benign, ill, per_ray)
+            break
+    assert chosen is not None, "no feature scale splits the rays around the f16mx limit"
+    fscale, fr, benign, ill, per_ray = chosen
+    print(f"feature scale {fscale}: {len(benign)} rays below {0.8 * limit:g}, {len(ill)} above {1.25 * limit:g} (max {per_ray.max():.1f})")
+    zb, zi = z[:len(benign)], z[:len(ill)]
+    # unguarded: nothing happens, the indicator is reported
+    r = renderer(fr)
+    plain = r.render_rays(o[ill], d[ill], qc, z_vals=zi)
+    dg = r.diagnostics()
+    assert dg["logit_absmax"] > limit and dg["guard_precision"] is None and dg["guard_escalations"] == 0
+    # guarded, batch by batch against ONE frame
+    r = renderer(fr)
+    first = r.render_rays(o[benign], d[benign], qc, z_vals=zb, precision_guard=True)
+    dg = r.diagnostics()
+    assert dg["guard_precision"] == "f16mx" and dg["guard_escalations"] == 0 and dg["logit_absmax"] <= limit, dg
+    second = r.render_rays(o[ill], d[ill], qc, z_vals=zi, precision_guard=True)
+    dg = r.diagnostics()
+    assert dg["guard_precision"] == "bf16x3" and dg["guard_escalations"] == 1, dg
+    third = r.render_rays(o[benign], d[benign], qc, z_vals=zb, precision_guard=True)   # the frame stays in the safer mode
+    assert r.diagnostics()["guard_escalations"] == 1 and r.diagnostics()["guard_precision"] == "bf16x3"
+    rx = renderer(fr, "bf16x3")
+    want_ill, want_benign = rx.render_rays(o[ill], d[ill], qc, z_vals=zi), rx.render_rays(o[benign], d[benign], qc, z_vals=zb)
+    r32 = renderer(fr, "fp32")
+    exact = r32.render_rays(o[ill], d[ill], qc, z_vals=zi)
+    for k in KEYS:
+        assert torch.equal(second[k], want_ill[k]) and torch.equal(third[k], want_benign[k]), k
+        assert rel_err(second[k].cpu().numpy(), exact[k].cpu().numpy()) < 1e-4, (k, "guarded vs fp32 mode")
+    assert not all(torch.equal(first[k], third[k]) for k in KEYS)    # (the first batch really was rendered in f16mx)
+    assert not all(torch.equal(plain[k], second[k]) for k in KEYS)
+    # a new frame starts from the configured mode; the guard is refused where it would serialise concurrent jobs
+    r.set_frame(base["topk_images"], base["feat_fine_src"], base["vis_featmaps"], base["topk_Ks"], base["topk_poses"], cfg.near, cfg.far, base["support_fine"])
+    r.render_rays(o, d, qc, z_vals=z, precision_guard=True)
+    dg = r.diagnostics()
+    assert dg["guard_precision"] == "f16mx" and dg["guard_escalations"] == 0 and 0 < dg["logit_absmax"] < limit
+    # the staged kernels (W = 64: the v1 fused kernel; fp32 mode: the staged attention kernel) report the indicator too
+    c64 = cfg.replace(W=64, name="guard_w64")
+    w64 = make_weights(c64)
+    for prec in ("bf16x3", "fp32"):
+        r64 = HipRenderer(c64.W, c64.C, c64.S, prec)
+        r64.load_weights({k: torch.from_numpy(v) for k, v in w64.items()})
+        r64.set_frame(base["topk_images"], base["feat_fine_src"], base["vis_featmaps"], base["topk_Ks"], base["topk_poses"], cfg.near, cfg.far, base["support_fine"])
+        r64.render_rays(o, d, qc, z_vals=z)
+        assert r64.diagnostics()["logit_absmax"] > 0, prec

@@ -103,3 +103,60 @@ def test_strong_scaling_split_reassembles_the_batch():
     for p in ps:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+class _FakeRenderer:
+    """Stands in for HipRenderer on the CPU: any per-ray function with render_rays' signature and output keys."""
+
+    def render_rays(self, o, d, qc, z_vals=None, white_bkgd=False):
+        qc = torch.as_tensor(qc, dtype=o.dtype)
+        c = qc if qc.dim() == 2 else qc.expand(o.shape[0], 3)
+        return {"rgb": o * d + c, "depth": (o * d).sum(1) + (0 if z_vals is None else z_vals.sum(1)), "weights": torch.stack([o[:, 0], d[:, 1]], 1),
+                "mask": o[:, 0] > d[:, 0], "depth_uncertainty": o.sum(1), "feat": torch.cat([o, d], 1), "knn_idx": torch.zeros(o.shape[0], 8)}
+
+
+def _product_worker(rank, world, port, q):
+    """render_rays_sharded / ShardedRenderLoop / shard_rays (the product-side sharded step) reassemble the single-rank result exactly;
+    a rank with ZERO rays (R < world) takes part in the collective like any other."""
+    from nerf_loc_amd.sharding import ShardedRenderLoop, render_rays_sharded, shard_counts, shard_rays
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    r = _FakeRenderer()
+    for R in (37, 12, 1):
+        g = torch.Generator().manual_seed(R)
+        o, d, z = torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g), torch.rand(R, 5, generator=g)
+        for qc in (torch.tensor([1., 2., 3.]), torch.rand(R, 3, generator=g)):
+            full = r.render_rays(o, d, qc, z_vals=z)
+            got = render_rays_sharded(r, o, d, qc, dist, z_vals=z)
+            ok = ok and "knn_idx" not in got and all(torch.equal(got[k], full[k]) for k in got) and set(got) == set(full) - {"knn_idx"}
+            pend = render_rays_sharded(r, o, d, qc, dist, z_vals=z, async_op=True)
+            ok = ok and all(torch.equal(v, full[k]) for k, v in pend.result().items())
+        cnt = shard_counts(R, world)
+        lo, hi = shard_range(R, rank, world)
+        loop = ShardedRenderLoop(dist, None if len(set(cnt)) == 1 else cnt)
+        qc = torch.tensor([0.5, 0., 1.])
+        first = loop.step(lambda: r.render_rays(o[lo:hi], d[lo:hi], qc))
+        second = loop.step(lambda: r.render_rays(d[lo:hi], o[lo:hi], qc))
+        last = loop.drain()
+        want1, want2 = r.render_rays(o, d, qc), r.render_rays(d, o, qc)
+        ok = ok and first is None and all(torch.equal(second[k], want1[k]) and torch.equal(last[k], want2[k]) for k in second) and loop.drain() is None
+        rays = {"rays_o": o, "rays_d": d, "pixel_coordinates": torch.rand(R, 2, generator=g), "K": torch.eye(3), "pose": torch.eye(4), "H": 3, "W": 3}
+        sub = shard_rays(rays, rank, world)
+        ok = ok and sub["rays_o"].shape[0] == hi - lo and torch.equal(sub["pixel_coordinates"], rays["pixel_coordinates"][lo:hi]) and sub["K"] is rays["K"] \
+            and sub["pose"] is rays["pose"]   # (a 3x3 K with R = 3 rays must not be sliced: only the per-ray keys are)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_product_sharded_render_reassembles_single_rank_result():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_product_worker, args=(r, 2, 29563, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res

@@ -31,23 +31,9 @@ def eager64(cfg, frame, weights, rays, z, white):
 
 
 def borderline_rays(cfg, frame, rays, z):
-    """rays with a sample that projects within 1e-3 pixel of an image border of some support view (or within 1e-4 of its camera plane): the in-image masks of the
-    reference (ibrnet.py / neuray_ops.py) are hard thresholds on fp32 projections, so such a sample is inside for one summation order and outside for another —
-    a scene in 600 had one at y = 60.49999 against the bound 60.5, visibility 0.99 vs 0 — and the ray's outputs legitimately differ"""
-    o, d = rays["rays_o"].astype(np.float64), rays["rays_d"].astype(np.float64)
-    x = o[:, None, :] + d[:, None, :] * z.numpy().astype(np.float64)[..., None]
-    flag = np.zeros(x.shape[0], bool)
-    for v in range(cfg.V):
-        w2c = np.linalg.inv(frame["topk_poses"][v].astype(np.float64))
-        pc = x @ w2c[:3, :3].T + w2c[:3, 3]
-        uv = pc @ frame["topk_Ks"][v].astype(np.float64)[:3, :3].T
-        px, py, pz = uv[..., 0] / uv[..., 2], uv[..., 1] / uv[..., 2], pc[..., 2]
-        near = np.abs(pz) < 1e-4
-        for val, size in ((px, cfg.Wimg), (py, cfg.H)):
-            for b in (-0.5, 0.0, size - 1.0, size - 0.5):
-                near |= np.abs(val - b) < 1e-3
-        flag |= near.any(1)
-    return flag
+    """nerf_loc_amd.synth.borderline_rays (moved there in round 6: bench.py's parity block and the full-batch test use it too)"""
+    from nerf_loc_amd.synth import borderline_rays as _b
+    return _b(cfg, frame, rays["rays_o"], rays["rays_d"], z.numpy())
 
 
 def run(ncases=20, seed0=0, verbose=True):
