@@ -573,7 +573,7 @@ def parity_block(cfg, frame, rays, kept, gpu_out, precision):
     max_rel = {k: rel(got[k][core], ref[k][core]) for k in PARITY_KEYS}
     l2_rel = {k: l2(got[k][core], ref[k][core]) for k in PARITY_KEYS}
     mask_equal = bool(np.array_equal(got["mask"][core].astype(bool), ref["mask"][core].astype(bool)))
-    b_rel = {k: rel(got[k][border], ref[k][core | border]) for k in PARITY_KEYS} if border.any() else {}
+    b_rel = {}
     if border.any():   # (denominator: the whole sample's max |oracle|, so that the two groups are on one scale)
         b_rel = {k: float(np.abs(got[k][border].astype(np.float64) - ref[k][border].astype(np.float64)).max() / max(np.abs(ref[k].astype(np.float64)).max(), 1e-30))
                  for k in PARITY_KEYS}

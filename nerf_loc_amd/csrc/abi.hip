@@ -31,6 +31,8 @@ int nl_launch_point_encode(const float* xyz, const float* dir, int dir_stride, i
 int nl_launch_attn(const float* Q, const float* KV, int64_t N, int K, float* O, hipStream_t st, unsigned* logit_amax = nullptr);
 int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const float* gamma, const float* beta, float eps, const float* wscale, float* out, hipStream_t st);
 int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
+bool nl_unet_inner_supported(int S, int precision);
+int nl_launch_unet_inner(const NlUnetInnerArgs& a, int precision, hipStream_t st);
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
 int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st,
@@ -1251,8 +1253,10 @@ int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const fl
 // need_geo == false: the caller only wants the density (model.py:525 is the sole consumer of the U-Net's output); when the density
 // head runs inside conv_out's epilogue the (N, W) output rows are then never written (0.5 GB per config-2 batch)
 // in_frag: `in` is feature_agg as the chain kernel's fragment image (NlGemmSeg::frag) instead of fp32 rows
+// fuse_inner: the caller needs nothing of the five inner layers but their result (u.x2) — the inference render path; the backward passes and the stage entry
+// point keep the separate launches (their pre-LayerNorm outputs and block outputs are read back)
 int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr,
-            bool need_geo = true, bool in_frag = false) {
+            bool need_geo = true, bool in_frag = false, bool fuse_inner = false) {
   const int W = x.c->W, S = x.c->S;
   // the two phases of every transposed convolution as one launch (bf16 modes; the fp32 kernels keep the separate phases)
   static const bool no_merge = dbg_switch("NERFLOC_NO_TMERGE");
@@ -1274,6 +1278,16 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
     NL_TRY(run_gemm(x, korder ? G_CONV1F : G_CONV1, s, 1, R * S, u.r1, 64, NL_ACT_NONE, S, S, S, 1, 0, &ep, &fused));
     if (!fused) NL_TRY(nl_launch_ln_slab_elu(u.r1, R, S, 64, g(U_CONV1), b(U_CONV1), eps, nullptr, u.c1, x.st));
   }
+  // conv2 ... trans_conv1 as one kernel (unet_inner.hip: a pair of rays per workgroup, every slab in LDS): S = 128, the streaming kernels' weight images
+  static const bool no_inner = dbg_switch("NERFLOC_NO_UNET_INNER");
+  const uint64_t inner_bits = (1ull << G_CONV2) | (1ull << G_CONV3) | (1ull << G_T3M) | (1ull << G_T2M) | (1ull << G_T1M);
+  if (fuse_inner && merged && !no_inner && nl_unet_inner_supported(S, x.c->precision) && (x.has_bst & inner_bits) == inner_bits) {
+    NlUnetInnerArgs ia;
+    ia.c1 = u.c1; ia.x2 = u.x2; ia.R = (int)R; ia.eps = eps;
+    const int gs[5] = {G_CONV2, G_CONV3, G_T3M, G_T2M, G_T1M}, us[5] = {U_CONV2, U_CONV3, U_T3, U_T2, U_T1};
+    for (int i = 0; i < 5; ++i) { ia.w[i] = x.pk + x.L.bst[gs[i]]; ia.bias[i] = x.p<float>(x.L.bias[gs[i]]); ia.gl[i] = gl(us[i]); ia.bl[i] = bl(us[i]); }
+    NL_TRY(nl_launch_unet_inner(ia, x.c->precision, x.st));
+  } else {
   {  // conv2: 64 -> 128 over S/2
     SegSpec s[1] = {{u.c1, 64, 64, 0, 1, 3}};
     const RowEpi ep{nullptr, 0, gl(U_CONV2), bl(U_CONV2), nullptr, eps, u.c2, NL_EPI_LNSLAB, 1};   // two rays per workgroup at S = 128
@@ -1328,6 +1342,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
       NL_TRY(run_gemm(x, G_T1O, o, 4, R * Li, u.x2r, 32, NL_ACT_NONE, Li, Li, Lo, 2, 1));
     }
     if (!tfused) NL_TRY(nl_launch_ln_slab_elu(u.x2r, R, Lo, 32, g(U_T1), b(U_T1), eps, u.x2, nullptr, x.st));
+  }
   }
   {  // conv_out on cat[in, x2]
     SegSpec s[2] = {{in, W, W, 0, 1, 3, fa_mode}, {u.x2, 32, 32, 0, 1, 3}};
@@ -2482,7 +2497,7 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
     bool have_sigma = false;
-    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag));
+    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag, true));
     NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -125,6 +125,18 @@ struct NlPointFusedArgs {
   unsigned* logit_amax = nullptr;   // optional (v1 kernel; the v2 launcher takes it as a parameter): running max |attention logit| as float bits (nl_frame_diagnostics)
 };
 
+// ------------------------------------------------------------------ the five inner ray-U-Net layers as one kernel (unet_inner.hip)
+struct NlUnetInnerArgs {
+  const float* c1;            // (R, 64, 64) fp32: conv1's pooled block output
+  float* x2;                  // (R, 128, 32) fp32: trans_conv1's block output (conv_out's second source)
+  const char* w[5];           // weight streams in tgemm_kernel's chunk layout: conv2, conv3, trans_conv3 / 2 / 1 (merged phases)
+  const float* bias[5];
+  const float* gl[5];         // LayerNorm tables in accumulator-lane order (abi.hip: ln_lane_major_kernel)
+  const float* bl[5];
+  int R;
+  float eps;
+};
+
 // ------------------------------------------------------------------ generic segment GEMM (gemm.hip)
 #define NL_GEMM_MAX_SEG 6
 struct NlGemmSeg {

@@ -569,12 +569,18 @@ int nl_knn_search(const NlKnnGrid* g, const float* xyz, int64_t N, int K, int* i
   if (K < 1 || K > 8) return NL_ERR_UNSUPPORTED;
   // consecutive queries per wave (each takes its bound from the one before): 16 for render-sized batches (-7 % against 4), 4 where the
   // batch would not fill the chip otherwise (descriptor queries: 1024 points)
-  const bool big = N >= (1 << 18);
-  const int spw = big ? 16 : 4;
+#ifndef NL_KNN_BIG_LOG2
+#define NL_KNN_BIG_LOG2 18
+#endif
+#ifndef NL_KNN_SPW_SMALL
+#define NL_KNN_SPW_SMALL 4
+#endif
+  const bool big = N >= (1 << NL_KNN_BIG_LOG2);
+  const int spw = big ? 16 : NL_KNN_SPW_SMALL;
   dim3 grid(nl_xcd_grid(nl_cdiv(N, 4 * spw)));
 #define NL_KNN(KK, SPW) hipLaunchKernelGGL((knn_wave_kernel<KK, SPW>), grid, dim3(256), 0, st, xyz, (int)N, g->params, g->starts, g->sorted, K, idx, d2)
-  if (K == 1) { if (big) NL_KNN(1, 16); else NL_KNN(1, 4); }
-  else { if (big) NL_KNN(8, 16); else NL_KNN(8, 4); }
+  if (K == 1) { if (big) NL_KNN(1, 16); else NL_KNN(1, NL_KNN_SPW_SMALL); }
+  else { if (big) NL_KNN(8, 16); else NL_KNN(8, NL_KNN_SPW_SMALL); }
 #undef NL_KNN
   NL_LAUNCH_CHECK();
 #ifdef KNN_STATS

@@ -671,7 +671,10 @@ int nl_launch_mv_vis_mfma(const NlViews& vw, const float* visf_hwc, const void* 
                           float* dd_out, bool x3, hipStream_t st) {
   if (N <= 0) return NL_OK;
   const int tpv = (int)nl_cdiv(N, 32), total = tpv * vw.V;
-  const int blocks = (int)(nl_cdiv(total, 4) < 2048 ? nl_cdiv(total, 4) : 2048);
+#ifndef MV_VIS_MAX_BLOCKS
+#define MV_VIS_MAX_BLOCKS 2048
+#endif
+  const int blocks = (int)(nl_cdiv(total, 4) < MV_VIS_MAX_BLOCKS ? nl_cdiv(total, 4) : MV_VIS_MAX_BLOCKS);
   if (x3) hipLaunchKernelGGL(mv_vis_mfma_kernel<true>, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, vis_out, dd_out);
   else hipLaunchKernelGGL(mv_vis_mfma_kernel<false>, dim3(blocks), dim3(256), 0, st, vw, visf_hwc, (const uint4*)dpack, xyz, (int)N, tpv, total, vis_out, dd_out);
   NL_LAUNCH_CHECK();
