@@ -146,7 +146,11 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
     const ui_bf16x8* src = reinterpret_cast<const ui_bf16x8*>(a.w[decltype(LT)::value]) + (size_t)c * (4 * L::NRT * 64) + ct * 64 + lane;
     w[0] = src[(0 * 2 + 0) * L::NRT * 64];
     w[1] = src[(0 * 2 + 1) * L::NRT * 64];
+#ifdef UI_KO_LO      // knock-out (timing only, wrong results): half of the weight bytes are not fetched
+    if (X3) { w[2] = w[0]; w[3] = w[1]; }
+#else
     if (X3) { w[2] = src[(1 * 2 + 0) * L::NRT * 64]; w[3] = src[(1 * 2 + 1) * L::NRT * 64]; }
+#endif
   };
   {   // the first layer's first chunks are on their way while c1 is staged
     const int ct0 = wave % Lyr<0>::NRT;
@@ -220,10 +224,12 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
+#ifndef UI_KO_MFMA   // knock-out (timing only): two of the three matrix instructions are not issued
           if (X3) {
             acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2 + ks], b[ks][ti][0], acc[ti], 0, 0, 0);
             acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], b[ks][ti][1], acc[ti], 0, 0, 0);
           }
+#endif
           acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], b[ks][ti][0], acc[ti], 0, 0, 0);
         }
       }

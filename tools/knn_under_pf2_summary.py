@@ -1,4 +1,5 @@
-"""Summary of tools/knn_under_pf2.py's kernel trace: KNN launch durations by what ran beside them.  python tools/knn_under_pf2_summary.py results.db [out.txt]"""
+"""Summary of tools/knn_under_pf2.py's kernel trace: how much search work gets done beside each kernel of the step, and what it costs that kernel.
+python tools/knn_under_pf2_summary.py results.db [out.txt]"""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
@@ -7,29 +8,30 @@ ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 scol = [r[1] for r in db.execute(f"pragma table_info({ks})")]
 name_col = "display_name" if "display_name" in scol else ("kernel_name" if "kernel_name" in scol else "name")
 rows = list(db.execute(f"select s.{name_col}, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
+short = lambda n: re.sub(r"\(anonymous namespace\)::", "", re.sub(r"\s+", " ", n)).split("(")[0].replace("void ", "")[:48]
 knn = [(s, e) for n, s, e in rows if "knn_wave_kernel" in n]
-pf2 = [(s, e) for n, s, e in rows if "point_fused2_kernel" in n]
-others = [(n, s, e) for n, s, e in rows if "knn_wave_kernel" not in n]
+others = [(short(n), s, e) for n, s, e in rows if "knn_wave_kernel" not in n]
 def overlap(a, b): return max(0, min(a[1], b[1]) - max(a[0], b[0]))
-out = []
-alone, under, mixed = [], [], []
-for k in knn:
-    dur = k[1] - k[0]
-    ov_pf2 = sum(overlap(k, p) for p in pf2)
-    ov_any = sum(overlap(k, (s, e)) for _, s, e in others)
-    (under if ov_pf2 > 0.9 * dur else alone if ov_any < 0.05 * dur else mixed).append(dur / 1e3)
 med = lambda v: sorted(v)[len(v) // 2] if v else float("nan")
-out.append(f"half-batch KNN launches (262 144 queries): {len(knn)}")
-out.append(f"  nothing else running:            n = {len(alone):3d}, median {med(alone):8.1f} us")
-out.append(f"  entirely under point_fused2:     n = {len(under):3d}, median {med(under):8.1f} us")
-out.append(f"  beside other kernels / partly:   n = {len(mixed):3d}, median {med(mixed):8.1f} us")
-pf_alone = [(e - s) / 1e3 for s, e in pf2 if sum(overlap((s, e), k) for k in knn) < 0.05 * (e - s)]
-pf_with = [(e - s) / 1e3 for s, e in pf2 if sum(overlap((s, e), k) for k in knn) > 0.9 * (e - s)]
-out.append(f"point_fused2_kernel: alone n = {len(pf_alone)}, median {med(pf_alone):.1f} us; with searches beside it the whole time n = {len(pf_with)}, median {med(pf_with):.1f} us")
-if under and pf_with and pf_alone and alone:
-    gain = med(alone) - 0.0   # a half-batch search moved entirely under the matrix kernel leaves the critical path ...
-    cost = (med(pf_with) - med(pf_alone)) * min(1.0, med(under) / med(pf_with))   # ... and the matrix kernel pays this while the search runs beside it
-    out.append(f"a search that takes {med(alone):.0f} us alone takes {med(under):.0f} us under the matrix kernel, which runs {med(pf_with) - med(pf_alone):.0f} us longer per launch while searches run beside it")
+# searches with nothing else on the device = the search alone
+alone = [(e - s) / 1e3 for s, e in knn if sum(overlap((s, e), (a, b)) for _, a, b in others) < 0.02 * (e - s)]
+t_alone = med(alone)
+out = [f"half-batch exact KNN (262 144 queries), nothing else running: {t_alone:.0f} us (n = {len(alone)})",
+       "per kernel of the render step: its duration alone | with searches beside it the whole time | search progress per launch of it, in search-alone microseconds",
+       "(progress = sum over the searches of overlap / that search's duration x the search's alone time: what the side stream got done while this kernel ran)"]
+names = []
+for n, _, _ in others:
+    if n not in names: names.append(n)
+tot_gain = tot_cost = 0.0
+for nm in names:
+    iv = [(s, e) for n, s, e in others if n == nm]
+    if med([(e - s) / 1e3 for s, e in iv]) < 30: continue
+    d_alone = [(e - s) / 1e3 for s, e in iv if sum(overlap((s, e), k) for k in knn) < 0.02 * (e - s)]
+    busy = [(s, e) for s, e in iv if sum(overlap((s, e), k) for k in knn) > 0.95 * (e - s)]
+    d_with = [(e - s) / 1e3 for s, e in busy]
+    prog = [sum(overlap((s, e), k) / (k[1] - k[0]) for k in knn) * t_alone for s, e in busy]
+    if not d_alone or not d_with: continue
+    out.append(f"  {nm:48s} {med(d_alone):8.0f} | {med(d_with):8.0f} (+{med(d_with) - med(d_alone):5.0f}) | {med(prog):7.0f}")
 txt = "\n".join(out)
 if len(sys.argv) > 2: open(sys.argv[2], "w").write(txt + "\n")
 print(txt)
