@@ -515,6 +515,10 @@ struct nl_frame {
   // never lazily inside a render call (stream / event creation is illegal during graph capture) and never shared between frames, so two
   // renderers on two caller streams do not record into each other's events.  side_ok == false: everything runs on the caller's stream.
   hipStream_t side; hipEvent_t ev_fork, ev_join; bool side_ok;
+  // round 6: the search in parts (do_point: part p + 1 of the exact KNN is released onto the side stream when the neural-point kernel of part p starts) —
+  // ev_go[p]: recorded on the caller's stream in front of part p - 1's neural-point launch; ev_done[p]: part p's neighbours and aggregation scales are written
+  static constexpr int kMaxParts = 4;
+  hipEvent_t ev_go[kMaxParts], ev_done[kMaxParts]; bool parts_ok;
   // precision guard (NL_RENDER_PRECISION_GUARD): the mode guarded calls render this frame in once one of them found the conditioning indicator beyond the
   // configured mode's validated range (-1: none yet), how often that happened, and the mode the last guarded call's outputs were produced in.  Host-side
   // state of a frame that is documented as not re-entrant; mutable because render calls take the frame as const.
@@ -762,6 +766,8 @@ int ensure_ptt(const Ctx& x, const nl_frame* fc) {
 // side stream first, so no kernel is left writing the caller's workspace behind its back and an active capture stays well-formed.
 struct SideJoin {
   hipStream_t main = nullptr, side = nullptr; hipEvent_t ev = nullptr; bool armed = false;
+  int parts = 1;            // > 1: only part 0 of the search has been issued (rows [0, part_rows)); do_point issues the others, each when the part before it starts
+  int64_t part_rays = 0;    // rays per part (parts are cut at ray boundaries: the per-sample direction is the ray's)
   void arm(hipStream_t m, hipStream_t s_, hipEvent_t e) { main = m; side = s_; ev = e; armed = true; }
   int join() {
     if (!armed) return NL_OK;
@@ -830,7 +836,9 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     SegSpec sg{G, W, W, 0, 1};
     NL_TRY(run_gemm(x, G_Q, &sg, 1, N, p.Q, 128, NL_ACT_NONE));
   }
-  if (knn_done) NL_TRY(knn_done->join());
+  const int parts = knn_done ? knn_done->parts : 1;
+  if (knn_done && parts == 1) NL_TRY(knn_done->join());
+  if (parts > 1 && (!fused_path || dir_div <= 0)) return NL_ERR_UNSUPPORTED;   // (render_rays_impl plans parts for the fused kernels only)
   if (fused_path) {
     NL_TRY(ensure_ptt(x, f));
     if (!knn_done) NL_TRY(nl_launch_wscale(p.idx, p.d2, f->sp_conf, N, K, f->M, p.wscale, x.st));
@@ -845,12 +853,38 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
     if (prof_arm(&pe0, &pe1)) NL_CHECK_HIP(hipEventRecord(pe0, x.st));
     const bool use_v1 = dbg_switch("NERFLOC_POINT_V1");
     a.logit_amax = reinterpret_cast<unsigned*>(f->views_dev + 249);   // (read by the v1 kernel; the v2 launcher takes it as a parameter)
-    int rc2 = NL_ERR_UNSUPPORTED;
-    if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(a, W, x.c->precision, x.st, mx, nullptr, nullptr, f->views_dev + 248,
-                                                                                                      reinterpret_cast<unsigned*>(f->views_dev + 249),
-                                                                                                      reinterpret_cast<unsigned long long*>(f->views_dev + 250));
-    if (rc2 == NL_ERR_UNSUPPORTED) rc2 = nl_launch_point_fused(a, W, x.c->precision, x.st);   // (e.g. more rows than 32-bit buffer offsets reach)
-    NL_TRY(rc2);
+    // The search in parts (round 6; VERDICT r5 item 1c: "KNN of chunk k + 1 under point_fused2 of chunk k — build it, keep the timeline whichever way it falls").
+    // Only part 0 of the search is issued up front; part p + 1 is released onto the side stream when the neural-point launch of part p starts (rows of different
+    // samples are independent: the kernel runs once per part).  BUILT, MEASURED, OFF (NL_KNN_PARTS = 1): beside the persistent matrix kernel the search finds room
+    // for ONE of its workgroups per CU (88 of the 512 registers per lane are left) and runs at 130 queries / us instead of 700; the front end does end 0.30 / 0.40 ms
+    // earlier with 2 / 4 parts, but the neural-point launches take 0.34 ms longer per 262 144 queries searched beside them (+17-20 %: the search's vector instructions
+    // issue from the same SIMDs) and wait for their part — 7.70 (1 part) / 7.89 (2) / 8.05 ms (4) per config-2 step, same box (profiles/r6_knn_parts_*_timeline.txt).
+    const int64_t rows_pp = parts > 1 ? knn_done->part_rays * a.dir_div : N;
+    for (int pt = 0; pt < parts; ++pt) {
+      const int64_t n0 = pt * rows_pp, n1 = n0 + rows_pp < N ? n0 + rows_pp : N;
+      if (n0 >= N) break;
+      if (parts > 1) {
+        const int64_t m0 = n1, m1 = m0 + rows_pp < N ? m0 + rows_pp : N;
+        if (pt + 1 < parts && m0 < N) {
+          NL_CHECK_HIP(hipEventRecord(f->ev_go[pt + 1], x.st));
+          NL_CHECK_HIP(hipStreamWaitEvent(f->side, f->ev_go[pt + 1], 0));
+          NL_TRY(nl_knn_search(&f->grid, xyz + 3 * m0, m1 - m0, K, p.idx + (size_t)K * m0, p.d2 + (size_t)K * m0, f->side));
+          NL_TRY(nl_launch_wscale(p.idx + (size_t)K * m0, p.d2 + (size_t)K * m0, f->sp_conf, m1 - m0, K, f->M, p.wscale + m0, f->side));
+          NL_CHECK_HIP(hipEventRecord(f->ev_done[pt + 1], f->side));
+        }
+        NL_CHECK_HIP(hipStreamWaitEvent(x.st, f->ev_done[pt], 0));
+      }
+      NlPointFusedArgs b = a;
+      b.xyz = xyz + 3 * n0; b.dir = dir + (size_t)dir_stride * (n0 / a.dir_div); b.idx = p.idx + (size_t)K * n0; b.Q = p.Q + (size_t)128 * n0; b.O = p.O + (size_t)128 * n0;
+      b.N = (int)(n1 - n0);
+      int rc2 = NL_ERR_UNSUPPORTED;
+      if (!use_v1 && nl_point_fused2_supported(W, x.c->precision)) rc2 = nl_launch_point_fused2(b, W, x.c->precision, x.st, mx, nullptr, nullptr, f->views_dev + 248,
+                                                                                                        reinterpret_cast<unsigned*>(f->views_dev + 249),
+                                                                                                        reinterpret_cast<unsigned long long*>(f->views_dev + 250));
+      if (rc2 == NL_ERR_UNSUPPORTED) rc2 = nl_launch_point_fused(b, W, x.c->precision, x.st);   // (e.g. more rows than 32-bit buffer offsets reach)
+      NL_TRY(rc2);
+    }
+    if (knn_done && parts > 1) NL_TRY(knn_done->join());   // (the last part's event was waited for above: this only disarms the guard)
     if (pe1) NL_CHECK_HIP(hipEventRecord(pe1, x.st));
   } else {
     if (!p.X) return NL_ERR_UNSUPPORTED;
@@ -1283,7 +1317,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   const uint64_t inner_bits = (1ull << G_CONV2) | (1ull << G_CONV3) | (1ull << G_T3M) | (1ull << G_T2M) | (1ull << G_T1M);
   if (fuse_inner && merged && !no_inner && nl_unet_inner_supported(S, x.c->precision) && (x.has_bst & inner_bits) == inner_bits) {
     NlUnetInnerArgs ia;
-    ia.c1 = u.c1; ia.x2 = u.x2; ia.R = (int)R; ia.eps = eps;
+    ia.c1 = u.c1; ia.c2 = u.c2; ia.x2 = u.x2; ia.R = (int)R; ia.eps = eps;
     const int gs[5] = {G_CONV2, G_CONV3, G_T3M, G_T2M, G_T1M}, us[5] = {U_CONV2, U_CONV3, U_T3, U_T2, U_T1};
     for (int i = 0; i < 5; ++i) { ia.w[i] = x.pk + x.L.bst[gs[i]]; ia.bias[i] = x.p<float>(x.L.bias[gs[i]]); ia.gl[i] = gl(us[i]); ia.bl[i] = bl(us[i]); }
     NL_TRY(nl_launch_unet_inner(ia, x.c->precision, x.st));
@@ -1948,6 +1982,11 @@ int nl_frame_create(const nl_config* cfg, const nl_frame_desc* d, void* mem, siz
                hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!f->side_ok) (void)hipGetLastError();
+  f->parts_ok = f->side_ok;
+  for (int i = 0; i < nl_frame::kMaxParts; ++i) { f->ev_go[i] = f->ev_done[i] = nullptr; }
+  for (int i = 0; i < nl_frame::kMaxParts && f->parts_ok; ++i)
+    f->parts_ok = hipEventCreateWithFlags(&f->ev_go[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&f->ev_done[i], hipEventDisableTiming) == hipSuccess;
+  if (!f->parts_ok) (void)hipGetLastError();
   *out = f;
   return NL_OK;
 }
@@ -1957,6 +1996,7 @@ int nl_frame_destroy(nl_frame* f) {
   if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
   if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
   if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+  for (int i = 0; i < nl_frame::kMaxParts; ++i) { if (f->ev_go[i]) (void)hipEventDestroy(f->ev_go[i]); if (f->ev_done[i]) (void)hipEventDestroy(f->ev_done[i]); }
   delete f;
   return NL_OK;
 }
@@ -2475,8 +2515,19 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
       NL_CHECK_HIP(hipEventRecord(f->ev_fork, x.st));
       NL_CHECK_HIP(hipStreamWaitEvent(f->side, f->ev_fork, 0));
       knn.arm(x.st, f->side, f->ev_join);
-      NL_TRY(nl_knn_search(&f->grid, rb.xyz, N, 8, rb.pt.idx, rb.pt.d2, f->side));
-      NL_TRY(nl_launch_wscale(rb.pt.idx, rb.pt.d2, f->sp_conf, N, 8, f->M, rb.pt.wscale, f->side));
+#ifndef NL_KNN_PARTS
+#define NL_KNN_PARTS 1   // measured (profiles/r6_knn_parts_{1,2,4}_timeline.txt): 2 / 4 parts shorten the front end by 0.3 / 0.4 ms and lengthen the neural-point span by 0.41 / 0.92 ms — off
+#endif
+#ifndef NL_KNN_PARTS_MIN_ROWS
+#define NL_KNN_PARTS_MIN_ROWS (1 << 18)
+#endif
+      // the search in parts (do_point): part 0 now, the others as the neural-point launches of the parts before them start
+      const int parts = (f->parts_ok && NL_KNN_PARTS > 1 && N >= NL_KNN_PARTS_MIN_ROWS && rc >= NL_KNN_PARTS && !dbg_switch("NERFLOC_NO_KNN_PARTS")) ? NL_KNN_PARTS : 1;
+      static_assert(NL_KNN_PARTS <= nl_frame::kMaxParts, "events per frame");
+      const int64_t part_rays = (rc + parts - 1) / parts, n_first = parts > 1 ? part_rays * S : N;
+      NL_TRY(nl_knn_search(&f->grid, rb.xyz, n_first, 8, rb.pt.idx, rb.pt.d2, f->side));
+      NL_TRY(nl_launch_wscale(rb.pt.idx, rb.pt.d2, f->sp_conf, n_first, 8, f->M, rb.pt.wscale, f->side));
+      if (parts > 1) { NL_CHECK_HIP(hipEventRecord(f->ev_done[0], f->side)); knn.parts = parts; knn.part_rays = part_rays; }
     }
     // the chain kernels recompute the multiview feature rows G (N x W) from out_fc's 64-wide hidden rows: G is only materialised for
     // the stage output or when the separate launches run instead

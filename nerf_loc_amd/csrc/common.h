@@ -128,6 +128,7 @@ struct NlPointFusedArgs {
 // ------------------------------------------------------------------ the five inner ray-U-Net layers as one kernel (unet_inner.hip)
 struct NlUnetInnerArgs {
   const float* c1;            // (R, 64, 64) fp32: conv1's pooled block output
+  float* c2;                  // (R, 32, 128) fp32: conv2's pooled block output — written (it is also parked here while its LDS region holds x0) and read back
   float* x2;                  // (R, 128, 32) fp32: trans_conv1's block output (conv_out's second source)
   const char* w[5];           // weight streams in tgemm_kernel's chunk layout: conv2, conv3, trans_conv3 / 2 / 1 (merged phases)
   const float* bias[5];

@@ -101,6 +101,14 @@ constexpr int DEPTH = UI_DEPTH;   // weight chunks in flight per wave (16 regist
 __host__ __device__ constexpr int nch_of(int id) { return id == 0 ? Lyr<0>::NCH : id == 1 ? Lyr<1>::NCH : id == 2 ? Lyr<2>::NCH : id == 3 ? Lyr<3>::NCH : Lyr<4>::NCH; }
 __host__ __device__ constexpr int ring_phase(int id) { int p = 0; for (int i = 0; i < id; ++i) p += nch_of(i); return p % DEPTH; }
 
+#ifdef UI_TRACE   // debug build (tools/unet_inner_trace.py): cycle counter of one workgroup's wave 0 at [0 start | 1 staged | per layer: 2 + 4 l: product done, + 1: after the first
+// statistics barrier, + 2: after the second, + 3: epilogue done and the layer's last barrier passed]
+__device__ unsigned long long ui_trace[32];
+#define UI_T(i) do { if (pair == UI_TRACE && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) ui_trace[(i)] = t_; } } while (0)
+#else
+#define UI_T(i)
+#endif
+
 template <bool X3>
 __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArgs a, const int npairs) {
   __shared__ uint4 lds_all[LDS_BYTES / 16];
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
   if (pair >= npairs) return;
   const int ray0 = 2 * pair;
   const bool two = ray0 + 1 < a.R;   // the last pair of an odd batch holds one ray: the second one is rendered on zero rows and not stored
+  UI_T(0);
 
   // ---- halo rows of every slab that is written once (x1's are zeroed when it is written: it lies over c2 | c3)
   {
@@ -157,6 +166,7 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
     ui_static_for<DEPTH>([&](auto C) __attribute__((always_inline)) { load_w(std::integral_constant<int, 0>{}, decltype(C)::value, ct0, wreg[decltype(C)::value]); });
   }
   __syncthreads();
+  UI_T(1);
 
   ui_static_for<5>([&](auto LT) __attribute__((always_inline)) {
     constexpr int ID = decltype(LT)::value;
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
       __builtin_amdgcn_sched_barrier(0);
     });
 
+    UI_T(2 + 4 * ID);
     // ---- bias, LayerNorm statistics of each ray's whole slab (two-pass), ELU (+ MaxPool), split, store
     float s1[2] = {0.f, 0.f};
 #pragma unroll
@@ -261,6 +272,7 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
     s1[0] = wave_sum(s1[0]); s1[1] = wave_sum(s1[1]);
     if (lane == 0) { red[wave * 2 + 0] = s1[0]; red[wave * 2 + 1] = s1[1]; }
     __syncthreads();   // (every wave is past its last read of this layer's inputs: the epilogue below may overwrite dead slabs)
+    UI_T(3 + 4 * ID);
     float mean[2] = {0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 8; ++w) { mean[0] += red[w * 2 + 0]; mean[1] += red[w * 2 + 1]; }
@@ -279,6 +291,7 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
     s2[0] = wave_sum(s2[0]); s2[1] = wave_sum(s2[1]);
     if (lane == 0) { red[16 + wave * 2 + 0] = s2[0]; red[16 + wave * 2 + 1] = s2[1]; }
     __syncthreads();
+    UI_T(4 + 4 * ID);
     float var[2] = {0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 8; ++w) { var[0] += red[16 + w * 2 + 0]; var[1] += red[16 + w * 2 + 1]; }
@@ -331,10 +344,17 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
       }
     }
     if constexpr (ID + 1 < 5) __syncthreads();   // the next layer's operands are in place; `red` may be written again
+    UI_T(5 + 4 * ID);
   });
 }
 
 }  // namespace
+
+#ifdef UI_TRACE
+extern "C" __attribute__((visibility("default"))) int nl_debug_unet_inner_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ui_trace), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool nl_unet_inner_supported(int S, int precision) { return S == 128 && (precision == NL_PREC_BF16X3 || precision == NL_PREC_BF16); }
 

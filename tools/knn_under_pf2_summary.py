@@ -1,5 +1,10 @@
 """Summary of tools/knn_under_pf2.py's kernel trace: how much search work gets done beside each kernel of the step, and what it costs that kernel.
-python tools/knn_under_pf2_summary.py results.db [out.txt]"""
+python tools/knn_under_pf2_summary.py results.db [out.txt]
+
+CAVEAT (found the hard way, round 6): the "progress" column spreads a search's work evenly over its duration.  A search that starts beside a gather kernel (fast) and
+ends under the neural-point kernel (5 x slower: one of its workgroups fits a CU there) has most of its progress credited to the wrong window, so the column OVERSTATES
+what runs beside the matrix kernel by ~4 x.  The in-situ measurement is profiles/r6_knn_parts_*_timeline.txt (the search released in parts under the neural-point
+launches: 262 144 queries take 1.97 ms there and cost the kernel +0.34 ms).  The slow-down columns (kernel alone | with searches beside it) are sound."""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
