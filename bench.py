@@ -478,7 +478,7 @@ def hbm_traffic(config: str, precision: str):
     by tools/hbm_traffic.py; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  A constant read from a committed
     file, NOT measured in this run: it carries the fingerprint of the kernel sources it was measured on and says whether that is
     the build being benchmarked.  None when no committed measurement matches the workload."""
-    for name in ("r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+    for name in ("r6_hbm_traffic.json", "r5_hbm_traffic.json", "r4_hbm_traffic.json", "r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if config != "c2" or not os.path.exists(path):
             continue
