@@ -183,14 +183,14 @@ def main():
     loop = [None]
     last_out = [None]
 
-    def render_local():
+    def render_local(out_buffers=None):
         zz = B["z"]
         if hier:
             zz, depth_coarse, _ = rnd.hierarchical_depths(B["pix"], B["Kq"], B["pose_q"], B["z"], B["u"], near=cfg.near, far=cfg.far)
         # --graph: batches of <= 1024 rays replay as a HIP graph from the second step on (HipRenderer.GRAPH_MAX_RAYS).  Opt-in: measured, the replay is no faster
         # than the eager launch chain (config 1: 0.397 ms eager, 0.423 ms with the graph's static-buffer copies; a 512-ray shard of config 2: 1.400 / 1.412 ms)
         out = rnd.render_rays(B["o"], B["d"], qc, z_vals=zz, white_bkgd=cfg.white_bkgd, early_term_eps=et_eps, side_stream=not args.no_side_stream,
-                              graph=args.graph)
+                              graph=args.graph, out_buffers=out_buffers)
         if hier:
             out["depth_coarse"] = depth_coarse
         return out
@@ -199,7 +199,9 @@ def main():
         if gather:
             if loop[0] is None or loop[0].counts is not B["counts"]:
                 loop[0] = ShardedRenderLoop(dist, B["counts"])
-            out = loop[0].step(render_local)
+            # (plain configs: the kernels write into ONE buffer per rank and that buffer is gathered — no pack step; a hierarchical config carries `depth_coarse`
+            # from outside the render call and takes the generic packed-dict path)
+            out = loop[0].step(render_local) if (hier or args.graph) else loop[0].step_packed(rnd, B["R_local"], render_local)
             last_out[0] = loop[0].last_local
             return out
         out = render_local()

@@ -209,6 +209,7 @@ class TrainGrads:
 
 class HipRenderer:
     """One renderer per (device, W, C, S, precision).  Not thread-safe (like the reference module)."""
+    supports_out_buffers = True   # render_rays(out_buffers=...): sharding.py renders into one buffer per rank and gathers that buffer
 
     def __init__(self, W: int, C: int, S: int, precision: str = "bf16x3", device: str = "cuda:0", workspace_bytes: Optional[int] = None):
         if not torch.cuda.is_available():
@@ -426,8 +427,11 @@ class HipRenderer:
 
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
                     intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0,
-                    side_stream: bool = True, want_knn: bool = False, graph: bool = False, precision_guard: bool = False) -> Dict[str, torch.Tensor]:
-        """precision_guard=True (nl_render_opts.flags = NL_RENDER_PRECISION_GUARD, ABI 7): the LIBRARY checks the frame's conditioning indicator after the batch
+                    side_stream: bool = True, want_knn: bool = False, graph: bool = False, precision_guard: bool = False,
+                    out_buffers: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """out_buffers: preallocated, contiguous destination tensors for the per-ray outputs (rgb (R,3), depth (R), weights (R,S), mask (R) uint8, depth_uncertainty (R),
+        feat (R,C); fp32 but for the mask) — the kernels write straight into them (sharding.py hands in views of ONE buffer per rank, so the all-gather needs no pack step).
+        precision_guard=True (nl_render_opts.flags = NL_RENDER_PRECISION_GUARD, ABI 7): the LIBRARY checks the frame's conditioning indicator after the batch
         (max |attention logit|; one 4-byte copy + a stream synchronisation) and renders the batch again in the next more exact mode (f16mx -> bf16x3 -> fp32) while
         it lies beyond the validated range of the mode the outputs were produced in; the frame then stays in that mode for later guarded calls
         (`diagnostics()['guard_precision']`).  Off by default: the synchronisation keeps the host from running ahead of the device.
@@ -448,7 +452,7 @@ class HipRenderer:
         per_ray = qc_t.dim() == 2
         if per_ray and tuple(qc_t.shape) != (R, 3):
             raise ValueError(f"per-ray query centres must have shape ({R}, 3), got {tuple(qc_t.shape)}")
-        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream and not precision_guard \
+        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream and not precision_guard and out_buffers is None \
                 and not getattr(self, "guard_bytes", 0) and self._ws_request is None:
             g = self._graphed_render(R, white_bkgd, want_feat, z is not None)
             if g is not None:
@@ -457,12 +461,23 @@ class HipRenderer:
         if not per_ray and qc_t.is_cuda:   # one centre that lives on the device: R identical rows instead of a device-to-host copy (= a synchronisation
             qc_t, per_ray = qc_t.reshape(1, 3).expand(R, 3), True   # point per call: 21 of them in a render_image loop)
         qc = qc_t.to(dev).contiguous() if per_ray else qc_t.cpu().contiguous()
-        out = {
-            "rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
-            "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev),
-        }
-        if want_feat:
-            out["feat"] = torch.empty(R, self.C, device=dev)
+        if out_buffers is not None:
+            want = {"rgb": (R, 3), "depth": (R,), "weights": (R, S), "mask": (R,), "depth_uncertainty": (R,)}
+            if want_feat:
+                want["feat"] = (R, self.C)
+            out = {}
+            for k, shp in want.items():
+                t = out_buffers[k]
+                if tuple(t.shape) != shp or not t.is_contiguous() or t.device != dev or t.dtype != (torch.uint8 if k == "mask" else torch.float32):
+                    raise ValueError(f"out_buffers['{k}']: expected a contiguous {'uint8' if k == 'mask' else 'float32'} tensor of shape {shp} on {dev}")
+                out[k] = t
+        else:
+            out = {
+                "rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": torch.empty(R, S, device=dev),
+                "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev),
+            }
+            if want_feat:
+                out["feat"] = torch.empty(R, self.C, device=dev)
         if want_knn and not intermediates:   # the neighbours alone (the gradient path hands them to nl_render_rays_backward)
             out.update({"knn_idx": torch.empty(R * S, 8, dtype=torch.int32, device=dev), "knn_d2": torch.empty(R * S, 8, device=dev)})
         if intermediates:

@@ -98,6 +98,65 @@ def gather_ray_outputs(out: Dict[str, torch.Tensor], dist, counts=None) -> Dict[
 # A ray's result does not depend on the batch it is rendered in (tests: bit-identical for any chunking), so the gathered
 # dict equals the single-rank render bit for bit.
 
+# ---- the outputs of a rank as ONE buffer the kernels write into (no pack step, no per-key copy on a single rank) ----------------------------------------
+class PackedOutputs:
+    """Per-ray outputs of up to `rows` rays as views of one byte buffer: [rgb (rows,3) f32 | depth | weights (rows,S) | depth_uncertainty | feat (rows,C) | mask (rows) u8],
+    every block 256-byte aligned.  `views(n)` are the contiguous (n, ...) tensors `HipRenderer.render_rays(out_buffers=...)` writes into (n <= rows: an uneven shard
+    uses the head of every block); the whole buffer is what the all-gather moves."""
+
+    def __init__(self, rows: int, S: int, C: int, device, want_feat: bool = True):
+        self.rows, self.layout, off = int(rows), [], 0
+        spec = [("rgb", 3, torch.float32), ("depth", 0, torch.float32), ("weights", S, torch.float32), ("depth_uncertainty", 0, torch.float32)]
+        if want_feat:
+            spec.append(("feat", C, torch.float32))
+        spec.append(("mask", 0, torch.uint8))
+        for k, w, dt in spec:
+            nbytes = self.rows * max(w, 1) * (4 if dt == torch.float32 else 1)
+            self.layout.append((k, w, dt, off, nbytes))
+            off += (nbytes + 255) // 256 * 256
+        self.nbytes = max(off, 256)
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+
+    @staticmethod
+    def _view(buf, off, k, w, dt, rows_alloc, n):
+        t = buf[off: off + rows_alloc * max(w, 1) * (4 if dt == torch.float32 else 1)].view(dt)
+        t = t.view(rows_alloc, w) if w else t
+        return t[:n]
+
+    def views(self, n: int) -> Dict[str, torch.Tensor]:
+        return {k: self._view(self.buf, off, k, w, dt, self.rows, n) for k, w, dt, off, _ in self.layout}
+
+
+class PendingPackedGather:
+    """An all-gather of PackedOutputs buffers in flight; `result()` -> the (sum of counts, ...) output dict in rank order (views of the gathered buffer on one rank,
+    one concatenation per key otherwise)."""
+
+    def __init__(self, work, full, packed: PackedOutputs, counts):
+        self.work, self.full, self.packed, self.counts = work, full, packed, counts
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        p, B = self.packed, self.packed.nbytes
+        out = {}
+        for k, w, dt, off, _ in p.layout:
+            parts = [PackedOutputs._view(self.full[r * B:(r + 1) * B], off, k, w, dt, p.rows, c) for r, c in enumerate(self.counts)]
+            t = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+            out[k] = t.view(torch.bool) if k == "mask" else t
+        return out
+
+
+def gather_packed_async(packed: PackedOutputs, dist, counts) -> PendingPackedGather:
+    world = dist.get_world_size()
+    full = torch.empty(world * packed.nbytes, dtype=torch.uint8, device=packed.buf.device)
+    if packed.buf.is_cuda and dist.get_backend() == "nccl":
+        work = dist.all_gather_into_tensor(full, packed.buf, async_op=True)
+    else:
+        work = dist.all_gather(list(full.chunk(world, 0)), packed.buf, async_op=True)
+    return PendingPackedGather(work, full, packed, list(counts))
+
+
 _PER_RAY_KEYS = ("rays_o", "rays_d", "pixel_coordinates")
 
 
@@ -126,12 +185,25 @@ def render_rays_sharded(renderer, rays_o, rays_d, query_center, dist, z_vals=Non
     qc = query_center
     if hasattr(qc, "dim") and qc.dim() == 2 and qc.shape[0] == R:
         qc = qc[lo:hi]
-    out = renderer.render_rays(rays_o[lo:hi], rays_d[lo:hi], qc, z_vals=None if z_vals is None else z_vals[lo:hi], **render_kw)
+    counts = shard_counts(R, world)
+    zl = None if z_vals is None else z_vals[lo:hi]
+    if _packable(renderer, extra, render_kw):
+        # the kernels write into ONE buffer per rank, and that buffer is what the collective moves: no pack step, and on one rank no copy at all
+        packed = PackedOutputs(max(counts), renderer.S, renderer.C, renderer.device, want_feat=render_kw.get("want_feat", True))
+        renderer.render_rays(rays_o[lo:hi], rays_d[lo:hi], qc, z_vals=zl, out_buffers=packed.views(hi - lo), **render_kw)
+        pend = gather_packed_async(packed, dist, counts)
+        return pend if async_op else pend.result()
+    out = renderer.render_rays(rays_o[lo:hi], rays_d[lo:hi], qc, z_vals=zl, **render_kw)
     if extra:
         out.update(extra)
-    counts = shard_counts(R, world)
     pend = gather_ray_outputs_async({k: v for k, v in out.items() if k in _ORDER}, dist, None if len(set(counts)) == 1 else counts)
     return pend if async_op else pend.result()
+
+
+def _packable(renderer, extra, render_kw) -> bool:
+    """The packed path needs a renderer that takes `out_buffers` (HipRenderer.supports_out_buffers) and a call whose outputs are exactly the per-ray set."""
+    return bool(getattr(renderer, "supports_out_buffers", False)) and not extra and not render_kw.get("intermediates") and not render_kw.get("want_knn") \
+        and not render_kw.get("graph")
 
 
 class ShardedRenderLoop:
@@ -149,6 +221,19 @@ class ShardedRenderLoop:
         self.last_local = out
         prev = self._pending
         self._pending = gather_ray_outputs_async({k: v for k, v in out.items() if k in _ORDER}, self.dist, self.counts)
+        return None if prev is None else prev.result()
+
+    def step_packed(self, renderer, n_local: int, render_into, want_feat: bool = True):
+        """The same step without the pack: `render_into(out_buffers)` renders this rank's n_local rays into the views of ONE buffer (HipRenderer.render_rays(out_buffers=...)),
+        and that buffer is what the collective moves.  A fresh buffer per step (the previous one is still being gathered)."""
+        world = self.dist.get_world_size()
+        counts = self.counts if self.counts is not None else [n_local] * world
+        packed = PackedOutputs(max(counts), renderer.S, renderer.C, renderer.device, want_feat=want_feat)
+        views = packed.views(n_local)
+        render_into(views)
+        self.last_local = {k: (v.view(torch.bool) if k == "mask" else v) for k, v in views.items()}
+        prev = self._pending
+        self._pending = gather_packed_async(packed, self.dist, counts)
         return None if prev is None else prev.result()
 
     def drain(self):

@@ -67,6 +67,12 @@ def _rank(rank, world, port, two_devices, q):
             a = loop.step(lambda: r.render_rays(o2[lo:hi], d2[lo:hi], qc, z_vals=z[lo:hi], white_bkgd=cfg.white_bkgd))
             b = loop.drain()
             ok_loop = first is None and all(torch.equal(a[k], single[k]) and torch.equal(b[k], single[k].flip(0)) for k in KEYS)
+            # ... and its packed form (what bench.py --gpus N times for the plain configs): the kernels write into the buffer that is gathered
+            lp = ShardedRenderLoop(dist, None if len(set(cnt)) == 1 else cnt)
+            p1 = lp.step_packed(r, hi - lo, lambda ob: r.render_rays(o[lo:hi], d[lo:hi], qc, z_vals=z[lo:hi], white_bkgd=cfg.white_bkgd, out_buffers=ob))
+            p2 = lp.step_packed(r, hi - lo, lambda ob: r.render_rays(o2[lo:hi], d2[lo:hi], qc, z_vals=z[lo:hi], white_bkgd=cfg.white_bkgd, out_buffers=ob))
+            p3 = lp.drain()
+            ok_loop = ok_loop and p1 is None and all(torch.equal(p2[k], single[k]) and torch.equal(p3[k], single[k].flip(0)) for k in KEYS)
             res[f"{name}/{R}"] = (bool(ok), bool(ok_loop), int(hi - lo))
             del r
         dist.barrier()

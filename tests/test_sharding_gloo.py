@@ -115,6 +115,21 @@ class _FakeRenderer:
                 "mask": o[:, 0] > d[:, 0], "depth_uncertainty": o.sum(1), "feat": torch.cat([o, d], 1), "knn_idx": torch.zeros(o.shape[0], 8)}
 
 
+class _FakePackedRenderer(_FakeRenderer):
+    """... and one that writes into preallocated buffers like HipRenderer.render_rays(out_buffers=...) (the packed gather path)"""
+    supports_out_buffers = True
+    S, C, device = 2, 6, torch.device("cpu")
+
+    def render_rays(self, o, d, qc, z_vals=None, white_bkgd=False, out_buffers=None, want_feat=True):
+        out = _FakeRenderer.render_rays(self, o, d, qc, z_vals, white_bkgd)
+        out.pop("knn_idx")
+        if out_buffers is None:
+            return out
+        for k, v in out.items():
+            out_buffers[k].copy_(v.to(torch.uint8) if k == "mask" else v)
+        return {k: (v.view(torch.bool) if k == "mask" else v) for k, v in out_buffers.items()}
+
+
 def _product_worker(rank, world, port, q):
     """render_rays_sharded / ShardedRenderLoop / shard_rays (the product-side sharded step) reassemble the single-rank result exactly;
     a rank with ZERO rays (R < world) takes part in the collective like any other."""
@@ -142,6 +157,17 @@ def _product_worker(rank, world, port, q):
         last = loop.drain()
         want1, want2 = r.render_rays(o, d, qc), r.render_rays(d, o, qc)
         ok = ok and first is None and all(torch.equal(second[k], want1[k]) and torch.equal(last[k], want2[k]) for k in second) and loop.drain() is None
+        # the packed path: the renderer writes into ONE buffer per rank, the buffer is gathered (even, uneven and empty shards)
+        rp = _FakePackedRenderer()
+        full_p = rp.render_rays(o, d, qc, z_vals=z)
+        got_p = render_rays_sharded(rp, o, d, qc, dist, z_vals=z)
+        ok = ok and set(got_p) == set(full_p) and all(got_p[k].dtype == full_p[k].dtype and torch.equal(got_p[k], full_p[k]) for k in full_p)
+        lp = ShardedRenderLoop(dist, None if len(set(cnt)) == 1 else cnt)
+        f1 = lp.step_packed(rp, hi - lo, lambda ob: rp.render_rays(o[lo:hi], d[lo:hi], qc, z_vals=z[lo:hi], out_buffers=ob))
+        f2 = lp.step_packed(rp, hi - lo, lambda ob: rp.render_rays(d[lo:hi], o[lo:hi], qc, z_vals=z[lo:hi], out_buffers=ob))
+        f3 = lp.drain()
+        w1, w2 = rp.render_rays(o, d, qc, z_vals=z), rp.render_rays(d, o, qc, z_vals=z)
+        ok = ok and f1 is None and all(torch.equal(f2[k], w1[k]) and torch.equal(f3[k], w2[k]) for k in w1)
         rays = {"rays_o": o, "rays_d": d, "pixel_coordinates": torch.rand(R, 2, generator=g), "K": torch.eye(3), "pose": torch.eye(4), "H": 3, "W": 3}
         sub = shard_rays(rays, rank, world)
         ok = ok and sub["rays_o"].shape[0] == hi - lo and torch.equal(sub["pixel_coordinates"], rays["pixel_coordinates"][lo:hi]) and sub["K"] is rays["K"] \
