@@ -33,6 +33,7 @@ int nl_launch_ln_agg(const float* FC, const float* G, int64_t N, int W, const fl
 int nl_launch_ln_slab_elu(const float* in, int64_t R, int L, int Cc, const float* gamma, const float* beta, float eps, float* out, float* pooled, hipStream_t st);
 bool nl_unet_inner_supported(int S, int precision);
 int nl_launch_unet_inner(const NlUnetInnerArgs& a, int precision, hipStream_t st);
+size_t nl_tgemm_mx_image_bytes(int Kpad);
 int nl_launch_sample_points(const float* rays_o, const float* rays_d, int64_t R, int S, float near_, float far_, const float* z_in, float* z_out, float* xyz, hipStream_t st);
 int nl_launch_sigma(const float* geo, int64_t N, int W, const float* w, const float* b, float* sigma, hipStream_t st);
 int nl_launch_blend(const float* hA, const float* h1, const float* rgbv, int64_t N, int V, const float* w2, const float* b2, const float* w4, const float* b4, float* rgb_s, hipStream_t st,
@@ -201,6 +202,7 @@ struct Layout {
   size_t b32[G_COUNT], bhi[G_COUNT], blo[G_COUNT], bst[G_COUNT], bsh[G_COUNT], bias[G_COUNT];   // bsh: the weight stream in fp16 hi / lo (split-FP16 arithmetic)
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
   size_t pt_stream, pt_stream2, pt_stream2_mx, pt_stream2_f16, pt_bwd_stream, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
+  size_t mx_convout;   // NL_PREC_F16MX (round 6): fp6 images + block scales of G_CONVOUTF for tgemm_mx_kernel (W = 256)
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
   size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
   int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
@@ -322,6 +324,7 @@ Layout make_layout(const nl_config* c) {
   L.pt_mx_sc = take(4 * 64);
   L.mvf_pack = take(nl_mv_front_pack_bytes());                                          // out_fc.0 as register-resident A fragments of mv_front_kernel (C = 192)                                                            // their per-chunk scale bytes while packing
   L.zeros = take(4096);
+  L.mx_convout = take(W == 256 ? nl_tgemm_mx_image_bytes(L.g[G_CONVOUTF].Kpad) : 0);
   L.total = off;
   return L;
 }
@@ -363,6 +366,51 @@ __global__ void pack_block_kernel(const float* __restrict__ src, int off, int ld
     bsh[e] = __builtin_bit_cast(unsigned short, g);
     bsh[e + (size_t)2 * nrts * 512] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)g));
   }
+}
+
+// MX-FP6 images of a 256-column layer for tgemm_mx_kernel (tgemm.hip): one thread = one MX block = (slab of 64 k, row tile, lane, image).  The 32 weights of output
+// column 32 rt + (lane & 31) whose k-slots belong to half lane >> 5 of the slab, in the natural position order P = 8 s + t <-> k = 64 slab + 16 s + 8 hh + t (what the
+// kernel's activation images have): image 0 = e2m3(f16(w)) (meets the activations' residual image), image 1 = e2m3(w - f16(w)) (meets their hi image).  Block scale
+// 2^(floor(log2 max) - 2): the largest magnitude lands in [4, 8) (e2m3 saturates at 7.5).  Per slab: [rt][image][lane] dwords 0-3 (16 KB) | [rt][image][lane]
+// {dword 4, dword 5, E8M0 scale, 0} (16 KB).  K rows past Kpad are zero.
+__device__ __forceinline__ unsigned pk_e2m3(float a) {   // a >= 0, already divided by the block scale; round to nearest even, saturating
+  if (!(a < 7.5f)) return 31u;
+  if (a < 1.f) return (unsigned)rintf(a * 8.f);
+  const int e = a < 2.f ? 0 : a < 4.f ? 1 : 2;
+  unsigned m = (unsigned)rintf(ldexpf(a, 3 - e));
+  unsigned c = ((unsigned)(e + 1) << 3) + (m - 8u);
+  return c > 31u ? 31u : c;
+}
+__global__ void pack_tgemm_mx6_kernel(const float* __restrict__ b32, int Kpad, int Npad, int N, int nslab, unsigned char* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nslab * 8 * 64 * 2) return;
+  const int im = e & 1, lane = (e >> 1) & 63, rt = (e >> 7) & 7, sl = e >> 10;
+  const int hh = lane >> 5, n = 32 * rt + (lane & 31);
+  float v[32], mx = 0.f;
+  for (int P = 0; P < 32; ++P) {
+    const int k = 64 * sl + 16 * (P >> 3) + 8 * hh + (P & 7);
+    const float w = (k < Kpad && n < N) ? b32[(size_t)k * Npad + n] : 0.f;
+    const float h = (float)(_Float16)w;
+    v[P] = im == 0 ? h : w - h;
+    mx = fmaxf(mx, fabsf(v[P]));
+  }
+  int E = -60;
+  if (mx > 0.f) { int ex; (void)frexpf(mx, &ex); E = ex - 1; }   // mx = 1.xxx 2^E
+  int sb = E - 2 + 127;
+  sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+  const float inv = ldexpf(1.f, 127 - sb);
+  unsigned d[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  for (int P = 0; P < 32; ++P) {
+    const unsigned c = pk_e2m3(fabsf(v[P]) * inv) | (v[P] < 0.f ? 32u : 0u);
+    const int b = 6 * P;
+    d[b >> 5] |= c << (b & 31);
+    if ((b & 31) > 26) d[(b >> 5) + 1] |= c >> (32 - (b & 31));
+  }
+  unsigned char* base = out + (size_t)sl * (16384 + 16384);
+  unsigned* a = reinterpret_cast<unsigned*>(base + ((size_t)(rt * 2 + im) * 64 + lane) * 16);
+  a[0] = d[0]; a[1] = d[1]; a[2] = d[2]; a[3] = d[3];
+  unsigned* b2 = reinterpret_cast<unsigned*>(base + 16384 + ((size_t)(rt * 2 + im) * 64 + lane) * 16);
+  b2[0] = d[4]; b2[1] = d[5]; b2[2] = (unsigned)sb; b2[3] = 0u;   // (the matrix instruction reads byte 0 of the scale register)
 }
 
 // [32][8] = rgb(3) | vis(1) | angle(4) columns of rgb_blending_mlp.0.weight (32, W+F+5), then its bias[32]
@@ -657,6 +705,10 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   }
   if (prec == NL_PREC_F32) a.B = x.pk + x.L.b32[g];
   else if (prec != NL_PREC_F16X3_INTERNAL) { a.B = x.pk + x.L.bhi[g]; a.Blo = x.pk + x.L.blo[g]; a.Bst = ((x.has_bst >> g) & 1) ? x.pk + x.L.bst[g] : nullptr; }
+  // NL_PREC_F16MX: conv_out multiplies as fp16 hi.hi + two MX-FP6 cross terms too (tgemm_mx_kernel) when its images exist
+  if (x.mx && g == G_CONVOUTF && prec == NL_PREC_BF16X3 && x.c->W == 256 && ((x.has_bsh >> g) & 1) && !dbg_switch("NERFLOC_NO_TGEMM_MX")) {
+    a.Bsh_mx = x.pk + x.L.bsh[g]; a.Bmx = x.pk + x.L.mx_convout;
+  }
   a.zeros = x.p<float>(x.L.zeros);
   a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
   a.C = C; a.ldc = ldc; a.act = act;
@@ -1847,6 +1899,12 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   P.convT_merged(G_T2M, un[16], un[17], 256, 64);
   P.convT_merged(G_T1M, un[20], un[21], 128, 32);
   { const int wo[2] = {W, 32}; P.conv3(G_CONVOUT, un[24], un[25], W + 32, wo, 2); P.conv3(G_CONVOUTF, un[24], un[25], W + 32, wo, 2, 1u); }
+  if (W == 256) {   // NL_PREC_F16MX: conv_out's fp6 images for tgemm_mx_kernel, from the layer's packed fp32 matrix (same K order as its streams)
+    const GemmDim& d = L.g[G_CONVOUTF];
+    const int nslab = (d.Kpad / 32 + 1) / 2;
+    hipLaunchKernelGGL(pack_tgemm_mx6_kernel, dim3((unsigned)nl_cdiv((int64_t)nslab * 1024, 256)), dim3(256), 0, st, (const float*)((char*)packed + L.b32[G_CONVOUTF]), d.Kpad, d.Npad,
+                       d.N, nslab, (unsigned char*)packed + L.mx_convout);
+  }
   P.conv3_dgrad(G_UB_OUTA, un[24], W, W + 32, 0, W);
   P.conv3_dgrad(G_UB_OUTB, un[24], W, W + 32, W, 32);
   P.convT_dgrad(G_UB_T1, un[20], 128, 32);

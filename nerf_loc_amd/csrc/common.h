@@ -165,6 +165,8 @@ struct NlGemmArgs {
   const void* B;        // packed weights: f32 [Kpad][Npad]  or bf16 hi/lo [Npad][Kpad] (see pack.hip)
   const void* Blo;      // bf16x3 only
   const void* Bst;      // bf16 hi/lo weight stream in A-fragment chunk order (tgemm.hip), or null
+  const void* Bsh_mx;   // NL_PREC_F16MX (round 6, tgemm_mx_kernel): the layer's fp16 hi/lo stream (its hi fragments are read) ...
+  const void* Bmx;      // ... and its fp6 images + block scales (pack_tgemm_mx6_kernel), or null
   const float* zeros;   // >= 512 zero floats (source row of conv halos / rows beyond M in tgemm.hip)
   int kstart[NL_GEMM_MAX_SEG];   // first k of each segment in the padded K space; INT_MAX for unused slots
   const float* bias;    // [N] or null

@@ -16,6 +16,8 @@
 
 typedef __bf16 tg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -461,6 +463,314 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
 
 
 // ====================================================================================================================
+// conv_out in the f16mx arithmetic (round 6; NL_PREC_F16MX, W = 256, S = 128): the product of `tgemm_kernel<8, 4, true, NL_EPI_LNSLAB>` as fp16 hi.hi + two MX-FP6
+// cross terms — per K = 64 slab and 32 x 32 tile 4 x v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4 (48 matrix passes) instead of 12 bf16
+// instructions (96), the arithmetic the fused neural-point kernel has had since round 5.
+//   * B operand (activations): built PER SLAB IN REGISTERS from whatever the producer left — the chain kernel's split-bf16 fragments (hi + lo = the value to 16 bits) or
+//     fp32 rows: 32 values per lane -> f16 pairs + running maximum, exact residuals, block scale 2^(floor(log2 max) - 2) from the values themselves, ONE
+//     v_cvt_scalef32_pk32_fp6_f16 for the hi image and ONE v_cvt_scalef32_2xpk16_fp6_f32 for the residual image (on the hi image's scale x 2^-11).  No producer changes
+//     its output format; the conversion (~170 vector instructions per slab) is paid once per 32 rows x 256 columns = 48 matrix instructions.
+//   * A operand (weights): the layer's fp16 stream (hi fragments: the `bsh` image nl_pack_weights writes anyway) + fp6 images of f16(w) and w - f16(w) with one E8M0
+//     scale per (output row, half-wave, slab) (abi.hip: pack_tgemm_mx6_kernel), both in the natural position order P = 8 s + t (k-step s, element t) that the
+//     activation images have.  64 KB per slab through a two-slot LDS ring by LDS-DMA (no staging registers: 128 accumulators + the next slab's 32 raw activation
+//     words + the converted operand leave no room for them at two waves per SIMD).
+//   * 130 KB of LDS = ONE workgroup per CU, so the workgroup is eight waves = 256 rows = two rays: the same two waves per SIMD as the two four-wave workgroups of
+//     the bf16x3 kernel, every weight byte staged once per 256 rows instead of once per 128.
+// Epilogue: LayerNorm over each ray's (128 x 256) slab + ELU + the density head, as tgemm_kernel's NL_EPI_LNSLAB.
+typedef int tg_i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int tg_u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned int tg_u32x16 __attribute__((ext_vector_type(16)));
+
+// f16 pair of two values + the running maximum of their magnitudes
+__device__ __forceinline__ unsigned tg_hi2_f16_amax(float v0, float v1, float& m) {
+  unsigned hi;
+  asm("v_max3_f32 %1, |%2|, |%3|, %1\n\tv_cvt_pk_f16_f32 %0, %2, %3" : "=&v"(hi), "+v"(m) : "v"(v0), "v"(v1));
+  return hi;
+}
+// residuals of a pair as floats: v - float(hi half) (exact)
+__device__ __forceinline__ void tg_lo2_f32(float v0, float v1, unsigned hi, float& l0, float& l1) {
+  asm("v_fma_mix_f32 %0, %4, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %4, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l0), "=&v"(l1) : "v"(v0), "v"(v1), "v"(hi));
+}
+// (asm with early-clobber results: hipcc 7.2 lets the builtins' 6-register result overlap the scale operand — point_fused2.hip)
+__device__ __forceinline__ tg_u32x6 tg_cvt_pk32_fp6_f16(tg_u32x16 h, float sc) {
+  tg_u32x6 r;
+  asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(r) : "v"(h), "v"(sc));
+  return r;
+}
+__device__ __forceinline__ tg_u32x6 tg_cvt_2xpk16_fp6_f32(tg_f32x16 a, tg_f32x16 b, float sc) {
+  tg_u32x6 r;
+  asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(sc));
+  return r;
+}
+
+constexpr int TGMX_NRT = 8, TGMX_NW = 8;
+constexpr int TGMX_F16B = 4 * TGMX_NRT * 1024;                 // f16 hi fragments of a slab: [chunk of the slab][k-step][row tile][lane] x 16 B
+constexpr int TGMX_IMA = 2 * TGMX_NRT * 1024, TGMX_IMB = TGMX_IMA;   // fp6 images of [row tile][w_hi6, w_lo6][lane]: dwords 0-3 | {dword 4, dword 5, E8M0 scale byte, 0} — 16-byte reads only
+                                                                     // (every LDS read of the loop has ONE native vector type: a scalar-typed read made the waitcnt pass drain the DMA in front of it)
+constexpr int TGMX_IMG = TGMX_IMA + TGMX_IMB;                  // bytes per slab in the image stream (32 KB)
+constexpr int TGMX_SLOT = TGMX_F16B + TGMX_IMG;                // 64 KB: eight 1-KB pieces per wave
+constexpr int TGMX_PIECES = TGMX_SLOT / 1024;
+
+__global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmArgs a, const char* __restrict__ p_bsh, const char* __restrict__ p_bmx, float* __restrict__ p_c,
+                                                                    const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
+  constexpr int NRT = TGMX_NRT, NW = TGMX_NW;
+  __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1): MODE.FP16_OVFL — f32 -> f16 / fp6 conversions saturate instead of producing inf / NaN
+  __shared__ uint4 lds_all[2 * TGMX_SLOT / 16 + NRT * 8 * 2 + 8];
+  float* sbias = reinterpret_cast<float*>(lds_all + 2 * TGMX_SLOT / 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31;
+  const int tile = blockIdx.x * NW + wave;
+  const int m = tile * 32 + j;
+  const bool mok = m < a.M;
+  const int q = m / a.So, t = m - q * a.So;
+  const int NC = a.Kpad >> 5, NS = (NC + 1) >> 1;
+
+  for (int i = tid; i < NRT * 32; i += 64 * NW) {
+    sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
+    sbias[NRT * 32 + 32 + i] = (a.ep_sig_w && i < a.N) ? a.ep_sig_w[i] : 0.f;   // density-head weights (after the 32 floats of `red`)
+  }
+
+  // ---- weights of slab s -> LDS slot: 1-KB pieces by BUFFER LDS-DMA (counted like any load: the compiler's waits stay exact; a flat global_load_lds turns every
+  // later wait into vmcnt(0)), each lane 16 bytes, pieces dealt round-robin to the waves.  The slot is a COMPILE-TIME constant here and in the reads below: with a
+  // run-time slot the waitcnt pass cannot tell the DMA's destination from the slot being read and drains vmcnt(0) in front of every LDS read.
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p_bsh, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmx = __builtin_amdgcn_make_buffer_rsrc((void*)p_bmx, 0, 0x7fffffff, 0x00020000);
+  const unsigned lane16 = lane * 16;
+  auto stage = [&](int sl, auto SLOTc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOTc)::value;
+    const int cA = 2 * sl, cB = (2 * sl + 1 < NC) ? 2 * sl + 1 : NC - 1;   // (an odd chunk count: the last slab's second half re-reads the last chunk — its activations are zero)
+    const unsigned oA = (unsigned)cA * (4 * NRT * 1024), oB = (unsigned)cB * (4 * NRT * 1024);   // the hi part (first 2 NRT KB) of each chunk of the fp16 stream
+    const unsigned oI = (unsigned)sl * TGMX_IMG;
+    tg_static_for<(TGMX_PIECES + NW - 1) / NW>([&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      const int pp = wave + NW * i;   // (wave-uniform; TGMX_PIECES = 8 NW: no tail)
+      static_assert(TGMX_PIECES % TGMX_NW == 0, "pieces per wave");
+      {
+        auto* dst = (__attribute__((address_space(3))) void*)(lds_all + (slot * TGMX_SLOT) / 16 + pp * 64);
+        if (pp < 4 * NRT) {
+          unsigned so = pp < 2 * NRT ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
+          asm volatile("" : "+s"(so));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, dst, 16, lane16, so, 0, 0);
+        } else {
+          unsigned so = oI + (pp - 4 * NRT) * 1024;
+          asm volatile("" : "+s"(so));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rmx, dst, 16, lane16, so, 0, 0);
+        }
+      }
+    });
+  };
+  // ---- activations: the 2 k-steps x 8 values of this lane's row for chunk c, as four 16-byte words (tgemm_kernel's act_ptr / act_off)
+  auto act_ptr = [&](int c, int& fr) __attribute__((always_inline)) -> const float* {
+    fr = 0;
+    if (c >= NC) return p_zeros;
+    const int k0 = 32 * c;
+    const int s = tg_find_seg(a, k0);
+    const NlGemmSeg& sg = a.seg[s];
+    int kbase = k0 - a.kstart[s];
+    int ioff = sg.ioff;
+    if (sg.ntap > 1) {
+      const int cc = kbase >> 5, cb = cc / sg.ntap;
+      ioff += cc - cb * sg.ntap - (sg.ntap >> 1);
+      kbase = cb << 5;
+    }
+    const int i = t + ioff;
+    const bool ok = mok && i >= 0 && i < a.Li;
+    const int row = q * a.Li + i;
+    fr = sg.frag;
+    if (fr == 1) return ok ? sg.ptr + ((size_t)(row >> 5) * (sg.k >> 4) + (kbase >> 4)) * 512 + ((row & 31) + 32 * hh) * 4 : p_zeros;
+    return (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + (fr == 2 ? 4 : 8) * hh;
+  };
+  auto act_off = [](int fr, int pc) __attribute__((always_inline)) { return fr == 1 ? 256 * pc : 16 * (pc >> 1) + (fr == 2 ? 8 : 4) * (pc & 1); };
+  float4 raw[2][4];
+  int rfr[2] = {0, 0};
+  auto load_act = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      const float* p = act_ptr(2 * sl + ci, rfr[ci]);
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) raw[ci][pc] = *(const float4*)(p + act_off(rfr[ci], pc));
+    }
+  };
+
+  tg_f32x16 acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+
+  stage(0, std::integral_constant<int, 0>{});
+  load_act(0);
+  tg_wait_vmcnt<0>();
+  __syncthreads();
+
+  auto slab = [&](auto SLOTc, int g) __attribute__((always_inline)) {
+    constexpr int SL = decltype(SLOTc)::value;
+    // ---- this slab's B operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks)
+    float v[32];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+      if (rfr[ci] == 1) {   // split-bf16 fragments [ks 0: hi | lo | ks 1: hi | lo]: value = hi + lo (wave-uniform branch around vector moves only)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float4 fh = raw[ci][2 * ks], fl = raw[ci][2 * ks + 1];
+          const unsigned uh[4] = {__float_as_uint(fh.x), __float_as_uint(fh.y), __float_as_uint(fh.z), __float_as_uint(fh.w)};
+          const unsigned ul[4] = {__float_as_uint(fl.x), __float_as_uint(fl.y), __float_as_uint(fl.z), __float_as_uint(fl.w)};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            v[16 * ci + 8 * ks + 2 * d] = __uint_as_float(uh[d] << 16) + __uint_as_float(ul[d] << 16);
+            v[16 * ci + 8 * ks + 2 * d + 1] = __uint_as_float(uh[d] & 0xffff0000u) + __uint_as_float(ul[d] & 0xffff0000u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float4 f0 = raw[ci][2 * ks], f1 = raw[ci][2 * ks + 1];
+          v[16 * ci + 8 * ks + 0] = f0.x; v[16 * ci + 8 * ks + 1] = f0.y; v[16 * ci + 8 * ks + 2] = f0.z; v[16 * ci + 8 * ks + 3] = f0.w;
+          v[16 * ci + 8 * ks + 4] = f1.x; v[16 * ci + 8 * ks + 5] = f1.y; v[16 * ci + 8 * ks + 6] = f1.z; v[16 * ci + 8 * ks + 7] = f1.w;
+        }
+        if (rfr[ci] == 2) {   // the same rows the chain kernel would have handed over as fragments: take the value its split carries (bf16 hi + bf16 lo), so that a batch
+                              // renders to the same bits whichever source format its chunk took (early termination, a sample count that is not a multiple of 32)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float x = v[16 * ci + i];
+            const float h = (float)(__bf16)x;
+            v[16 * ci + i] = h + (float)(__bf16)(x - h);
+          }
+        }
+      }
+    }
+    float amax = 0.f;
+    tg_u32x16 H;
+    float lo[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      H[i] = tg_hi2_f16_amax(v[2 * i], v[2 * i + 1], amax);
+      tg_lo2_f32(v[2 * i], v[2 * i + 1], H[i], lo[2 * i], lo[2 * i + 1]);
+    }
+    int eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // block scale 2^(ex - 3) for amax = m 2^ex, m in [0.5, 1): the largest value lands in [4, 8)
+    eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);          // (12: the residual image's byte eb - 11 stays positive; an all-zero block takes any scale)
+    const float scf = __builtin_bit_cast(float, eb << 23);
+    const tg_u32x6 xh6 = tg_cvt_pk32_fp6_f16(H, scf);
+    const tg_f32x16 le = {lo[0], lo[2], lo[4], lo[6], lo[8], lo[10], lo[12], lo[14], lo[16], lo[18], lo[20], lo[22], lo[24], lo[26], lo[28], lo[30]};
+    const tg_f32x16 lod = {lo[1], lo[3], lo[5], lo[7], lo[9], lo[11], lo[13], lo[15], lo[17], lo[19], lo[21], lo[23], lo[25], lo[27], lo[29], lo[31]};
+    const tg_u32x6 xl6 = tg_cvt_2xpk16_fp6_f32(le, lod, scf * 0.00048828125f);   // (interleaves its operands: position 2 i <- le[i], 2 i + 1 <- lod[i] = the natural order)
+    const tg_i32x8 bh6 = {(int)xh6[0], (int)xh6[1], (int)xh6[2], (int)xh6[3], (int)xh6[4], (int)xh6[5], 0, 0};
+    const tg_i32x8 bl6 = {(int)xl6[0], (int)xl6[1], (int)xl6[2], (int)xl6[3], (int)xl6[4], (int)xl6[5], 0, 0};
+    const int sxh = eb, sxl = eb - 11;
+
+    // ---- the next slab: weights by LDS-DMA into the other slot (every wave left it before the barrier that ended the previous iteration), its raw activation words
+    {
+      stage(g + 1 < NS ? g + 1 : NS - 1, std::integral_constant<int, 1 - SL>{});   // (past the end: the last slab again, never used — no data-dependent control flow around the matrix instructions)
+      load_act(g + 1);                                                               // (past the end: zero rows)
+    }
+
+    // ---- the slab's product: per row tile 4 f16 k-steps + the two cross terms = 48 units; the A operand of unit u + 2 is read from LDS before the matrix instruction of
+    // unit u is issued (three rotating register sets: without the read-ahead every matrix instruction waits out an LDS round trip, ~170 cycles for a 32-cycle instruction)
+    const tg_u32x4* Lf = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT) / 16);
+    const tg_u32x4* La = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT + TGMX_F16B) / 16);
+    const tg_u32x4* Lb = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT + TGMX_F16B + TGMX_IMA) / 16);
+    tg_u32x4 ra[3], rb[3];
+    auto rdA = [&](auto Uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % 3;
+      if constexpr (k < 4) ra[r] = Lf[(k * NRT + rt) * 64 + lane];
+      else { ra[r] = La[(rt * 2 + (k - 4)) * 64 + lane]; rb[r] = Lb[(rt * 2 + (k - 4)) * 64 + lane]; }   // rb: {dword 4, dword 5, scale byte, 0}
+    };
+    rdA(std::integral_constant<int, 0>{});
+    rdA(std::integral_constant<int, 1>{});
+    tg_static_for<6 * NRT>([&](auto Uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % 3;
+      if constexpr (u + 2 < 6 * NRT) rdA(std::integral_constant<int, u + 2>{});
+      if constexpr (k < 4) {
+        const tg_f16x8 bf = __builtin_bit_cast(tg_f16x8, (tg_u32x4){H[4 * k], H[4 * k + 1], H[4 * k + 2], H[4 * k + 3]});
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, ra[r]), bf, acc[rt], 0, 0, 0);
+      } else {
+        const tg_i32x8 w6 = {(int)ra[r][0], (int)ra[r][1], (int)ra[r][2], (int)ra[r][3], (int)rb[r][0], (int)rb[r][1], 0, 0};
+        if constexpr (k == 4) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, bl6, acc[rt], 2, 2, 0, (int)rb[r][2], 0, sxl);   // w_hi6 x a_lo6
+        else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, bh6, acc[rt], 2, 2, 0, (int)rb[r][2], 0, sxh);                     // w_lo6 x a_hi6
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    tg_wait_vmcnt<0>();
+    __syncthreads();
+  };
+  for (int g = 0; g < NS; g += 2) {   // (an odd slab count runs one more: its activations are zero rows)
+    slab(std::integral_constant<int, 0>{}, g);
+    slab(std::integral_constant<int, 1>{}, g + 1);
+  }
+
+  // ---- epilogue: LayerNorm over each ray's whole (So x N) slab (So = 128: four waves per ray, two rays per workgroup), ELU, the density head (tgemm_kernel's NL_EPI_LNSLAB)
+  float* red = sbias + NRT * 32;   // [2][NW] partial sums
+  const int wpr = a.So >> 5, gb = (wave / wpr) * wpr;
+  float s1 = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = 32 * rt + 8 * gq + 4 * hh;
+      const float4 b4 = *(const float4*)(sbias + n);
+      acc[rt][4 * gq + 0] += b4.x; acc[rt][4 * gq + 1] += b4.y; acc[rt][4 * gq + 2] += b4.z; acc[rt][4 * gq + 3] += b4.w;
+      s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+    }
+  s1 = wave_sum(s1);
+  if (lane == 0) red[wave] = s1;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) tot += red[gb + w];
+  const float cnt = (float)a.So * (float)a.N;
+  const float mean = tot / cnt;
+  float s2 = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+  s2 = wave_sum(s2);
+  if (lane == 0) red[NW + wave] = s2;
+  __syncthreads();
+  float tot2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) tot2 += red[NW + gb + w];
+  const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
+  const float* grow = a.ep_gamma + ((size_t)(wave % wpr) * NRT * 4 * 64 + lane) * 4;
+  const float* brow = a.ep_beta + ((size_t)(wave % wpr) * NRT * 4 * 64 + lane) * 4;
+  float4 gbuf[2][4], bbuf[2][4];
+  auto load_gb = [&](int rt, float4 (&gd)[4], float4 (&bd)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) { gd[gq] = *(const float4*)(grow + (rt * 4 + gq) * 256); bd[gq] = *(const float4*)(brow + (rt * 4 + gq) * 256); }
+  };
+  load_gb(0, gbuf[0], bbuf[0]);
+  float* orow_p = p_c + (size_t)m * a.ldc;
+  float sg = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    if (rt + 1 < NRT) load_gb(rt + 1, gbuf[(rt + 1) & 1], bbuf[(rt + 1) & 1]);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = 32 * rt + 8 * gq + 4 * hh;
+      const float4 g4 = gbuf[rt & 1][gq], be4 = bbuf[rt & 1][gq];
+      float4 vv;
+      vv.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
+      vv.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
+      vv.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
+      vv.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
+      if (p_c && mok) *(float4*)(orow_p + n) = vv;   // p_c == null: only the density head's output is wanted
+      if (a.ep_sig_w) {
+        const float4 w4 = *(const float4*)(sbias + NRT * 32 + 32 + n);
+        sg = fmaf(vv.x, w4.x, sg); sg = fmaf(vv.y, w4.y, sg); sg = fmaf(vv.z, w4.z, sg); sg = fmaf(vv.w, w4.w, sg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (a.ep_sig_w) {
+    sg += __shfl_xor(sg, 32, 64);
+    if (hh == 0 && mok) a.ep_sig_out[m] = nl_softplus(sg + a.ep_sig_b[0]);
+  }
+}
+
+
+// ====================================================================================================================
 // Per-sample chains around the neural-point branch (W = 256), one persistent workgroup per CU, a wave keeps its 32 rows:
 //   chain (after the branch):  G = ELU(out_fc.2(t64))  (ibrnet.py:104-106)  ->  feature_agg = LayerNorm(fc(O) + G) * wscale  (ibrnet.py:
 //     110-117, model.py:419-427)  ->  feat_mlp.0 + LeakyReLU (model.py:85-89)  and the feature_agg columns of rgb_blending_mlp.0 (model.py:532)
@@ -488,8 +798,6 @@ struct NlChainArgs {
   int M;
 };
 
-typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
-typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
 
 enum { CK_G2 = 0, CK_FC, CK_F0, CK_BL, CK_Q, CK_NOP };
 #ifdef CHAIN_TRACE   // debug build (tools/chain_trace.py): cycle counter of block 0, wave 0 at [kernel][tile][chunk][before wait | after barrier | end of slot]
@@ -872,6 +1180,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
 
 // stream layout helpers (also used by the packer in abi.hip)
 int nl_tgemm_nrt(int N) { return N <= 64 ? 2 : (N <= 128 ? 4 : 8); }
+size_t nl_tgemm_mx_image_bytes(int Kpad) { return (size_t)((Kpad / 32 + 1) / 2) * TGMX_IMG; }   // fp6 images + scales of a 256-column layer (pack_tgemm_mx6_kernel)
 size_t nl_tgemm_stream_bytes(int Kpad, int N) { return (size_t)(Kpad / 32) * 4 * nl_tgemm_nrt(N) * 1024; }
 
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
@@ -893,9 +1202,19 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
   return true;
 }
 
+// f16mx form of an LNSLAB launch (conv_out): 256-wide, one ray = 128 rows, whole 32-k chunks from 16-byte-aligned sources, both weight images present
+bool nl_tgemm_mx_supported(const NlGemmArgs& a, int precision) {
+  if (precision != NL_PREC_BF16X3 || !a.Bsh_mx || !a.Bmx || a.epi != NL_EPI_LNSLAB || a.So != 128 || a.N != 256 || a.ep_pool || a.tile_map) return false;
+  return nl_tgemm_supported(a, precision);
+}
+
 int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   const bool x3 = precision == NL_PREC_BF16X3;
   const int nrt = nl_tgemm_nrt(a.N);
+  if (nl_tgemm_mx_supported(a, precision)) {
+    hipLaunchKernelGGL(tgemm_mx_kernel, dim3((unsigned)nl_cdiv(a.M, 32 * TGMX_NW)), dim3(64 * TGMX_NW), 0, st, a, (const char*)a.Bsh_mx, (const char*)a.Bmx, a.C, a.zeros, a.bias);
+    return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+  }
 #define NL_TG(NRT, NW, X3)                                                                                  \
   do {                                                                                                       \
     dim3 grid((unsigned)nl_cdiv(a.M, 32 * NW));                                                              \
