@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   const int m = tile * 32 + j;
   const bool mok = m < a.M;
   const int q = m / a.So, t = m - q * a.So;
-  const int NC = a.Kpad >> 5, NS = (NC + 1) >> 1;
+  const int NC = a.Kpad >> 5;
 
   for (int i = tid; i < NRT * 32; i += 64 * NW) {
     sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
@@ -561,37 +561,43 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
       }
     });
   };
-  // ---- activations: the 2 k-steps x 8 values of this lane's row for chunk c, as four 16-byte words (tgemm_kernel's act_ptr / act_off)
-  auto act_ptr = [&](int c, int& fr) __attribute__((always_inline)) -> const float* {
-    fr = 0;
-    if (c >= NC) return p_zeros;
-    const int k0 = 32 * c;
-    const int s = tg_find_seg(a, k0);
-    const NlGemmSeg& sg = a.seg[s];
-    int kbase = k0 - a.kstart[s];
-    int ioff = sg.ioff;
-    if (sg.ntap > 1) {
-      const int cc = kbase >> 5, cb = cc / sg.ntap;
-      ioff += cc - cb * sg.ntap - (sg.ntap >> 1);
-      kbase = cb << 5;
-    }
-    const int i = t + ioff;
+  // ---- activations.  The layer's K structure is conv_out's (W = 256; checked by nl_tgemm_mx_supported): chunks 0 .. 23 = feature_agg (eight 32-channel blocks x three
+  // taps, [block][tap]), 24 .. 26 = the three taps of x2's one block, 27 = nothing.  Everything that depends on the chunk is therefore a compile-time constant, and what
+  // depends on the lane — the row of each of the three taps, whether it exists (a ray's first / last position), the lane's slice of it — is worked out ONCE here:
+  // tgemm_kernel's act_ptr costs ~150 scalar instructions and several kernarg loads per chunk (segment look-up, a division by the tap count), eight waves x 28 chunks of
+  // them through the CU's one scalar unit.
+  const NlGemmSeg& g0 = a.seg[0];
+  const NlGemmSeg& g1 = a.seg[1];
+  const int fr0 = __builtin_amdgcn_readfirstlane(g0.frag);        // 1: the chain kernel's fragment image, 2 / 0: fp32 rows (2: the same K order inside a block as the image)
+  const int cstride0 = fr0 == 1 ? 1024 : 32;                       // floats between consecutive 32-channel blocks of a row
+  const float* P0[3]; const float* P1[3]; int okm[3];
+#pragma unroll
+  for (int tp = 0; tp < 3; ++tp) {
+    const int i = t + tp - 1;
     const bool ok = mok && i >= 0 && i < a.Li;
     const int row = q * a.Li + i;
-    fr = sg.frag;
-    if (fr == 1) return ok ? sg.ptr + ((size_t)(row >> 5) * (sg.k >> 4) + (kbase >> 4)) * 512 + ((row & 31) + 32 * hh) * 4 : p_zeros;
-    return (ok ? sg.ptr + (size_t)row * sg.ld + kbase : p_zeros) + (fr == 2 ? 4 : 8) * hh;
-  };
+    okm[tp] = ok ? 1 : 0;
+    const float* f = fr0 == 1 ? g0.ptr + ((size_t)(row >> 5) * (g0.k >> 4)) * 512 + ((row & 31) + 32 * hh) * 4 : g0.ptr + (size_t)row * g0.ld + (fr0 == 2 ? 4 : 8) * hh;
+    P0[tp] = ok ? f : p_zeros;
+    P1[tp] = ok ? g1.ptr + (size_t)row * g1.ld + 8 * hh : p_zeros;
+  }
   auto act_off = [](int fr, int pc) __attribute__((always_inline)) { return fr == 1 ? 256 * pc : 16 * (pc >> 1) + (fr == 2 ? 8 : 4) * (pc & 1); };
   float4 raw[2][4];
   int rfr[2] = {0, 0};
-  auto load_act = [&](int sl) __attribute__((always_inline)) {
+  auto load_chunk = [&](auto Cc, auto CIc) __attribute__((always_inline)) {
+    constexpr int c = decltype(Cc)::value, ci = decltype(CIc)::value;
+    const float* p; int fr;
+    if constexpr (c < 24) { constexpr int tp = c % 3, cb = c / 3; p = P0[tp] + okm[tp] * (cb * cstride0); fr = fr0; }
+    else if constexpr (c < 27) { p = P1[c - 24]; fr = 0; }
+    else { p = p_zeros; fr = 0; }
+    rfr[ci] = fr;
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-      const float* p = act_ptr(2 * sl + ci, rfr[ci]);
-#pragma unroll
-      for (int pc = 0; pc < 4; ++pc) raw[ci][pc] = *(const float4*)(p + act_off(rfr[ci], pc));
-    }
+    for (int pc = 0; pc < 4; ++pc) raw[ci][pc] = *(const float4*)(p + act_off(fr, pc));
+  };
+  auto load_act = [&](auto SLc) __attribute__((always_inline)) {   // the raw words of slab SL (past the end: zero rows)
+    constexpr int sl = decltype(SLc)::value;
+    load_chunk(std::integral_constant<int, (2 * sl < 28 ? 2 * sl : 27)>{}, std::integral_constant<int, 0>{});
+    load_chunk(std::integral_constant<int, (2 * sl + 1 < 28 ? 2 * sl + 1 : 27)>{}, std::integral_constant<int, 1>{});
   };
 
   tg_f32x16 acc[NRT];
@@ -601,12 +607,13 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 
   stage(0, std::integral_constant<int, 0>{});
-  load_act(0);
+  load_act(std::integral_constant<int, 0>{});
   tg_wait_vmcnt<0>();
   __syncthreads();
 
-  auto slab = [&](auto SLOTc, int g) __attribute__((always_inline)) {
-    constexpr int SL = decltype(SLOTc)::value;
+  constexpr int NSC = 14;   // slabs of the layer (27 chunks)
+  auto slab = [&](auto Gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(Gc)::value, SL = g & 1;
     // ---- this slab's B operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks)
     float v[32];
 #pragma unroll
@@ -662,8 +669,8 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
 
     // ---- the next slab: weights by LDS-DMA into the other slot (every wave left it before the barrier that ended the previous iteration), its raw activation words
     {
-      stage(g + 1 < NS ? g + 1 : NS - 1, std::integral_constant<int, 1 - SL>{});   // (past the end: the last slab again, never used — no data-dependent control flow around the matrix instructions)
-      load_act(g + 1);                                                               // (past the end: zero rows)
+      stage(g + 1 < NSC ? g + 1 : NSC - 1, std::integral_constant<int, 1 - SL>{});   // (past the end: the last slab again, never used)
+      load_act(std::integral_constant<int, g + 1>{});                               // (past the end: zero rows)
     }
 
     // ---- the slab's product: per row tile 4 f16 k-steps + the two cross terms = 48 units; the A operand of unit u + 2 is read from LDS before the matrix instruction of
@@ -695,10 +702,7 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     tg_wait_vmcnt<0>();
     __syncthreads();
   };
-  for (int g = 0; g < NS; g += 2) {   // (an odd slab count runs one more: its activations are zero rows)
-    slab(std::integral_constant<int, 0>{}, g);
-    slab(std::integral_constant<int, 1>{}, g + 1);
-  }
+  tg_static_for<NSC>([&](auto Gc) __attribute__((always_inline)) { slab(Gc); });
 
   // ---- epilogue: LayerNorm over each ray's whole (So x N) slab (So = 128: four waves per ray, two rays per workgroup), ELU, the density head (tgemm_kernel's NL_EPI_LNSLAB)
   float* red = sbias + NRT * 32;   // [2][NW] partial sums
@@ -1204,7 +1208,11 @@ bool nl_tgemm_supported(const NlGemmArgs& a, int precision) {
 
 // f16mx form of an LNSLAB launch (conv_out): 256-wide, one ray = 128 rows, whole 32-k chunks from 16-byte-aligned sources, both weight images present
 bool nl_tgemm_mx_supported(const NlGemmArgs& a, int precision) {
-  if (precision != NL_PREC_BF16X3 || !a.Bsh_mx || !a.Bmx || a.epi != NL_EPI_LNSLAB || a.So != 128 || a.N != 256 || a.ep_pool || a.tile_map) return false;
+  if (precision != NL_PREC_BF16X3 || !a.Bsh_mx || !a.Bmx || a.epi != NL_EPI_LNSLAB || a.So != 128 || a.Li != 128 || a.N != 256 || a.ep_pool || a.tile_map) return false;
+  // conv_out's K structure at W = 256 (the kernel's chunk table is a compile-time constant): [feature_agg: 8 blocks x 3 taps | x2: 1 block x 3 taps]
+  if (a.nseg != 2 || a.Kpad != 864 || a.seg[0].k != 256 || a.seg[0].ntap != 3 || a.seg[0].ioff != 0 || a.seg[1].k != 32 || a.seg[1].ntap != 3 || a.seg[1].ioff != 0 ||
+      a.seg[1].frag != 0)
+    return false;
   return nl_tgemm_supported(a, precision);
 }
 
