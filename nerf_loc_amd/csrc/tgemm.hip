@@ -516,6 +516,9 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
                                                                     const float* __restrict__ p_zeros, const float* __restrict__ p_bias) {
   constexpr int NRT = TGMX_NRT, NW = TGMX_NW;
   __builtin_amdgcn_s_setreg(1473, 1);   // hwreg(HW_REG_MODE, 23, 1): MODE.FP16_OVFL — f32 -> f16 / fp6 conversions saturate instead of producing inf / NaN
+  // (The two waves of a SIMD — wave w and w + 4: the two rays — run the same program between the same barriers: both convert, then both multiply.  A phase-shifted
+  // program, one group converting while the other multiplies, needs a wave-uniform branch around the matrix instructions, and hipcc then spills the accumulators:
+  // 2 768 spilled registers; a static issue priority for the first ray's waves, s_setprio 3, measured no change: 504 / 519 against 508 / 523 us.)
   __shared__ uint4 lds_all[2 * TGMX_SLOT / 16 + NRT * 8 * 2 + 8];
   float* sbias = reinterpret_cast<float*>(lds_all + 2 * TGMX_SLOT / 16);
 
