@@ -778,6 +778,174 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
 
 
 // ====================================================================================================================
+// conv1 of the ray U-Net (W = 256 -> 64, k = 3, S = 128; round 6): `tgemm_kernel<2, 4, .., NL_EPI_LNSLAB>` ran this layer at ~2 k cycles per 32-k chunk for 12 matrix
+// instructions of 32 — the chunk loop fetches one chunk ahead (weights through registers into LDS, a barrier per chunk), which covers 384 cycles of a ~1.5 k-cycle load.
+// With 64 output columns the accumulators are 32 registers, so this kernel can afford what the 256-wide one cannot: the raw activation words of THREE chunks in flight
+// (48 registers), the weights by buffer LDS-DMA into a four-slot ring three chunks ahead (8 KB per slot: 33 KB per workgroup), ~110 registers = four workgroups per CU to
+// cover the one barrier per chunk that is left.  The layer's K structure (eight 32-channel blocks x three taps of feature_agg, from the chain kernel's fragment image or
+// fp32 rows) is a compile-time chunk table as in tgemm_mx_kernel; the product is the same three-term split-bf16 in the same order as tgemm_kernel's (bit-identical
+// accumulators), the epilogue its NL_EPI_LNSLAB with MaxPool.
+constexpr int TGC1_NRT = 2, TGC1_NW = 4, TGC1_D = 3, TGC1_NB = TGC1_D + 1, TGC1_NCH = 24;
+template <bool X3>
+__global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c, const float* __restrict__ p_zeros,
+                                                                      const float* __restrict__ p_bias) {
+  constexpr int NRT = TGC1_NRT, NW = TGC1_NW, D = TGC1_D, NB = TGC1_NB, NCH = TGC1_NCH;
+  constexpr int PARTS = X3 ? 2 : 1;
+  constexpr int CHB = 4 * NRT * 1024;              // bytes per chunk in the global stream (hi and lo parts are always stored)
+  constexpr int SLOTB = PARTS * 2 * NRT * 1024;    // bytes per LDS slot
+  constexpr int PPW = SLOTB / 1024 / NW;           // 1-KB pieces per wave and chunk
+  static_assert(PPW * NW * 1024 == SLOTB, "pieces per wave");
+  __shared__ uint4 lds_all[NB * SLOTB / 16 + NRT * 8 * 2 + 8];
+  float* sbias = reinterpret_cast<float*>(lds_all + NB * SLOTB / 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31;
+  const int tile = blockIdx.x * NW + wave;
+  const int m = tile * 32 + j;
+  const bool mok = m < a.M;
+  const int q = m / a.So, t = m - q * a.So;
+
+  for (int i = tid; i < NRT * 32; i += 64 * NW) sbias[i] = (p_bias && i < a.N) ? p_bias[i] : 0.f;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p_bst, 0, 0x7fffffff, 0x00020000);
+  const unsigned lane16 = lane * 16;
+  auto stage = [&](auto Cc) __attribute__((always_inline)) {   // chunk c -> slot c % NB (compile-time: see tgemm_mx_kernel)
+    constexpr int c = decltype(Cc)::value, slot = c % NB;
+    tg_static_for<PPW>([&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      const int pp = wave + NW * i;
+      unsigned so = (unsigned)c * CHB + pp * 1024;
+      asm volatile("" : "+s"(so));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_all + (slot * SLOTB) / 16 + pp * 64), 16, lane16, so, 0, 0);
+    });
+  };
+  // activations: three per-tap row pointers worked out once (tgemm_mx_kernel)
+  const NlGemmSeg& g0 = a.seg[0];
+  const int fr0 = __builtin_amdgcn_readfirstlane(g0.frag);
+  const int cstride0 = fr0 == 1 ? 1024 : 32;
+  const float* P0[3]; int okm[3];
+#pragma unroll
+  for (int tp = 0; tp < 3; ++tp) {
+    const int i = t + tp - 1;
+    const bool ok = mok && i >= 0 && i < a.Li;
+    const int row = q * a.Li + i;
+    okm[tp] = ok ? 1 : 0;
+    const float* f = fr0 == 1 ? g0.ptr + ((size_t)(row >> 5) * (g0.k >> 4)) * 512 + ((row & 31) + 32 * hh) * 4 : g0.ptr + (size_t)row * g0.ld + (fr0 == 2 ? 4 : 8) * hh;
+    P0[tp] = ok ? f : p_zeros;
+  }
+  auto act_off = [](int fr, int pc) __attribute__((always_inline)) { return fr == 1 ? 256 * pc : 16 * (pc >> 1) + (fr == 2 ? 8 : 4) * (pc & 1); };
+  float4 raw[D][4];   // the raw words of the chunks in flight (ring: chunk c in raw[c % D])
+  auto load_act = [&](auto Cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(Cc)::value, tp = c % 3, cb = c / 3;
+    const float* p = P0[tp] + okm[tp] * (cb * cstride0);
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) raw[c % D][pc] = *(const float4*)(p + act_off(fr0, pc));
+  };
+
+  tg_f32x16 acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+
+  // prologue: chunks 0 .. D - 1 on their way
+  tg_static_for<D>([&](auto Cc) __attribute__((always_inline)) { stage(Cc); load_act(Cc); });
+
+  tg_static_for<NCH>([&](auto Gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(Gc)::value;
+    // chunk g has landed when at most the later chunks' operations are in flight (each chunk: PPW DMA pieces + 4 row loads per wave; vmcnt retires in order)
+    constexpr int later = (g + D - 1 < NCH ? D - 1 : NCH - 1 - g) * (PPW + 4);
+    tg_wait_vmcnt<later>();
+    __syncthreads();   // every wave's pieces of chunk g are in LDS; every wave has left slot (g + D) % NB = (g - 1) % NB
+    tg_bf16x8 bh[2], bl[2];
+    {
+      const float4 (&rw4)[4] = raw[g % D];
+      if (fr0 == 1) {   // fragment image: [k-step 0: hi | lo | k-step 1: hi | lo] (wave-uniform branch around vector moves only)
+        bh[0] = __builtin_bit_cast(tg_bf16x8, rw4[0]); bl[0] = __builtin_bit_cast(tg_bf16x8, rw4[1]);
+        bh[1] = __builtin_bit_cast(tg_bf16x8, rw4[2]); bl[1] = __builtin_bit_cast(tg_bf16x8, rw4[3]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const float v[8] = {rw4[2 * ks].x, rw4[2 * ks].y, rw4[2 * ks].z, rw4[2 * ks].w, rw4[2 * ks + 1].x, rw4[2 * ks + 1].y, rw4[2 * ks + 1].z, rw4[2 * ks + 1].w};
+          tg_split8<X3>(v, bh[ks], bl[ks]);
+        }
+      }
+    }
+    if constexpr (g + D < NCH) { stage(std::integral_constant<int, g + D>{}); load_act(std::integral_constant<int, g + D>{}); }
+    const tg_bf16x8* L = reinterpret_cast<const tg_bf16x8*>(lds_all + ((g % NB) * SLOTB) / 16);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        const tg_bf16x8 ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
+        if (X3) {
+          const tg_bf16x8 al = L[((1 * 2 + ks) * NRT + rt) * 64 + lane];
+          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc[rt], 0, 0, 0);
+        }
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc[rt], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+
+  // ---- epilogue: LayerNorm over the ray's (128 x 64) slab + ELU + MaxPool(2) (tgemm_kernel's NL_EPI_LNSLAB, one ray per workgroup)
+  __syncthreads();   // (sbias was written before the loop's first barrier; red lies behind it)
+  float* red = sbias + NRT * 32;
+  float s1 = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = 32 * rt + 8 * gq + 4 * hh;
+      const float4 b4 = *(const float4*)(sbias + n);
+      acc[rt][4 * gq + 0] += b4.x; acc[rt][4 * gq + 1] += b4.y; acc[rt][4 * gq + 2] += b4.z; acc[rt][4 * gq + 3] += b4.w;
+      s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+    }
+  s1 = wave_sum(s1);
+  if (lane == 0) red[wave] = s1;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tot += red[w];
+  const float cnt = (float)a.So * (float)a.N;
+  const float mean = tot / cnt;
+  float s2 = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+  s2 = wave_sum(s2);
+  if (lane == 0) red[NW + wave] = s2;
+  __syncthreads();
+  float tot2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tot2 += red[NW + w];
+  const float rstd = 1.f / sqrtf(tot2 / cnt + a.ep_eps);
+  const float* grow = a.ep_gamma + ((size_t)wave * NRT * 4 * 64 + lane) * 4;   // (a ray = the workgroup's four waves: wave = row tile inside the ray)
+  const float* brow = a.ep_beta + ((size_t)wave * NRT * 4 * 64 + lane) * 4;
+  const bool pool = a.ep_pool != 0;
+  float* orow_p = p_c + (size_t)(pool ? q * (a.So / 2) + (t >> 1) : m) * a.ldc;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = 32 * rt + 8 * gq + 4 * hh;
+      const float4 g4 = *(const float4*)(grow + (rt * 4 + gq) * 256), be4 = *(const float4*)(brow + (rt * 4 + gq) * 256);
+      float4 v;
+      v.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
+      v.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
+      v.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
+      v.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
+      if (pool) {
+        v.x = fmaxf(v.x, nl_dpp<0xB1>(v.x, v.x)); v.y = fmaxf(v.y, nl_dpp<0xB1>(v.y, v.y));
+        v.z = fmaxf(v.z, nl_dpp<0xB1>(v.z, v.z)); v.w = fmaxf(v.w, nl_dpp<0xB1>(v.w, v.w));
+      }
+      if (mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;
+    }
+}
+
+
+// ====================================================================================================================
 // Per-sample chains around the neural-point branch (W = 256), one persistent workgroup per CU, a wave keeps its 32 rows:
 //   chain (after the branch):  G = ELU(out_fc.2(t64))  (ibrnet.py:104-106)  ->  feature_agg = LayerNorm(fc(O) + G) * wscale  (ibrnet.py:
 //     110-117, model.py:419-427)  ->  feat_mlp.0 + LeakyReLU (model.py:85-89)  and the feature_agg columns of rgb_blending_mlp.0 (model.py:532)
@@ -1219,9 +1387,24 @@ bool nl_tgemm_mx_supported(const NlGemmArgs& a, int precision) {
   return nl_tgemm_supported(a, precision);
 }
 
+// conv1 of the ray U-Net at W = 256, S = 128 (tgemm_conv1_kernel): one segment of 256 channels x 3 taps, 64 columns, one ray = 128 rows per workgroup
+bool nl_tgemm_conv1_supported(const NlGemmArgs& a, int precision) {
+  if ((precision != NL_PREC_BF16X3 && precision != NL_PREC_BF16) || a.epi != NL_EPI_LNSLAB || a.So != 128 || a.Li != 128 || a.N != 64 || a.tile_map || a.ep_sig_w || !a.C) return false;
+  if (a.nseg != 1 || a.Kpad != 768 || a.seg[0].k != 256 || a.seg[0].ntap != 3 || a.seg[0].ioff != 0) return false;
+  return nl_tgemm_supported(a, precision);
+}
+
 int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
   const bool x3 = precision == NL_PREC_BF16X3;
   const int nrt = nl_tgemm_nrt(a.N);
+#ifndef NL_NO_TGEMM_CONV1
+  if (nl_tgemm_conv1_supported(a, precision)) {
+    const dim3 grid((unsigned)nl_cdiv(a.M, 32 * TGC1_NW));
+    if (x3) hipLaunchKernelGGL(tgemm_conv1_kernel<true>, grid, dim3(64 * TGC1_NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    else hipLaunchKernelGGL(tgemm_conv1_kernel<false>, grid, dim3(64 * TGC1_NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+  }
+#endif
   if (nl_tgemm_mx_supported(a, precision)) {
     hipLaunchKernelGGL(tgemm_mx_kernel, dim3((unsigned)nl_cdiv(a.M, 32 * TGMX_NW)), dim3(64 * TGMX_NW), 0, st, a, (const char*)a.Bsh_mx, (const char*)a.Bmx, a.C, a.zeros, a.bias);
     return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
