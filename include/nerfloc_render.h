@@ -66,8 +66,9 @@ typedef enum nl_precision {
                         * (the MFMA-bound kernel): fp16 hi.hi (v_mfma_f32_32x32x16_f16) + the two cross terms hi.lo / lo.hi on gfx950's
                         * block-scaled instruction v_mfma_scale_f32_32x32x64_f8f6f4 — since round 5 with FP6 (e2m3) operands, 8 passes per K = 64 where FP8 takes 16
                         * (the cross terms are 2^-11 of a product: three mantissa bits leave 2^-15, whether the element is e4m3 or e2m3; what e2m3 lacks is range,
-                        * which the block scales supply).  Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as
-                        * NL_PREC_BF16X3.
+                        * which the block scales supply).  Round 6: the ray U-Net's conv_out (W = 256, S = 128: the second-largest kernel of nl_render_rays) multiplies
+                        * in the same arithmetic, its B operand rebuilt per K = 64 slab in registers with a scale per 32-value block from the values themselves.
+                        * Every other GEMM-shaped stage, the stage entry points and the backward passes run exactly as NL_PREC_BF16X3.
                         * RANGE: every MX block — a row's 32 values of one K half-slab — carries its own power-of-two scale 2^(floor(log2 max) - 2), taken from the
                         * values themselves: in the kernel for the activations (per row, slab and layer; the residual image uses the same scale x 2^-11), at
                         * packing time for the weights (per output row and half-slab).  No activation or weight magnitude saturates or flushes a block.  What is
