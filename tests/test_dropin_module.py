@@ -151,7 +151,7 @@ def test_dropin_end_to_end_matches_reference(case_name, precision, tol):
     net.multiview_aggregator.vis_featmaps = None
     out2 = net.render_rays(data, rd)
     # (MIOpen may pick another conv algorithm for the per-frame CNN on a later call: equal up to fp32 noise, not bitwise)
-    assert rel_err(out2["rgb"].cpu().numpy(), out["rgb"].cpu().numpy()) < 3e-5   # (MIOpen jitter of the re-run per-frame CNN: see the 3e-5 note further down)
+    assert rel_err(out2["rgb"].cpu().numpy(), out["rgb"].cpu().numpy()) < 1e-5   # (round 6: MIOpen is pinned to its deterministic algorithms in tests/conftest.py: rebuilt maps are bit-identical)
 
 
 def _module_and_data(case, dev, precision="bf16x3"):
@@ -197,7 +197,7 @@ def test_frame_tables_follow_the_callers_cache_reset():
     # and the fine level through render_rays
     ob = net.render_rays(data, rd)
     of = fresh.render_rays(data_f, rd)
-    assert rel_err(ob["rgb"].cpu().numpy(), of["rgb"].cpu().numpy()) < 3e-5   # (MIOpen jitter of the re-run per-frame CNN: see the 3e-5 note further down)
+    assert rel_err(ob["rgb"].cpu().numpy(), of["rgb"].cpu().numpy()) < 1e-5   # (MIOpen pinned: tests/conftest.py)
 
 
 def test_cache_attributes_count_generations():
@@ -346,7 +346,7 @@ def test_dropin_without_feature_rendering():
     assert "feat" in outs[0] and "feat" not in outs[1]
     assert torch.equal(outs[0]["mask"], outs[1]["mask"])
     for k in ("rgb", "depth", "weights", "depth_uncertainty"):   # two module instances: MIOpen may pick another algorithm for the per-frame CNN
-        assert rel_err(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy()) < 3e-5, k
+        assert rel_err(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy()) < 1e-5, k   # (MIOpen pinned: tests/conftest.py)
 
 
 @pytest.mark.parametrize("case_name", ["setup", "setup_holes"])
@@ -467,7 +467,8 @@ def test_frames_with_different_support_sets_in_one_call_equal_separate_calls():
         assert torch.equal(got["mask"], want["mask"])
         for k in ("rgb", "depth", "weights", "feat", "depth_uncertainty"):
             # (3e-5: the MIOpen jitter of the per-frame CNN, ~1e-6 on its maps, reaches the outputs amplified — 1.06e-5 on `weights` once in 14 loops of the GPU suite at the end of round 5)
-            assert got[k].shape == want[k].shape and rel_err(got[k].cpu().numpy(), want[k].cpu().numpy()) < 3e-5, k
+            # (round 6: with MIOpen pinned to its deterministic algorithms — tests/conftest.py, tools/miopen_repeat.py: 156 of 156 rebuilds bit-identical — the bar is back at 1e-5)
+            assert got[k].shape == want[k].shape and rel_err(got[k].cpu().numpy(), want[k].cpu().numpy()) < 1e-5, k
     assert rel_err(singles[1]["rgb"][:14].cpu().numpy(), singles[0]["rgb"][:14].cpu().numpy()) > 1e-3, "the frames must differ for this test to mean anything"
     # the single-frame path still works afterwards (its renderer's tables are rebuilt for the module's current caches)
     net.support_neural_points = None
