@@ -41,6 +41,59 @@ __device__ __forceinline__ float nl_elu(float x) { return x > 0.f ? x : expm1f(x
 // products still carry into the hidden units of the OTHER rows of the tap (the outputs stay non-finite in practice: tests feed finite maps only), but this function
 // by itself does not propagate it — use nl_elu where that matters.
 __device__ __forceinline__ float nl_elu_fast(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+// max(v, the value of lane ^ 1) as ONE DPP-modified v_max_f32 (MaxPool over neighbouring positions held in neighbouring lanes).  `fmaxf(v, nl_dpp<0xB1>(v, v))` costs four:
+// the DPP move plus a canonicalising v_max_f32 x, x per operand in front of the maximum (llvm.maxnum under IEEE mode).  The hardware instruction quiets NaNs by itself; for
+// everything else the value is the same.  (s_nop 1: the two wait states a DPP read needs behind a VALU write of its source — the compiler does not see into the statement.)
+__device__ __forceinline__ float nl_max_lane_xor1(float v) {
+  float r;
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+  return r;
+}
+// Split-bf16 of a PAIR: hi = the pair rounded to bf16 (one v_cvt_pk_bf16_f32), lo = bf16(v - float(hi)) with the subtraction as one packed instruction — per element the
+// same two roundings as `h = (__bf16)v; l = (__bf16)(v - (float)h)`, which hipcc lowers to a conversion per ELEMENT for the subtraction and a second, packed one for the
+// store (32 vector instructions per 8 values; this form: 20).  Results as raw 32-bit words: element 0 in the low half.
+typedef float nl_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 nl_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nl_bf16_pair(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(nl_f32x2{a, b}, nl_bf16x2)); }
+__device__ __forceinline__ void nl_split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const nl_f32x2 v = {a, b};
+  const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, nl_bf16x2));
+  const nl_f32x2 f = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  hi = u;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - f, nl_bf16x2));
+}
+// Element-wise epilogue arithmetic on PAIRS (v_pk_add_f32 / v_pk_mul_f32; round 6): per element the same operations in the same order as the scalar forms they replace.
+// ELU of a pair (nl_elu_fast per element): 6 vector instructions per pair instead of 8
+__device__ __forceinline__ nl_f32x2 nl_elu_fast2(nl_f32x2 x) {
+  const nl_f32x2 y = x * nl_f32x2{1.4426950408889634f, 1.4426950408889634f};
+  nl_f32x2 e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+  e = e - nl_f32x2{1.f, 1.f};
+  return nl_f32x2{__builtin_amdgcn_fmed3f(x[0], e[0], 0.f), __builtin_amdgcn_fmed3f(x[1], e[1], 0.f)};
+}
+// ELU((x - mean) * rstd * g + b) of four values
+__device__ __forceinline__ float4 nl_ln_elu4(float x0, float x1, float x2, float x3, float mean, float rstd, const float4& g, const float4& b) {
+  const nl_f32x2 mm = {mean, mean}, rr = {rstd, rstd};
+  const nl_f32x2 p0 = nl_elu_fast2((nl_f32x2{x0, x1} - mm) * rr * nl_f32x2{g.x, g.y} + nl_f32x2{b.x, b.y});
+  const nl_f32x2 p1 = nl_elu_fast2((nl_f32x2{x2, x3} - mm) * rr * nl_f32x2{g.z, g.w} + nl_f32x2{b.z, b.w});
+  return make_float4(p0[0], p0[1], p1[0], p1[1]);
+}
+// LeakyReLU(0.01) of a pair: max(x, 0.01 x) — the value of `x > 0 ? x : 0.01 x` for every input (both orderings agree on +-0 and NaN); one packed multiply + two maxima
+__device__ __forceinline__ nl_f32x2 nl_lrelu2(nl_f32x2 x) {
+  const nl_f32x2 z = x * nl_f32x2{0.01f, 0.01f};
+  return nl_f32x2{fmaxf(x[0], z[0]), fmaxf(x[1], z[1])};
+}
+// (x0..x3) + b as two pairs; their sum in `sum` (two packed adds + the horizontal ones)
+__device__ __forceinline__ void nl_bias_sum4(float x0, float x1, float x2, float x3, const float4& b, nl_f32x2& p0, nl_f32x2& p1, float& sum) {
+  p0 = nl_f32x2{x0, x1} + nl_f32x2{b.x, b.y};
+  p1 = nl_f32x2{x2, x3} + nl_f32x2{b.z, b.w};
+  const nl_f32x2 q = p0 + p1;
+  sum += q[0] + q[1];
+}
+// sp += (x - mean)^2 of a pair (two running sums; the caller adds the halves at the end)
+__device__ __forceinline__ void nl_sumsq_dev2(nl_f32x2& sp, float x0, float x1, float mean) {
+  const nl_f32x2 d = nl_f32x2{x0, x1} - nl_f32x2{mean, mean};
+  sp += d * d;
+}
 __device__ __forceinline__ float nl_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float nl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float nl_act(float x, int act) {

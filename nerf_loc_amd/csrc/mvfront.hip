@@ -25,10 +25,14 @@ using namespace nlmv;
 
 typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned mf_u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef MF_KO
 #define MF_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no texel loads in phase B, 2 no phase B, 4 no colour taps in phase A, 8 no MFMA phase, 16 no staging writes, 64 every texel fetch from texel 0 (all cache hits)
+#endif
+#ifndef MF_PK
+#define MF_PK 1   // phase B's channel pairs on the packed-fp32 instructions (round 6); 0 = one scalar FMA per channel
 #endif
 #ifndef MF_CPL
 #define MF_CPL 3
@@ -241,12 +245,28 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
           }
         }
         const float w0 = c4.y, w1 = c4.z, w2 = c4.w, w3 = c2.x, wg = c2.y;
+        if constexpr (CPL == 3 && MF_PK) {
+          // channels 0, 1 as one packed operation each (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: the same roundings in the same order, two thirds of the instructions)
+          const mf_f32x2 t0 = {T[0][0], T[0][1]}, t1 = {T[1][0], T[1][1]}, t2 = {T[2][0], T[2][1]}, t3 = {T[3][0], T[3][1]};
+          const mf_f32x2 W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3}, WG = {wg, wg};
+          const mf_f32x2 x = __builtin_elementwise_fma(t3, W3, __builtin_elementwise_fma(t2, W2, __builtin_elementwise_fma(t1, W1, t0 * W0)));
+          const mf_f32x2 t = WG * x;
+          mf_f32x2 A1 = {a1[s][0], a1[s][1]}, A2 = {a2[s][0], a2[s][1]};
+          A1 += t;
+          A2 = __builtin_elementwise_fma(t, x, A2);
+          a1[s][0] = A1[0]; a1[s][1] = A1[1]; a2[s][0] = A2[0]; a2[s][1] = A2[1];
+          const float xs = fmaf(T[3][2], w3, fmaf(T[2][2], w2, fmaf(T[1][2], w1, T[0][2] * w0)));
+          const float ts = wg * xs;
+          a1[s][2] += ts;
+          a2[s][2] = fmaf(ts, xs, a2[s][2]);
+        } else {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           const float x = fmaf(T[3][j], w3, fmaf(T[2][j], w2, fmaf(T[1][j], w1, T[0][j] * w0)));
           const float t = wg * x;
           a1[s][j] += t;
           a2[s][j] = fmaf(t, x, a2[s][j]);
+        }
         }
       }
     }

@@ -42,7 +42,7 @@ typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 namespace {
 
 #ifndef PF2_KO
-#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention, 256 no barriers in the tile loop (what the waves' skew costs), 16 the second cross-term matrix instruction of every slab skipped (its reads and fills stay): the matrix-pipe time fp6 cross terms would take
+#define PF2_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no in-loop prologue, 2 no layer epilogues, 4 no LDS-DMA in the loop, 8 no attention, 256 no barriers in the tile loop (what the waves' skew costs), 512 the barrier of every odd region only (what a ring with one slot of slack could return at most), 16 the second cross-term matrix instruction of every slab skipped (its reads and fills stay): the matrix-pipe time fp6 cross terms would take
 #endif
 constexpr int KO = PF2_KO;
 #ifndef PF2_MX_FP6
@@ -53,6 +53,10 @@ constexpr int KO = PF2_KO;
 #endif
 constexpr bool L1MX = PF2_L1_MX;
 constexpr int MXK = PF2_MX_FP6 ? 2 : 1;   // the one MX instance this library carries (pack and launch agree by construction)
+#ifndef PF2_PE_F32
+#define PF2_PE_F32 1   // the positional encoding's sin / cos recurrence of the f16mx instance in fp32 (round 6): 4.5e-6 on the encoding against the 3e-5 of its fp6
+                       // cross-term image; 0 = fp64 like the other precisions (whose operands carry 1e-7)
+#endif
 #ifdef PF2_TRACE
 __device__ unsigned long long pf2_trace[256];   // debug: cycle counter at every region start of one tile (block 0, wave 0)
 #endif
@@ -470,7 +474,10 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
   unsigned rdbh[2] = {0, 0}, rdbl[2] = {0, 0}, hidh[4] = {0, 0, 0, 0}, hidl[4] = {0, 0, 0, 0};
   f32x16 pa = zero16;
   f32x4 pb[4];
-  double sx[3], skd[3], sr[3], sr2[3], su[3], sw[3], ss[3], scs[3];
+  using pe_t = std::conditional_t<(MX6 && L1MX && PF2_PE_F32), float, double>;   // fp64 FMAs issue at the fp32 rate on this part: what fp32 returns is registers (24 instead of 48)
+  constexpr pe_t PE_PIO2_HI = sizeof(pe_t) == 4 ? (pe_t)1.57079637050628662 : (pe_t)1.5707963267948966;
+  constexpr pe_t PE_PIO2_LO = sizeof(pe_t) == 4 ? (pe_t)-4.37113882867379e-8 : (pe_t)6.123233995736766e-17;
+  pe_t sx[3], skd[3], sr[3], sr2[3], su[3], sw[3], ss[3], scs[3];
   int skq[3];
   constexpr int NPL = 2, NPC = (MX6 && L1MX) ? 57 : 55, NPRO = NPL + NPC;   // load steps, compute steps (L1MX: + the two slabs' packing conversions)
   auto pro_step = [&](auto Ic) __attribute__((always_inline)) {
@@ -563,17 +570,17 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         // axis at the half's first octave (Cody-Waite to [-pi/4, pi/4] + Taylor, error < 1e-11) + the double-angle recurrence in
         // fp64 (abs error < 1e-12: correctly rounded in fp32).  Nine sub-steps per axis, the three axes interleaved.
         constexpr int x = (C - 12) / 3, a = (C - 12) % 3;
-        if constexpr (x == 0) { sx[a] = (double)poff[a] * (hh ? 32.0 : 1.0); skd[a] = rint(sx[a] * 0.63661977236758134308); }
-        else if constexpr (x == 1) { sr[a] = fma(-skd[a], 1.5707963267948966, sx[a]); sr[a] = fma(-skd[a], 6.123233995736766e-17, sr[a]); }
-        else if constexpr (x == 2) { sr2[a] = sr[a] * sr[a]; skq[a] = (int)skd[a]; su[a] = fma(sr2[a], -1.0 / 39916800, 1.0 / 362880); }
-        else if constexpr (x == 3) { su[a] = fma(sr2[a], su[a], -1.0 / 5040); su[a] = fma(sr2[a], su[a], 1.0 / 120); }
-        else if constexpr (x == 4) { su[a] = fma(sr2[a], su[a], -1.0 / 6); sw[a] = fma(sr2[a], 1.0 / 479001600, -1.0 / 3628800); }
-        else if constexpr (x == 5) { sw[a] = fma(sr2[a], sw[a], 1.0 / 40320); sw[a] = fma(sr2[a], sw[a], -1.0 / 720); }
-        else if constexpr (x == 6) { sw[a] = fma(sr2[a], sw[a], 1.0 / 24); sw[a] = fma(sr2[a], sw[a], -0.5); }
-        else if constexpr (x == 7) { su[a] = fma(sr[a] * sr2[a], su[a], sr[a]); sw[a] = fma(sr2[a], sw[a], 1.0); }
+        if constexpr (x == 0) { sx[a] = (pe_t)poff[a] * (hh ? (pe_t)(32.0) : (pe_t)(1.0)); skd[a] = rint(sx[a] * (pe_t)(0.63661977236758134308)); }
+        else if constexpr (x == 1) { sr[a] = fma(-skd[a], PE_PIO2_HI, sx[a]); sr[a] = fma(-skd[a], PE_PIO2_LO, sr[a]); }
+        else if constexpr (x == 2) { sr2[a] = sr[a] * sr[a]; skq[a] = (int)skd[a]; su[a] = fma(sr2[a], (pe_t)(-1.0 / 39916800), (pe_t)(1.0 / 362880)); }
+        else if constexpr (x == 3) { su[a] = fma(sr2[a], su[a], (pe_t)(-1.0 / 5040)); su[a] = fma(sr2[a], su[a], (pe_t)(1.0 / 120)); }
+        else if constexpr (x == 4) { su[a] = fma(sr2[a], su[a], (pe_t)(-1.0 / 6)); sw[a] = fma(sr2[a], (pe_t)(1.0 / 479001600), (pe_t)(-1.0 / 3628800)); }
+        else if constexpr (x == 5) { sw[a] = fma(sr2[a], sw[a], (pe_t)(1.0 / 40320)); sw[a] = fma(sr2[a], sw[a], (pe_t)(-1.0 / 720)); }
+        else if constexpr (x == 6) { sw[a] = fma(sr2[a], sw[a], (pe_t)(1.0 / 24)); sw[a] = fma(sr2[a], sw[a], (pe_t)(-0.5)); }
+        else if constexpr (x == 7) { su[a] = fma(sr[a] * sr2[a], su[a], sr[a]); sw[a] = fma(sr2[a], sw[a], (pe_t)(1.0)); }
         else {
           const bool swp = skq[a] & 1;
-          const double s1 = swp ? sw[a] : su[a], c1 = swp ? su[a] : sw[a];
+          const pe_t s1 = swp ? sw[a] : su[a], c1 = swp ? su[a] : sw[a];
           ss[a] = (skq[a] & 2) ? -s1 : s1;
           scs[a] = ((skq[a] + 1) & 2) ? -c1 : c1;
         }
@@ -591,8 +598,8 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         if (X3) Pl[p / 4][p & 3] = l;
         }
         if constexpr (f < 4) {
-          const double s2 = 2.0 * ss[a] * scs[a];
-          scs[a] = fma(-2.0 * ss[a], ss[a], 1.0);
+          const pe_t s2 = (pe_t)(2.0) * ss[a] * scs[a];
+          scs[a] = fma((pe_t)(-2.0) * ss[a], ss[a], (pe_t)(1.0));
           ss[a] = s2;
         }
       } else if constexpr (C == 54) {
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
           if constexpr (ks == NKS - 1) {
             if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(KO & 256) && !((KO & 512) && (G & 1))) __builtin_amdgcn_s_barrier();
           }
           const u32x4 bh = __builtin_shufflevector(P16[q], P16[q], 4 * sI, 4 * sI + 1, 4 * sI + 2, 4 * sI + 3);
           if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
           if constexpr (ks == NKS - 1) {
             if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(KO & 256) && !((KO & 512) && (G & 1))) __builtin_amdgcn_s_barrier();
           }
           const u32x4 bh = __builtin_shufflevector(Xh16[IN][q], Xh16[IN][q], 4 * sI, 4 * sI + 1, 4 * sI + 2, 4 * sI + 3);
           if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
@@ -980,7 +987,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
           if constexpr (ks == NKS - 1) {
             if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(KO & 256) && !((KO & 512) && (G & 1))) __builtin_amdgcn_s_barrier();
           }
           const u32x4 bh = frag4(Xh[IN][ks]);
           if constexpr (ks + 2 < NKS) read_frag(Gc, std::integral_constant<int, ks + 2>{}, std::integral_constant<int, 0>{});
@@ -1036,7 +1043,7 @@ __global__ __launch_bounds__(256, 1) void point_fused2_kernel(
         // slot reads; its last fragments are in registers already
         if constexpr (!(KO & 4)) wait_vmcnt<GG::ppw(G + 2) + GG::ppw(G + 3)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (!(KO & 256)) __builtin_amdgcn_s_barrier();
+        if constexpr (!(KO & 256) && !((KO & 512) && (G & 1))) __builtin_amdgcn_s_barrier();
       }
       auto bsel = [&](auto Hi) __attribute__((always_inline)) {
         if constexpr (L == 0) { if constexpr (decltype(Hi)::value) return frag4(Ph[ks]); else return frag4(Pl[ks]); }

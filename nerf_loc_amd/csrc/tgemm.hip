@@ -40,12 +40,14 @@ __device__ __forceinline__ void tg_static_for(F&& f) {
 
 template <bool X3>
 __device__ __forceinline__ void tg_split8(const float (&v)[8], tg_bf16x8& hi, tg_bf16x8& lo) {
+  unsigned h[4], l[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    __bf16 h = (__bf16)v[t];
-    hi[t] = h;
-    if (X3) lo[t] = (__bf16)(v[t] - (float)h);
+  for (int t = 0; t < 4; ++t) {
+    if (X3) nl_split_bf16_pair(v[2 * t], v[2 * t + 1], h[t], l[t]);
+    else h[t] = nl_bf16_pair(v[2 * t], v[2 * t + 1]);
   }
+  hi = __builtin_bit_cast(tg_bf16x8, tg_u32x4{h[0], h[1], h[2], h[3]});
+  if (X3) lo = __builtin_bit_cast(tg_bf16x8, tg_u32x4{l[0], l[1], l[2], l[3]});
 }
 
 // three-term split-FP16 variant (internal precision NL_PREC_F16X3_INTERNAL: the backward passes' recomputed forward): the same storage type (16-bit
@@ -343,14 +345,10 @@ __global__ __launch_bounds__(64 * NW, NW > 4 ? 1 : 2) void tgemm_kernel(const Nl
         const int n = 32 * rt + 8 * gq + 4 * hh;
         if (n < a.N) {
           const float4 g4 = gbuf[rt & 1][gq], be4 = bbuf[rt & 1][gq];
-          float4 v;
-          v.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
-          v.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
-          v.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
-          v.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
+          float4 v = nl_ln_elu4(acc[rt][4 * gq + 0], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3], mean, rstd, g4, be4);
           if (pool) {   // positions 2p, 2p+1 are neighbouring lanes
-            v.x = fmaxf(v.x, nl_dpp<0xB1>(v.x, v.x)); v.y = fmaxf(v.y, nl_dpp<0xB1>(v.y, v.y));   // quad_perm [1,0,3,2]: lane ^ 1
-            v.z = fmaxf(v.z, nl_dpp<0xB1>(v.z, v.z)); v.w = fmaxf(v.w, nl_dpp<0xB1>(v.w, v.w));
+            v.x = nl_max_lane_xor1(v.x); v.y = nl_max_lane_xor1(v.y);   // quad_perm [1,0,3,2]: lane ^ 1
+            v.z = nl_max_lane_xor1(v.z); v.w = nl_max_lane_xor1(v.w);
           }
           if (p_c && mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;   // p_c == null: only the density head's output is wanted
           if (a.ep_sig_w) {
@@ -643,10 +641,11 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
         if (rfr[ci] == 2) {   // the same rows the chain kernel would have handed over as fragments: take the value its split carries (bf16 hi + bf16 lo), so that a batch
                               // renders to the same bits whichever source format its chunk took (early termination, a sample count that is not a multiple of 32)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float x = v[16 * ci + i];
-            const float h = (float)(__bf16)x;
-            v[16 * ci + i] = h + (float)(__bf16)(x - h);
+          for (int i = 0; i < 16; i += 2) {   // (pairs: nl_split_bf16_pair's instruction sequence, the two words put back together)
+            unsigned h, l;
+            nl_split_bf16_pair(v[16 * ci + i], v[16 * ci + i + 1], h, l);
+            const nl_f32x2 r = nl_f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)} + nl_f32x2{__uint_as_float(l << 16), __uint_as_float(l & 0xffff0000u)};
+            v[16 * ci + i] = r[0]; v[16 * ci + i + 1] = r[1];
           }
         }
       }
@@ -717,8 +716,9 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     for (int gq = 0; gq < 4; ++gq) {
       const int n = 32 * rt + 8 * gq + 4 * hh;
       const float4 b4 = *(const float4*)(sbias + n);
-      acc[rt][4 * gq + 0] += b4.x; acc[rt][4 * gq + 1] += b4.y; acc[rt][4 * gq + 2] += b4.z; acc[rt][4 * gq + 3] += b4.w;
-      s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+      nl_f32x2 p0, p1;
+      nl_bias_sum4(acc[rt][4 * gq + 0], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3], b4, p0, p1, s1);
+      acc[rt][4 * gq + 0] = p0[0]; acc[rt][4 * gq + 1] = p0[1]; acc[rt][4 * gq + 2] = p1[0]; acc[rt][4 * gq + 3] = p1[1];
     }
   s1 = wave_sum(s1);
   if (lane == 0) red[wave] = s1;
@@ -728,11 +728,15 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   for (int w = 0; w < 4; ++w) tot += red[gb + w];
   const float cnt = (float)a.So * (float)a.N;
   const float mean = tot / cnt;
-  float s2 = 0.f;
+  float s2;
+  {
+    nl_f32x2 sp = {0.f, 0.f};
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+      for (int r = 0; r < 16; r += 2) nl_sumsq_dev2(sp, acc[rt][r], acc[rt][r + 1], mean);
+    s2 = sp[0] + sp[1];
+  }
   s2 = wave_sum(s2);
   if (lane == 0) red[NW + wave] = s2;
   __syncthreads();
@@ -757,11 +761,7 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     for (int gq = 0; gq < 4; ++gq) {
       const int n = 32 * rt + 8 * gq + 4 * hh;
       const float4 g4 = gbuf[rt & 1][gq], be4 = bbuf[rt & 1][gq];
-      float4 vv;
-      vv.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
-      vv.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
-      vv.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
-      vv.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
+      const float4 vv = nl_ln_elu4(acc[rt][4 * gq + 0], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3], mean, rstd, g4, be4);
       if (p_c && mok) *(float4*)(orow_p + n) = vv;   // p_c == null: only the density head's output is wanted
       if (a.ep_sig_w) {
         const float4 w4 = *(const float4*)(sbias + NRT * 32 + 32 + n);
@@ -898,8 +898,9 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
     for (int gq = 0; gq < 4; ++gq) {
       const int n = 32 * rt + 8 * gq + 4 * hh;
       const float4 b4 = *(const float4*)(sbias + n);
-      acc[rt][4 * gq + 0] += b4.x; acc[rt][4 * gq + 1] += b4.y; acc[rt][4 * gq + 2] += b4.z; acc[rt][4 * gq + 3] += b4.w;
-      s1 += (acc[rt][4 * gq + 0] + acc[rt][4 * gq + 1]) + (acc[rt][4 * gq + 2] + acc[rt][4 * gq + 3]);
+      nl_f32x2 p0, p1;
+      nl_bias_sum4(acc[rt][4 * gq + 0], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3], b4, p0, p1, s1);
+      acc[rt][4 * gq + 0] = p0[0]; acc[rt][4 * gq + 1] = p0[1]; acc[rt][4 * gq + 2] = p1[0]; acc[rt][4 * gq + 3] = p1[1];
     }
   s1 = wave_sum(s1);
   if (lane == 0) red[wave] = s1;
@@ -909,11 +910,15 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
   for (int w = 0; w < NW; ++w) tot += red[w];
   const float cnt = (float)a.So * (float)a.N;
   const float mean = tot / cnt;
-  float s2 = 0.f;
+  float s2;
+  {
+    nl_f32x2 sp = {0.f, 0.f};
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+      for (int r = 0; r < 16; r += 2) nl_sumsq_dev2(sp, acc[rt][r], acc[rt][r + 1], mean);
+    s2 = sp[0] + sp[1];
+  }
   s2 = wave_sum(s2);
   if (lane == 0) red[NW + wave] = s2;
   __syncthreads();
@@ -931,14 +936,10 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
     for (int gq = 0; gq < 4; ++gq) {
       const int n = 32 * rt + 8 * gq + 4 * hh;
       const float4 g4 = *(const float4*)(grow + (rt * 4 + gq) * 256), be4 = *(const float4*)(brow + (rt * 4 + gq) * 256);
-      float4 v;
-      v.x = nl_elu_fast((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x);
-      v.y = nl_elu_fast((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y);
-      v.z = nl_elu_fast((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z);
-      v.w = nl_elu_fast((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w);
+      float4 v = nl_ln_elu4(acc[rt][4 * gq + 0], acc[rt][4 * gq + 1], acc[rt][4 * gq + 2], acc[rt][4 * gq + 3], mean, rstd, g4, be4);
       if (pool) {
-        v.x = fmaxf(v.x, nl_dpp<0xB1>(v.x, v.x)); v.y = fmaxf(v.y, nl_dpp<0xB1>(v.y, v.y));
-        v.z = fmaxf(v.z, nl_dpp<0xB1>(v.z, v.z)); v.w = fmaxf(v.w, nl_dpp<0xB1>(v.w, v.w));
+        v.x = nl_max_lane_xor1(v.x); v.y = nl_max_lane_xor1(v.y);
+        v.z = nl_max_lane_xor1(v.z); v.w = nl_max_lane_xor1(v.w);
       }
       if (mok && (!pool || !(j & 1))) *(float4*)(orow_p + n) = v;
     }
@@ -1130,10 +1131,9 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
     if (step < 4) {
       const int gq = step;
       const float4 b4 = *(const float4*)(stab + 768 + 32 * rt + 8 * gq + 4 * hh);
-      acc[rt][4 * gq + 0] = nl_elu_fast(acc[rt][4 * gq + 0] + b4.x);
-      acc[rt][4 * gq + 1] = nl_elu_fast(acc[rt][4 * gq + 1] + b4.y);
-      acc[rt][4 * gq + 2] = nl_elu_fast(acc[rt][4 * gq + 2] + b4.z);
-      acc[rt][4 * gq + 3] = nl_elu_fast(acc[rt][4 * gq + 3] + b4.w);
+      const nl_f32x2 e0 = nl_elu_fast2(nl_f32x2{acc[rt][4 * gq + 0], acc[rt][4 * gq + 1]} + nl_f32x2{b4.x, b4.y});
+      const nl_f32x2 e1 = nl_elu_fast2(nl_f32x2{acc[rt][4 * gq + 2], acc[rt][4 * gq + 3]} + nl_f32x2{b4.z, b4.w});
+      acc[rt][4 * gq + 0] = e0[0]; acc[rt][4 * gq + 1] = e0[1]; acc[rt][4 * gq + 2] = e1[0]; acc[rt][4 * gq + 3] = e1[1];
     } else if (QUERY && step < 6) {
       const int sI = step - 4;
       const float u[8] = {acc[rt][8 * sI], acc[rt][8 * sI + 1], acc[rt][8 * sI + 2], acc[rt][8 * sI + 3],
@@ -1256,18 +1256,21 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
       if constexpr (kd == CK_FC && Geo::last(c)) {
         // ---- (fc + residual) -> LayerNorm(row) * aggregation scale -> feature_agg: into `fa` for the scheduled stores, and split
         // to bf16 as the next products' B operand
-        float s1 = 0.f;
+        // (the element-wise arithmetic of this epilogue on pairs: packed fp32 instructions, the same operations per element)
+        nl_f32x2 sp1 = {0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-          for (int r = 0; r < 16; r += 4) s1 += (acc[rt][r] + acc[rt][r + 1]) + (acc[rt][r + 2] + acc[rt][r + 3]);
+          for (int r = 0; r < 16; r += 4) sp1 += nl_f32x2{acc[rt][r], acc[rt][r + 1]} + nl_f32x2{acc[rt][r + 2], acc[rt][r + 3]};
+        float s1 = sp1[0] + sp1[1];
         s1 += __shfl_xor(s1, 32, 64);
         const float mean = s1 / 256.f;
-        float s2 = 0.f;
+        nl_f32x2 sp2 = {0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { const float d = acc[rt][r] - mean; s2 += d * d; }
+          for (int r = 0; r < 16; r += 2) nl_sumsq_dev2(sp2, acc[rt][r], acc[rt][r + 1], mean);
+        float s2 = sp2[0] + sp2[1];
         s2 += __shfl_xor(s2, 32, 64);
         const float rstd = 1.f / sqrtf(s2 / 256.f + a.eps);
         const float sc = a.wscale[mm_c];
@@ -1278,10 +1281,10 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           for (int gq = 0; gq < 4; ++gq) {
             const int n = 32 * rt + 8 * gq + 4 * hh;
             const float4 g4 = *(const float4*)(stab + n), be4 = *(const float4*)(stab + 256 + n);
-            v[4 * gq + 0] = ((acc[rt][4 * gq + 0] - mean) * rstd * g4.x + be4.x) * sc;
-            v[4 * gq + 1] = ((acc[rt][4 * gq + 1] - mean) * rstd * g4.y + be4.y) * sc;
-            v[4 * gq + 2] = ((acc[rt][4 * gq + 2] - mean) * rstd * g4.z + be4.z) * sc;
-            v[4 * gq + 3] = ((acc[rt][4 * gq + 3] - mean) * rstd * g4.w + be4.w) * sc;
+            const nl_f32x2 mm = {mean, mean}, rr = {rstd, rstd}, ss = {sc, sc};
+            const nl_f32x2 p0 = ((nl_f32x2{acc[rt][4 * gq + 0], acc[rt][4 * gq + 1]} - mm) * rr * nl_f32x2{g4.x, g4.y} + nl_f32x2{be4.x, be4.y}) * ss;
+            const nl_f32x2 p1 = ((nl_f32x2{acc[rt][4 * gq + 2], acc[rt][4 * gq + 3]} - mm) * rr * nl_f32x2{g4.z, g4.w} + nl_f32x2{be4.z, be4.w}) * ss;
+            v[4 * gq + 0] = p0[0]; v[4 * gq + 1] = p0[1]; v[4 * gq + 2] = p1[0]; v[4 * gq + 3] = p1[1];
           }
 #pragma unroll
           for (int sI = 0; sI < 2; ++sI) {   // accumulator registers 8 s .. 8 s + 7 of row tile rt = k-step 2 rt + s in accumulator order
@@ -1306,8 +1309,9 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
               const int n = 32 * rt + 8 * gq + 4 * hh;
               const float4 b4 = *(const float4*)(stab + 512 + n);
               float (&v)[16] = fa[rt % (QUERY ? 4 : 8)];
-              v[4 * gq] = nl_lrelu(acc[rt][4 * gq] + b4.x); v[4 * gq + 1] = nl_lrelu(acc[rt][4 * gq + 1] + b4.y);
-              v[4 * gq + 2] = nl_lrelu(acc[rt][4 * gq + 2] + b4.z); v[4 * gq + 3] = nl_lrelu(acc[rt][4 * gq + 3] + b4.w);
+              const nl_f32x2 l0 = nl_lrelu2(nl_f32x2{acc[rt][4 * gq], acc[rt][4 * gq + 1]} + nl_f32x2{b4.x, b4.y});
+              const nl_f32x2 l1 = nl_lrelu2(nl_f32x2{acc[rt][4 * gq + 2], acc[rt][4 * gq + 3]} + nl_f32x2{b4.z, b4.w});
+              v[4 * gq] = l0[0]; v[4 * gq + 1] = l0[1]; v[4 * gq + 2] = l1[0]; v[4 * gq + 3] = l1[1];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;

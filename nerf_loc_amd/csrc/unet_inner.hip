@@ -25,6 +25,17 @@
 typedef __bf16 ui_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 ui_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float ui_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ui_f32x2 __attribute__((ext_vector_type(2)));
+#ifndef UI_PK
+#define UI_PK 1   // the epilogue's element-wise arithmetic on pairs (v_pk_add_f32 / v_pk_mul_f32: the same operations in the same order per element, half the instructions); 0 = scalar
+#endif
+// ELU of a pair (nl_elu_fast per element; the scale by log2(e) and the -1 packed)
+__device__ __forceinline__ ui_f32x2 ui_elu2(ui_f32x2 x) {
+  const ui_f32x2 y = x * ui_f32x2{1.4426950408889634f, 1.4426950408889634f};
+  ui_f32x2 e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+  e = e - ui_f32x2{1.f, 1.f};
+  return ui_f32x2{__builtin_amdgcn_fmed3f(x[0], e[0], 0.f), __builtin_amdgcn_fmed3f(x[1], e[1], 0.f)};
+}
 
 namespace {
 
@@ -138,9 +149,9 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ray == 0 || two) v = *reinterpret_cast<const float4*>(a.c1 + ((size_t)(ray0 + ray) * 64 + row) * 64 + 4 * c4);
     const float f[4] = {v.x, v.y, v.z, v.w};
-    ui_bf16x4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const __bf16 x = (__bf16)f[e]; h[e] = x; l[e] = (__bf16)(f[e] - (float)x); }
+    unsigned hw[2], lw[2];
+    nl_split_bf16_pair(f[0], f[1], hw[0], lw[0]); nl_split_bf16_pair(f[2], f[3], hw[1], lw[1]);
+    const ui_bf16x4 h = __builtin_bit_cast(ui_bf16x4, make_uint2(hw[0], hw[1])), l = __builtin_bit_cast(ui_bf16x4, make_uint2(lw[0], lw[1]));
     char* dst = lds + OFF_C1 + (ray * 2) * PL_C1 + (row + 1) * STR64 + 8 * c4;
     *reinterpret_cast<ui_bf16x4*>(dst) = h;
     if (X3) *reinterpret_cast<ui_bf16x4*>(dst + PL_C1) = l;
@@ -263,8 +274,16 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const float4 b4 = UI_LNPRE ? bias4[gq] : *reinterpret_cast<const float4*>(a.bias[ID] + 32 * ct + 8 * gq + 4 * hh);
+        if constexpr (UI_PK) {
+          const ui_f32x2 p0 = ui_f32x2{acc[ti][4 * gq + 0], acc[ti][4 * gq + 1]} + ui_f32x2{b4.x, b4.y};
+          const ui_f32x2 p1 = ui_f32x2{acc[ti][4 * gq + 2], acc[ti][4 * gq + 3]} + ui_f32x2{b4.z, b4.w};
+          acc[ti][4 * gq + 0] = p0[0]; acc[ti][4 * gq + 1] = p0[1]; acc[ti][4 * gq + 2] = p1[0]; acc[ti][4 * gq + 3] = p1[1];
+          const ui_f32x2 q = p0 + p1;
+          s += q[0] + q[1];
+        } else {
         acc[ti][4 * gq + 0] += b4.x; acc[ti][4 * gq + 1] += b4.y; acc[ti][4 * gq + 2] += b4.z; acc[ti][4 * gq + 3] += b4.w;
         s += (acc[ti][4 * gq + 0] + acc[ti][4 * gq + 1]) + (acc[ti][4 * gq + 2] + acc[ti][4 * gq + 3]);
+        }
       }
       s1[0] += rayl[ti] == 0 ? s : 0.f;
       s1[1] += rayl[ti] == 0 ? 0.f : s;
@@ -283,8 +302,16 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
     for (int ti = 0; ti < TPW; ++ti) {
       const float m = rayl[ti] == 0 ? mean[0] : mean[1];
       float s = 0.f;
+      if constexpr (UI_PK) {
+        ui_f32x2 sp = {0.f, 0.f};
+        const ui_f32x2 mm = {m, m};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { const ui_f32x2 d = ui_f32x2{acc[ti][r], acc[ti][r + 1]} - mm; sp += d * d; }
+        s = sp[0] + sp[1];
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const float d = acc[ti][r] - m; s += d * d; }
+      }
       s2[0] += rayl[ti] == 0 ? s : 0.f;
       s2[1] += rayl[ti] == 0 ? 0.f : s;
     }
@@ -314,13 +341,20 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
         const float4 g4 = UI_LNPRE ? gpre[ti][gq] : *reinterpret_cast<const float4*>(gp + gq * 256);
         const float4 be4 = UI_LNPRE ? bpre[ti][gq] : *reinterpret_cast<const float4*>(bp + gq * 256);
         float v[4];
+        if constexpr (UI_PK) {
+          const ui_f32x2 mm = {m, m}, rr = {rs, rs};
+          const ui_f32x2 p0 = ui_elu2((ui_f32x2{acc[ti][4 * gq + 0], acc[ti][4 * gq + 1]} - mm) * rr * ui_f32x2{g4.x, g4.y} + ui_f32x2{be4.x, be4.y});
+          const ui_f32x2 p1 = ui_elu2((ui_f32x2{acc[ti][4 * gq + 2], acc[ti][4 * gq + 3]} - mm) * rr * ui_f32x2{g4.z, g4.w} + ui_f32x2{be4.z, be4.w});
+          v[0] = p0[0]; v[1] = p0[1]; v[2] = p1[0]; v[3] = p1[1];
+        } else {
         v[0] = nl_elu_fast((acc[ti][4 * gq + 0] - m) * rs * g4.x + be4.x);
         v[1] = nl_elu_fast((acc[ti][4 * gq + 1] - m) * rs * g4.y + be4.y);
         v[2] = nl_elu_fast((acc[ti][4 * gq + 2] - m) * rs * g4.z + be4.z);
         v[3] = nl_elu_fast((acc[ti][4 * gq + 3] - m) * rs * g4.w + be4.w);
+        }
         if constexpr (L::POOL) {   // positions 2 p, 2 p + 1 are neighbouring lanes
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], nl_dpp<0xB1>(v[e], v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = nl_max_lane_xor1(v[e]);
         }
         const int n = 32 * ct + 8 * gq + 4 * hh;          // first of this lane's four output columns
         constexpr int CO = L::TRANS ? N / 2 : N;
@@ -332,9 +366,9 @@ __global__ __launch_bounds__(512, 1) void unet_inner_kernel(const NlUnetInnerArg
             *reinterpret_cast<float4*>(a.x2 + ((size_t)(ray0 + rayl[ti]) * 128 + pos) * 32 + ch) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           if (!L::POOL || !(j & 1)) {
-            ui_bf16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const __bf16 x = (__bf16)v[e]; h[e] = x; l[e] = (__bf16)(v[e] - (float)x); }
+            unsigned hw[2], lw[2];
+            nl_split_bf16_pair(v[0], v[1], hw[0], lw[0]); nl_split_bf16_pair(v[2], v[3], hw[1], lw[1]);
+            const ui_bf16x4 h = __builtin_bit_cast(ui_bf16x4, make_uint2(hw[0], hw[1])), l = __builtin_bit_cast(ui_bf16x4, make_uint2(lw[0], lw[1]));
             constexpr int so = L::OUT >= 0 ? L::OUT : 0;
             char* dst = lds + slab_off(so) + (rayl[ti] * 2) * slab_pl(so) + (pos + 1) * slab_str(so) + 2 * ch;
             *reinterpret_cast<ui_bf16x4*>(dst) = h;
