@@ -29,10 +29,13 @@ typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned mf_u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef MF_KO
-#define MF_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no texel loads in phase B, 2 no phase B, 4 no colour taps in phase A, 8 no MFMA phase, 16 no staging writes, 64 every texel fetch from texel 0 (all cache hits)
+#define MF_KO 0   // knock-out bits for timing experiments (results are garbage): 1 no texel loads in phase B, 2 no phase B, 4 no colour taps in phase A, 8 no MFMA phase, 16 no staging writes, 64 every texel fetch from texel 0 (all cache hits), 128 phase A's inputs computed instead of loaded (what fetching them a round ahead could return at most)
 #endif
 #ifndef MF_PK
 #define MF_PK 1   // phase B's channel pairs on the packed-fp32 instructions (round 6); 0 = one scalar FMA per channel
+#endif
+#ifndef MF_AHEAD
+#define MF_AHEAD 0   // 1 = phase A's inputs fetched across the previous round's matrix phase: measured 870 -> 920 us (the five registers spill loop invariants to scratch, whose reloads drain vmcnt: round 6); 0 = loaded where they are used
 #endif
 #ifndef MF_CPL
 #define MF_CPL 3
@@ -117,6 +120,19 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
   const int r_begin = lb * rounds_per_block, r_end = min(nrounds, r_begin + rounds_per_block);
   float* myslots = slots + (size_t)wave * 4 * 16 * MF_SLOT;
 
+  // the round's per-(sample, view) inputs (position, visibility, depth difference) are fetched while the PREVIOUS round's out_fc.0 phase runs (round 6): phase A otherwise
+  // starts with a global-memory latency at two waves per SIMD, and in that phase the accumulators and texel rows of phase B are dead, so five registers cost nothing
+  auto load_in = [&](int round, float& X, float& Y, float& Z, float& vis, float& dd) __attribute__((always_inline)) {
+    const int s = lane >> 4, v = lane & 15;
+    const int n = round * MF_NS + wave * 4 + s;
+    const int nn = n < N ? n : N - 1;
+    const int vl = v < V ? v : 0;
+    X = xyz[3 * (size_t)nn]; Y = xyz[3 * (size_t)nn + 1]; Z = xyz[3 * (size_t)nn + 2];
+    const unsigned vo = (unsigned)vl * (unsigned)N + (unsigned)nn;   // V N < 2^31 (nl_mv_front_supported): a 32-bit offset from the scalar base, no hoisted 64-bit lane pointer
+    vis = vis_in[vo]; dd = dd_in[vo];
+  };
+  float nX = 0.f, nY = 0.f, nZ = 0.f, nvis = 0.f, ndd = 0.f;
+  if (MF_AHEAD && r_begin < r_end) load_in(r_begin, nX, nY, nZ, nvis, ndd);
   for (int round = r_begin; round < r_end; ++round) {
     const int n0 = round * MF_NS + wave * 4;
     // ---------------------------------------------------------------- phase A: lane = (sample s, view v)
@@ -128,7 +144,10 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
       const int nn = live ? n : N - 1;
       const bool vact = v < V;
       const int vl = vact ? v : 0;
-      const float X = xyz[3 * (size_t)nn], Y = xyz[3 * (size_t)nn + 1], Z = xyz[3 * (size_t)nn + 2];
+      float X, Y, Z, vis_l = 0.f, dd_l = 0.f;
+      if (MF_KO & 128) { X = 0.25f + 1e-6f * (float)nn; Y = 0.5f - 1e-6f * (float)nn; Z = 1.f + 2e-6f * (float)nn; }   // (knock-out 128: phase A's position / visibility / depth-difference inputs without memory)
+      else if (MF_AHEAD) { X = nX; Y = nY; Z = nZ; vis_l = nvis; dd_l = ndd; }
+      else load_in(round, X, Y, Z, vis_l, dd_l);
       const float4 p0 = *(const float4*)(viewsdev + 12 * vl), p1 = *(const float4*)(viewsdev + 12 * vl + 4), p2 = *(const float4*)(viewsdev + 12 * vl + 8);
       const float cx = fmaf(p0.z, Z, fmaf(p0.y, Y, p0.x * X)) + p0.w;
       const float cy = fmaf(p1.z, Z, fmaf(p1.y, Y, p1.x * X)) + p1.w;
@@ -161,8 +180,8 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
         }
       }
       const unsigned vo = (unsigned)vl * (unsigned)N + (unsigned)nn;   // V N < 2^31 (nl_mv_front_supported): a 32-bit offset from the scalar base, no hoisted 64-bit lane pointer
-      const float vis = vact ? vis_in[vo] : 0.f;
-      const float dd = vact ? dd_in[vo] : 0.f;
+      const float vis = (MF_KO & 128) ? (vact ? 0.125f + 1e-7f * (float)vo : 0.f) : (vact ? vis_l : 0.f);
+      const float dd = (MF_KO & 128) ? 0.01f : (vact ? dd_l : 0.f);
       const float vsum = mf_sum16(vis);
       const float wgt = vis / (vsum + 1e-8f);
       vmask = 0;
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(64 * MF_NWAVES, 1) void mv_front_kernel(const NlVie
         }
       }
     }
+    if (MF_AHEAD && round + 1 < r_end) load_in(round + 1, nX, nY, nZ, nvis, ndd);   // (in flight across the staging writes, both barriers and the matrix phase)
     // every wave is through with the previous round's staging tile (its MFMA phase ended at a barrier) — this round's rows may be written
 #pragma unroll
     for (int s = 0; s < ((MF_KO & 16) ? 0 : 4); ++s) {
