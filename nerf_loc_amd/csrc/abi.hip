@@ -52,7 +52,8 @@ int nl_launch_coarse_weights(const NlViews& vw, const float* w2c_kinv_host, cons
 int nl_launch_sample_pdf(const float* zc, const float* wc, int Sc, const float* u, int Ni, const float* zb, int Sb, int64_t R,
                          float* z_out, hipStream_t st);
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s, int64_t R, int S, int C,
-                        int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst, hipStream_t st, const int* n_alive = nullptr);
+                        int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst, hipStream_t st, const int* n_alive = nullptr,
+                        float* w_scratch = nullptr);
 
 size_t nl_point_stream_bytes(int W);
 int nl_pack_point_stream(const float* w1, const float* w2, const float* w3, const float* wk, const float* wv, void* out, int W, int F, hipStream_t st);
@@ -203,6 +204,7 @@ struct Layout {
   size_t rd_w, dec_w, sig_w, sig_b, bl2_w, bl2_b, bl4_w, bl4_b, ln_g, ln_b;
   size_t pt_stream, pt_stream2, pt_stream2_mx, pt_stream2_f16, pt_bwd_stream, pt_mx_sc, mvf_pack, pt_bias, blw, dec_mfma, zeros;   // blw: [32][8] rgb/vis/angle columns of rgb_blending_mlp.0 + bias[32]  // fused point-branch weight stream (W in {64,128,256}) and its 3 bias rows
   size_t mx_convout;   // NL_PREC_F16MX (round 6): fp6 images + block scales of G_CONVOUTF for tgemm_mx_kernel (W = 256)
+  size_t mx_feat0;     // ... and of G_FEAT0P for feat_comp_mx_kernel (feat_mlp.0 + compositing in one kernel)
   size_t un_g[U_COUNT], un_b[U_COUNT];     // LayerNorm([C, L]) affine tables, position-major (L, C)
   size_t un_gl[U_COUNT], un_bl[U_COUNT];   // the same tables in the accumulator-lane order of the GEMM that fuses the LayerNorm (un_n x un_so)
   int un_c[U_COUNT], un_l[U_COUNT], un_n[U_COUNT], un_so[U_COUNT];
@@ -325,6 +327,7 @@ Layout make_layout(const nl_config* c) {
   L.mvf_pack = take(nl_mv_front_pack_bytes());                                          // out_fc.0 as register-resident A fragments of mv_front_kernel (C = 192)                                                            // their per-chunk scale bytes while packing
   L.zeros = take(4096);
   L.mx_convout = take(W == 256 ? nl_tgemm_mx_image_bytes(L.g[G_CONVOUTF].Kpad) : 0);
+  L.mx_feat0 = take(W == 256 ? nl_tgemm_mx_image_bytes(L.g[G_FEAT0P].Kpad) : 0);
   L.total = off;
   return L;
 }
@@ -1583,16 +1586,26 @@ int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const f
 
 int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
              const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false,
-             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0, const BlendTaps* bt = nullptr) {
+             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0, const BlendTaps* bt = nullptr, bool feat_late = false) {
   const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
   if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
   const bool want_feat = out->feat != nullptr;
   const bool term = term_eps > 0.f && !pre_done;
   if (term) NL_TRY(nl_launch_termination(z, h.sigma, R, S, term_eps, h.n_alive, h.tile_list, h.tile_count, x.st));
+  if (feat_late) {
+    // f16mx, W = 256, FA = the chain kernel's fragment image: feat_mlp.0's hidden rows are never materialised — the compositing pass leaves the samples' weights
+    // (in the caller's `weights` output, or in the buffer the hidden rows would have taken) and feat_comp_mx_kernel multiplies, activates, weights and sums in one go
+    if (!want_feat || term || pre_done || (chain_parts & 1)) return NL_ERR_BAD_ARG;
+    NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, false, h, 6 & ~chain_parts, false, bt));
+    float* wts = out->weights ? out->weights + ray0 * S : h.fth;
+    NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, nullptr, valid_s, R, S, W, white, out, ray0, nullptr, h.wsum, x.st, nullptr, out->weights ? nullptr : h.fth));
+    NL_TRY(nl_launch_feat_comp_mx(FA, wts, N, S, x.pk + x.L.bsh[G_FEAT0P], x.pk + x.L.mx_feat0, x.p<float>(x.L.bias[G_FEAT0P]), h.hc, x.st));
+  } else {
   if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7 & ~chain_parts, term, bt));   // chain_parts: what the chain kernel already produced
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
                              want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st, term ? h.n_alive : nullptr));
+  }
   if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
     SegSpec s1[2] = {{h.hc, W, W, 0, 1}, {h.wsum, 1, 1, 0, 1}};
     NL_TRY(run_gemm(x, G_FEAT2, s1, 2, R, out->feat + ray0 * C, C, NL_ACT_NONE));
@@ -1926,6 +1939,12 @@ int nl_pack_weights(const nl_config* cfg, const float* const* t, int n, void* pa
   if (W % 32 == 0) {   // accumulator-order copies for the chain kernel
     P.block(G_FEAT0P, 0, t[T_F0W], 0, W, 1, W, 1);
     P.copy(t[T_F0B], L.bias[G_FEAT0P], W);
+    if (W == 256) {   // NL_PREC_F16MX: feat_mlp.0's fp6 images for feat_comp_mx_kernel (K in accumulator order = the order of feature_agg's fragment image)
+      const GemmDim& d = L.g[G_FEAT0P];
+      const int nslab = (d.Kpad / 32 + 1) / 2;
+      hipLaunchKernelGGL(pack_tgemm_mx6_kernel, dim3((unsigned)nl_cdiv((int64_t)nslab * 1024, 256)), dim3(256), 0, st, (const float*)((char*)packed + L.b32[G_FEAT0P]), d.Kpad, d.Npad,
+                         d.N, nslab, (unsigned char*)packed + L.mx_feat0);
+    }
     P.block(G_BLENDAP, 0, t[T_BL0W], 0, W + F + 5, 1, W, 1);
     P.block(G_QP, 0, t[T_WQ], 0, W, 1, W, 1);
   }
@@ -2602,12 +2621,29 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
     // feature_agg has two consumers left on this path — conv1 and conv_out, three taps each: the chain kernel hands it over as the split-bf16 fragments it
     // holds anyway (same bytes in the same buffer) unless someone wants the fp32 rows: the stage output, or feat_mlp.0 over the live tiles of an early-terminated batch
     const bool fa_frag = use_chain && !dbg_switch("NERFLOC_NO_FRAG") && (N & 31) == 0 && !out->feature_agg && !(want_feat && term_eps > 0.f);
-    const ChainOut chain{(want_feat && term_eps == 0.f) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag};
+    // f16mx: feat_mlp.0 leaves the chain kernel — it runs after the density, fused with the compositing of its rows (do_heads: feat_late)
+    const bool feat_late = want_feat && term_eps == 0.f && fa_frag && x.mx && ((x.has_bsh >> G_FEAT0P) & 1) && nl_feat_comp_mx_supported(W, S, N) &&
+                           !dbg_switch("NERFLOC_NO_FEAT_COMP");
+    const ChainOut chain{(want_feat && term_eps == 0.f && !feat_late) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
-    const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f ? 1 : 0) | 2) : 0;
+    const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f && !feat_late ? 1 : 0) | 2) : 0;
+    // the colour-blend taps (a latency chain per view: gathers, ~77 registers) need the chain kernel's projection rows and the front end's outputs, not the density:
+    // they run on the frame's side stream beside the ray U-Net's matrix kernels and join in front of the compositing pass
+    SideJoin blend;
+    int side_parts = 0;
+    if (fork && !knn.armed && chain_done && front && term_eps == 0.f && !dbg_switch("NERFLOC_NO_BLEND_SIDE")) {
+      NL_CHECK_HIP(hipEventRecord(f->ev_fork, x.st));
+      NL_CHECK_HIP(hipStreamWaitEvent(f->side, f->ev_fork, 0));
+      blend.arm(x.st, f->side, f->ev_join);
+      Ctx xs = x; xs.st = f->side;
+      NL_TRY(do_heads_pre(xs, V, rb.FA, nullptr, rb.rgbv, N, false, rb.hd, 4, false, &bt));
+      side_parts = 4;
+    }
     bool have_sigma = false;
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag, true));
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt));
+    NL_TRY(blend.join());
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps,
+                    chain_parts | side_parts, &bt, feat_late && chain_done));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -260,3 +260,7 @@ int nl_tgemm_nrt(int N);
 size_t nl_tgemm_stream_bytes(int Kpad, int N);
 bool nl_tgemm_supported(const NlGemmArgs& a, int precision);
 int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);
+// feat_mlp.0 + LeakyReLU + the compositing of its rows along the ray in the f16mx arithmetic (tgemm.hip: feat_comp_mx_kernel): hc (N / S, 256) from feature_agg's
+// fragment image, the samples' compositing weights, G_FEAT0P's fp16 stream and its fp6 images
+bool nl_feat_comp_mx_supported(int W, int S, int64_t N);
+int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st);

@@ -581,13 +581,13 @@ int nl_launch_blend_taps(const NlViews& vw, const float* viewsdev, const float* 
 // `ft` (R*S, C) is composited into feat_dst (R, C) (any channel count; the caller passes feat_mlp's hidden layer, see abi.hip)
 int nl_launch_composite(const float* z_vals, const float* sigma, const float* rgb_s, const float* ft, const int* valid_s,
                         int64_t R, int S, int C, int white_bkgd, const nl_render_out* out, int64_t ray0, float* feat_dst, float* wsum_dst,
-                        hipStream_t st, const int* n_alive) {
+                        hipStream_t st, const int* n_alive, float* w_scratch) {
   if (R <= 0) return NL_OK;
   if (S > 256) return NL_ERR_UNSUPPORTED;
   dim3 grid((unsigned)nl_cdiv(R, 4));
   float* o_rgb = out->rgb ? out->rgb + 3 * ray0 : nullptr;
   float* o_depth = out->depth ? out->depth + ray0 : nullptr;
-  float* o_w = out->weights ? out->weights + ray0 * S : nullptr;
+  float* o_w = out->weights ? out->weights + ray0 * S : w_scratch;   // (w_scratch: the samples' weights for feat_comp_mx_kernel when the caller does not take them)
   unsigned char* o_mask = out->mask ? out->mask + ray0 : nullptr;
   float* o_unc = out->depth_uncertainty ? out->depth_uncertainty + ray0 : nullptr;
 #define NL_COMP(CH) hipLaunchKernelGGL(composite_kernel<CH>, grid, dim3(256), 0, st, z_vals, sigma, rgb_s, ft, valid_s, (int)R, S, C, \

@@ -778,6 +778,192 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
 
 
 // ====================================================================================================================
+// feat_mlp.0 + LeakyReLU + the compositing of its rows along the ray as ONE kernel in the f16mx arithmetic (round 6; NL_PREC_F16MX, W = 256):
+//   hc[ray][c] = sum_s w_s LeakyReLU(feat_mlp.0 . feature_agg_s + b)[c]          (model.py:594-597 composites feat_mlp's output; its last Linear is applied afterwards:
+// abi.hip do_heads).  Before, the chain kernel ran feat_mlp.0 as 8 of its 22 chunks (three-term split-bf16: 384 of a tile's 720 matrix instructions), wrote the hidden rows
+// (N x 256 fp32 = 0.54 GB at config 2) and composite_kernel read them back to weight and sum them.  Here the product runs AFTER the density is known, with the weights of
+// the samples at hand: the hidden rows are never written, feature_agg's fragment image (which conv1 and conv_out read anyway) is read once more.
+// The main loop is tgemm_mx_kernel's with K = 256 (four 64-k slabs, chunks = the eight 32-channel blocks of the fragment image) and the two MFMA operands SWAPPED:
+// activations = A, weights = B, so the 32x32 tile comes out as D[sample][channel] — lane = channel, registers = the wave's 32 samples — and the sum over samples is 16
+// in-lane multiply-adds + one exchange with lane ^ 32 (in the transposed orientation of every other kernel here the samples live in lanes: 5 cross-lane steps for each
+// of 128 registers).  Same operand registers, same LDS images, same weight streams (G_FEAT0P's fp16 stream + its fp6 images: pack_tgemm_mx6_kernel).
+// A group = NW waves = NW x 32 consecutive samples = whole rays (S / 32 waves each); the waves of a ray add their partial sums in wave order through LDS.
+// Persistent: one workgroup per CU walks the groups blockIdx.x, + gridDim.x, ...; the last slab of a group stages the first slab of the next (four slabs: the ring's
+// slot parity carries over), so the exposed load latency of a group's first slab — a fifth of a group's time with 130 KB of LDS = one workgroup per CU — is paid once.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* __restrict__ fa, const float* __restrict__ wts, const int M, const int S,
+                                                                   const char* __restrict__ p_bsh, const char* __restrict__ p_bmx, const float* __restrict__ p_bias,
+                                                                   float* __restrict__ hc, const int ngroups) {
+  constexpr int NRT = TGMX_NRT;
+  __builtin_amdgcn_s_setreg(1473, 1);   // MODE.FP16_OVFL: saturating f32 -> f16 / fp6 conversions (tgemm_mx_kernel)
+  __shared__ uint4 lds_all[2 * TGMX_SLOT / 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, j = lane & 31;
+  const int ntiles = M >> 5;
+  auto tile_ptr = [&](int grp) __attribute__((always_inline)) {   // the fragment rows of this wave's tile of group grp (past the end: the last tile, with zero weights below)
+    const int tl = grp * NW + wave;
+    return fa + (size_t)(tl < ntiles ? tl : ntiles - 1) * 8192 + (j + 32 * hh) * 4;
+  };
+
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p_bsh, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmx = __builtin_amdgcn_make_buffer_rsrc((void*)p_bmx, 0, 0x7fffffff, 0x00020000);
+  const unsigned lane16 = lane * 16;
+  auto stage = [&](int sl, auto SLOTc) __attribute__((always_inline)) {   // weights of slab sl -> LDS slot (compile-time): 1-KB pieces by buffer LDS-DMA, dealt round-robin
+    constexpr int slot = decltype(SLOTc)::value;
+    const unsigned oA = (unsigned)(2 * sl) * (4 * NRT * 1024), oB = (unsigned)(2 * sl + 1) * (4 * NRT * 1024);   // the hi part (first 2 NRT KB) of each chunk of the fp16 stream
+    const unsigned oI = (unsigned)sl * TGMX_IMG;
+    tg_static_for<(TGMX_PIECES + NW - 1) / NW>([&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      const int pp = wave + NW * i;   // (wave-uniform)
+      if (TGMX_PIECES % NW == 0 || pp < TGMX_PIECES) {
+        auto* dst = (__attribute__((address_space(3))) void*)(lds_all + (slot * TGMX_SLOT) / 16 + pp * 64);
+        if (pp < 4 * NRT) {
+          unsigned so = pp < 2 * NRT ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
+          asm volatile("" : "+s"(so));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, dst, 16, lane16, so, 0, 0);
+        } else {
+          unsigned so = oI + (pp - 4 * NRT) * 1024;
+          asm volatile("" : "+s"(so));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rmx, dst, 16, lane16, so, 0, 0);
+        }
+      }
+    });
+  };
+  // activations: the chain kernel's fragment image — per 32-row tile 16 k-steps x 512 floats, a 32-channel block = [ks 0: hi | lo | ks 1: hi | lo] x (64 lanes x 4 floats)
+  const float* P = tile_ptr(blockIdx.x);
+  float4 raw[2][4];
+  auto load_act = [&](const float* Pt, int sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) raw[ci][pc] = *(const float4*)(Pt + (2 * sl + ci) * 1024 + 256 * pc);
+  };
+
+  stage(0, std::integral_constant<int, 0>{});
+  load_act(P, 0);
+  tg_wait_vmcnt<0>();
+  __syncthreads();
+
+  constexpr int NSC = 4;   // slabs of the layer (K = 256)
+  static_assert(NSC % 2 == 0, "the ring's slot parity must carry over from one group to the next");
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  const int tile = grp * NW + wave;
+  const bool live = tile < ntiles;
+  const int tile_c = live ? tile : ntiles - 1;
+  const float* Pn = tile_ptr(grp + (int)gridDim.x);   // (past the last group: re-reads the last tile, never used)
+  tg_f32x16 acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  auto slab = [&](auto Gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(Gc)::value, SL = g & 1;
+    // ---- this slab's A operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks); value = bf16 hi + bf16 lo
+    float v[32];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4 fh = raw[ci][2 * ks], fl = raw[ci][2 * ks + 1];
+        const unsigned uh[4] = {__float_as_uint(fh.x), __float_as_uint(fh.y), __float_as_uint(fh.z), __float_as_uint(fh.w)};
+        const unsigned ul[4] = {__float_as_uint(fl.x), __float_as_uint(fl.y), __float_as_uint(fl.z), __float_as_uint(fl.w)};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          v[16 * ci + 8 * ks + 2 * d] = __uint_as_float(uh[d] << 16) + __uint_as_float(ul[d] << 16);
+          v[16 * ci + 8 * ks + 2 * d + 1] = __uint_as_float(uh[d] & 0xffff0000u) + __uint_as_float(ul[d] & 0xffff0000u);
+        }
+      }
+    float amax = 0.f;
+    tg_u32x16 H;
+    float lo[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      H[i] = tg_hi2_f16_amax(v[2 * i], v[2 * i + 1], amax);
+      tg_lo2_f32(v[2 * i], v[2 * i + 1], H[i], lo[2 * i], lo[2 * i + 1]);
+    }
+    int eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // block scale as in tgemm_mx_kernel: the largest value lands in [4, 8)
+    eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);
+    const float scf = __builtin_bit_cast(float, eb << 23);
+    const tg_u32x6 xh6 = tg_cvt_pk32_fp6_f16(H, scf);
+    const tg_f32x16 le = {lo[0], lo[2], lo[4], lo[6], lo[8], lo[10], lo[12], lo[14], lo[16], lo[18], lo[20], lo[22], lo[24], lo[26], lo[28], lo[30]};
+    const tg_f32x16 lod = {lo[1], lo[3], lo[5], lo[7], lo[9], lo[11], lo[13], lo[15], lo[17], lo[19], lo[21], lo[23], lo[25], lo[27], lo[29], lo[31]};
+    const tg_u32x6 xl6 = tg_cvt_2xpk16_fp6_f32(le, lod, scf * 0.00048828125f);
+    const tg_i32x8 bh6 = {(int)xh6[0], (int)xh6[1], (int)xh6[2], (int)xh6[3], (int)xh6[4], (int)xh6[5], 0, 0};
+    const tg_i32x8 bl6 = {(int)xl6[0], (int)xl6[1], (int)xl6[2], (int)xl6[3], (int)xl6[4], (int)xl6[5], 0, 0};
+    const int sxh = eb, sxl = eb - 11;
+
+    // the next slab — of this group or the first of the next: weights into the other slot (every wave left it before the barrier that ended the previous iteration;
+    // after the last slab: before the barrier that ends the epilogue's reads of `red`), its raw words
+    if constexpr (g + 1 < NSC) { stage(g + 1, std::integral_constant<int, 1 - SL>{}); load_act(P, g + 1); }
+    else { stage(0, std::integral_constant<int, 1 - SL>{}); load_act(Pn, 0); }
+
+    // ---- the slab's product, weights read two units ahead (tgemm_mx_kernel); operands swapped: D[sample][channel]
+    const tg_u32x4* Lf = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT) / 16);
+    const tg_u32x4* La = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT + TGMX_F16B) / 16);
+    const tg_u32x4* Lb = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT + TGMX_F16B + TGMX_IMA) / 16);
+    tg_u32x4 ra[3], rb[3];
+    auto rdW = [&](auto Uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % 3;
+      if constexpr (k < 4) ra[r] = Lf[(k * NRT + rt) * 64 + lane];
+      else { ra[r] = La[(rt * 2 + (k - 4)) * 64 + lane]; rb[r] = Lb[(rt * 2 + (k - 4)) * 64 + lane]; }
+    };
+    rdW(std::integral_constant<int, 0>{});
+    rdW(std::integral_constant<int, 1>{});
+    tg_static_for<6 * NRT>([&](auto Uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % 3;
+      if constexpr (u + 2 < 6 * NRT) rdW(std::integral_constant<int, u + 2>{});
+      if constexpr (k < 4) {
+        const tg_f16x8 af = __builtin_bit_cast(tg_f16x8, (tg_u32x4){H[4 * k], H[4 * k + 1], H[4 * k + 2], H[4 * k + 3]});
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(tg_f16x8, ra[r]), acc[rt], 0, 0, 0);
+      } else {
+        const tg_i32x8 w6 = {(int)ra[r][0], (int)ra[r][1], (int)ra[r][2], (int)ra[r][3], (int)rb[r][0], (int)rb[r][1], 0, 0};
+        if constexpr (k == 4) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bl6, w6, acc[rt], 2, 2, 0, sxl, 0, (int)rb[r][2]);   // a_lo6 x w_hi6
+        else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bh6, w6, acc[rt], 2, 2, 0, sxh, 0, (int)rb[r][2]);                     // a_hi6 x w_lo6
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    tg_wait_vmcnt<0>();
+    __syncthreads();
+  };
+  tg_static_for<NSC>([&](auto Gc) __attribute__((always_inline)) { slab(Gc); });
+
+  // ---- epilogue.  Tile rt: lane (c, hh) holds channel 32 rt + c of the wave's rows m(r, hh) = (r & 3) + 8 (r >> 2) + 4 hh, r = 0 .. 15
+  const float* wrow = wts + (size_t)tile_c * 32 + 4 * hh;
+  nl_f32x2 wp[8];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    float4 w4 = *(const float4*)(wrow + 8 * gq);
+    if (!live) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    wp[2 * gq] = nl_f32x2{w4.x, w4.y}; wp[2 * gq + 1] = nl_f32x2{w4.z, w4.w};
+  }
+  float* red = reinterpret_cast<float*>(lds_all + TGMX_SLOT / 16);   // [NW][256] partial sums in slot 1: the last slab's, every wave passed its barrier (slot 0 is being filled)
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const float b = p_bias[32 * rt + j];
+    const nl_f32x2 bb = {b, b};
+    nl_f32x2 s = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) s = __builtin_elementwise_fma(nl_lrelu2(nl_f32x2{acc[rt][r], acc[rt][r + 1]} + bb), wp[r >> 1], s);
+    float p = s[0] + s[1];
+    p += __shfl_xor(p, 32, 64);
+    if (hh == 0) red[wave * 256 + 32 * rt + j] = p;
+  }
+  __syncthreads();
+  const int wpr = S >> 5, rays_wg = NW / wpr, R = M / S;
+  for (int i = tid; i < rays_wg * 256; i += 64 * NW) {
+    const int q = i >> 8, c = i & 255;
+    float sum = 0.f;
+    for (int w = 0; w < wpr; ++w) sum += red[(q * wpr + w) * 256 + c];
+    const int ray = grp * rays_wg + q;
+    if (ray < R) hc[(size_t)ray * 256 + c] = sum;
+  }
+  __syncthreads();   // `red` is read: the next group's first slab may stage slab 1 over it
+  P = Pn;
+  }
+}
+
+// ====================================================================================================================
 // conv1 of the ray U-Net (W = 256 -> 64, k = 3, S = 128; round 6): `tgemm_kernel<2, 4, .., NL_EPI_LNSLAB>` ran this layer at ~2 k cycles per 32-k chunk for 12 matrix
 // instructions of 32 — the chunk loop fetches one chunk ahead (weights through registers into LDS, a barrier per chunk), which covers 384 cycles of a ~1.5 k-cycle load.
 // With 64 output columns the accumulators are 32 registers, so this kernel can afford what the 256-wide one cannot: the raw activation words of THREE chunks in flight
@@ -1503,5 +1689,22 @@ int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, co
   a.wbase = (const char*)wbase; a.M = (int)M; a.T64 = T64; a.off_g2 = (unsigned)off_g2; a.off_q = (unsigned)off_q; a.bias_g2 = bias_g2; a.Q = Q;
   if (precision == NL_PREC_BF16X3) hipLaunchKernelGGL((sample_chain_kernel<true, false, true>), grid, dim3(256), 0, st, a, ntiles);
   else hipLaunchKernelGGL((sample_chain_kernel<false, false, true>), grid, dim3(256), 0, st, a, ntiles);
+  return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+
+// feat_mlp.0 + LeakyReLU + compositing along the ray (feat_comp_mx_kernel): W = 256, rays of 32 .. 256 samples whose waves divide a workgroup of 8 or 6
+bool nl_feat_comp_mx_supported(int W, int S, int64_t N) {
+  if (W != 256 || S < 32 || (S & 31) || N <= 0 || (N & 31) || N % S || N * 256 > 0x7fffffffll * 4) return false;
+  const int wpr = S >> 5;
+  return (8 % wpr) == 0 || (6 % wpr) == 0;
+}
+int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st) {
+  if (!nl_feat_comp_mx_supported(256, S, N) || !fa_frag || !wts || !bsh || !bmx || !bias || !hc || (((size_t)wts) & 15)) return NL_ERR_UNSUPPORTED;
+  const int wpr = S >> 5, nw = (8 % wpr) == 0 ? 8 : 6;
+  const int ngroups = (int)nl_cdiv(N, 32 * nw);
+  dim3 grid;
+  if (chain_grid(ngroups, &grid) != NL_OK) return NL_ERR_HIP;   // one workgroup per CU (130 KB of LDS), XCD-aware when there are fewer groups than CUs
+  if (nw == 8) hipLaunchKernelGGL(feat_comp_mx_kernel<8>, grid, dim3(64 * 8), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups);
+  else hipLaunchKernelGGL(feat_comp_mx_kernel<6>, grid, dim3(64 * 6), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
