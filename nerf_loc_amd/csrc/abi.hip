@@ -2627,23 +2627,12 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
     const ChainOut chain{(want_feat && term_eps == 0.f && !feat_late) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f && !feat_late ? 1 : 0) | 2) : 0;
-    // the colour-blend taps (a latency chain per view: gathers, ~77 registers) need the chain kernel's projection rows and the front end's outputs, not the density:
-    // they run on the frame's side stream beside the ray U-Net's matrix kernels and join in front of the compositing pass
-    SideJoin blend;
-    int side_parts = 0;
-    if (fork && !knn.armed && chain_done && front && term_eps == 0.f && !dbg_switch("NERFLOC_NO_BLEND_SIDE")) {
-      NL_CHECK_HIP(hipEventRecord(f->ev_fork, x.st));
-      NL_CHECK_HIP(hipStreamWaitEvent(f->side, f->ev_fork, 0));
-      blend.arm(x.st, f->side, f->ev_join);
-      Ctx xs = x; xs.st = f->side;
-      NL_TRY(do_heads_pre(xs, V, rb.FA, nullptr, rb.rgbv, N, false, rb.hd, 4, false, &bt));
-      side_parts = 4;
-    }
     bool have_sigma = false;
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag, true));
-    NL_TRY(blend.join());
-    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps,
-                    chain_parts | side_parts, &bt, feat_late && chain_done));
+    // (The colour-blend taps on the frame's side stream beside the ray U-Net's kernels — they need the chain kernel's projection rows, not the density — measured
+    // neutral: conv1 stretches by what the taps take, 7.396 -> 7.387 ms; profiles/r6_blend_side_stream.txt.  Not kept.)
+    NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt,
+                    feat_late && chain_done));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
