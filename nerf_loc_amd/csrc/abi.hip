@@ -2629,8 +2629,9 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f && !feat_late ? 1 : 0) | 2) : 0;
     bool have_sigma = false;
     NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag, true));
-    // (The colour-blend taps on the frame's side stream beside the ray U-Net's kernels — they need the chain kernel's projection rows, not the density — measured
-    // neutral: conv1 stretches by what the taps take, 7.396 -> 7.387 ms; profiles/r6_blend_side_stream.txt.  Not kept.)
+    // (The colour-blend taps on the frame's side stream beside the ray U-Net's kernels — they need the chain kernel's projection rows, not the density — built and
+    // traced: conv1 stretches by what the taps take (conv1 399 us with the taps' 369 us inside it = a 403-us span against 192 + 222 us one after the other;
+    // profiles/r6_blend_side_stream.txt).  Not kept.)
     NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt,
                     feat_late && chain_done));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -428,8 +428,9 @@ class HipRenderer:
     def render_rays(self, rays_o, rays_d, query_center, z_vals=None, white_bkgd: bool = False,
                     intermediates: bool = False, want_feat: bool = True, early_term_eps: float = 0.0,
                     side_stream: bool = True, want_knn: bool = False, graph: bool = False, precision_guard: bool = False,
-                    out_buffers: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
-        """out_buffers: preallocated, contiguous destination tensors for the per-ray outputs (rgb (R,3), depth (R), weights (R,S), mask (R) uint8, depth_uncertainty (R),
+                    out_buffers: Optional[Dict[str, torch.Tensor]] = None, want_weights: bool = True) -> Dict[str, torch.Tensor]:
+        """want_weights=False: the per-sample compositing weights (R, S) are not returned (nl_render_out.weights = null; every other output is unchanged).
+        out_buffers: preallocated, contiguous destination tensors for the per-ray outputs (rgb (R,3), depth (R), weights (R,S), mask (R) uint8, depth_uncertainty (R),
         feat (R,C); fp32 but for the mask) — the kernels write straight into them (sharding.py hands in views of ONE buffer per rank, so the all-gather needs no pack step).
         precision_guard=True (nl_render_opts.flags = NL_RENDER_PRECISION_GUARD, ABI 7): the LIBRARY checks the frame's conditioning indicator after the batch
         (max |attention logit|; one 4-byte copy + a stream synchronisation) and renders the batch again in the next more exact mode (f16mx -> bf16x3 -> fp32) while
@@ -452,7 +453,7 @@ class HipRenderer:
         per_ray = qc_t.dim() == 2
         if per_ray and tuple(qc_t.shape) != (R, 3):
             raise ValueError(f"per-ray query centres must have shape ({R}, 3), got {tuple(qc_t.shape)}")
-        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream and not precision_guard and out_buffers is None \
+        if graph and 0 < R <= self.GRAPH_MAX_RAYS and not intermediates and not want_knn and early_term_eps == 0.0 and side_stream and not precision_guard and out_buffers is None and want_weights \
                 and not getattr(self, "guard_bytes", 0) and self._ws_request is None:
             g = self._graphed_render(R, white_bkgd, want_feat, z is not None)
             if g is not None:
@@ -478,6 +479,8 @@ class HipRenderer:
             }
             if want_feat:
                 out["feat"] = torch.empty(R, self.C, device=dev)
+            if not want_weights:
+                del out["weights"]
         if want_knn and not intermediates:   # the neighbours alone (the gradient path hands them to nl_render_rays_backward)
             out.update({"knn_idx": torch.empty(R * S, 8, dtype=torch.int32, device=dev), "knn_d2": torch.empty(R * S, 8, device=dev)})
         if intermediates:
