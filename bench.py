@@ -61,10 +61,13 @@ def executed_mfma_equiv_mac_per_sample(W: int, V: int, S: int, precision: str, C
     point = K * (96 * W * l1 + (2 * W * W + 256 * W) * wide)                        # layer 1 (K = 96: posenc + ray_diff_fc) + layers 2, 3 + k / v
     conv_out = 3 * (W + 32) * W
     unet = 192 * W + 12288 + 12288 + 6144 + 12288 + 6144   # the other six convolutions per sample (pooled levels, transposed = 1.5 taps per output)
-    other = (384 * 64 + 2 * 64 * W + W * 128 + 128 * W + W * W + W * 32 + V * (4 * 2 * 32 * 32 + 6 * 32) + unet + C * W / S)
-    # round 6: conv_out multiplies in the f16mx arithmetic too (tgemm_mx_kernel: W = 256, S = 128)
+    feat0 = W * W                                           # feat_mlp.0
+    other = (384 * 64 + 2 * 64 * W + W * 128 + 128 * W + W * 32 + V * (4 * 2 * 32 * 32 + 6 * 32) + unet + C * W / S)
+    # round 6: conv_out multiplies in the f16mx arithmetic too (tgemm_mx_kernel: W = 256, S = 128), and so does feat_mlp.0, fused with the compositing of its rows
+    # (feat_comp_mx_kernel: W = 256, rays of 32 .. 256 samples in whole 32-row tiles)
     conv_out_per = 1.5 if (precision == "f16mx" and W == 256 and S == 128) else per
-    return point + other * per + conv_out * conv_out_per, point
+    feat0_per = 1.5 if (precision == "f16mx" and W == 256 and S % 32 == 0 and S <= 256 and ((8 % (S // 32)) == 0 or (6 % (S // 32)) == 0)) else per
+    return point + other * per + conv_out * conv_out_per + feat0 * feat0_per, point
 
 
 def main():
@@ -269,7 +272,7 @@ def main():
         "metric": baseline_metric(), "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
-                                                            "f16mx": "f16mx (neural-point kernel and conv_out: fp16 hi.hi + two MX-FP6 cross terms, 1.5 MFMA-equivalents per product; every other GEMM "
+                                                            "f16mx": "f16mx (neural-point kernel, conv_out and feat_mlp.0: fp16 hi.hi + two MX-FP6 cross terms, 1.5 MFMA-equivalents per product; every other GEMM "
                                                                      "3-term split-bf16; fp32 accumulate; meets 1e-4)",
                                                             "bf16": "bf16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
