@@ -1593,6 +1593,7 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
   const bool want_feat = out->feat != nullptr;
   const bool term = term_eps > 0.f && !pre_done;
   if (term) NL_TRY(nl_launch_termination(z, h.sigma, R, S, term_eps, h.n_alive, h.tile_list, h.tile_count, x.st));
+  bool feat_done = false;
   if (feat_late) {
     // f16mx, W = 256, FA = the chain kernel's fragment image: feat_mlp.0's hidden rows are never materialised — the compositing pass leaves the samples' weights
     // (in the caller's `weights` output, or in the buffer the hidden rows would have taken) and feat_comp_mx_kernel multiplies, activates, weights and sums in one go
@@ -1600,13 +1601,17 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
     NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, false, h, 6 & ~chain_parts, false, bt));
     float* wts = out->weights ? out->weights + ray0 * S : h.fth;
     NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, nullptr, valid_s, R, S, W, white, out, ray0, nullptr, h.wsum, x.st, nullptr, out->weights ? nullptr : h.fth));
-    NL_TRY(nl_launch_feat_comp_mx(FA, wts, N, S, x.pk + x.L.bsh[G_FEAT0P], x.pk + x.L.mx_feat0, x.p<float>(x.L.bias[G_FEAT0P]), h.hc, x.st));
+    // ... and applies feat_mlp.2 to the rows it has summed (the per-ray GEMM below: 33 us whatever the batch, 3 % of a 512-ray shard's step)
+    const bool f2 = x.L.g[G_FEAT2].Npad <= 192 && !dbg_switch("NERFLOC_NO_FEAT2_FUSED");
+    NL_TRY(nl_launch_feat_comp_mx(FA, wts, N, S, x.pk + x.L.bsh[G_FEAT0P], x.pk + x.L.mx_feat0, x.p<float>(x.L.bias[G_FEAT0P]), h.hc, x.st,
+                                  f2 ? x.p<float>(x.L.b32[G_FEAT2]) : nullptr, x.L.g[G_FEAT2].Npad, C, h.wsum, out->feat + ray0 * C));
+    feat_done = f2;
   } else {
   if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7 & ~chain_parts, term, bt));   // chain_parts: what the chain kernel already produced
   NL_TRY(nl_launch_composite(z, h.sigma, h.rgb_s, want_feat ? h.fth : nullptr, valid_s, R, S, W, white, out, ray0,
                              want_feat ? h.hc : nullptr, want_feat ? h.wsum : nullptr, x.st, term ? h.n_alive : nullptr));
   }
-  if (want_feat) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
+  if (want_feat && !feat_done) {   // feat = W2 . (sum_s w_s hidden_s) + b2 * sum_s w_s  ==  sum_s w_s (W2 . hidden_s + b2)
     SegSpec s1[2] = {{h.hc, W, W, 0, 1}, {h.wsum, 1, 1, 0, 1}};
     NL_TRY(run_gemm(x, G_FEAT2, s1, 2, R, out->feat + ray0 * C, C, NL_ACT_NONE));
   }

@@ -263,4 +263,6 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);
 // feat_mlp.0 + LeakyReLU + the compositing of its rows along the ray in the f16mx arithmetic (tgemm.hip: feat_comp_mx_kernel): hc (N / S, 256) from feature_agg's
 // fragment image, the samples' compositing weights, G_FEAT0P's fp16 stream and its fp6 images
 bool nl_feat_comp_mx_supported(int W, int S, int64_t N);
-int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st);
+// w2 != null: feat_mlp.2 too (G_FEAT2's packed fp32 matrix [k][npad], row 256 = the bias that meets the weight sum): feat (N / S, C) is written, hc is not
+int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st,
+                           const float* w2 = nullptr, int npad = 0, int C = 0, const float* wsum = nullptr, float* feat = nullptr);

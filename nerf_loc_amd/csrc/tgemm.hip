@@ -793,10 +793,13 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* __restrict__ fa, const float* __restrict__ wts, const int M, const int S,
                                                                    const char* __restrict__ p_bsh, const char* __restrict__ p_bmx, const float* __restrict__ p_bias,
-                                                                   float* __restrict__ hc, const int ngroups) {
+                                                                   float* __restrict__ hc, const int ngroups, const float* __restrict__ w2, const int npad, const int C,
+                                                                   const float* __restrict__ wsum, float* __restrict__ feat) {
   constexpr int NRT = TGMX_NRT;
+  constexpr int HB = 16;   // composited rows kept for feat_mlp.2 (w2 != null): 16 rays x 256 floats, channel-major
   __builtin_amdgcn_s_setreg(1473, 1);   // MODE.FP16_OVFL: saturating f32 -> f16 / fp6 conversions (tgemm_mx_kernel)
   __shared__ uint4 lds_all[2 * TGMX_SLOT / 16];
+  __shared__ float4 hcsT[256 * HB / 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, j = lane & 31;
@@ -847,6 +850,7 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
 
   constexpr int NSC = 4;   // slabs of the layer (K = 256)
   static_assert(NSC % 2 == 0, "the ring's slot parity must carry over from one group to the next");
+  int nbuf = 0, grp0 = 0;   // rays collected for feat_mlp.2 since the last flush, the group of the first of them
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
   const int tile = grp * NW + wave;
   const bool live = tile < ntiles;
@@ -956,12 +960,50 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
     float sum = 0.f;
     for (int w = 0; w < wpr; ++w) sum += red[(q * wpr + w) * 256 + c];
     const int ray = grp * rays_wg + q;
-    if (ray < R) hc[(size_t)ray * 256 + c] = sum;
+    if (w2) reinterpret_cast<float*>(hcsT)[c * HB + nbuf + q] = sum;
+    else if (ray < R) hc[(size_t)ray * 256 + c] = sum;
   }
   __syncthreads();   // `red` is read: the next group's first slab may stage slab 1 over it
   P = Pn;
+  if (w2) {
+    // ---- feat_mlp.2 on the composited rows (it is linear: applied after the sum, abi.hip do_heads), for the rays this workgroup has collected: once per HB rays and
+    // after the last group — the per-ray GEMM launch this replaces cost 33 us whatever the batch.  feat[ray][n] = sum_k hc[ray][k] W2[n][k] + wsum[ray] b2[n]; the weights
+    // are G_FEAT2's packed fp32 matrix ([k][npad], row 256 = the bias), read once per flush, coalesced over n; two thread sets of npad, eight rays each.
+    if (nbuf == 0) grp0 = grp;
+    nbuf += rays_wg;
+    const bool last = grp + (int)gridDim.x >= ngroups;
+    if (nbuf + rays_wg > HB || last) {
+      const int n = tid % npad, set = tid / npad;
+      if (set < 2 && n < C) {
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = 0.f;
+#pragma unroll 8   // (unroll 32 — four times the loads in flight — measured 252 instead of 178 us for the whole kernel: the allocator then reshapes the main loop)
+        for (int k = 0; k < 256; ++k) {
+          const float b = w2[(size_t)k * npad + n];
+          const float4 h0 = hcsT[k * (HB / 4) + set * 2], h1 = hcsT[k * (HB / 4) + set * 2 + 1];
+          a[0] = fmaf(h0.x, b, a[0]); a[1] = fmaf(h0.y, b, a[1]); a[2] = fmaf(h0.z, b, a[2]); a[3] = fmaf(h0.w, b, a[3]);
+          a[4] = fmaf(h1.x, b, a[4]); a[5] = fmaf(h1.y, b, a[5]); a[6] = fmaf(h1.z, b, a[6]); a[7] = fmaf(h1.w, b, a[7]);
+        }
+        const float b2 = w2[(size_t)256 * npad + n];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int slot = set * 8 + i;
+          const int ray = (grp0 + (slot / rays_wg) * (int)gridDim.x) * rays_wg + slot % rays_wg;
+          if (slot < nbuf && ray < R) feat[(size_t)ray * C + n] = fmaf(wsum[ray], b2, a[i]);
+        }
+      }
+      nbuf = 0;
+      __syncthreads();   // the rows are read: the next group's sums may overwrite them
+    }
+  }
   }
 }
+
+// (Two row tiles per wave — four waves, one per SIMD, 64 samples x 256 channels in 256 AGPR accumulators, every weight fragment read from LDS feeding two matrix
+// instructions — was built and measured: 251 + 256 registers, no scratch, parity green, and SLOWER: 192-195 against 156-163 us on the same box, with the weight
+// fragments read two or four units ahead alike.  The kernel streams 537 MB of fragments (0.11 ms of HBM time at the ~5 TB/s these kernels see) in lock-step
+// phases; with one wave per SIMD nothing runs under the operand conversion or the load waits.  Removed; profiles/r6_feat_comp_two_tiles.txt.)
 
 // ====================================================================================================================
 // conv1 of the ray U-Net (W = 256 -> 64, k = 3, S = 128; round 6): `tgemm_kernel<2, 4, .., NL_EPI_LNSLAB>` ran this layer at ~2 k cycles per 32-k chunk for 12 matrix
@@ -1698,13 +1740,16 @@ bool nl_feat_comp_mx_supported(int W, int S, int64_t N) {
   const int wpr = S >> 5;
   return (8 % wpr) == 0 || (6 % wpr) == 0;
 }
-int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st) {
+int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st,
+                           const float* w2, int npad, int C, const float* wsum, float* feat) {
   if (!nl_feat_comp_mx_supported(256, S, N) || !fa_frag || !wts || !bsh || !bmx || !bias || !hc || (((size_t)wts) & 15)) return NL_ERR_UNSUPPORTED;
+  if (w2 && (npad <= 0 || npad > 192 || C <= 0 || C > npad || !wsum || !feat)) return NL_ERR_UNSUPPORTED;   // (two thread sets of npad in a workgroup of 384 / 512)
   const int wpr = S >> 5, nw = (8 % wpr) == 0 ? 8 : 6;
   const int ngroups = (int)nl_cdiv(N, 32 * nw);
   dim3 grid;
   if (chain_grid(ngroups, &grid) != NL_OK) return NL_ERR_HIP;   // one workgroup per CU (130 KB of LDS), XCD-aware when there are fewer groups than CUs
-  if (nw == 8) hipLaunchKernelGGL(feat_comp_mx_kernel<8>, grid, dim3(64 * 8), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups);
-  else hipLaunchKernelGGL(feat_comp_mx_kernel<6>, grid, dim3(64 * 6), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups);
+  if (nw == 8) hipLaunchKernelGGL(feat_comp_mx_kernel<8>, grid, dim3(64 * 8), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups, w2, npad, C, wsum,
+                                    feat);
+  else hipLaunchKernelGGL(feat_comp_mx_kernel<6>, grid, dim3(64 * 6), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups, w2, npad, C, wsum, feat);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
