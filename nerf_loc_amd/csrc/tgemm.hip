@@ -1218,12 +1218,18 @@ __device__ unsigned long long chain_trace[2 * 4 * 96];
 #endif
 
 // weight chunks (32 k each) per 128-row tile: chain = out_fc.2 0,1 | fc 2..5 | feat_mlp.0 6..13 | blend projection 14..21 | 2 empty;
+// chain without feat_mlp.0 (FEAT = false: the f16mx render path since round 6, where feat_comp_mx_kernel runs that layer — and early termination): out_fc.2 0,1 |
+// fc 2..5 | blend projection 6..13 | 2 empty — until late round 6 this program kept the eight feat_mlp.0 slots as barrier + weight DMA + row traffic with nothing to
+// multiply: 256 KB of L2 -> LDS traffic and eight barriers per tile for nothing; their row traffic (24 feature_agg stores, the next tile's 8 hidden-row loads) now
+// rides in the blend projection's slots;
 // query = out_fc.2 0,1 | w_qs 2..9 | 2 empty.  (The ring slot of a chunk is c % 4 at compile time: programs are padded with empty
 // chunks — barrier only — to a multiple of 4.)
-template <bool QUERY>
+template <bool QUERY, bool FEAT = true>
 struct ChainGeo {
-  static constexpr int NST = QUERY ? 2 : 4;
-  static constexpr int kind_at(int s) { return QUERY ? (s == 0 ? CK_G2 : CK_Q) : (s == 0 ? CK_G2 : s == 1 ? CK_FC : s == 2 ? CK_F0 : CK_BL); }
+  static constexpr int NST = QUERY ? 2 : (FEAT ? 4 : 3);
+  static constexpr int kind_at(int s) {
+    return QUERY ? (s == 0 ? CK_G2 : CK_Q) : (s == 0 ? CK_G2 : s == 1 ? CK_FC : (FEAT ? (s == 2 ? CK_F0 : CK_BL) : CK_BL));
+  }
   static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : 8; }
   static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : k == CK_BL ? 2 : k == CK_Q ? 4 : 8; }
   static constexpr int start(int s) { int c = 0; for (int i = 0; i < s; ++i) c += nch_k(kind_at(i)); return c; }
@@ -1242,7 +1248,7 @@ struct ChainGeo {
     if (k == CK_G2) return 4 + (i == 1 && feat ? 8 : 0);                    // attention rows | ELU epilogue: previous tile's rows 8..15
     if (k == CK_FC) return (i < 2 ? 4 : feat ? 4 : 0) + (i == 3 ? 1 + 8 + (feat ? 8 : 0) : 0);   // + scale, LayerNorm epilogue
     if (k == CK_F0) return 4 + (i == 7 && feat ? 6 : 0);                    // 3 feature_agg + 1 hidden-row | epilogue: own rows 0..5
-    if (k == CK_BL) return (i < 2 && feat ? 1 : 0) + (i == 7 ? 4 : 0);      // own rows 6, 7 | blend projection rows
+    if (k == CK_BL) return (feat ? (i < 2 ? 1 : 0) : 4) + (i == 7 ? 4 : 0);   // own rows 6, 7 (no feat_mlp.0: 3 feature_agg + 1 hidden-row) | blend projection rows
     return 0;
   }
 };
@@ -1253,7 +1259,7 @@ struct ChainGeo {
 template <bool X3, bool FEAT, bool QUERY, bool FRAGOUT = false>
 __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a, const int ntiles) {
   static_assert(!(FRAGOUT && QUERY), "the query program has no feature_agg");
-  using Geo = ChainGeo<QUERY>;
+  using Geo = ChainGeo<QUERY, FEAT>;
   constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = Geo::NCH, NB = 4;
   constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per ring slot (sized for 8 row tiles)
   __shared__ uint4 lds_all[NB * SLOT16 + 4 * 64];
@@ -1437,12 +1443,12 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           if constexpr (kd == CK_G2) load_oraw(4 * g + k, mm_c);
           else if constexpr (kd == CK_FC && g < 2) load_oraw(8 + 4 * g + k, mm_c);
           else if constexpr (kd == CK_FC) { if constexpr (FEAT) store_fa(16 + 4 * (g - 2) + k, rFT, prev_row); }   // previous tile's rows 16..23
-          else if constexpr (kd == CK_F0) { if (k < 3) store_FA(8 + 3 * g + k, row1k); else load_traw(g, mm_n); }
+          else if constexpr (kd == CK_F0 || (kd == CK_BL && !FEAT)) { if (k < 3) store_FA(8 + 3 * g + k, row1k); else load_traw(g, mm_n); }
         }
       };
       auto mem_fill = [&](int tt) __attribute__((always_inline)) { if ((tt & 3) == 1) mem_op(tt >> 2); };
       if constexpr (kd == CK_BL && FEAT && g < 2) store_fa(6 + g, rFT, row1k);
-      if constexpr (kd == CK_F0 && !FEAT) {   // no feat_mlp.0 MFMAs to hide behind: the slot's operations in one go
+      if constexpr (kd == CK_BL && !FEAT) {   // no feat_mlp.0 chunks to spread them over: the slot's operations in one go, in front of the blend projection's 6 MFMAs
 #pragma unroll
         for (int k = 0; k < 4; ++k) mem_op(k);
       }
