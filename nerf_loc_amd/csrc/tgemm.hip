@@ -1230,8 +1230,10 @@ struct ChainGeo {
   static constexpr int kind_at(int s) {
     return QUERY ? (s == 0 ? CK_G2 : CK_Q) : (s == 0 ? CK_G2 : s == 1 ? CK_FC : (FEAT ? (s == 2 ? CK_F0 : CK_BL) : CK_BL));
   }
-  static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : 8; }
-  static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : k == CK_BL ? 2 : k == CK_Q ? 4 : 8; }
+  // (the blend projection: 8 k-chunks of 2 row tiles = 8 KB each; FOUR of them travel as one ring chunk — a full 32-KB slot, contiguous in the stream — so the
+  // projection costs two barriers per tile instead of eight: late round 6)
+  static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : k == CK_BL ? 2 : 8; }
+  static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : k == CK_Q ? 4 : 8; }
   static constexpr int start(int s) { int c = 0; for (int i = 0; i < s; ++i) c += nch_k(kind_at(i)); return c; }
   static constexpr int NREAL = start(NST), NCH = (NREAL + 3) / 4 * 4;
   static constexpr int cm(int c) { return ((c % NCH) + NCH) % NCH; }
@@ -1248,7 +1250,7 @@ struct ChainGeo {
     if (k == CK_G2) return 4 + (i == 1 && feat ? 8 : 0);                    // attention rows | ELU epilogue: previous tile's rows 8..15
     if (k == CK_FC) return (i < 2 ? 4 : feat ? 4 : 0) + (i == 3 ? 1 + 8 + (feat ? 8 : 0) : 0);   // + scale, LayerNorm epilogue
     if (k == CK_F0) return 4 + (i == 7 && feat ? 6 : 0);                    // 3 feature_agg + 1 hidden-row | epilogue: own rows 0..5
-    if (k == CK_BL) return (feat ? (i < 2 ? 1 : 0) : 4) + (i == 7 ? 4 : 0);   // own rows 6, 7 (no feat_mlp.0: 3 feature_agg + 1 hidden-row) | blend projection rows
+    if (k == CK_BL) return (feat ? (i == 0 ? 2 : 0) : 16) + (i == 1 ? 4 : 0);   // own rows 6, 7 (no feat_mlp.0: 4 x (3 feature_agg + 1 hidden-row)) | blend projection rows
     return 0;
   }
 };
@@ -1293,7 +1295,8 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
                   (unsigned)(Geo::idx(c) * 4 * nrt * 1024);
     tg_static_for<ppw(c)>([&](auto Ic) __attribute__((always_inline)) {
       constexpr int i = decltype(Ic)::value;
-      unsigned s2 = so + i * 4096;
+      // (the blend projection's ring chunk = four 8-KB k-chunks [hi 4 KB | lo 4 KB]: contiguous in three-term mode; single-bf16 mode takes the four hi parts)
+      unsigned s2 = so + i * ((kd == CK_BL && !X3) ? 8192 : 4096);
       asm volatile("" : "+s"(s2));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + (c % NB) * SLOT16 + i * 256), 16, wvoff, s2, 0, 0);
     });
@@ -1334,9 +1337,9 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
     } else store_fa(q, rFA, rowoff);
   };
   // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`; filler(step) runs between the MFMA groups
-  auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2], auto& dst, auto&& filler) __attribute__((always_inline)) {
+  auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2], auto& dst, auto&& filler, int sub = 0) __attribute__((always_inline)) {
     constexpr int NRT = decltype(Nc)::value, nt = 2 * NRT;
-    const tg_bf16x8* L = ring[slot];
+    const tg_bf16x8* L = ring[slot] + sub * (PARTS * 2 * NRT * 64);   // sub: the k-chunk inside a ring chunk that carries several (the blend projection's four)
     auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
       const int ks = tt / NRT, rt = tt - ks * NRT;
       ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
@@ -1443,15 +1446,18 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
           if constexpr (kd == CK_G2) load_oraw(4 * g + k, mm_c);
           else if constexpr (kd == CK_FC && g < 2) load_oraw(8 + 4 * g + k, mm_c);
           else if constexpr (kd == CK_FC) { if constexpr (FEAT) store_fa(16 + 4 * (g - 2) + k, rFT, prev_row); }   // previous tile's rows 16..23
-          else if constexpr (kd == CK_F0 || (kd == CK_BL && !FEAT)) { if (k < 3) store_FA(8 + 3 * g + k, row1k); else load_traw(g, mm_n); }
+          else if constexpr (kd == CK_F0) { if (k < 3) store_FA(8 + 3 * g + k, row1k); else load_traw(g, mm_n); }
+        }
+      };
+      auto bl_mem = [&](int kc) __attribute__((always_inline)) {   // the row traffic of blend k-chunk kc (0 .. 7), in one go in front of its 12 MFMAs
+        if constexpr (FEAT) { if (kc < 2) store_fa(6 + kc, rFT, row1k); }
+        else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) store_FA(8 + 3 * kc + k, row1k);
+          load_traw(kc, mm_n);
         }
       };
       auto mem_fill = [&](int tt) __attribute__((always_inline)) { if ((tt & 3) == 1) mem_op(tt >> 2); };
-      if constexpr (kd == CK_BL && FEAT && g < 2) store_fa(6 + g, rFT, row1k);
-      if constexpr (kd == CK_BL && !FEAT) {   // no feat_mlp.0 chunks to spread them over: the slot's operations in one go, in front of the blend projection's 6 MFMAs
-#pragma unroll
-        for (int k = 0; k < 4; ++k) mem_op(k);
-      }
       __builtin_amdgcn_sched_barrier(0);
 
       tg_bf16x8 bh[2], bl[2];
@@ -1466,9 +1472,18 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
         }
         compute(I8{}, c % NB, bh, bl, acc, mem_fill);
       } else if constexpr (kd != CK_NOP) {
-        bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1];
+        if constexpr (kd != CK_BL) { bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1]; }
         if constexpr (kd == CK_F0) { if constexpr (FEAT) compute(I8{}, c % NB, bh, bl, acc, mem_fill); }
-        else if constexpr (kd == CK_BL) compute(I2{}, c % NB, bh, bl, acc, no_fill);
+        else if constexpr (kd == CK_BL) {
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) {
+            const int kc = 4 * g + sub;
+            bl_mem(kc);
+            __builtin_amdgcn_sched_barrier(0);
+            bh[0] = Xh[2 * kc]; bh[1] = Xh[2 * kc + 1]; bl[0] = Xl[2 * kc]; bl[1] = Xl[2 * kc + 1];
+            compute(I2{}, c % NB, bh, bl, acc, no_fill, sub);
+          }
+        }
         else if constexpr (g + 1 < 8)   // w_qs chunk g (k-steps of G's row tile g): row tile g + 1 is converted between its MFMAs
           compute(I4{}, c % NB, bh, bl, qacc, [&](int tt) __attribute__((always_inline)) { g2_epilogue_step(std::integral_constant<int, (g + 1) % 8>{}, tt); mem_fill(tt); });
         else compute(I4{}, c % NB, bh, bl, qacc, mem_fill);
