@@ -2627,8 +2627,9 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
     // holds anyway (same bytes in the same buffer) unless someone wants the fp32 rows: the stage output, or feat_mlp.0 over the live tiles of an early-terminated batch
     const bool fa_frag = use_chain && !dbg_switch("NERFLOC_NO_FRAG") && (N & 31) == 0 && !out->feature_agg && !(want_feat && term_eps > 0.f);
     // f16mx: feat_mlp.0 leaves the chain kernel — it runs after the density, fused with the compositing of its rows (do_heads: feat_late)
+    // (the kernel reads the samples' weights as 16-byte rows: a caller's `weights` buffer that is not 16-byte aligned keeps the old path — no alignment was ever asked of it)
     const bool feat_late = want_feat && term_eps == 0.f && fa_frag && x.mx && ((x.has_bsh >> G_FEAT0P) & 1) && nl_feat_comp_mx_supported(W, S, N) &&
-                           !dbg_switch("NERFLOC_NO_FEAT_COMP");
+                           (((size_t)out->weights) & 15) == 0 && !dbg_switch("NERFLOC_NO_FEAT_COMP");
     const ChainOut chain{(want_feat && term_eps == 0.f && !feat_late) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f && !feat_late ? 1 : 0) | 2) : 0;

@@ -67,3 +67,27 @@ def test_fused_feature_compositing_is_batch_invariant():
         part = r.render_rays(rays["rays_o"][sel], rays["rays_d"][sel], qc, z_vals=z[sel])
         for k in KEYS:
             assert torch.equal(part[k], full[k][sel]), (k, sel)
+
+
+def test_misaligned_weights_buffer_takes_the_old_path():
+    """The fused kernel reads the samples' weights as 16-byte rows; the C-ABI never asked for an aligned `weights` buffer, so a misaligned one must still render
+    (the library keeps the chain kernel's feat_mlp.0 + composite_kernel for that call) and agree with the aligned call."""
+    from oracle import render_oracle as orc
+    cfg, frame, rays, weights = _case(128, 6)
+    r = _renderer(cfg, frame, weights)
+    R, S, C = cfg.R, cfg.S, cfg.C
+    z = orc.sample_depths(S, torch.tensor(cfg.near), torch.tensor(cfg.far)).expand(R, S).contiguous()
+    qc = frame["pose"][:3, 3]
+    ref = r.render_rays(rays["rays_o"], rays["rays_d"], qc, z_vals=z)
+    dev = ref["rgb"].device
+    wbuf = torch.zeros(R * S + 4, device=dev)
+    bufs = {"rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, device=dev), "weights": wbuf[1:1 + R * S].view(R, S),
+            "mask": torch.empty(R, dtype=torch.uint8, device=dev), "depth_uncertainty": torch.empty(R, device=dev), "feat": torch.empty(R, C, device=dev)}
+    assert bufs["weights"].data_ptr() % 16 == 4 and bufs["weights"].is_contiguous()
+    out = r.render_rays(rays["rays_o"], rays["rays_d"], qc, z_vals=z, out_buffers=bufs)
+    torch.cuda.synchronize()
+    for k in ("rgb", "depth", "weights", "depth_uncertainty"):
+        assert torch.equal(out[k], ref[k]), k
+    fa, fb = out["feat"].cpu().numpy().astype(np.float64), ref["feat"].cpu().numpy().astype(np.float64)
+    assert np.abs(fa - fb).max() / np.abs(fb).max() < 5e-5
+    assert float(wbuf[0]) == 0.0 and float(wbuf[-1]) == 0.0   # nothing written outside the view
