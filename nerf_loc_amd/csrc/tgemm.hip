@@ -1232,8 +1232,9 @@ struct ChainGeo {
   }
   // (the blend projection: 8 k-chunks of 2 row tiles = 8 KB each; FOUR of them travel as one ring chunk — a full 32-KB slot, contiguous in the stream — so the
   // projection costs two barriers per tile instead of eight: late round 6)
-  static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : k == CK_BL ? 2 : 8; }
-  static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : k == CK_Q ? 4 : 8; }
+  // (likewise w_qs: 8 k-chunks of 4 row tiles = 16 KB each, TWO to a ring chunk: the query program is 2 + 4 chunks + 2 empty instead of 2 + 8 + 2)
+  static constexpr int nch_k(int k) { return k == CK_G2 ? 2 : k == CK_FC ? 4 : k == CK_BL ? 2 : k == CK_Q ? 4 : 8; }
+  static constexpr int nrt_k(int k) { return k == CK_NOP ? 0 : 8; }
   static constexpr int start(int s) { int c = 0; for (int i = 0; i < s; ++i) c += nch_k(kind_at(i)); return c; }
   static constexpr int NREAL = start(NST), NCH = (NREAL + 3) / 4 * 4;
   static constexpr int cm(int c) { return ((c % NCH) + NCH) % NCH; }
@@ -1246,7 +1247,7 @@ struct ChainGeo {
   // lane-instruction).  Waits count them: vmcnt retires in issue order.
   static constexpr int post(int c, bool feat) {
     const int k = kind(c), i = idx(c);
-    if (QUERY) return k == CK_G2 ? 4 : k == CK_Q ? 2 : 0;
+    if (QUERY) return k == CK_G2 ? 4 : k == CK_Q ? 4 : 0;
     if (k == CK_G2) return 4 + (i == 1 && feat ? 8 : 0);                    // attention rows | ELU epilogue: previous tile's rows 8..15
     if (k == CK_FC) return (i < 2 ? 4 : feat ? 4 : 0) + (i == 3 ? 1 + 8 + (feat ? 8 : 0) : 0);   // + scale, LayerNorm epilogue
     if (k == CK_F0) return 4 + (i == 7 && feat ? 6 : 0);                    // 3 feature_agg + 1 hidden-row | epilogue: own rows 0..5
@@ -1296,7 +1297,8 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
     tg_static_for<ppw(c)>([&](auto Ic) __attribute__((always_inline)) {
       constexpr int i = decltype(Ic)::value;
       // (the blend projection's ring chunk = four 8-KB k-chunks [hi 4 KB | lo 4 KB]: contiguous in three-term mode; single-bf16 mode takes the four hi parts)
-      unsigned s2 = so + i * ((kd == CK_BL && !X3) ? 8192 : 4096);
+      //  w_qs's ring chunk = two 16-KB k-chunks [hi 8 KB | lo 8 KB]: likewise)
+      unsigned s2 = so + ((kd == CK_Q && !X3) ? (i / 2) * 16384 + (i % 2) * 4096 : i * ((kd == CK_BL && !X3) ? 8192 : 4096));
       asm volatile("" : "+s"(s2));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + (c % NB) * SLOT16 + i * 256), 16, wvoff, s2, 0, 0);
     });
@@ -1440,14 +1442,17 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
       auto mem_op = [&](int k) __attribute__((always_inline)) {
         if constexpr (QUERY) {
           if constexpr (kd == CK_G2) store_fa(4 * g + k, rFA, prev_row);                       // previous tile's rows 0..7
-          else if constexpr (g < 4) store_fa(8 + 2 * g + k, rFA, prev_row);                    // 8..15
-          else load_traw(2 * (g - 4) + k, mm_n);
+          // (w_qs: q_mem below, per k-chunk)
         } else {
           if constexpr (kd == CK_G2) load_oraw(4 * g + k, mm_c);
           else if constexpr (kd == CK_FC && g < 2) load_oraw(8 + 4 * g + k, mm_c);
           else if constexpr (kd == CK_FC) { if constexpr (FEAT) store_fa(16 + 4 * (g - 2) + k, rFT, prev_row); }   // previous tile's rows 16..23
           else if constexpr (kd == CK_F0) { if (k < 3) store_FA(8 + 3 * g + k, row1k); else load_traw(g, mm_n); }
         }
+      };
+      auto q_mem = [&](int gq, int k) __attribute__((always_inline)) {   // the row traffic of w_qs k-chunk gq (0 .. 7), operation k (0, 1)
+        if (gq < 4) store_fa(8 + 2 * gq + k, rFA, prev_row);                                  // previous tile's rows 8..15
+        else load_traw(2 * (gq - 4) + k, mm_n);
       };
       auto bl_mem = [&](int kc) __attribute__((always_inline)) {   // the row traffic of blend k-chunk kc (0 .. 7), in one go in front of its 12 MFMAs
         if constexpr (FEAT) { if (kc < 2) store_fa(6 + kc, rFT, row1k); }
@@ -1472,7 +1477,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
         }
         compute(I8{}, c % NB, bh, bl, acc, mem_fill);
       } else if constexpr (kd != CK_NOP) {
-        if constexpr (kd != CK_BL) { bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1]; }
+        if constexpr (kd == CK_F0) { bh[0] = Xh[2 * g]; bh[1] = Xh[2 * g + 1]; bl[0] = Xl[2 * g]; bl[1] = Xl[2 * g + 1]; }
         if constexpr (kd == CK_F0) { if constexpr (FEAT) compute(I8{}, c % NB, bh, bl, acc, mem_fill); }
         else if constexpr (kd == CK_BL) {
 #pragma unroll
@@ -1484,9 +1489,16 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
             compute(I2{}, c % NB, bh, bl, acc, no_fill, sub);
           }
         }
-        else if constexpr (g + 1 < 8)   // w_qs chunk g (k-steps of G's row tile g): row tile g + 1 is converted between its MFMAs
-          compute(I4{}, c % NB, bh, bl, qacc, [&](int tt) __attribute__((always_inline)) { g2_epilogue_step(std::integral_constant<int, (g + 1) % 8>{}, tt); mem_fill(tt); });
-        else compute(I4{}, c % NB, bh, bl, qacc, mem_fill);
+        else {   // w_qs: the two k-chunks of this ring chunk; k-chunk gq multiplies G's row tile gq, row tile gq + 1 is converted between its MFMAs
+          tg_static_for<2>([&](auto Sc) __attribute__((always_inline)) {
+            constexpr int sub = decltype(Sc)::value, gq = 2 * g + sub;
+            bh[0] = Xh[2 * gq]; bh[1] = Xh[2 * gq + 1]; bl[0] = Xl[2 * gq]; bl[1] = Xl[2 * gq + 1];
+            compute(I4{}, c % NB, bh, bl, qacc, [&](int tt) __attribute__((always_inline)) {
+              if constexpr (gq + 1 < 8) g2_epilogue_step(std::integral_constant<int, (gq + 1) % 8>{}, tt);
+              if ((tt & 3) == 1) q_mem(gq, tt >> 2);
+            }, sub);
+          });
+        }
       }
 
       if constexpr (kd == CK_G2 && Geo::last(c)) {
