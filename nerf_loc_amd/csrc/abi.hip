@@ -67,7 +67,7 @@ int nl_pack_point_stream2(const float* w1, const float* w2, const float* w3, con
 bool nl_point_fused2_supported(int W, int precision);
 int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
                            size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
-                           float* blA, int64_t M, int precision, hipStream_t st, bool frag_out = false);
+                           float* blA, int64_t M, int precision, hipStream_t st, bool frag_out = false, bool frag_f16 = false);
 int nl_launch_query_chain(const float* T64, const void* wbase, size_t off_g2, const float* bias_g2, size_t off_q, float* Q, int64_t M, int precision,
                           hipStream_t st);
 int nl_launch_point_fused2(const NlPointFusedArgs& a, int W, int precision, hipStream_t st, bool mx = false, float* keep_kv = nullptr, unsigned* const* keep_mk = nullptr,
@@ -712,6 +712,7 @@ int run_gemm(const Ctx& x, int g, const SegSpec* segs, int nseg, int64_t M, floa
   if (x.mx && g == G_CONVOUTF && prec == NL_PREC_BF16X3 && x.c->W == 256 && ((x.has_bsh >> g) & 1) && !dbg_switch("NERFLOC_NO_TGEMM_MX")) {
     a.Bsh_mx = x.pk + x.L.bsh[g]; a.Bmx = x.pk + x.L.mx_convout;
   }
+  for (int i = 0; i < nseg; ++i) if (segs[i].frag == 3 && ((x.has_bsh >> g) & 1)) a.Bsh16 = x.pk + x.L.bsh[g];   // split-FP16 fragments: the layer's fp16 stream (conv1)
   a.zeros = x.p<float>(x.L.zeros);
   a.bias = d.bias ? x.p<float>(x.L.bias[g]) : nullptr;
   a.C = C; a.ldc = ldc; a.act = act;
@@ -878,7 +879,7 @@ int do_mv(const Ctx& x, const nl_frame* f, const float* qc, const float* xyz, in
 // chain != null && chain->t64 != null (fused render path, W = 256, bf16 modes): the query rows before the branch and fc + LayerNorm +
 // scale, feat_mlp.0 (chain->fth, may be null) and the blend projection (chain->blA) after it run as two chain kernels that recompute
 // the multiview feature rows G from out_fc's hidden rows t64 (G is then not read here and need not exist); *chain->done reports it
-struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; bool fa_frag = false; };   // fa_frag: FA leaves the chain kernel as a fragment image
+struct ChainOut { float* fth; float* blA; bool* done; const float* t64 = nullptr; bool fa_frag = false; bool fa_f16 = false; };   // fa_frag: FA leaves the chain kernel as a fragment image (fa_f16: in split-FP16)
 int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir, int dir_stride, int dir_div, const float* G, int64_t N, int K,
              float* FA, const PtBufs& p, SideJoin* knn_done = nullptr, const ChainOut* chain = nullptr) {
   const int W = x.c->W, F = f->C + 3;
@@ -957,8 +958,8 @@ int do_point(const Ctx& x, const nl_frame* f, const float* xyz, const float* dir
   if (chain && chain->done) *chain->done = false;
   if (t64) {   // (the caller checked W, precision and the 32-bit offset range before leaving G unmaterialised)
     NL_TRY(nl_launch_sample_chain(p.O, t64, p.wscale, x.p<float>(x.L.ln_g), x.p<float>(x.L.ln_b), 1e-6f, x.pk, x.L.bst[G_OUTFC2],
-                                  x.p<float>(x.L.bias[G_OUTFC2]), x.L.bst[G_FC], x.L.bst[G_FEAT0P], x.L.bst[G_BLENDAP], x.p<float>(x.L.bias[G_FEAT0P]), FA,
-                                  chain->fth, chain->blA, N, x.c->precision, x.st, chain->fa_frag));
+                                  x.p<float>(x.L.bias[G_OUTFC2]), x.L.bst[G_FC], x.L.bst[G_FEAT0P], chain->fa_f16 ? x.L.bsh[G_BLENDAP] : x.L.bst[G_BLENDAP],
+                                  x.p<float>(x.L.bias[G_FEAT0P]), FA, chain->fth, chain->blA, N, x.c->precision, x.st, chain->fa_frag, chain->fa_f16));
     if (chain->done) *chain->done = true;
     return NL_OK;
   }
@@ -1345,7 +1346,7 @@ int do_blend_backward(const Ctx& xb, const Ctx& x32, const nl_frame* f, const fl
 // fuse_inner: the caller needs nothing of the five inner layers but their result (u.x2) — the inference render path; the backward passes and the stage entry
 // point keep the separate launches (their pre-LayerNorm outputs and block outputs are read back)
 int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& u, float* sigma_out = nullptr, bool* sigma_done = nullptr,
-            bool need_geo = true, bool in_frag = false, bool fuse_inner = false) {
+            bool need_geo = true, int in_frag = 0, bool fuse_inner = false) {   // in_frag: NlGemmSeg::frag of `in` (0: fp32 rows, 1: fragment image, 3: its split-FP16 form)
   const int W = x.c->W, S = x.c->S;
   // the two phases of every transposed convolution as one launch (bf16 modes; the fp32 kernels keep the separate phases)
   static const bool no_merge = dbg_switch("NERFLOC_NO_TMERGE");
@@ -1359,7 +1360,7 @@ int do_unet(const Ctx& x, const float* in, int64_t R, float* geo, const UnBufs& 
   // kernel): from the chain kernel's fragment image (in_frag) or from fp32 rows read in that order — the same products in the same order either way
   const bool korder = in_frag || ((x.c->precision == NL_PREC_BF16X3 || x.c->precision == NL_PREC_BF16) && !dbg_switch("NERFLOC_NO_FRAG") && (((size_t)in) & 15) == 0 &&
                                   ((x.has_bst >> G_CONV1F) & 1) && ((x.has_bst >> G_CONVOUTF) & 1));
-  const int fa_mode = in_frag ? 1 : (korder ? 2 : 0);
+  const int fa_mode = in_frag ? in_frag : (korder ? 2 : 0);
   {  // conv1: W -> 64 over S
     SegSpec s[1] = {{in, W, W, 0, 1, 3, fa_mode}};   // 3 taps, interleaved per 32-channel block
     const RowEpi ep{nullptr, 0, gl(U_CONV1), bl(U_CONV1), nullptr, eps, u.c1, NL_EPI_LNSLAB, 1};   // LN + ELU + MaxPool inside the GEMM when one workgroup = one ray
@@ -1586,7 +1587,7 @@ int do_heads_pre(const Ctx& x, int V, const float* FA, const float* bl1, const f
 
 int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* geo, const float* bl1, const float* rgbv,
              const int* valid_s, int64_t R, int white, const nl_render_out* out, int64_t ray0, const HdBufs& h, bool have_sigma = false,
-             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0, const BlendTaps* bt = nullptr, bool feat_late = false) {
+             bool pre_done = false, float term_eps = 0.f, int chain_parts = 0, const BlendTaps* bt = nullptr, bool feat_late = false, bool fa_f16 = false) {
   const int W = x.c->W, S = x.c->S, C = x.c->C;
   const int64_t N = R * S;
   if (!have_sigma) NL_TRY(nl_launch_sigma(geo, N, W, x.p<float>(x.L.sig_w), x.p<float>(x.L.sig_b), h.sigma, x.st));
@@ -1604,7 +1605,7 @@ int do_heads(const Ctx& x, int V, const float* z, const float* FA, const float* 
     // ... and applies feat_mlp.2 to the rows it has summed (the per-ray GEMM below: 33 us whatever the batch, 3 % of a 512-ray shard's step)
     const bool f2 = x.L.g[G_FEAT2].Npad <= 192 && !dbg_switch("NERFLOC_NO_FEAT2_FUSED");
     NL_TRY(nl_launch_feat_comp_mx(FA, wts, N, S, x.pk + x.L.bsh[G_FEAT0P], x.pk + x.L.mx_feat0, x.p<float>(x.L.bias[G_FEAT0P]), h.hc, x.st,
-                                  f2 ? x.p<float>(x.L.b32[G_FEAT2]) : nullptr, x.L.g[G_FEAT2].Npad, C, h.wsum, out->feat + ray0 * C));
+                                  f2 ? x.p<float>(x.L.b32[G_FEAT2]) : nullptr, x.L.g[G_FEAT2].Npad, C, h.wsum, out->feat + ray0 * C, fa_f16));
     feat_done = f2;
   } else {
   if (!pre_done) NL_TRY(do_heads_pre(x, V, FA, bl1, rgbv, N, want_feat, h, 7 & ~chain_parts, term, bt));   // chain_parts: what the chain kernel already produced
@@ -2630,16 +2631,20 @@ int render_rays_impl(const nl_config* cfg, const void* packed, const nl_frame* f
     // (the kernel reads the samples' weights as 16-byte rows: a caller's `weights` buffer that is not 16-byte aligned keeps the old path — no alignment was ever asked of it)
     const bool feat_late = want_feat && term_eps == 0.f && fa_frag && x.mx && ((x.has_bsh >> G_FEAT0P) & 1) && nl_feat_comp_mx_supported(W, S, N) &&
                            (((size_t)out->weights) & 15) == 0 && !dbg_switch("NERFLOC_NO_FEAT_COMP");
-    const ChainOut chain{(want_feat && term_eps == 0.f && !feat_late) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag};
+    // split-FP16 fragments where EVERY consumer of the image multiplies in fp16-based arithmetic: conv1 -> tgemm_conv1_kernel<true, true>, conv_out -> tgemm_mx_kernel,
+    // feat_mlp.0 -> feat_comp_mx_kernel (or nobody), the blend projection inside the chain kernel on its fp16 stream (W = 256, S = 128, f16mx)
+    const bool fa_f16 = fa_frag && x.mx && W == 256 && S == 128 && (!want_feat || feat_late) && ((x.has_bsh >> G_CONV1F) & 1) && ((x.has_bsh >> G_CONVOUTF) & 1) &&
+                        ((x.has_bsh >> G_BLENDAP) & 1) && !dbg_switch("NERFLOC_NO_TGEMM_MX") && !dbg_switch("NERFLOC_NO_F16FRAG");
+    const ChainOut chain{(want_feat && term_eps == 0.f && !feat_late) ? rb.hd.fth : nullptr, rb.hd.blA, &chain_done, use_chain ? rb.mv.t64 : nullptr, fa_frag, fa_f16};
     NL_TRY(do_point(x, f, rb.xyz, rays_d + 3 * r0, 3, S, rb.G, N, 8, rb.FA, rb.pt, fork ? &knn : nullptr, &chain));
     const int chain_parts = chain_done ? ((want_feat && term_eps == 0.f && !feat_late ? 1 : 0) | 2) : 0;
     bool have_sigma = false;
-    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag, true));
+    NL_TRY(do_unet(x, rb.FA, rc, rb.geo, rb.un, rb.hd.sigma, &have_sigma, out->geo != nullptr, fa_frag ? (fa_f16 ? 3 : 1) : 0, true));
     // (The colour-blend taps on the frame's side stream beside the ray U-Net's kernels — they need the chain kernel's projection rows, not the density — built and
     // traced: conv1 stretches by what the taps take (conv1 399 us with the taps' 369 us inside it = a 403-us span against 192 + 222 us one after the other;
     // profiles/r6_blend_side_stream.txt).  Not kept.)
     NL_TRY(do_heads(x, V, rb.z, rb.FA, rb.geo, front ? nullptr : rb.bl1, rb.rgbv, rb.valid_s, rc, white, out, r0, rb.hd, have_sigma, false, term_eps, chain_parts, &bt,
-                    feat_late && chain_done));
+                    feat_late && chain_done, fa_f16));
     if (out->feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->feature_agg + r0 * S * W, rb.FA, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->mv_feature_agg) NL_CHECK_HIP(hipMemcpyAsync(out->mv_feature_agg + r0 * S * W, rb.G, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));
     if (out->geo) NL_CHECK_HIP(hipMemcpyAsync(out->geo + r0 * S * W, rb.geo, sizeof(float) * N * W, hipMemcpyDeviceToDevice, x.st));

@@ -209,6 +209,8 @@ struct NlGemmSeg {
                      // match, G_CONV1F / G_CONVOUTF).  The consumer loads 16-byte pieces that are contiguous across the wave and converts nothing (round 5).
                      // 2: fp32 rows as ever, but the layer's K order inside every 32-block is that accumulator order (the same packed weights serve both source
                      // formats, so a batch renders to the same bits whichever format its chunk took)
+                     // 3 (late round 6; tgemm_conv1_kernel / tgemm_mx_kernel / feat_comp_mx_kernel only): the fragment image of 1 in split-FP16 — hi = f16(v), lo = f16(v - hi)
+                     // (sample_chain_kernel<.., F16FRAG>): the same bytes in the same places, taken as fp16 operands
 };
 struct NlGemmArgs {
   NlGemmSeg seg[NL_GEMM_MAX_SEG];
@@ -218,6 +220,7 @@ struct NlGemmArgs {
   const void* B;        // packed weights: f32 [Kpad][Npad]  or bf16 hi/lo [Npad][Kpad] (see pack.hip)
   const void* Blo;      // bf16x3 only
   const void* Bst;      // bf16 hi/lo weight stream in A-fragment chunk order (tgemm.hip), or null
+  const void* Bsh16;    // the layer's fp16 hi / lo stream for a launch whose input is the split-FP16 fragment image (NlGemmSeg::frag == 3: tgemm_conv1_kernel<true, true>), or null
   const void* Bsh_mx;   // NL_PREC_F16MX (round 6, tgemm_mx_kernel): the layer's fp16 hi/lo stream (its hi fragments are read) ...
   const void* Bmx;      // ... and its fp6 images + block scales (pack_tgemm_mx6_kernel), or null
   const float* zeros;   // >= 512 zero floats (source row of conv halos / rows beyond M in tgemm.hip)
@@ -265,4 +268,4 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t stream);
 bool nl_feat_comp_mx_supported(int W, int S, int64_t N);
 // w2 != null: feat_mlp.2 too (G_FEAT2's packed fp32 matrix [k][npad], row 256 = the bias that meets the weight sum): feat (N / S, C) is written, hc is not
 int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st,
-                           const float* w2 = nullptr, int npad = 0, int C = 0, const float* wsum = nullptr, float* feat = nullptr);
+                           const float* w2 = nullptr, int npad = 0, int C = 0, const float* wsum = nullptr, float* feat = nullptr, bool frag_f16 = false);

@@ -490,6 +490,50 @@ __device__ __forceinline__ void tg_lo2_f32(float v0, float v1, unsigned hi, floa
   asm("v_fma_mix_f32 %0, %4, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %4, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
       : "=&v"(l0), "=&v"(l1) : "v"(v0), "v"(v1), "v"(hi));
 }
+// split-FP16 of 8 values on the packed conversions (hi = f16(v), lo = f16(v - hi); 16 instructions): the chain kernel's F16FRAG rows
+__device__ __forceinline__ void tg_split8_f16_pk(const float (&v)[8], tg_bf16x8& hi, tg_bf16x8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h[t]) : "v"(v[2 * t]), "v"(v[2 * t + 1]));
+    float l0, l1;
+    tg_lo2_f32(v[2 * t], v[2 * t + 1], h[t], l0, l1);
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l[t]) : "v"(l0), "v"(l1));
+  }
+  hi = __builtin_bit_cast(tg_bf16x8, tg_u32x4{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(tg_bf16x8, tg_u32x4{l[0], l[1], l[2], l[3]});
+}
+// The f16mx operand of a 64-k slab from split-FP16 fragment words (NlGemmSeg::frag == 3): the hi plane IS the f16 operand, the block maximum is an integer maximum of
+// its magnitudes, the lo plane becomes the residual fp6 image with the same instruction that makes the hi image (on the hi image's scale x 2^-11).  raw[ci][2 ks] /
+// raw[ci][2 ks + 1] = hi / lo words of chunk ci (0, 1), k-step ks: positions P = 16 ci + 8 ks + 0 .. 7.  Returns the block exponent byte eb (scale 2^(eb - 127)).
+typedef unsigned short tg_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tg_u32x6 tg_cvt_pk32_fp6_f16(tg_u32x16 h, float sc);
+__device__ __forceinline__ int tg_mx_operand_f16frag(const float4 (&raw)[2][4], tg_u32x16& H, tg_u32x6& xh6, tg_u32x6& xl6) {
+  tg_u32x16 Lw;
+  tg_u16x2 mx = {0, 0};
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float4 fh = raw[ci][2 * ks], fl = raw[ci][2 * ks + 1];
+      const unsigned uh[4] = {__float_as_uint(fh.x), __float_as_uint(fh.y), __float_as_uint(fh.z), __float_as_uint(fh.w)};
+      const unsigned ul[4] = {__float_as_uint(fl.x), __float_as_uint(fl.y), __float_as_uint(fl.z), __float_as_uint(fl.w)};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        H[8 * ci + 4 * ks + d] = uh[d];
+        Lw[8 * ci + 4 * ks + d] = ul[d];
+        mx = __builtin_elementwise_max(mx, __builtin_bit_cast(tg_u16x2, uh[d] & 0x7fff7fffu));   // (f16 magnitudes order like their bit patterns)
+      }
+    }
+  const unsigned short m16 = mx[0] > mx[1] ? mx[0] : mx[1];
+  const float amax = (float)__builtin_bit_cast(_Float16, m16);
+  int eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // as tgemm_mx_kernel: the largest value lands in [4, 8)
+  eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);
+  const float scf = __builtin_bit_cast(float, eb << 23);
+  xh6 = tg_cvt_pk32_fp6_f16(H, scf);
+  xl6 = tg_cvt_pk32_fp6_f16(Lw, scf * 0.00048828125f);
+  return eb;
+}
 // (asm with early-clobber results: hipcc 7.2 lets the builtins' 6-register result overlap the scale operand — point_fused2.hip)
 __device__ __forceinline__ tg_u32x6 tg_cvt_pk32_fp6_f16(tg_u32x16 h, float sc) {
   tg_u32x6 r;
@@ -569,7 +613,9 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   // them through the CU's one scalar unit.
   const NlGemmSeg& g0 = a.seg[0];
   const NlGemmSeg& g1 = a.seg[1];
-  const int fr0 = __builtin_amdgcn_readfirstlane(g0.frag);        // 1: the chain kernel's fragment image, 2 / 0: fp32 rows (2: the same K order inside a block as the image)
+  const int frg = __builtin_amdgcn_readfirstlane(g0.frag);        // 1: the chain kernel's fragment image (3: its split-FP16 form), 2 / 0: fp32 rows (2: the same K order inside a block as the image)
+  const bool f16in = frg == 3;                                     // split-FP16 fragments: the hi plane is the f16 operand as it stands (tg_mx_operand_f16frag)
+  const int fr0 = f16in ? 1 : frg;                                 // (addressing: the two fragment forms have one layout)
   const int cstride0 = fr0 == 1 ? 1024 : 32;                       // floats between consecutive 32-channel blocks of a row
   const float* P0[3]; const float* P1[3]; int okm[3];
 #pragma unroll
@@ -616,6 +662,11 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   auto slab = [&](auto Gc) __attribute__((always_inline)) {
     constexpr int g = decltype(Gc)::value, SL = g & 1;
     // ---- this slab's B operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks)
+    tg_u32x16 H;
+    tg_u32x6 xh6, xl6;
+    int eb;
+    if (g < 12 && f16in) eb = tg_mx_operand_f16frag(raw, H, xh6, xl6);   // feature_agg's slabs from split-FP16 fragments: no sums, no conversions to f16, no residuals
+    else {
     float v[32];
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
@@ -651,20 +702,20 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
       }
     }
     float amax = 0.f;
-    tg_u32x16 H;
     float lo[32];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       H[i] = tg_hi2_f16_amax(v[2 * i], v[2 * i + 1], amax);
       tg_lo2_f32(v[2 * i], v[2 * i + 1], H[i], lo[2 * i], lo[2 * i + 1]);
     }
-    int eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // block scale 2^(ex - 3) for amax = m 2^ex, m in [0.5, 1): the largest value lands in [4, 8)
+    eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // block scale 2^(ex - 3) for amax = m 2^ex, m in [0.5, 1): the largest value lands in [4, 8)
     eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);          // (12: the residual image's byte eb - 11 stays positive; an all-zero block takes any scale)
     const float scf = __builtin_bit_cast(float, eb << 23);
-    const tg_u32x6 xh6 = tg_cvt_pk32_fp6_f16(H, scf);
+    xh6 = tg_cvt_pk32_fp6_f16(H, scf);
     const tg_f32x16 le = {lo[0], lo[2], lo[4], lo[6], lo[8], lo[10], lo[12], lo[14], lo[16], lo[18], lo[20], lo[22], lo[24], lo[26], lo[28], lo[30]};
     const tg_f32x16 lod = {lo[1], lo[3], lo[5], lo[7], lo[9], lo[11], lo[13], lo[15], lo[17], lo[19], lo[21], lo[23], lo[25], lo[27], lo[29], lo[31]};
-    const tg_u32x6 xl6 = tg_cvt_2xpk16_fp6_f32(le, lod, scf * 0.00048828125f);   // (interleaves its operands: position 2 i <- le[i], 2 i + 1 <- lod[i] = the natural order)
+    xl6 = tg_cvt_2xpk16_fp6_f32(le, lod, scf * 0.00048828125f);   // (interleaves its operands: position 2 i <- le[i], 2 i + 1 <- lod[i] = the natural order)
+    }
     const tg_i32x8 bh6 = {(int)xh6[0], (int)xh6[1], (int)xh6[2], (int)xh6[3], (int)xh6[4], (int)xh6[5], 0, 0};
     const tg_i32x8 bl6 = {(int)xl6[0], (int)xl6[1], (int)xl6[2], (int)xl6[3], (int)xl6[4], (int)xl6[5], 0, 0};
     const int sxh = eb, sxl = eb - 11;
@@ -794,9 +845,10 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* __restrict__ fa, const float* __restrict__ wts, const int M, const int S,
                                                                    const char* __restrict__ p_bsh, const char* __restrict__ p_bmx, const float* __restrict__ p_bias,
                                                                    float* __restrict__ hc, const int ngroups, const float* __restrict__ w2, const int npad, const int C,
-                                                                   const float* __restrict__ wsum, float* __restrict__ feat) {
+                                                                   const float* __restrict__ wsum, float* __restrict__ feat, const int f16frag) {
   constexpr int NRT = TGMX_NRT;
   constexpr int HB = 16;   // composited rows kept for feat_mlp.2 (w2 != null): 16 rays x 256 floats, channel-major
+  const bool f16in = __builtin_amdgcn_readfirstlane(f16frag) != 0;   // the fragment image is split-FP16 (sample_chain_kernel: F16FRAG)
   __builtin_amdgcn_s_setreg(1473, 1);   // MODE.FP16_OVFL: saturating f32 -> f16 / fp6 conversions (tgemm_mx_kernel)
   __shared__ uint4 lds_all[2 * TGMX_SLOT / 16];
   __shared__ float4 hcsT[256 * HB / 4];
@@ -863,7 +915,13 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
     for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
   auto slab = [&](auto Gc) __attribute__((always_inline)) {
     constexpr int g = decltype(Gc)::value, SL = g & 1;
-    // ---- this slab's A operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks); value = bf16 hi + bf16 lo
+    // ---- this slab's A operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks); value = bf16 hi + bf16 lo, or
+    // (f16in: split-FP16 fragments) the hi plane as it stands
+    tg_u32x16 H;
+    tg_u32x6 xh6, xl6;
+    int eb;
+    if (f16in) eb = tg_mx_operand_f16frag(raw, H, xh6, xl6);
+    else {
     float v[32];
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci)
@@ -879,20 +937,20 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
         }
       }
     float amax = 0.f;
-    tg_u32x16 H;
     float lo[32];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       H[i] = tg_hi2_f16_amax(v[2 * i], v[2 * i + 1], amax);
       tg_lo2_f32(v[2 * i], v[2 * i + 1], H[i], lo[2 * i], lo[2 * i + 1]);
     }
-    int eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // block scale as in tgemm_mx_kernel: the largest value lands in [4, 8)
+    eb = __builtin_amdgcn_frexp_expf(amax) + 124;   // block scale as in tgemm_mx_kernel: the largest value lands in [4, 8)
     eb = eb < 12 ? 12 : (eb > 254 ? 254 : eb);
     const float scf = __builtin_bit_cast(float, eb << 23);
-    const tg_u32x6 xh6 = tg_cvt_pk32_fp6_f16(H, scf);
+    xh6 = tg_cvt_pk32_fp6_f16(H, scf);
     const tg_f32x16 le = {lo[0], lo[2], lo[4], lo[6], lo[8], lo[10], lo[12], lo[14], lo[16], lo[18], lo[20], lo[22], lo[24], lo[26], lo[28], lo[30]};
     const tg_f32x16 lod = {lo[1], lo[3], lo[5], lo[7], lo[9], lo[11], lo[13], lo[15], lo[17], lo[19], lo[21], lo[23], lo[25], lo[27], lo[29], lo[31]};
-    const tg_u32x6 xl6 = tg_cvt_2xpk16_fp6_f32(le, lod, scf * 0.00048828125f);
+    xl6 = tg_cvt_2xpk16_fp6_f32(le, lod, scf * 0.00048828125f);
+    }
     const tg_i32x8 bh6 = {(int)xh6[0], (int)xh6[1], (int)xh6[2], (int)xh6[3], (int)xh6[4], (int)xh6[5], 0, 0};
     const tg_i32x8 bl6 = {(int)xl6[0], (int)xl6[1], (int)xl6[2], (int)xl6[3], (int)xl6[4], (int)xl6[5], 0, 0};
     const int sxh = eb, sxl = eb - 11;
@@ -1014,7 +1072,7 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
 // fp32 rows) is a compile-time chunk table as in tgemm_mx_kernel; the product is the same three-term split-bf16 in the same order as tgemm_kernel's (bit-identical
 // accumulators), the epilogue its NL_EPI_LNSLAB with MaxPool.
 constexpr int TGC1_NRT = 2, TGC1_NW = 4, TGC1_D = 3, TGC1_NB = TGC1_D + 1, TGC1_NCH = 24;
-template <bool X3>
+template <bool X3, bool F16 = false>   // F16: split-FP16 fragments (NlGemmSeg::frag == 3) against the layer's fp16 hi / lo weight stream (p_bst then points at it): three-term split-FP16
 __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c, const float* __restrict__ p_zeros,
                                                                       const float* __restrict__ p_bias) {
   constexpr int NRT = TGC1_NRT, NW = TGC1_NW, D = TGC1_D, NB = TGC1_NB, NCH = TGC1_NCH;
@@ -1049,7 +1107,8 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
   };
   // activations: three per-tap row pointers worked out once (tgemm_mx_kernel)
   const NlGemmSeg& g0 = a.seg[0];
-  const int fr0 = __builtin_amdgcn_readfirstlane(g0.frag);
+  const int frg = __builtin_amdgcn_readfirstlane(g0.frag);
+  const int fr0 = frg == 3 ? 1 : frg;   // (3: the fragment image in split-FP16 — same layout, F16 instantiation)
   const int cstride0 = fr0 == 1 ? 1024 : 32;
   const float* P0[3]; int okm[3];
 #pragma unroll
@@ -1095,7 +1154,7 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const float v[8] = {rw4[2 * ks].x, rw4[2 * ks].y, rw4[2 * ks].z, rw4[2 * ks].w, rw4[2 * ks + 1].x, rw4[2 * ks + 1].y, rw4[2 * ks + 1].z, rw4[2 * ks + 1].w};
-          tg_split8<X3>(v, bh[ks], bl[ks]);
+          if constexpr (F16) tg_split8_f16(v, bh[ks], bl[ks]); else tg_split8<X3>(v, bh[ks], bl[ks]);
         }
       }
     }
@@ -1108,10 +1167,10 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
         const tg_bf16x8 ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
         if (X3) {
           const tg_bf16x8 al = L[((1 * 2 + ks) * NRT + rt) * 64 + lane];
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc[rt], 0, 0, 0);
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc[rt], 0, 0, 0);
+          acc[rt] = tg_mfma<F16>(al, bh[ks], acc[rt]);
+          acc[rt] = tg_mfma<F16>(ah, bl[ks], acc[rt]);
         }
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc[rt], 0, 0, 0);
+        acc[rt] = tg_mfma<F16>(ah, bh[ks], acc[rt]);
       }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -1259,10 +1318,16 @@ struct ChainGeo {
 // FRAGOUT (chain program only; round 5): feature_agg leaves the kernel as the split-bf16 B fragments the LayerNorm epilogue builds anyway (Xh / Xl: feat_mlp.0's
 // operand) in the fragment-native layout of NlGemmSeg::frag — 32 coalesced 1-KB stores per tile instead of 32 row stores — and the ray U-Net's conv1 / conv_out
 // (three taps each) load them as they are: no fp32 row loads (lane = row: 64 cache lines per instruction), no hi / lo split per tap.  Same bytes, same values.
-template <bool X3, bool FEAT, bool QUERY, bool FRAGOUT = false>
+// F16FRAG (late round 6; the f16mx render path at W = 256, S = 128, where every consumer of the image multiplies in fp16-based arithmetic): the fragments are split-FP16
+// (hi = f16(v), lo = f16(v - hi)) instead of split-bf16 — the same 4 bytes per value in the same places.  conv_out and feat_comp_mx_kernel then take the hi plane AS their
+// f16 operand and turn the lo plane into the residual fp6 image with one instruction (~45 instead of ~170 vector instructions per 64-k slab and wave), conv1 multiplies
+// it as three-term split-FP16 (2^-22 per product instead of 2^-16), and so does the blend projection in here (its fp16 weight stream: `off_ba` then points at it).
+template <bool X3, bool FEAT, bool QUERY, bool FRAGOUT = false, bool F16FRAG = false>
 __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs a, const int ntiles) {
   static_assert(!(FRAGOUT && QUERY), "the query program has no feature_agg");
+  static_assert(!F16FRAG || (FRAGOUT && X3 && !FEAT && !QUERY), "split-FP16 fragments: the three-term chain program without feat_mlp.0");
   using Geo = ChainGeo<QUERY, FEAT>;
+  if constexpr (F16FRAG) __builtin_amdgcn_s_setreg(1473, 1);   // MODE.FP16_OVFL: the split-FP16 rows saturate instead of overflowing to inf (as their consumers' conversions did)
   constexpr int NW = 4, PARTS = X3 ? 2 : 1, NCH = Geo::NCH, NB = 4;
   constexpr int SLOT16 = PARTS * 2 * 8 * 64;   // 16-B units per ring slot (sized for 8 row tiles)
   __shared__ uint4 lds_all[NB * SLOT16 + 4 * 64];
@@ -1341,6 +1406,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
   // one chunk (32 k): 2 k-steps x NRT row tiles x (3 | 1) MFMAs out of ring slot `slot`; filler(step) runs between the MFMA groups
   auto compute = [&](auto Nc, int slot, const tg_bf16x8 (&bh)[2], const tg_bf16x8 (&bl)[2], auto& dst, auto&& filler, int sub = 0) __attribute__((always_inline)) {
     constexpr int NRT = decltype(Nc)::value, nt = 2 * NRT;
+    constexpr bool F16 = F16FRAG && NRT == 2;   // the blend projection (the only two-row-tile product of the chain program) on the split-FP16 rows
     const tg_bf16x8* L = ring[slot] + sub * (PARTS * 2 * NRT * 64);   // sub: the k-chunk inside a ring chunk that carries several (the blend projection's four)
     auto ldA = [&](int tt, tg_bf16x8& ah, tg_bf16x8& al) __attribute__((always_inline)) {
       const int ks = tt / NRT, rt = tt - ks * NRT;
@@ -1354,11 +1420,17 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
     for (int tt = 0; tt < nt; ++tt) {
       if (tt + 2 < nt) ldA(tt + 2, ah[(tt + 2) % 3], al[(tt + 2) % 3]);
       const int ks = tt / NRT, rt = tt - ks * NRT;
+      if constexpr (F16) {
+        dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, al[tt % 3]), __builtin_bit_cast(tg_f16x8, bh[ks]), dst[rt], 0, 0, 0);
+        dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, ah[tt % 3]), __builtin_bit_cast(tg_f16x8, bl[ks]), dst[rt], 0, 0, 0);
+        dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, ah[tt % 3]), __builtin_bit_cast(tg_f16x8, bh[ks]), dst[rt], 0, 0, 0);
+      } else {
       if (X3) {
         dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt % 3], bh[ks], dst[rt], 0, 0, 0);
         dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bl[ks], dst[rt], 0, 0, 0);
       }
       dst[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tt % 3], bh[ks], dst[rt], 0, 0, 0);
+      }
       filler(tt);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1550,7 +1622,7 @@ __global__ __launch_bounds__(256, 1) void sample_chain_kernel(const NlChainArgs 
 #pragma unroll
           for (int sI = 0; sI < 2; ++sI) {   // accumulator registers 8 s .. 8 s + 7 of row tile rt = k-step 2 rt + s in accumulator order
             const float u[8] = {v[8 * sI], v[8 * sI + 1], v[8 * sI + 2], v[8 * sI + 3], v[8 * sI + 4], v[8 * sI + 5], v[8 * sI + 6], v[8 * sI + 7]};
-            tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
+            if constexpr (F16FRAG) tg_split8_f16_pk(u, Xh[2 * rt + sI], Xl[2 * rt + sI]); else tg_split8<X3>(u, Xh[2 * rt + sI], Xl[2 * rt + sI]);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
@@ -1665,7 +1737,10 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
 #ifndef NL_NO_TGEMM_CONV1
   if (nl_tgemm_conv1_supported(a, precision)) {
     const dim3 grid((unsigned)nl_cdiv(a.M, 32 * TGC1_NW));
-    if (x3) hipLaunchKernelGGL(tgemm_conv1_kernel<true>, grid, dim3(64 * TGC1_NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
+    if (a.seg[0].frag == 3) {
+      if (!x3 || !a.Bsh16) return NL_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((tgemm_conv1_kernel<true, true>), grid, dim3(64 * TGC1_NW), 0, st, a, (const char*)a.Bsh16, a.C, a.zeros, a.bias);
+    } else if (x3) hipLaunchKernelGGL(tgemm_conv1_kernel<true>, grid, dim3(64 * TGC1_NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
     else hipLaunchKernelGGL(tgemm_conv1_kernel<false>, grid, dim3(64 * TGC1_NW), 0, st, a, (const char*)a.Bst, a.C, a.zeros, a.bias);
     return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
   }
@@ -1674,6 +1749,7 @@ int nl_tgemm_launch(const NlGemmArgs& a, int precision, hipStream_t st) {
     hipLaunchKernelGGL(tgemm_mx_kernel, dim3((unsigned)nl_cdiv(a.M, 32 * TGMX_NW)), dim3(64 * TGMX_NW), 0, st, a, (const char*)a.Bsh_mx, (const char*)a.Bmx, a.C, a.zeros, a.bias);
     return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
   }
+  for (int sI = 0; sI < a.nseg; ++sI) if (a.seg[sI].frag == 3) return NL_ERR_UNSUPPORTED;   // split-FP16 fragments: tgemm_conv1_kernel / tgemm_mx_kernel only
 #define NL_TG(NRT, NW, X3)                                                                                  \
   do {                                                                                                       \
     dim3 grid((unsigned)nl_cdiv(a.M, 32 * NW));                                                              \
@@ -1729,7 +1805,7 @@ int chain_grid(int ntiles, dim3* grid) {
 // feature_agg (+ feat_mlp.0's rows when fth != null, + the blend projection) from the attention rows O and out_fc's hidden rows T64
 int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale, const float* gamma, const float* beta, float eps, const void* wbase,
                            size_t off_g2, const float* bias_g2, size_t off_fc, size_t off_f0, size_t off_ba, const float* bias_f0, float* FA, float* fth,
-                           float* blA, int64_t M, int precision, hipStream_t st, bool frag_out) {
+                           float* blA, int64_t M, int precision, hipStream_t st, bool frag_out, bool frag_f16) {
   if (M <= 0) return NL_OK;
   if ((int64_t)(M + 31) * 1024 > 0x7fffffffll) return NL_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   const int ntiles = (int)nl_cdiv(M, 128);
@@ -1747,7 +1823,10 @@ int nl_launch_sample_chain(const float* O, const float* T64, const float* wscale
     else if (fth) hipLaunchKernelGGL((sample_chain_kernel<false, true, false, FR>), grid, dim3(256), 0, st, a, ntiles);         \
     else hipLaunchKernelGGL((sample_chain_kernel<false, false, false, FR>), grid, dim3(256), 0, st, a, ntiles);                 \
   } while (0)
-  if (frag_out) NL_CHAIN(true); else NL_CHAIN(false);
+  if (frag_f16) {   // split-FP16 fragments (off_ba: the blend projection's fp16 stream)
+    if (!x3 || fth || !frag_out) return NL_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((sample_chain_kernel<true, false, false, true, true>), grid, dim3(256), 0, st, a, ntiles);
+  } else if (frag_out) NL_CHAIN(true); else NL_CHAIN(false);
 #undef NL_CHAIN
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
@@ -1774,7 +1853,7 @@ bool nl_feat_comp_mx_supported(int W, int S, int64_t N) {
   return (8 % wpr) == 0 || (6 % wpr) == 0;
 }
 int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, int S, const void* bsh, const void* bmx, const float* bias, float* hc, hipStream_t st,
-                           const float* w2, int npad, int C, const float* wsum, float* feat) {
+                           const float* w2, int npad, int C, const float* wsum, float* feat, bool frag_f16) {
   if (!nl_feat_comp_mx_supported(256, S, N) || !fa_frag || !wts || !bsh || !bmx || !bias || !hc || (((size_t)wts) & 15)) return NL_ERR_UNSUPPORTED;
   if (w2 && (npad <= 0 || npad > 192 || C <= 0 || C > npad || !wsum || !feat)) return NL_ERR_UNSUPPORTED;   // (two thread sets of npad in a workgroup of 384 / 512)
   const int wpr = S >> 5, nw = (8 % wpr) == 0 ? 8 : 6;
@@ -1782,7 +1861,7 @@ int nl_launch_feat_comp_mx(const float* fa_frag, const float* wts, int64_t N, in
   dim3 grid;
   if (chain_grid(ngroups, &grid) != NL_OK) return NL_ERR_HIP;   // one workgroup per CU (130 KB of LDS), XCD-aware when there are fewer groups than CUs
   if (nw == 8) hipLaunchKernelGGL(feat_comp_mx_kernel<8>, grid, dim3(64 * 8), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups, w2, npad, C, wsum,
-                                    feat);
-  else hipLaunchKernelGGL(feat_comp_mx_kernel<6>, grid, dim3(64 * 6), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups, w2, npad, C, wsum, feat);
+                                    feat, frag_f16 ? 1 : 0);
+  else hipLaunchKernelGGL(feat_comp_mx_kernel<6>, grid, dim3(64 * 6), 0, st, fa_frag, wts, (int)N, S, (const char*)bsh, (const char*)bmx, bias, hc, ngroups, w2, npad, C, wsum, feat, frag_f16 ? 1 : 0);
   return hipPeekAtLastError() == hipSuccess ? NL_OK : NL_ERR_HIP;
 }
