@@ -731,17 +731,20 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     const tg_u32x4* Lf = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT) / 16);
     const tg_u32x4* La = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT + TGMX_F16B) / 16);
     const tg_u32x4* Lb = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT + TGMX_F16B + TGMX_IMA) / 16);
-    tg_u32x4 ra[3], rb[3];
+#ifndef TGMX_RD
+#define TGMX_RD 4   // measured 2 / 3 / 4 units ahead: 481-483 / 475 / 472-473 us (241 / 245 registers at 3 / 4, no scratch)
+#endif
+    constexpr int RD = TGMX_RD, RR = RD + 1;   // weight fragments read RD units ahead (RR rotating register sets)
+    tg_u32x4 ra[RR], rb[RR];
     auto rdA = [&](auto Uc) __attribute__((always_inline)) {
-      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % 3;
+      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % RR;
       if constexpr (k < 4) ra[r] = Lf[(k * NRT + rt) * 64 + lane];
       else { ra[r] = La[(rt * 2 + (k - 4)) * 64 + lane]; rb[r] = Lb[(rt * 2 + (k - 4)) * 64 + lane]; }   // rb: {dword 4, dword 5, scale byte, 0}
     };
-    rdA(std::integral_constant<int, 0>{});
-    rdA(std::integral_constant<int, 1>{});
+    tg_static_for<RD>([&](auto Uc) __attribute__((always_inline)) { rdA(Uc); });
     tg_static_for<6 * NRT>([&](auto Uc) __attribute__((always_inline)) {
-      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % 3;
-      if constexpr (u + 2 < 6 * NRT) rdA(std::integral_constant<int, u + 2>{});
+      constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % RR;
+      if constexpr (u + RD < 6 * NRT) rdA(std::integral_constant<int, u + RD>{});
       if constexpr (k < 4) {
         const tg_f16x8 bf = __builtin_bit_cast(tg_f16x8, (tg_u32x4){H[4 * k], H[4 * k + 1], H[4 * k + 2], H[4 * k + 3]});
         acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, ra[r]), bf, acc[rt], 0, 0, 0);
