@@ -634,7 +634,10 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   auto load_chunk = [&](auto Cc, auto CIc) __attribute__((always_inline)) {
     constexpr int c = decltype(Cc)::value, ci = decltype(CIc)::value;
     const float* p; int fr;
-    if constexpr (c < 24) { constexpr int tp = c % 3, cb = c / 3; p = P0[tp] + okm[tp] * (cb * cstride0); fr = fr0; }
+#ifndef TGMX_KO
+#define TGMX_KO 0   // timing experiment (results wrong): 1 = every tap of feature_agg reads the centre row
+#endif
+    if constexpr (c < 24) { constexpr int tp = TGMX_KO ? 1 : c % 3, cb = c / 3; p = P0[tp] + okm[tp] * (cb * cstride0); fr = fr0; }
     else if constexpr (c < 27) { p = P1[c - 24]; fr = 0; }
     else { p = p_zeros; fr = 0; }
     rfr[ci] = fr;
@@ -1075,6 +1078,9 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
 // fp32 rows) is a compile-time chunk table as in tgemm_mx_kernel; the product is the same three-term split-bf16 in the same order as tgemm_kernel's (bit-identical
 // accumulators), the epilogue its NL_EPI_LNSLAB with MaxPool.
 constexpr int TGC1_NRT = 2, TGC1_NW = 4, TGC1_D = 3, TGC1_NB = TGC1_D + 1, TGC1_NCH = 24;
+#ifndef TGC1_KO   // knock-outs for timing experiments (results wrong): 1 = no cross terms (one matrix instruction per product instead of three), 2 = every tap reads the centre row
+#define TGC1_KO 0
+#endif
 template <bool X3, bool F16 = false>   // F16: split-FP16 fragments (NlGemmSeg::frag == 3) against the layer's fp16 hi / lo weight stream (p_bst then points at it): three-term split-FP16
 __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGemmArgs a, const char* __restrict__ p_bst, float* __restrict__ p_c, const float* __restrict__ p_zeros,
                                                                       const float* __restrict__ p_bias) {
@@ -1126,7 +1132,7 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
   auto act_off = [](int fr, int pc) __attribute__((always_inline)) { return fr == 1 ? 256 * pc : 16 * (pc >> 1) + (fr == 2 ? 8 : 4) * (pc & 1); };
   float4 raw[D][4];   // the raw words of the chunks in flight (ring: chunk c in raw[c % D])
   auto load_act = [&](auto Cc) __attribute__((always_inline)) {
-    constexpr int c = decltype(Cc)::value, tp = c % 3, cb = c / 3;
+    constexpr int c = decltype(Cc)::value, tp = (TGC1_KO & 2) ? 1 : c % 3, cb = c / 3;   // (TGC1_KO & 2: every tap reads the centre row — timing experiment, results wrong)
     const float* p = P0[tp] + okm[tp] * (cb * cstride0);
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) raw[c % D][pc] = *(const float4*)(p + act_off(fr0, pc));
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) {
         const tg_bf16x8 ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
-        if (X3) {
+        if (X3 && !(TGC1_KO & 1)) {
           const tg_bf16x8 al = L[((1 * 2 + ks) * NRT + rt) * 64 + lane];
           acc[rt] = tg_mfma<F16>(al, bh[ks], acc[rt]);
           acc[rt] = tg_mfma<F16>(ah, bl[ks], acc[rt]);
