@@ -583,19 +583,26 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p_bsh, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rmx = __builtin_amdgcn_make_buffer_rsrc((void*)p_bmx, 0, 0x7fffffff, 0x00020000);
   const unsigned lane16 = lane * 16;
-  auto stage = [&](int sl, auto SLOTc) __attribute__((always_inline)) {
+  // (stage_piece: piece i of this wave; stage: all of them.  Since late round 6 the pieces and the raw activation loads of the next slab go out BETWEEN the matrix
+  // instructions of the current one, one memory instruction every third unit: issued in one go behind the slab's barrier they cost the wave 1.1-3.5 k cycles of a
+  // 6.3-7.8 k-cycle slab before its first matrix instruction — a CU accepts one 1-KB wave load per ~17 cycles and all eight waves arrive at once; tools/tgmx_trace.py)
+  constexpr int TGMX_PPW = (TGMX_PIECES + NW - 1) / NW;
+  auto stage_piece = [&](int sl, auto SLOTc, auto Ic) __attribute__((always_inline)) {
     constexpr int slot = decltype(SLOTc)::value;
     const int cA = 2 * sl, cB = (2 * sl + 1 < NC) ? 2 * sl + 1 : NC - 1;   // (an odd chunk count: the last slab's second half re-reads the last chunk — its activations are zero)
     const unsigned oA = (unsigned)cA * (4 * NRT * 1024), oB = (unsigned)cB * (4 * NRT * 1024);   // the hi part (first 2 NRT KB) of each chunk of the fp16 stream
     const unsigned oI = (unsigned)sl * TGMX_IMG;
-    tg_static_for<(TGMX_PIECES + NW - 1) / NW>([&](auto Ic) __attribute__((always_inline)) {
+    {
       constexpr int i = decltype(Ic)::value;
       const int pp = wave + NW * i;   // (wave-uniform; TGMX_PIECES = 8 NW: no tail)
       static_assert(TGMX_PIECES % TGMX_NW == 0, "pieces per wave");
       {
         auto* dst = (__attribute__((address_space(3))) void*)(lds_all + (slot * TGMX_SLOT) / 16 + pp * 64);
-        if (pp < 4 * NRT) {
-          unsigned so = pp < 2 * NRT ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
+        // (which stream a piece comes from is a function of i alone — pp = wave + 8 i: i < 2 chunk A's hi part, i < 4 chunk B's, else the fp6 images — so no
+        // wave-uniform branch sits between the matrix instructions this is issued among)
+        static_assert(TGMX_NW == 8 && TGMX_NRT == 8, "piece -> stream by i");
+        if constexpr (i < 4) {
+          unsigned so = i < 2 ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
           asm volatile("" : "+s"(so));
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, dst, 16, lane16, so, 0, 0);
         } else {
@@ -604,7 +611,10 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rmx, dst, 16, lane16, so, 0, 0);
         }
       }
-    });
+    }
+  };
+  auto stage = [&](int sl, auto SLOTc) __attribute__((always_inline)) {
+    tg_static_for<TGMX_PPW>([&](auto Ic) __attribute__((always_inline)) { stage_piece(sl, SLOTc, Ic); });
   };
   // ---- activations.  The layer's K structure is conv_out's (W = 256; checked by nl_tgemm_mx_supported): chunks 0 .. 23 = feature_agg (eight 32-channel blocks x three
   // taps, [block][tap]), 24 .. 26 = the three taps of x2's one block, 27 = nothing.  Everything that depends on the chunk is therefore a compile-time constant, and what
@@ -631,8 +641,8 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   auto act_off = [](int fr, int pc) __attribute__((always_inline)) { return fr == 1 ? 256 * pc : 16 * (pc >> 1) + (fr == 2 ? 8 : 4) * (pc & 1); };
   float4 raw[2][4];
   int rfr[2] = {0, 0};
-  auto load_chunk = [&](auto Cc, auto CIc) __attribute__((always_inline)) {
-    constexpr int c = decltype(Cc)::value, ci = decltype(CIc)::value;
+  auto load_chunk = [&](auto Cc, auto CIc, auto PCc_) __attribute__((always_inline)) {   // PCc: the one 16-byte piece to load (-1: all four)
+    constexpr int c = decltype(Cc)::value, ci = decltype(CIc)::value, PCc = decltype(PCc_)::value;
     const float* p; int fr;
 #ifndef TGMX_KO
 #define TGMX_KO 0   // timing experiment (results wrong): 1 = every tap of feature_agg reads the centre row
@@ -642,12 +652,16 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     else { p = p_zeros; fr = 0; }
     rfr[ci] = fr;
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) raw[ci][pc] = *(const float4*)(p + act_off(fr, pc));
+    for (int pc = 0; pc < 4; ++pc) if (PCc < 0 || pc == PCc) raw[ci][pc] = *(const float4*)(p + act_off(fr, pc));
   };
   auto load_act = [&](auto SLc) __attribute__((always_inline)) {   // the raw words of slab SL (past the end: zero rows)
     constexpr int sl = decltype(SLc)::value;
-    load_chunk(std::integral_constant<int, (2 * sl < 28 ? 2 * sl : 27)>{}, std::integral_constant<int, 0>{});
-    load_chunk(std::integral_constant<int, (2 * sl + 1 < 28 ? 2 * sl + 1 : 27)>{}, std::integral_constant<int, 1>{});
+    load_chunk(std::integral_constant<int, (2 * sl < 28 ? 2 * sl : 27)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
+    load_chunk(std::integral_constant<int, (2 * sl + 1 < 28 ? 2 * sl + 1 : 27)>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{});
+  };
+  auto load_act_piece = [&](auto SLc, auto Kc) __attribute__((always_inline)) {   // memory instruction k (0 .. 7) of slab SL's raw words: chunk k / 4, piece k % 4
+    constexpr int sl = decltype(SLc)::value, k = decltype(Kc)::value, ci = k >> 2;
+    load_chunk(std::integral_constant<int, (2 * sl + ci < 28 ? 2 * sl + ci : 27)>{}, std::integral_constant<int, ci>{}, std::integral_constant<int, (k & 3)>{});
   };
 
   tg_f32x16 acc[NRT];
@@ -662,8 +676,14 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   __syncthreads();
 
   constexpr int NSC = 14;   // slabs of the layer (27 chunks)
+#ifdef TG_TRACE   // (tools/tgmx_trace.py: phases of slabs 4 .. 9 of block 0, waves 0 and 4 — the two waves of SIMD 0)
+#define TGMX_T(k) do { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && g >= 4 && g < 10) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) tg_trace[(wave ? 32 : 0) + 5 * (g - 4) + (k)] = t_; } } while (0)
+#else
+#define TGMX_T(k)
+#endif
   auto slab = [&](auto Gc) __attribute__((always_inline)) {
     constexpr int g = decltype(Gc)::value, SL = g & 1;
+    TGMX_T(0);
     // ---- this slab's B operand from the raw words: 32 values (position P = 8 s + t, k-step s = 2 (chunk of the slab) + ks)
     tg_u32x16 H;
     tg_u32x6 xh6, xl6;
@@ -722,12 +742,15 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     const tg_i32x8 bh6 = {(int)xh6[0], (int)xh6[1], (int)xh6[2], (int)xh6[3], (int)xh6[4], (int)xh6[5], 0, 0};
     const tg_i32x8 bl6 = {(int)xl6[0], (int)xl6[1], (int)xl6[2], (int)xl6[3], (int)xl6[4], (int)xl6[5], 0, 0};
     const int sxh = eb, sxl = eb - 11;
+    TGMX_T(1);
 
     // ---- the next slab: weights by LDS-DMA into the other slot (every wave left it before the barrier that ended the previous iteration), its raw activation words
-    {
-      stage(g + 1 < NSC ? g + 1 : NSC - 1, std::integral_constant<int, 1 - SL>{});   // (past the end: the last slab again, never used)
-      load_act(std::integral_constant<int, g + 1>{});                               // (past the end: zero rows)
-    }
+    // (issued between the matrix instructions below: mem_slot)
+    auto mem_slot = [&](auto Mc) __attribute__((always_inline)) {   // memory instruction m (0 .. 15) of the next slab: 8 weight pieces, then the 8 raw-word loads
+      constexpr int m = decltype(Mc)::value;
+      if constexpr (m < TGMX_PPW) stage_piece(g + 1 < NSC ? g + 1 : NSC - 1, std::integral_constant<int, 1 - SL>{}, Mc);   // (past the end: the last slab again, never used)
+      else if constexpr (m < TGMX_PPW + 8) load_act_piece(std::integral_constant<int, g + 1>{}, std::integral_constant<int, m - TGMX_PPW>{});   // (past the end: zero rows)
+    };
 
     // ---- the slab's product: per row tile 4 f16 k-steps + the two cross terms = 48 units; the A operand of unit u + 2 is read from LDS before the matrix instruction of
     // unit u is issued (three rotating register sets: without the read-ahead every matrix instruction waits out an LDS round trip, ~170 cycles for a 32-cycle instruction)
@@ -738,6 +761,7 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
 #define TGMX_RD 4   // measured 2 / 3 / 4 units ahead: 481-483 / 475 / 472-473 us (241 / 245 registers at 3 / 4, no scratch)
 #endif
     constexpr int RD = TGMX_RD, RR = RD + 1;   // weight fragments read RD units ahead (RR rotating register sets)
+    TGMX_T(2);
     tg_u32x4 ra[RR], rb[RR];
     auto rdA = [&](auto Uc) __attribute__((always_inline)) {
       constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % RR;
@@ -748,6 +772,7 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
     tg_static_for<6 * NRT>([&](auto Uc) __attribute__((always_inline)) {
       constexpr int u = decltype(Uc)::value, rt = u / 6, k = u % 6, r = u % RR;
       if constexpr (u + RD < 6 * NRT) rdA(std::integral_constant<int, u + RD>{});
+      if constexpr (u % 3 == 0) mem_slot(std::integral_constant<int, u / 3>{});   // 16 slots in 48 units
       if constexpr (k < 4) {
         const tg_f16x8 bf = __builtin_bit_cast(tg_f16x8, (tg_u32x4){H[4 * k], H[4 * k + 1], H[4 * k + 2], H[4 * k + 3]});
         acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tg_f16x8, ra[r]), bf, acc[rt], 0, 0, 0);
@@ -758,7 +783,9 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    TGMX_T(3);
     tg_wait_vmcnt<0>();
+    TGMX_T(4);
     __syncthreads();
   };
   tg_static_for<NSC>([&](auto Gc) __attribute__((always_inline)) { slab(Gc); });
@@ -870,26 +897,38 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
   const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)p_bsh, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rmx = __builtin_amdgcn_make_buffer_rsrc((void*)p_bmx, 0, 0x7fffffff, 0x00020000);
   const unsigned lane16 = lane * 16;
-  auto stage = [&](int sl, auto SLOTc) __attribute__((always_inline)) {   // weights of slab sl -> LDS slot (compile-time): 1-KB pieces by buffer LDS-DMA, dealt round-robin
-    constexpr int slot = decltype(SLOTc)::value;
+  // weights of slab sl -> LDS slot (compile-time): 1-KB pieces by buffer LDS-DMA, dealt round-robin; stage_piece: piece i of this wave
+  constexpr int PPW = (TGMX_PIECES + NW - 1) / NW;
+  auto stage_piece = [&](int sl, auto SLOTc, auto Ic) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOTc)::value, i = decltype(Ic)::value;
     const unsigned oA = (unsigned)(2 * sl) * (4 * NRT * 1024), oB = (unsigned)(2 * sl + 1) * (4 * NRT * 1024);   // the hi part (first 2 NRT KB) of each chunk of the fp16 stream
     const unsigned oI = (unsigned)sl * TGMX_IMG;
-    tg_static_for<(TGMX_PIECES + NW - 1) / NW>([&](auto Ic) __attribute__((always_inline)) {
-      constexpr int i = decltype(Ic)::value;
-      const int pp = wave + NW * i;   // (wave-uniform)
-      if (TGMX_PIECES % NW == 0 || pp < TGMX_PIECES) {
-        auto* dst = (__attribute__((address_space(3))) void*)(lds_all + (slot * TGMX_SLOT) / 16 + pp * 64);
-        if (pp < 4 * NRT) {
-          unsigned so = pp < 2 * NRT ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
-          asm volatile("" : "+s"(so));
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, dst, 16, lane16, so, 0, 0);
-        } else {
-          unsigned so = oI + (pp - 4 * NRT) * 1024;
-          asm volatile("" : "+s"(so));
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rmx, dst, 16, lane16, so, 0, 0);
-        }
+    const int pp = wave + NW * i;   // (wave-uniform)
+    auto* dst = (__attribute__((address_space(3))) void*)(lds_all + (slot * TGMX_SLOT) / 16 + pp * 64);
+    if constexpr (NW == 8) {   // the stream of a piece is a function of i alone (pp = wave + 8 i): no wave-uniform branch
+      if constexpr (i < 4) {
+        unsigned so = i < 2 ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
+        asm volatile("" : "+s"(so));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, dst, 16, lane16, so, 0, 0);
+      } else {
+        unsigned so = oI + (pp - 4 * NRT) * 1024;
+        asm volatile("" : "+s"(so));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rmx, dst, 16, lane16, so, 0, 0);
       }
-    });
+    } else if (TGMX_PIECES % NW == 0 || pp < TGMX_PIECES) {
+      if (pp < 4 * NRT) {
+        unsigned so = pp < 2 * NRT ? oA + pp * 1024 : oB + (pp - 2 * NRT) * 1024;
+        asm volatile("" : "+s"(so));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsh, dst, 16, lane16, so, 0, 0);
+      } else {
+        unsigned so = oI + (pp - 4 * NRT) * 1024;
+        asm volatile("" : "+s"(so));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rmx, dst, 16, lane16, so, 0, 0);
+      }
+    }
+  };
+  auto stage = [&](int sl, auto SLOTc) __attribute__((always_inline)) {
+    tg_static_for<PPW>([&](auto Ic) __attribute__((always_inline)) { stage_piece(sl, SLOTc, Ic); });
   };
   // activations: the chain kernel's fragment image — per 32-row tile 16 k-steps x 512 floats, a 32-channel block = [ks 0: hi | lo | ks 1: hi | lo] x (64 lanes x 4 floats)
   const float* P = tile_ptr(blockIdx.x);
@@ -963,8 +1002,12 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
 
     // the next slab — of this group or the first of the next: weights into the other slot (every wave left it before the barrier that ended the previous iteration;
     // after the last slab: before the barrier that ends the epilogue's reads of `red`), its raw words
-    if constexpr (g + 1 < NSC) { stage(g + 1, std::integral_constant<int, 1 - SL>{}); load_act(P, g + 1); }
-    else { stage(0, std::integral_constant<int, 1 - SL>{}); load_act(Pn, 0); }
+    constexpr int nsl = g + 1 < NSC ? g + 1 : 0;
+    const float* Pnx = g + 1 < NSC ? P : Pn;
+    // (All of the next slab's memory instructions go out HERE, in front of the matrix instructions — not between them as in tgemm_mx_kernel: measured, spreading them
+    // over the slab made this kernel 216 instead of 174 us.  Its fragment rows come from HBM, not from L2: a load issued 2 k cycles later lands 2 k cycles later.)
+    stage(nsl, std::integral_constant<int, 1 - SL>{});
+    load_act(Pnx, nsl);
 
     // ---- the slab's product, weights read two units ahead (tgemm_mx_kernel); operands swapped: D[sample][channel]
     const tg_u32x4* Lf = reinterpret_cast<const tg_u32x4*>(lds_all + (SL * TGMX_SLOT) / 16);
