@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64 * TGMX_NW, 1) void tgemm_mx_kernel(const NlGemmA
   __syncthreads();
 
   constexpr int NSC = 14;   // slabs of the layer (27 chunks)
-#ifdef TG_TRACE   // (tools/tgmx_trace.py: phases of slabs 4 .. 9 of block 0, waves 0 and 4 — the two waves of SIMD 0)
+#if defined(TG_TRACE) && !defined(TG_TRACE_C1)   // (tools/tgmx_trace.py: phases of slabs 4 .. 9 of block 0, waves 0 and 4 — the two waves of SIMD 0)
 #define TGMX_T(k) do { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && g >= 4 && g < 10) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) tg_trace[(wave ? 32 : 0) + 5 * (g - 4) + (k)] = t_; } } while (0)
 #else
 #define TGMX_T(k)
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(64 * NW, 1) void feat_comp_mx_kernel(const float* _
 // fp32 rows) is a compile-time chunk table as in tgemm_mx_kernel; the product is the same three-term split-bf16 in the same order as tgemm_kernel's (bit-identical
 // accumulators), the epilogue its NL_EPI_LNSLAB with MaxPool.
 constexpr int TGC1_NRT = 2, TGC1_NW = 4, TGC1_D = 3, TGC1_NB = TGC1_D + 1, TGC1_NCH = 24;
-#ifndef TGC1_KO   // knock-outs for timing experiments (results wrong): 1 = no cross terms (one matrix instruction per product instead of three), 2 = every tap reads the centre row
+#ifndef TGC1_KO   // knock-outs for timing experiments (results wrong): 1 = no cross terms (one matrix instruction per product instead of three), 2 = every tap reads the centre row, 4 = the side taps are not loaded at all
 #define TGC1_KO 0
 #endif
 template <bool X3, bool F16 = false>   // F16: split-FP16 fragments (NlGemmSeg::frag == 3) against the layer's fp16 hi / lo weight stream (p_bst then points at it): three-term split-FP16
@@ -1147,15 +1147,15 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p_bst, 0, 0x7fffffff, 0x00020000);
   const unsigned lane16 = lane * 16;
-  auto stage = [&](auto Cc) __attribute__((always_inline)) {   // chunk c -> slot c % NB (compile-time: see tgemm_mx_kernel)
-    constexpr int c = decltype(Cc)::value, slot = c % NB;
-    tg_static_for<PPW>([&](auto Ic) __attribute__((always_inline)) {
-      constexpr int i = decltype(Ic)::value;
-      const int pp = wave + NW * i;
-      unsigned so = (unsigned)c * CHB + pp * 1024;
-      asm volatile("" : "+s"(so));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_all + (slot * SLOTB) / 16 + pp * 64), 16, lane16, so, 0, 0);
-    });
+  auto stage_piece = [&](auto Cc, auto Ic) __attribute__((always_inline)) {   // piece i of chunk c -> slot c % NB (compile-time: see tgemm_mx_kernel)
+    constexpr int c = decltype(Cc)::value, slot = c % NB, i = decltype(Ic)::value;
+    const int pp = wave + NW * i;
+    unsigned so = (unsigned)c * CHB + pp * 1024;
+    asm volatile("" : "+s"(so));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lds_all + (slot * SLOTB) / 16 + pp * 64), 16, lane16, so, 0, 0);
+  };
+  auto stage = [&](auto Cc) __attribute__((always_inline)) {
+    tg_static_for<PPW>([&](auto Ic) __attribute__((always_inline)) { stage_piece(Cc, Ic); });
   };
   // activations: three per-tap row pointers worked out once (tgemm_mx_kernel)
   const NlGemmSeg& g0 = a.seg[0];
@@ -1180,6 +1180,11 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) raw[c % D][pc] = *(const float4*)(p + act_off(fr0, pc));
   };
+  auto load_act_piece = [&](auto Cc, auto Pc) __attribute__((always_inline)) {
+    constexpr int c = decltype(Cc)::value, tp = (TGC1_KO & 2) ? 1 : c % 3, cb = c / 3, pc = decltype(Pc)::value;
+    const float* p = P0[tp] + okm[tp] * (cb * cstride0);
+    raw[c % D][pc] = *(const float4*)(p + act_off(fr0, pc));
+  };
 
   tg_f32x16 acc[NRT];
 #pragma unroll
@@ -1190,15 +1195,25 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
   // prologue: chunks 0 .. D - 1 on their way
   tg_static_for<D>([&](auto Cc) __attribute__((always_inline)) { stage(Cc); load_act(Cc); });
 
+#if defined(TG_TRACE) && defined(TG_TRACE_C1)   // (tools/tgmx_trace.py conv1, a -DTG_TRACE -DTG_TRACE_C1 build: phases of chunks 8 .. 13 of block 0, wave 0)
+#define TGC1_T(k) do { if (blockIdx.x == 0 && wave == 0 && g >= 8 && g < 14) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) tg_trace[5 * (g - 8) + (k)] = t_; } } while (0)
+#else
+#define TGC1_T(k)
+#endif
   tg_static_for<NCH>([&](auto Gc) __attribute__((always_inline)) {
     constexpr int g = decltype(Gc)::value;
+    TGC1_T(0);
     // chunk g has landed when at most the later chunks' operations are in flight (each chunk: PPW DMA pieces + 4 row loads per wave; vmcnt retires in order)
-    constexpr int later = (g + D - 1 < NCH ? D - 1 : NCH - 1 - g) * (PPW + 4);
+    constexpr int nlater = (g + D - 1 < NCH ? D - 1 : NCH - 1 - g);
+    // (TGC1_KO & 4, timing only: the side taps are not loaded — the centre chunk's words stand in for them: a third of the row-load instructions)
+    constexpr int later = (TGC1_KO & 4) ? nlater * PPW + 4 * ((g + 1 < NCH && g + 1 <= g + nlater && (g + 1) % 3 == 1) + (g + 2 <= g + nlater && (g + 2) % 3 == 1)) : nlater * (PPW + 4);
     tg_wait_vmcnt<later>();
+    TGC1_T(1);
     __syncthreads();   // every wave's pieces of chunk g are in LDS; every wave has left slot (g + D) % NB = (g - 1) % NB
+    TGC1_T(2);
     tg_bf16x8 bh[2], bl[2];
     {
-      const float4 (&rw4)[4] = raw[g % D];
+      const float4 (&rw4)[4] = raw[(TGC1_KO & 4) ? 1 : g % D];
       if (fr0 == 1) {   // fragment image: [k-step 0: hi | lo | k-step 1: hi | lo] (wave-uniform branch around vector moves only)
         bh[0] = __builtin_bit_cast(tg_bf16x8, rw4[0]); bl[0] = __builtin_bit_cast(tg_bf16x8, rw4[1]);
         bh[1] = __builtin_bit_cast(tg_bf16x8, rw4[2]); bl[1] = __builtin_bit_cast(tg_bf16x8, rw4[3]);
@@ -1210,12 +1225,19 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
         }
       }
     }
-    if constexpr (g + D < NCH) { stage(std::integral_constant<int, g + D>{}); load_act(std::integral_constant<int, g + D>{}); }
+    // chunk g + D's memory instructions (PPW weight pieces + 4 raw-word loads per wave) go out BETWEEN the matrix instructions below (late round 6: issued in one go
+    // behind the barrier they cost the wave 730-1 320 cycles of a 2-3 k-cycle chunk — sixteen waves per CU arrive at once; tools/tgmx_trace.py conv1)
+    auto mem_slot = [&](auto Mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(Mc)::value;
+      if constexpr (g + D < NCH) {
+        if constexpr (m < PPW) stage_piece(std::integral_constant<int, g + D>{}, Mc);
+        else if constexpr (m < PPW + 4 && (!(TGC1_KO & 4) || (g + D) % 3 == 1)) load_act_piece(std::integral_constant<int, g + D>{}, std::integral_constant<int, m - PPW>{});
+      }
+    };
+    TGC1_T(3);
     const tg_bf16x8* L = reinterpret_cast<const tg_bf16x8*>(lds_all + ((g % NB) * SLOTB) / 16);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
+    tg_static_for<2 * NRT>([&](auto Tc) __attribute__((always_inline)) {
+        constexpr int tt = decltype(Tc)::value, ks = tt / NRT, rt = tt % NRT;
         const tg_bf16x8 ah = L[((0 * 2 + ks) * NRT + rt) * 64 + lane];
         if (X3 && !(TGC1_KO & 1)) {
           const tg_bf16x8 al = L[((1 * 2 + ks) * NRT + rt) * 64 + lane];
@@ -1223,8 +1245,13 @@ __global__ __launch_bounds__(64 * TGC1_NW, 4) void tgemm_conv1_kernel(const NlGe
           acc[rt] = tg_mfma<F16>(ah, bl[ks], acc[rt]);
         }
         acc[rt] = tg_mfma<F16>(ah, bh[ks], acc[rt]);
-      }
+        // two memory instructions behind each of the first matrix groups, then one (PPW + 4 = 5 or 6 of them over 2 NRT = 4 groups)
+        mem_slot(std::integral_constant<int, (tt < 2 ? 2 * tt : 2 + tt)>{});
+        if constexpr (tt < 2) mem_slot(std::integral_constant<int, 2 * tt + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
     __builtin_amdgcn_sched_barrier(0);
+    TGC1_T(4);
   });
 
   // ---- epilogue: LayerNorm over the ray's (128 x 64) slab + ELU + MaxPool(2) (tgemm_kernel's NL_EPI_LNSLAB, one ray per workgroup)

@@ -20,6 +20,13 @@ lib = L.load()
 lib.nl_debug_tg_trace.argtypes = [ct.c_void_p]
 assert lib.nl_debug_tg_trace(buf) == 0
 t = np.array(buf[:], dtype=np.int64)
+if len(sys.argv) > 1 and sys.argv[1] == "conv1":   # tgemm_conv1_kernel: chunks 8 .. 13 of block 0, wave 0
+    tt = t[:30].reshape(6, 5)
+    print("conv1, wave 0: per chunk [wait vmcnt, barrier, operand + issue of chunk g + 3's loads, 12 matrix instructions, -> next chunk] and the chunk's total")
+    for i in range(5):
+        ph = [int(tt[i, 1] - tt[i, 0]), int(tt[i, 2] - tt[i, 1]), int(tt[i, 3] - tt[i, 2]), int(tt[i, 4] - tt[i, 3]), int(tt[i + 1, 0] - tt[i, 4])]
+        print(f"  chunk {8 + i}: {ph}  total {int(tt[i + 1, 0] - tt[i, 0])}")
+    sys.exit(0)
 for w, base in ((0, 0), (4, 32)):
     tt = t[base:base + 30].reshape(6, 5)
     print(f"wave {w}: per slab [convert, issue loads, matrix phase, wait vmcnt, barrier -> next slab start] and the slab's total")
