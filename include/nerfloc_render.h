@@ -111,7 +111,8 @@ typedef struct nl_frame nl_frame;   /* opaque: device tables + KNN grid living i
 typedef struct nl_render_out {
   float* rgb;                /* (R,3)  */
   float* depth;              /* (R)    */
-  float* weights;            /* (R,S)  */
+  float* weights;            /* (R,S)  any alignment is accepted; 16-byte aligned (or null) lets the f16mx path at W = 256 fuse feat_mlp with the
+                              *        compositing pass (the library falls back to the staged feature path otherwise: same results to ~1e-6) */
   uint8_t* mask;             /* (R)    0/1 */
   float* depth_uncertainty;  /* (R)    */
   float* feat;               /* (R,C)  */
