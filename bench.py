@@ -273,7 +273,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": {"bf16x3": "bf16x3 (3-term split-bf16 MFMA, fp32 accumulate; meets 1e-4)",
                                                             "f16mx": "f16mx (neural-point kernel, conv_out and feat_mlp.0: fp16 hi.hi + two MX-FP6 cross terms, 1.5 MFMA-equivalents per product; every other GEMM "
-                                                                     "3-term split-bf16; fp32 accumulate; meets 1e-4)",
+                                                                     "3-term split-bf16 or split-fp16; fp32 accumulate; meets 1e-4)",
                                                             "bf16": "bf16", "fp32": "f32"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"{cfg.name}: {total_rays} rays x {S} samples" + (f" (64 coarse + {cfg.S} + {cfg.N_importance} resampled)" if hier else "")
